@@ -1,0 +1,15 @@
+// Error reporting + version for libepcnet_hip.so.
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void epc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* epc_last_error(void) { return g_err; }
+extern "C" int epc_version(void) { return 100; }

@@ -1,0 +1,71 @@
+// Shared device/host helpers for libepcnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/epcnet.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Row of a 32x32 MFMA C/D tile held by register r of lane-half h (column = lane & 31).
+__host__ __device__ __forceinline__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// D = A(32x2) * B(2x32) + C, exact f32 (v_mfma_f32_32x32x2_f32).
+// lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// a_ij = -((sq_i + (-2 * inner)) + sq_j), inner = (x x' + y y') + z z', one rounding per operation.
+// Restates utils/tf_util.py:650-656; must stay bit-identical to oracle/epcnet_oracle.py:neg_sq_dist.
+__device__ __forceinline__ float sq3(float x, float y, float z) {
+#pragma clang fp contract(off)
+    return (x * x + y * y) + z * z;
+}
+__device__ __forceinline__ float neg_sq_dist(float sqi, float xi, float yi, float zi, float xj, float yj,
+                                             float zj, float sqj) {
+#pragma clang fp contract(off)
+    float inner = (xi * xj + yi * yj) + zi * zj;
+    float t = -2.0f * inner;
+    return -((sqi + t) + sqj);
+}
+
+void epc_set_error(const char* fmt, ...);
+
+#define EPC_CHECK_ARG(cond, msg)                                  \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            epc_set_error("%s: %s", __func__, msg);               \
+            return EPC_EINVAL;                                    \
+        }                                                         \
+    } while (0)
+
+#define EPC_CHECK_LAUNCH()                                                        \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            epc_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return EPC_EHIP;                                                      \
+        }                                                                         \
+    } while (0)
+
+// ---- packed inference-weight layout (floats) --------------------------------------------------------------
+// A "layer pack" for a Cin->Cout 1x1 conv consumed by mfma32 in the transposed orientation
+//   out^T[ch][pt] = sum_k Wf[k][ch] * in[pt][k]
+// is   Wp[tile_out][e/4][lane][e%4] = Wf[chan(e, lane>>5)][32*tile_out + (lane&31)],  e = k-step (Cin/2 of them)
+// followed by the folded bias bf[Cout].  Two k-step -> channel maps:
+//   PACK_SPLIT : chan(e,h) = (Cin/2)*h + e                  (B operand read from a [pt][ch] row, half per lane-half)
+//   PACK_ACC   : chan(e,h) = 32*(e/16) + mfma_row(e%16, h)  (B operand = accumulator registers of the previous layer)
+enum { PACK_SPLIT = 0, PACK_ACC = 1 };
+__host__ __device__ __forceinline__ constexpr int pack_chan(int mode, int cin, int e, int h) {
+    return mode == PACK_SPLIT ? (cin / 2) * h + e : 32 * (e / 16) + mfma_row(e % 16, h);
+}
+__host__ __device__ __forceinline__ constexpr size_t layer_pack_floats(int cin, int cout) {
+    return (size_t)cin * cout + cout;
+}
+
+// Block pack: [conv_a SPLIT 64x64][conv_b ACC 64x64][conv_next SPLIT 64x64 (zeros when absent)]
+#define EPC_BLOCK_PACK_FLOATS (3 * (64 * 64 + 64))
+// conv1 pack: Wf[3][64] + bf[64]
+#define EPC_CONV1_PACK_FLOATS (3 * 64 + 64)

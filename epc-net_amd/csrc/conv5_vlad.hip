@@ -1,0 +1,337 @@
+// conv5 (+BN+ReLU) fused with what consumes it.
+//
+// MODE_VLAD  (EPC-Net: models/epc-net.py:136-139,147-148 + loupe.py:249-272)
+//   feat^T chunk (32 ch x 32 pts) = W5f^T X^T on the f32 MFMA; epilogue per chunk: ReLU, |feat|^2 partial, store
+//   feat, and P^T (64 clusters x 32 pts) += Wc^T feat^T with the chunk's ACCUMULATORS as the B operand
+//   ((feat*rn) @ Wc == (feat @ Wc) * rn, so the assignment GEMM runs on the un-normalised features while the norm
+//   is still being accumulated).  Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64.
+// MODE_MAX   (EPC-Net-L: models/epc-net-l.py:84-92)
+//   same conv5, epilogue = max over the 32 points of the tile, atomicMax into pooled (values are >= 0 after ReLU,
+//   so the uint ordering equals the float ordering and 0-initialisation is the identity).
+//
+// Geometry: 512 threads = 8 waves, one 32-point tile per wave, the wave's whole input row block (32 pts x CIN)
+// lives in registers as MFMA B operands for all 32 output chunks; W5 (1 MB) streams through a double-buffered
+// LDS chunk shared by the 8 waves (one barrier per chunk).
+#include "common.h"
+
+#define C5_THREADS 512
+#define C5_WAVES 8
+enum { MODE_VLAD = 0, MODE_MAX = 1 };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int CIN>
+struct C5Lds {
+    static constexpr int W5_CHUNK = 32 * CIN;  // floats per 32-channel chunk
+    static constexpr int WC_CHUNK = 2048;      // 32 ch x 64 clusters
+    static constexpr int OFF_W5 = 0;
+    static constexpr int OFF_WC = 2 * W5_CHUNK;
+    static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
+    static constexpr int OFF_CBN = OFF_B5 + 1024;
+    static constexpr int TOTAL = OFF_CBN + 128;
+};
+
+// packed conv5 stage (floats): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
+//                              [W5p CIN*1024][b5f 1024]                                     (MAX)
+template <int CIN, int MODE>
+__global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restrict__ cat,
+                                                           const float* __restrict__ pack, int total_points,
+                                                           int n, float* __restrict__ feat,
+                                                           float* __restrict__ rnorm,
+                                                           float* __restrict__ assign,
+                                                           float* __restrict__ pooled) {
+    using L = C5Lds<CIN>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const float* gw5 = pack;
+    const float* gb5 = pack + (size_t)CIN * 1024;
+    const float* gwc = gb5 + 1024;
+    const float* gcbn = gwc + 1024 * 64;
+
+    constexpr int W5_LD = L::W5_CHUNK / (C5_THREADS * 4);  // float4 per thread per chunk
+    float4 pre5[W5_LD];
+    float4 prec;
+
+    // chunk 0 + constants
+#pragma unroll
+    for (int u = 0; u < W5_LD; ++u) st4(lds + L::OFF_W5 + (u * C5_THREADS + tid) * 4, ld4(gw5 + (u * C5_THREADS + tid) * 4));
+    if (MODE == MODE_VLAD) st4(lds + L::OFF_WC + tid * 4, ld4(gwc + tid * 4));
+    for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_B5 + o] = gb5[o];
+    if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
+
+    const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
+    const bool active = g0 < total_points;
+
+    // this lane's B operands: point j, input channels (CIN/2)*h .. +CIN/2
+    float xb[CIN / 2];
+    if (active) {
+        const float* row = cat + (size_t)(g0 + j) * CIN + (CIN / 2) * h;
+#pragma unroll
+        for (int u = 0; u < CIN / 8; ++u) {
+            const float4 v = ld4(row + 4 * u);
+            xb[4 * u] = v.x;
+            xb[4 * u + 1] = v.y;
+            xb[4 * u + 2] = v.z;
+            xb[4 * u + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < CIN / 2; ++u) xb[u] = 0.f;
+    }
+
+    f32x16 P[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[0][r] = P[1][r] = 0.f;
+    float ss = 0.f;
+    __syncthreads();
+
+    for (int c = 0; c < 32; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < 32) {  // prefetch the next chunk into registers
+#pragma unroll
+            for (int u = 0; u < W5_LD; ++u)
+                pre5[u] = ld4(gw5 + (size_t)(c + 1) * L::W5_CHUNK + (u * C5_THREADS + tid) * 4);
+            if (MODE == MODE_VLAD) prec = ld4(gwc + (size_t)(c + 1) * L::WC_CHUNK + tid * 4);
+        }
+        const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
+        f32x16 acc;
+        {
+            const float* b = lds + L::OFF_B5 + 32 * c;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = ld4(b + 8 * g + 4 * h);
+                acc[4 * g] = bv.x;
+                acc[4 * g + 1] = bv.y;
+                acc[4 * g + 2] = bv.z;
+                acc[4 * g + 3] = bv.w;
+            }
+        }
+#pragma unroll
+        for (int e4 = 0; e4 < CIN / 8; ++e4) {
+            const float4 a = ld4(w5 + (e4 * 64 + lane) * 4);
+            acc = mfma32(a.x, xb[4 * e4 + 0], acc);
+            acc = mfma32(a.y, xb[4 * e4 + 1], acc);
+            acc = mfma32(a.z, xb[4 * e4 + 2], acc);
+            acc = mfma32(a.w, xb[4 * e4 + 3], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+
+        if (MODE == MODE_VLAD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
+            if (active) {
+                float* frow = feat + (size_t)(g0 + j) * 1024 + 32 * c + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    st4(frow + 8 * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+            }
+            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 a = ld4(wc + ((t * 4 + r4) * 64 + lane) * 4);
+                    P[t] = mfma32(a.x, acc[4 * r4 + 0], P[t]);
+                    P[t] = mfma32(a.y, acc[4 * r4 + 1], P[t]);
+                    P[t] = mfma32(a.z, acc[4 * r4 + 2], P[t]);
+                    P[t] = mfma32(a.w, acc[4 * r4 + 3], P[t]);
+                }
+        } else {
+            // max over the tile's 32 points (lanes of one half), then one atomic per channel
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m = acc[r];
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+                m = fmaxf(m, __shfl_xor(m, 8));
+                m = fmaxf(m, __shfl_xor(m, 16));
+                if (active && j == 0)
+                    atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + mfma_row(r, h)),
+                              __float_as_uint(m));
+            }
+        }
+
+        if (c + 1 < 32) {
+#pragma unroll
+            for (int u = 0; u < W5_LD; ++u)
+                st4(lds + L::OFF_W5 + (buf ^ 1) * L::W5_CHUNK + (u * C5_THREADS + tid) * 4, pre5[u]);
+            if (MODE == MODE_VLAD) st4(lds + L::OFF_WC + (buf ^ 1) * L::WC_CHUNK + tid * 4, prec);
+        }
+        __syncthreads();
+    }
+
+    if (MODE == MODE_VLAD && active) {
+        // per-point inverse norm (models/epc-net.py:148)
+        ss += __shfl_xor(ss, 32);
+        const float rn = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        // cluster_bn (folded: logit*s + t) then softmax over the 64 clusters (32 here, 32 in lane^32)
+        const float* cs = lds + L::OFF_CBN;
+        const float* ct = cs + 64;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * t + mfma_row(r, h);
+                const float v = (P[t][r] * rn) * cs[k] + ct[k];
+                P[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(P[t][r] - mx);
+                P[t][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        float* arow = assign + (size_t)(g0 + j) * 64 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st4(arow + 32 * t + 8 * g, make_float4(P[t][4 * g] / sum, P[t][4 * g + 1] / sum,
+                                                       P[t][4 * g + 2] / sum, P[t][4 * g + 3] / sum));
+        if (h == 0) rnorm[g0 + j] = rn;
+    }
+}
+
+template <int CIN, int MODE>
+static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
+                        float* assign, float* pooled, hipStream_t stream, const char* who) {
+    const size_t lds_bytes = C5Lds<CIN>::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
+    hipLaunchKernelGGL((conv5_kernel<CIN, MODE>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
+                       (int)total, n, feat, rnorm, assign, pooled);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
+        return EPC_EHIP;
+    }
+    return EPC_OK;
+}
+
+extern "C" int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
+                                    float* feat, float* rnorm, float* assign, void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && feat && rnorm && assign, "null pointer");
+    EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
+    EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
+    if (num_points_total == 0) return EPC_OK;
+    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, feat, rnorm, assign,
+                                        nullptr, (hipStream_t)stream, __func__);
+}
+
+extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
+                                     float* pooled, void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && pooled, "null pointer");
+    EPC_CHECK_ARG(cin == 128, "EPC-Net-L conv5 takes the 128-channel concat (models/epc-net-l.py:84)");
+    EPC_CHECK_ARG(n > 0 && n % 32 == 0 && num_clouds >= 0, "num_points must be a multiple of 32");
+    if (num_clouds == 0) return EPC_OK;
+    const long total = (long)num_clouds * n;
+    hipError_t e = hipMemsetAsync(pooled, 0, (size_t)num_clouds * 1024 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    return launch_conv5<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, pooled,
+                                       (hipStream_t)stream, __func__);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * (assign[n][k] * rnorm[n]) per cloud, as an MFMA
+// GEMM with the point index as K.  Both operands are read with 128-B coalesced dword loads straight into
+// registers (A: 32 consecutive f of row n, B: 32 consecutive clusters of row n); no LDS.
+// One wave = 128 features x 64 clusters (8 accumulator tiles) over a `splits`-th of the cloud's points.
+// ---------------------------------------------------------------------------------------------------------------
+#define AGG_THREADS 256
+
+__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat,
+                                                                     const float* __restrict__ rnorm,
+                                                                     const float* __restrict__ assign, int n,
+                                                                     int splits, float* __restrict__ vpart,
+                                                                     float* __restrict__ apart) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int fg = blockIdx.x * 4 + wave;  // 128-feature group, 0..7
+    const int sp = blockIdx.y;
+    const int cloud = blockIdx.z;
+    const int per = n / splits;
+    const size_t pt0 = (size_t)cloud * n + (size_t)sp * per;
+    const float* fbase = feat + pt0 * 1024 + fg * 128 + j;
+    const float* abase = assign + pt0 * 64 + j;
+    const float* rbase = rnorm + pt0;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
+    float as0 = 0.f, as1 = 0.f;
+
+    for (int nn = 0; nn < per; nn += 8) {
+        float a[4][4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pt = nn + 2 * u + h;
+            const float r = rbase[pt];
+            const float v0 = abase[(size_t)pt * 64];
+            const float v1 = abase[(size_t)pt * 64 + 32];
+            as0 += v0;
+            as1 += v1;
+            b0[u] = v0 * r;
+            b1[u] = v1 * r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[u][t] = fbase[(size_t)pt * 1024 + 32 * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t][0] = mfma32(a[u][t], b0[u], acc[t][0]);
+                acc[t][1] = mfma32(a[u][t], b1[u], acc[t][1]);
+            }
+    }
+    float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = fg * 128 + 32 * t + mfma_row(r, h);
+            vout[(size_t)f * 64 + j] = acc[t][0][r];
+            vout[(size_t)f * 64 + 32 + j] = acc[t][1][r];
+        }
+    if (fg == 0) {
+        as0 += __shfl_xor(as0, 32);
+        as1 += __shfl_xor(as1, 32);
+        if (h == 0) {
+            float* ao = apart + ((size_t)cloud * splits + sp) * 64;
+            ao[j] = as0;
+            ao[32 + j] = as1;
+        }
+    }
+}
+
+extern "C" int epc_vlad_aggregate_fwd(const float* feat, const float* rnorm, const float* assign, int num_clouds,
+                                      int n, int splits, float* vpart, float* apart, void* stream) {
+    EPC_CHECK_ARG(feat && rnorm && assign && vpart && apart, "null pointer");
+    EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (8 * splits) == 0, "num_points must be a multiple of 8*splits");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && splits <= 65535, "bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(2, splits, num_clouds), dim3(AGG_THREADS), 0,
+                       (hipStream_t)stream, feat, rnorm, assign, n, splits, vpart, apart);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

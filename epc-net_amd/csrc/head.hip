@@ -1,0 +1,219 @@
+// Descriptor heads.
+//   EPC-Net  : loupe.py:292-331 + models/epc-net.py:153  (three small kernels, ~0.9 % of the FLOPs)
+//   EPC-Net-L: models/epc-net-l.py:95-98                  (one kernel)
+#include "common.h"
+
+// packed head stage (floats): [C 1024*64][H KH*256][bn_s 256][bn_t 256][Wg 256*256][gbn_s 256][gbn_t 256]
+// with KH = 65536 / groups.
+
+// ---- H1: centre subtraction, intra-norm over the 1024 features of each cluster, global norm, group fold ------
+// One 1024-thread workgroup per cloud; thread (k = tid&63, fgp = tid>>6) owns V[fgp + 16 m][k], m < 64.
+// In inference the grouped projection sum_g BN(v_g W) equals s * ((sum_g v_g) W) + G t (one shared W, affine BN),
+// so the G group slices are folded before the GEMM: U[fi*64 + k] = sum_g Vn[g*FPG + fi][k].
+template <int GROUPS>
+__global__ __launch_bounds__(1024) void vlad_finish_kernel(const float* __restrict__ vpart,
+                                                           const float* __restrict__ apart, int splits,
+                                                           const float* __restrict__ centres,
+                                                           float* __restrict__ U) {
+    constexpr int groups = GROUPS;
+    __shared__ float red[16][64];
+    __shared__ float cn[64];
+    __shared__ float gsum[64];
+    const int cloud = blockIdx.x;
+    const int k = threadIdx.x & 63, fgp = threadIdx.x >> 6;
+    float asum = 0.f;
+    for (int s = 0; s < splits; ++s) asum += apart[((size_t)cloud * splits + s) * 64 + k];
+    // V[f][k] is recomputed in the second sweep (L2-resident re-read) instead of holding 64 values per thread
+    auto vval = [&](int f) {
+        float acc = 0.f;
+        for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
+        return acc - asum * centres[f * 64 + k];
+    };
+    float ss = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < 64; ++m) {
+        const float a = vval(fgp + 16 * m);
+        ss += a * a;
+    }
+    red[fgp][k] = ss;
+    __syncthreads();
+    if (fgp == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][k];
+        const float inv = 1.0f / sqrtf(fmaxf(t, 1e-12f));
+        cn[k] = inv;
+        gsum[k] = t * inv * inv;  // squared norm of the normalised column (1 unless the column is ~0)
+    }
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) tot += gsum[q];
+    const float sc = cn[k] * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+    constexpr int mpg = 64 / groups;  // m values per group
+    float* uo = U + (size_t)cloud * (65536 / groups);
+#pragma unroll
+    for (int mi = 0; mi < mpg; ++mi) {
+        float u = 0.f;
+#pragma unroll
+        for (int g = 0; g < groups; ++g) u += vval(fgp + 16 * (mi + g * mpg)) * sc;
+        uo[(size_t)(fgp + 16 * mi) * 64 + k] = u;
+    }
+}
+
+// ---- H2: Yp[slice][row][256] = U[row][slice*256 .. +256] @ H[slice*256 .. +256][256]  (split-K, f32 MFMA) --------
+// One wave per (32-column tile, K slice, 64-row group).  A (row on lane) is read as float4 along K: k-step (q,c) takes
+// k = 8q + c from lane-half 0 and k = 8q + 4 + c from lane-half 1; B rows are read to match.
+__global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict__ U, const float* __restrict__ H,
+                                                         int rows, int kh, float* __restrict__ Yp) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int nb = blockIdx.x * 32;
+    const int slice = blockIdx.y;
+    const int m0 = blockIdx.z * 64;
+    const int k0 = slice * 256;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    const int r0 = m0 + j, r1 = m0 + 32 + j;
+    const float* a0p = U + (size_t)min(r0, rows - 1) * kh + k0 + 4 * h;
+    const float* a1p = U + (size_t)min(r1, rows - 1) * kh + k0 + 4 * h;
+    const float z0 = r0 < rows ? 1.f : 0.f, z1 = r1 < rows ? 1.f : 0.f;
+    const float* bp = H + (size_t)(k0 + 4 * h) * 256 + nb + j;
+#pragma unroll 4
+    for (int q = 0; q < 32; ++q) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * q);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * q);
+        const float b0 = bp[(size_t)(8 * q + 0) * 256], b1 = bp[(size_t)(8 * q + 1) * 256];
+        const float b2 = bp[(size_t)(8 * q + 2) * 256], b3 = bp[(size_t)(8 * q + 3) * 256];
+        acc[0] = mfma32(a0.x * z0, b0, acc[0]);
+        acc[1] = mfma32(a1.x * z1, b0, acc[1]);
+        acc[0] = mfma32(a0.y * z0, b1, acc[0]);
+        acc[1] = mfma32(a1.y * z1, b1, acc[1]);
+        acc[0] = mfma32(a0.z * z0, b2, acc[0]);
+        acc[1] = mfma32(a1.z * z1, b2, acc[1]);
+        acc[0] = mfma32(a0.w * z0, b3, acc[0]);
+        acc[1] = mfma32(a1.w * z1, b3, acc[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * t + mfma_row(r, h);
+            if (row < rows) Yp[((size_t)slice * rows + row) * 256 + nb + j] = acc[t][r];
+        }
+}
+
+// ---- H3: sum slices, BN (folded, summed over groups), context gating, final L2 -------------------------------
+__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ Yp, int slices, int rows,
+                                                          const float* __restrict__ hp, int groups,
+                                                          float* __restrict__ out) {
+    __shared__ float v[256];
+    __shared__ float red[4];
+    const int cloud = blockIdx.x, c = threadIdx.x;
+    const float* bn_s = hp;
+    const float* bn_t = hp + 256;
+    const float* Wg = hp + 512;
+    const float* g_s = Wg + 65536;
+    const float* g_t = g_s + 256;
+    float y = 0.f;
+    for (int s = 0; s < slices; ++s) y += Yp[((size_t)s * rows + cloud) * 256 + c];
+    const float val = y * bn_s[c] + (float)groups * bn_t[c];
+    v[c] = val;
+    __syncthreads();
+    float g = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) g += v[k] * Wg[k * 256 + c];
+    g = g * g_s[c] + g_t[c];
+    const float o = val * (1.0f / (1.0f + expf(-g)));
+    float ss = o * o;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    out[(size_t)cloud * 256 + c] = o * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+}
+
+// ---- EPC-Net-L head: fc1 (1024->256, folded BN) + ReLU + L2.  packed: [Wf 1024*256][bf 256] ------------------
+__global__ __launch_bounds__(256) void fc_head_kernel(const float* __restrict__ pooled,
+                                                      const float* __restrict__ pack, float* __restrict__ out) {
+    __shared__ float m[1024];
+    __shared__ float red[4];
+    const int cloud = blockIdx.x, c = threadIdx.x;
+    for (int o = c; o < 1024; o += 256) m[o] = pooled[(size_t)cloud * 1024 + o];
+    __syncthreads();
+    float y = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 1024; ++k) y += m[k] * pack[k * 256 + c];
+    y = fmaxf(y + pack[1024 * 256 + c], 0.f);
+    float ss = y * y;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    out[(size_t)cloud * 256 + c] = y * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
+    if (num_clouds <= 0 || groups <= 0 || 64 % groups) return 0;
+    const size_t kh = 65536 / groups;
+    const size_t u = align_up((size_t)num_clouds * kh * sizeof(float), 256);
+    const size_t yp = align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
+    return u + yp;
+}
+
+extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, const void* packed_head,
+                                 int groups, int num_clouds, float* out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    EPC_CHECK_ARG(vpart && apart && packed_head && out && workspace, "null pointer");
+    EPC_CHECK_ARG(groups > 0 && 64 % groups == 0, "GROUPS must divide 64");
+    EPC_CHECK_ARG(splits >= 1 && num_clouds >= 0, "bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    if (workspace_bytes < epc_vlad_head_workspace_bytes(num_clouds, groups)) {
+        epc_set_error("epc_vlad_head_fwd: workspace too small");
+        return EPC_ENOMEM;
+    }
+    const int kh = 65536 / groups;
+    const float* hp = (const float*)packed_head;
+    const float* centres = hp;
+    const float* Hw = hp + 65536;
+    const float* tail = Hw + (size_t)kh * 256;
+    float* U = (float*)workspace;
+    float* Yp = (float*)((char*)workspace + align_up((size_t)num_clouds * kh * sizeof(float), 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (groups) {
+#define EPC_VF(G)                                                                                              \
+    case G:                                                                                                    \
+        hipLaunchKernelGGL(vlad_finish_kernel<G>, dim3(num_clouds), dim3(1024), 0, st, vpart, apart, splits,  \
+                           centres, U);                                                                        \
+        break;
+        EPC_VF(1) EPC_VF(2) EPC_VF(4) EPC_VF(8) EPC_VF(16)
+#undef EPC_VF
+        default:
+            epc_set_error("epc_vlad_head_fwd: GROUPS must be one of 1,2,4,8,16");
+            return EPC_EINVAL;
+    }
+    EPC_CHECK_LAUNCH();
+    const int slices = kh / 256;
+    hipLaunchKernelGGL(hidden_gemm_kernel, dim3(8, slices, (num_clouds + 63) / 64), dim3(64), 0, st, U, Hw,
+                       num_clouds, kh, Yp);
+    EPC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head_finish_kernel, dim3(num_clouds), dim3(256), 0, st, Yp, slices, num_clouds, tail,
+                       groups, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, float* out,
+                               void* stream) {
+    EPC_CHECK_ARG(pooled && packed_fc && out, "null pointer");
+    EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    hipLaunchKernelGGL(fc_head_kernel, dim3(num_clouds), dim3(256), 0, (hipStream_t)stream, pooled,
+                       (const float*)packed_fc, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

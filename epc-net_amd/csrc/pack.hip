@@ -1,0 +1,279 @@
+// Inference weight preparation: fold every BatchNorm into its producer (tf.nn.batch_normalization:
+// y = x*inv + (beta - mean*inv), inv = rsqrt(var + 1e-3)*gamma; utils/tf_util.py:490, slim default epsilon) and
+// lay the matrices out in MFMA operand order (common.h).  Runs once per weight load on the device.
+#include <string.h>
+#include <string>
+#include "common.h"
+
+#define BN_EPS 1e-3f
+
+static inline size_t align64(size_t v) { return (v + 63) / 64 * 64; }
+
+struct StageLayout {
+    size_t off[8];  // float offsets of stages 0..6, off[7] = total
+};
+
+static bool cfg_ok(const epc_cfg* c) {
+    if (!c) return false;
+    if (c->arch != EPC_ARCH_EPC_NET && c->arch != EPC_ARCH_EPC_NET_L) return false;
+    if (c->num_points < 32 || c->num_points % 32) return false;
+    if (c->input_dim != 3 || c->output_dim != 256 || c->knn <= 0) return false;
+    if (c->arch == EPC_ARCH_EPC_NET) {
+        if (c->cluster_size != 64) return false;
+        if (!(c->groups == 1 || c->groups == 2 || c->groups == 4 || c->groups == 8 || c->groups == 16)) return false;
+    }
+    return true;
+}
+
+static StageLayout stage_layout(const epc_cfg* c) {
+    StageLayout L;
+    size_t o = 0;
+    const int nblocks = c->arch == EPC_ARCH_EPC_NET ? 4 : 2;
+    L.off[0] = o;
+    o += align64(EPC_CONV1_PACK_FLOATS);
+    for (int b = 1; b <= 4; ++b) {
+        L.off[b] = o;
+        if (b <= nblocks) o += align64(EPC_BLOCK_PACK_FLOATS);
+    }
+    L.off[5] = o;
+    if (c->arch == EPC_ARCH_EPC_NET) {
+        o += align64((size_t)256 * 1024 + 1024 + 1024 * 64 + 128);
+        L.off[6] = o;
+        const size_t kh = 65536 / c->groups;
+        o += align64((size_t)65536 + kh * 256 + 512 + 65536 + 512);
+    } else {
+        o += align64((size_t)128 * 1024 + 1024);
+        L.off[6] = o;
+        o += align64((size_t)1024 * 256 + 256);
+    }
+    L.off[7] = o;
+    return L;
+}
+
+extern "C" size_t epc_net_packed_bytes(const epc_cfg* cfg) {
+    if (!cfg_ok(cfg)) return 0;
+    return stage_layout(cfg).off[7] * sizeof(float);
+}
+
+extern "C" size_t epc_net_packed_offset(const epc_cfg* cfg, int stage) {
+    if (!cfg_ok(cfg) || stage < 0 || stage > 6) return (size_t)-1;
+    return stage_layout(cfg).off[stage] * sizeof(float);
+}
+
+// ---- device kernels ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bn_inv(const float* gamma, const float* var, int c) {
+    return (1.0f / sqrtf(var[c] + BN_EPS)) * gamma[c];
+}
+
+// MFMA-ordered layer pack (common.h) with folded BN.  W is [cin][cout] row-major.
+__global__ void fold_pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                       int cout, int mode, float* __restrict__ dstW, float* __restrict__ dstB) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < cin * cout) {
+        const int per_tile = 32 * cin;
+        const int tile = o / per_tile, rem = o % per_tile;
+        const int e4 = rem / 256, lane = (rem % 256) / 4, q = rem % 4;
+        const int e = 4 * e4 + q, h = lane >> 5;
+        const int chan = pack_chan(mode, cin, e, h);
+        const int col = 32 * tile + (lane & 31);
+        dstW[o] = W[(size_t)chan * cout + col] * bn_inv(gamma, var, col);
+    }
+    if (o < cout) {
+        const float inv = bn_inv(gamma, var, o);
+        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+    }
+}
+
+// Row-major [cin][cout] with folded BN (conv1 3x64, fc1 1024x256).
+__global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                     int cout, float* __restrict__ dstW, float* __restrict__ dstB) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < cin * cout) dstW[o] = W[o] * bn_inv(gamma, var, o % cout);
+    if (o < cout) {
+        const float inv = bn_inv(gamma, var, o);
+        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+    }
+}
+
+// cluster_weights [1024][64] -> [chunk 32][tile 2][r4 4][lane 64][4]: A operand of P^T += Wc^T feat^T where the
+// B operand is conv5's accumulator registers (channel = 32*chunk + mfma_row(r, lane>>5)).
+__global__ void pack_wc_kernel(const float* __restrict__ Wc, float* __restrict__ dst) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 1024 * 64) return;
+    const int chunk = o / 2048, rem = o % 2048;
+    const int t = rem / 1024, r4 = (rem % 1024) / 256, lane = (rem % 256) / 4, q = rem % 4;
+    const int ch = 32 * chunk + mfma_row(4 * r4 + q, lane >> 5);
+    dst[o] = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
+}
+
+__global__ void bn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ mean, const float* __restrict__ var, int n,
+                                 float* __restrict__ s, float* __restrict__ t) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    const float inv = bn_inv(gamma, var, o);
+    s[o] = inv;
+    t[o] = beta[o] - mean[o] * inv;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+struct NameTable {
+    const char* const* names;
+    const float* const* tensors;
+    int n;
+    const float* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i)
+            if (name == names[i]) return tensors[i];
+        return nullptr;
+    }
+    // EMA shadows embed the caller's outer scope in the middle of the name
+    // ("<scope>/bn/<outer>/<scope>/bn/moments/Squeeze/ExponentialMovingAverage", utils/tf_util.py:474-487).
+    const float* find_ema(const std::string& scope, bool variance) const {
+        const std::string prefix = scope + "/bn/";
+        const std::string suffix = variance ? "/bn/moments/Squeeze_1/ExponentialMovingAverage"
+                                            : "/bn/moments/Squeeze/ExponentialMovingAverage";
+        for (int i = 0; i < n; ++i) {
+            const std::string s(names[i]);
+            if (s.size() > prefix.size() + suffix.size() && s.compare(0, prefix.size(), prefix) == 0 &&
+                s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0)
+                return tensors[i];
+        }
+        return nullptr;
+    }
+};
+
+struct ConvVars {
+    const float *W, *b, *gamma, *beta, *mean, *var;
+};
+
+static int get_conv(const NameTable& T, const std::string& scope, ConvVars* v) {
+    v->W = T.find(scope + "/weights");
+    v->b = T.find(scope + "/biases");
+    v->gamma = T.find(scope + "/bn/gamma");
+    v->beta = T.find(scope + "/bn/beta");
+    v->mean = T.find_ema(scope, false);
+    v->var = T.find_ema(scope, true);
+    if (!(v->W && v->b && v->gamma && v->beta && v->mean && v->var)) {
+        epc_set_error("epc_net_pack_weights: variables of scope '%s' are incomplete", scope.c_str());
+        return EPC_ENOTFOUND;
+    }
+    return EPC_OK;
+}
+
+static int get_slim_bn(const NameTable& T, const std::string& scope, const float** g, const float** b,
+                       const float** m, const float** v) {
+    *g = T.find(scope + "/gamma");
+    *b = T.find(scope + "/beta");
+    *m = T.find(scope + "/moving_mean");
+    *v = T.find(scope + "/moving_variance");
+    if (!(*g && *b && *m && *v)) {
+        epc_set_error("epc_net_pack_weights: variables of scope '%s' are incomplete", scope.c_str());
+        return EPC_ENOTFOUND;
+    }
+    return EPC_OK;
+}
+
+#define PACK_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != EPC_OK) return rc__; \
+    } while (0)
+
+static int launch_layer(const ConvVars& v, int cin, int cout, int mode, float* dst, hipStream_t st) {
+    const int total = cin * cout;
+    hipLaunchKernelGGL(fold_pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, st, v.W, v.b, v.gamma,
+                       v.beta, v.mean, v.var, cin, cout, mode, dst, dst + total);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names, const float* const* tensors,
+                                    int n, void* packed, size_t packed_bytes, void* stream) {
+    EPC_CHECK_ARG(cfg_ok(cfg), "unsupported configuration");
+    EPC_CHECK_ARG(names && tensors && packed && n > 0, "null pointer");
+    if (packed_bytes < epc_net_packed_bytes(cfg)) {
+        epc_set_error("epc_net_pack_weights: packed buffer too small");
+        return EPC_ENOMEM;
+    }
+    const NameTable T{names, tensors, n};
+    const StageLayout L = stage_layout(cfg);
+    float* P = (float*)packed;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = cfg->arch == EPC_ARCH_EPC_NET ? 4 : 2;
+    ConvVars v;
+
+    PACK_TRY(get_conv(T, "fastdgcnn/conv1", &v));
+    hipLaunchKernelGGL(fold_rowmajor_kernel, dim3(1), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var, 3,
+                       64, P + L.off[0], P + L.off[0] + 192);
+    EPC_CHECK_LAUNCH();
+
+    for (int b = 1; b <= nblocks; ++b) {
+        float* dst = P + L.off[b];
+        const std::string base = "fastdgcnn/conv" + std::to_string(b);
+        PACK_TRY(get_conv(T, base + "_a", &v));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, dst, st));
+        PACK_TRY(get_conv(T, base + "_b", &v));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, dst + 4160, st));
+        if (b < nblocks) {
+            PACK_TRY(get_conv(T, "fastdgcnn/conv" + std::to_string(b + 1), &v));
+            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, dst + 8320, st));
+        } else {
+            hipError_t e = hipMemsetAsync(dst + 8320, 0, 4160 * sizeof(float), st);
+            if (e != hipSuccess) {
+                epc_set_error("epc_net_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e));
+                return EPC_EHIP;
+            }
+        }
+    }
+
+    PACK_TRY(get_conv(T, "fastdgcnn/conv5", &v));
+    const int c5in = 64 * nblocks;
+    PACK_TRY(launch_layer(v, c5in, 1024, PACK_SPLIT, P + L.off[5], st));
+
+    if (cfg->arch == EPC_ARCH_EPC_NET) {
+        float* s5 = P + L.off[5] + (size_t)c5in * 1024 + 1024;
+        const float* Wc = T.find("VLAD/cluster_weights");
+        const float* C2 = T.find("VLAD/cluster_weights2");
+        const float* H = T.find("VLAD/hidden1_weights");
+        const float* Wg = T.find("VLAD/gating_weights");
+        if (!(Wc && C2 && H && Wg)) {
+            epc_set_error("epc_net_pack_weights: VLAD weight matrices are incomplete");
+            return EPC_ENOTFOUND;
+        }
+        hipLaunchKernelGGL(pack_wc_kernel, dim3(256), dim3(256), 0, st, Wc, s5);
+        EPC_CHECK_LAUNCH();
+        const float *g, *b, *m, *vv;
+        PACK_TRY(get_slim_bn(T, "VLAD/cluster_bn", &g, &b, &m, &vv));
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 64, s5 + 65536, s5 + 65536 + 64);
+        EPC_CHECK_LAUNCH();
+
+        float* h = P + L.off[6];
+        const size_t kh = 65536 / cfg->groups;
+        hipError_t e = hipMemcpyAsync(h, C2, 65536 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h + 65536, H, kh * 256 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        float* tail = h + 65536 + kh * 256;
+        if (e == hipSuccess) e = hipMemcpyAsync(tail + 512, Wg, 65536 * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) {
+            epc_set_error("epc_net_pack_weights: hipMemcpyAsync: %s", hipGetErrorString(e));
+            return EPC_EHIP;
+        }
+        PACK_TRY(get_slim_bn(T, "VLAD/bn", &g, &b, &m, &vv));
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 256, tail, tail + 256);
+        EPC_CHECK_LAUNCH();
+        PACK_TRY(get_slim_bn(T, "VLAD/gating_bn", &g, &b, &m, &vv));
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 256, tail + 512 + 65536,
+                           tail + 512 + 65536 + 256);
+        EPC_CHECK_LAUNCH();
+    } else {
+        PACK_TRY(get_conv(T, "VLAD/fc1", &v));
+        float* f = P + L.off[6];
+        hipLaunchKernelGGL(fold_rowmajor_kernel, dim3(1024), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean,
+                           v.var, 1024, 256, f, f + 1024 * 256);
+        EPC_CHECK_LAUNCH();
+    }
+    return EPC_OK;
+}

@@ -1,0 +1,115 @@
+// Whole-path orchestration: xyz -> descriptors.  Replaces MODEL.forward(...) executed by sess.run with
+// is_training=False (train.py:254, evaluate.py:250-251).  Launch sequence per micro-batch (one HIP stream):
+//   knn -> conv1 -> block x4 (x2 for EPC-Net-L) -> conv5+assign -> aggregate -> head      (EPC-Net)
+//                                               -> conv5+maxpool -> fc head               (EPC-Net-L)
+#include "common.h"
+
+#define AGG_SPLITS 4
+
+static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
+
+static int micro_batch(const epc_cfg* c, int num_clouds) {
+    int mb = c->micro_batch > 0 ? c->micro_batch : (c->arch == EPC_ARCH_EPC_NET ? 64 : 256);
+    return num_clouds < mb ? num_clouds : mb;
+}
+
+struct WsLayout {
+    size_t idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, vpart, apart, head, pooled, total;
+};
+
+static WsLayout ws_layout(const epc_cfg* c, int mb) {
+    WsLayout w;
+    const size_t M = (size_t)mb * c->num_points;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o += al(bytes);
+        return at;
+    };
+    w.idx = take(M * EPC_KNN_CAP * 4);
+    w.cnt = take(M * 4);
+    w.kth = take(M * 4);
+    w.xa = take(M * 64 * 4);
+    w.xb = take(M * 64 * 4);
+    const int ccat = c->arch == EPC_ARCH_EPC_NET ? 256 : 128;
+    w.cat = take(M * ccat * 4);
+    w.feat = w.rnorm = w.assign = w.vpart = w.apart = w.head = w.pooled = 0;
+    if (c->arch == EPC_ARCH_EPC_NET) {
+        w.feat = take(M * 1024 * 4);
+        w.rnorm = take(M * 4);
+        w.assign = take(M * 64 * 4);
+        w.vpart = take((size_t)mb * AGG_SPLITS * 65536 * 4);
+        w.apart = take((size_t)mb * AGG_SPLITS * 64 * 4);
+        w.head = take(epc_vlad_head_workspace_bytes(mb, c->groups));
+    } else {
+        w.pooled = take((size_t)mb * 1024 * 4);
+    }
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds) {
+    if (epc_net_packed_bytes(cfg) == 0 || num_clouds <= 0) return 0;
+    return ws_layout(cfg, micro_batch(cfg, num_clouds)).total;
+}
+
+#define TRY(expr)                        \
+    do {                                 \
+        int rc__ = (expr);               \
+        if (rc__ != EPC_OK) return rc__; \
+    } while (0)
+
+extern "C" int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(epc_net_packed_bytes(cfg) != 0, "unsupported configuration");
+    EPC_CHECK_ARG(packed && xyz && out, "null pointer");
+    EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    const int mb = micro_batch(cfg, num_clouds);
+    const WsLayout w = ws_layout(cfg, mb);
+    if (!workspace || workspace_bytes < w.total) {
+        epc_set_error("epc_net_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+        return EPC_ENOMEM;
+    }
+    char* ws = (char*)workspace;
+    const char* pk = (const char*)packed;
+    const int n = cfg->num_points;
+    const int nblocks = cfg->arch == EPC_ARCH_EPC_NET ? 4 : 2;
+    const int ccat = 64 * nblocks;
+    int32_t* idx = (int32_t*)(ws + w.idx);
+    int32_t* cnt = (int32_t*)(ws + w.cnt);
+    float* kth = (float*)(ws + w.kth);
+    float* xs[2] = {(float*)(ws + w.xa), (float*)(ws + w.xb)};
+    float* cat = (float*)(ws + w.cat);
+
+    for (int c0 = 0; c0 < num_clouds; c0 += mb) {
+        const int nc = (num_clouds - c0) < mb ? (num_clouds - c0) : mb;
+        const float* pc = xyz + (size_t)c0 * n * 3;
+        float* o = out + (size_t)c0 * cfg->output_dim;
+        TRY(epc_knn_topk(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, stream));
+        TRY(epc_conv1_fwd(pc, pk + epc_net_packed_offset(cfg, 0), nc * n, xs[0], stream));
+        for (int b = 1; b <= nblocks; ++b) {
+            const int has_next = b < nblocks;
+            TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], pc, idx, cnt, kth, EPC_KNN_CAP,
+                                        pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn, cat, ccat,
+                                        64 * (b - 1), xs[b & 1], stream));
+        }
+        if (cfg->arch == EPC_ARCH_EPC_NET) {
+            float* feat = (float*)(ws + w.feat);
+            float* rnorm = (float*)(ws + w.rnorm);
+            float* assign = (float*)(ws + w.assign);
+            float* vpart = (float*)(ws + w.vpart);
+            float* apart = (float*)(ws + w.apart);
+            TRY(epc_conv5_assign_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign,
+                                     stream));
+            TRY(epc_vlad_aggregate_fwd(feat, rnorm, assign, nc, n, AGG_SPLITS, vpart, apart, stream));
+            TRY(epc_vlad_head_fwd(vpart, apart, AGG_SPLITS, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
+                                  ws + w.head, w.total - w.head, stream));
+        } else {
+            float* pooled = (float*)(ws + w.pooled);
+            TRY(epc_conv5_maxpool_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc, n, pooled, stream));
+            TRY(epc_fc_head_fwd(pooled, pk + epc_net_packed_offset(cfg, 6), nc, o, stream));
+        }
+    }
+    return EPC_OK;
+}

@@ -1,0 +1,96 @@
+"""Inference engine: owns the packed (BN-folded, MFMA-ordered) weights and the workspace, and drives
+``epc_net_forward`` of libepcnet_hip.so.  This is what ``forward(..., is_training=False)`` of the model
+modules runs (reference: ``sess.run`` of ``models/epc-net.py:29-157`` / ``models/epc-net-l.py:29-102``).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+from .variables import VariableStore
+
+ARCH_IDS = {"epc-net": L.EPC_ARCH_EPC_NET, "epc-net-l": L.EPC_ARCH_EPC_NET_L}
+
+DEFAULT_PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INPUT_DIM": 3, "GROUPS": 4}
+
+
+def make_cfg(arch: str, num_points: int, params: Optional[dict], micro_batch: int = 0) -> L.EpcCfg:
+    p = dict(DEFAULT_PARAMS)
+    p.update(params or {})
+    if arch not in ARCH_IDS:
+        raise ValueError("unknown ARCH %r" % arch)
+    return L.EpcCfg(arch=ARCH_IDS[arch], num_points=int(num_points), input_dim=int(p["INPUT_DIM"]),
+                    knn=int(p["KNN"]), cluster_size=int(p["CLUSTER_SIZE"]), output_dim=int(p["FEATURE_OUTPUT_DIM"]),
+                    groups=int(p.get("GROUPS", 4)), micro_batch=int(micro_batch))
+
+
+class InferenceEngine:
+    def __init__(self, arch: str, params: Optional[dict], store: VariableStore, outer: str = "query_triplets",
+                 micro_batch: int = 0):
+        self.arch = arch
+        self.params = dict(params or {})
+        self.store = store
+        self.outer = outer
+        self.micro_batch = micro_batch
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def _relative_tensors(self) -> Dict[str, torch.Tensor]:
+        prefix = self.outer + "/" if self.outer else ""
+        out = {}
+        for name, t in self.store.vars.items():
+            if prefix and not name.startswith(prefix):
+                continue
+            out[name[len(prefix):]] = t
+        return out
+
+    def packed(self, cfg: L.EpcCfg) -> torch.Tensor:
+        key = (self.store.version, cfg.num_points, cfg.groups, cfg.knn)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        L.require_gpu()
+        nbytes = L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            raise L.EpcNetError(-1, "unsupported configuration (see include/epcnet.h: epc_cfg)")
+        rel = self._relative_tensors()
+        names = list(rel.keys())
+        tensors = [rel[n] for n in names]
+        for t in tensors:
+            if not t.is_cuda:
+                raise L.EpcNetError(-1, "variables must live on a ROCm device")
+        c_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
+        c_ptrs = (ctypes.c_void_p * len(names))(*[t.data_ptr() for t in tensors])
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
+        L.check(L.lib().epc_net_pack_weights(ctypes.byref(cfg), c_names, c_ptrs, len(names), buf.data_ptr(), nbytes,
+                                             L.current_stream()))
+        self._packed, self._packed_key = buf, key
+        return buf
+
+    def workspace(self, cfg: L.EpcCfg, num_clouds: int, device) -> torch.Tensor:
+        need = L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), num_clouds)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xyz (num_clouds, N, 3) float32 on the GPU -> (num_clouds, FEATURE_OUTPUT_DIM)."""
+        if xyz.dim() != 3 or xyz.shape[-1] != 3:
+            raise L.EpcNetError(-1, "expected (num_clouds, N, 3) points, got %s" % (tuple(xyz.shape),))
+        if xyz.dtype != torch.float32:
+            raise L.EpcNetError(-1, "points must be float32")
+        L.require_gpu()
+        xyz = xyz.contiguous()
+        nc, n = int(xyz.shape[0]), int(xyz.shape[1])
+        cfg = make_cfg(self.arch, n, self.params, self.micro_batch)
+        packed = self.packed(cfg)
+        if out is None:
+            out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
+        ws = self.workspace(cfg, max(nc, 1), xyz.device)
+        L.check(L.lib().epc_net_forward(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
+                                        ws.data_ptr(), ws.numel(), L.current_stream()))
+        return out

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libepcnet_hip.so`` (declarations: ``include/epcnet.h``).
+
+There is NO fallback: if the shared library has not been built (``python -c "import __graft_entry__ as g;
+g.build()"`` or ``make -C epc-net_amd/csrc``) importing this module raises, and every op raises ``EpcNetError``
+when the library reports a failure.  ``import torch`` happens first on purpose: the library's
+``libamdhip64.so.7`` dependency then resolves to the HIP runtime torch already loaded, so device pointers and
+streams are shared between torch (plumbing: allocation, streams, RCCL) and the kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libepcnet_hip.so")
+
+EPC_OK = 0
+EPC_ARCH_EPC_NET = 0
+EPC_ARCH_EPC_NET_L = 1
+EPC_KNN_SELECT = 20
+EPC_KNN_CAP = 32
+STATUS_NAMES = {0: "EPC_OK", -1: "EPC_EINVAL", -2: "EPC_ENOMEM", -3: "EPC_EHIP", -4: "EPC_ENOTFOUND"}
+
+# every symbol include/epcnet.h declares (tests check the library exports exactly these)
+EXPORTS = [
+    "epc_last_error", "epc_version", "epc_net_packed_bytes", "epc_net_pack_weights", "epc_net_workspace_bytes",
+    "epc_net_forward", "epc_knn_topk", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
+    "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
+    "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
+]
+
+
+class EpcNetError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__("%s (%d): %s" % (STATUS_NAMES.get(status, "?"), status, message))
+        self.status = status
+
+
+class EpcCfg(ctypes.Structure):
+    """``struct epc_cfg`` of include/epcnet.h."""
+    _fields_ = [("arch", c_int32), ("num_points", c_int32), ("input_dim", c_int32), ("knn", c_int32),
+                ("cluster_size", c_int32), ("output_dim", c_int32), ("groups", c_int32),
+                ("micro_batch", c_int32)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' or "
+        "make -C epc-net_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_P = c_void_p
+_lib.epc_last_error.restype = c_char_p
+_lib.epc_last_error.argtypes = []
+_lib.epc_version.restype = c_int
+_lib.epc_net_packed_bytes.restype = c_size_t
+_lib.epc_net_packed_bytes.argtypes = [POINTER(EpcCfg)]
+_lib.epc_net_packed_offset.restype = c_size_t
+_lib.epc_net_packed_offset.argtypes = [POINTER(EpcCfg), c_int]
+_lib.epc_net_pack_weights.argtypes = [POINTER(EpcCfg), POINTER(c_char_p), POINTER(_P), c_int, _P, c_size_t, _P]
+_lib.epc_net_workspace_bytes.restype = c_size_t
+_lib.epc_net_workspace_bytes.argtypes = [POINTER(EpcCfg), c_int]
+_lib.epc_net_forward.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P]
+_lib.epc_knn_topk.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P]
+_lib.epc_knn_mask.argtypes = [_P, _P, c_int, c_int, _P, _P]
+_lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P]
+_lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int,
+                                         c_int, _P, _P]
+_lib.epc_conv5_assign_fwd.argtypes = [_P, c_int, _P, c_int, _P, _P, _P, _P]
+_lib.epc_vlad_aggregate_fwd.argtypes = [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P]
+_lib.epc_vlad_head_workspace_bytes.restype = c_size_t
+_lib.epc_vlad_head_workspace_bytes.argtypes = [c_int, c_int]
+_lib.epc_vlad_head_fwd.argtypes = [_P, _P, c_int, _P, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
+_lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
+_lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
+for _name in EXPORTS:
+    if getattr(_lib, _name).restype is c_int and _name not in ("epc_version",):
+        pass  # int-returning entry points (ctypes default restype)
+
+
+def lib() -> ctypes.CDLL:
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != EPC_OK:
+        raise EpcNetError(status, (_lib.epc_last_error() or b"").decode("utf-8", "replace"))
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous CUDA/HIP tensor (or None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EpcNetError(-1, "tensor must live on a ROCm device: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise EpcNetError(-1, "tensor must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise EpcNetError(-3, "no ROCm device visible: the EPC-Net HIP path cannot run (no CPU fallback)")

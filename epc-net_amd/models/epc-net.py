@@ -1,0 +1,57 @@
+"""EPC-Net model module with the reference's surface (reference ``models/epc-net.py``): ``placeholder_inputs``,
+``forward`` and the loss family.  Load it like the reference does: ``importlib.import_module`` (train.py:81).
+
+``forward`` builds nothing symbolic: it makes sure the variables exist (reference names / shapes / initialisers)
+and runs the fused MI355X pipeline of libepcnet_hip.so:
+    kNN index (utils/tf_util.py:647-666) -> conv1 -> 4 x ProxyConv block (:66-132) -> conv5 + L2 + soft assignment
+    (:136-148, loupe.py:249-272) -> VLAD aggregation (loupe.py:276-292) -> head (loupe.py:295-331, :153).
+"""
+from __future__ import annotations
+
+from .. import loupe as lp
+from ..utils import tf_util
+from ..variables import variable_scope
+from ._common import *  # noqa: F401,F403  (loss family, placeholder_inputs)
+from ._common import LOSS_NAMES, engine_for, placeholder_inputs  # noqa: F401
+
+ARCH = "epc-net"
+
+
+def declare_variables(params, num_points):
+    """Create every variable ``forward`` owns, in the reference's creation order (models/epc-net.py:62-149)."""
+    input_dim = params["INPUT_DIM"]
+    with variable_scope('fastdgcnn'):
+        tf_util.declare_conv1d('conv1', input_dim, 64)
+        for b in (1, 2, 3, 4):
+            if b > 1:
+                tf_util.declare_conv1d('conv%d' % b, 64, 64)
+            tf_util.declare_conv1d('conv%d_a' % b, 64, 64)
+            tf_util.declare_conv1d('conv%d_b' % b, 64, 64)
+        tf_util.declare_conv1d('conv5', 256, 1024)
+    with variable_scope('VLAD'):
+        lp.G_VLAD(feature_size=1024, max_samples=num_points, cluster_size=params["CLUSTER_SIZE"],
+                  output_dim=params["FEATURE_OUTPUT_DIM"], groups=params["GROUPS"], gating=True,
+                  add_batch_norm=True, is_training=False).declare_variables()
+
+
+def forward(point_cloud, is_training, bn_decay=None, params=None):
+    """models/epc-net.py:29-157.
+    INPUT : batch_num_queries X num_pointclouds_per_query X num_points_per_pointcloud X input_dim
+    OUTPUT: batch_num_queries X num_pointclouds_per_query X output_dim ("last_output")."""
+    if params is None:
+        raise TypeError("forward() needs the config dict as `params` (models/epc-net.py:37-40)")
+    if point_cloud.dim() != 4:
+        raise ValueError("point_cloud must be (B, P, N, INPUT_DIM), got %s" % (tuple(point_cloud.shape),))
+    batch_num_queries, num_pointclouds_per_query, num_points, dim = (int(s) for s in point_cloud.shape)
+    CLUSTER_SIZE = params["CLUSTER_SIZE"]        # noqa: F841  default: 64
+    OUTPUT_DIM = params["FEATURE_OUTPUT_DIM"]    # default: 256
+    INPUT_DIM = params["INPUT_DIM"]
+    if dim != INPUT_DIM:
+        raise ValueError("last dimension %d != INPUT_DIM %d (reshape at models/epc-net.py:41)" % (dim, INPUT_DIM))
+    declare_variables(params, num_points)
+    if is_training:
+        raise NotImplementedError("is_training=True (batch-statistics BN + EMA updates) is the training-step "
+                                  "milestone; inference uses the stored statistics")
+    pc = point_cloud.reshape(batch_num_queries * num_pointclouds_per_query, num_points, INPUT_DIM)
+    output = engine_for(ARCH, params).forward(pc)
+    return output.reshape(batch_num_queries, num_pointclouds_per_query, OUTPUT_DIM)

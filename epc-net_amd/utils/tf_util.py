@@ -1,0 +1,143 @@
+"""Operator wrappers with the reference's names and argument meaning (reference ``utils/tf_util.py``).
+
+Tensors are ``torch.Tensor`` on a ROCm device; every computation is a call into libepcnet_hip.so -- there is no
+torch / CPU fallback (``EpcNetError`` if no GPU is visible).  Variables are created in the current
+``variable_scope`` with the reference's names and initialisers, so a model built from these wrappers has the
+same state-dict as the reference checkpoint.
+
+The fused model path (``models/epc-net.py: forward``) does NOT go through these wrappers op by op: it runs the
+fused kernels of ``epc_net_forward``.  The wrappers exist for op-level callers and API-surface parity; the
+reference functions EPC-Net never calls (conv2d, conv3d, avg_pool*, dropout, knn, get_edge_feature, ...) are
+out of scope and raise ``NotImplementedError`` naming the reference line.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from .. import lib as L
+from ..variables import (constant, default_store, ema_shadow_names, scoped, truncated_normal, variable_scope,
+                         xavier_uniform)
+
+relu = "relu"  # sentinel for activation_fn=tf.nn.relu (the only activation the hot path uses)
+
+
+def _variable_on_cpu(name, shape, initializer, use_fp16=False):
+    """utils/tf_util.py:10-22.  The '/cpu:0' pin is a TF1 idiom; variables live in HBM here."""
+    if use_fp16:
+        raise NotImplementedError("use_fp16 variables are not used by EPC-Net (utils/tf_util.py:20)")
+    return default_store().get_variable(scoped(name), shape, initializer)
+
+
+def _variable_with_weight_decay(name, shape, stddev, wd, use_xavier=True):
+    """utils/tf_util.py:24-49.  wd is 0.0 everywhere on the hot path, so 'weight_loss' is identically 0."""
+    init = xavier_uniform if use_xavier else truncated_normal(stddev)
+    return _variable_on_cpu(name, shape, init)
+
+
+def _bn_variables(scope: str, num_channels: int):
+    """Variables of batch_norm_template (utils/tf_util.py:465-487) inside the CURRENT scope + ``scope``."""
+    st = default_store()
+    with variable_scope(scope) as full:
+        beta = st.get_variable(full + "/beta", (num_channels,), constant(0.0))
+        gamma = st.get_variable(full + "/gamma", (num_channels,), constant(1.0))
+        mname, vname = ema_shadow_names(full)
+        mean = st.get_variable(mname, (num_channels,), constant(0.0), trainable=False)
+        var = st.get_variable(vname, (num_channels,), constant(0.0), trainable=False)
+    return beta, gamma, mean, var
+
+
+def declare_conv1d(scope, num_in_channels, num_output_channels, kernel_size=1, use_xavier=True, stddev=1e-3,
+                   bn=True):
+    """Create (or fetch) the variables ``conv1d`` owns: weights [k,Cin,Cout], biases, bn/*."""
+    with variable_scope(scope):
+        w = _variable_with_weight_decay("weights", [kernel_size, num_in_channels, num_output_channels], stddev,
+                                        0.0, use_xavier)
+        b = _variable_on_cpu("biases", [num_output_channels], constant(0.0))
+        bnv = _bn_variables("bn", num_output_channels) if bn else None
+    return w, b, bnv
+
+
+def declare_fully_connected(scope, num_input_units, num_outputs, use_xavier=True, stddev=1e-3, bn=True):
+    with variable_scope(scope):
+        w = _variable_with_weight_decay("weights", [num_input_units, num_outputs], stddev, 0.0, use_xavier)
+        b = _variable_on_cpu("biases", [num_outputs], constant(0.0))
+        bnv = _bn_variables("bn", num_outputs) if bn else None
+    return w, b, bnv
+
+
+# ---- ops ---------------------------------------------------------------------------------------------------
+def pairwise_distance_mask(pc: torch.Tensor, k: int = 20) -> torch.Tensor:
+    """utils/tf_util.py:647-666: (B,N,3) -> (B,N,N) float 0/1 mask of every j with a_ij >= (20th largest a_i.).
+    ``k`` is ignored exactly as the reference ignores it (top_k is hard-coded to 20, :660)."""
+    L.require_gpu()
+    if pc.dim() != 3 or pc.shape[-1] != 3:
+        raise L.EpcNetError(-1, "pairwise_distance_mask expects (B,N,3)")
+    pc = pc.contiguous().float()
+    B, N, _ = pc.shape
+    kth, _, _ = knn_index(pc)
+    mask = torch.empty((B, N, N), dtype=torch.float32, device=pc.device)
+    L.check(L.lib().epc_knn_mask(L.ptr(pc), L.ptr(kth), B, N, L.ptr(mask), L.current_stream()))
+    return mask
+
+
+def knn_index(pc: torch.Tensor):
+    """Index form of the same graph: (kth (B,N) f32, idx (B,N,32) int32 ascending, cnt (B,N) int32)."""
+    L.require_gpu()
+    pc = pc.contiguous().float()
+    B, N, _ = pc.shape
+    idx = torch.empty((B, N, L.EPC_KNN_CAP), dtype=torch.int32, device=pc.device)
+    cnt = torch.empty((B, N), dtype=torch.int32, device=pc.device)
+    kth = torch.empty((B, N), dtype=torch.float32, device=pc.device)
+    L.check(L.lib().epc_knn_topk(L.ptr(pc), B, N, L.EPC_KNN_CAP, L.ptr(idx), L.ptr(cnt), L.ptr(kth),
+                                 L.current_stream()))
+    return kth, idx, cnt
+
+
+def _op_level_pending(name, where):
+    raise NotImplementedError(
+        "%s as a stand-alone op is not built yet (reference %s); the fused model path `forward` covers it" %
+        (name, where))
+
+
+def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME', use_xavier=True,
+           stddev=1e-3, weight_decay=0.0, activation_fn=relu, bn=False, bn_decay=None, is_training=None):
+    """utils/tf_util.py:52-107.  Declares the variables; stand-alone execution arrives with the generic GEMM."""
+    if kernel_size != 1 or stride != 1:
+        raise NotImplementedError("EPC-Net only uses kernel_size=1, stride=1 (models/epc-net.py:66-139)")
+    declare_conv1d(scope, int(inputs.shape[-1]), num_output_channels, kernel_size, use_xavier, stddev, bn)
+    _op_level_pending("conv1d", "utils/tf_util.py:52-107")
+
+
+def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=0.0,
+                    activation_fn=relu, bn=False, bn_decay=None, is_training=None):
+    """utils/tf_util.py:310-346."""
+    declare_fully_connected(scope, int(inputs.shape[-1]), num_outputs, use_xavier, stddev, bn)
+    _op_level_pending("fully_connected", "utils/tf_util.py:310-346")
+
+
+def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
+    """utils/tf_util.py:349-372; EPC-Net-L uses it as the global max over N (models/epc-net-l.py:91)."""
+    _op_level_pending("max_pool2d", "utils/tf_util.py:349-372")
+
+
+def _unused(name, where):
+    def f(*a, **k):
+        raise NotImplementedError("%s (reference %s) is never called by EPC-Net / EPC-Net-L and is out of the "
+                                  "hot-path scope (SURVEY.md 2.1 #3)" % (name, where))
+    f.__name__ = name
+    return f
+
+
+conv2d = _unused("conv2d", "utils/tf_util.py:111-168")
+conv2d_transpose = _unused("conv2d_transpose", "utils/tf_util.py:171-248")
+conv3d = _unused("conv3d", "utils/tf_util.py:251-308")
+avg_pool2d = _unused("avg_pool2d", "utils/tf_util.py:374-396")
+max_pool3d = _unused("max_pool3d", "utils/tf_util.py:399-422")
+avg_pool3d = _unused("avg_pool3d", "utils/tf_util.py:424-447")
+dropout = _unused("dropout", "utils/tf_util.py:553-574")
+pairwise_distance = _unused("pairwise_distance", "utils/tf_util.py:577-596")
+knn = _unused("knn", "utils/tf_util.py:599-610")
+get_edge_feature = _unused("get_edge_feature", "utils/tf_util.py:613-645")

@@ -1,0 +1,10 @@
+"""Importable alias of the hyphenated package directory ``epc-net_amd/`` (``import epcnet_amd``)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("epc-net_amd")
+sys.modules[__name__] = _pkg

@@ -1,0 +1,143 @@
+/*
+ * epcnet.h -- C ABI of libepcnet_hip.so: the MI355X (gfx950) EPC-Net hot path.
+ *
+ * The reference (fpthink/EPC-Net) has no FFI: its "operator API" is Python graph-building functions executed
+ * by TensorFlow.  This header declares the boundary a maintainer would bind in their place
+ * (ctypes, a TF custom op, cgo, JNI ... see INTEGRATION.md).  Each entry cites the reference code it replaces
+ * (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch/HIP types.  `stream` is a hipStream_t passed as void* (NULL =
+ *     default stream).  All pointers are DEVICE pointers unless a parameter is documented as host.
+ *   - the caller owns every buffer; the library allocates nothing and keeps no mutable global state
+ *     (except the thread-local last-error string).  Calls are asynchronous on `stream` and re-entrant
+ *     across streams as long as workspaces are distinct.
+ *   - tensors are contiguous row-major float32 (indices int32).
+ *   - return value: EPC_OK (0) or a negative epc_status.
+ */
+#ifndef EPCNET_H
+#define EPCNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum epc_status {
+    EPC_OK = 0,
+    EPC_EINVAL = -1, /* bad shape / alignment / unsupported configuration */
+    EPC_ENOMEM = -2, /* workspace or packed-weight buffer too small       */
+    EPC_EHIP = -3,   /* a HIP runtime call failed: see epc_last_error()   */
+    EPC_ENOTFOUND = -4 /* a required named tensor is missing              */
+} epc_status;
+
+#define EPC_ARCH_EPC_NET 0   /* models/epc-net.py   */
+#define EPC_ARCH_EPC_NET_L 1 /* models/epc-net-l.py */
+
+#define EPC_KNN_SELECT 20 /* utils/tf_util.py:660: tf.nn.top_k(a, k=20), hard-coded */
+#define EPC_KNN_CAP 32    /* neighbour-list slots per point; rows with more ties take the exact scan path */
+
+/* Model configuration = the YAML keys `forward` consumes (models/epc-net.py:34-40,144; configs/epc-net.yaml). */
+typedef struct epc_cfg {
+    int32_t arch;          /* EPC_ARCH_*                                   */
+    int32_t num_points;    /* NUM_POINTS (N), multiple of 32               */
+    int32_t input_dim;     /* INPUT_DIM, must be 3                         */
+    int32_t knn;           /* KNN: the DIVISOR of the neighbour mean       */
+    int32_t cluster_size;  /* CLUSTER_SIZE, must be 64   (EPC-Net only)    */
+    int32_t output_dim;    /* FEATURE_OUTPUT_DIM, must be 256              */
+    int32_t groups;        /* GROUPS, must divide 1024   (EPC-Net only)    */
+    int32_t micro_batch;   /* clouds processed per internal pass (<= 0: library default) */
+} epc_cfg;
+
+const char* epc_last_error(void); /* thread-local, valid until the next failing call on this thread */
+int epc_version(void);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Whole-path entry points: replace `MODEL.forward(...)` inside `sess.run` for is_training=False           */
+/* (train.py:254, evaluate.py:250-251 -> models/epc-net.py:29-157, models/epc-net-l.py:29-102).             */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* Bytes of the packed inference-weight buffer (BN folded, MFMA operand order). */
+size_t epc_net_packed_bytes(const epc_cfg* cfg);
+
+/* Fold + pack the reference's variables.  `names[i]` are the checkpoint names relative to the outer
+ * `query_triplets/` scope (e.g. "fastdgcnn/conv1/weights", "VLAD/cluster_bn/moving_mean" -- table in
+ * tests/golden/ckpt_tables.json); `tensors[i]` the matching float32 DEVICE buffers in the reference's shapes.
+ * `names`/`tensors` are HOST arrays.  EPC_ENOTFOUND if a variable the architecture needs is absent. */
+int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names, const float* const* tensors, int n,
+                         void* packed, size_t packed_bytes, void* stream);
+
+size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds);
+
+/* xyz (num_clouds, N, 3) -> out (num_clouds, output_dim) unit-norm descriptors ("last_output",
+ * models/epc-net.py:153-155).  num_clouds = B*P of the reference's (B,P,N,3) placeholder. */
+int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* Stage entry points (what epc_net_forward chains; exported for parity tests and for op-level callers).    */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* utils/tf_util.py:647-666 pairwise_distance_mask, in index form.  For every point i of every cloud:
+ *   kth[i]  = 20th largest a_ij (with multiplicity), a_ij = -((|p_i|^2 + -2 p_i.p_j) + |p_j|^2) in fp32,
+ *             products/sums rounded individually (no FMA), inner = (x x' + y y') + z z';
+ *   cnt[i]  = #{j : a_ij >= kth[i]}  (>= 20; ties and zero-padded clouds make it larger);
+ *   idx[i]  = the first min(cnt, cap) such j in ascending order (cap slots per point).
+ * The dense mask the reference materialises is mask[i][j] = (a_ij >= kth[i]). */
+int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
+                 void* stream);
+
+/* Dense (num_clouds,N,N) 0/1 float mask from kth -- API parity with pairwise_distance_mask's return value
+ * (64 MB per 4096-point cloud: for tests / op-level callers only; the fused path never builds it). */
+int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask, void* stream);
+
+/* models/epc-net.py:66-69 conv1 (3->64) + folded BN + ReLU. */
+int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* stream);
+
+/* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
+ *   xm = (sum_{j in nbr(i)} x_j) / knn ; t = xm - x ; t = conv_a(t) ; t = conv_b(t) ; out = t + xm ;
+ *   x_next = conv_{b+1}(out) (when packed_next != NULL).
+ * `out` is written with row stride `out_stride` floats at column offset `out_off` (the concat buffer of
+ * models/epc-net.py:134). */
+int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                            const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
+                            int n, int knn, float* out, int out_stride, int out_off, float* x_next, void* stream);
+
+/* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the
+ * soft assignment.  cat (M, cin) -> feat (M,1024) UN-normalised conv5 output, rnorm (M) = rsqrt(max(|feat|^2,
+ * 1e-12)), assign (M,64) = softmax(cluster_bn((feat*rnorm) @ cluster_weights)). */
+int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat,
+                         float* rnorm, float* assign, void* stream);
+
+/* loupe.py:276-292: vlad[f][k] = sum_n assign[n][k]*feat[n][f]*rnorm[n] - (sum_n assign[n][k]) * centres[f][k]
+ * written as `splits` partial slabs vpart (num_clouds, splits, 1024, 64) + apart (num_clouds, splits, 64)
+ * (summed, and the centre term applied, by epc_vlad_head_fwd). */
+int epc_vlad_aggregate_fwd(const float* feat, const float* rnorm, const float* assign, int num_clouds, int n,
+                           int splits, float* vpart, float* apart, void* stream);
+
+/* loupe.py:292-331 + models/epc-net.py:153: centre subtraction, intra-normalisation, flatten + L2, grouped
+ * hidden projection with the shared weight (+BN, summed over groups), context gating, final L2. */
+size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups);
+int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, const void* packed_head, int groups,
+                      int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* models/epc-net-l.py:84-98: conv5 (128->1024)+BN+ReLU, global max over N, fc1 (1024->256)+BN+ReLU, L2. */
+int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
+                          float* pooled, void* stream);
+int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, float* out, void* stream);
+
+/* evaluate.py:463,481: exact k nearest database descriptors per query by Euclidean distance (replaces
+ * sklearn KDTree.query(k=25)); ties -> lower database index first.  idx (Q,k) int32, dist (Q,k) float32. */
+int epc_pairwise_topk(const float* database, int num_db, const float* queries, int num_q, int dim, int k,
+                      int32_t* idx, float* dist, void* stream);
+
+/* Offsets (in bytes) of the per-stage sub-buffers inside the packed weight buffer, for the stage entry
+ * points above.  stage: 0 conv1, 1..4 block b, 5 conv5(+assign), 6 head. */
+size_t epc_net_packed_offset(const epc_cfg* cfg, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPCNET_H */

@@ -1,0 +1,96 @@
+"""Test-side helpers: build a variable store from oracle weights, drive the stage entry points of the C ABI."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import epcnet_oracle as O  # noqa: E402
+
+PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INPUT_DIM": 3, "GROUPS": 4}
+OUTER = "query_triplets"
+
+
+def pkg(name=""):
+    return importlib.import_module("epc-net_amd" + ("." + name if name else ""))
+
+
+def make_store(arch, weights, device):
+    """Variable store holding `weights` (oracle names, relative to OUTER) under the reference's full names."""
+    V = pkg("variables")
+    st = V.reset_default_store(device=device, seed=0)
+    M = pkg("models." + arch)
+    with V.variable_scope(OUTER):
+        M.declare_variables(PARAMS, 4096)
+    st.load_state_dict({OUTER + "/" + k: v for k, v in weights.items()}, strict=True)
+    return st
+
+
+def make_engine(arch, weights, device="cuda", micro_batch=0):
+    E = pkg("engine")
+    st = make_store(arch, weights, device)
+    return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch), st
+
+
+def run_stages(eng, xyz):
+    """Run the pipeline stage by stage through the C ABI, returning every intermediate as a torch tensor."""
+    L = pkg("lib")
+    E = pkg("engine")
+    lib = L.lib()
+    nc, n, _ = xyz.shape
+    cfg = E.make_cfg(eng.arch, n, eng.params)
+    packed = eng.packed(cfg)
+    base = packed.data_ptr()
+    off = lambda s: base + lib.epc_net_packed_offset(ctypes.byref(cfg), s)
+    dev = xyz.device
+    st = L.current_stream()
+    M = nc * n
+    out = {}
+    idx = torch.empty((nc, n, L.EPC_KNN_CAP), dtype=torch.int32, device=dev)
+    cnt = torch.empty((nc, n), dtype=torch.int32, device=dev)
+    kth = torch.empty((nc, n), dtype=torch.float32, device=dev)
+    L.check(lib.epc_knn_topk(xyz.data_ptr(), nc, n, L.EPC_KNN_CAP, idx.data_ptr(), cnt.data_ptr(), kth.data_ptr(), st))
+    out.update(idx=idx, cnt=cnt, kth=kth)
+    nblocks = 4 if eng.arch == "epc-net" else 2
+    ccat = 64 * nblocks
+    xs = [torch.empty((nc, n, 64), dtype=torch.float32, device=dev) for _ in range(nblocks + 1)]
+    cat = torch.empty((nc, n, ccat), dtype=torch.float32, device=dev)
+    L.check(lib.epc_conv1_fwd(xyz.data_ptr(), off(0), M, xs[0].data_ptr(), st))
+    for b in range(1, nblocks + 1):
+        has_next = 1 if b < nblocks else 0
+        L.check(lib.epc_proxyconv_block_fwd(xs[b - 1].data_ptr(), xyz.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
+                                            kth.data_ptr(), L.EPC_KNN_CAP, off(b), has_next, nc, n, cfg.knn,
+                                            cat.data_ptr(), ccat, 64 * (b - 1), xs[b].data_ptr(), st))
+    out.update(xs=xs, cat=cat)
+    desc = torch.empty((nc, 256), dtype=torch.float32, device=dev)
+    if eng.arch == "epc-net":
+        feat = torch.empty((nc, n, 1024), dtype=torch.float32, device=dev)
+        rnorm = torch.empty((nc, n), dtype=torch.float32, device=dev)
+        assign = torch.empty((nc, n, 64), dtype=torch.float32, device=dev)
+        L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), ccat, off(5), M, feat.data_ptr(), rnorm.data_ptr(),
+                                         assign.data_ptr(), st))
+        S = 4
+        vpart = torch.empty((nc, S, 1024, 64), dtype=torch.float32, device=dev)
+        apart = torch.empty((nc, S, 64), dtype=torch.float32, device=dev)
+        L.check(lib.epc_vlad_aggregate_fwd(feat.data_ptr(), rnorm.data_ptr(), assign.data_ptr(), nc, n, S,
+                                           vpart.data_ptr(), apart.data_ptr(), st))
+        wsb = lib.epc_vlad_head_workspace_bytes(nc, cfg.groups)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        L.check(lib.epc_vlad_head_fwd(vpart.data_ptr(), apart.data_ptr(), S, off(6), cfg.groups, nc, desc.data_ptr(),
+                                      ws.data_ptr(), wsb, st))
+        out.update(feat=feat, rnorm=rnorm, assign=assign, vpart=vpart, apart=apart)
+    else:
+        pooled = torch.empty((nc, 1024), dtype=torch.float32, device=dev)
+        L.check(lib.epc_conv5_maxpool_fwd(cat.data_ptr(), ccat, off(5), nc, n, pooled.data_ptr(), st))
+        L.check(lib.epc_fc_head_fwd(pooled.data_ptr(), off(6), nc, desc.data_ptr(), st))
+        out.update(pooled=pooled)
+    out["desc"] = desc
+    torch.cuda.synchronize()
+    return out

@@ -1,0 +1,157 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for the kNN graph (integer / selection work); descriptor L2 error <= 1e-4 in fp32
+(BASELINE.json north_star) -- measured error is ~1e-6, the fp32-vs-fp64 budget of the oracle itself is ~2e-7.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from helpers import O
+
+pytestmark = pytest.mark.gpu
+
+DESC_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X; there is no CPU fallback"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("kind,n,seed", [("uniform", 64, 0), ("uniform", 256, 1), ("uniform", 4096, 2),
+                                         ("lidar", 4096, 0), ("lattice", 512, 0), ("dup", 256, 0), ("zeros", 128, 0),
+                                         ("uniform", 96, 3)])
+def test_knn_bit_exact(dev, kind, n, seed):
+    tf_util = H.pkg("utils.tf_util")
+    pc = O.synthetic_clouds(2, n, seed, kind)
+    kth_ref, lists = O.knn_lists(pc)
+    kth, idx, cnt = tf_util.knn_index(torch.from_numpy(pc).to(dev))
+    kth, idx, cnt = kth.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    assert np.array_equal(kth, kth_ref), "kth differs (== on float32: bit-exact up to the sign of zero)"
+    for b in range(pc.shape[0]):
+        for i in range(n):
+            ref = lists[b][i]
+            assert cnt[b, i] == len(ref)
+            m = min(len(ref), idx.shape[-1])
+            assert np.array_equal(idx[b, i, :m], ref[:m])
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 256), ("lattice", 512), ("zeros", 64)])
+def test_knn_mask_matches_reference_form(dev, kind, n):
+    """pairwise_distance_mask returns the dense 0/1 mask the reference builds (utils/tf_util.py:647-666)."""
+    tf_util = H.pkg("utils.tf_util")
+    pc = O.synthetic_clouds(2, n, 0, kind)
+    mask = tf_util.pairwise_distance_mask(torch.from_numpy(pc).to(dev), k=20).cpu().numpy()
+    assert np.array_equal(mask, O.pairwise_distance_mask(pc))
+
+
+def _stage_compare(arch, pc, seed, dev):
+    w = O.seeded_weights(arch, seed)
+    ref, st = O.forward(pc[:, None], w, arch=arch)
+    eng, _ = H.make_engine(arch, w, dev)
+    got = H.run_stages(eng, torch.from_numpy(pc).to(dev))
+    return ref.reshape(pc.shape[0], -1), st, got, eng
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+@pytest.mark.parametrize("kind,n", [("uniform", 256), ("lidar", 512), ("dup", 128), ("zeros", 64)])
+def test_stages_against_oracle(dev, arch, kind, n):
+    pc = O.synthetic_clouds(3, n, 5, kind)
+    ref, st, got, eng = _stage_compare(arch, pc, 1, dev)
+    nblocks = 4 if arch == "epc-net" else 2
+
+    def close(a, b, tol, what):
+        a = a.cpu().numpy() if torch.is_tensor(a) else a
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= tol, "%s: relative max error %.3e > %.1e" % (what, err, tol)
+
+    close(got["xs"][0], st.taps["fastdgcnn/conv1"], 1e-5, "conv1")
+    for b in range(1, nblocks + 1):
+        close(got["cat"][..., 64 * (b - 1):64 * b], st.taps["block%d" % b], 2e-5, "block%d" % b)
+        if b < nblocks:
+            close(got["xs"][b], st.taps["fastdgcnn/conv%d" % (b + 1)], 2e-5, "conv%d" % (b + 1))
+    if arch == "epc-net":
+        close(got["feat"], st.taps["fastdgcnn/conv5"], 2e-5, "conv5")
+        close(got["assign"].reshape(-1, 64), st.taps["vlad_assign"], 1e-4, "assign")
+        v = got["vpart"].sum(1).cpu().numpy()
+        asum = got["apart"].sum(1).cpu().numpy()
+        v = v - asum[:, None, :] * eng.store.vars["query_triplets/VLAD/cluster_weights2"].cpu().numpy()
+        close(v, st.taps["vlad_raw"], 1e-4, "vlad")
+    else:
+        close(got["pooled"], st.taps["maxpool"], 2e-5, "maxpool")
+    err = np.linalg.norm(got["desc"].cpu().numpy() - ref, axis=1).max()
+    assert err <= DESC_TOL, "descriptor L2 error %.3e" % err
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+def test_forward_api_full_size(dev, arch):
+    """The drop-in call: MODEL.forward(point_cloud (B,P,N,3), is_training=False, params=...) at N = 4096."""
+    V = H.pkg("variables")
+    pc = O.synthetic_clouds(3, 4096, 11).reshape(1, 3, 4096, 3)
+    w = O.seeded_weights(arch, 3)
+    ref, _ = O.forward(pc, w, arch=arch)
+    H.make_store(arch, w, dev)
+    M = H.pkg("models." + arch)
+    with V.variable_scope(H.OUTER):
+        x = M.placeholder_inputs(1, 3, 4096, 3)
+        x.copy_(torch.from_numpy(pc))
+        out = M.forward(x, False, bn_decay=None, params=H.PARAMS)
+    assert tuple(out.shape) == (1, 3, 256)
+    out = out.cpu().numpy()
+    assert np.allclose(np.linalg.norm(out, axis=-1), 1.0, atol=1e-5)
+    err = np.linalg.norm(out - ref, axis=-1).max()
+    assert err <= DESC_TOL, "descriptor L2 error %.3e" % err
+
+
+def test_micro_batching_is_invisible(dev):
+    w = O.seeded_weights("epc-net", 0)
+    pc = torch.from_numpy(O.synthetic_clouds(5, 256, 2)).to(dev)
+    a = H.make_engine("epc-net", w, dev)[0].forward(pc).cpu()
+    b = H.make_engine("epc-net", w, dev, micro_batch=2)[0].forward(pc).cpu()
+    assert torch.equal(a, b)
+
+
+def test_permutation_invariance(dev):
+    """Permuting a cloud's points leaves the descriptor unchanged up to fp32 summation order."""
+    w = O.seeded_weights("epc-net", 0)
+    eng, _ = H.make_engine("epc-net", w, dev)
+    pc = O.synthetic_clouds(1, 4096, 7)
+    perm = np.random.RandomState(0).permutation(4096)
+    a = eng.forward(torch.from_numpy(pc).to(dev)).cpu().numpy()
+    b = eng.forward(torch.from_numpy(np.ascontiguousarray(pc[:, perm])).to(dev)).cpu().numpy()
+    assert np.linalg.norm(a - b) <= 1e-5
+
+
+def test_pairwise_topk(dev):
+    L = H.pkg("lib")
+    rng = np.random.RandomState(0)
+    db = rng.randn(500, 256).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    db[17] = db[3]  # exact tie: lower index first
+    q = rng.randn(50, 256).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = db[3]
+    dist_ref, idx_ref = O.knn_bruteforce(db, q, 25)
+    tdb, tq = torch.from_numpy(db).to(dev), torch.from_numpy(q).to(dev)
+    idx = torch.empty((50, 25), dtype=torch.int32, device=dev)
+    dist = torch.empty((50, 25), dtype=torch.float32, device=dev)
+    L.check(L.lib().epc_pairwise_topk(tdb.data_ptr(), 500, tq.data_ptr(), 50, 256, 25, idx.data_ptr(),
+                                      dist.data_ptr(), L.current_stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert np.allclose(dist.cpu().numpy(), dist_ref, atol=1e-5)
+
+
+def test_errors_are_loud(dev):
+    L = H.pkg("lib")
+    w = O.seeded_weights("epc-net", 0)
+    eng, _ = H.make_engine("epc-net", w, dev)
+    with pytest.raises(L.EpcNetError):
+        eng.forward(torch.zeros((1, 100, 3), device=dev))      # N not a multiple of 32
+    with pytest.raises(L.EpcNetError):
+        eng.forward(torch.zeros((1, 64, 3)))                   # CPU tensor: no fallback
+    with pytest.raises(L.EpcNetError):
+        eng.forward(torch.zeros((1, 64, 4), device=dev))       # INPUT_DIM != 3
