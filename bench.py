@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- clouds/s of EPC-Net 256-d global-descriptor extraction on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path (epc_net_forward: kNN graph -> ProxyConv blocks -> conv5 -> G_VLAD -> 256-d
+descriptor) over one batch of synthetic clouds per GPU.  Workload at any N = BASELINE.json configs[1]: EPC-Net
+inference, batch 64 x 4096 x 3 fp32 per GPU, NetVLAD K=64, 256-D output; inputs are resident in HBM before the timed
+region.  Descriptor extraction shards over GPUs with no data-path collective (clouds are independent in inference,
+SURVEY.md 8e) -> weak scaling; value = clouds all ranks processed / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = conv5 + L2 + soft-assignment (conv5_kernel<256,VLAD>), bound = f32 MFMA.
+               achieved = algorithmic FLOPs per launch (2.684 GFLOP per cloud) / its average duration,
+               measured with HIP events recorded by the library on the launch stream inside the timed region.
+  cpu_baseline the CPU oracle (numpy restatement of the reference's dense (N,N)-mask formulation, batch = 1 cloud per
+               call as evaluate.py:86-90 does) timed on this box's host cores on a bounded sample.  Rank 0, N = 1 only.
+               It is NOT TensorFlow (not installable here) -- kind "port".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INPUT_DIM": 3, "GROUPS": 4}
+OUTER = "query_triplets"
+N_POINTS = 4096
+# algorithmic FLOPs per cloud of the dominant kernel: conv5 256->1024 + assignment 1024->64
+CONV5_ASSIGN_FLOPS = 2.0 * N_POINTS * 256 * 1024 + 2.0 * N_POINTS * 1024 * 64
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (matrix)
+FLOPS_PER_CLOUD = {"epc-net": 3.747e9, "epc-net-l": 1.355e9}
+
+
+def pkg(name=""):
+    return importlib.import_module("epc-net_amd" + ("." + name if name else ""))
+
+
+def build_store(arch, device, seed):
+    V = pkg("variables")
+    st = V.reset_default_store(device=device, seed=seed)
+    M = pkg("models." + arch)
+    with V.variable_scope(OUTER):
+        M.declare_variables(PARAMS, N_POINTS)
+    st.randomize_statistics(seed)
+    return st
+
+
+def cpu_baseline(arch, store, budget_s, max_clouds):
+    """Time the oracle on host cores.  The ONLY place bench.py touches oracle/ (never the measured GPU path)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import epcnet_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    w = {k[len(OUTER) + 1:]: v.detach().cpu().numpy() for k, v in store.vars.items()}
+    pcs = O.synthetic_clouds(max_clouds + 1, N_POINTS, 1234)
+    O.forward(pcs[:1, None], w, arch=arch)  # warm-up (BLAS threads, page faults)
+    done, t0 = 0, time.perf_counter()
+    while done < max_clouds and (time.perf_counter() - t0) < budget_s:
+        O.forward(pcs[done + 1:done + 2, None], w, arch=arch)  # batch = 1 cloud per call (evaluate.py:86-90)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 4), "unit": "clouds/s", "cores": int(threads), "kind": "port",
+            "sample": "%d clouds x %d pts, 1 cloud per call, numpy/OpenBLAS restatement of the reference's dense "
+                      "(N,N)-mask graph (oracle/epcnet_oracle.py), %.1f s; host has %d logical CPUs"
+                      % (done, N_POINTS, dt, os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per step per GPU (configs[1]: 64)")
+    ap.add_argument("--arch", default="epc-net", choices=["epc-net", "epc-net-l"])
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-clouds", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    E = pkg("engine")
+    store = build_store(args.arch, device, seed=0)            # same weights on every rank
+    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(100 + rank)                                  # every rank extracts different clouds
+    xyz = (torch.rand((args.batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
+    out = torch.empty((args.batch, 256), dtype=torch.float32, device=device)
+
+    for _ in range(max(args.warmup, 0)):
+        eng.forward(xyz, out=out)
+    profiles = [E.StageProfile() for _ in range(args.steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        eng.forward(xyz, out=out, profile=profiles[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    norms = out.norm(dim=1)
+    if not bool(torch.isfinite(out).all()) or float((norms - 1).abs().max()) > 1e-3:
+        raise SystemExit("descriptors are not unit-norm / finite: refusing to report a number")
+
+    stage = {}
+    for pr in profiles:
+        for k, v in pr.elapsed_ms().items():
+            stage[k] = stage.get(k, 0.0) + v / args.steps
+    conv5_ms = stage["conv5"]
+    conv5_flops = (CONV5_ASSIGN_FLOPS if args.arch == "epc-net" else 2.0 * N_POINTS * 128 * 1024) * args.batch
+    achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12
+    clouds = world * args.batch * args.steps
+    value = clouds / elapsed
+
+    if rank == 0:
+        line = {
+            "metric": "point-clouds/sec (4096 pts) descriptor extraction",
+            "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s inference, batch %dx%dx3 fp32 per GPU, NetVLAD K=64, 256-D output "
+                                   "(BASELINE.json configs[1])" % (args.arch, args.batch, N_POINTS),
+                       "clouds_per_step_per_gpu": args.batch, "num_points": N_POINTS,
+                       "weights": "seeded random init of the architecture (no checkpoint payloads exist)",
+                       "parallelism": "independent clouds sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv5_kernel (conv5 + L2 + soft-assignment)",
+                         "avg_launch_ms": round(conv5_ms, 4),
+                         "algorithmic_flops_per_launch": conv5_flops},
+            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+            "pipeline_tflops": round(value / world * FLOPS_PER_CLOUD[args.arch] / 1e12, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.arch, store, args.cpu_budget_s, args.cpu_clouds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,13 +59,83 @@ extern "C" size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds) {
         if (rc__ != EPC_OK) return rc__; \
     } while (0)
 
+// ---- stage profile: HIP events recorded on the caller's stream at the stage boundaries of ONE pass -----------
+struct epc_profile {
+    hipEvent_t ev[EPC_NUM_STAGES + 1];
+    int recorded[EPC_NUM_STAGES + 1];
+};
+
+extern "C" int epc_profile_create(epc_profile** prof) {
+    EPC_CHECK_ARG(prof, "null pointer");
+    epc_profile* p = new epc_profile();
+    for (int i = 0; i <= EPC_NUM_STAGES; ++i) {
+        p->recorded[i] = 0;
+        hipError_t e = hipEventCreate(&p->ev[i]);
+        if (e != hipSuccess) {
+            epc_set_error("epc_profile_create: hipEventCreate: %s", hipGetErrorString(e));
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(p->ev[k]);
+            delete p;
+            return EPC_EHIP;
+        }
+    }
+    *prof = p;
+    return EPC_OK;
+}
+
+extern "C" int epc_profile_destroy(epc_profile* prof) {
+    if (!prof) return EPC_OK;
+    for (int i = 0; i <= EPC_NUM_STAGES; ++i) (void)hipEventDestroy(prof->ev[i]);
+    delete prof;
+    return EPC_OK;
+}
+
+extern "C" int epc_profile_elapsed_ms(epc_profile* prof, float* stage_ms) {
+    EPC_CHECK_ARG(prof && stage_ms, "null pointer");
+    int last = -1;
+    for (int i = 0; i <= EPC_NUM_STAGES; ++i) {
+        if (i < EPC_NUM_STAGES) stage_ms[i] = 0.f;
+        if (!prof->recorded[i]) continue;
+        if (last >= 0) {
+            float ms = 0.f;
+            hipError_t e = hipEventElapsedTime(&ms, prof->ev[last], prof->ev[i]);
+            if (e != hipSuccess) {
+                epc_set_error("epc_profile_elapsed_ms: %s (stream not synchronised?)", hipGetErrorString(e));
+                return EPC_EHIP;
+            }
+            stage_ms[last] = ms;  // boundary `last` opens stage `last`; the next recorded boundary closes it
+        }
+        last = i;
+    }
+    return EPC_OK;
+}
+
+static int mark(epc_profile* prof, int boundary, void* stream) {
+    if (!prof) return EPC_OK;
+    hipError_t e = hipEventRecord(prof->ev[boundary], (hipStream_t)stream);
+    if (e != hipSuccess) {
+        epc_set_error("epc_net_forward_profiled: hipEventRecord: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    prof->recorded[boundary] = 1;
+    return EPC_OK;
+}
+
 extern "C" int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds,
                                float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return epc_net_forward_profiled(cfg, packed, xyz, num_clouds, out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds,
+                                        float* out, void* workspace, size_t workspace_bytes, void* stream,
+                                        epc_profile* prof) {
     EPC_CHECK_ARG(epc_net_packed_bytes(cfg) != 0, "unsupported configuration");
     EPC_CHECK_ARG(packed && xyz && out, "null pointer");
     EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     const int mb = micro_batch(cfg, num_clouds);
+    EPC_CHECK_ARG(!prof || num_clouds <= mb, "a stage profile covers one pass: num_clouds must be <= micro_batch");
+    if (prof)
+        for (int i = 0; i <= EPC_NUM_STAGES; ++i) prof->recorded[i] = 0;
     const WsLayout w = ws_layout(cfg, mb);
     if (!workspace || workspace_bytes < w.total) {
         epc_set_error("epc_net_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
@@ -86,9 +156,12 @@ extern "C" int epc_net_forward(const epc_cfg* cfg, const void* packed, const flo
         const int nc = (num_clouds - c0) < mb ? (num_clouds - c0) : mb;
         const float* pc = xyz + (size_t)c0 * n * 3;
         float* o = out + (size_t)c0 * cfg->output_dim;
+        TRY(mark(prof, EPC_STAGE_KNN, stream));
         TRY(epc_knn_topk(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, stream));
+        TRY(mark(prof, EPC_STAGE_CONV1, stream));
         TRY(epc_conv1_fwd(pc, pk + epc_net_packed_offset(cfg, 0), nc * n, xs[0], stream));
         for (int b = 1; b <= nblocks; ++b) {
+            TRY(mark(prof, EPC_STAGE_BLOCK1 + b - 1, stream));
             const int has_next = b < nblocks;
             TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], pc, idx, cnt, kth, EPC_KNN_CAP,
                                         pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn, cat, ccat,
@@ -100,16 +173,22 @@ extern "C" int epc_net_forward(const epc_cfg* cfg, const void* packed, const flo
             float* assign = (float*)(ws + w.assign);
             float* vpart = (float*)(ws + w.vpart);
             float* apart = (float*)(ws + w.apart);
+            TRY(mark(prof, EPC_STAGE_CONV5, stream));
             TRY(epc_conv5_assign_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign,
                                      stream));
+            TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
             TRY(epc_vlad_aggregate_fwd(feat, rnorm, assign, nc, n, AGG_SPLITS, vpart, apart, stream));
+            TRY(mark(prof, EPC_STAGE_HEAD, stream));
             TRY(epc_vlad_head_fwd(vpart, apart, AGG_SPLITS, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
                                   ws + w.head, w.total - w.head, stream));
         } else {
             float* pooled = (float*)(ws + w.pooled);
+            TRY(mark(prof, EPC_STAGE_CONV5, stream));
             TRY(epc_conv5_maxpool_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc, n, pooled, stream));
+            TRY(mark(prof, EPC_STAGE_HEAD, stream));
             TRY(epc_fc_head_fwd(pooled, pk + epc_net_packed_offset(cfg, 6), nc, o, stream));
         }
+        TRY(mark(prof, EPC_NUM_STAGES, stream));
     }
     return EPC_OK;
 }

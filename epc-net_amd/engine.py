@@ -77,8 +77,10 @@ class InferenceEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
-    def forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """xyz (num_clouds, N, 3) float32 on the GPU -> (num_clouds, FEATURE_OUTPUT_DIM)."""
+    def forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None, profile: "Optional[StageProfile]" = None
+                ) -> torch.Tensor:
+        """xyz (num_clouds, N, 3) float32 on the GPU -> (num_clouds, FEATURE_OUTPUT_DIM).
+        ``profile``: record HIP events at the stage boundaries of this pass (same launches, same stream)."""
         if xyz.dim() != 3 or xyz.shape[-1] != 3:
             raise L.EpcNetError(-1, "expected (num_clouds, N, 3) points, got %s" % (tuple(xyz.shape),))
         if xyz.dtype != torch.float32:
@@ -91,6 +93,30 @@ class InferenceEngine:
         if out is None:
             out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
         ws = self.workspace(cfg, max(nc, 1), xyz.device)
-        L.check(L.lib().epc_net_forward(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
-                                        ws.data_ptr(), ws.numel(), L.current_stream()))
+        L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
+                                                 ws.data_ptr(), ws.numel(), L.current_stream(),
+                                                 profile.handle if profile is not None else None))
         return out
+
+
+class StageProfile:
+    """HIP-event stage timer (``epc_profile`` of include/epcnet.h)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        L.check(L.lib().epc_profile_create(ctypes.byref(h)))
+        self.handle = h
+
+    def elapsed_ms(self) -> Dict[str, float]:
+        """Per-stage milliseconds; call after the stream is synchronised."""
+        arr = (ctypes.c_float * L.EPC_NUM_STAGES)()
+        L.check(L.lib().epc_profile_elapsed_ms(self.handle, arr))
+        return {L.STAGE_NAMES[i]: float(arr[i]) for i in range(L.EPC_NUM_STAGES)}
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.lib().epc_profile_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

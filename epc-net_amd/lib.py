@@ -30,7 +30,10 @@ EXPORTS = [
     "epc_net_forward", "epc_knn_topk", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
+    "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
 ]
+EPC_NUM_STAGES = 9
+STAGE_NAMES = ["knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
 
 
 class EpcNetError(RuntimeError):
@@ -78,9 +81,12 @@ _lib.epc_vlad_head_fwd.argtypes = [_P, _P, c_int, _P, c_int, c_int, _P, _P, c_si
 _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
 _lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
+_lib.epc_profile_create.argtypes = [POINTER(_P)]
+_lib.epc_profile_destroy.argtypes = [_P]
+_lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]
+_lib.epc_profile_elapsed_ms.argtypes = [_P, POINTER(c_float)]
 for _name in EXPORTS:
-    if getattr(_lib, _name).restype is c_int and _name not in ("epc_version",):
-        pass  # int-returning entry points (ctypes default restype)
+    getattr(_lib, _name)  # AttributeError here = the built library is stale (rebuild it)
 
 
 def lib() -> ctypes.CDLL:

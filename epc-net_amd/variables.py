@@ -85,6 +85,31 @@ class VariableStore:
         from . import tf_bundle
         return self.load_state_dict(tf_bundle.load_checkpoint(prefix), strict=True)
 
+    def randomize_statistics(self, seed: int = 0) -> None:
+        """Synthetic 'trained-like' values for everything the reference initialises to a constant (biases 0,
+        gamma 1, beta 0, EMA shadows 0, moving_variance 1): with the raw initial values inference-mode BN divides
+        by sqrt(0 + 1e-3) in every tf_util layer and the activations are meaningless.  Used by bench.py / smoke()
+        (no checkpoint payloads or datasets exist in this environment -- BASELINE.md 1)."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int(seed))
+        for name, t in self.vars.items():
+            leaf = name.rsplit("/", 1)[-1]
+            n = t.numel()
+            if leaf == "biases":
+                v = torch.randn(n, generator=g) * 0.05
+            elif leaf == "beta":
+                v = torch.randn(n, generator=g) * 0.1
+            elif leaf == "gamma":
+                v = torch.rand(n, generator=g) + 0.5
+            elif leaf in ("moving_mean",) or name.endswith(EMA_MEAN_SUFFIX):
+                v = torch.randn(n, generator=g) * 0.1
+            elif leaf in ("moving_variance",) or name.endswith(EMA_VAR_SUFFIX):
+                v = torch.rand(n, generator=g) + 0.5
+            else:
+                continue
+            t.copy_(v.reshape(t.shape).to(t.device))
+        self.version += 1
+
     def num_trainable_params(self) -> int:
         """``count_params()`` of train.py:202-206."""
         return int(sum(self.vars[n].numel() for n in self.trainable))

@@ -76,6 +76,24 @@ size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds);
 int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stage profile: same launches as epc_net_forward, plus HIP events recorded on `stream` at the stage boundaries
+ * (measurement only; SURVEY.md 5 "tracing": the reference wraps sess.run in RunOptions(FULL_TRACE),
+ * evaluate.py:275,385-390).  One profile covers one pass (num_clouds <= micro_batch).  Read the per-stage
+ * milliseconds with epc_profile_elapsed_ms after the stream has been synchronised. */
+#define EPC_STAGE_KNN 0
+#define EPC_STAGE_CONV1 1
+#define EPC_STAGE_BLOCK1 2 /* .. EPC_STAGE_BLOCK1+3 */
+#define EPC_STAGE_CONV5 6  /* conv5 + L2 + assignment (EPC-Net) / conv5 + max-pool (EPC-Net-L) */
+#define EPC_STAGE_AGGREGATE 7
+#define EPC_STAGE_HEAD 8
+#define EPC_NUM_STAGES 9
+typedef struct epc_profile epc_profile;
+int epc_profile_create(epc_profile** prof);
+int epc_profile_destroy(epc_profile* prof);
+int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream, epc_profile* prof);
+int epc_profile_elapsed_ms(epc_profile* prof, float* stage_ms /* host, EPC_NUM_STAGES floats */);
+
 /* ------------------------------------------------------------------------------------------------------ */
 /* Stage entry points (what epc_net_forward chains; exported for parity tests and for op-level callers).    */
 /* ------------------------------------------------------------------------------------------------------ */
