@@ -218,9 +218,9 @@ def write_checkpoint_payload(prefix: str, tensors: Dict[str, np.ndarray]) -> Non
     total = max(e.offset + e.size for e in entries.values())
     blob = bytearray(total)
     for name, e in entries.items():
-        arr = np.ascontiguousarray(tensors[name], dtype=e.dtype)
+        arr = np.asarray(tensors[name], dtype=e.dtype)
         if tuple(arr.shape) != e.shape:
             raise ValueError("%s: shape %s != %s" % (name, arr.shape, e.shape))
-        blob[e.offset:e.offset + e.size] = arr.tobytes()
+        blob[e.offset:e.offset + e.size] = arr.tobytes(order="C")
     with open(data_path_for(prefix), "wb") as f:
         f.write(bytes(blob))

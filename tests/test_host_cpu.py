@@ -1,0 +1,146 @@
+"""CPU tests of the host layer: C-ABI exports, naming contract, checkpoint reader, loud failure without a GPU."""
+import importlib
+import json
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from helpers import O, ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TABLES = json.load(open(os.path.join(GOLD, "ckpt_tables.json")))
+
+
+def test_library_exports_every_declared_symbol():
+    L = H.pkg("lib")
+    header = open(os.path.join(ROOT, "include", "epcnet.h")).read()
+    declared = set(re.findall(r"\b(epc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(L.lib(), name), name
+    assert L.lib().epc_version() >= 100
+
+
+def test_cfg_struct_layout_and_sizes():
+    import ctypes
+    L, E = H.pkg("lib"), H.pkg("engine")
+    assert ctypes.sizeof(L.EpcCfg) == 32
+    cfg = E.make_cfg("epc-net", 4096, H.PARAMS)
+    nbytes = L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
+    assert nbytes >= 4704832 * 4 - 4 * 10000          # folded weights: ~ the trainable matrices
+    offs = [L.lib().epc_net_packed_offset(ctypes.byref(cfg), s) for s in range(7)]
+    assert offs == sorted(offs) and offs[0] == 0 and all(o % 256 == 0 for o in offs)
+    assert L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64) > 64 * 4096 * 1024 * 4   # holds the conv5 map
+    bad = E.make_cfg("epc-net", 4100, H.PARAMS)       # N not a multiple of 32
+    assert L.lib().epc_net_packed_bytes(ctypes.byref(bad)) == 0
+
+
+@pytest.mark.parametrize("arch,count", [("epc-net", 4704832), ("epc-net-l", 418880)])
+def test_state_dict_equals_reference_checkpoint_names(arch, count):
+    st = H.make_store(arch, O.seeded_weights(arch, 0), "cpu")
+    ref = {e["name"]: tuple(e["shape"]) for e in TABLES[arch]["entries"]
+           if not e["name"].endswith(("/Adam", "/Adam_1")) and e["name"] not in ("Variable", "beta1_power", "beta2_power")}
+    assert {k: tuple(v.shape) for k, v in st.state_dict().items()} == ref
+    assert st.num_trainable_params() == count
+
+
+def test_reference_initialisers():
+    V = H.pkg("variables")
+    st = V.reset_default_store(device="cpu", seed=1)
+    M = H.pkg("models.epc-net")
+    with V.variable_scope("query_triplets"):
+        M.declare_variables(H.PARAMS, 4096)
+    w = st.vars["query_triplets/fastdgcnn/conv5/weights"]
+    lim = (6.0 / (256 + 1024)) ** 0.5                                # xavier uniform, utils/tf_util.py:42
+    assert float(w.abs().max()) <= lim and float(w.abs().max()) > 0.95 * lim
+    assert float(st.vars["query_triplets/fastdgcnn/conv1/biases"].abs().max()) == 0.0
+    assert float(st.vars["query_triplets/VLAD/bn/moving_variance"].min()) == 1.0
+    h = st.vars["query_triplets/VLAD/hidden1_weights"]
+    assert abs(float(h.std()) - 1 / 8.0) < 2e-3                      # N(0, 1/sqrt(cluster_size)), loupe.py:316
+
+
+@pytest.mark.parametrize("tag,n", [("epc-net", 221), ("epc-net-l", 115), ("epc-net-l-d_student", 113),
+                                   ("epc-net-l-d_teacher", 221)])
+def test_tf_bundle_index_reader_on_reference_files(tag, n):
+    tfb = H.pkg("tf_bundle")
+    entries = tfb.read_index(os.path.join(GOLD, tag + ".ckpt.index"))
+    assert len(entries) == n
+    want = {e["name"]: (e["dtype"], tuple(e["shape"]), e["offset"], e["size"]) for e in TABLES[tag]["entries"]}
+    got = {e.name: (e.dtype.name, e.shape, e.offset, e.size) for e in entries.values()}
+    assert got == want
+
+
+def test_checkpoint_round_trip_and_missing_payload(tmp_path):
+    """Seeded weights written through the REFERENCE's index table load back into the store; a missing .data shard
+    raises like evaluate.py:264-266 refuses to run."""
+    tfb = H.pkg("tf_bundle")
+    prefix = str(tmp_path / "model_epoch22_iter18101.ckpt")
+    shutil.copyfile(os.path.join(GOLD, "epc-net.ckpt.index"), prefix + ".index")
+    st = H.make_store("epc-net", O.seeded_weights("epc-net", 0, mode="init"), "cpu")
+    with pytest.raises(FileNotFoundError):
+        st.load_checkpoint(prefix)
+    entries = tfb.read_index(prefix + ".index")
+    w = O.seeded_weights("epc-net", 5)
+    tensors = {}
+    for name, e in entries.items():
+        rel = name[len("query_triplets/"):] if name.startswith("query_triplets/") else None
+        tensors[name] = w[rel] if rel in w else np.zeros(e.shape, dtype=e.dtype)
+    tfb.write_checkpoint_payload(prefix, tensors)
+    assert os.path.getsize(tfb.data_path_for(prefix)) == 56476940            # SURVEY.md 8c payload size
+    unused = st.load_checkpoint(prefix)
+    assert "beta1_power" in unused and any(u.endswith("/Adam") for u in unused)
+    for k, v in w.items():
+        assert np.array_equal(st.vars["query_triplets/" + k].numpy(), v)
+
+
+def test_forward_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L, V = H.pkg("lib"), H.pkg("variables")
+    V.reset_default_store(device="cpu", seed=0)
+    M = H.pkg("models.epc-net")
+    x = M.placeholder_inputs(1, 1, 64, 3)
+    with V.variable_scope("query_triplets"), pytest.raises(L.EpcNetError):
+        M.forward(x, False, params=H.PARAMS)
+
+
+def test_forward_argument_errors():
+    V = H.pkg("variables")
+    V.reset_default_store(device="cpu", seed=0)
+    M = H.pkg("models.epc-net")
+    with pytest.raises(TypeError):
+        M.forward(torch.zeros(1, 1, 64, 3), False)                        # params is required (epc-net.py:37)
+    with pytest.raises(ValueError):
+        M.forward(torch.zeros(1, 1, 64, 13), False, params=H.PARAMS)      # INPUT_DIM mismatch
+
+
+def test_losses_match_oracle_and_reference_error_behaviour():
+    M = H.pkg("models.epc-net")
+    rng = np.random.RandomState(0)
+    def unit(*s):
+        a = rng.randn(*s); return a / np.linalg.norm(a, axis=-1, keepdims=True)
+    q, pos, neg, oth = unit(3, 1, 256), unit(3, 2, 256), unit(3, 14, 256), unit(3, 1, 256)
+    tq, tp, tn, to = (torch.from_numpy(a) for a in (q, pos, neg, oth))
+    assert float(M.lazy_quadruplet_loss(tq, tp, tn, to, 0.5, 0.2)) == pytest.approx(O.lazy_quadruplet_loss(q, pos, neg, oth, 0.5, 0.2), rel=1e-12)
+    assert float(M.quadruplet_loss(tq, tp, tn, to, 0.5, 0.2)) == pytest.approx(O.quadruplet_loss(q, pos, neg, oth, 0.5, 0.2), rel=1e-12)
+    assert float(M.lazy_triplet_loss(tq, tp, tn, 0.5)) == pytest.approx(O.lazy_triplet_loss(q, pos, neg, 0.5), rel=1e-12)
+    assert float(M.triplet_loss(tq, tp, tn, 0.5)) == pytest.approx(O.triplet_loss(q, pos, neg, 0.5), rel=1e-12)
+    assert float(M.lazy_quadruplet_loss_sm(tq, tp, tn, to, 0.2)) == pytest.approx(O.lazy_quadruplet_loss_sm(q, pos, neg, oth, 0.2), rel=1e-12)
+    with pytest.raises(NameError):                                         # models/epc-net.py:205 returns `soft_los`
+        M.softmargin_loss(tq, tp, tn)
+    with pytest.raises(NameError):
+        M.quadruplet_loss_sm(tq, tp, tn, to, 0.2)
+    L = importlib.import_module("epc-net_amd.models.epc-net-l")
+    assert set(M.LOSS_NAMES) <= set(dir(L))                                # identical loss family in both files
+
+
+def test_unused_reference_ops_are_named_not_silently_missing():
+    tf_util = H.pkg("utils.tf_util")
+    for name in ("conv2d", "conv3d", "dropout", "knn", "get_edge_feature", "pairwise_distance", "avg_pool2d"):
+        with pytest.raises(NotImplementedError):
+            getattr(tf_util, name)()

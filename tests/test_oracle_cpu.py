@@ -1,0 +1,132 @@
+"""CPU tests of the oracle: pinned against the reference's own artefacts where any exist (variable tables, parameter
+counts, graph constants -- SURVEY.md 8c) and against its own internal consistency elsewhere (PARITY UNPINNED vs a
+running TensorFlow: not installable here)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import O, ROOT
+
+TABLES = json.load(open(os.path.join(ROOT, "tests", "golden", "ckpt_tables.json")))
+
+
+def _ref_vars(tag):
+    return {e["name"]: tuple(e["shape"]) for e in TABLES[tag]["entries"]
+            if not e["name"].endswith(("/Adam", "/Adam_1")) and e["name"] not in ("Variable", "beta1_power", "beta2_power")}
+
+
+@pytest.mark.parametrize("arch,count", [("epc-net", 4704832), ("epc-net-l", 418880)])
+def test_variable_table_matches_reference_checkpoint(arch, count):
+    t = O.variable_table(arch)
+    assert {"query_triplets/" + k: v[0] for k, v in t.items()} == _ref_vars(arch)
+    assert O.count_trainable(t) == count        # README/ckpt-derived parameter counts
+
+
+def test_every_trainable_has_adam_slots_in_reference_table():
+    names = {e["name"] for e in TABLES["epc-net"]["entries"]}
+    t = O.variable_table("epc-net")
+    for k, (_, kind) in t.items():
+        if kind in ("weight", "bias", "gamma", "beta"):
+            assert "query_triplets/%s/Adam" % k in names and "query_triplets/%s/Adam_1" % k in names
+
+
+def test_mask_semantics_ties_and_padding():
+    # self is always selected; row sum >= 20; all-zero cloud selects everything
+    pc = O.synthetic_clouds(1, 128, 0)
+    m = O.pairwise_distance_mask(pc)
+    assert m.shape == (1, 128, 128) and m.dtype == np.float32
+    assert np.all(np.diagonal(m[0]) == 1.0)
+    assert np.all(m.sum(-1) >= 20)
+    z = O.pairwise_distance_mask(O.synthetic_clouds(1, 64, 0, "zeros"))
+    assert np.all(z == 1.0)
+    lat = O.pairwise_distance_mask(O.synthetic_clouds(1, 512, 0, "lattice"))
+    assert lat.sum(-1).max() > 20              # exact ties are all kept (greater_equal)
+
+
+def test_mask_k_argument_is_ignored_like_the_reference():
+    pc = O.synthetic_clouds(1, 64, 1)
+    assert np.array_equal(O.pairwise_distance_mask(pc, k=5), O.pairwise_distance_mask(pc, k=20))
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+def test_dense_and_index_formulations_agree(arch):
+    w = O.seeded_weights(arch, 0)
+    pc = O.synthetic_clouds(2, 128, 3, "lidar")[:, None]
+    a, _ = O.forward(pc, w, arch=arch, formulation="dense")
+    b, _ = O.forward(pc, w, arch=arch, formulation="lists")
+    assert np.abs(a - b).max() <= 2e-6
+    assert np.allclose(np.linalg.norm(a, axis=-1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+def test_fp32_tolerance_budget(arch):
+    """fp32 vs the fp64 shadow (same neighbour sets): the error budget the 1e-4 GPU bar sits far above."""
+    w = O.seeded_weights(arch, 1)
+    pc = O.synthetic_clouds(2, 256, 4)
+    mask = O.pairwise_distance_mask(pc)
+    a, _ = O.forward(pc[:, None], w, arch=arch)
+    b, _ = O.forward(pc[:, None], w, arch=arch, dtype=np.float64, mask=mask)
+    assert np.linalg.norm(a - b, axis=-1).max() <= 5e-6
+
+
+def test_grouped_projection_fold_identity():
+    """with affine (inference) BN and one shared weight, sum_g BN(v_g W) == s*((sum_g v_g) W) + G*t."""
+    w = O.seeded_weights("epc-net", 2)
+    st = O.State(w, np.float64)
+    rng = np.random.RandomState(0)
+    v = rng.randn(3, 65536)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    H = st.w["VLAD/hidden1_weights"]
+    y = O.slim_batch_norm(st, (v.reshape(-1, 16384) @ H), "VLAD/bn", False, True).reshape(3, 4, 256).sum(1)
+    s = st.w["VLAD/bn/gamma"] / np.sqrt(st.w["VLAD/bn/moving_variance"] + 1e-3)
+    t = st.w["VLAD/bn/beta"] - st.w["VLAD/bn/moving_mean"] * s
+    y2 = (v.reshape(3, 4, 16384).sum(1) @ H) * s + 4 * t
+    assert np.abs(y - y2).max() <= 1e-10
+
+
+def test_training_mode_statistics_and_ema():
+    w = O.seeded_weights("epc-net", 0, mode="init")
+    pc = O.synthetic_clouds(2, 64, 0)[None]                  # (1, 2, 64, 3)
+    out, st = O.forward(pc, w, is_training=True, bn_decay=0.5)
+    assert np.allclose(np.linalg.norm(out, axis=-1), 1.0, atol=1e-5)
+    m, v = O.ema_names("fastdgcnn/conv1")
+    bm, bv = st.batch_stats["fastdgcnn/conv1/bn"]
+    assert np.allclose(st.new_stats[m], 0.5 * bm, atol=1e-7)  # shadow starts at 0: 0 - 0.5*(0 - mean)
+    assert np.allclose(st.new_stats[v], 0.5 * bv, atol=1e-7)
+    # fused slim BN feeds the Bessel-corrected variance to the moving average (rows = B*P*G = 8)
+    _, var = st.batch_stats["VLAD/bn"]
+    assert np.allclose(st.new_stats["VLAD/bn/moving_variance"], 1 - (1 - var * 8 / 7) * 0.001, atol=1e-6)
+
+
+def test_losses_known_answers():
+    q = np.zeros((1, 1, 4)); q[0, 0, 0] = 1
+    pos = np.stack([q[0, 0], np.array([0, 1, 0, 0.])])[None]           # best positive distance 0
+    neg = np.array([[[-1, 0, 0, 0.], [0, 0, 1, 0.]]])                   # d^2 = 4 and 2
+    other = np.array([[[0, 0, 0, 1.]]])
+    assert O.lazy_triplet_loss(q, pos, neg, 0.5) == 0.0                  # negatives are far
+    assert O.triplet_loss(q, pos, neg, 2.5) == pytest.approx(0.5)        # only the d^2 = 2 negative violates
+    assert O.lazy_quadruplet_loss(q, pos, neg, other, 0.5, 0.2) == 0.0
+    assert O.lazy_quadruplet_loss(q, pos, neg, other, 2.5, 2.5) == pytest.approx(0.5 + 0.5)
+
+
+def test_schedules():
+    assert O.get_bn_decay(0) == 0.5 and O.get_bn_decay(200000) == 0.75 and O.get_bn_decay(10 ** 8) == 0.99
+    assert O.get_learning_rate(0) == 5e-5 and O.get_learning_rate(5) == pytest.approx(4.5e-5)
+    assert O.get_learning_rate(1000) == 1e-5
+
+
+def test_get_recall_semantics_against_sklearn():
+    from sklearn.neighbors import KDTree
+    rng = np.random.RandomState(0)
+    db = rng.randn(250, 256).astype(np.float32); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[rng.randint(0, 250, 40)] + 0.2 * rng.randn(40, 256).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    truth = [list(rng.choice(250, size=rng.randint(0, 4), replace=False)) for _ in range(40)]
+    _, ind = KDTree(db).query(q, k=25)
+    rec, sim, one = O.get_recall(db, q, truth, indices=ind)
+    rec2, sim2, one2 = O.get_recall(db, q, truth)                     # brute-force neighbours
+    assert np.array_equal(rec, rec2) and one == one2 and np.allclose(sim, sim2)
+    assert max(int(round(250 / 100.0)), 1) == 2 and max(int(round(50 / 100.0)), 1) == 1  # banker's rounding, :470
+    assert rec.shape == (25,) and np.all(np.diff(rec) >= 0)
