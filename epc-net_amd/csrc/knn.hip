@@ -1,22 +1,257 @@
 // Static xyz kNN graph in index form -- replaces utils/tf_util.py:647-666 (pairwise_distance_mask), which
 // materialises a dense (B,N,N) float mask (64 MB per 4096-point cloud).
 //
-// One thread per query point; candidates stream through LDS as (x,y,z,|p|^2) float4 tiles that every lane
-// reads at the same address (LDS broadcast, conflict-free).  Pass 1 keeps the 20 largest a_ij of the row in
-// registers (sorted, v_max/v_min insertion network, skipped wave-wide when no lane improves) and yields
-// kth = the 20th largest with multiplicity (tf.nn.top_k + reduce_min).  Pass 2 re-scans and emits every
-// j with a_ij >= kth in ascending order (greater_equal, tf_util.py:664), counting past the list capacity so the
-// consumer knows when a row needs the exact scan path.  VALU/LDS bound; no HBM traffic beyond xyz and the lists.
+// Semantics (bit-exact w.r.t. oracle/epcnet_oracle.py): a_ij = -((sq_i + -2*inner_ij) + sq_j) in f32 with one
+// rounding per operation; kth_i = 20th largest a_i. with multiplicity (tf.nn.top_k + reduce_min); the selected set is
+// {j : a_ij >= kth_i} (greater_equal), emitted in ascending j, counted past the list capacity.
+//
+// knn_topk_culled_kernel (N <= 8192): the whole cloud sits in LDS as (x,y,z,|p|^2); one thread per query; candidates
+// are visited in 32-point tiles, nearest tiles (by index distance from the query's own tile) first.  Before a tile is
+// scanned every lane computes the exact lower bound of its distance to the tile's bounding box and the wave votes:
+// the tile is skipped when no lane can improve its current 20th distance (minus a rounding margin that covers the
+// difference between the computed a_ij and the true squared distance).  On spatially ordered clouds (the pipeline
+// Morton-sorts them first, sort.hip) a wave's 64 queries are neighbours and ~3/4 of the tiles are skipped; on
+// arbitrary order the bounds are loose and the kernel degrades gracefully to the full scan with identical results.
+// Pass 1 keeps the 20 largest a_ij in a sorted register file (v_max/v_min insertion network, skipped wave-wide when
+// no lane improves); pass 2 re-visits the surviving tiles in ascending order and emits the list.
+//
+// knn_topk_stream_kernel (any N): same two passes with candidates streamed through an LDS tile, no culling.
 #include "common.h"
 
-#define KNN_THREADS 256
+#ifndef KNN_THREADS
+#define KNN_THREADS 512
+#endif
 #define KNN_TILE 1024
+#ifndef KNN_CT
+#define KNN_CT 32             // candidate tile (culled kernel)
+#endif
+#define KNN_WAVES (KNN_THREADS / 64)
+#define KNN_LDS_MAX_N 8192    // (N * 16 B + N/32 * 32 B) <= 160 KB
+
+// Order-preserving float -> int key (involution): integer compare == float compare for non-NaN values once -0.0 has
+// been folded into +0.0 (callers add +0.0f).  The insertion network then runs on v_max_i32 / v_min_i32 (the float
+// forms cost an extra canonicalising v_max per slot).
+__device__ __forceinline__ int fkey(float v) {
+    const int b = __float_as_int(v);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 
 template <int KSEL>
-__global__ __launch_bounds__(KNN_THREADS) void knn_topk_kernel(const float* __restrict__ xyz, int n, int cap,
-                                                               int32_t* __restrict__ idx,
-                                                               int32_t* __restrict__ cnt,
-                                                               float* __restrict__ kth_out) {
+__device__ __forceinline__ void topk_insert(float (&top)[KSEL], float v) {
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) {
+        const float hi = fmaxf(top[s], v);
+        v = fminf(top[s], v);
+        top[s] = hi;
+    }
+}
+
+template <int KSEL>
+__device__ __forceinline__ void topk_insert_key(int (&top)[KSEL], int v) {
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) {
+        const int hi = max(top[s], v);
+        v = min(top[s], v);
+        top[s] = hi;
+    }
+}
+
+#define KNN_BATCH 8
+
+#ifdef KNN_STATS  // tuning builds only (scripts/tune_knn.sh): wave-level event counters
+__device__ unsigned long long g_knn_stats[8];
+#define KSTAT(i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_knn_stats[i], 1ull); } while (0)
+extern "C" int epc_debug_knn_stats(unsigned long long* host_out, int reset) {
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_knn_stats), sizeof(g_knn_stats)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#else
+#define KSTAT(i) do { } while (0)
+#endif
+
+template <int KSEL>
+__global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const float* __restrict__ xyz, int n, int cap,
+                                                                      int32_t* __restrict__ idx,
+                                                                      int32_t* __restrict__ cnt,
+                                                                      float* __restrict__ kth_out) {
+    extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, then 2 float4 per tile (lo, hi)
+    const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+    const int npad = ntiles * KNN_CT;
+    float4* bb = cand + npad;                  // [2*ntiles] boxes, then one float4 holding the margin
+    float* s_margin = reinterpret_cast<float*>(bb + 2 * ntiles);
+    const int cloud = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pc = xyz + (size_t)cloud * n * 3;
+
+    for (int j = tid; j < npad; j += KNN_THREADS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);
+        if (j < n) {
+            v.x = pc[3 * j + 0];
+            v.y = pc[3 * j + 1];
+            v.z = pc[3 * j + 2];
+            v.w = sq3(v.x, v.y, v.z);
+        }
+        cand[j] = v;
+    }
+    __syncthreads();
+    // tile bounding boxes: KNN_CT lanes per tile, shuffle min/max
+    for (int t = wave * (64 / KNN_CT) + lane / KNN_CT; t < ntiles; t += KNN_WAVES * (64 / KNN_CT)) {
+        const float4 v = cand[t * KNN_CT + (lane % KNN_CT)];
+        const bool ok = v.w != INFINITY;
+        float lx = ok ? v.x : INFINITY, ly = ok ? v.y : INFINITY, lz = ok ? v.z : INFINITY;
+        float hx = ok ? v.x : -INFINITY, hy = ok ? v.y : -INFINITY, hz = ok ? v.z : -INFINITY;
+#pragma unroll
+        for (int off = KNN_CT / 2; off >= 1; off >>= 1) {
+            lx = fminf(lx, __shfl_xor(lx, off));
+            ly = fminf(ly, __shfl_xor(ly, off));
+            lz = fminf(lz, __shfl_xor(lz, off));
+            hx = fmaxf(hx, __shfl_xor(hx, off));
+            hy = fmaxf(hy, __shfl_xor(hy, off));
+            hz = fmaxf(hz, __shfl_xor(hz, off));
+        }
+        if ((lane % KNN_CT) == 0) {
+            bb[2 * t] = make_float4(lx, ly, lz, 0.f);
+            bb[2 * t + 1] = make_float4(hx, hy, hz, 0.f);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // margin >= |computed(-a_ij) - true d^2| + rounding of the box bound: 256 ulp of the largest |p|^2 bound
+        float m = 0.f;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float4 lo = bb[2 * t], hi = bb[2 * t + 1];
+            const float ax = fmaxf(fabsf(lo.x), fabsf(hi.x)), ay = fmaxf(fabsf(lo.y), fabsf(hi.y)),
+                        az = fmaxf(fabsf(lo.z), fabsf(hi.z));
+            m = fmaxf(m, ax * ax + ay * ay + az * az);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) *s_margin = m * (256.0f * 5.9604645e-08f);
+    }
+    __syncthreads();
+    const float margin = *s_margin;
+
+    const int i = blockIdx.x * KNN_THREADS + tid;
+    const bool valid = i < n;
+    float xi = 0.f, yi = 0.f, zi = 0.f, sqi = 0.f;
+    if (valid) {
+        const float4 me = cand[i];
+        xi = me.x;
+        yi = me.y;
+        zi = me.z;
+        sqi = me.w;
+    }
+    int top[KSEL];  // fkey() of the KSEL largest a_ij seen, descending
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) top[s] = fkey(-INFINITY);
+
+    auto lower_bound = [&](int c) {
+        const float4 lo = bb[2 * c], hi = bb[2 * c + 1];
+        const float dx = fmaxf(fmaxf(lo.x - xi, xi - hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(lo.y - yi, yi - hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(lo.z - zi, zi - hi.z), 0.f);
+        return dx * dx + dy * dy + dz * dz - margin;
+    };
+    // KNN_BATCH candidates at a time: the LDS reads are issued together, one wave vote decides whether any lane has
+    // anything to insert (almost never once the threshold has tightened).
+    // d'_ij = (sq_i + -2*inner) + sq_j = -a_ij (negation is exact, so all comparisons are done on d').
+    auto pos_sq_dist = [&](const float4& q) {
+#pragma clang fp contract(off)
+        const float inner = (xi * q.x + yi * q.y) + zi * q.z;
+        const float t = -2.0f * inner;
+        return (sqi + t) + q.w;
+    };
+    float thr = INFINITY;  // current 20th smallest d' (= -a of top[KSEL-1]); candidates must be strictly below it
+    auto scan1 = [&](int c) {
+        KSTAT(0);
+        if (!__any(valid && lower_bound(c) <= thr)) return;
+        KSTAT(1);
+        const float4* tp = cand + c * KNN_CT;
+#pragma unroll
+        for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+            float4 q[KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
+            float d[KNN_BATCH];
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) {
+                d[u] = pos_sq_dist(q[u]);
+                hit |= d[u] < thr;
+            }
+            if (__any(hit)) {
+                KSTAT(2);
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) {
+                    const int key = fkey(0.0f - d[u]);  // a_ij with -0.0 folded into +0.0
+                    if (key > top[KSEL - 1]) topk_insert_key<KSEL>(top, key);
+                }
+                thr = -fkey_inv(top[KSEL - 1]);
+            }
+        }
+    };
+
+    // ---- pass 1: own tiles first, then outwards ----
+    const int t0 = (blockIdx.x * KNN_THREADS + wave * 64) / KNN_CT;  // wave-uniform
+    constexpr int OWN = 64 / KNN_CT;  // tiles covered by the wave's own 64 queries
+#pragma unroll
+    for (int o = 0; o < OWN; ++o)
+        if (t0 + o < ntiles) scan1(t0 + o);
+    for (int d = 1; d < ntiles; ++d) {
+        const int cl = t0 - d, cr = t0 + OWN - 1 + d;
+        if (cl >= 0 && cl < ntiles) scan1(cl);
+        if (cr < ntiles) scan1(cr);
+    }
+    const int kkey = top[KSEL - 1];
+    const float kth = fkey_inv(kkey);
+
+    // ---- pass 2: emit {j : a_ij >= kth} = {j : d'_ij <= -kth} ascending ----
+    int count = 0;
+    int32_t* my = idx + ((size_t)cloud * n + (valid ? i : 0)) * cap;
+    const float dk = -kth;
+    for (int c = 0; c < ntiles; ++c) {
+        if (!__any(valid && lower_bound(c) <= dk)) continue;
+        KSTAT(4);
+        const float4* tp = cand + c * KNN_CT;
+#pragma unroll
+        for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+            float4 q[KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
+            float d[KNN_BATCH];
+            bool hit = false;
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) {
+                d[u] = pos_sq_dist(q[u]);
+                hit |= d[u] <= dk;
+            }
+            if (__any(hit)) {
+                KSTAT(5);
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u)
+                    if (d[u] <= dk) {
+                        if (valid && count < cap) my[count] = c * KNN_CT + k0 + u;
+                        ++count;
+                    }
+            }
+        }
+    }
+    if (valid) {
+        cnt[(size_t)cloud * n + i] = count;
+        kth_out[(size_t)cloud * n + i] = kth;
+    }
+}
+
+template <int KSEL>
+__global__ __launch_bounds__(KNN_THREADS) void knn_topk_stream_kernel(const float* __restrict__ xyz, int n, int cap,
+                                                                      int32_t* __restrict__ idx,
+                                                                      int32_t* __restrict__ cnt,
+                                                                      float* __restrict__ kth_out) {
     __shared__ float4 tile[KNN_TILE];
     const int cloud = blockIdx.y;
     const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
@@ -29,13 +264,11 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_kernel(const float* __re
         zi = pc[3 * i + 2];
     }
     const float sqi = sq3(xi, yi, zi);
-
     float top[KSEL];
 #pragma unroll
     for (int s = 0; s < KSEL; ++s) top[s] = -INFINITY;
 
-    // ---- pass 1: k-th largest ----
-    for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+    auto load_tile = [&](int t0) {
         __syncthreads();
         for (int c = threadIdx.x; c < KNN_TILE; c += KNN_THREADS) {
             const int j = t0 + c;
@@ -49,40 +282,23 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_kernel(const float* __re
             tile[c] = v;
         }
         __syncthreads();
+    };
+
+    for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
+        load_tile(t0);
         const int lim = min(KNN_TILE, n - t0);
 #pragma unroll 4
         for (int c = 0; c < lim; ++c) {
             const float4 q = tile[c];
-            float v = neg_sq_dist(sqi, xi, yi, zi, q.x, q.y, q.z, q.w);
-            if (v > top[KSEL - 1]) {
-#pragma unroll
-                for (int s = 0; s < KSEL; ++s) {
-                    const float hi = fmaxf(top[s], v);
-                    v = fminf(top[s], v);
-                    top[s] = hi;
-                }
-            }
+            const float v = neg_sq_dist(sqi, xi, yi, zi, q.x, q.y, q.z, q.w);
+            if (v > top[KSEL - 1]) topk_insert<KSEL>(top, v);
         }
     }
     const float kth = top[KSEL - 1];
-
-    // ---- pass 2: emit {j : a_ij >= kth} ascending ----
     int count = 0;
     int32_t* my = idx + ((size_t)cloud * n + (valid ? i : 0)) * cap;
     for (int t0 = 0; t0 < n; t0 += KNN_TILE) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < KNN_TILE; c += KNN_THREADS) {
-            const int j = t0 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);
-            if (j < n) {
-                v.x = pc[3 * j + 0];
-                v.y = pc[3 * j + 1];
-                v.z = pc[3 * j + 2];
-                v.w = sq3(v.x, v.y, v.z);
-            }
-            tile[c] = v;
-        }
-        __syncthreads();
+        load_tile(t0);
         const int lim = min(KNN_TILE, n - t0);
 #pragma unroll 4
         for (int c = 0; c < lim; ++c) {
@@ -117,12 +333,26 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
 extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt,
                             float* kth, void* stream) {
     EPC_CHECK_ARG(xyz && idx && cnt && kth, "null pointer");
-    EPC_CHECK_ARG(num_clouds >= 0 && n >= EPC_KNN_SELECT, "need num_points >= 20 (tf.nn.top_k k=20)");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT,
+                  "need num_points >= 20 (tf.nn.top_k k=20)");
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
-    hipLaunchKernelGGL(knn_topk_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream, xyz, n,
-                       cap, idx, cnt, kth);
+    if (n <= KNN_LDS_MAX_N) {
+        const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 1) * sizeof(float4);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            epc_set_error("epc_knn_topk: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return EPC_EHIP;
+        }
+        hipLaunchKernelGGL(knn_topk_culled_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), lds_bytes,
+                           (hipStream_t)stream, xyz, n, cap, idx, cnt, kth);
+    } else {
+        hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
+                           xyz, n, cap, idx, cnt, kth);
+    }
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -130,7 +360,7 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
 extern "C" int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask,
                             void* stream) {
     EPC_CHECK_ARG(xyz && kth && mask, "null pointer");
-    EPC_CHECK_ARG(num_clouds >= 0 && n > 0 && n <= 65535, "bad shape");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n > 0 && n <= 65535, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     dim3 grid((n + 255) / 256, n, num_clouds);
     hipLaunchKernelGGL(knn_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, kth, n, mask);

@@ -14,7 +14,7 @@ static int micro_batch(const epc_cfg* c, int num_clouds) {
 }
 
 struct WsLayout {
-    size_t idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, vpart, apart, head, pooled, total;
+    size_t sorted, idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, vpart, apart, head, pooled, total;
 };
 
 static WsLayout ws_layout(const epc_cfg* c, int mb) {
@@ -26,6 +26,7 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
         o += al(bytes);
         return at;
     };
+    w.sorted = take(M * 3 * 4);
     w.idx = take(M * EPC_KNN_CAP * 4);
     w.cnt = take(M * 4);
     w.kth = take(M * 4);
@@ -156,6 +157,12 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
         const int nc = (num_clouds - c0) < mb ? (num_clouds - c0) : mb;
         const float* pc = xyz + (size_t)c0 * n * 3;
         float* o = out + (size_t)c0 * cfg->output_dim;
+        TRY(mark(prof, EPC_STAGE_SORT, stream));
+        if (n <= 16384) {  // descriptors are permutation-invariant: run the whole pipeline on the Z-ordered cloud
+            float* sorted = (float*)(ws + w.sorted);
+            TRY(epc_morton_sort(pc, nc, n, sorted, nullptr, stream));
+            pc = sorted;
+        }
         TRY(mark(prof, EPC_STAGE_KNN, stream));
         TRY(epc_knn_topk(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, stream));
         TRY(mark(prof, EPC_STAGE_CONV1, stream));

@@ -1,0 +1,125 @@
+// Per-cloud Morton (Z-order) sort of the points -- a pure re-ordering stage in front of the pipeline.
+//
+// Why it is legal: every stage of EPC-Net / EPC-Net-L is equivariant to a permutation of the points and the final
+// pooling (VLAD sums, EPC-Net-L max) is invariant, so descriptors of the sorted cloud equal those of the original
+// up to fp32 summation order (tests/test_gpu_parity.py::test_permutation_invariance).  Why it pays: consecutive
+// points become spatial neighbours, so (i) the kNN kernel's tile bounding boxes are tight and most candidate
+// tiles are culled, (ii) the ProxyConv gathers hit rows that sit close together in L2/L1.
+//
+// One workgroup (1024 threads) per cloud: cloud bounding box -> 10 bits per axis -> 30-bit Morton code; 64-bit keys
+// (code << 32 | original index: a total order, so the result is deterministic) are bitonic-sorted in LDS.
+#include "common.h"
+
+#define SORT_THREADS 1024
+#define SORT_MAX_N 16384  // 128 KB of 8-byte keys
+
+__device__ __forceinline__ unsigned int spread10(unsigned int v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void morton_sort_kernel(const float* __restrict__ xyz, int n, int npow2,
+                                                                   float* __restrict__ xyz_sorted,
+                                                                   int32_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    __shared__ float red[6][SORT_THREADS / 64];
+    __shared__ float box[6];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pc = xyz + (size_t)cloud * n * 3;
+
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = tid; j < n; j += SORT_THREADS)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = pc[3 * j + d];
+            lo[d] = fminf(lo[d], v);
+            hi[d] = fmaxf(hi[d], v);
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off));
+        }
+        if (lane == 0) {
+            red[d][wave] = lo[d];
+            red[3 + d][wave] = hi[d];
+        }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        float v = red[tid][0];
+        for (int w = 1; w < SORT_THREADS / 64; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        box[tid] = v;
+    }
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float ext = box[3 + d] - box[d];
+        scale[d] = ext > 0.f ? 1023.0f / ext : 0.f;
+    }
+    for (int j = tid; j < npow2; j += SORT_THREADS) {
+        unsigned long long key = ~0ull;
+        if (j < n) {
+            unsigned int code = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float q = (pc[3 * j + d] - box[d]) * scale[d];
+                const unsigned int qi = (unsigned int)fminf(fmaxf(q, 0.f), 1023.f);
+                code |= spread10(qi) << d;
+            }
+            key = ((unsigned long long)code << 32) | (unsigned int)j;
+        }
+        keys[j] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            for (int t = tid; t < npow2 / 2; t += SORT_THREADS) {
+                const int i0 = ((t / s) * 2 * s) + (t % s);
+                const int i1 = i0 + s;
+                const bool up = ((i0 & k) == 0);
+                const unsigned long long a = keys[i0], b = keys[i1];
+                if ((a > b) == up) {
+                    keys[i0] = b;
+                    keys[i1] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < n; r += SORT_THREADS) {
+        const int src = (int)(keys[r] & 0xffffffffu);
+        float* o = xyz_sorted + ((size_t)cloud * n + r) * 3;
+        o[0] = pc[3 * src + 0];
+        o[1] = pc[3 * src + 1];
+        o[2] = pc[3 * src + 2];
+        if (perm) perm[(size_t)cloud * n + r] = src;
+    }
+}
+
+extern "C" int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm,
+                               void* stream) {
+    EPC_CHECK_ARG(xyz && xyz_sorted, "null pointer");
+    EPC_CHECK_ARG(num_clouds >= 0 && n > 0 && n <= SORT_MAX_N, "num_points must be in 1..16384");
+    EPC_CHECK_ARG(xyz != xyz_sorted, "in-place sort is not supported");
+    if (num_clouds == 0) return EPC_OK;
+    int npow2 = 2;
+    while (npow2 < n) npow2 <<= 1;
+    const size_t lds_bytes = (size_t)npow2 * sizeof(unsigned long long);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(morton_sort_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        epc_set_error("epc_morton_sort: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(morton_sort_kernel, dim3(num_clouds), dim3(SORT_THREADS), lds_bytes, (hipStream_t)stream, xyz,
+                       n, npow2, xyz_sorted, perm);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -31,9 +31,10 @@ EXPORTS = [
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
+    "epc_morton_sort",
 ]
-EPC_NUM_STAGES = 9
-STAGE_NAMES = ["knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
+EPC_NUM_STAGES = 10
+STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
 
 
 class EpcNetError(RuntimeError):
@@ -81,6 +82,7 @@ _lib.epc_vlad_head_fwd.argtypes = [_P, _P, c_int, _P, c_int, c_int, _P, _P, c_si
 _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
 _lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
+_lib.epc_morton_sort.argtypes = [_P, c_int, c_int, _P, _P, _P]
 _lib.epc_profile_create.argtypes = [POINTER(_P)]
 _lib.epc_profile_destroy.argtypes = [_P]
 _lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]

@@ -80,13 +80,14 @@ int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, in
  * (measurement only; SURVEY.md 5 "tracing": the reference wraps sess.run in RunOptions(FULL_TRACE),
  * evaluate.py:275,385-390).  One profile covers one pass (num_clouds <= micro_batch).  Read the per-stage
  * milliseconds with epc_profile_elapsed_ms after the stream has been synchronised. */
-#define EPC_STAGE_KNN 0
-#define EPC_STAGE_CONV1 1
-#define EPC_STAGE_BLOCK1 2 /* .. EPC_STAGE_BLOCK1+3 */
-#define EPC_STAGE_CONV5 6  /* conv5 + L2 + assignment (EPC-Net) / conv5 + max-pool (EPC-Net-L) */
-#define EPC_STAGE_AGGREGATE 7
-#define EPC_STAGE_HEAD 8
-#define EPC_NUM_STAGES 9
+#define EPC_STAGE_SORT 0
+#define EPC_STAGE_KNN 1
+#define EPC_STAGE_CONV1 2
+#define EPC_STAGE_BLOCK1 3 /* .. EPC_STAGE_BLOCK1+3 */
+#define EPC_STAGE_CONV5 7  /* conv5 + L2 + assignment (EPC-Net) / conv5 + max-pool (EPC-Net-L) */
+#define EPC_STAGE_AGGREGATE 8
+#define EPC_STAGE_HEAD 9
+#define EPC_NUM_STAGES 10
 typedef struct epc_profile epc_profile;
 int epc_profile_create(epc_profile** prof);
 int epc_profile_destroy(epc_profile* prof);
@@ -97,6 +98,11 @@ int epc_profile_elapsed_ms(epc_profile* prof, float* stage_ms /* host, EPC_NUM_S
 /* ------------------------------------------------------------------------------------------------------ */
 /* Stage entry points (what epc_net_forward chains; exported for parity tests and for op-level callers).    */
 /* ------------------------------------------------------------------------------------------------------ */
+
+/* Morton (Z-order) sort of each cloud's points: xyz (num_clouds,N,3) -> xyz_sorted, optional perm (num_clouds,N)
+ * with xyz_sorted[r] = xyz[perm[r]].  No reference counterpart: descriptors are permutation-invariant, the
+ * pipeline sorts first so that kNN tiles are spatially tight and gathers are cache-local.  N <= 16384. */
+int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm, void* stream);
 
 /* utils/tf_util.py:647-666 pairwise_distance_mask, in index form.  For every point i of every cloud:
  *   kth[i]  = 20th largest a_ij (with multiplicity), a_ij = -((|p_i|^2 + -2 p_i.p_j) + |p_j|^2) in fp32,

@@ -39,6 +39,63 @@ def test_knn_bit_exact(dev, kind, n, seed):
             assert np.array_equal(idx[b, i, :m], ref[:m])
 
 
+def _morton_sort(pc, dev):
+    L = H.pkg("lib")
+    t = torch.from_numpy(pc).to(dev)
+    out = torch.empty_like(t)
+    perm = torch.empty(pc.shape[:2], dtype=torch.int32, device=dev)
+    L.check(L.lib().epc_morton_sort(t.data_ptr(), pc.shape[0], pc.shape[1], out.data_ptr(), perm.data_ptr(),
+                                    L.current_stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), perm.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 4096), ("lidar", 4096), ("uniform", 100), ("zeros", 64), ("dup", 256)])
+def test_morton_sort_is_a_z_order_permutation(dev, kind, n):
+    pc = O.synthetic_clouds(2, n, 3, kind)
+    srt, perm = _morton_sort(pc, dev)
+    for b in range(2):
+        assert np.array_equal(np.sort(perm[b]), np.arange(n))
+        assert np.array_equal(srt[b], pc[b][perm[b]])
+        lo, hi = pc[b].min(0), pc[b].max(0)
+        ext = hi - lo
+        scale = np.where(ext > 0, np.float32(1023.0) / np.where(ext > 0, ext, 1), 0).astype(np.float32)
+        q = np.clip(((srt[b] - lo) * scale), 0, 1023).astype(np.uint32)
+        code = np.zeros(n, dtype=np.uint64)
+        for bit in range(10):
+            for d in range(3):
+                code |= ((q[:, d] >> bit) & 1).astype(np.uint64) << np.uint64(3 * bit + d)
+        key = (code << np.uint64(32)) | perm[b].astype(np.uint64)
+        assert np.all(np.diff(key.astype(np.int64)) > 0)
+
+
+@pytest.mark.parametrize("kind,n,seed", [("uniform", 4096, 0), ("lidar", 4096, 1), ("uniform", 1024, 2),
+                                         ("lattice", 4096, 0), ("dup", 2048, 0), ("uniform", 8192, 4)])
+def test_knn_bit_exact_on_sorted_clouds(dev, kind, n, seed):
+    """Same bit-exact bar on Z-ordered clouds, where the bounding-box culling actually skips tiles."""
+    tf_util = H.pkg("utils.tf_util")
+    pc, _ = _morton_sort(O.synthetic_clouds(1, n, seed, kind), dev)
+    kth_ref, lists = O.knn_lists(pc)
+    kth, idx, cnt = tf_util.knn_index(torch.from_numpy(pc).to(dev))
+    kth, idx, cnt = kth.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    assert np.array_equal(kth, kth_ref)
+    for i in range(n):
+        ref = lists[0][i]
+        assert cnt[0, i] == len(ref)
+        m = min(len(ref), idx.shape[-1])
+        assert np.array_equal(idx[0, i, :m], ref[:m])
+
+
+def test_knn_streaming_kernel_large_n(dev):
+    """N > 8192 takes the streaming (un-culled) kernel."""
+    tf_util = H.pkg("utils.tf_util")
+    pc = O.synthetic_clouds(1, 8224, 5)
+    kth_ref, lists = O.knn_lists(pc)
+    kth, idx, cnt = tf_util.knn_index(torch.from_numpy(pc).to(dev))
+    assert np.array_equal(kth.cpu().numpy(), kth_ref)
+    assert np.array_equal(cnt.cpu().numpy()[0], np.array([len(l) for l in lists[0]]))
+
+
 @pytest.mark.parametrize("kind,n", [("uniform", 256), ("lattice", 512), ("zeros", 64)])
 def test_knn_mask_matches_reference_form(dev, kind, n):
     """pairwise_distance_mask returns the dense 0/1 mask the reference builds (utils/tf_util.py:647-666)."""
