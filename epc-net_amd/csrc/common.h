@@ -7,6 +7,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Row of a 32x32 MFMA C/D tile held by register r of lane-half h (column = lane & 31).
 __host__ __device__ __forceinline__ constexpr int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -29,6 +31,33 @@ __device__ __forceinline__ float neg_sq_dist(float sqi, float xi, float yi, floa
     float inner = (xi * xj + yi * yj) + zi * zj;
     float t = -2.0f * inner;
     return -((sqi + t) + sqj);
+}
+
+// D = A(32x16) * B(16x32) + C on bf16 inputs, f32 accumulate (v_mfma_f32_32x32x16_bf16, 32 cycles/SIMD: 16x the f32
+// MFMA rate).  lane l supplies A[i = l & 31][k = 8*(l>>5) + j] and B[k = 8*(l>>5) + j][n = l & 31], j = 0..7.
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Split-bf16 ("bf16x3") arithmetic: x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi);
+// a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, accumulated in f32 by the MFMA.  Measured on the whole network this
+// keeps the descriptor within 4e-7 of the f32 oracle (plain bf16: 1.7e-4, over the 1e-4 budget) -- DESIGN.md 4.
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+}
+__host__ __device__ __forceinline__ unsigned short bf16_bits_rne(float f) {
+    union { float f; unsigned int u; } c;
+    c.f = f;
+    return (unsigned short)((c.u + 0x7fffu + ((c.u >> 16) & 1u)) >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
+    union { float f; unsigned int u; } c;
+    c.u = (unsigned int)b << 16;
+    return c.f;
 }
 
 void epc_set_error(const char* fmt, ...);
@@ -65,6 +94,11 @@ __host__ __device__ __forceinline__ constexpr size_t layer_pack_floats(int cin, 
     return (size_t)cin * cout + cout;
 }
 
+// conv5 / cluster_weights are consumed by the bf16 MFMA as split hi/lo fragments (same byte count as f32):
+//   W5p[chunk c][k-step s][part p (0 hi, 1 lo)][lane][8 bf16], value = part(W5f[16s + 8(lane>>5) + j][32c + (lane&31)])
+//   Wcp[chunk c][s' (2)][tile t (2)][part p][lane][8 bf16],
+//        value = part(Wc[32c + 16s' + 8(j>>2) + 4(lane>>5) + (j&3)][32t + (lane&31)])
+//        (the k order of an accumulator tile used as B operand: element j of lane-half h is row 16s'+8(j>>2)+4h+(j&3))
 // Block pack: [conv_a SPLIT 64x64][conv_b ACC 64x64][conv_next SPLIT 64x64 (zeros when absent)]
 #define EPC_BLOCK_PACK_FLOATS (3 * (64 * 64 + 64))
 // conv1 pack: Wf[3][64] + bf[64]

@@ -1,17 +1,22 @@
-// conv5 (+BN+ReLU) fused with what consumes it.
+// conv5 (+BN+ReLU) fused with what consumes it, on the bf16 MFMA in split ("bf16x3") arithmetic.
+//
+// Arithmetic: every f32 operand x is carried as hi = bf16(x), lo = bf16(x - hi); a product a*b is evaluated as
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with f32 accumulation inside v_mfma_f32_32x32x16_bf16.  Three bf16 MFMAs replace
+// eight f32 MFMAs (32x32x2) per 16-deep k-step: 5.3x fewer matrix-pipe cycles, at f32-level accuracy (descriptor
+// error vs the f32 oracle 4e-7; the 1e-4 budget of BASELINE.json is not reachable with plain bf16: 1.7e-4).
 //
 // MODE_VLAD  (EPC-Net: models/epc-net.py:136-139,147-148 + loupe.py:249-272)
-//   feat^T chunk (32 ch x 32 pts) = W5f^T X^T on the f32 MFMA; epilogue per chunk: ReLU, |feat|^2 partial, store
-//   feat, and P^T (64 clusters x 32 pts) += Wc^T feat^T with the chunk's ACCUMULATORS as the B operand
-//   ((feat*rn) @ Wc == (feat @ Wc) * rn, so the assignment GEMM runs on the un-normalised features while the norm
-//   is still being accumulated).  Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64.
+//   feat^T chunk (32 ch x 32 pts) = W5f^T X^T; epilogue per chunk: ReLU, |feat|^2 partial, store feat (f32), split the
+//   accumulators into hi/lo bf16 and use them directly as the B operand of P^T (64 clusters x 32 pts) += Wc^T feat^T
+//   ((feat*rn) @ Wc == (feat @ Wc) * rn, so the assignment GEMM runs while the norm is still being accumulated).
+//   Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64.
 // MODE_MAX   (EPC-Net-L: models/epc-net-l.py:84-92)
 //   same conv5, epilogue = max over the 32 points of the tile, atomicMax into pooled (values are >= 0 after ReLU,
 //   so the uint ordering equals the float ordering and 0-initialisation is the identity).
 //
-// Geometry: 512 threads = 8 waves, one 32-point tile per wave, the wave's whole input row block (32 pts x CIN)
-// lives in registers as MFMA B operands for all 32 output chunks; W5 (1 MB) streams through a double-buffered
-// LDS chunk shared by the 8 waves (one barrier per chunk).
+// Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x CIN) lives in
+// registers as split B fragments (CIN/2 VGPRs hi + CIN/2 lo) for all 32 output chunks; W5 (hi+lo: 4 B per weight,
+// 1 MB) streams through a double-buffered LDS chunk shared by the 8 waves (one barrier per chunk).
 #include "common.h"
 
 #define C5_THREADS 512
@@ -20,11 +25,14 @@ enum { MODE_VLAD = 0, MODE_MAX = 1 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ bf16x8 ldfrag(const float* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
 
 template <int CIN>
-struct C5Lds {
-    static constexpr int W5_CHUNK = 32 * CIN;  // floats per 32-channel chunk
-    static constexpr int WC_CHUNK = 2048;      // 32 ch x 64 clusters
+struct C5Lds {  // offsets in floats (4 B)
+    static constexpr int W5_CHUNK = 32 * CIN;  // 32 channels x CIN k x (2 B hi + 2 B lo)
+    static constexpr int WC_CHUNK = 2048;      // 32 ch x 64 clusters x 4 B
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
@@ -32,8 +40,8 @@ struct C5Lds {
     static constexpr int TOTAL = OFF_CBN + 128;
 };
 
-// packed conv5 stage (floats): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
-//                              [W5p CIN*1024][b5f 1024]                                     (MAX)
+// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
+//                                    [W5p CIN*1024][b5f 1024]                                     (MAX)
 template <int CIN, int MODE>
 __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restrict__ cat,
                                                            const float* __restrict__ pack, int total_points,
@@ -42,6 +50,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            float* __restrict__ assign,
                                                            float* __restrict__ pooled) {
     using L = C5Lds<CIN>;
+    constexpr int STEPS = CIN / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -64,21 +73,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
 
-    // this lane's B operands: point j, input channels (CIN/2)*h .. +CIN/2
-    float xb[CIN / 2];
-    if (active) {
-        const float* row = cat + (size_t)(g0 + j) * CIN + (CIN / 2) * h;
+    // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7
+    bf16x8 xh[STEPS], xl[STEPS];
+    {
+        const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
 #pragma unroll
-        for (int u = 0; u < CIN / 8; ++u) {
-            const float4 v = ld4(row + 4 * u);
-            xb[4 * u] = v.x;
-            xb[4 * u + 1] = v.y;
-            xb[4 * u + 2] = v.z;
-            xb[4 * u + 3] = v.w;
+        for (int s = 0; s < STEPS; ++s) {
+            float v[8];
+            const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+            split8(v, xh[s], xl[s]);
         }
-    } else {
-#pragma unroll
-        for (int u = 0; u < CIN / 2; ++u) xb[u] = 0.f;
     }
 
     f32x16 P[2];
@@ -109,12 +115,12 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             }
         }
 #pragma unroll
-        for (int e4 = 0; e4 < CIN / 8; ++e4) {
-            const float4 a = ld4(w5 + (e4 * 64 + lane) * 4);
-            acc = mfma32(a.x, xb[4 * e4 + 0], acc);
-            acc = mfma32(a.y, xb[4 * e4 + 1], acc);
-            acc = mfma32(a.z, xb[4 * e4 + 2], acc);
-            acc = mfma32(a.w, xb[4 * e4 + 3], acc);
+        for (int s = 0; s < STEPS; ++s) {
+            const bf16x8 ah = ldfrag(w5 + ((s * 2 + 0) * 64 + lane) * 4);
+            const bf16x8 al = ldfrag(w5 + ((s * 2 + 1) * 64 + lane) * 4);
+            acc = mfma_bf16(al, xh[s], acc);
+            acc = mfma_bf16(ah, xl[s], acc);
+            acc = mfma_bf16(ah, xh[s], acc);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
@@ -128,16 +134,25 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 for (int g = 0; g < 4; ++g)
                     st4(frow + 8 * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
             }
+            // accumulators -> split B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp)
+            bf16x8 fh[2], fl[2];
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
+                split8(v, fh[sp], fl[sp]);
+            }
             const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 a = ld4(wc + ((t * 4 + r4) * 64 + lane) * 4);
-                    P[t] = mfma32(a.x, acc[4 * r4 + 0], P[t]);
-                    P[t] = mfma32(a.y, acc[4 * r4 + 1], P[t]);
-                    P[t] = mfma32(a.z, acc[4 * r4 + 2], P[t]);
-                    P[t] = mfma32(a.w, acc[4 * r4 + 3], P[t]);
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 wh = ldfrag(wc + (((sp * 2 + t) * 2 + 0) * 64 + lane) * 4);
+                    const bf16x8 wl = ldfrag(wc + (((sp * 2 + t) * 2 + 1) * 64 + lane) * 4);
+                    P[t] = mfma_bf16(wl, fh[sp], P[t]);
+                    P[t] = mfma_bf16(wh, fl[sp], P[t]);
+                    P[t] = mfma_bf16(wh, fh[sp], P[t]);
                 }
         } else {
             // max over the tile's 32 points (lanes of one half), then one atomic per channel

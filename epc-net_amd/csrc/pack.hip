@@ -99,15 +99,41 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
     }
 }
 
-// cluster_weights [1024][64] -> [chunk 32][tile 2][r4 4][lane 64][4]: A operand of P^T += Wc^T feat^T where the
-// B operand is conv5's accumulator registers (channel = 32*chunk + mfma_row(r, lane>>5)).
-__global__ void pack_wc_kernel(const float* __restrict__ Wc, float* __restrict__ dst) {
+// conv5 weights for the split-bf16 MFMA (layout: common.h).  One thread per (chunk, k-step, lane, j); writes hi and lo.
+__global__ void fold_pack_conv5_bf16_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            const float* __restrict__ mean, const float* __restrict__ var, int cin,
+                                            unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int steps = cin / 16;
+    if (o < cin * 1024) {
+        const int j = o & 7, lane = (o >> 3) & 63, rest = o >> 9;
+        const int s = rest % steps, c = rest / steps;
+        const int k = 16 * s + 8 * (lane >> 5) + j, col = 32 * c + (lane & 31);
+        const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col);
+        const unsigned short hi = bf16_bits_rne(w);
+        const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
+        dstW[base] = hi;
+        dstW[base + 512] = lo;
+    }
+    if (o < 1024) {
+        const float inv = bn_inv(gamma, var, o);
+        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+    }
+}
+
+__global__ void pack_wc_bf16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= 1024 * 64) return;
-    const int chunk = o / 2048, rem = o % 2048;
-    const int t = rem / 1024, r4 = (rem % 1024) / 256, lane = (rem % 256) / 4, q = rem % 4;
-    const int ch = 32 * chunk + mfma_row(4 * r4 + q, lane >> 5);
-    dst[o] = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
+    const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
+    const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
+    const unsigned short hi = bf16_bits_rne(w);
+    const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+    const size_t base = ((size_t)((c * 2 + sp) * 2 + t) * 2) * 512 + lane * 8 + j;
+    dst[base] = hi;
+    dst[base + 512] = lo;
 }
 
 __global__ void bn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -232,7 +258,9 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
 
     PACK_TRY(get_conv(T, "fastdgcnn/conv5", &v));
     const int c5in = 64 * nblocks;
-    PACK_TRY(launch_layer(v, c5in, 1024, PACK_SPLIT, P + L.off[5], st));
+    hipLaunchKernelGGL(fold_pack_conv5_bf16_kernel, dim3(c5in * 1024 / 256), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta,
+                       v.mean, v.var, c5in, (unsigned short*)(P + L.off[5]), P + L.off[5] + (size_t)c5in * 1024);
+    EPC_CHECK_LAUNCH();
 
     if (cfg->arch == EPC_ARCH_EPC_NET) {
         float* s5 = P + L.off[5] + (size_t)c5in * 1024 + 1024;
@@ -244,7 +272,7 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
             epc_set_error("epc_net_pack_weights: VLAD weight matrices are incomplete");
             return EPC_ENOTFOUND;
         }
-        hipLaunchKernelGGL(pack_wc_kernel, dim3(256), dim3(256), 0, st, Wc, s5);
+        hipLaunchKernelGGL(pack_wc_bf16_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5);
         EPC_CHECK_LAUNCH();
         const float *g, *b, *m, *vv;
         PACK_TRY(get_slim_bn(T, "VLAD/cluster_bn", &g, &b, &m, &vv));
