@@ -17,6 +17,7 @@
 // Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x CIN) lives in
 // registers as split B fragments (CIN/2 VGPRs hi + CIN/2 lo) for all 32 output chunks; W5 (hi+lo: 4 B per weight,
 // 1 MB) streams through a double-buffered LDS chunk shared by the 8 waves (one barrier per chunk).
+#include <type_traits>
 #include "common.h"
 
 #define C5_THREADS 512
@@ -27,6 +28,17 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ bf16x8 ldfrag(const float* p) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+// 16 bytes per lane, global -> LDS without a VGPR destination (LDS-DMA): lane l reads uniform_base + lane_byte_off and lands at LDS byte
+// address lds_dst + 16*l (uniform_base and lds_dst wave-uniform, in SGPRs).  Written as inline asm on purpose: with the builtin hipcc (ROCm 7.2) drains
+// vmcnt(0) before the next ds_read of the same __shared__ array, which would serialise the prefetch; the asm form is
+// invisible to its wait bookkeeping, so completion is tracked by the hand-placed counted s_waitcnt in the chunk loop.
+__device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst)
+                 : "memory");
 }
 
 template <int CIN>
@@ -59,14 +71,28 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     const float* gwc = gb5 + 1024;
     const float* gcbn = gwc + 1024 * 64;
 
-    constexpr int W5_LD = L::W5_CHUNK / (C5_THREADS * 4);  // float4 per thread per chunk
-    float4 pre5[W5_LD];
-    float4 prec;
-
-    // chunk 0 + constants
+    // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction writes 1 KB at a
+    // wave-uniform LDS base + lane*16, which is exactly the packed fragment order), so no VGPRs are spent on staging
+    // and the loads of chunk c+1 stay in flight under chunk c's MFMAs.  Completion is a counted vmcnt (the chunk's
+    // 4 feat stores are younger and may stay in flight) followed by a raw s_barrier.
+    constexpr int W5_PIECES = L::W5_CHUNK / (C5_WAVES * 256);  // 1-KB pieces per wave per chunk (256 floats each)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
+    const unsigned lane_off = lane * 16;
+    auto stage_chunk = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-    for (int u = 0; u < W5_LD; ++u) st4(lds + L::OFF_W5 + (u * C5_THREADS + tid) * 4, ld4(gw5 + (u * C5_THREADS + tid) * 4));
-    if (MODE == MODE_VLAD) st4(lds + L::OFF_WC + tid * 4, ld4(gwc + tid * 4));
+        for (int u = 0; u < W5_PIECES; ++u) {
+            const int piece = u * C5_WAVES + wave_u;
+            glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
+                   lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
+        }
+        if (MODE == MODE_VLAD)
+            glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
+                   lds_base + 4u * (L::OFF_WC + buf * L::WC_CHUNK + wave_u * 256));
+    };
+
+    stage_chunk(0, std::integral_constant<int, 0>{});
     for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_B5 + o] = gb5[o];
     if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
 
@@ -91,16 +117,16 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) P[0][r] = P[1][r] = 0.f;
     float ss = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int c = 0; c < 32; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < 32) {  // prefetch the next chunk into registers
-#pragma unroll
-            for (int u = 0; u < W5_LD; ++u)
-                pre5[u] = ld4(gw5 + (size_t)(c + 1) * L::W5_CHUNK + (u * C5_THREADS + tid) * 4);
-            if (MODE == MODE_VLAD) prec = ld4(gwc + (size_t)(c + 1) * L::WC_CHUNK + tid * 4);
-        }
+    // one chunk; the LDS buffer index is a compile-time constant so that the compiler can see that the DMA destination
+    // (the other buffer) never aliases the fragments being read (otherwise it drains vmcnt before every ds_read)
+    auto do_chunk = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#ifndef C5_ABL_NODMA
+        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+#endif
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
         f32x16 acc;
         {
@@ -114,47 +140,71 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 acc[4 * g + 3] = bv.w;
             }
         }
+        {
+            // fragment reads run one k-step ahead of the MFMAs that consume them
+            bf16x8 fa[2][2];
+            fa[0][0] = ldfrag(w5 + (0 * 64 + lane) * 4);
+            fa[0][1] = ldfrag(w5 + (1 * 64 + lane) * 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const bf16x8 ah = ldfrag(w5 + ((s * 2 + 0) * 64 + lane) * 4);
-            const bf16x8 al = ldfrag(w5 + ((s * 2 + 1) * 64 + lane) * 4);
-            acc = mfma_bf16(al, xh[s], acc);
-            acc = mfma_bf16(ah, xl[s], acc);
-            acc = mfma_bf16(ah, xh[s], acc);
+            for (int s = 0; s < STEPS; ++s) {
+                if (s + 1 < STEPS) {
+                    fa[(s + 1) & 1][0] = ldfrag(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
+                    fa[(s + 1) & 1][1] = ldfrag(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
+                acc = mfma_bf16(fa[s & 1][1], xh[s], acc);
+                acc = mfma_bf16(fa[s & 1][0], xl[s], acc);
+                acc = mfma_bf16(fa[s & 1][0], xh[s], acc);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
-
-        if (MODE == MODE_VLAD) {
+#ifdef C5_ABL_NOEPI
+        constexpr bool kEpi = false;
+        asm volatile("" :: "v"(acc));
+#else
+        constexpr bool kEpi = true;
+#endif
+        if (kEpi && MODE == MODE_VLAD) {
+            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
+            auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
+            // cluster-weight fragments of k-step 0: issued now, they land under the VALU work below
+            bf16x8 wf[2][2];
+            wf[0][0] = wfrag(0, 0, 0), wf[0][1] = wfrag(0, 0, 1), wf[1][0] = wfrag(0, 1, 0), wf[1][1] = wfrag(0, 1, 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
+#ifndef C5_ABL_NOSTORE
             if (active) {
                 float* frow = feat + (size_t)(g0 + j) * 1024 + 32 * c + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     st4(frow + 8 * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
             }
+#endif
             // accumulators -> split B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp)
-            bf16x8 fh[2], fl[2];
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
-                split8(v, fh[sp], fl[sp]);
-            }
-            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
+                bf16x8 fh, fl;
+                split8(v, fh, fl);
+                bf16x8 wn[2][2];
+                if (sp == 0) wn[0][0] = wfrag(1, 0, 0), wn[0][1] = wfrag(1, 0, 1), wn[1][0] = wfrag(1, 1, 0), wn[1][1] = wfrag(1, 1, 1);
+#ifndef C5_ABL_NOASSIGN
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const bf16x8 wh = ldfrag(wc + (((sp * 2 + t) * 2 + 0) * 64 + lane) * 4);
-                    const bf16x8 wl = ldfrag(wc + (((sp * 2 + t) * 2 + 1) * 64 + lane) * 4);
-                    P[t] = mfma_bf16(wl, fh[sp], P[t]);
-                    P[t] = mfma_bf16(wh, fl[sp], P[t]);
-                    P[t] = mfma_bf16(wh, fh[sp], P[t]);
+                    P[t] = mfma_bf16(wf[t][1], fh, P[t]);
+                    P[t] = mfma_bf16(wf[t][0], fl, P[t]);
+                    P[t] = mfma_bf16(wf[t][0], fh, P[t]);
                 }
-        } else {
+#else
+                asm volatile("" :: "v"(fh), "v"(fl), "v"(wf[0][0]), "v"(wf[0][1]), "v"(wf[1][0]), "v"(wf[1][1]));
+#endif
+                if (sp == 0) wf[0][0] = wn[0][0], wf[0][1] = wn[0][1], wf[1][0] = wn[1][0], wf[1][1] = wn[1][1];
+            }
+        } else if (kEpi) {
             // max over the tile's 32 points (lanes of one half), then one atomic per channel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -170,13 +220,25 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             }
         }
 
-        if (c + 1 < 32) {
-#pragma unroll
-            for (int u = 0; u < W5_LD; ++u)
-                st4(lds + L::OFF_W5 + (buf ^ 1) * L::W5_CHUNK + (u * C5_THREADS + tid) * 4, pre5[u]);
-            if (MODE == MODE_VLAD) st4(lds + L::OFF_WC + (buf ^ 1) * L::WC_CHUNK + tid * 4, prec);
-        }
-        __syncthreads();
+        // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 4 feat
+        // stores issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of
+        // the grid) and the atomic-max variant drain everything.
+#ifdef C5_ABL_NOSTORE
+        if (false)
+#else
+        if (MODE == MODE_VLAD && active)
+#endif
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef C5_ABL_NOBARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+    };
+    for (int c = 0; c < 32; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{});
+        do_chunk(c + 1, std::integral_constant<int, 1>{});
     }
 
     if (MODE == MODE_VLAD && active) {

@@ -15,7 +15,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libepcnet_hip.so")
+# EPCNET_LIB: tuning-only override (scripts/tune_*.sh build throw-away variants of the same library)
+LIB_PATH = os.environ.get("EPCNET_LIB") or os.path.join(_HERE, "libepcnet_hip.so")
 
 EPC_OK = 0
 EPC_ARCH_EPC_NET = 0
