@@ -331,9 +331,12 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 // VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * (assign[n][k] * rnorm[n]) per cloud, as an MFMA
 // GEMM with the point index as K.  Both operands are read with 128-B coalesced dword loads straight into
 // registers (A: 32 consecutive f of row n, B: 32 consecutive clusters of row n); no LDS.
-// One wave = 128 features x 64 clusters (8 accumulator tiles) over a `splits`-th of the cloud's points.
+// One wave = 32*AGG_FT features x 64 clusters over a `splits`-th of the cloud's points.
 // ---------------------------------------------------------------------------------------------------------------
 #define AGG_THREADS 256
+#ifndef AGG_FT
+#define AGG_FT 2  // 32-feature tiles per wave: 2 -> 64 accumulator registers, 4-5 waves/SIMD hide the load latency
+#endif
 
 __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat,
                                                                      const float* __restrict__ rnorm,
@@ -342,24 +345,24 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
                                                                      float* __restrict__ apart) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int fg = blockIdx.x * 4 + wave;  // 128-feature group, 0..7
+    const int fg = blockIdx.x * 4 + wave;  // feature group of 32*AGG_FT features
     const int sp = blockIdx.y;
     const int cloud = blockIdx.z;
     const int per = n / splits;
     const size_t pt0 = (size_t)cloud * n + (size_t)sp * per;
-    const float* fbase = feat + pt0 * 1024 + fg * 128 + j;
+    const float* fbase = feat + pt0 * 1024 + fg * (32 * AGG_FT) + j;
     const float* abase = assign + pt0 * 64 + j;
     const float* rbase = rnorm + pt0;
 
-    f32x16 acc[4][2];
+    f32x16 acc[AGG_FT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < AGG_FT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
     float as0 = 0.f, as1 = 0.f;
 
     for (int nn = 0; nn < per; nn += 8) {
-        float a[4][4], b0[4], b1[4];
+        float a[4][AGG_FT], b0[4], b1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pt = nn + 2 * u + h;
@@ -371,22 +374,22 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
             b0[u] = v0 * r;
             b1[u] = v1 * r;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a[u][t] = fbase[(size_t)pt * 1024 + 32 * t];
+            for (int t = 0; t < AGG_FT; ++t) a[u][t] = fbase[(size_t)pt * 1024 + 32 * t];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < AGG_FT; ++t) {
                 acc[t][0] = mfma32(a[u][t], b0[u], acc[t][0]);
                 acc[t][1] = mfma32(a[u][t], b1[u], acc[t][1]);
             }
     }
     float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < AGG_FT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = fg * 128 + 32 * t + mfma_row(r, h);
+            const int f = fg * (32 * AGG_FT) + 32 * t + mfma_row(r, h);
             vout[(size_t)f * 64 + j] = acc[t][0][r];
             vout[(size_t)f * 64 + 32 + j] = acc[t][1][r];
         }
@@ -407,7 +410,7 @@ extern "C" int epc_vlad_aggregate_fwd(const float* feat, const float* rnorm, con
     EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (8 * splits) == 0, "num_points must be a multiple of 8*splits");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && splits <= 65535, "bad shape");
     if (num_clouds == 0) return EPC_OK;
-    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(2, splits, num_clouds), dim3(AGG_THREADS), 0,
+    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(8 / AGG_FT, splits, num_clouds), dim3(AGG_THREADS), 0,
                        (hipStream_t)stream, feat, rnorm, assign, n, splits, vpart, apart);
     EPC_CHECK_LAUNCH();
     return EPC_OK;

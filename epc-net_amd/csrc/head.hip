@@ -6,41 +6,48 @@
 // packed head stage (floats): [C 1024*64][H KH*256][bn_s 256][bn_t 256][Wg 256*256][gbn_s 256][gbn_t 256]
 // with KH = 65536 / groups.
 
-// ---- H1: centre subtraction, intra-norm over the 1024 features of each cluster, global norm, group fold ------
-// One 1024-thread workgroup per cloud; thread (k = tid&63, fgp = tid>>6) owns V[fgp + 16 m][k], m < 64.
-// In inference the grouped projection sum_g BN(v_g W) equals s * ((sum_g v_g) W) + G t (one shared W, affine BN),
-// so the G group slices are folded before the GEMM: U[fi*64 + k] = sum_g Vn[g*FPG + fi][k].
-template <int GROUPS>
-__global__ __launch_bounds__(1024) void vlad_finish_kernel(const float* __restrict__ vpart,
-                                                           const float* __restrict__ apart, int splits,
-                                                           const float* __restrict__ centres,
-                                                           float* __restrict__ U) {
-    constexpr int groups = GROUPS;
-    __shared__ float red[16][64];
-    __shared__ float cn[64];
-    __shared__ float gsum[64];
-    const int cloud = blockIdx.x;
-    const int k = threadIdx.x & 63, fgp = threadIdx.x >> 6;
+// ---- H1a: V = sum of the aggregate's partial slabs - a_sum * centres; per-cluster sum of squares (partial) ----------
+// grid (16 row slabs, clouds) x 256 threads: thread (k = tid & 63, r = tid >> 6) owns rows 64*slab + r + 4m, m < 16.
+__global__ __launch_bounds__(256) void vlad_reduce_kernel(const float* __restrict__ vpart,
+                                                          const float* __restrict__ apart, int splits,
+                                                          const float* __restrict__ centres,
+                                                          float* __restrict__ V, float* __restrict__ colss) {
+    __shared__ float red[4][64];
+    const int slab = blockIdx.x, cloud = blockIdx.y;
+    const int k = threadIdx.x & 63, r = threadIdx.x >> 6;
     float asum = 0.f;
     for (int s = 0; s < splits; ++s) asum += apart[((size_t)cloud * splits + s) * 64 + k];
-    // V[f][k] is recomputed in the second sweep (L2-resident re-read) instead of holding 64 values per thread
-    auto vval = [&](int f) {
+    float ss = 0.f;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+        const int f = 64 * slab + r + 4 * m;
         float acc = 0.f;
         for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
-        return acc - asum * centres[f * 64 + k];
-    };
-    float ss = 0.f;
-#pragma unroll 8
-    for (int m = 0; m < 64; ++m) {
-        const float a = vval(fgp + 16 * m);
-        ss += a * a;
+        acc -= asum * centres[f * 64 + k];
+        V[((size_t)cloud * 1024 + f) * 64 + k] = acc;
+        ss += acc * acc;
     }
-    red[fgp][k] = ss;
+    red[r][k] = ss;
     __syncthreads();
-    if (fgp == 0) {
+    if (r == 0) colss[((size_t)cloud * 16 + slab) * 64 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+
+// ---- H1b: intra-norm over the 1024 features of each cluster, global norm, group fold ---------------------------
+// In inference the grouped projection sum_g BN(v_g W) equals s * ((sum_g v_g) W) + G t (one shared W, affine BN),
+// so the G group slices are folded before the GEMM: U[fi*64 + k] = sum_g Vn[g*FPG + fi][k].
+// grid (FPG/16 slabs, clouds) x 256 threads: thread (k, r) owns fi = 16*slab + r + 4m, m < 4.
+template <int GROUPS>
+__global__ __launch_bounds__(256) void vlad_fold_kernel(const float* __restrict__ V, const float* __restrict__ colss,
+                                                        float* __restrict__ U) {
+    constexpr int FPG = 1024 / GROUPS;
+    __shared__ float cn[64];
+    __shared__ float gsum[64];
+    const int slab = blockIdx.x, cloud = blockIdx.y;
+    const int k = threadIdx.x & 63, r = threadIdx.x >> 6;
+    if (r == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][k];
+        for (int g = 0; g < 16; ++g) t += colss[((size_t)cloud * 16 + g) * 64 + k];
         const float inv = 1.0f / sqrtf(fmaxf(t, 1e-12f));
         cn[k] = inv;
         gsum[k] = t * inv * inv;  // squared norm of the normalised column (1 unless the column is ~0)
@@ -50,14 +57,15 @@ __global__ __launch_bounds__(1024) void vlad_finish_kernel(const float* __restri
 #pragma unroll
     for (int q = 0; q < 64; ++q) tot += gsum[q];
     const float sc = cn[k] * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
-    constexpr int mpg = 64 / groups;  // m values per group
-    float* uo = U + (size_t)cloud * (65536 / groups);
+    const float* v = V + (size_t)cloud * 1024 * 64;
+    float* uo = U + (size_t)cloud * FPG * 64;
 #pragma unroll
-    for (int mi = 0; mi < mpg; ++mi) {
+    for (int m = 0; m < 4; ++m) {
+        const int fi = 16 * slab + r + 4 * m;
         float u = 0.f;
 #pragma unroll
-        for (int g = 0; g < groups; ++g) u += vval(fgp + 16 * (mi + g * mpg)) * sc;
-        uo[(size_t)(fgp + 16 * mi) * 64 + k] = u;
+        for (int g = 0; g < GROUPS; ++g) u += v[(size_t)(g * FPG + fi) * 64 + k] * sc;
+        uo[(size_t)fi * 64 + k] = u;
     }
 }
 
@@ -162,7 +170,9 @@ extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
     const size_t kh = 65536 / groups;
     const size_t u = align_up((size_t)num_clouds * kh * sizeof(float), 256);
     const size_t yp = align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
-    return u + yp;
+    const size_t v = align_up((size_t)num_clouds * 65536 * sizeof(float), 256);
+    const size_t cs = align_up((size_t)num_clouds * 16 * 64 * sizeof(float), 256);
+    return u + yp + v + cs;
 }
 
 extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, const void* packed_head,
@@ -181,14 +191,23 @@ extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int spl
     const float* centres = hp;
     const float* Hw = hp + 65536;
     const float* tail = Hw + (size_t)kh * 256;
-    float* U = (float*)workspace;
-    float* Yp = (float*)((char*)workspace + align_up((size_t)num_clouds * kh * sizeof(float), 256));
+    char* wsp = (char*)workspace;
+    float* U = (float*)wsp;
+    wsp += align_up((size_t)num_clouds * kh * sizeof(float), 256);
+    float* Yp = (float*)wsp;
+    wsp += align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
+    float* V = (float*)wsp;
+    wsp += align_up((size_t)num_clouds * 65536 * sizeof(float), 256);
+    float* colss = (float*)wsp;
     hipStream_t st = (hipStream_t)stream;
+    EPC_CHECK_ARG(num_clouds <= 65535, "too many clouds per call");
+    hipLaunchKernelGGL(vlad_reduce_kernel, dim3(16, num_clouds), dim3(256), 0, st, vpart, apart, splits, centres, V,
+                       colss);
+    EPC_CHECK_LAUNCH();
     switch (groups) {
-#define EPC_VF(G)                                                                                              \
-    case G:                                                                                                    \
-        hipLaunchKernelGGL(vlad_finish_kernel<G>, dim3(num_clouds), dim3(1024), 0, st, vpart, apart, splits,  \
-                           centres, U);                                                                        \
+#define EPC_VF(G)                                                                                                  \
+    case G:                                                                                                        \
+        hipLaunchKernelGGL(vlad_fold_kernel<G>, dim3(1024 / G / 16, num_clouds), dim3(256), 0, st, V, colss, U);   \
         break;
         EPC_VF(1) EPC_VF(2) EPC_VF(4) EPC_VF(8) EPC_VF(16)
 #undef EPC_VF
