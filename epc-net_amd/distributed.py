@@ -1,0 +1,79 @@
+"""One process per GPU: sharding of descriptor extraction and the one real exchange step of the path.
+
+The reference is single-process / single-GPU; this is new, MI355X-first work:
+
+  * inference BN uses stored statistics, so every cloud's descriptor is independent -> clouds are sharded over the
+    ranks with NO data-path collective during extraction (``shard_bounds``, ``extract_shard``);
+  * retrieval needs every query to see the whole database -> ONE all-gather of the (n_r, 256) f32 descriptor shards
+    (``all_gather_rows``; RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).  An Oxford-scale database
+    is ~10 MB, i.e. latency-bound: a single fused all-gather of equal-sized (padded) shards, not a ring of small sends;
+  * each rank then ranks ITS query shard against the full database locally (``epc_pairwise_topk``) and only the
+    (Q_r, 25) int32 neighbour lists travel back to rank 0 for the recall bookkeeping of evaluate.py:476-530.
+
+``torch.distributed`` is plumbing here (process group, collectives); all arithmetic is in libepcnet_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous, balanced shards: the first (n % world) ranks hold one extra row.  [start, stop)."""
+    q, r = divmod(n, world_size)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def shard_sizes(n: int, world_size: int) -> List[int]:
+    return [shard_bounds(n, r, world_size)[1] - shard_bounds(n, r, world_size)[0] for r in range(world_size)]
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather row shards laid out by ``shard_bounds`` into the full (n_total, ...) tensor on every rank.
+    Shards are padded to the largest shard so that ONE equal-size all-gather moves everything."""
+    rank, ws = world()
+    if ws == 1:
+        assert local.shape[0] == n_total
+        return local
+    sizes = shard_sizes(n_total, ws)
+    assert local.shape[0] == sizes[rank], "local shard has %d rows, expected %d" % (local.shape[0], sizes[rank])
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((ws * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    parts = [out[r * m: r * m + sizes[r]] for r in range(ws)]
+    return torch.cat(parts, dim=0)
+
+
+def extract_shard(extract: Callable[[object], torch.Tensor], clouds) -> Tuple[torch.Tensor, int]:
+    """Run ``extract`` (e.g. ``lambda x: engine.forward(x)``) on this rank's shard of ``clouds`` (n, N, 3)."""
+    rank, ws = world()
+    n = len(clouds)
+    a, b = shard_bounds(n, rank, ws)
+    return extract(clouds[a:b]), n
+
+
+def sharded_knn(database_local: torch.Tensor, n_db: int, queries_local: torch.Tensor, n_q: int, k: int,
+                search: Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]
+                ) -> Optional[np.ndarray]:
+    """Database and queries are sharded by rows.  All-gather the database, search this rank's queries locally,
+    gather the (Q_r, k) neighbour indices to rank 0.  Returns the full (n_q, k) int32 array on rank 0, None elsewhere."""
+    rank, ws = world()
+    database = all_gather_rows(database_local, n_db)
+    _, idx = search(database, queries_local, k)
+    idx = idx.to(torch.int32)
+    if ws == 1:
+        return idx.cpu().numpy()
+    full = all_gather_rows(idx, n_q)       # (n_q, k) everywhere; tiny (25 ints per query)
+    return full.cpu().numpy() if rank == 0 else None

@@ -1,0 +1,90 @@
+"""world_size-2 gloo tests (CPU) of the sharding / all-gather / index-gather arithmetic of the multi-GPU path.
+The neighbour search itself is injected (oracle brute force) -- on a GPU box it is epc_pairwise_topk."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as H
+from helpers import O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_search(db, q, k):
+    d, i = O.knn_bruteforce(db.numpy(), q.numpy(), k)
+    return torch.from_numpy(d.astype(np.float32)), torch.from_numpy(i.astype(np.int32))
+
+
+def _worker(rank, ws, port, n_db, n_q, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    D = H.pkg("distributed")
+    rng = np.random.RandomState(0)
+    db = rng.randn(n_db, 256).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = rng.randn(n_q, 256).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    a, b = D.shard_bounds(n_db, rank, ws)
+    qa, qb = D.shard_bounds(n_q, rank, ws)
+    full = D.all_gather_rows(torch.from_numpy(db[a:b]), n_db)
+    assert torch.equal(full, torch.from_numpy(db)), "all-gathered database differs from the unsharded one"
+    idx = D.sharded_knn(torch.from_numpy(db[a:b]), n_db, torch.from_numpy(q[qa:qb]), n_q, 25, _oracle_search)
+    if rank == 0:
+        _, ref = O.knn_bruteforce(db, q, 25)
+        assert np.array_equal(idx, ref)
+        ret.put("ok")
+    else:
+        assert idx is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_db,n_q", [(101, 37), (64, 64), (3, 5)])
+def test_sharded_retrieval_world2_gloo(n_db, n_q):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    n_db_eff = max(n_db, 25)  # k = 25 neighbours need >= 25 database rows
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_db_eff, n_q, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
+def test_shard_bounds_cover_exactly():
+    D = H.pkg("distributed")
+    for n in (0, 1, 7, 64, 1000):
+        for ws in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == D.shard_sizes(n, ws)
+
+
+def test_recall_bookkeeping_matches_oracle():
+    R = H.pkg("retrieval")
+    rng = np.random.RandomState(1)
+    db = rng.randn(250, 256).astype(np.float32); db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[rng.randint(0, 250, 40)] + 0.2 * rng.randn(40, 256).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    truth = [list(rng.choice(250, size=rng.randint(0, 4), replace=False)) for _ in range(40)]
+    _, ind = O.knn_bruteforce(db, q, 25)
+    a = R.recall_from_indices(ind, db, q, truth)
+    b = O.get_recall(db, q, truth)
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.allclose(a[1], b[1])

@@ -202,6 +202,34 @@ def test_pairwise_topk(dev):
     assert np.allclose(dist.cpu().numpy(), dist_ref, atol=1e-5)
 
 
+def test_evaluate_protocol_single_rank(dev):
+    """get_latent_vectors + get_recall/evaluate_runs (evaluate.py:293-332, 351-537) on synthetic runs: GPU neighbour
+    search + host bookkeeping must reproduce the oracle's recall numbers on the same descriptors."""
+    R, D = H.pkg("retrieval"), H.pkg("distributed")
+    w = O.seeded_weights("epc-net-l", 0)
+    eng, _ = H.make_engine("epc-net-l", w, dev)
+    rng = np.random.RandomState(3)
+    runs = [O.synthetic_clouds(40 + 5 * r, 256, 50 + r) for r in range(3)]
+    vecs = [R.get_latent_vectors(eng, c, batch_size=16, device=dev) for c in runs]
+    for v, c in zip(vecs, runs):
+        assert v.shape == (len(c), 256) and np.allclose(np.linalg.norm(v, axis=1), 1, atol=1e-5)
+    truth = {(m, n): [list(rng.choice(len(runs[m]), size=rng.randint(0, 4), replace=False)) for _ in range(len(runs[n]))]
+             for m in range(3) for n in range(3)}
+    res = R.evaluate_runs(vecs, vecs, lambda m, n: truth[(m, n)], device=dev)
+    rec = np.zeros(25); opr = []; sim = []
+    for m in range(3):
+        for n in range(3):
+            if m != n:
+                r_, s_, o_ = O.get_recall(vecs[m], vecs[n], truth[(m, n)])
+                rec += r_; opr.append(o_); sim.extend(s_)
+    assert np.allclose(res["ave_recall"], rec / 6) and np.isclose(res["ave_one_percent_recall"], np.mean(opr))
+    assert np.isclose(res["average_similarity"], np.mean(sim), atol=1e-6)
+    # world_size 1 degenerates cleanly
+    idx = D.sharded_knn(torch.from_numpy(vecs[0]).to(dev), len(vecs[0]), torch.from_numpy(vecs[1]).to(dev),
+                        len(vecs[1]), 25, R.knn_search)
+    assert np.array_equal(idx, O.knn_bruteforce(vecs[0], vecs[1], 25)[1])
+
+
 def test_errors_are_loud(dev):
     L = H.pkg("lib")
     w = O.seeded_weights("epc-net", 0)
