@@ -1,0 +1,490 @@
+// Training-step operators (config c3: train.py:251-277).  The fused inference kernels fold BatchNorm into the weights;
+// training needs batch statistics between layers (utils/tf_util.py:454-491: moments over all B*N rows), so the step is
+// built from per-layer operators, each with its backward twin:
+//
+//   epc_gemm_f32            C = op(A) op(B) (+bias)   exact f32 MFMA; NN (y = x W), NT (dx = dy W^T), TN (dW = x^T dy,
+//                           split-K with f32 atomics), batched (VLAD aggregate fwd/bwd, loupe.py:286-292)
+//   epc_col_moments         per-channel mean / population variance over rows (tf.nn.moments), two-pass, deterministic
+//   epc_bn_apply_fwd/bwd    y = act(gamma (z-mean) rstd + beta) and its backward (dgamma, dbeta, dz)
+//   epc_neighbour_mean_fwd/bwd   xm_i = sum_{j in nbr(i)} x_j / k (models/epc-net.py:70-71) and its transpose
+//   epc_rownorm_fwd/bwd     tf.nn.l2_normalize over the channel axis (models/epc-net.py:148)
+//   epc_softmax64_fwd/bwd   tf.nn.softmax over the 64 clusters (loupe.py:272)
+//   epc_adam_step           tf.train.AdamOptimizer update (train.py:273), one fused pass per tensor
+//
+// Arithmetic is plain f32 throughout (the reference trains in fp32).
+#include "common.h"
+
+// ----------------------------------------------------------------------------------------------------------------
+// GEMM: 64x64 output tile per 256-thread workgroup (4 waves x one 32x32 MFMA tile), K in steps of 32 through LDS.
+// A(m,k) = A[m*sAm + k*sAk], B(k,n) = B[k*sBk + n*sBn]: the four transpose forms are stride choices; tiles are
+// loaded with the contiguous index on the lanes and stored k-major in LDS (+1 pad: conflict-free both ways).
+// ----------------------------------------------------------------------------------------------------------------
+#define G_BM 64
+#define G_BN 64
+#define G_BK 32
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    long sAm, sAk, sBk, sBn;
+    int ldc;
+    long bA, bB, bC;
+    int splitk, accumulate;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[G_BK][G_BM + 1];
+    __shared__ float Bs[G_BK][G_BN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * G_BN, m0 = blockIdx.y * G_BM;
+    const int batch = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
+    const float* A = g.A + (size_t)batch * g.bA;
+    const float* B = g.B + (size_t)batch * g.bB;
+    float* C = g.C + (size_t)batch * g.bC;
+    int kchunk = (g.K + g.splitk - 1) / g.splitk;
+    kchunk = (kchunk + G_BK - 1) / G_BK * G_BK;
+    const int k0 = ks * kchunk, k1 = min(g.K, k0 + kchunk);
+    const bool a_kc = g.sAk == 1, b_nc = g.sBn == 1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int kt = k0; kt < k1; kt += G_BK) {
+#pragma unroll
+        for (int u = 0; u < (G_BM * G_BK) / 256; ++u) {
+            const int e = tid + 256 * u;
+            const int kk = a_kc ? e % G_BK : e / G_BM, mm = a_kc ? e / G_BK : e % G_BM;
+            const int gm = m0 + mm, gk = kt + kk;
+            As[kk][mm] = (gm < g.M && gk < k1) ? A[(size_t)gm * g.sAm + (size_t)gk * g.sAk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < (G_BN * G_BK) / 256; ++u) {
+            const int e = tid + 256 * u;
+            const int nn = b_nc ? e % G_BN : e / G_BK, kk = b_nc ? e / G_BN : e % G_BK;
+            const int gn = n0 + nn, gk = kt + kk;
+            Bs[kk][nn] = (gn < g.N && gk < k1) ? B[(size_t)gk * g.sBk + (size_t)gn * g.sBn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < G_BK / 2; ++s) acc = mfma32(As[2 * s + h][32 * wm + i], Bs[2 * s + h][32 * wn + i], acc);
+        __syncthreads();
+    }
+    const int col = n0 + 32 * wn + i;
+    if (col < g.N) {
+        const float bv = (g.bias && ks == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wm + mfma_row(r, h);
+            if (row < g.M) {
+                float* p = C + (size_t)row * g.ldc + col;
+                const float v = acc[r] + bv;
+                if (g.splitk > 1)
+                    atomicAdd(p, v);
+                else
+                    *p = g.accumulate ? *p + v : v;
+            }
+        }
+    }
+}
+
+extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                            long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
+                            int splitk, int accumulate, void* stream) {
+    EPC_CHECK_ARG(A && B && C, "null pointer");
+    EPC_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1 && ldc >= N, "bad shape");
+    EPC_CHECK_ARG((long)batch * splitk <= 65535, "batch*splitk too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (splitk > 1 && !accumulate) {  // split-K partial sums are added atomically into a zeroed C
+        if (ldc == N && (batch == 1 || bC == (long)M * N)) {
+            if (hipMemsetAsync(C, 0, (size_t)batch * M * N * sizeof(float), st) != hipSuccess) {
+                epc_set_error("epc_gemm_f32: hipMemsetAsync failed");
+                return EPC_EHIP;
+            }
+        } else {
+            EPC_CHECK_ARG(false, "split-K needs a dense C (ldc == N, contiguous batches) or accumulate=1");
+        }
+    }
+    GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, bA, bB, bC, splitk, accumulate};
+    dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM, batch * splitk);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Column reductions over rows: out[q][c] = sum_rows f_q(...).  Deterministic: per-block partials, then a fixed-order
+// finalize.  kind 0: {x}; kind 1: {(x-mean)^2}; kind 2: {dyr, dyr*zhat} with dyr = dy * (y > 0 or no relu).
+// ----------------------------------------------------------------------------------------------------------------
+#define CR_ROWS 256  // rows per block
+
+template <int KIND>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ aux,
+                                                        const float* __restrict__ y, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, int rows, int C, int relu,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rsub = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * CR_ROWS;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        const float mu = (KIND >= 1) ? mean[c] : 0.f;
+        const float rs = (KIND == 2) ? rstd[c] : 0.f;
+        for (int r = r0 + rsub; r < min(rows, r0 + CR_ROWS); r += 4) {
+            const size_t o = (size_t)r * C + c;
+            if (KIND == 0) {
+                s0 += x[o];
+            } else if (KIND == 1) {
+                const float d = x[o] - mu;
+                s0 += d * d;
+            } else {
+                float d = aux[o];  // dy
+                if (relu && !(y[o] > 0.f)) d = 0.f;
+                s0 += d;
+                s1 += d * ((x[o] - mu) * rs);
+            }
+        }
+    }
+    red[0][rsub][threadIdx.x & 63] = s0;
+    red[1][rsub][threadIdx.x & 63] = s1;
+    __syncthreads();
+    if (rsub == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        partial[((size_t)0 * gridDim.x + blockIdx.x) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        if (KIND == 2)
+            partial[((size_t)1 * gridDim.x + blockIdx.x) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+__global__ void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int nq, float scale,
+                                          float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int q = 0; q < nq; ++q) {
+        float s = 0.f;
+        for (int b = 0; b < nblocks; ++b) s += partial[((size_t)q * nblocks + b) * C + c];
+        out[(size_t)q * C + c] = s * scale;
+    }
+}
+
+extern "C" size_t epc_colreduce_workspace_bytes(int rows, int C) {
+    const size_t nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    return 2 * nb * (size_t)C * sizeof(float);
+}
+
+// mean[c], var[c] (population) over `rows` rows of x (rows, C).  tf.nn.moments (utils/tf_util.py:472).
+extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, float* var, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(x && mean && var && workspace, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C > 0, "bad shape");
+    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
+        epc_set_error("epc_col_moments: workspace too small");
+        return EPC_ENOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    dim3 grid(nb, (C + 63) / 64);
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, rows, C, 0, part);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, mean);
+    hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, st, x, nullptr, nullptr, mean, nullptr, rows, C, 0, part);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, var);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// out[c] = sum over rows of x[:, c]  (bias gradients)
+extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    EPC_CHECK_ARG(x && out && workspace && rows > 0 && C > 0, "bad argument");
+    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
+        epc_set_error("epc_col_sum: workspace too small");
+        return EPC_ENOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
+                       rows, C, 0, part);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// y = act(z*s + t), s = gamma*rsqrt(var+eps), t = beta - mean*s  (tf.nn.batch_normalization, utils/tf_util.py:490)
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                    const float* __restrict__ var, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float eps, int relu, long total4, int C,
+                                    float* __restrict__ y) {
+    const long o4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o4 >= total4) return;
+    const int c = (int)((o4 * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(z)[o4];
+    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float s = (1.0f / sqrtf(var[c + q] + eps)) * gamma[c + q];
+        const float r = in[q] * s + (beta[c + q] - mean[c + q] * s);
+        out[q] = relu ? fmaxf(r, 0.f) : r;
+    }
+    reinterpret_cast<float4*>(y)[o4] = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+extern "C" int epc_bn_apply_fwd(const float* z, const float* mean, const float* var, const float* gamma,
+                                const float* beta, float eps, int relu, int rows, int C, float* y, void* stream) {
+    EPC_CHECK_ARG(z && mean && var && gamma && beta && y, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "C must be a multiple of 4");
+    const long total4 = (long)rows * C / 4;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
+                       mean, var, gamma, beta, eps, relu, total4, C, y);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// dz = gamma*rstd * (dyr - dbeta/rows - zhat * dgamma/rows)
+__global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_rows,
+                                    int relu, long total, int C, float* __restrict__ dz) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int c = (int)(o % C);
+    float d = dy[o];
+    if (relu && !(y[o] > 0.f)) d = 0.f;
+    const float zh = (z[o] - mean[c]) * rstd[c];
+    dz[o] = gamma[c] * rstd[c] * (d - dbeta[c] * inv_rows - zh * dgamma[c] * inv_rows);
+}
+
+__global__ void rstd_kernel(const float* __restrict__ var, float eps, int C, float* __restrict__ rstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+// Backward of training-mode BN (+ReLU).  Outputs dz (rows,C), dgamma (C), dbeta (C); rstd_out (C) is scratch.
+extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* y, const float* mean, const float* var,
+                                const float* gamma, float eps, int relu, int rows, int C, float* dz, float* dgamma,
+                                float* dbeta, float* rstd_out, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(dy && z && mean && var && gamma && dz && dgamma && dbeta && rstd_out && workspace, "null pointer");
+    EPC_CHECK_ARG(!relu || y, "y required for the ReLU mask");
+    EPC_CHECK_ARG(rows > 0 && C > 0, "bad shape");
+    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
+        epc_set_error("epc_bn_apply_bwd: workspace too small");
+        return EPC_ENOMEM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, var, eps, C, rstd_out);
+    hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, z, dy, y, mean, rstd_out, rows, C,
+                       relu, part);
+    // partial layout [2][nb][C] -> dbeta = q0, dgamma = q1; finalize writes out[q*C + c]: use a 2*C temp = part tail
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f, dbeta);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part + (size_t)nb * C, nb, C, 1,
+                       1.0f, dgamma);
+    const long total = (long)rows * C;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, z, y, mean,
+                       rstd_out, gamma, dbeta, dgamma, 1.0f / rows, relu, total, C, dz);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Neighbour mean over the kNN index lists (64 channels): forward gather, backward scatter (f32 atomics).
+// Rows with more than `cap` selected entries take the exact scan (same rule as the fused block kernel).
+// ----------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void neighbour_mean_kernel(const float* __restrict__ src, const float* __restrict__ xyz,
+                                                             const int32_t* __restrict__ idx,
+                                                             const int32_t* __restrict__ cnt,
+                                                             const float* __restrict__ kth, int cap, int total_points,
+                                                             int n, float kdiv, float* __restrict__ dst) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int g = t >> 4, q = t & 15;
+    if (g >= total_points) return;
+    const int cloud_base = (g / n) * n;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int c = cnt[g];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 mine;
+    if (BWD) {
+        mine = s4[(size_t)g * 16 + q];
+        mine.x /= kdiv, mine.y /= kdiv, mine.z /= kdiv, mine.w /= kdiv;
+    }
+    auto visit = [&](int j) {
+        if (BWD) {
+            float* d = dst + ((size_t)(cloud_base + j) * 16 + q) * 4;
+            atomicAdd(d + 0, mine.x);
+            atomicAdd(d + 1, mine.y);
+            atomicAdd(d + 2, mine.z);
+            atomicAdd(d + 3, mine.w);
+        } else {
+            const float4 v = s4[(size_t)(cloud_base + j) * 16 + q];
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+    };
+    if (c <= cap) {
+        for (int m = 0; m < c; ++m) visit(idx[(size_t)g * cap + m]);
+    } else {
+        const float* pc = xyz + (size_t)cloud_base * 3;
+        const int i = g - cloud_base;
+        const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
+        const float sqi = sq3(xi, yi, zi), kv = kth[g];
+        for (int j = 0; j < n; ++j) {
+            const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
+            if (neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj)) >= kv) visit(j);
+        }
+    }
+    if (!BWD) {
+        acc.x /= kdiv, acc.y /= kdiv, acc.z /= kdiv, acc.w /= kdiv;
+        reinterpret_cast<float4*>(dst)[(size_t)g * 16 + q] = acc;
+    }
+}
+
+extern "C" int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                                      const float* kth, int cap, int num_clouds, int n, int knn, float* xm,
+                                      void* stream) {
+    EPC_CHECK_ARG(x && xyz && idx && cnt && kth && xm, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT, "bad shape");
+    const long total = (long)num_clouds * n;
+    hipLaunchKernelGGL(neighbour_mean_kernel<false>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, xm);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// dx[j] += sum_{i : j in nbr(i)} dxm[i] / k.  dx must be zero-initialised (or hold the other gradient path).
+extern "C" int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                                      const float* kth, int cap, int num_clouds, int n, int knn, float* dx,
+                                      void* stream) {
+    EPC_CHECK_ARG(dxm && xyz && idx && cnt && kth && dx, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT, "bad shape");
+    const long total = (long)num_clouds * n;
+    hipLaunchKernelGGL(neighbour_mean_kernel<true>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, dxm, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Row L2 normalisation (tf.nn.l2_normalize, eps 1e-12) over C channels: one wave per row.
+//   fwd: y = x * rn, rn = rsqrt(max(sum x^2, eps));  bwd: dx = rn * (dy - y * sum(dy*y))   (0 where the clamp is active)
+// ----------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ rn_in, int rows, int C,
+                                                      float* __restrict__ out, float* __restrict__ rn_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* pa = a + (size_t)row * C;
+    float s = 0.f;
+    if (!BWD) {
+        for (int c = lane; c < C; c += 64) s += pa[c] * pa[c];
+    } else {
+        const float* pb = b + (size_t)row * C;
+        for (int c = lane; c < C; c += 64) s += pa[c] * pb[c];  // a = dy, b = y
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    float* po = out + (size_t)row * C;
+    if (!BWD) {
+        const float rn = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+        for (int c = lane; c < C; c += 64) po[c] = pa[c] * rn;
+        if (lane == 0) rn_out[row] = rn;
+    } else {
+        const float* pb = b + (size_t)row * C;
+        const float rn = rn_in[row];
+        const bool clamped = rn >= 0.99e6f;  // sum x^2 <= 1e-12: y = x * 1e6, d/dx = 1e6 (no projection term)
+        for (int c = lane; c < C; c += 64) po[c] = clamped ? pa[c] * rn : rn * (pa[c] - pb[c] * s);
+    }
+}
+
+extern "C" int epc_rownorm_fwd(const float* x, int rows, int C, float* y, float* rn, void* stream) {
+    EPC_CHECK_ARG(x && y && rn && rows > 0 && C > 0, "bad argument");
+    hipLaunchKernelGGL(rownorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                       nullptr, rows, C, y, rn);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_rownorm_bwd(const float* dy, const float* y, const float* rn, int rows, int C, float* dx,
+                               void* stream) {
+    EPC_CHECK_ARG(dy && y && rn && dx && rows > 0 && C > 0, "bad argument");
+    hipLaunchKernelGGL(rownorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, rn, rows, C,
+                       dx, nullptr);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Softmax over 64 columns, one wave per row.  bwd: dx = y * (dy - sum(dy*y)).
+// ----------------------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax64_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        int rows, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t o = (size_t)row * 64 + lane;
+    if (!BWD) {
+        const float v = a[o];
+        float m = v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float e = expf(v - m);
+        float s = e;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        out[o] = e / s;
+    } else {
+        const float dy = a[o], y = b[o];
+        float s = dy * y;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        out[o] = y * (dy - s);
+    }
+}
+
+extern "C" int epc_softmax64_fwd(const float* x, int rows, float* y, void* stream) {
+    EPC_CHECK_ARG(x && y && rows > 0, "bad argument");
+    hipLaunchKernelGGL(softmax64_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, nullptr, rows, y);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void* stream) {
+    EPC_CHECK_ARG(dy && y && dx && rows > 0, "bad argument");
+    hipLaunchKernelGGL(softmax64_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, rows, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// tf.train.AdamOptimizer (train.py:273; beta1 .9, beta2 .999, eps 1e-8): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+// m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; w -= lr_t * m / (sqrt(v) + eps)
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, long n, float lr_t, float b1, float b2, float eps) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    const float gi = g[o];
+    const float mi = b1 * m[o] + (1.0f - b1) * gi;
+    const float vi = b2 * v[o] + (1.0f - b2) * gi * gi;
+    m[o] = mi;
+    v[o] = vi;
+    w[o] = w[o] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+extern "C" int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2,
+                             float eps, int t, void* stream) {
+    EPC_CHECK_ARG(w && m && v && g && n > 0 && t >= 1, "bad argument");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, m, v, g, n,
+                       (float)lr_t, beta1, beta2, eps);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

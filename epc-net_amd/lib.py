@@ -33,6 +33,9 @@ EXPORTS = [
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
+    "epc_gemm_f32", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
+    "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
+    "epc_softmax64_bwd", "epc_adam_step",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -84,6 +87,22 @@ _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
 _lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_morton_sort.argtypes = [_P, c_int, c_int, _P, _P, _P]
+from ctypes import c_long  # noqa: E402
+_lib.epc_gemm_f32.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int, c_int, c_long,
+                              c_long, c_long, c_int, c_int, _P]
+_lib.epc_colreduce_workspace_bytes.restype = c_size_t
+_lib.epc_colreduce_workspace_bytes.argtypes = [c_int, c_int]
+_lib.epc_col_moments.argtypes = [_P, c_int, c_int, _P, _P, _P, c_size_t, _P]
+_lib.epc_col_sum.argtypes = [_P, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_bn_apply_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P]
+_lib.epc_bn_apply_bwd.argtypes = [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]
+_lib.epc_neighbour_mean_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
+_lib.epc_neighbour_mean_bwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
+_lib.epc_rownorm_fwd.argtypes = [_P, c_int, c_int, _P, _P, _P]
+_lib.epc_rownorm_bwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P]
+_lib.epc_softmax64_fwd.argtypes = [_P, c_int, _P, _P]
+_lib.epc_softmax64_bwd.argtypes = [_P, _P, c_int, _P, _P]
+_lib.epc_adam_step.argtypes = [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]
 _lib.epc_profile_create.argtypes = [POINTER(_P)]
 _lib.epc_profile_destroy.argtypes = [_P]
 _lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]

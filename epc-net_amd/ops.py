@@ -1,0 +1,223 @@
+"""Differentiable operators of the training step: ``torch.autograd.Function`` wrappers whose forward AND backward are
+calls into libepcnet_hip.so (``csrc/train_ops.hip``).  autograd is used as the tape only; there is no torch arithmetic
+in these functions and no CPU fallback.  Reference semantics are cited per operator."""
+from __future__ import annotations
+
+import torch
+
+from . import lib as L
+
+BN_EPS = 1e-3
+
+
+def _st():
+    return L.current_stream()
+
+
+def _ws(rows, C, device):
+    n = L.lib().epc_colreduce_workspace_bytes(int(rows), int(C))
+    return torch.empty(n, dtype=torch.uint8, device=device), n
+
+
+def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False):
+    """out = op(A) @ op(B) (+ bias) on the f32 MFMA.  A, B: 2-D, or 3-D with a leading batch dim (same batch)."""
+    L.require_gpu()
+    batched = A.dim() == 3
+    a2 = A[0] if batched else A
+    b2 = B[0] if batched else B
+    M, K = (a2.shape[1], a2.shape[0]) if trans_a else (a2.shape[0], a2.shape[1])
+    Kb, N = (b2.shape[1], b2.shape[0]) if trans_b else (b2.shape[0], b2.shape[1])
+    assert K == Kb, "inner dimensions differ: %d vs %d" % (K, Kb)
+    nb = A.shape[0] if batched else 1
+    if out is None:
+        out = torch.empty(((nb, M, N) if batched else (M, N)), dtype=torch.float32, device=A.device)
+    sa = a2.stride()
+    sb = b2.stride()
+    sAm, sAk = (sa[1], sa[0]) if trans_a else (sa[0], sa[1])
+    sBk, sBn = (sb[1], sb[0]) if trans_b else (sb[0], sb[1])
+    L.check(L.lib().epc_gemm_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                 M, N, K, sAm, sAk, sBk, sBn, out.stride(-2), nb, A.stride(0) if batched else 0,
+                                 B.stride(0) if batched else 0, out.stride(0) if batched else 0, int(splitk),
+                                 1 if accumulate else 0, _st()))
+    return out
+
+
+def _splitk_for(M, N, K):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    return int(max(1, min(1024 // max(tiles, 1), K // 64, 512)))
+
+
+class Linear(torch.autograd.Function):
+    """y = x @ W + b on (rows, Cin): tf.nn.conv1d with kernel_size 1 (utils/tf_util.py:94-99) / tf.matmul + bias_add
+    (:336-339)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return gemm(x, W, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, cin = x.shape
+        cout = W.shape[1]
+        dx = gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
+        dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows))
+        db = None
+        if ctx.has_bias:
+            db = torch.empty(cout, dtype=torch.float32, device=x.device)
+            ws, n = _ws(rows, cout, x.device)
+            L.check(L.lib().epc_col_sum(dy.data_ptr(), rows, cout, db.data_ptr(), ws.data_ptr(), n, _st()))
+        return dx, dW, db
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """Training-mode batch normalisation over the rows of z (rows, C) (+ReLU): batch mean / POPULATION variance
+    (tf.nn.moments), y = act((z-mean)*rsqrt(var+eps)*gamma + beta) (utils/tf_util.py:472-490; slim.batch_norm in
+    loupe.py:257-263).  Returns (y, mean, var); mean/var feed the moving averages and carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps, relu):
+        z = z.contiguous()
+        rows, C = z.shape
+        mean = torch.empty(C, dtype=torch.float32, device=z.device)
+        var = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, n = _ws(rows, C, z.device)
+        L.check(L.lib().epc_col_moments(z.data_ptr(), rows, C, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
+        y = torch.empty_like(z)
+        L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                         float(eps), int(relu), rows, C, y.data_ptr(), _st()))
+        ctx.save_for_backward(z, y, mean, var, gamma)
+        ctx.eps, ctx.relu = float(eps), int(relu)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        z, y, mean, var, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C = z.shape
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, n = _ws(rows, C, z.device)
+        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), y.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                         gamma.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), rstd.data_ptr(), ws.data_ptr(), n, _st()))
+        return dz, dgamma, dbeta, None, None
+
+
+def bn_inference(z, mean, var, gamma, beta, eps=BN_EPS, relu=False):
+    """Inference-mode BN with stored statistics (no gradient path is needed by the reference in this mode)."""
+    z = z.contiguous()
+    rows, C = z.shape
+    y = torch.empty_like(z)
+    L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     float(eps), int(relu), rows, C, y.data_ptr(), _st()))
+    return y
+
+
+class KnnGraph:
+    """Static kNN graph of a batch of clouds in index form (utils/tf_util.py:647-666): non-differentiable."""
+
+    def __init__(self, xyz):
+        from .utils import tf_util
+        self.xyz = xyz.contiguous().float()
+        self.num_clouds, self.n = int(xyz.shape[0]), int(xyz.shape[1])
+        self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
+
+
+class NeighbourMean(torch.autograd.Function):
+    """xm = matmul(mask, x) / float(k) (models/epc-net.py:70-71) in index form; backward = mask^T @ dxm / k."""
+
+    @staticmethod
+    def forward(ctx, x, graph, k):
+        x = x.contiguous()
+        ctx.graph, ctx.k = graph, int(k)
+        xm = torch.empty_like(x)
+        g = graph
+        L.check(L.lib().epc_neighbour_mean_fwd(x.data_ptr(), g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(),
+                                               g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, int(k), xm.data_ptr(),
+                                               _st()))
+        return xm
+
+    @staticmethod
+    def backward(ctx, dxm):
+        g = ctx.graph
+        dxm = dxm.contiguous()
+        dx = torch.zeros_like(dxm)
+        L.check(L.lib().epc_neighbour_mean_bwd(dxm.data_ptr(), g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(),
+                                               g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, ctx.k, dx.data_ptr(),
+                                               _st()))
+        return dx, None, None
+
+
+class RowL2Normalize(torch.autograd.Function):
+    """tf.nn.l2_normalize(x, 1) on (rows, C) (models/epc-net.py:148)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        rows, C = x.shape
+        y = torch.empty_like(x)
+        rn = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.check(L.lib().epc_rownorm_fwd(x.data_ptr(), rows, C, y.data_ptr(), rn.data_ptr(), _st()))
+        ctx.save_for_backward(y, rn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, rn = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.lib().epc_rownorm_bwd(dy.data_ptr(), y.data_ptr(), rn.data_ptr(), y.shape[0], y.shape[1], dx.data_ptr(), _st()))
+        return dx
+
+
+class Softmax64(torch.autograd.Function):
+    """tf.nn.softmax over the 64 clusters (loupe.py:272)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        assert x.shape[1] == 64
+        y = torch.empty_like(x)
+        L.check(L.lib().epc_softmax64_fwd(x.data_ptr(), x.shape[0], y.data_ptr(), _st()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        L.check(L.lib().epc_softmax64_bwd(dy.data_ptr(), y.data_ptr(), y.shape[0], dx.data_ptr(), _st()))
+        return dx
+
+
+class VladAggregate(torch.autograd.Function):
+    """vlad[b] = f[b]^T @ a[b]: (B,N,F),(B,N,C) -> (B,F,C) (loupe.py:286-291: transpose, batched matmul, transpose)."""
+
+    @staticmethod
+    def forward(ctx, f, a):
+        f, a = f.contiguous(), a.contiguous()
+        ctx.save_for_backward(f, a)
+        return gemm(f, a, trans_a=True, splitk=max(1, min(8, f.shape[1] // 256)))
+
+    @staticmethod
+    def backward(ctx, dv):
+        f, a = ctx.saved_tensors
+        dv = dv.contiguous()
+        df = gemm(a, dv, trans_b=True)   # (B,N,C) @ (B,F,C)^T -> (B,N,F)
+        da = gemm(f, dv)                 # (B,N,F) @ (B,F,C)   -> (B,N,C)
+        return df, da
+
+
+def adam_step(w, m, v, g, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer update of one tensor, in place (train.py:273)."""
+    L.check(L.lib().epc_adam_step(w.data_ptr(), m.data_ptr(), v.data_ptr(), g.contiguous().data_ptr(), w.numel(), float(lr),
+                                  float(beta1), float(beta2), float(eps), int(t), _st()))

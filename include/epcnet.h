@@ -157,6 +157,51 @@ int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, 
 int epc_pairwise_topk(const float* database, int num_db, const float* queries, int num_q, int dim, int k,
                       int32_t* idx, float* dist, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------ */
+/* Training-step operators (config c3; train.py:251-277).  Per-layer forward/backward pairs: training-mode    */
+/* BatchNorm needs batch statistics between layers (utils/tf_util.py:454-491), so nothing is folded here.     */
+/* ------------------------------------------------------------------------------------------------------ */
+
+/* C (M,N; row stride ldc) = op(A) op(B) (+ bias[N]) in exact f32 (MFMA).  A(m,k) = A[m*sAm + k*sAk], B(k,n) =
+ * B[k*sBk + n*sBn]: y = x W (tf.nn.conv1d k=1 / tf.matmul, utils/tf_util.py:94,336; loupe.py:255,290,322), dx = dy W^T,
+ * dW = x^T dy (split-K: f32 atomics into a zeroed C).  `batch` strided problems (bA, bB, bC elements apart). */
+int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                 long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                 void* stream);
+
+/* tf.nn.moments over the rows of x (rows, C): mean and POPULATION variance (utils/tf_util.py:472). */
+size_t epc_colreduce_workspace_bytes(int rows, int C);
+int epc_col_moments(const float* x, int rows, int C, float* mean, float* var, void* workspace, size_t workspace_bytes,
+                    void* stream);
+int epc_col_sum(const float* x, int rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* tf.nn.batch_normalization (+ReLU) with given statistics, and its training-mode backward (statistics are functions
+ * of z): dz, dgamma, dbeta.  utils/tf_util.py:490, loupe.py:257-263. */
+int epc_bn_apply_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                     float eps, int relu, int rows, int C, float* y, void* stream);
+int epc_bn_apply_bwd(const float* dy, const float* z, const float* y, const float* mean, const float* var,
+                     const float* gamma, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
+                     float* rstd_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* xm = (mask @ x) / knn in index form (models/epc-net.py:70-71) for 64-channel x, and its transpose
+ * dx += mask^T @ dxm / knn (dx pre-initialised by the caller). */
+int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt, const float* kth,
+                           int cap, int num_clouds, int n, int knn, float* xm, void* stream);
+int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                           const float* kth, int cap, int num_clouds, int n, int knn, float* dx, void* stream);
+
+/* tf.nn.l2_normalize over the last axis (models/epc-net.py:148): y = x*rn, rn = rsqrt(max(sum x^2, 1e-12)). */
+int epc_rownorm_fwd(const float* x, int rows, int C, float* y, float* rn, void* stream);
+int epc_rownorm_bwd(const float* dy, const float* y, const float* rn, int rows, int C, float* dx, void* stream);
+
+/* tf.nn.softmax over 64 clusters (loupe.py:272). */
+int epc_softmax64_fwd(const float* x, int rows, float* y, void* stream);
+int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void* stream);
+
+/* tf.train.AdamOptimizer.apply (train.py:273): t = 1-based step count for the bias correction. */
+int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2, float eps,
+                  int t, void* stream);
+
 /* Offsets (in bytes) of the per-stage sub-buffers inside the packed weight buffer, for the stage entry
  * points above.  stage: 0 conv1, 1..4 block b, 5 conv5(+assign), 6 head. */
 size_t epc_net_packed_offset(const epc_cfg* cfg, int stage);

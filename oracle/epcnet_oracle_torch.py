@@ -1,0 +1,168 @@
+"""Gradient ORACLE for the EPC-Net training step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see epcnet_oracle.py).
+
+A torch-CPU (float64 by default) restatement of the same graph as ``epcnet_oracle.forward`` so that autograd yields
+the gradients the reference's ``optimizer.minimize(loss)`` applies (train.py:264-277), plus TensorFlow's Adam update
+rule and the BN moving-average updates that run with the step (UPDATE_OPS, train.py:275-277).  Its forward is pinned
+against the numpy oracle in tests/test_oracle_cpu.py (training and inference mode); like the numpy oracle it is
+PARITY UNPINNED against a running TensorFlow.
+
+The kNN mask is non-differentiable (Cast(GreaterEqual), utils/tf_util.py:664-665) and is taken from the numpy oracle.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+import epcnet_oracle as O
+
+
+def _bn_train(x, gamma, beta, axes, eps=O.BN_EPS):
+    mean = x.mean(dim=axes)
+    var = ((x - mean) ** 2).mean(dim=axes)          # tf.nn.moments: population variance
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv), mean, var
+
+
+def _bn_infer(x, gamma, beta, mean, var, eps=O.BN_EPS):
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def _l2n(x, dim):
+    ss = (x * x).sum(dim=dim, keepdim=True)
+    return x * torch.rsqrt(torch.clamp(ss, min=O.L2_EPS))
+
+
+class TorchOracle:
+    def __init__(self, weights: Dict[str, np.ndarray], arch="epc-net", params=None, dtype=torch.float64,
+                 outer="query_triplets"):
+        self.arch, self.dtype, self.outer = arch, dtype, outer
+        self.p = dict(O.DEFAULT_PARAMS)
+        self.p.update(params or {})
+        table = O.variable_table(arch, self.p, outer)
+        self.w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for k, (shape, kind) in table.items():
+            t = torch.tensor(np.asarray(weights[k], dtype=np.float64), dtype=dtype)
+            t.requires_grad_(kind in ("weight", "bias", "gamma", "beta"))
+            self.w[k] = t
+        self.trainable = [k for k, (_, kind) in table.items() if kind in ("weight", "bias", "gamma", "beta")]
+        self.new_stats: Dict[str, torch.Tensor] = {}
+
+    # ---- layers ----------------------------------------------------------------------------------------------
+    def _tfutil_bn(self, z, scope, axes, training, bn_decay):
+        g, b = self.w[scope + "/bn/gamma"], self.w[scope + "/bn/beta"]
+        mname, vname = O.ema_names(scope, self.outer)
+        if training:
+            y, mean, var = _bn_train(z, g, b, axes)
+            decay = 0.9 if bn_decay is None else bn_decay
+            with torch.no_grad():
+                self.new_stats[mname] = self.w[mname] - (1 - decay) * (self.w[mname] - mean)
+                self.new_stats[vname] = self.w[vname] - (1 - decay) * (self.w[vname] - var)
+            return y
+        return _bn_infer(z, g, b, self.w[mname], self.w[vname])
+
+    def conv1d(self, x, scope, training, bn_decay):
+        W = self.w[scope + "/weights"]
+        z = x @ W.reshape(W.shape[-2], W.shape[-1]) + self.w[scope + "/biases"]
+        return torch.relu(self._tfutil_bn(z, scope, (0, 1), training, bn_decay))
+
+    def _slim_bn(self, x, scope, training, fused):
+        g, b = self.w[scope + "/gamma"], self.w[scope + "/beta"]
+        mm, mv = self.w[scope + "/moving_mean"], self.w[scope + "/moving_variance"]
+        if training:
+            y, mean, var = _bn_train(x, g, b, (0,))
+            rows = x.shape[0]
+            var_upd = var * (rows / max(rows - 1, 1)) if fused else var
+            with torch.no_grad():
+                self.new_stats[scope + "/moving_mean"] = mm - (mm - mean) * (1 - O.SLIM_DECAY)
+                self.new_stats[scope + "/moving_variance"] = mv - (mv - var_upd) * (1 - O.SLIM_DECAY)
+            return y
+        return _bn_infer(x, g, b, mm, mv)
+
+    # ---- forward -----------------------------------------------------------------------------------------------
+    def forward(self, point_cloud: np.ndarray, is_training: bool, bn_decay: Optional[float] = None,
+                mask: Optional[np.ndarray] = None) -> torch.Tensor:
+        B, P, N, D = point_cloud.shape
+        pc32 = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(B * P, N, D)
+        if mask is None:
+            mask = O.pairwise_distance_mask(pc32)
+        m = torch.tensor(mask, dtype=self.dtype)
+        k = float(self.p["KNN"])
+        inp = torch.tensor(pc32, dtype=self.dtype)
+        nblocks = 4 if self.arch == "epc-net" else 2
+        outs = []
+        tr, bd = is_training, bn_decay
+        for b in range(1, nblocks + 1):
+            x = self.conv1d(inp, "fastdgcnn/conv%d" % b, tr, bd)
+            xm = torch.matmul(m, x) / k
+            t = xm - x
+            t = self.conv1d(t, "fastdgcnn/conv%d_a" % b, tr, bd)
+            t = self.conv1d(t, "fastdgcnn/conv%d_b" % b, tr, bd)
+            inp = t + xm
+            outs.append(inp)
+        x = self.conv1d(torch.cat(outs, dim=-1), "fastdgcnn/conv5", tr, bd)
+        if self.arch == "epc-net":
+            G = self.p["GROUPS"]
+            f = _l2n(x.reshape(-1, 1024), 1)
+            act = f @ self.w["VLAD/cluster_weights"]
+            act = torch.softmax(self._slim_bn(act, "VLAD/cluster_bn", tr, fused=False), dim=1).reshape(-1, N, 64)
+            a_sum = act.sum(dim=-2, keepdim=True)
+            a = a_sum * self.w["VLAD/cluster_weights2"]
+            vlad = torch.matmul(act.transpose(1, 2), f.reshape(-1, N, 1024)).transpose(1, 2) - a
+            vlad = _l2n(vlad, 1).reshape(-1, 64 * 1024)
+            vlad = _l2n(vlad, 1)
+            y = vlad.reshape(-1, 65536 // G) @ self.w["VLAD/hidden1_weights"]
+            y = self._slim_bn(y, "VLAD/bn", tr, fused=True).reshape(-1, G, 256).sum(dim=-2)
+            gates = torch.sigmoid(self._slim_bn(y @ self.w["VLAD/gating_weights"], "VLAD/gating_bn", tr, fused=True))
+            out = y * gates
+        else:
+            net = x.max(dim=1).values
+            z = net @ self.w["VLAD/fc1/weights"] + self.w["VLAD/fc1/biases"]
+            out = torch.relu(self._tfutil_bn(z, "VLAD/fc1", (0,), tr, bd))
+        return _l2n(out, 1).reshape(B, P, self.p["FEATURE_OUTPUT_DIM"])
+
+
+def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
+    """models/epc-net.py:269-284."""
+    best = ((pos - q) ** 2).sum(2).min(1).values.reshape(-1, 1)
+    l1 = torch.clamp(m1 + best - ((neg - q) ** 2).sum(2), min=0).max(1).values.mean()
+    l2 = torch.clamp(m2 + best - ((neg - other) ** 2).sum(2), min=0).max(1).values.mean()
+    return l1 + l2
+
+
+def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, other_neg, step: int, epoch: int,
+               adam_m: Optional[Dict[str, np.ndarray]] = None, adam_v: Optional[Dict[str, np.ndarray]] = None,
+               arch="epc-net", params=None, m1=0.5, m2=0.2, base_lr=5e-5, batch_num_queries=1, dtype=torch.float64):
+    """One reference training step (train.py:251-277, 484-495): returns dict(loss, grads, new_weights, adam_m, adam_v).
+
+    ``step`` = value of the global-step variable BEFORE the step (``batch``, train.py:246): bn_decay is evaluated with
+    it; Adam's bias correction uses t = step + 1 (TensorFlow's beta*_power are multiplied after each apply)."""
+    orc = TorchOracle(weights, arch, params, dtype)
+    vecs = np.concatenate([query, positives, negatives, other_neg], axis=1)          # train.py:252
+    bn_decay = O.get_bn_decay(step, batch_num_queries)
+    out = orc.forward(vecs, True, bn_decay)
+    npos, nneg = positives.shape[1], negatives.shape[1]
+    q, pos, neg, oth = torch.split(out, [1, npos, nneg, 1], dim=1)                    # train.py:255
+    loss = lazy_quadruplet_loss(q, pos, neg, oth, m1, m2)
+    grads = torch.autograd.grad(loss, [orc.w[k] for k in orc.trainable], allow_unused=True)
+    lr = O.get_learning_rate(epoch, base_lr)
+    b1, b2, eps = 0.9, 0.999, 1e-8                                                    # tf.train.AdamOptimizer defaults
+    t = step + 1
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    new_w = {k: v.detach().numpy().copy() for k, v in orc.w.items()}
+    am, av, g_out = {}, {}, {}
+    for k, g in zip(orc.trainable, grads):
+        g = np.zeros_like(new_w[k]) if g is None else g.detach().numpy()
+        m_prev = np.zeros_like(g) if adam_m is None else adam_m[k]
+        v_prev = np.zeros_like(g) if adam_v is None else adam_v[k]
+        am[k] = b1 * m_prev + (1 - b1) * g
+        av[k] = b2 * v_prev + (1 - b2) * g * g
+        new_w[k] = new_w[k] - lr_t * am[k] / (np.sqrt(av[k]) + eps)
+        g_out[k] = g
+    for k, v in orc.new_stats.items():
+        new_w[k] = v.numpy().copy()
+    return {"loss": float(loss.detach()), "grads": g_out, "new_weights": new_w, "adam_m": am, "adam_v": av,
+            "lr": lr, "bn_decay": bn_decay, "descriptors": out.detach().numpy()}

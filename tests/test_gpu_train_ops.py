@@ -1,0 +1,109 @@
+"""GPU tests of the training-step operators (csrc/train_ops.hip via epc-net_amd/ops.py): forward and backward against
+a float64 torch-CPU autograd restatement of the same reference op (tolerances are fp32 rounding, relative to the
+largest magnitude of each tensor)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from helpers import O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else b
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def run_pair(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
+    """inputs: list of float64 CPU tensors.  Compares outputs and the gradients of sum(out * r) w.r.t. every input."""
+    g_in = [t.float().to(dev).requires_grad_(True) for t in inputs]
+    r_in = [t.clone().requires_grad_(True) for t in inputs]
+    og, orf = fn_gpu(*g_in), fn_ref(*r_in)
+    assert rel(og, orf) <= tol, "forward: %.3e" % rel(og, orf)
+    up = torch.randn(orf.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+    (og * up.float().to(dev)).sum().backward()
+    (orf * up).sum().backward()
+    for i, (a, b) in enumerate(zip(g_in, r_in)):
+        assert rel(a.grad, b.grad) <= tol * 5, "grad of input %d: %.3e" % (i, rel(a.grad, b.grad))
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4096, 64, 64), (1000, 3, 64), (2048, 256, 1024), (72, 16384, 256), (300, 1024, 64)])
+def test_linear(dev, rows, cin, cout):
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, cin, dtype=torch.float64, generator=g)
+    W = torch.randn(cin, cout, dtype=torch.float64, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, dtype=torch.float64, generator=g)
+    run_pair(lambda x, W, b: ops.Linear.apply(x, W, b), lambda x, W, b: x @ W + b, [x, W, b], dev)
+
+
+@pytest.mark.parametrize("rows,C,relu", [(8192, 64, 1), (5000, 1024, 1), (72, 256, 0), (18, 256, 0), (4096, 64, 0)])
+def test_batch_norm_train(dev, rows, C, relu):
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(rows, C, dtype=torch.float64, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, dtype=torch.float64, generator=g) + 0.5
+    beta = torch.randn(C, dtype=torch.float64, generator=g) * 0.1
+
+    def ref(z, gamma, beta):
+        mean = z.mean(0)
+        var = ((z - mean) ** 2).mean(0)
+        y = (z - mean) * torch.rsqrt(var + 1e-3) * gamma + beta
+        return torch.relu(y) if relu else y
+
+    run_pair(lambda z, g_, b_: ops.BatchNormTrain.apply(z, g_, b_, 1e-3, relu)[0], ref, [z, gamma, beta], dev, tol=5e-5)
+    y, mean, var = ops.BatchNormTrain.apply(z.float().to(dev), gamma.float().to(dev), beta.float().to(dev), 1e-3, relu)
+    assert rel(mean, z.mean(0)) <= 1e-5 and rel(var, z.var(0, unbiased=False)) <= 1e-5
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 256), ("lattice", 512), ("zeros", 64)])
+def test_neighbour_mean(dev, kind, n):
+    ops = H.pkg("ops")
+    pc = O.synthetic_clouds(2, n, 0, kind)
+    mask = torch.tensor(O.pairwise_distance_mask(pc), dtype=torch.float64)
+    graph = ops.KnnGraph(torch.from_numpy(pc).to(dev))
+    x = torch.randn(2, n, 64, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    run_pair(lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), graph, 20).reshape(2, n, 64),
+             lambda x: torch.matmul(mask, x) / 20.0, [x], dev)
+
+
+def test_rownorm_and_softmax(dev):
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3000, 1024, dtype=torch.float64, generator=g).clamp(min=0)
+    x[5] = 0.0                                                          # clamp branch of l2_normalize
+    run_pair(lambda x: ops.RowL2Normalize.apply(x), lambda x: x * torch.rsqrt(torch.clamp((x * x).sum(1, keepdim=True), min=1e-12)), [x], dev)
+    a = torch.randn(5000, 64, dtype=torch.float64, generator=g) * 3
+    run_pair(lambda a: ops.Softmax64.apply(a), lambda a: torch.softmax(a, 1), [a], dev)
+
+
+def test_vlad_aggregate(dev):
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(4)
+    f = torch.rand(3, 512, 1024, dtype=torch.float64, generator=g)
+    a = torch.softmax(torch.randn(3, 512, 64, dtype=torch.float64, generator=g), -1)
+    run_pair(lambda f, a: ops.VladAggregate.apply(f, a), lambda f, a: torch.matmul(f.transpose(1, 2), a), [f, a], dev)
+
+
+def test_adam_matches_tensorflow_rule(dev):
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(10000, generator=g); m = torch.randn(10000, generator=g) * 0.01; v = torch.rand(10000, generator=g) * 1e-4
+    gr = torch.randn(10000, generator=g) * 0.1
+    wd, md, vd = w.to(dev), m.to(dev), v.to(dev)
+    ops.adam_step(wd, md, vd, gr.to(dev), 5e-5, 7)
+    torch.cuda.synchronize()
+    w64, m64, v64, g64 = (t.double() for t in (w, m, v, gr))
+    m2 = 0.9 * m64 + 0.1 * g64; v2 = 0.999 * v64 + 0.001 * g64 * g64
+    lr_t = 5e-5 * np.sqrt(1 - 0.999 ** 7) / (1 - 0.9 ** 7)
+    assert rel(md, m2) <= 1e-6 and rel(vd, v2) <= 1e-6
+    assert np.abs((wd.cpu().double() - (w64 - lr_t * m2 / (v2.sqrt() + 1e-8))).numpy()).max() <= 1e-7
