@@ -5,14 +5,44 @@ model instantiates it.  Constructing a class and calling ``declare_variables()``
 reference's variables in the current scope: cluster_weights [F,C], cluster_bn/*, cluster_weights2 [1,F,C],
 hidden1_weights [C*F/G, O], bn/*, gating_weights [O,O], gating_bn/* (``loupe.py:75-79, 249-316``).
 
-Stand-alone ``forward`` on arbitrary features runs the HIP VLAD kernels (aggregate + head) -- the conv5-fused
-assignment lives in ``epc_conv5_assign_fwd``; the fused model path is ``models/epc-net.py: forward``.
+``forward`` runs op by op on the differentiable HIP operators of ``epc-net_amd/ops.py`` (GEMMs, batch-norm, softmax,
+row norms, VLAD aggregation); it is what ``models/epc-net.py: forward(is_training=True)`` uses.  The inference fast
+path fuses the same computation into ``epc_conv5_assign_fwd`` / ``epc_vlad_aggregate_fwd`` / ``epc_vlad_head_fwd``.
+The per-descriptor tail (B x 65536 and smaller: intra-normalisation, flatten, group reshape, sigmoid gate) is a
+handful of torch tensor ops on B-row tensors.
 """
 from __future__ import annotations
 
 import math
 
+import torch
+
 from .variables import constant, default_store, random_normal, scoped, variable_scope
+
+SLIM_DECAY = 0.999   # slim.batch_norm default decay
+BN_EPS = 1e-3        # slim.batch_norm default epsilon
+
+
+def _l2_normalize(x, dim):
+    """tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), 1e-12))."""
+    return x * torch.rsqrt(torch.clamp((x * x).sum(dim=dim, keepdim=True), min=1e-12))
+
+
+def _slim_batch_norm(x2d, scope, is_training, fused):
+    """slim.batch_norm / tf.contrib.layers.batch_norm on (rows, C) (loupe.py:82-87, 257-263, 323): batch statistics
+    in training (population variance normalises; the FUSED op feeds the Bessel-corrected variance to the moving
+    average), moving statistics otherwise.  Moving averages are updated in place with decay 0.999 (UPDATE_OPS run
+    with the train op, train.py:275-277)."""
+    from . import ops
+    from .utils.tf_util import _ema_update
+    beta, gamma, mm, mv = _slim_bn_variables(scope, int(x2d.shape[1]))
+    if is_training:
+        y, mean, var = ops.BatchNormTrain.apply(x2d, gamma, beta, BN_EPS, 0)
+        rows = int(x2d.shape[0])
+        _ema_update(mm, mean, SLIM_DECAY)
+        _ema_update(mv, var * (rows / max(rows - 1, 1)) if fused else var, SLIM_DECAY)
+        return y
+    return ops.bn_inference(x2d, mm, mv, gamma, beta, BN_EPS, False)
 
 
 def _slim_bn_variables(scope: str, n: int):
@@ -51,8 +81,13 @@ class PoolingBaseModel(object):
 
     def context_gating(self, input_layer):
         """loupe.py:61-101: input * sigmoid(BN(input @ gating_weights))."""
-        self._declare_gating(int(input_layer.shape[1]))
-        raise NotImplementedError("stand-alone context_gating: fused into epc_vlad_head_fwd (loupe.py:61-101)")
+        from . import ops
+        dim = int(input_layer.shape[1])
+        self._declare_gating(dim)
+        w = default_store().vars[scoped("gating_weights")]
+        gates = ops.Linear.apply(input_layer, w, None)
+        gates = _slim_batch_norm(gates, "gating_bn", self.is_training, fused=True)
+        return input_layer * torch.sigmoid(gates)
 
 
 class _VladBase(PoolingBaseModel):
@@ -72,10 +107,33 @@ class _VladBase(PoolingBaseModel):
             self._declare_gating(O)
 
     def forward(self, reshaped_input):
+        """loupe.py:121-214 (NetVLAD) / :233-333 (G_VLAD): (B*max_samples, F) -> (B, output_dim)."""
+        from . import ops
         self.declare_variables()
-        raise NotImplementedError(
-            "stand-alone %s.forward on external features is not built yet; use models/epc-net.py forward "
-            "(conv5 + assignment + aggregation are fused in libepcnet_hip.so)" % type(self).__name__)
+        st = default_store().vars
+        F, C, O, G, N = self.feature_size, self.cluster_size, self.output_dim, self.groups, self.max_samples
+        if C != 64:
+            raise NotImplementedError("cluster_size must be 64 (configs/*.yaml CLUSTER_SIZE)")
+        x = reshaped_input.reshape(-1, F)
+        activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255
+        activation = _slim_batch_norm(activation, "cluster_bn", self.is_training, fused=False)   # :257-263
+        activation = ops.Softmax64.apply(activation)                                             # :272
+        activation = activation.reshape(-1, N, C)                                                # :274
+        a_sum = activation.sum(dim=-2, keepdim=True)                                             # :276
+        a = a_sum * st[scoped("cluster_weights2")]                                               # :284
+        vlad = ops.VladAggregate.apply(x.reshape(-1, N, F), activation)                          # :286-291 (B,F,C)
+        vlad = vlad - a                                                                          # :292
+        vlad = _l2_normalize(vlad, 1)                                                            # :295
+        vlad = vlad.reshape(-1, C * F)                                                           # :297
+        vlad = _l2_normalize(vlad, 1)                                                            # :298
+        vlad = vlad.reshape(-1, C * F // G)                                                      # :302 (groups)
+        vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                       # :322
+        vlad = _slim_batch_norm(vlad, "bn", self.is_training, fused=True)                        # :323
+        if G > 1:
+            vlad = vlad.reshape(-1, G, O).sum(dim=-2)                                            # :326-328
+        if self.gating:
+            vlad = self.context_gating(vlad)                                                     # :330-331
+        return vlad
 
 
 class NetVLAD(_VladBase):

@@ -36,8 +36,42 @@ def forward(point_cloud, is_training, bn_decay=None, params=None):
     if dim != INPUT_DIM:
         raise ValueError("last dimension %d != INPUT_DIM %d" % (dim, INPUT_DIM))
     declare_variables(params, num_points)
-    if is_training:
-        raise NotImplementedError("is_training=True is the training-step milestone")
     pc = point_cloud.reshape(batch_num_queries * num_pointclouds_per_query, num_points, INPUT_DIM)
-    output = engine_for(ARCH, params).forward(pc)
+    if is_training:
+        output = forward_ops(pc, True, bn_decay, params)
+    else:
+        output = engine_for(ARCH, params).forward(pc)
     return output.reshape(batch_num_queries, num_pointclouds_per_query, OUTPUT_DIM)
+
+
+def forward_ops(point_cloud, is_training, bn_decay, params):
+    """models/epc-net-l.py:44-98 op by op on the differentiable operators (training path / unfused cross-check)."""
+    import torch
+    from .. import loupe as lp
+    from .. import ops
+    num_points = int(point_cloud.shape[1])
+    k = params["KNN"]
+    with variable_scope('fastdgcnn'):
+        dpist = ops.KnnGraph(point_cloud)
+        nmean = lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), dpist, k).reshape(x.shape)
+        conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
+                                                  scope=scope, bn_decay=bn_decay)
+        outs = []
+        inp = point_cloud
+        for b in (1, 2):
+            x = conv(inp, 64, 'conv%d' % b)
+            xb = nmean(x)
+            t = xb - x
+            t = conv(t, 64, 'conv%d_a' % b)
+            t = conv(t, 64, 'conv%d_b' % b)
+            inp = t + xb
+            outs.append(inp)
+        x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
+        x = x.unsqueeze(2)                                               # :88
+    with variable_scope('VLAD'):
+        net = tf_util.max_pool2d(x, [num_points, 1], padding='VALID', scope='maxpool')
+        net = net.reshape(-1, 1024)
+        output = tf_util.fully_connected(net, params["FEATURE_OUTPUT_DIM"], bn=True, is_training=is_training,
+                                         scope="fc1", bn_decay=bn_decay)
+        output = lp._l2_normalize(output, 1)
+    return output

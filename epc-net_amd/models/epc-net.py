@@ -49,9 +49,44 @@ def forward(point_cloud, is_training, bn_decay=None, params=None):
     if dim != INPUT_DIM:
         raise ValueError("last dimension %d != INPUT_DIM %d (reshape at models/epc-net.py:41)" % (dim, INPUT_DIM))
     declare_variables(params, num_points)
-    if is_training:
-        raise NotImplementedError("is_training=True (batch-statistics BN + EMA updates) is the training-step "
-                                  "milestone; inference uses the stored statistics")
     pc = point_cloud.reshape(batch_num_queries * num_pointclouds_per_query, num_points, INPUT_DIM)
-    output = engine_for(ARCH, params).forward(pc)
+    if is_training:
+        output = forward_ops(pc, True, bn_decay, params)
+    else:
+        output = engine_for(ARCH, params).forward(pc)
     return output.reshape(batch_num_queries, num_pointclouds_per_query, OUTPUT_DIM)
+
+
+def forward_ops(point_cloud, is_training, bn_decay, params):
+    """The same graph built op by op from the differentiable operators, line for line as models/epc-net.py:62-155.
+    Used for is_training=True (batch statistics, EMA updates, gradients); with is_training=False it is an
+    independent (unfused) second implementation of the inference path (tests cross-check the two)."""
+    import torch
+    from .. import ops
+    num_points = int(point_cloud.shape[1])
+    k = params["KNN"]
+    with variable_scope('fastdgcnn'):
+        dpist = ops.KnnGraph(point_cloud)                    # tf_util.pairwise_distance_mask in index form (:63)
+        nmean = lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), dpist, k).reshape(x.shape)  # matmul(dpist,x)/k
+        conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
+                                                  scope=scope, bn_decay=bn_decay)
+        outs = []
+        inp = point_cloud
+        for b in (1, 2, 3, 4):
+            x = conv(inp, 64, 'conv%d' % b)
+            xb = nmean(x)                                    # x1 = tf.matmul(dpist, x) / float(k)
+            t = xb - x
+            t = conv(t, 64, 'conv%d_a' % b)
+            t = conv(t, 64, 'conv%d_b' % b)
+            inp = t + xb
+            outs.append(inp)
+        x = torch.cat(outs, dim=-1)                          # :134
+        x = conv(x, 1024, 'conv5')                           # :136-139
+    with variable_scope('VLAD'):
+        NetVLAD = lp.G_VLAD(feature_size=1024, max_samples=num_points, cluster_size=params["CLUSTER_SIZE"],
+                            output_dim=params["FEATURE_OUTPUT_DIM"], groups=params["GROUPS"], gating=True,
+                            add_batch_norm=True, is_training=is_training)
+        net = ops.RowL2Normalize.apply(x.reshape(-1, 1024))  # :147-148
+        output = NetVLAD.forward(net)
+        output = lp._l2_normalize(output, 1)                 # :153
+    return output

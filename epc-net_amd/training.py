@@ -1,0 +1,92 @@
+"""The reference's training step (train.py:238-277, 484-495) on the HIP operators.
+
+One ``TrainStep.step(query, positives, negatives, other_neg, epoch)`` = one ``sess.run([train_op, loss, ...])``:
+  concat the four inputs on axis 1 -> MODEL.forward(is_training=True, bn_decay) -> split [1, P, N, 1] ->
+  lazy_quadruplet_loss(m1, m2) -> gradients -> tf.train.AdamOptimizer(learning_rate) update of the 62 trainable tensors,
+  with the BatchNorm moving averages updated by the same run (UPDATE_OPS).  Schedules: get_bn_decay (train.py:138-146),
+  get_learning_rate (train.py:154-157).  State follows the checkpoint contract: ``Variable`` (global step), ``beta1_power``,
+  ``beta2_power``, ``<var>/Adam`` (m) and ``<var>/Adam_1`` (v)  (tests/golden/ckpt_tables.json).
+"""
+from __future__ import annotations
+
+import importlib
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .variables import VariableStore, default_store, variable_scope
+
+BN_INIT_DECAY, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP = 0.5, 0.5, 0.99   # train.py:127-130 (hard-coded there)
+
+
+def get_bn_decay(batch: int, batch_num_queries: int, decay_step: float) -> float:
+    """train.py:138-146: min(0.99, 1 - 0.5 * 0.5 ** floor(batch*BATCH_NUM_QUERIES / DECAY_STEP))."""
+    bn_momentum = BN_INIT_DECAY * BN_DECAY_DECAY_RATE ** math.floor(batch * batch_num_queries / float(decay_step))
+    return min(BN_DECAY_CLIP, 1 - bn_momentum)
+
+
+def get_learning_rate(epoch: int, base_learning_rate: float) -> float:
+    """train.py:154-157."""
+    return max(base_learning_rate * (0.9 ** (epoch // 5)), 0.00001)
+
+
+class TrainStep:
+    def __init__(self, params: dict, store: Optional[VariableStore] = None, outer: str = "query_triplets"):
+        self.params = dict(params)
+        self.arch = params.get("ARCH", "epc-net")
+        self.model = importlib.import_module("epc-net_amd.models." + self.arch)
+        self.store = store or default_store()
+        self.outer = outer
+        self.global_step = 0                      # tf.Variable(0) `batch`, train.py:246
+        self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
+        self.m: Dict[str, torch.Tensor] = {}
+        self.v: Dict[str, torch.Tensor] = {}
+
+    # -- checkpoint-shaped optimizer state ---------------------------------------------------------------------------
+    def optimizer_state(self) -> Dict[str, torch.Tensor]:
+        dev = self.store.device
+        out = {"Variable": torch.tensor(self.global_step, dtype=torch.int32),
+               "beta1_power": torch.tensor(self.beta1 ** (self.global_step + 1), dtype=torch.float32),
+               "beta2_power": torch.tensor(self.beta2 ** (self.global_step + 1), dtype=torch.float32)}
+        for name in self.store.trainable:
+            out[name + "/Adam"] = self.m.get(name, torch.zeros_like(self.store.vars[name]))
+            out[name + "/Adam_1"] = self.v.get(name, torch.zeros_like(self.store.vars[name]))
+        return out
+
+    def _ensure_built(self, num_points: int):
+        with variable_scope(self.outer):
+            self.model.declare_variables(self.params, num_points)
+        for name in self.store.trainable:
+            self.store.vars[name].requires_grad_(True)
+            if name not in self.m:
+                self.m[name] = torch.zeros_like(self.store.vars[name])
+                self.v[name] = torch.zeros_like(self.store.vars[name])
+
+    def step(self, query, positives, negatives, other_neg, epoch: int = 0):
+        """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3)."""
+        p = self.params
+        B = int(query.shape[0])
+        self._ensure_built(int(query.shape[2]))
+        bn_decay = get_bn_decay(self.global_step, p.get("BATCH_NUM_QUERIES", B), p.get("DECAY_STEP", 200000))
+        lr = get_learning_rate(epoch, p.get("BASE_LEARNING_RATE", 5e-5))
+        for name in self.store.trainable:
+            self.store.vars[name].grad = None
+        with variable_scope(self.outer):
+            vecs = torch.cat([query, positives, negatives, other_neg], 1)                               # train.py:252
+            out_vecs = self.model.forward(vecs, True, bn_decay=bn_decay, params=p)                       # :254
+            q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
+                out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)                  # :255
+            loss = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
+                                                   p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))       # :264
+        loss.backward()
+        t = self.global_step + 1
+        with torch.no_grad():
+            for name in self.store.trainable:
+                w = self.store.vars[name]
+                g = w.grad if w.grad is not None else torch.zeros_like(w)
+                ops.adam_step(w, self.m[name], self.v[name], g, lr, t, self.beta1, self.beta2, self.eps)  # :273-277
+        self.store.version += 1
+        self.global_step += 1
+        return loss.detach(), lr, bn_decay

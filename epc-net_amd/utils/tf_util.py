@@ -6,8 +6,8 @@ torch / CPU fallback (``EpcNetError`` if no GPU is visible).  Variables are crea
 same state-dict as the reference checkpoint.
 
 The fused model path (``models/epc-net.py: forward``) does NOT go through these wrappers op by op: it runs the
-fused kernels of ``epc_net_forward``.  The wrappers exist for op-level callers and API-surface parity; the
-reference functions EPC-Net never calls (conv2d, conv3d, avg_pool*, dropout, knn, get_edge_feature, ...) are
+fused kernels of ``epc_net_forward``.  The wrappers are what `forward(..., is_training=True)` is built from (differentiable: epc-net_amd/ops.py) and serve
+op-level callers; the reference functions EPC-Net never calls (conv2d, conv3d, avg_pool*, dropout, knn, get_edge_feature, ...) are
 out of scope and raise ``NotImplementedError`` naming the reference line.
 """
 from __future__ import annotations
@@ -96,31 +96,82 @@ def knn_index(pc: torch.Tensor):
     return kth, idx, cnt
 
 
-def _op_level_pending(name, where):
-    raise NotImplementedError(
-        "%s as a stand-alone op is not built yet (reference %s); the fused model path `forward` covers it" %
-        (name, where))
+def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay: float) -> None:
+    """tf.train.ExponentialMovingAverage.apply / assign_moving_average: shadow -= (1 - decay) * (shadow - value)."""
+    with torch.no_grad():
+        shadow.sub_((shadow - value) * (1.0 - float(decay)))
+    default_store().version += 1
+
+
+def batch_norm_template(inputs, is_training, scope, moments_dims, bn_decay, activation_relu=False):
+    """utils/tf_util.py:454-491 on (rows, C) data (the caller flattens the moment axes).  Training: batch mean /
+    population variance, EMA shadows updated with ``bn_decay`` (0.9 when None); inference: the EMA shadows.
+    ``activation_relu`` fuses the ReLU that follows in conv1d / fully_connected into the same kernel."""
+    from .. import ops
+    C = int(inputs.shape[-1])
+    beta, gamma, ema_mean, ema_var = _bn_variables(scope, C)
+    x2 = inputs.reshape(-1, C)
+    if is_training:
+        y, mean, var = ops.BatchNormTrain.apply(x2, gamma, beta, 1e-3, int(activation_relu))
+        decay = 0.9 if bn_decay is None else float(bn_decay)
+        _ema_update(ema_mean, mean, decay)
+        _ema_update(ema_var, var, decay)
+    else:
+        y = ops.bn_inference(x2, ema_mean, ema_var, gamma, beta, 1e-3, activation_relu)
+    return y.reshape(inputs.shape)
+
+
+def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
+    """utils/tf_util.py:494-505."""
+    return batch_norm_template(inputs, is_training, scope, [0, ], bn_decay)
+
+
+def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope):
+    """utils/tf_util.py:508-519."""
+    return batch_norm_template(inputs, is_training, scope, [0, 1], bn_decay)
+
+
+def _dense(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training):
+    from .. import ops
+    z = ops.Linear.apply(inputs2d, w2d, b)
+    want_relu = activation_fn is not None
+    if activation_fn not in (None, relu):
+        raise NotImplementedError("only activation_fn=tf.nn.relu / None are used by EPC-Net")
+    if bn:
+        return batch_norm_template(z, bool(is_training), scope_bn, None, bn_decay, activation_relu=want_relu)
+    return torch.relu(z) if want_relu else z
 
 
 def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME', use_xavier=True,
            stddev=1e-3, weight_decay=0.0, activation_fn=relu, bn=False, bn_decay=None, is_training=None):
-    """utils/tf_util.py:52-107.  Declares the variables; stand-alone execution arrives with the generic GEMM."""
+    """utils/tf_util.py:52-107 for kernel_size 1: per-point matmul + bias (+ BN over axes (0,1)) (+ ReLU) on (B,L,C)."""
     if kernel_size != 1 or stride != 1:
         raise NotImplementedError("EPC-Net only uses kernel_size=1, stride=1 (models/epc-net.py:66-139)")
-    declare_conv1d(scope, int(inputs.shape[-1]), num_output_channels, kernel_size, use_xavier, stddev, bn)
-    _op_level_pending("conv1d", "utils/tf_util.py:52-107")
+    L.require_gpu()
+    cin = int(inputs.shape[-1])
+    w, b, _ = declare_conv1d(scope, cin, num_output_channels, kernel_size, use_xavier, stddev, bn)
+    with variable_scope(scope):
+        y = _dense(inputs.reshape(-1, cin), w.reshape(cin, num_output_channels), b, bn, "bn", activation_fn, bn_decay,
+                   is_training)
+    return y.reshape(tuple(inputs.shape[:-1]) + (num_output_channels,))
 
 
 def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=0.0,
                     activation_fn=relu, bn=False, bn_decay=None, is_training=None):
-    """utils/tf_util.py:310-346."""
-    declare_fully_connected(scope, int(inputs.shape[-1]), num_outputs, use_xavier, stddev, bn)
-    _op_level_pending("fully_connected", "utils/tf_util.py:310-346")
+    """utils/tf_util.py:310-346: (B, Cin) -> (B, num_outputs), BN over axis 0, ReLU by default."""
+    L.require_gpu()
+    cin = int(inputs.shape[-1])
+    w, b, _ = declare_fully_connected(scope, cin, num_outputs, use_xavier, stddev, bn)
+    with variable_scope(scope):
+        return _dense(inputs.reshape(-1, cin), w, b, bn, "bn", activation_fn, bn_decay, is_training)
 
 
 def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
-    """utils/tf_util.py:349-372; EPC-Net-L uses it as the global max over N (models/epc-net-l.py:91)."""
-    _op_level_pending("max_pool2d", "utils/tf_util.py:349-372")
+    """utils/tf_util.py:349-372.  EPC-Net-L's only use is the global max over the N points of a (B,N,1,C) map
+    (models/epc-net-l.py:88-92); that is the one configuration implemented."""
+    if inputs.dim() != 4 or list(kernel_size) != [int(inputs.shape[1]), int(inputs.shape[2])] or padding != 'VALID':
+        raise NotImplementedError("max_pool2d is implemented for the global pool of models/epc-net-l.py:91 only")
+    return torch.amax(inputs, dim=(1, 2), keepdim=True)
 
 
 def _unused(name, where):

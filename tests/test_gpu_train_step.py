@@ -1,0 +1,118 @@
+"""GPU tests of the training step (config c3; train.py:251-277) against the float64 torch gradient oracle, and of the
+op-by-op (unfused) model path against the fused inference engine."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from helpers import O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("arch,nneg", [("epc-net", 14), ("epc-net", 18), ("epc-net-l", 14)])
+def test_train_step_matches_gradient_oracle(dev, arch, nneg):
+    import epcnet_oracle_torch as T
+    n = 256
+    ncl = 1 + 2 + nneg + 1                                   # 18 (reference config) or 22 (BASELINE.json "18 neg")
+    w0 = O.seeded_weights(arch, 4)
+    pcs = O.synthetic_clouds(ncl, n, 9)
+    q, pos, neg, oth = pcs[None, :1], pcs[None, 1:3], pcs[None, 3:3 + nneg], pcs[None, 3 + nneg:]
+    step0, epoch = 3, 7                                      # non-trivial bias correction and LR decay
+    ref = T.train_step(w0, q, pos, neg, oth, step=step0, epoch=epoch, arch=arch)
+
+    st = H.make_store(arch, w0, dev)
+    TR = H.pkg("training")
+    params = dict(H.PARAMS, ARCH=arch, BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5,
+                  MARGIN_1=0.5, MARGIN_2=0.2)
+    ts = TR.TrainStep(params, st, outer=H.OUTER)
+    ts.global_step = step0
+    # capture gradients before Adam consumes them
+    grads = {}
+    orig = H.pkg("ops").adam_step
+
+    def spy(w, m, v, g, lr, t, *a):
+        for k, t_ in st.vars.items():
+            if t_.data_ptr() == w.data_ptr():
+                grads[k] = g.detach().cpu().numpy().copy()
+        return orig(w, m, v, g, lr, t, *a)
+
+    H.pkg("ops").adam_step = spy
+    TR.ops.adam_step = spy
+    try:
+        to = lambda a: torch.from_numpy(a).to(dev)
+        loss, lr, bn_decay = ts.step(to(q), to(pos), to(neg), to(oth), epoch=epoch)
+    finally:
+        H.pkg("ops").adam_step = orig
+        TR.ops.adam_step = orig
+    torch.cuda.synchronize()
+
+    assert lr == pytest.approx(ref["lr"]) and bn_decay == pytest.approx(ref["bn_decay"])
+    assert float(loss) == pytest.approx(ref["loss"], rel=2e-5, abs=1e-6)
+    assert ts.global_step == step0 + 1
+    worst = 0.0
+    for k, g_ref in ref["grads"].items():
+        g = grads[H.OUTER + "/" + k].reshape(g_ref.shape)
+        scale = max(np.abs(g_ref).max(), 1e-7)
+        err = np.abs(g - g_ref).max() / scale
+        worst = max(worst, err)
+        assert err <= 5e-3, "gradient of %s: relative max error %.3e" % (k, err)
+    # moving averages (updated by the same run) and Adam-updated weights
+    for k, v_ref in ref["new_weights"].items():
+        v = st.vars[H.OUTER + "/" + k].detach().cpu().numpy().reshape(v_ref.shape)
+        assert np.abs(v - v_ref).max() <= 2e-6 + 2e-5 * np.abs(v_ref).max(), k
+    state = ts.optimizer_state()
+    assert int(state["Variable"]) == step0 + 1 and len([k for k in state if k.endswith("/Adam")]) == len(ref["grads"])
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+def test_unfused_inference_path_equals_fused_engine(dev, arch):
+    V = H.pkg("variables")
+    w = O.seeded_weights(arch, 2)
+    pc = O.synthetic_clouds(3, 512, 21)
+    ref, _ = O.forward(pc[:, None], w, arch=arch)
+    H.make_store(arch, w, dev)
+    M = H.pkg("models." + arch)
+    x = torch.from_numpy(pc).to(dev)
+    with V.variable_scope(H.OUTER), torch.no_grad():
+        unfused = M.forward_ops(x, False, None, H.PARAMS).cpu().numpy()
+        fused = M.forward(x[None], False, params=H.PARAMS).cpu().numpy()[0]
+    assert np.linalg.norm(unfused - ref.reshape(3, -1), axis=1).max() <= 1e-4
+    assert np.linalg.norm(unfused - fused, axis=1).max() <= 1e-5
+
+
+def test_op_level_conv1d_and_g_vlad_api(dev):
+    """Reference-style op calls: tf_util.conv1d(...) and lp.G_VLAD(...).forward(...) create the reference's variables
+    and compute what the oracle computes."""
+    V, tf_util, lp = H.pkg("variables"), H.pkg("utils.tf_util"), H.pkg("loupe")
+    st = V.reset_default_store(device=dev, seed=0)
+    x = torch.randn(2, 128, 64, device=dev)
+    with V.variable_scope("query_triplets"), V.variable_scope("fastdgcnn"), torch.no_grad():
+        y = tf_util.conv1d(x, 64, 1, padding='VALID', stride=1, bn=True, is_training=True, scope='conv2', bn_decay=0.5)
+    assert tuple(y.shape) == (2, 128, 64) and float(y.min()) >= 0.0
+    W = st.vars["query_triplets/fastdgcnn/conv2/weights"].reshape(64, 64).double().cpu()
+    z = x.double().cpu().reshape(-1, 64) @ W
+    zn = (z - z.mean(0)) / torch.sqrt(z.var(0, unbiased=False) + 1e-3)
+    assert np.abs(y.cpu().double().reshape(-1, 64) - torch.relu(zn)).max() <= 1e-4
+    m_name = [k for k in st.vars if k.endswith("conv2/bn/moments/Squeeze/ExponentialMovingAverage")][0]
+    assert np.allclose(st.vars[m_name].cpu().double(), 0.5 * z.mean(0), atol=1e-5)          # shadow 0 -> 0.5*mean
+    feats = torch.nn.functional.normalize(torch.rand(2 * 256, 1024, device=dev), dim=1)
+    with V.variable_scope("query_triplets"), V.variable_scope("VLAD"), torch.no_grad():
+        out = lp.G_VLAD(feature_size=1024, max_samples=256, cluster_size=64, output_dim=256, groups=4, gating=True,
+                        add_batch_norm=True, is_training=False).forward(feats)
+    assert tuple(out.shape) == (2, 256)
+    wts = {k[len("query_triplets/"):]: v.cpu().numpy() for k, v in st.vars.items() if "/VLAD/" in k}
+    ref = O.g_vlad_forward(O.State(wts, np.float32), feats.cpu().numpy(), 256, 4, False)
+    assert _rel(out.cpu().numpy(), ref) <= 1e-4
