@@ -106,4 +106,4 @@ def test_adam_matches_tensorflow_rule(dev):
     m2 = 0.9 * m64 + 0.1 * g64; v2 = 0.999 * v64 + 0.001 * g64 * g64
     lr_t = 5e-5 * np.sqrt(1 - 0.999 ** 7) / (1 - 0.9 ** 7)
     assert rel(md, m2) <= 1e-6 and rel(vd, v2) <= 2e-5      # (1 - 0.999f) is 0.00100005 in f32, as in TensorFlow's kernel
-    assert np.abs((wd.cpu().double() - (w64 - lr_t * m2 / (v2.sqrt() + 1e-8))).numpy()).max() <= 1e-7
+    assert np.abs((wd.cpu().double() - (w64 - lr_t * m2 / (v2.sqrt() + 1e-8))).numpy()).max() <= 5e-7   # f32 ulp of |w| ~ 2 is 2.4e-7
