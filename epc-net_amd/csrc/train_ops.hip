@@ -121,7 +121,7 @@ extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const floa
 // Column reductions over rows: out[q][c] = sum_rows f_q(...).  Deterministic: per-block partials, then a fixed-order
 // finalize.  kind 0: {x}; kind 1: {(x-mean)^2}; kind 2: {dyr, dyr*zhat} with dyr = dy * (y > 0 or no relu).
 // ----------------------------------------------------------------------------------------------------------------
-#define CR_ROWS 256  // rows per block
+#define CR_ROWS 1024  // rows per block
 
 template <int KIND>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ aux,
@@ -161,14 +161,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int nq, float scale,
-                                          float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                                 int nq, float scale, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
     for (int q = 0; q < nq; ++q) {
         float s = 0.f;
-        for (int b = 0; b < nblocks; ++b) s += partial[((size_t)q * nblocks + b) * C + c];
-        out[(size_t)q * C + c] = s * scale;
+        if (c < C)
+            for (int b = rsub; b < nblocks; b += 4) s += partial[((size_t)q * nblocks + b) * C + c];
+        red[rsub][l] = s;
+        __syncthreads();
+        if (rsub == 0 && c < C) out[(size_t)q * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+        __syncthreads();
     }
 }
 
@@ -191,9 +196,9 @@ extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, flo
     dim3 grid(nb, (C + 63) / 64);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, mean);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, mean);
     hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, st, x, nullptr, nullptr, mean, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, var);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, var);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -211,7 +216,7 @@ extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* wo
     float* part = (float*)workspace;
     hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f, out);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -284,8 +289,8 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* y,
     hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, z, dy, y, mean, rstd_out, rows, C,
                        relu, part);
     // partial layout [2][nb][C] -> dbeta = q0, dgamma = q1; finalize writes out[q*C + c]: use a 2*C temp = part tail
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, nb, C, 1, 1.0f, dbeta);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part + (size_t)nb * C, nb, C, 1,
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f, dbeta);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part + (size_t)nb * C, nb, C, 1,
                        1.0f, dgamma);
     const long total = (long)rows * C;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, z, y, mean,
@@ -358,15 +363,46 @@ extern "C" int epc_neighbour_mean_fwd(const float* x, const float* xyz, const in
     return EPC_OK;
 }
 
+// Scatter form: one wave per point, lane = channel, so every atomic wave-instruction adds 256 contiguous bytes (the
+// shape the f32 atomic units take at full rate; 16-byte pieces run several times slower).
+__global__ __launch_bounds__(256) void neighbour_scatter_kernel(const float* __restrict__ dxm, const float* __restrict__ xyz,
+                                                                const int32_t* __restrict__ idx,
+                                                                const int32_t* __restrict__ cnt,
+                                                                const float* __restrict__ kth, int cap, int total_points,
+                                                                int n, float kdiv, float* __restrict__ dx) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= total_points) return;
+    const int cloud_base = (g / n) * n;
+    const float v = dxm[(size_t)g * 64 + lane] / kdiv;
+    const int c = cnt[g];
+    if (c <= cap) {
+        const int mine = lane < c ? idx[(size_t)g * cap + lane] : 0;  // cap <= 64: one list entry per lane
+        for (int m = 0; m < c; ++m) {
+            const int j = __shfl(mine, m);
+            atomicAdd(dx + (size_t)(cloud_base + j) * 64 + lane, v);
+        }
+    } else {
+        const float* pc = xyz + (size_t)cloud_base * 3;
+        const int i = g - cloud_base;
+        const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
+        const float sqi = sq3(xi, yi, zi), kv = kth[g];
+        for (int j = 0; j < n; ++j) {
+            const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
+            if (neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj)) >= kv)
+                atomicAdd(dx + (size_t)(cloud_base + j) * 64 + lane, v);
+        }
+    }
+}
+
 // dx[j] += sum_{i : j in nbr(i)} dxm[i] / k.  dx must be zero-initialised (or hold the other gradient path).
 extern "C" int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
                                       const float* kth, int cap, int num_clouds, int n, int knn, float* dx,
                                       void* stream) {
     EPC_CHECK_ARG(dxm && xyz && idx && cnt && kth && dx, "null pointer");
-    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT, "bad shape");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
     const long total = (long)num_clouds * n;
-    hipLaunchKernelGGL(neighbour_mean_kernel<true>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, dxm, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, dx);
+    hipLaunchKernelGGL(neighbour_scatter_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dxm,
+                       xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, dx);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -65,6 +65,7 @@ def forward_ops(point_cloud, is_training, bn_decay, params):
     from .. import ops
     num_points = int(point_cloud.shape[1])
     k = params["KNN"]
+    point_cloud = ops.morton_sort(point_cloud)           # re-ordering only (permutation-invariant network)
     with variable_scope('fastdgcnn'):
         dpist = ops.KnnGraph(point_cloud)                    # tf_util.pairwise_distance_mask in index form (:63)
         nmean = lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), dpist, k).reshape(x.shape)  # matmul(dpist,x)/k

@@ -126,7 +126,7 @@ class KnnGraph:
 
     def __init__(self, xyz):
         from .utils import tf_util
-        self.xyz = xyz.contiguous().float()
+        self.xyz = xyz.contiguous().float()   # callers pass Z-ordered clouds (morton_sort) for speed; any order is exact
         self.num_clouds, self.n = int(xyz.shape[0]), int(xyz.shape[1])
         self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
 
@@ -215,6 +215,18 @@ class VladAggregate(torch.autograd.Function):
         df = gemm(a, dv, trans_b=True)   # (B,N,C) @ (B,F,C)^T -> (B,N,F)
         da = gemm(f, dv)                 # (B,N,F) @ (B,F,C)   -> (B,N,C)
         return df, da
+
+
+def morton_sort(xyz):
+    """Z-order every cloud of (B, N, 3) (epc_morton_sort): a pure re-ordering, legal because the whole network is
+    permutation-equivariant and the pooling invariant; it makes the kNN culling and the gathers cache-local."""
+    L.require_gpu()
+    xyz = xyz.contiguous().float()
+    if xyz.shape[1] > 16384:
+        return xyz
+    out = torch.empty_like(xyz)
+    L.check(L.lib().epc_morton_sort(xyz.data_ptr(), int(xyz.shape[0]), int(xyz.shape[1]), out.data_ptr(), None, _st()))
+    return out
 
 
 def adam_step(w, m, v, g, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
