@@ -121,7 +121,7 @@ extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const floa
 // Column reductions over rows: out[q][c] = sum_rows f_q(...).  Deterministic: per-block partials, then a fixed-order
 // finalize.  kind 0: {x}; kind 1: {(x-mean)^2}; kind 2: {dyr, dyr*zhat} with dyr = dy * (y > 0 or no relu).
 // ----------------------------------------------------------------------------------------------------------------
-#define CR_ROWS 1024  // rows per block
+#define CR_ROWS 256  // rows per block
 
 template <int KIND>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ aux,
