@@ -49,7 +49,9 @@ struct C5Lds {  // offsets in floats (4 B)
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
     static constexpr int OFF_CBN = OFF_B5 + 1024;
-    static constexpr int TOTAL = OFF_CBN + 128;
+    static constexpr int OFF_T = OFF_CBN + 128;            // per-wave 32 x 32 f32 transpose tile, row stride 36
+    static constexpr int T_WAVE = 33 * 36;         // + one spare row (the tile's 32 rnorm values)
+    static constexpr int TOTAL = OFF_T + 8 * T_WAVE;
 };
 
 // packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
@@ -60,6 +62,8 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            int n, float* __restrict__ feat,
                                                            float* __restrict__ rnorm,
                                                            float* __restrict__ assign,
+                                                           float* __restrict__ assign_frag,
+                                                           float* __restrict__ apart,
                                                            float* __restrict__ pooled) {
     using L = C5Lds<CIN>;
     constexpr int STEPS = CIN / 16;
@@ -175,11 +179,26 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
 #ifndef C5_ABL_NOSTORE
-            if (active) {
-                float* frow = feat + (size_t)(g0 + j) * 1024 + 32 * c + 4 * h;
+            {
+                // feat leaves the kernel as ready-made A fragments of the aggregate GEMM (V = feat^T a', K = points):
+                // transpose the 32 ch x 32 pt tile through the wave's LDS tile (channel -> lane, 8 consecutive points ->
+                // fragment), split hi/lo, store 1 KB per wave-instruction.  Layout: common.h (featF).
+                float* T = lds + L::OFF_T + wave * L::T_WAVE;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    st4(frow + 8 * g, make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]));
+                for (int r = 0; r < 16; ++r) T[mfma_row(r, h) * 36 + j] = acc[r];
+                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float v[8];
+                    const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
+                    v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+                    bf16x8 th, tl;
+                    split8(v, th, tl);
+                    if (active) {
+                        *reinterpret_cast<u32x4*>(fdst + (ks * 2 + 0) * 256) = __builtin_bit_cast(u32x4, th);
+                        *reinterpret_cast<u32x4*>(fdst + (ks * 2 + 1) * 256) = __builtin_bit_cast(u32x4, tl);
+                    }
+                }
             }
 #endif
             // accumulators -> split B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp)
@@ -277,12 +296,44 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 st4(arow + 32 * t + 8 * g, make_float4(P[t][4 * g] / sum, P[t][4 * g + 1] / sum,
                                                        P[t][4 * g + 2] / sum, P[t][4 * g + 3] / sum));
         if (h == 0) rnorm[g0 + j] = rn;
+        // a' = a * rn as B fragments of the aggregate GEMM (cluster -> lane, 8 consecutive points -> fragment) and the
+        // tile's partial a_sum (loupe.py:276).  rn of the tile's 32 points goes through the first row of the pad area.
+        float* T = lds + L::OFF_T + wave * L::T_WAVE;
+        float* fdst = assign_frag + (size_t)(g0 >> 5) * 2048 + lane * 4;
+        float asum[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[mfma_row(r, h) * 36 + j] = P[t][r] / sum;
+            if (t == 0 && h == 0) T[32 * 36 + j] = rn;   // 32 spare floats follow each wave's tile (T_WAVE has room: see below)
+            float s_ = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
+                const float4 r0 = ld4(T + 32 * 36 + 16 * ks + 8 * h), r1 = ld4(T + 32 * 36 + 16 * ks + 8 * h + 4);
+                v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s_ += v[q];
+                v[0] *= r0.x, v[1] *= r0.y, v[2] *= r0.z, v[3] *= r0.w, v[4] *= r1.x, v[5] *= r1.y, v[6] *= r1.z, v[7] *= r1.w;
+                bf16x8 th, tl;
+                split8(v, th, tl);
+                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 0) * 256) = __builtin_bit_cast(u32x4, th);
+                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 1) * 256) = __builtin_bit_cast(u32x4, tl);
+            }
+            asum[t] = s_ + __shfl_xor(s_, 32);
+        }
+        if (h == 0) {
+            apart[(size_t)(g0 >> 5) * 64 + j] = asum[0];
+            apart[(size_t)(g0 >> 5) * 64 + 32 + j] = asum[1];
+        }
     }
 }
 
 template <int CIN, int MODE>
 static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
-                        float* assign, float* pooled, hipStream_t stream, const char* who) {
+                        float* assign, float* assign_frag, float* apart, float* pooled, hipStream_t stream,
+                        const char* who) {
     const size_t lds_bytes = C5Lds<CIN>::TOTAL * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -292,7 +343,7 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
     }
     const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
     hipLaunchKernelGGL((conv5_kernel<CIN, MODE>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
-                       (int)total, n, feat, rnorm, assign, pooled);
+                       (int)total, n, feat, rnorm, assign, assign_frag, apart, pooled);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
@@ -302,13 +353,14 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
 }
 
 extern "C" int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
-                                    float* feat, float* rnorm, float* assign, void* stream) {
-    EPC_CHECK_ARG(cat && packed_conv5 && feat && rnorm && assign, "null pointer");
+                                    float* feat_frag, float* rnorm, float* assign, float* assign_frag, float* apart,
+                                    void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, feat, rnorm, assign,
-                                        nullptr, (hipStream_t)stream, __func__);
+    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, feat_frag, rnorm, assign,
+                                        assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
 }
 
 extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
@@ -323,95 +375,82 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
         epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    return launch_conv5<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, pooled,
+    return launch_conv5<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr, pooled,
                                        (hipStream_t)stream, __func__);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * (assign[n][k] * rnorm[n]) per cloud, as an MFMA
-// GEMM with the point index as K.  Both operands are read with 128-B coalesced dword loads straight into
-// registers (A: 32 consecutive f of row n, B: 32 consecutive clusters of row n); no LDS.
-// One wave = 32*AGG_FT features x 64 clusters over a `splits`-th of the cloud's points.
+// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * a'[n][k] per cloud, a' = assign * rnorm, as a bf16x3
+// MFMA GEMM with the point index as K.  Both operands arrive as ready-made hi/lo fragments written by conv5_kernel
+// (featF / assignF, common.h): every load is one fully coalesced 1-KB wave-instruction and no conversion happens here,
+// so the kernel streams feat once from HBM (17 MB per cloud) and is bound by that read.
+// One wave = AGG_FT 32-feature tiles x 64 clusters over a `splits`-th of the cloud's 32-point tiles.
 // ---------------------------------------------------------------------------------------------------------------
 #define AGG_THREADS 256
 #ifndef AGG_FT
-#define AGG_FT 2  // 32-feature tiles per wave: 2 -> 64 accumulator registers, 4-5 waves/SIMD hide the load latency
+#define AGG_FT 4
 #endif
 
-__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat,
-                                                                     const float* __restrict__ rnorm,
-                                                                     const float* __restrict__ assign, int n,
-                                                                     int splits, float* __restrict__ vpart,
-                                                                     float* __restrict__ apart) {
+__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
+                                                                     const float* __restrict__ assign_frag, int n,
+                                                                     int splits, float* __restrict__ vpart) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int fg = blockIdx.x * 4 + wave;  // feature group of 32*AGG_FT features
+    const int fg = blockIdx.x * 4 + wave;  // group of AGG_FT chunks (32 features each)
     const int sp = blockIdx.y;
     const int cloud = blockIdx.z;
-    const int per = n / splits;
-    const size_t pt0 = (size_t)cloud * n + (size_t)sp * per;
-    const float* fbase = feat + pt0 * 1024 + fg * (32 * AGG_FT) + j;
-    const float* abase = assign + pt0 * 64 + j;
-    const float* rbase = rnorm + pt0;
+    const int tiles = n / 32, per = tiles / splits;
+    const size_t gt0 = (size_t)cloud * tiles + (size_t)sp * per;
 
     f32x16 acc[AGG_FT][2];
 #pragma unroll
     for (int t = 0; t < AGG_FT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
-    float as0 = 0.f, as1 = 0.f;
 
-    for (int nn = 0; nn < per; nn += 8) {
-        float a[4][AGG_FT], b0[4], b1[4];
+    for (int tt = 0; tt < per; ++tt) {
+        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 1024 + lane * 4;
+        const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pt = nn + 2 * u + h;
-            const float r = rbase[pt];
-            const float v0 = abase[(size_t)pt * 64];
-            const float v1 = abase[(size_t)pt * 64 + 32];
-            as0 += v0;
-            as1 += v1;
-            b0[u] = v0 * r;
-            b1[u] = v1 * r;
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bh[2], bl[2];
 #pragma unroll
-            for (int t = 0; t < AGG_FT; ++t) a[u][t] = fbase[(size_t)pt * 1024 + 32 * t];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < AGG_FT; ++t) {
-                acc[t][0] = mfma32(a[u][t], b0[u], acc[t][0]);
-                acc[t][1] = mfma32(a[u][t], b1[u], acc[t][1]);
+            for (int t = 0; t < 2; ++t) {
+                bh[t] = ldfrag(fb + ((t * 2 + ks) * 2 + 0) * 256);
+                bl[t] = ldfrag(fb + ((t * 2 + ks) * 2 + 1) * 256);
             }
+#pragma unroll
+            for (int c = 0; c < AGG_FT; ++c) {
+                const bf16x8 ah = ldfrag(fa + (size_t)c * 1024 + (ks * 2 + 0) * 256);
+                const bf16x8 al = ldfrag(fa + (size_t)c * 1024 + (ks * 2 + 1) * 256);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[c][t] = mfma_bf16(al, bh[t], acc[c][t]);
+                    acc[c][t] = mfma_bf16(ah, bl[t], acc[c][t]);
+                    acc[c][t] = mfma_bf16(ah, bh[t], acc[c][t]);
+                }
+            }
+        }
     }
     float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
 #pragma unroll
-    for (int t = 0; t < AGG_FT; ++t)
+    for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = fg * (32 * AGG_FT) + 32 * t + mfma_row(r, h);
-            vout[(size_t)f * 64 + j] = acc[t][0][r];
-            vout[(size_t)f * 64 + 32 + j] = acc[t][1][r];
+            const int f = (fg * AGG_FT + c) * 32 + mfma_row(r, h);
+            vout[(size_t)f * 64 + j] = acc[c][0][r];
+            vout[(size_t)f * 64 + 32 + j] = acc[c][1][r];
         }
-    if (fg == 0) {
-        as0 += __shfl_xor(as0, 32);
-        as1 += __shfl_xor(as1, 32);
-        if (h == 0) {
-            float* ao = apart + ((size_t)cloud * splits + sp) * 64;
-            ao[j] = as0;
-            ao[32 + j] = as1;
-        }
-    }
 }
 
-extern "C" int epc_vlad_aggregate_fwd(const float* feat, const float* rnorm, const float* assign, int num_clouds,
-                                      int n, int splits, float* vpart, float* apart, void* stream) {
-    EPC_CHECK_ARG(feat && rnorm && assign && vpart && apart, "null pointer");
-    EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (8 * splits) == 0, "num_points must be a multiple of 8*splits");
+extern "C" int epc_vlad_aggregate_fwd(const float* feat_frag, const float* assign_frag, int num_clouds, int n, int splits,
+                                      float* vpart, void* stream) {
+    EPC_CHECK_ARG(feat_frag && assign_frag && vpart, "null pointer");
+    EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (32 * splits) == 0, "num_points must be a multiple of 32*splits");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && splits <= 65535, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(8 / AGG_FT, splits, num_clouds), dim3(AGG_THREADS), 0,
-                       (hipStream_t)stream, feat, rnorm, assign, n, splits, vpart, apart);
+                       (hipStream_t)stream, feat_frag, assign_frag, n, splits, vpart);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -9,14 +9,18 @@
 // ---- H1a: V = sum of the aggregate's partial slabs - a_sum * centres; per-cluster sum of squares (partial) ----------
 // grid (16 row slabs, clouds) x 256 threads: thread (k = tid & 63, r = tid >> 6) owns rows 64*slab + r + 4m, m < 16.
 __global__ __launch_bounds__(256) void vlad_reduce_kernel(const float* __restrict__ vpart,
-                                                          const float* __restrict__ apart, int splits,
+                                                          const float* __restrict__ apart, int splits, int asplits,
                                                           const float* __restrict__ centres,
                                                           float* __restrict__ V, float* __restrict__ colss) {
     __shared__ float red[4][64];
     const int slab = blockIdx.x, cloud = blockIdx.y;
     const int k = threadIdx.x & 63, r = threadIdx.x >> 6;
     float asum = 0.f;
-    for (int s = 0; s < splits; ++s) asum += apart[((size_t)cloud * splits + s) * 64 + k];
+    for (int s = r; s < asplits; s += 4) asum += apart[((size_t)cloud * asplits + s) * 64 + k];
+    red[r][k] = asum;
+    __syncthreads();
+    asum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    __syncthreads();
     float ss = 0.f;
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) {
@@ -175,12 +179,13 @@ extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
     return u + yp + v + cs;
 }
 
-extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, const void* packed_head,
+extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, int asplits,
+                                 const void* packed_head,
                                  int groups, int num_clouds, float* out, void* workspace, size_t workspace_bytes,
                                  void* stream) {
     EPC_CHECK_ARG(vpart && apart && packed_head && out && workspace, "null pointer");
     EPC_CHECK_ARG(groups > 0 && 64 % groups == 0, "GROUPS must divide 64");
-    EPC_CHECK_ARG(splits >= 1 && num_clouds >= 0, "bad shape");
+    EPC_CHECK_ARG(splits >= 1 && asplits >= 1 && num_clouds >= 0, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     if (workspace_bytes < epc_vlad_head_workspace_bytes(num_clouds, groups)) {
         epc_set_error("epc_vlad_head_fwd: workspace too small");
@@ -201,7 +206,7 @@ extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int spl
     float* colss = (float*)wsp;
     hipStream_t st = (hipStream_t)stream;
     EPC_CHECK_ARG(num_clouds <= 65535, "too many clouds per call");
-    hipLaunchKernelGGL(vlad_reduce_kernel, dim3(16, num_clouds), dim3(256), 0, st, vpart, apart, splits, centres, V,
+    hipLaunchKernelGGL(vlad_reduce_kernel, dim3(16, num_clouds), dim3(256), 0, st, vpart, apart, splits, asplits, centres, V,
                        colss);
     EPC_CHECK_LAUNCH();
     switch (groups) {

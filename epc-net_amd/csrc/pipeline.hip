@@ -4,7 +4,11 @@
 //                                               -> conv5+maxpool -> fc head               (EPC-Net-L)
 #include "common.h"
 
-#define AGG_SPLITS 4
+#define AGG_SPLITS 4  // upper bound (workspace); the split actually used must divide the cloud's n/32 tiles
+static int agg_splits(int n) {
+    const int tiles = n / 32;
+    return tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);
+}
 
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -14,7 +18,7 @@ static int micro_batch(const epc_cfg* c, int num_clouds) {
 }
 
 struct WsLayout {
-    size_t sorted, idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, vpart, apart, head, pooled, total;
+    size_t sorted, idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, afrag, vpart, apart, head, pooled, total;
 };
 
 static WsLayout ws_layout(const epc_cfg* c, int mb) {
@@ -34,13 +38,14 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
     w.xb = take(M * 64 * 4);
     const int ccat = c->arch == EPC_ARCH_EPC_NET ? 256 : 128;
     w.cat = take(M * ccat * 4);
-    w.feat = w.rnorm = w.assign = w.vpart = w.apart = w.head = w.pooled = 0;
+    w.feat = w.rnorm = w.assign = w.afrag = w.vpart = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
         w.feat = take(M * 1024 * 4);
         w.rnorm = take(M * 4);
         w.assign = take(M * 64 * 4);
+        w.afrag = take(M * 64 * 4);
         w.vpart = take((size_t)mb * AGG_SPLITS * 65536 * 4);
-        w.apart = take((size_t)mb * AGG_SPLITS * 64 * 4);
+        w.apart = take(M / 32 * 64 * 4);
         w.head = take(epc_vlad_head_workspace_bytes(mb, c->groups));
     } else {
         w.pooled = take((size_t)mb * 1024 * 4);
@@ -181,12 +186,14 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
             float* vpart = (float*)(ws + w.vpart);
             float* apart = (float*)(ws + w.apart);
             TRY(mark(prof, EPC_STAGE_CONV5, stream));
-            TRY(epc_conv5_assign_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign,
-                                     stream));
+            float* afrag = (float*)(ws + w.afrag);
+            TRY(epc_conv5_assign_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign, afrag,
+                                     apart, stream));
             TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
-            TRY(epc_vlad_aggregate_fwd(feat, rnorm, assign, nc, n, AGG_SPLITS, vpart, apart, stream));
+            const int asp = agg_splits(n);
+            TRY(epc_vlad_aggregate_fwd(feat, afrag, nc, n, asp, vpart, stream));
             TRY(mark(prof, EPC_STAGE_HEAD, stream));
-            TRY(epc_vlad_head_fwd(vpart, apart, AGG_SPLITS, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
+            TRY(epc_vlad_head_fwd(vpart, apart, asp, n / 32, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
                                   ws + w.head, w.total - w.head, stream));
         } else {
             float* pooled = (float*)(ws + w.pooled);

@@ -129,23 +129,31 @@ int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx
                             const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
                             int n, int knn, float* out, int out_stride, int out_off, float* x_next, void* stream);
 
-/* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the
- * soft assignment.  cat (M, cin) -> feat (M,1024) UN-normalised conv5 output, rnorm (M) = rsqrt(max(|feat|^2,
- * 1e-12)), assign (M,64) = softmax(cluster_bn((feat*rnorm) @ cluster_weights)). */
-int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat,
-                         float* rnorm, float* assign, void* stream);
+/* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the soft
+ * assignment, in split-bf16 (x3) MFMA arithmetic with f32 accumulation (f32-accurate).  cat (M, cin) ->
+ *   feat_frag   (M/32, 32 chunks, 2 k-steps, {hi,lo}, 64 lanes, 8 bf16): the UN-normalised conv5 output as ready-made
+ *               MFMA A fragments of the aggregate GEMM: lane l of (tile g, chunk c, k-step s) holds channel 32c + (l&31)
+ *               at points 32g + 16s + 8(l>>5) + 0..7; value = hi + lo (16 significant bits);
+ *   rnorm (M)   rsqrt(max(|feat|^2, 1e-12));
+ *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major;
+ *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, {hi,lo}, 64 lanes, 8 bf16): assign*rnorm as B fragments (lane l of
+ *               (tile g, t, s): cluster 32t + (l&31) at points 32g + 16s + 8(l>>5) + 0..7);
+ *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276). */
+int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat_frag,
+                         float* rnorm, float* assign, float* assign_frag, float* apart, void* stream);
 
-/* loupe.py:276-292: vlad[f][k] = sum_n assign[n][k]*feat[n][f]*rnorm[n] - (sum_n assign[n][k]) * centres[f][k]
- * written as `splits` partial slabs vpart (num_clouds, splits, 1024, 64) + apart (num_clouds, splits, 64)
- * (summed, and the centre term applied, by epc_vlad_head_fwd). */
-int epc_vlad_aggregate_fwd(const float* feat, const float* rnorm, const float* assign, int num_clouds, int n,
-                           int splits, float* vpart, float* apart, void* stream);
+/* loupe.py:286-291: vlad[f][k] = sum_n feat[n][f]*assign[n][k]*rnorm[n] from the fragment-ordered operands, written as
+ * `splits` partial slabs vpart (num_clouds, splits, 1024, 64) (summed, and the a_sum*centres term of :292 applied, by
+ * epc_vlad_head_fwd). */
+int epc_vlad_aggregate_fwd(const float* feat_frag, const float* assign_frag, int num_clouds, int n, int splits,
+                           float* vpart, void* stream);
 
 /* loupe.py:292-331 + models/epc-net.py:153: centre subtraction, intra-normalisation, flatten + L2, grouped
- * hidden projection with the shared weight (+BN, summed over groups), context gating, final L2. */
+ * hidden projection with the shared weight (+BN, summed over groups), context gating, final L2.
+ * apart holds `asplits` a_sum partials per cloud. */
 size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups);
-int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, const void* packed_head, int groups,
-                      int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, int asplits, const void* packed_head,
+                      int groups, int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* models/epc-net-l.py:84-98: conv5 (128->1024)+BN+ReLU, global max over N, fc1 (1024->256)+BN+ReLU, L2. */
 int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
