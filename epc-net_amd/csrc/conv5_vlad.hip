@@ -16,7 +16,8 @@
 //
 // Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x CIN) lives in
 // registers as split B fragments (CIN/2 VGPRs hi + CIN/2 lo) for all 32 output chunks; W5 (hi+lo: 4 B per weight,
-// 1 MB) streams through a double-buffered LDS chunk shared by the 8 waves (one barrier per chunk).
+// 1 MB) streams through a double-buffered LDS chunk shared by the 8 waves (one barrier per chunk).  feat is written as
+// the hi/lo bf16 fragments the assignment GEMM consumes anyway (4 coalesced 1-KB stores per chunk).
 #include <type_traits>
 #include "common.h"
 
@@ -178,29 +179,6 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             wf[0][0] = wfrag(0, 0, 0), wf[0][1] = wfrag(0, 0, 1), wf[1][0] = wfrag(0, 1, 0), wf[1][1] = wfrag(0, 1, 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
-#ifndef C5_ABL_NOSTORE
-            {
-                // feat leaves the kernel as ready-made A fragments of the aggregate GEMM (V = feat^T a', K = points):
-                // transpose the 32 ch x 32 pt tile through the wave's LDS tile (channel -> lane, 8 consecutive points ->
-                // fragment), split hi/lo, store 1 KB per wave-instruction.  Layout: common.h (featF).
-                float* T = lds + L::OFF_T + wave * L::T_WAVE;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[mfma_row(r, h) * 36 + j] = acc[r];
-                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    float v[8];
-                    const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
-                    v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
-                    bf16x8 th, tl;
-                    split8(v, th, tl);
-                    if (active) {
-                        *reinterpret_cast<u32x4*>(fdst + (ks * 2 + 0) * 256) = __builtin_bit_cast(u32x4, th);
-                        *reinterpret_cast<u32x4*>(fdst + (ks * 2 + 1) * 256) = __builtin_bit_cast(u32x4, tl);
-                    }
-                }
-            }
-#endif
             // accumulators -> split B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
@@ -209,6 +187,15 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
                 bf16x8 fh, fl;
                 split8(v, fh, fl);
+#ifndef C5_ABL_NOSTORE
+                // feat leaves the kernel as the hi/lo fragments just computed (accumulator order: lane = point, element q =
+                // channel 32c + 16sp + 8(q>>2) + 4h + (q&3)): 1 KB per wave-instruction; the aggregate kernel transposes.
+                if (active) {
+                    float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
+                    *reinterpret_cast<u32x4*>(fdst + (sp * 2 + 0) * 256) = __builtin_bit_cast(u32x4, fh);
+                    *reinterpret_cast<u32x4*>(fdst + (sp * 2 + 1) * 256) = __builtin_bit_cast(u32x4, fl);
+                }
+#endif
                 bf16x8 wn[2][2];
                 if (sp == 0) wn[0][0] = wfrag(1, 0, 0), wn[0][1] = wfrag(1, 0, 1), wn[1][0] = wfrag(1, 1, 0), wn[1][1] = wfrag(1, 1, 1);
 #ifndef C5_ABL_NOASSIGN
@@ -381,19 +368,22 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 
 // ---------------------------------------------------------------------------------------------------------------
 // VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * a'[n][k] per cloud, a' = assign * rnorm, as a bf16x3
-// MFMA GEMM with the point index as K.  Both operands arrive as ready-made hi/lo fragments written by conv5_kernel
-// (featF / assignF, common.h): every load is one fully coalesced 1-KB wave-instruction and no conversion happens here,
-// so the kernel streams feat once from HBM (17 MB per cloud) and is bound by that read.
-// One wave = AGG_FT 32-feature tiles x 64 clusters over a `splits`-th of the cloud's 32-point tiles.
+// MFMA GEMM with the point index as K.  a' arrives as ready-made B fragments; feat arrives in conv5's accumulator
+// fragment order (lane = point, 8 channels per fragment) and is transposed here into A fragments (lane = channel, 8
+// consecutive points) through a per-wave 32x32 bf16 LDS tile (row stride 80 B: conflict-free b128 reads).  The kernel
+// streams feat once from HBM (17 MB per cloud) and is bound by that read; the transposition rides on idle LDS/VALU.
+// One wave = AGG_FT 32-feature chunks x 64 clusters over a `splits`-th of the cloud's 32-point tiles.
 // ---------------------------------------------------------------------------------------------------------------
 #define AGG_THREADS 256
 #ifndef AGG_FT
 #define AGG_FT 4
 #endif
+#define AGG_ROW 40  // bf16 per LDS row: 32 points + 8 pad
 
 __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
                                                                      const float* __restrict__ assign_frag, int n,
                                                                      int splits, float* __restrict__ vpart) {
+    __shared__ __attribute__((aligned(16))) unsigned short xt[4][2][32 * AGG_ROW];  // [wave][hi/lo][ch][pt]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int fg = blockIdx.x * 4 + wave;  // group of AGG_FT chunks (32 features each)
@@ -411,23 +401,42 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     for (int tt = 0; tt < per; ++tt) {
         const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 1024 + lane * 4;
         const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
+        u32x4 raw[AGG_FT][2][2];  // [chunk][s'][hi/lo]: all of the tile's feat loads are issued first
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bh[2], bl[2];
+        for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bh[t] = ldfrag(fb + ((t * 2 + ks) * 2 + 0) * 256);
-                bl[t] = ldfrag(fb + ((t * 2 + ks) * 2 + 1) * 256);
+            for (int q = 0; q < 4; ++q) raw[c][q >> 1][q & 1] = *reinterpret_cast<const u32x4*>(fa + (size_t)c * 1024 + q * 256);
+        bf16x8 bh[2][2], bl[2][2];  // [cluster tile][k-step]
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bh[t][ks] = ldfrag(fb + ((t * 2 + ks) * 2 + 0) * 256);
+                bl[t][ks] = ldfrag(fb + ((t * 2 + ks) * 2 + 1) * 256);
             }
 #pragma unroll
-            for (int c = 0; c < AGG_FT; ++c) {
-                const bf16x8 ah = ldfrag(fa + (size_t)c * 1024 + (ks * 2 + 0) * 256);
-                const bf16x8 al = ldfrag(fa + (size_t)c * 1024 + (ks * 2 + 1) * 256);
+        for (int c = 0; c < AGG_FT; ++c) {
+            // transpose: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) at point j
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const unsigned int w = raw[c][s2][part][m];
+                        const int row = 16 * s2 + 8 * (m >> 1) + 4 * h + 2 * (m & 1);
+                        xt[wave][part][row * AGG_ROW + j] = (unsigned short)(w & 0xffffu);
+                        xt[wave][part][(row + 1) * AGG_ROW + j] = (unsigned short)(w >> 16);
+                    }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xt[wave][0][j * AGG_ROW + 16 * ks + 8 * h]));
+                const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xt[wave][1][j * AGG_ROW + 16 * ks + 8 * h]));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    acc[c][t] = mfma_bf16(al, bh[t], acc[c][t]);
-                    acc[c][t] = mfma_bf16(ah, bl[t], acc[c][t]);
-                    acc[c][t] = mfma_bf16(ah, bh[t], acc[c][t]);
+                    acc[c][t] = mfma_bf16(al, bh[t][ks], acc[c][t]);
+                    acc[c][t] = mfma_bf16(ah, bl[t][ks], acc[c][t]);
+                    acc[c][t] = mfma_bf16(ah, bh[t][ks], acc[c][t]);
                 }
             }
         }

@@ -131,9 +131,9 @@ int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx
 
 /* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the soft
  * assignment, in split-bf16 (x3) MFMA arithmetic with f32 accumulation (f32-accurate).  cat (M, cin) ->
- *   feat_frag   (M/32, 32 chunks, 2 k-steps, {hi,lo}, 64 lanes, 8 bf16): the UN-normalised conv5 output as ready-made
- *               MFMA A fragments of the aggregate GEMM: lane l of (tile g, chunk c, k-step s) holds channel 32c + (l&31)
- *               at points 32g + 16s + 8(l>>5) + 0..7; value = hi + lo (16 significant bits);
+ *   feat_frag   (M/32, 32 chunks, 2 halves s, {hi,lo}, 64 lanes, 8 bf16): the UN-normalised conv5 output in the kernel's
+ *               accumulator-fragment order: lane l of (tile g, chunk c, half s) holds point 32g + (l&31), element q =
+ *               channel 32c + 16s + 8(q>>2) + 4(l>>5) + (q&3); value = hi + lo (16 significant bits);
  *   rnorm (M)   rsqrt(max(|feat|^2, 1e-12));
  *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major;
  *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, {hi,lo}, 64 lanes, 8 bf16): assign*rnorm as B fragments (lane l of

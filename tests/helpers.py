@@ -85,11 +85,11 @@ def run_stages(eng, xyz):
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         L.check(lib.epc_vlad_head_fwd(vpart.data_ptr(), apart.data_ptr(), S, n // 32, off(6), cfg.groups, nc,
                                       desc.data_ptr(), ws.data_ptr(), wsb, st))
-        # unpack the fragment order (include/epcnet.h): [tile g][chunk c][k-step s][hi/lo][lane l][e] ->
-        # feat[32g + 16s + 8(l>>5) + e][32c + (l&31)]
+        # unpack the fragment order (include/epcnet.h): [tile g][chunk c][half s][hi/lo][lane l][q] ->
+        # feat[32g + (l&31)][32c + 16s + 8(q>>2) + 4(l>>5) + (q&3)]
         ff = featf.float().sum(dim=3)                                  # hi + lo -> (G, 32, 2, 64, 8)
-        ff = ff.reshape(M // 32, 32, 2, 2, 32, 8)                      # (g, c, s, h, i, e)
-        feat = ff.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 1024)       # (g, s, h, e, c, i) -> point-major
+        ff = ff.reshape(M // 32, 32, 2, 2, 32, 2, 4)                   # (g, c, s, h, j, q>>2, q&3)
+        feat = ff.permute(0, 4, 1, 2, 5, 3, 6).reshape(nc, n, 1024)    # (g, j, c, s, q>>2, h, q&3) -> point-major
         af = assignf.float().sum(dim=3).reshape(M // 32, 2, 2, 2, 32, 8)
         aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64)       # assign * rnorm
         out.update(feat=feat, rnorm=rnorm, assign=assign, aprime=aprime, vpart=vpart, apart=apart)
