@@ -3,7 +3,7 @@
 //   xm  = (sum_{j in nbr(i)} x_j) / k         gather over the kNN index lists (the reference multiplies a dense
 //                                             (N,N) 0/1 mask: 2.15 GFLOP per cloud and block; here 5.2 M adds)
 //   t   = xm - x
-//   t   = relu(bn(conv_a(t)))                 64x64, f32 MFMA, BN folded into the weights
+//   t   = relu(bn(conv_a(t)))                 64x64, bf16x3 MFMA (f32-accurate), BN folded into the weights
 //   t   = relu(bn(conv_b(t)))                 B operand = the previous accumulators (no LDS round trip)
 //   out = t + xm                  -> concat buffer slice (models/epc-net.py:134)
 //   x'  = relu(bn(conv_{b+1}(out)))           the next block's leading conv, fused (grid-wide dependency sits
@@ -41,41 +41,52 @@ __device__ __forceinline__ void relu16(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
 }
 
-// 64->64 layer whose B operand comes from a staged [pt][64] row: lane-half h holds channels 32h..32h+31.
-__device__ __forceinline__ void layer_split64(const float* lw, const float* lbias, const float (&bop)[32],
-                                              f32x16 (&acc)[2], int lane) {
+__device__ __forceinline__ bf16x8 ldfrag(const float* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// The three 64x64 layers run on the bf16 MFMA in split (bf16x3) arithmetic like conv5: 24 MFMAs of 32
+// cycles per layer instead of 64 f32 MFMAs of 64 cycles.  Weight fragments: pack.hip fold_pack_block_bf16_kernel.
+// 64->64 layer whose B operand comes from a staged [pt][64] row: k-step s = channels 16s + 8h .. +7 of the lane's point.
+__device__ __forceinline__ void layer_split64(const float* lw, const float* lbias, const bf16x8 (&bh)[4],
+                                              const bf16x8 (&bl)[4], f32x16 (&acc)[2], int lane) {
     const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         acc_init_bias(acc[t], lbias + 32 * t, h);
 #pragma unroll
-        for (int e4 = 0; e4 < 8; ++e4) {
-            const float4 a = ld4(lw + ((t * 8 + e4) * 64 + lane) * 4);
-            acc[t] = mfma32(a.x, bop[4 * e4 + 0], acc[t]);
-            acc[t] = mfma32(a.y, bop[4 * e4 + 1], acc[t]);
-            acc[t] = mfma32(a.z, bop[4 * e4 + 2], acc[t]);
-            acc[t] = mfma32(a.w, bop[4 * e4 + 3], acc[t]);
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ah = ldfrag(lw + (((t * 4 + s) * 2 + 0) * 64 + lane) * 4);
+            const bf16x8 al = ldfrag(lw + (((t * 4 + s) * 2 + 1) * 64 + lane) * 4);
+            acc[t] = mfma_bf16(al, bh[s], acc[t]);
+            acc[t] = mfma_bf16(ah, bl[s], acc[t]);
+            acc[t] = mfma_bf16(ah, bh[s], acc[t]);
         }
     }
 }
 
-// 64->64 layer whose B operand is the previous layer's accumulators.
+// 64->64 layer whose B operand is the previous layer's accumulators: k-step (tin, s') = registers 8s'..8s'+7 of tile tin.
 __device__ __forceinline__ void layer_acc64(const float* lw, const float* lbias, const f32x16 (&in)[2],
                                             f32x16 (&acc)[2], int lane) {
     const int h = lane >> 5;
+    bf16x8 fh[4], fl[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = in[st >> 1][8 * (st & 1) + q];
+        split8(v, fh[st], fl[st]);
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         acc_init_bias(acc[t], lbias + 32 * t, h);
 #pragma unroll
-        for (int tin = 0; tin < 2; ++tin) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 a = ld4(lw + ((t * 8 + 4 * tin + r4) * 64 + lane) * 4);
-                acc[t] = mfma32(a.x, in[tin][4 * r4 + 0], acc[t]);
-                acc[t] = mfma32(a.y, in[tin][4 * r4 + 1], acc[t]);
-                acc[t] = mfma32(a.z, in[tin][4 * r4 + 2], acc[t]);
-                acc[t] = mfma32(a.w, in[tin][4 * r4 + 3], acc[t]);
-            }
+        for (int st = 0; st < 4; ++st) {
+            const bf16x8 ah = ldfrag(lw + (((t * 4 + st) * 2 + 0) * 64 + lane) * 4);
+            const bf16x8 al = ldfrag(lw + (((t * 4 + st) * 2 + 1) * 64 + lane) * 4);
+            acc[t] = mfma_bf16(al, fh[st], acc[t]);
+            acc[t] = mfma_bf16(ah, fl[st], acc[t]);
+            acc[t] = mfma_bf16(ah, fh[st], acc[t]);
         }
     }
 }
@@ -91,15 +102,14 @@ __device__ __forceinline__ void acc_to_stage(float* st, const f32x16 (&acc)[2], 
                 make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]));
 }
 
-__device__ __forceinline__ void stage_to_bop(const float* st, float (&bop)[32], int lane) {
+// staged [pt][64] row of the lane's point -> split B fragments (k-step s = channels 16s + 8h .. +7)
+__device__ __forceinline__ void stage_to_bop(const float* st, bf16x8 (&bh)[4], bf16x8 (&bl)[4], int lane) {
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const float4 v = ld4(st + j * ST_STRIDE + 32 * h + 4 * u);
-        bop[4 * u + 0] = v.x;
-        bop[4 * u + 1] = v.y;
-        bop[4 * u + 2] = v.z;
-        bop[4 * u + 3] = v.w;
+    for (int s = 0; s < 4; ++s) {
+        const float4 a = ld4(st + j * ST_STRIDE + 16 * s + 8 * h), b = ld4(st + j * ST_STRIDE + 16 * s + 8 * h + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        split8(v, bh[s], bl[s]);
     }
 }
 
@@ -206,10 +216,10 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     }
 
     // ---- conv_a, conv_b ----
-    float bop[32];
+    bf16x8 bh[4], bl[4];
     f32x16 a1[2], a2[2];
-    stage_to_bop(st, bop, lane);
-    layer_split64(wa, ba, bop, a1, lane);
+    stage_to_bop(st, bh, bl, lane);
+    layer_split64(wa, ba, bh, bl, a1, lane);
     relu16(a1[0]);
     relu16(a1[1]);
     layer_acc64(wb, bb, a1, a2, lane);
@@ -229,8 +239,8 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     if (!has_next) return;
 
     // ---- next block's leading conv ----
-    stage_to_bop(st, bop, lane);
-    layer_split64(wn, bn, bop, a1, lane);
+    stage_to_bop(st, bh, bl, lane);
+    layer_split64(wn, bn, bh, bl, a1, lane);
     relu16(a1[0]);
     relu16(a1[1]);
     acc_to_stage(st, a1, lane);

@@ -65,27 +65,6 @@ __device__ __forceinline__ float bn_inv(const float* gamma, const float* var, in
     return (1.0f / sqrtf(var[c] + BN_EPS)) * gamma[c];
 }
 
-// MFMA-ordered layer pack (common.h) with folded BN.  W is [cin][cout] row-major.
-__global__ void fold_pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       const float* __restrict__ mean, const float* __restrict__ var, int cin,
-                                       int cout, int mode, float* __restrict__ dstW, float* __restrict__ dstB) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o < cin * cout) {
-        const int per_tile = 32 * cin;
-        const int tile = o / per_tile, rem = o % per_tile;
-        const int e4 = rem / 256, lane = (rem % 256) / 4, q = rem % 4;
-        const int e = 4 * e4 + q, h = lane >> 5;
-        const int chan = pack_chan(mode, cin, e, h);
-        const int col = 32 * tile + (lane & 31);
-        dstW[o] = W[(size_t)chan * cout + col] * bn_inv(gamma, var, col);
-    }
-    if (o < cout) {
-        const float inv = bn_inv(gamma, var, o);
-        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
-    }
-}
-
 // Row-major [cin][cout] with folded BN (conv1 3x64, fc1 1024x256).
 __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -118,6 +97,32 @@ __global__ void fold_pack_conv5_bf16_kernel(const float* __restrict__ W, const f
         dstW[base + 512] = lo;
     }
     if (o < 1024) {
+        const float inv = bn_inv(gamma, var, o);
+        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+    }
+}
+
+// 64x64 block layer for the split-bf16 MFMA: Wp[tile t (2)][k-step s (4)][part (hi,lo)][lane][8 bf16] + bias.
+// mode PACK_SPLIT: k-step s covers input channels 16s + 8h + q (B operand read from a staged [pt][ch] row);
+// mode PACK_ACC  : k-step s = 2*tin + s' covers 32tin + 16s' + 8(q>>2) + 4h + (q&3) (B = accumulators of the previous layer).
+__global__ void fold_pack_block_bf16_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            const float* __restrict__ mean, const float* __restrict__ var, int mode,
+                                            unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < 4096) {
+        const int q = o & 7, lane = (o >> 3) & 63, st = (o >> 9) & 3, t = o >> 11;
+        const int h = lane >> 5;
+        const int k = mode == PACK_SPLIT ? 16 * st + 8 * h + q : 32 * (st >> 1) + 16 * (st & 1) + 8 * (q >> 2) + 4 * h + (q & 3);
+        const int col = 32 * t + (lane & 31);
+        const float w = W[(size_t)k * 64 + col] * bn_inv(gamma, var, col);
+        const unsigned short hi = bf16_bits_rne(w);
+        const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        const size_t base = ((size_t)(t * 4 + st) * 2) * 512 + lane * 8 + q;
+        dstW[base] = hi;
+        dstW[base + 512] = lo;
+    }
+    if (o < 64) {
         const float inv = bn_inv(gamma, var, o);
         dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
     }
@@ -210,9 +215,9 @@ static int get_slim_bn(const NameTable& T, const std::string& scope, const float
     } while (0)
 
 static int launch_layer(const ConvVars& v, int cin, int cout, int mode, float* dst, hipStream_t st) {
-    const int total = cin * cout;
-    hipLaunchKernelGGL(fold_pack_layer_kernel, dim3((total + 255) / 256), dim3(256), 0, st, v.W, v.b, v.gamma,
-                       v.beta, v.mean, v.var, cin, cout, mode, dst, dst + total);
+    EPC_CHECK_ARG(cin == 64 && cout == 64, "block layers are 64x64");
+    hipLaunchKernelGGL(fold_pack_block_bf16_kernel, dim3(16), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var,
+                       mode, (unsigned short*)dst, dst + 4096);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
