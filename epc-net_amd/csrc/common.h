@@ -39,6 +39,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// fp16 form of the same instruction (v_mfma_f32_32x32x16_f16): same rate and operand layout as the bf16 one.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// scale of the fp16 assignment fragments between epc_conv5_assign_fwd and epc_vlad_aggregate_fwd (exact power of two)
+#define AGG_ASSIGN_SCALE 16384.0f
+
 // Split-bf16 ("bf16x3") arithmetic: x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi);
 // a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, accumulated in f32 by the MFMA.  Measured on the whole network this
 // keeps the descriptor within 4e-7 of the f32 oracle (plain bf16: 1.7e-4, over the 1e-4 budget) -- DESIGN.md 4.

@@ -188,12 +188,16 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 bf16x8 fh, fl;
                 split8(v, fh, fl);
 #ifndef C5_ABL_NOSTORE
-                // feat leaves the kernel as the hi/lo fragments just computed (accumulator order: lane = point, element q =
-                // channel 32c + 16sp + 8(q>>2) + 4h + (q&3)): 1 KB per wave-instruction; the aggregate kernel transposes.
+                // feat leaves the kernel as ONE fp16 fragment per accumulator half (accumulator order: lane = point,
+                // element q = channel 32c + 16sp + 8(q>>2) + 4h + (q&3)): 1 KB per wave-instruction, 2 B per value; the
+                // aggregate kernel scales by rnorm and transposes.  (fp16 keeps 11 significant bits of a value that is
+                // then averaged over the cloud's points: measured descriptor effect 7e-7)
                 if (active) {
-                    float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
-                    *reinterpret_cast<u32x4*>(fdst + (sp * 2 + 0) * 256) = __builtin_bit_cast(u32x4, fh);
-                    *reinterpret_cast<u32x4*>(fdst + (sp * 2 + 1) * 256) = __builtin_bit_cast(u32x4, fl);
+                    f16x8 fs;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fs[q] = (_Float16)v[q];
+                    float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 512 + lane * 4;
+                    *reinterpret_cast<u32x4*>(fdst + sp * 256) = __builtin_bit_cast(u32x4, fs);
                 }
 #endif
                 bf16x8 wn[2][2];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             }
         }
 
-        // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 4 feat
+        // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 2 feat
         // stores issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of
         // the grid) and the atomic-max variant drain everything.
 #ifdef C5_ABL_NOSTORE
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #else
         if (MODE == MODE_VLAD && active)
 #endif
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -283,30 +287,29 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 st4(arow + 32 * t + 8 * g, make_float4(P[t][4 * g] / sum, P[t][4 * g + 1] / sum,
                                                        P[t][4 * g + 2] / sum, P[t][4 * g + 3] / sum));
         if (h == 0) rnorm[g0 + j] = rn;
-        // a' = a * rn as B fragments of the aggregate GEMM (cluster -> lane, 8 consecutive points -> fragment) and the
-        // tile's partial a_sum (loupe.py:276).  rn of the tile's 32 points goes through the first row of the pad area.
+        // a * 2^14 as fp16 B fragments of the aggregate GEMM (cluster -> lane, 8 consecutive points -> fragment) and the
+        // tile's partial a_sum (loupe.py:276).  The 2^14 keeps small assignments in fp16's normal range; it is exact
+        // and the aggregate kernel removes it.  rnorm is applied on the feature side there.
         float* T = lds + L::OFF_T + wave * L::T_WAVE;
-        float* fdst = assign_frag + (size_t)(g0 >> 5) * 2048 + lane * 4;
+        float* fdst = assign_frag + (size_t)(g0 >> 5) * 1024 + lane * 4;
         float asum[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[mfma_row(r, h) * 36 + j] = P[t][r] / sum;
-            if (t == 0 && h == 0) T[32 * 36 + j] = rn;   // 32 spare floats follow each wave's tile (T_WAVE has room: see below)
             float s_ = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 float v[8];
                 const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
-                const float4 r0 = ld4(T + 32 * 36 + 16 * ks + 8 * h), r1 = ld4(T + 32 * 36 + 16 * ks + 8 * h + 4);
                 v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+                f16x8 th;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s_ += v[q];
-                v[0] *= r0.x, v[1] *= r0.y, v[2] *= r0.z, v[3] *= r0.w, v[4] *= r1.x, v[5] *= r1.y, v[6] *= r1.z, v[7] *= r1.w;
-                bf16x8 th, tl;
-                split8(v, th, tl);
-                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 0) * 256) = __builtin_bit_cast(u32x4, th);
-                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 1) * 256) = __builtin_bit_cast(u32x4, tl);
+                for (int q = 0; q < 8; ++q) {
+                    s_ += v[q];
+                    th[q] = (_Float16)(v[q] * AGG_ASSIGN_SCALE);
+                }
+                *reinterpret_cast<u32x4*>(fdst + (t * 2 + ks) * 256) = __builtin_bit_cast(u32x4, th);
             }
             asum[t] = s_ + __shfl_xor(s_, 32);
         }
@@ -340,14 +343,14 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
 }
 
 extern "C" int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
-                                    float* feat_frag, float* rnorm, float* assign, float* assign_frag, float* apart,
+                                    void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
                                     void* stream) {
     EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, feat_frag, rnorm, assign,
-                                        assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
+    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, (float*)feat_frag, rnorm,
+                                        assign, (float*)assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
 }
 
 extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
@@ -367,23 +370,26 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n feat[n][f] * a'[n][k] per cloud, a' = assign * rnorm, as a bf16x3
-// MFMA GEMM with the point index as K.  a' arrives as ready-made B fragments; feat arrives in conv5's accumulator
-// fragment order (lane = point, 8 channels per fragment) and is transposed here into A fragments (lane = channel, 8
-// consecutive points) through a per-wave 32x32 bf16 LDS tile (row stride 80 B: conflict-free b128 reads).  The kernel
-// streams feat once from HBM (17 MB per cloud) and is bound by that read; the transposition rides on idle LDS/VALU.
+// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n (feat[n][f] * rnorm[n]) * a[n][k] per cloud, as an fp16 MFMA GEMM
+// (f32 accumulate) with the point index as K.  a arrives as ready-made fp16 B fragments (scaled by 2^14, removed at the
+// store); feat arrives as fp16 in conv5's accumulator-fragment order (lane = point, 8 channels per fragment): each lane
+// multiplies its 8 values by its point's rnorm in f32 (the normalised feature is <= 1: no range concern), rounds to fp16
+// and the wave transposes them into A fragments (lane = channel, 8 consecutive points) through a per-wave 32x32 LDS tile
+// (row stride 80 B: conflict-free b128 reads).  The kernel streams feat once from HBM (8.4 MB per cloud) and is bound by
+// that read; the scaling and transposition ride on idle VALU/LDS.
 // One wave = AGG_FT 32-feature chunks x 64 clusters over a `splits`-th of the cloud's 32-point tiles.
 // ---------------------------------------------------------------------------------------------------------------
 #define AGG_THREADS 256
 #ifndef AGG_FT
 #define AGG_FT 4
 #endif
-#define AGG_ROW 40  // bf16 per LDS row: 32 points + 8 pad
+#define AGG_ROW 40  // fp16 per LDS row: 32 points + 8 pad
 
 __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
-                                                                     const float* __restrict__ assign_frag, int n,
-                                                                     int splits, float* __restrict__ vpart) {
-    __shared__ __attribute__((aligned(16))) unsigned short xt[4][2][32 * AGG_ROW];  // [wave][hi/lo][ch][pt]
+                                                                     const float* __restrict__ assign_frag,
+                                                                     const float* __restrict__ rnorm, int n, int splits,
+                                                                     float* __restrict__ vpart) {
+    __shared__ __attribute__((aligned(16))) unsigned short xt[4][32 * AGG_ROW];  // [wave][ch][pt]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int fg = blockIdx.x * 4 + wave;  // group of AGG_FT chunks (32 features each)
@@ -399,67 +405,61 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 
     for (int tt = 0; tt < per; ++tt) {
-        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 1024 + lane * 4;
-        const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
-        u32x4 raw[AGG_FT][2][2];  // [chunk][s'][hi/lo]: all of the tile's feat loads are issued first
+        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4;
+        const float* fb = assign_frag + (gt0 + tt) * 1024 + lane * 4;
+        u32x4 raw[AGG_FT][2];  // [chunk][s']: all of the tile's feat loads are issued first
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) raw[c][q >> 1][q & 1] = *reinterpret_cast<const u32x4*>(fa + (size_t)c * 1024 + q * 256);
-        bf16x8 bh[2][2], bl[2][2];  // [cluster tile][k-step]
+            for (int q = 0; q < 2; ++q) raw[c][q] = *reinterpret_cast<const u32x4*>(fa + (size_t)c * 512 + q * 256);
+        const float rn = rnorm[(gt0 + tt) * 32 + j];
+        f16x8 bf[2][2];  // [cluster tile][k-step]
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bh[t][ks] = ldfrag(fb + ((t * 2 + ks) * 2 + 0) * 256);
-                bl[t][ks] = ldfrag(fb + ((t * 2 + ks) * 2 + 1) * 256);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+                bf[t][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(fb + (t * 2 + ks) * 256));
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c) {
-            // transpose: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) at point j
+            // scale + transpose: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) at point j
 #pragma unroll
-            for (int part = 0; part < 2; ++part)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f16x8 fv = __builtin_bit_cast(f16x8, raw[c][s2]);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const unsigned int w = raw[c][s2][part][m];
-                        const int row = 16 * s2 + 8 * (m >> 1) + 4 * h + 2 * (m & 1);
-                        xt[wave][part][row * AGG_ROW + j] = (unsigned short)(w & 0xffffu);
-                        xt[wave][part][(row + 1) * AGG_ROW + j] = (unsigned short)(w >> 16);
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const _Float16 y = (_Float16)((float)fv[q] * rn);
+                    const int row = 16 * s2 + 8 * (q >> 2) + 4 * h + (q & 3);
+                    xt[wave][row * AGG_ROW + j] = __builtin_bit_cast(unsigned short, y);
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xt[wave][0][j * AGG_ROW + 16 * ks + 8 * h]));
-                const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xt[wave][1][j * AGG_ROW + 16 * ks + 8 * h]));
+                const f16x8 af = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&xt[wave][j * AGG_ROW + 16 * ks + 8 * h]));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[c][t] = mfma_bf16(al, bh[t][ks], acc[c][t]);
-                    acc[c][t] = mfma_bf16(ah, bl[t][ks], acc[c][t]);
-                    acc[c][t] = mfma_bf16(ah, bh[t][ks], acc[c][t]);
-                }
+                for (int t = 0; t < 2; ++t) acc[c][t] = mfma_f16(af, bf[t][ks], acc[c][t]);
             }
         }
     }
     float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
+    constexpr float unscale = 1.0f / AGG_ASSIGN_SCALE;
 #pragma unroll
     for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = (fg * AGG_FT + c) * 32 + mfma_row(r, h);
-            vout[(size_t)f * 64 + j] = acc[c][0][r];
-            vout[(size_t)f * 64 + 32 + j] = acc[c][1][r];
+            vout[(size_t)f * 64 + j] = acc[c][0][r] * unscale;
+            vout[(size_t)f * 64 + 32 + j] = acc[c][1][r] * unscale;
         }
 }
 
-extern "C" int epc_vlad_aggregate_fwd(const float* feat_frag, const float* assign_frag, int num_clouds, int n, int splits,
-                                      float* vpart, void* stream) {
-    EPC_CHECK_ARG(feat_frag && assign_frag && vpart, "null pointer");
+extern "C" int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm,
+                                      int num_clouds, int n, int splits, float* vpart, void* stream) {
+    EPC_CHECK_ARG(feat_frag && assign_frag && rnorm && vpart, "null pointer");
     EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (32 * splits) == 0, "num_points must be a multiple of 32*splits");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && splits <= 65535, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(8 / AGG_FT, splits, num_clouds), dim3(AGG_THREADS), 0,
-                       (hipStream_t)stream, feat_frag, assign_frag, n, splits, vpart);
+                       (hipStream_t)stream, (const float*)feat_frag, (const float*)assign_frag, rnorm, n, splits, vpart);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

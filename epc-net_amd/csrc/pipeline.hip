@@ -40,10 +40,10 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
     w.cat = take(M * ccat * 4);
     w.feat = w.rnorm = w.assign = w.afrag = w.vpart = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
-        w.feat = take(M * 1024 * 4);
+        w.feat = take(M * 1024 * 2);   // fp16 fragments
         w.rnorm = take(M * 4);
         w.assign = take(M * 64 * 4);
-        w.afrag = take(M * 64 * 4);
+        w.afrag = take(M * 64 * 2);    // fp16 fragments
         w.vpart = take((size_t)mb * AGG_SPLITS * 65536 * 4);
         w.apart = take(M / 32 * 64 * 4);
         w.head = take(epc_vlad_head_workspace_bytes(mb, c->groups));
@@ -191,7 +191,7 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
                                      apart, stream));
             TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
             const int asp = agg_splits(n);
-            TRY(epc_vlad_aggregate_fwd(feat, afrag, nc, n, asp, vpart, stream));
+            TRY(epc_vlad_aggregate_fwd(feat, afrag, rnorm, nc, n, asp, vpart, stream));
             TRY(mark(prof, EPC_STAGE_HEAD, stream));
             TRY(epc_vlad_head_fwd(vpart, apart, asp, n / 32, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
                                   ws + w.head, w.total - w.head, stream));

@@ -131,22 +131,23 @@ int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx
 
 /* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the soft
  * assignment, in split-bf16 (x3) MFMA arithmetic with f32 accumulation (f32-accurate).  cat (M, cin) ->
- *   feat_frag   (M/32, 32 chunks, 2 halves s, {hi,lo}, 64 lanes, 8 bf16): the UN-normalised conv5 output in the kernel's
- *               accumulator-fragment order: lane l of (tile g, chunk c, half s) holds point 32g + (l&31), element q =
- *               channel 32c + 16s + 8(q>>2) + 4(l>>5) + (q&3); value = hi + lo (16 significant bits);
- *   rnorm (M)   rsqrt(max(|feat|^2, 1e-12));
- *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major;
- *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, {hi,lo}, 64 lanes, 8 bf16): assign*rnorm as B fragments (lane l of
+ *   feat_frag   (M/32, 32 chunks, 2 halves s, 64 lanes, 8 fp16) = 2 bytes per value: the UN-normalised conv5 output
+ *               rounded to fp16, in the kernel's accumulator-fragment order: lane l of (tile g, chunk c, half s) holds
+ *               point 32g + (l&31), element q = channel 32c + 16s + 8(q>>2) + 4(l>>5) + (q&3).  Range: values must be
+ *               below 65504 (a BN+ReLU output);
+ *   rnorm (M)   rsqrt(max(|feat|^2, 1e-12)) from the f32 values;
+ *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major (from the f32-accurate feat);
+ *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, 64 lanes, 8 fp16): assign * 2^14 as B fragments (lane l of
  *               (tile g, t, s): cluster 32t + (l&31) at points 32g + 16s + 8(l>>5) + 0..7);
  *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276). */
-int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat_frag,
-                         float* rnorm, float* assign, float* assign_frag, float* apart, void* stream);
+int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, void* feat_frag,
+                         float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
 
-/* loupe.py:286-291: vlad[f][k] = sum_n feat[n][f]*assign[n][k]*rnorm[n] from the fragment-ordered operands, written as
- * `splits` partial slabs vpart (num_clouds, splits, 1024, 64) (summed, and the a_sum*centres term of :292 applied, by
- * epc_vlad_head_fwd). */
-int epc_vlad_aggregate_fwd(const float* feat_frag, const float* assign_frag, int num_clouds, int n, int splits,
-                           float* vpart, void* stream);
+/* loupe.py:286-291: vlad[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] from the fragment-ordered operands (fp16
+ * MFMA, f32 accumulate; the 2^14 of assign_frag is removed), written as `splits` partial slabs vpart
+ * (num_clouds, splits, 1024, 64) (summed, and the a_sum*centres term of :292 applied, by epc_vlad_head_fwd). */
+int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, int num_clouds, int n,
+                           int splits, float* vpart, void* stream);
 
 /* loupe.py:292-331 + models/epc-net.py:153: centre subtraction, intra-normalisation, flatten + L2, grouped
  * hidden projection with the shared weight (+BN, summed over groups), context gating, final L2.

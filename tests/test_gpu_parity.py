@@ -131,16 +131,20 @@ def test_stages_against_oracle(dev, arch, kind, n):
         if b < nblocks:
             close(got["xs"][b], st.taps["fastdgcnn/conv%d" % (b + 1)], 2e-5, "conv%d" % (b + 1))
     if arch == "epc-net":
-        close(got["feat"], st.taps["fastdgcnn/conv5"], 3e-5, "conv5 (fragment order, hi+lo)")
+        # feat is stored as fp16 (11 significant bits): half an ulp of the largest value
+        close(got["feat"], st.taps["fastdgcnn/conv5"], 2.0 ** -11, "conv5 (fp16 fragment order)")
         close(got["assign"].reshape(-1, 64), st.taps["vlad_assign"], 1e-4, "assign")
-        close(got["aprime"], got["assign"].cpu().numpy() * got["rnorm"].cpu().numpy()[..., None], 3e-5, "assign*rnorm fragments")
+        close(got["aprime"], got["assign"].cpu().numpy() * got["rnorm"].cpu().numpy()[..., None], 2.0 ** -11,
+              "assign fragments (fp16)")
         v = got["vpart"].sum(1).cpu().numpy()
         asum = got["apart"].sum(1).cpu().numpy()
         v = v - asum[:, None, :] * eng.store.vars["query_triplets/VLAD/cluster_weights2"].cpu().numpy()
-        close(v, st.taps["vlad_raw"], 1e-4, "vlad")
+        # worst case = the all-zero padding cloud (every point identical: the fp16 rounding of feat does not average out)
+        close(v, st.taps["vlad_raw"], 2.0 ** -11, "vlad")
     else:
         close(got["pooled"], st.taps["maxpool"], 2e-5, "maxpool")
     err = np.linalg.norm(got["desc"].cpu().numpy() - ref, axis=1).max()
+    print("descriptor L2 error %s %s n=%d: %.3e" % (arch, kind, n, err))
     assert err <= DESC_TOL, "descriptor L2 error %.3e" % err
 
 
