@@ -44,6 +44,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// conv5 / assignment weights are packed as fp16 hi + lo fragments of W * W5_SCALE (2^8 keeps the lo parts of ordinary
+// weights in fp16's normal range; biases are packed with the same factor and the kernel multiplies the result by
+// 2^-8).  With ONE fp16 value per activation the product is x16*W_hi + x16*W_lo, f32 accumulate: two MFMAs per f32 product.
+// The activation's rounding (2^-12 relative, independent per point and channel) averages out over the 256-term dot
+// product and the cloud's points: measured descriptor error 1e-6; a weight rounded to one fp16 would be a
+// systematic error (2e-5) -- hence the split on the weight side.
+#define W5_SCALE 256.0f
 // scale of the fp16 assignment fragments between epc_conv5_assign_fwd and epc_vlad_aggregate_fwd (exact power of two)
 #define AGG_ASSIGN_SCALE 16384.0f
 

@@ -30,6 +30,9 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ bf16x8 ldfrag(const float* p) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
 }
+__device__ __forceinline__ f16x8 ldfrag16(const float* p) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
+}
 // 16 bytes per lane, global -> LDS without a VGPR destination (LDS-DMA): lane l reads uniform_base + lane_byte_off and lands at LDS byte
 // address lds_dst + 16*l (uniform_base and lds_dst wave-uniform, in SGPRs).  Written as inline asm on purpose: with the builtin hipcc (ROCm 7.2) drains
 // vmcnt(0) before the next ds_read of the same __shared__ array, which would serialise the prefetch; the asm form is
@@ -104,8 +107,14 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
 
-    // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7
-    bf16x8 xh[STEPS], xl[STEPS];
+    // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7.
+    // VLAD mode: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
+    // common.h) -- the input rounding averages out over the cloud's points in the aggregation.  Max-pool mode keeps one
+    // point's value per channel, so nothing averages: it stays on the f32-accurate split-bf16 form (three MFMAs).
+    constexpr bool kF16 = MODE == MODE_VLAD;
+    constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
+    f16x8 xf[kF16 ? STEPS : 1];
+    bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
     {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
 #pragma unroll
@@ -114,7 +123,12 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-            split8(v, xh[s], xl[s]);
+            if constexpr (kF16) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xf[s][q] = (_Float16)v[q];
+            } else {
+                split8(v, xh[s], xl[s]);
+            }
         }
     }
 
@@ -147,24 +161,34 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
         {
             // fragment reads run one k-step ahead of the MFMAs that consume them
-            bf16x8 fa[2][2];
-            fa[0][0] = ldfrag(w5 + (0 * 64 + lane) * 4);
-            fa[0][1] = ldfrag(w5 + (1 * 64 + lane) * 4);
+            f16x8 fa[2][2];
+            fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
+            fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (s + 1 < STEPS) {
-                    fa[(s + 1) & 1][0] = ldfrag(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
-                    fa[(s + 1) & 1][1] = ldfrag(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
+                    fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
+                    fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
-                acc = mfma_bf16(fa[s & 1][1], xh[s], acc);
-                acc = mfma_bf16(fa[s & 1][0], xl[s], acc);
-                acc = mfma_bf16(fa[s & 1][0], xh[s], acc);
+                if constexpr (kF16) {
+                    acc = mfma_f16(fa[s & 1][1], xf[s], acc);  // lo part first, hi part last
+                    acc = mfma_f16(fa[s & 1][0], xf[s], acc);
+                } else {
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][1]), xh[s], acc);
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][0]), xl[s], acc);
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][0]), xh[s], acc);
+                }
             }
         }
+        // ReLU and (VLAD mode) the 2^-8 that removes W5_SCALE (bias and weights are packed scaled): max on the bit pattern
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const float a = acc[r];  // (a scalar copy: __builtin_bit_cast on a vector ELEMENT reads element 0 with hipcc 7.2)
+            const int vb = __float_as_int(a);
+            acc[r] = __int_as_float(vb > 0 ? vb : 0) * kDescale;
+        }
 #ifdef C5_ABL_NOEPI
         constexpr bool kEpi = false;
         asm volatile("" :: "v"(acc));
@@ -173,44 +197,39 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #endif
         if (kEpi && MODE == MODE_VLAD) {
             const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
-            auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
+            auto wfrag = [&](int sp, int t, int part) { return ldfrag16(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
             // cluster-weight fragments of k-step 0: issued now, they land under the VALU work below
-            bf16x8 wf[2][2];
+            f16x8 wf[2][2];
             wf[0][0] = wfrag(0, 0, 0), wf[0][1] = wfrag(0, 0, 1), wf[1][0] = wfrag(0, 1, 0), wf[1][1] = wfrag(0, 1, 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
-            // accumulators -> split B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp)
+            // accumulators -> fp16 B fragments: k-step s' = registers 8s' .. 8s'+7 (k order: common.h, Wcp).  The same
+            // fragment is the assignment GEMM's operand and what is stored.
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                float v[8];
+                f16x8 fs;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
-                bf16x8 fh, fl;
-                split8(v, fh, fl);
+                for (int q = 0; q < 8; ++q) fs[q] = (_Float16)acc[8 * sp + q];
 #ifndef C5_ABL_NOSTORE
                 // feat leaves the kernel as ONE fp16 fragment per accumulator half (accumulator order: lane = point,
                 // element q = channel 32c + 16sp + 8(q>>2) + 4h + (q&3)): 1 KB per wave-instruction, 2 B per value; the
                 // aggregate kernel scales by rnorm and transposes.  (fp16 keeps 11 significant bits of a value that is
                 // then averaged over the cloud's points: measured descriptor effect 7e-7)
                 if (active) {
-                    f16x8 fs;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) fs[q] = (_Float16)v[q];
                     float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 512 + lane * 4;
                     *reinterpret_cast<u32x4*>(fdst + sp * 256) = __builtin_bit_cast(u32x4, fs);
                 }
 #endif
-                bf16x8 wn[2][2];
+                f16x8 wn[2][2];
                 if (sp == 0) wn[0][0] = wfrag(1, 0, 0), wn[0][1] = wfrag(1, 0, 1), wn[1][0] = wfrag(1, 1, 0), wn[1][1] = wfrag(1, 1, 1);
 #ifndef C5_ABL_NOASSIGN
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    P[t] = mfma_bf16(wf[t][1], fh, P[t]);
-                    P[t] = mfma_bf16(wf[t][0], fl, P[t]);
-                    P[t] = mfma_bf16(wf[t][0], fh, P[t]);
+                    P[t] = mfma_f16(wf[t][1], fs, P[t]);
+                    P[t] = mfma_f16(wf[t][0], fs, P[t]);
                 }
 #else
-                asm volatile("" :: "v"(fh), "v"(fl), "v"(wf[0][0]), "v"(wf[0][1]), "v"(wf[1][0]), "v"(wf[1][1]));
+                asm volatile("" :: "v"(fs), "v"(wf[0][0]), "v"(wf[0][1]), "v"(wf[1][0]), "v"(wf[1][1]));
 #endif
                 if (sp == 0) wf[0][0] = wn[0][0], wf[0][1] = wn[0][1], wf[1][0] = wn[1][0], wf[1][1] = wn[1][1];
             }
@@ -259,12 +278,13 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         const float* cs = lds + L::OFF_CBN;
         const float* ct = cs + 64;
         float mx = -INFINITY;
+        const float rn_w = rn * (1.0f / W5_SCALE);  // the cluster weights are packed scaled as well
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = 32 * t + mfma_row(r, h);
-                const float v = (P[t][r] * rn) * cs[k] + ct[k];
+                const float v = (P[t][r] * rn_w) * cs[k] + ct[k];
                 P[t][r] = v;
                 mx = fmaxf(mx, v);
             }

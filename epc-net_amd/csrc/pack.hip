@@ -78,27 +78,38 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
     }
 }
 
-// conv5 weights for the split-bf16 MFMA (layout: common.h).  One thread per (chunk, k-step, lane, j); writes hi and lo.
-__global__ void fold_pack_conv5_bf16_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            const float* __restrict__ mean, const float* __restrict__ var, int cin,
-                                            unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+// conv5 weights as hi + lo fragments (layout + arithmetic: common.h).  One thread per (chunk, k-step, lane, j).
+// f16 = 1: fp16 parts of W * W5_SCALE, bias scaled alike (EPC-Net: conv5 feeds the VLAD aggregation);
+// f16 = 0: bf16 parts of W for the split-bf16 x3 form (EPC-Net-L: conv5 feeds the global max-pool).
+__global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ mean, const float* __restrict__ var, int cin, int f16,
+                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int steps = cin / 16;
+    const float scale = f16 ? W5_SCALE : 1.0f;
     if (o < cin * 1024) {
         const int j = o & 7, lane = (o >> 3) & 63, rest = o >> 9;
         const int s = rest % steps, c = rest / steps;
         const int k = 16 * s + 8 * (lane >> 5) + j, col = 32 * c + (lane & 31);
-        const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col);
-        const unsigned short hi = bf16_bits_rne(w);
-        const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col) * scale;
+        unsigned short hi, lo;
+        if (f16) {
+            const _Float16 h = (_Float16)w;
+            const _Float16 l = (_Float16)(w - (float)h);
+            hi = __builtin_bit_cast(unsigned short, h);
+            lo = __builtin_bit_cast(unsigned short, l);
+        } else {
+            hi = bf16_bits_rne(w);
+            lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        }
         const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
         dstW[base] = hi;
         dstW[base + 512] = lo;
     }
     if (o < 1024) {
         const float inv = bn_inv(gamma, var, o);
-        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+        dstB[o] = (b[o] * inv + (beta[o] - mean[o] * inv)) * scale;
     }
 }
 
@@ -128,17 +139,17 @@ __global__ void fold_pack_block_bf16_kernel(const float* __restrict__ W, const f
     }
 }
 
-__global__ void pack_wc_bf16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
+__global__ void pack_wc_f16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= 1024 * 64) return;
     const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
     const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
-    const unsigned short hi = bf16_bits_rne(w);
-    const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)] * W5_SCALE;
+    const _Float16 hi = (_Float16)w;
+    const _Float16 lo = (_Float16)(w - (float)hi);
     const size_t base = ((size_t)((c * 2 + sp) * 2 + t) * 2) * 512 + lane * 8 + j;
-    dst[base] = hi;
-    dst[base + 512] = lo;
+    dst[base] = __builtin_bit_cast(unsigned short, hi);
+    dst[base + 512] = __builtin_bit_cast(unsigned short, lo);
 }
 
 __global__ void bn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -263,8 +274,9 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
 
     PACK_TRY(get_conv(T, "fastdgcnn/conv5", &v));
     const int c5in = 64 * nblocks;
-    hipLaunchKernelGGL(fold_pack_conv5_bf16_kernel, dim3(c5in * 1024 / 256), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta,
-                       v.mean, v.var, c5in, (unsigned short*)(P + L.off[5]), P + L.off[5] + (size_t)c5in * 1024);
+    hipLaunchKernelGGL(fold_pack_conv5_kernel, dim3(c5in * 1024 / 256), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta,
+                       v.mean, v.var, c5in, cfg->arch == EPC_ARCH_EPC_NET ? 1 : 0, (unsigned short*)(P + L.off[5]),
+                       P + L.off[5] + (size_t)c5in * 1024);
     EPC_CHECK_LAUNCH();
 
     if (cfg->arch == EPC_ARCH_EPC_NET) {
@@ -277,7 +289,7 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
             epc_set_error("epc_net_pack_weights: VLAD weight matrices are incomplete");
             return EPC_ENOTFOUND;
         }
-        hipLaunchKernelGGL(pack_wc_bf16_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5);
+        hipLaunchKernelGGL(pack_wc_f16_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5);
         EPC_CHECK_LAUNCH();
         const float *g, *b, *m, *vv;
         PACK_TRY(get_slim_bn(T, "VLAD/cluster_bn", &g, &b, &m, &vv));

@@ -131,8 +131,8 @@ def test_stages_against_oracle(dev, arch, kind, n):
         if b < nblocks:
             close(got["xs"][b], st.taps["fastdgcnn/conv%d" % (b + 1)], 2e-5, "conv%d" % (b + 1))
     if arch == "epc-net":
-        # feat is stored as fp16 (11 significant bits): half an ulp of the largest value
-        close(got["feat"], st.taps["fastdgcnn/conv5"], 2.0 ** -11, "conv5 (fp16 fragment order)")
+        # feat is stored as fp16 (11 significant bits): half an ulp of the largest value, plus the arithmetic's 5e-5
+        close(got["feat"], st.taps["fastdgcnn/conv5"], 2.0 ** -11 + 5e-5, "conv5 (fp16 fragment order)")
         close(got["assign"].reshape(-1, 64), st.taps["vlad_assign"], 1e-4, "assign")
         close(got["aprime"], got["assign"].cpu().numpy() * got["rnorm"].cpu().numpy()[..., None], 2.0 ** -11,
               "assign fragments (fp16)")
