@@ -16,8 +16,10 @@
 // through a per-wave LDS staging tile to switch between the row layout and the MFMA layout.
 #include "common.h"
 
-#define BLK_THREADS 512
+#ifndef BLK_WAVES
 #define BLK_WAVES 8
+#endif
+#define BLK_THREADS (64 * BLK_WAVES)
 #define ST_STRIDE 68  // floats per staged row: 64 + 4 pad -> conflict-free b128 reads in both layouts
 #define BLK_PACK EPC_BLOCK_PACK_FLOATS
 #define BLK_LDS_FLOATS (BLK_PACK + BLK_WAVES * 32 * ST_STRIDE)
@@ -113,6 +115,20 @@ __device__ __forceinline__ void stage_to_bop(const float* st, bf16x8 (&bh)[4], b
     }
 }
 
+// ---- shared pieces of the two block kernels ------------------------------------------------------------------
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so
+// giving each group a CONTIGUOUS range of tiles keeps all tiles of a cloud -- which gather from the same rows of x --
+// behind one L2 instead of eight.  Speed only: any mapping is correct.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
+#ifndef BLK_NO_XCD_REMAP
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any grid size
+#else
+    return bid;
+#endif
+}
+
+// ---- f32 rows, split-bf16 layers (EPC-Net-L; f32-accurate at every stage boundary) -------------------------------
 __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* __restrict__ x, const float* __restrict__ xyz, const int32_t* __restrict__ idx,
     const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
@@ -130,21 +146,22 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* bn = lds + 8320 + 4096;
     float* st = lds + BLK_PACK + wave * 32 * ST_STRIDE;
 
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so
-    // giving each group a CONTIGUOUS range of tiles keeps all tiles of a cloud -- which gather from the same 1 MB of
-    // x rows -- behind one L2 instead of eight.  Speed only: any mapping is correct.
-    int bid = blockIdx.x;
-#ifndef BLK_NO_XCD_REMAP
-    {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any grid size
-    }
-#endif
+    const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int g0 = (bid * BLK_WAVES + wave) * 32;
     if (g0 >= total_points) return;  // no further workgroup barriers below
-    const int cloud_base = (g0 / n) * n;
+    // a wave's 32 points lie in one cloud: wave-uniform bases + 32-bit lane offsets (saddr addressing, no 64-bit VALU math)
+    const int cloud_base = __builtin_amdgcn_readfirstlane((g0 / n) * n);
     const int p = lane >> 4, q = lane & 15;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const char* xc = reinterpret_cast<const char*>(x) + (size_t)cloud_base * 256;  // 256-B rows
+    auto row32 = [&](int row) { return *reinterpret_cast<const float4*>(xc + (unsigned)(row * 256 + q * 16)); };
+    const int wg0 = __builtin_amdgcn_readfirstlane(g0);
+    const int32_t* idx_w = idx + (size_t)wg0 * cap;  // this wave's 32 index rows
+    const float rk = 1.0f / kdiv;
+    // a / kdiv, correctly rounded for ordinary operands: quotient estimate + one exact-remainder correction
+    auto div_k = [&](float a) {
+        const float q0 = a * rk;
+        return __builtin_fmaf(__builtin_fmaf(-q0, kdiv, a), rk, q0);
+    };
 
     // ---- gather-mean, 4 points per pass ----
     float4 xm[8];
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
         const int c = cnt[g];
         const bool ovf = c > cap;
         // every row holds >= 20 valid entries (cnt >= 20 by construction); ties beyond 20 are the rare tail
-        const int4* il = reinterpret_cast<const int4*>(idx + (size_t)g * cap);
+        const int4* il = reinterpret_cast<const int4*>(idx_w + (unsigned)((4 * s + p) * cap));
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ovf) {
             int nb[EPC_KNN_SELECT];
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
             }
             float4 v[EPC_KNN_SELECT];
 #pragma unroll
-            for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = x4[(size_t)(cloud_base + nb[m]) * 16 + q];
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(nb[m]);
 #pragma unroll
             for (int m = 0; m < EPC_KNN_SELECT; ++m) {  // ascending j, one rounding per add
                 acc.x += v[m].x;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
                 acc.w += v[m].w;
             }
             for (int m = EPC_KNN_SELECT; m < c; ++m) {
-                const float4 w = x4[(size_t)(cloud_base + idx[(size_t)g * cap + m]) * 16 + q];
+                const float4 w = row32(idx[(size_t)g * cap + m]);
                 acc.x += w.x;
                 acc.y += w.y;
                 acc.z += w.z;
@@ -196,21 +213,18 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
                     const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
                     const float a = neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj));
                     if (a >= kv) {
-                        const float4 v = x4[(size_t)(cloud_base + j) * 16 + q];
-                        acc.x += v.x;
-                        acc.y += v.y;
-                        acc.z += v.z;
-                        acc.w += v.w;
+                        const float4 w = row32(j);
+                        acc.x += w.x;
+                        acc.y += w.y;
+                        acc.z += w.z;
+                        acc.w += w.w;
                     }
                 }
             }
         }
-        acc.x /= kdiv;
-        acc.y /= kdiv;
-        acc.z /= kdiv;
-        acc.w /= kdiv;
+        acc.x = div_k(acc.x), acc.y = div_k(acc.y), acc.z = div_k(acc.z), acc.w = div_k(acc.w);
         xm[s] = acc;
-        const float4 xi4 = x4[(size_t)g * 16 + q];
+        const float4 xi4 = row32(g - cloud_base);
         st4(st + (4 * s + p) * ST_STRIDE + 4 * q,
             make_float4(acc.x - xi4.x, acc.y - xi4.y, acc.z - xi4.z, acc.w - xi4.w));
     }
@@ -249,9 +263,213 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
         st4(x_next + (size_t)(g0 + 4 * s + p) * 64 + 4 * q, ld4(st + (4 * s + p) * ST_STRIDE + 4 * q));
 }
 
+// ---- fp16 rows, fp16 activations (EPC-Net) ---------------------------------------------------------------------------
+// Every tensor that crosses HBM is fp16 (x rows, the concat slice, x_next: the kernel's HBM bytes halve, and so do the
+// gather's), every MFMA operand is ONE fp16 value per activation against fp16 hi + lo weights (W5_SCALE comment in
+// common.h: two MFMAs per product, 16 per layer), and everything in between (neighbour sum, mean, xm - x, t + xm,
+// accumulators) is f32.  The 2^-12 roundings are independent per point and channel and average out in the VLAD
+// aggregation over the cloud: measured descriptor effect 6e-7.  EPC-Net-L's max-pool head keeps single
+// points, so it stays on the f32 kernel above.
+// Lane mapping of the row phases: 8 lanes x 8 channels (16 B of fp16) per point, 8 points per wave-instruction.
+#define ST16 72  // halfs per staged row: 64 + 8 pad (144 B: conflict-free b128 / b64 accesses in both layouts)
+
+__device__ __forceinline__ f16x8 ldfrag16(const float* p) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
+}
+
+// 64->64 layer on fp16 fragments: bop[s] = the lane's B fragment of k-step s (order fixed by the pack mode)
+__device__ __forceinline__ void layer_f16(const float* lw, const float* lbias, const f16x8 (&bop)[4], f32x16 (&acc)[2],
+                                          int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        acc_init_bias(acc[t], lbias + 32 * t, h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f16x8 ah = ldfrag16(lw + (((t * 4 + s) * 2 + 0) * 64 + lane) * 4);
+            const f16x8 al = ldfrag16(lw + (((t * 4 + s) * 2 + 1) * 64 + lane) * 4);
+            acc[t] = mfma_f16(al, bop[s], acc[t]);
+            acc[t] = mfma_f16(ah, bop[s], acc[t]);
+        }
+    }
+}
+
+// ReLU + removal of W5_SCALE + rounding to fp16 of 4 consecutive accumulator registers (= 4 consecutive channels)
+__device__ __forceinline__ uint2 relu_descale_pack4(const f32x16& a, int r0) {
+    _Float16 hv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = (_Float16)(fmaxf(a[r0 + e], 0.f) * (1.0f / W5_SCALE));
+    uint2 w;
+    w.x = (unsigned)__builtin_bit_cast(unsigned short, hv[0]) | ((unsigned)__builtin_bit_cast(unsigned short, hv[1]) << 16);
+    w.y = (unsigned)__builtin_bit_cast(unsigned short, hv[2]) | ((unsigned)__builtin_bit_cast(unsigned short, hv[3]) << 16);
+    return w;
+}
+
+// accumulators (channel in register, point on lane) -> staged fp16 rows [pt][64]
+__device__ __forceinline__ void acc_to_stage16(unsigned short* st, const f32x16 (&acc)[2], int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2*>(st + j * ST16 + 32 * t + 8 * g + 4 * h) = relu_descale_pack4(acc[t], 4 * g);
+}
+
+// staged fp16 row of the lane's point -> B fragments (k-step s = channels 16s + 8h .. +7)
+__device__ __forceinline__ void stage16_to_bop(const unsigned short* st, f16x8 (&bop)[4], int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        bop[s] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(st + j * ST16 + 16 * s + 8 * h));
+}
+
+// waves per workgroup of the fp16 kernel (its staging tile is 4.5 KB per wave, so more waves fit beside the 49-KB
+// weight pack than in the f32 kernel): tuned on MI355X, scripts/tune_lib.sh
+#ifndef BLK16_WAVES
+#define BLK16_WAVES 16
+#endif
+#define BLK16_THREADS (64 * BLK16_WAVES)
+#define BLK16_LDS_BYTES (BLK_PACK * 4 + BLK16_WAVES * 32 * ST16 * 2)
+
+__global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
+    const unsigned short* __restrict__ x16, const float* __restrict__ xyz, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
+    int has_next, int total_points, int n, float kdiv, unsigned short* __restrict__ out16, int out_stride, int out_off,
+    unsigned short* __restrict__ x_next16) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int o = tid * 4; o < BLK_PACK; o += BLK16_THREADS * 4) st4(lds + o, ld4(pack + o));
+    __syncthreads();
+    const float* wa = lds;
+    const float* ba = lds + 4096;
+    const float* wb = lds + 4160;
+    const float* bb = lds + 4160 + 4096;
+    const float* wn = lds + 8320;
+    const float* bn = lds + 8320 + 4096;
+    unsigned short* st = reinterpret_cast<unsigned short*>(lds + BLK_PACK) + wave * 32 * ST16;
+
+    const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int g0 = (bid * BLK16_WAVES + wave) * 32;
+    if (g0 >= total_points) return;  // no further workgroup barriers below
+    const int cloud_base = __builtin_amdgcn_readfirstlane((g0 / n) * n);
+    const int p = lane >> 3, q = lane & 7;
+    const char* xc = reinterpret_cast<const char*>(x16) + (size_t)cloud_base * 128;  // 128-B rows
+    auto row16 = [&](int row) { return *reinterpret_cast<const u32x4*>(xc + (unsigned)(row * 128 + q * 16)); };
+    // acc[0..7] += the 8 halfs of a row slice: v_fma_mix_f32 converts and adds in one instruction (x * 1.0 + acc: the only
+    // rounding is the add's)
+    auto add_row = [&](float (&acc)[8], const u32x4& raw) {
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * w2]) : "v"(raw[w2]));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * w2 + 1]) : "v"(raw[w2]));
+        }
+    };
+    const int wg0 = __builtin_amdgcn_readfirstlane(g0);
+    const int32_t* idx_w = idx + (size_t)wg0 * cap;
+    const float rk = 1.0f / kdiv;
+    auto div_k = [&](float a) {
+        const float q0 = a * rk;
+        return __builtin_fmaf(__builtin_fmaf(-q0, kdiv, a), rk, q0);
+    };
+
+    // ---- gather-mean, 8 points per pass; t = xm - x staged as fp16 rows ----
+    float xm[4][8];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int g = g0 + 8 * s + p;
+        const int c = cnt[g];
+        const bool ovf = c > cap;
+        const int4* il = reinterpret_cast<const int4*>(idx_w + (unsigned)((8 * s + p) * cap));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (!ovf) {
+            int nb[EPC_KNN_SELECT];
+#pragma unroll
+            for (int m4 = 0; m4 < EPC_KNN_SELECT / 4; ++m4) {
+                const int4 t = il[m4];
+                nb[4 * m4] = t.x;
+                nb[4 * m4 + 1] = t.y;
+                nb[4 * m4 + 2] = t.z;
+                nb[4 * m4 + 3] = t.w;
+            }
+            u32x4 raw[EPC_KNN_SELECT];
+#pragma unroll
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) raw[m] = row16(nb[m]);
+#pragma unroll
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) add_row(acc, raw[m]);  // ascending j, one rounding per add
+            for (int m = EPC_KNN_SELECT; m < c; ++m) add_row(acc, row16(idx[(size_t)g * cap + m]));
+        }
+        if (__any(ovf)) {
+            // more than `cap` entries satisfy a_ij >= kth (ties / zero-padded cloud): exact scan of the row
+            if (ovf) {
+                const float* pc = xyz + (size_t)cloud_base * 3;
+                const int i = g - cloud_base;
+                const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
+                const float sqi = sq3(xi, yi, zi);
+                const float kv = kth[g];
+                for (int j = 0; j < n; ++j) {
+                    const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
+                    const float a = neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj));
+                    if (a >= kv) add_row(acc, row16(j));
+                }
+            }
+        }
+        const f16x8 self = __builtin_bit_cast(f16x8, row16(g - cloud_base));
+        f16x8 t16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xm[s][e] = div_k(acc[e]);
+            t16[e] = (_Float16)(xm[s][e] - (float)self[e]);
+        }
+        *reinterpret_cast<u32x4*>(st + (8 * s + p) * ST16 + 8 * q) = __builtin_bit_cast(u32x4, t16);
+    }
+
+    // ---- conv_a, conv_b ----
+    f16x8 bop[4];
+    f32x16 a1[2], a2[2];
+    stage16_to_bop(st, bop, lane);
+    layer_f16(wa, ba, bop, a1, lane);
+    {   // accumulators -> B fragments of conv_b: k-step st = registers 8(st&1) .. +7 of tile st>>1 (PACK_ACC order)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const uint2 lo = relu_descale_pack4(a1[k4 >> 1], 8 * (k4 & 1)), hi = relu_descale_pack4(a1[k4 >> 1], 8 * (k4 & 1) + 4);
+            u32x4 w;
+            w[0] = lo.x, w[1] = lo.y, w[2] = hi.x, w[3] = hi.y;
+            bop[k4] = __builtin_bit_cast(f16x8, w);
+        }
+    }
+    layer_f16(wb, bb, bop, a2, lane);
+
+    // ---- out = t + xm: fp16 rows to the concat slice, and staged again as the next conv's operand ----
+    acc_to_stage16(st, a2, lane);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        unsigned short* row = st + (8 * s + p) * ST16 + 8 * q;
+        const f16x8 t16 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row));
+        f16x8 o16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o16[e] = (_Float16)((float)t16[e] + xm[s][e]);
+        const u32x4 ow = __builtin_bit_cast(u32x4, o16);
+        *reinterpret_cast<u32x4*>(out16 + (size_t)(g0 + 8 * s + p) * out_stride + out_off + 8 * q) = ow;
+        *reinterpret_cast<u32x4*>(row) = ow;
+    }
+    if (!has_next) return;
+
+    // ---- next block's leading conv -> fp16 rows ----
+    stage16_to_bop(st, bop, lane);
+    layer_f16(wn, bn, bop, a1, lane);
+    acc_to_stage16(st, a1, lane);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        *reinterpret_cast<u32x4*>(x_next16 + (size_t)(g0 + 8 * s + p) * 64 + 8 * q) =
+            *reinterpret_cast<const u32x4*>(st + (8 * s + p) * ST16 + 8 * q);
+}
+
 // conv1 (models/epc-net.py:66-69): 3 -> 64, folded BN, ReLU.  16 lanes x float4 per point.
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ xyz, const float* __restrict__ pack,
-                                                    int total_points, float* __restrict__ x) {
+                                                    int total_points, float* __restrict__ x,
+                                                    unsigned short* __restrict__ x16) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int g = t >> 4, q = t & 15;
     if (g >= total_points) return;
@@ -263,45 +481,66 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ xy
     y.y = fmaxf(((px * w0.y + py * w1.y) + pz * w2.y) + b.y, 0.f);
     y.z = fmaxf(((px * w0.z + py * w1.z) + pz * w2.z) + b.z, 0.f);
     y.w = fmaxf(((px * w0.w + py * w1.w) + pz * w2.w) + b.w, 0.f);
-    st4(x + (size_t)g * 64 + 4 * q, y);
+    if (x) st4(x + (size_t)g * 64 + 4 * q, y);
+    if (x16) {  // fp16 copy of the rows: block 1's gather source (proxyconv_block_kernel<true>)
+        const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+        uint2 w;
+        w.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        w.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+        reinterpret_cast<uint2*>(x16)[(size_t)g * 16 + q] = w;
+    }
 }
 
-extern "C" int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x,
+extern "C" int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
                              void* stream) {
-    EPC_CHECK_ARG(xyz && packed_conv1 && x, "null pointer");
+    EPC_CHECK_ARG(xyz && packed_conv1 && (x || x16), "null pointer");
     EPC_CHECK_ARG(num_points_total >= 0, "bad shape");
     if (num_points_total == 0) return EPC_OK;
     const long threads = (long)num_points_total * 16;
     hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       xyz, (const float*)packed_conv1, num_points_total, x);
+                       xyz, (const float*)packed_conv1, num_points_total, x, (unsigned short*)x16);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 
-extern "C" int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
-                                       const float* kth, int cap, const void* packed_block, int has_next,
-                                       int num_clouds, int n, int knn, float* out, int out_stride, int out_off,
-                                       float* x_next, void* stream) {
-    EPC_CHECK_ARG(x && xyz && idx && cnt && kth && packed_block && out, "null pointer");
-    EPC_CHECK_ARG(!has_next || x_next, "x_next required when has_next");
+extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const int32_t* idx,
+                                       const int32_t* cnt, const float* kth, int cap, const void* packed_block,
+                                       int has_next, int num_clouds, int n, int knn, float* out, void* out16,
+                                       int out_stride, int out_off, float* x_next, void* x_next16, void* stream) {
+    const bool f16 = x16 != nullptr;
+    EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_block, "null pointer");
+    if (f16) {
+        EPC_CHECK_ARG(out16 && (!has_next || x_next16), "fp16 mode needs out16 (and x_next16 when has_next)");
+        EPC_CHECK_ARG(out_stride % 8 == 0 && out_off % 8 == 0 && out_off + 64 <= out_stride, "bad output slice");
+    } else {
+        EPC_CHECK_ARG(x && out && (!has_next || x_next), "f32 mode needs x, out (and x_next when has_next)");
+        EPC_CHECK_ARG(out_stride % 4 == 0 && out_off % 4 == 0 && out_off + 64 <= out_stride, "bad output slice");
+    }
     EPC_CHECK_ARG(cap == EPC_KNN_CAP, "neighbour-list capacity must be EPC_KNN_CAP (32)");
     EPC_CHECK_ARG(n > 0 && n % 32 == 0, "num_points must be a multiple of 32");
     EPC_CHECK_ARG(knn > 0, "KNN divisor must be positive");
-    EPC_CHECK_ARG(out_stride % 4 == 0 && out_off % 4 == 0 && out_off + 64 <= out_stride, "bad output slice");
     if (num_clouds <= 0) return num_clouds == 0 ? EPC_OK : EPC_EINVAL;
     const long total = (long)num_clouds * n;
     EPC_CHECK_ARG(total < (1L << 31), "too many points");
-    static const size_t lds_bytes = BLK_LDS_FLOATS * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proxyconv_block_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const size_t lds_bytes = f16 ? (size_t)BLK16_LDS_BYTES : BLK_LDS_FLOATS * sizeof(float);
+    const void* fn = f16 ? reinterpret_cast<const void*>(proxyconv_block_f16_kernel)
+                         : reinterpret_cast<const void*>(proxyconv_block_kernel);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         epc_set_error("epc_proxyconv_block_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    const unsigned blocks = (unsigned)((total + BLK_WAVES * 32 - 1) / (BLK_WAVES * 32));
-    hipLaunchKernelGGL(proxyconv_block_kernel, dim3(blocks), dim3(BLK_THREADS), lds_bytes, (hipStream_t)stream, x,
-                       xyz, idx, cnt, kth, cap, (const float*)packed_block, has_next, (int)total, n, (float)knn,
-                       out, out_stride, out_off, x_next);
+    const int wpb = f16 ? BLK16_WAVES : BLK_WAVES;
+    const unsigned blocks = (unsigned)((total + wpb * 32 - 1) / (wpb * 32));
+    if (f16)
+        hipLaunchKernelGGL(proxyconv_block_f16_kernel, dim3(blocks), dim3(BLK16_THREADS), lds_bytes, (hipStream_t)stream,
+                           (const unsigned short*)x16, xyz, idx, cnt, kth, cap, (const float*)packed_block, has_next,
+                           (int)total, n, (float)knn, (unsigned short*)out16, out_stride, out_off,
+                           (unsigned short*)x_next16);
+    else
+        hipLaunchKernelGGL(proxyconv_block_kernel, dim3(blocks), dim3(BLK_THREADS), lds_bytes, (hipStream_t)stream, x,
+                           xyz, idx, cnt, kth, cap, (const float*)packed_block, has_next, (int)total, n, (float)knn,
+                           out, out_stride, out_off, x_next);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

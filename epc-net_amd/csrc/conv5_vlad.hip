@@ -60,7 +60,7 @@ struct C5Lds {  // offsets in floats (4 B)
 
 // packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
 //                                    [W5p CIN*1024][b5f 1024]                                     (MAX)
-template <int CIN, int MODE>
+template <int CIN, int MODE, bool CAT16>
 __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restrict__ cat,
                                                            const float* __restrict__ pack, int total_points,
                                                            int n, float* __restrict__ feat,
@@ -115,7 +115,16 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
     f16x8 xf[kF16 ? STEPS : 1];
     bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
-    {
+    if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
+        static_assert(!CAT16 || MODE == MODE_VLAD, "fp16 input only feeds the fp16 arithmetic");
+        const unsigned short* row = reinterpret_cast<const unsigned short*>(cat) + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            u32x4 w = *reinterpret_cast<const u32x4*>(row + 16 * s);
+            if (!active) w = u32x4{0u, 0u, 0u, 0u};
+            xf[kF16 ? s : 0] = __builtin_bit_cast(f16x8, w);
+        }
+    } else {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -340,19 +349,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     }
 }
 
-template <int CIN, int MODE>
+template <int CIN, int MODE, bool CAT16>
 static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
                         float* assign, float* assign_frag, float* apart, float* pooled, hipStream_t stream,
                         const char* who) {
     const size_t lds_bytes = C5Lds<CIN>::TOTAL * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE, CAT16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
         return EPC_EHIP;
     }
     const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
-    hipLaunchKernelGGL((conv5_kernel<CIN, MODE>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
+    hipLaunchKernelGGL((conv5_kernel<CIN, MODE, CAT16>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
                        (int)total, n, feat, rnorm, assign, assign_frag, apart, pooled);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
@@ -362,15 +371,20 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
     return EPC_OK;
 }
 
-extern "C" int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
-                                    void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
-                                    void* stream) {
+extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5,
+                                    int num_points_total, void* feat_frag, float* rnorm, float* assign,
+                                    void* assign_frag, float* apart, void* stream) {
     EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    return launch_conv5<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 0, (float*)feat_frag, rnorm,
-                                        assign, (float*)assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
+    if (cat_fp16)
+        return launch_conv5<256, MODE_VLAD, true>((const float*)cat, (const float*)packed_conv5, num_points_total, 0,
+                                                  (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
+                                                  (hipStream_t)stream, __func__);
+    return launch_conv5<256, MODE_VLAD, false>((const float*)cat, (const float*)packed_conv5, num_points_total, 0,
+                                               (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
+                                               (hipStream_t)stream, __func__);
 }
 
 extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
@@ -385,7 +399,7 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
         epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    return launch_conv5<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr, pooled,
+    return launch_conv5<128, MODE_MAX, false>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr, pooled,
                                        (hipStream_t)stream, __func__);
 }
 

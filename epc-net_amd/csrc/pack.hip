@@ -113,29 +113,40 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
     }
 }
 
-// 64x64 block layer for the split-bf16 MFMA: Wp[tile t (2)][k-step s (4)][part (hi,lo)][lane][8 bf16] + bias.
+// 64x64 block layer as hi + lo fragments: Wp[tile t (2)][k-step s (4)][part (hi,lo)][lane][8 x 16 bit] + bias.
+// f16 = 0: bf16 parts for the split-bf16 x3 form (EPC-Net-L); f16 = 1: fp16 parts of W * W5_SCALE, bias scaled alike
+// (EPC-Net: fp16 activations, two MFMAs per product -- common.h).
 // mode PACK_SPLIT: k-step s covers input channels 16s + 8h + q (B operand read from a staged [pt][ch] row);
 // mode PACK_ACC  : k-step s = 2*tin + s' covers 32tin + 16s' + 8(q>>2) + 4h + (q&3) (B = accumulators of the previous layer).
-__global__ void fold_pack_block_bf16_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            const float* __restrict__ mean, const float* __restrict__ var, int mode,
-                                            unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+__global__ void fold_pack_block_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ mean, const float* __restrict__ var, int mode, int f16,
+                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
     const int o = blockIdx.x * 256 + threadIdx.x;
+    const float scale = f16 ? W5_SCALE : 1.0f;
     if (o < 4096) {
         const int q = o & 7, lane = (o >> 3) & 63, st = (o >> 9) & 3, t = o >> 11;
         const int h = lane >> 5;
         const int k = mode == PACK_SPLIT ? 16 * st + 8 * h + q : 32 * (st >> 1) + 16 * (st & 1) + 8 * (q >> 2) + 4 * h + (q & 3);
         const int col = 32 * t + (lane & 31);
-        const float w = W[(size_t)k * 64 + col] * bn_inv(gamma, var, col);
-        const unsigned short hi = bf16_bits_rne(w);
-        const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        const float w = W[(size_t)k * 64 + col] * bn_inv(gamma, var, col) * scale;
+        unsigned short hi, lo;
+        if (f16) {
+            const _Float16 hh = (_Float16)w;
+            const _Float16 ll = (_Float16)(w - (float)hh);
+            hi = __builtin_bit_cast(unsigned short, hh);
+            lo = __builtin_bit_cast(unsigned short, ll);
+        } else {
+            hi = bf16_bits_rne(w);
+            lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+        }
         const size_t base = ((size_t)(t * 4 + st) * 2) * 512 + lane * 8 + q;
         dstW[base] = hi;
         dstW[base + 512] = lo;
     }
     if (o < 64) {
         const float inv = bn_inv(gamma, var, o);
-        dstB[o] = b[o] * inv + (beta[o] - mean[o] * inv);
+        dstB[o] = (b[o] * inv + (beta[o] - mean[o] * inv)) * scale;
     }
 }
 
@@ -225,10 +236,10 @@ static int get_slim_bn(const NameTable& T, const std::string& scope, const float
         if (rc__ != EPC_OK) return rc__; \
     } while (0)
 
-static int launch_layer(const ConvVars& v, int cin, int cout, int mode, float* dst, hipStream_t st) {
+static int launch_layer(const ConvVars& v, int cin, int cout, int mode, int f16, float* dst, hipStream_t st) {
     EPC_CHECK_ARG(cin == 64 && cout == 64, "block layers are 64x64");
-    hipLaunchKernelGGL(fold_pack_block_bf16_kernel, dim3(16), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var,
-                       mode, (unsigned short*)dst, dst + 4096);
+    hipLaunchKernelGGL(fold_pack_block_kernel, dim3(16), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var,
+                       mode, f16, (unsigned short*)dst, dst + 4096);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -246,6 +257,7 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
     float* P = (float*)packed;
     hipStream_t st = (hipStream_t)stream;
     const int nblocks = cfg->arch == EPC_ARCH_EPC_NET ? 4 : 2;
+    const int f16 = cfg->arch == EPC_ARCH_EPC_NET ? 1 : 0;  // EPC-Net: fp16 activations (common.h); EPC-Net-L: split-bf16
     ConvVars v;
 
     PACK_TRY(get_conv(T, "fastdgcnn/conv1", &v));
@@ -257,12 +269,12 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
         float* dst = P + L.off[b];
         const std::string base = "fastdgcnn/conv" + std::to_string(b);
         PACK_TRY(get_conv(T, base + "_a", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, dst, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst, st));
         PACK_TRY(get_conv(T, base + "_b", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, dst + 4160, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, f16, dst + 4160, st));
         if (b < nblocks) {
             PACK_TRY(get_conv(T, "fastdgcnn/conv" + std::to_string(b + 1), &v));
-            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, dst + 8320, st));
+            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst + 8320, st));
         } else {
             hipError_t e = hipMemsetAsync(dst + 8320, 0, 4160 * sizeof(float), st);
             if (e != hipSuccess) {

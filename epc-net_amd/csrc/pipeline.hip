@@ -18,7 +18,7 @@ static int micro_batch(const epc_cfg* c, int num_clouds) {
 }
 
 struct WsLayout {
-    size_t sorted, idx, cnt, kth, xa, xb, cat, feat, rnorm, assign, afrag, vpart, apart, head, pooled, total;
+    size_t sorted, idx, cnt, kth, xa, xb, xa16, xb16, cat, feat, rnorm, assign, afrag, vpart, apart, head, pooled, total;
 };
 
 static WsLayout ws_layout(const epc_cfg* c, int mb) {
@@ -34,10 +34,17 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
     w.idx = take(M * EPC_KNN_CAP * 4);
     w.cnt = take(M * 4);
     w.kth = take(M * 4);
-    w.xa = take(M * 64 * 4);
-    w.xb = take(M * 64 * 4);
-    const int ccat = c->arch == EPC_ARCH_EPC_NET ? 256 : 128;
-    w.cat = take(M * ccat * 4);
+    // EPC-Net: the block chain's tensors are fp16 rows (block.hip); EPC-Net-L: f32 rows
+    w.xa = w.xb = w.xa16 = w.xb16 = 0;
+    if (c->arch == EPC_ARCH_EPC_NET) {
+        w.xa16 = take(M * 64 * 2);
+        w.xb16 = take(M * 64 * 2);
+        w.cat = take(M * 256 * 2);
+    } else {
+        w.xa = take(M * 64 * 4);
+        w.xb = take(M * 64 * 4);
+        w.cat = take(M * 128 * 4);
+    }
     w.feat = w.rnorm = w.assign = w.afrag = w.vpart = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
         w.feat = take(M * 1024 * 2);   // fp16 fragments
@@ -156,6 +163,9 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
     int32_t* cnt = (int32_t*)(ws + w.cnt);
     float* kth = (float*)(ws + w.kth);
     float* xs[2] = {(float*)(ws + w.xa), (float*)(ws + w.xb)};
+    const bool f16 = cfg->arch == EPC_ARCH_EPC_NET;
+    void* xs16[2] = {f16 ? (void*)(ws + w.xa16) : nullptr, f16 ? (void*)(ws + w.xb16) : nullptr};
+    if (f16) xs[0] = xs[1] = nullptr;
     float* cat = (float*)(ws + w.cat);
 
     for (int c0 = 0; c0 < num_clouds; c0 += mb) {
@@ -171,13 +181,14 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
         TRY(mark(prof, EPC_STAGE_KNN, stream));
         TRY(epc_knn_topk(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, stream));
         TRY(mark(prof, EPC_STAGE_CONV1, stream));
-        TRY(epc_conv1_fwd(pc, pk + epc_net_packed_offset(cfg, 0), nc * n, xs[0], stream));
+        TRY(epc_conv1_fwd(pc, pk + epc_net_packed_offset(cfg, 0), nc * n, xs[0], xs16[0], stream));
         for (int b = 1; b <= nblocks; ++b) {
             TRY(mark(prof, EPC_STAGE_BLOCK1 + b - 1, stream));
             const int has_next = b < nblocks;
-            TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], pc, idx, cnt, kth, EPC_KNN_CAP,
-                                        pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn, cat, ccat,
-                                        64 * (b - 1), xs[b & 1], stream));
+            TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], xs16[(b - 1) & 1], pc, idx, cnt, kth, EPC_KNN_CAP,
+                                        pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn,
+                                        f16 ? nullptr : cat, f16 ? (void*)cat : nullptr, ccat, 64 * (b - 1), xs[b & 1],
+                                        xs16[b & 1], stream));
         }
         if (cfg->arch == EPC_ARCH_EPC_NET) {
             float* feat = (float*)(ws + w.feat);
@@ -187,7 +198,7 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
             float* apart = (float*)(ws + w.apart);
             TRY(mark(prof, EPC_STAGE_CONV5, stream));
             float* afrag = (float*)(ws + w.afrag);
-            TRY(epc_conv5_assign_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign, afrag,
+            TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign, afrag,
                                      apart, stream));
             TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
             const int asp = agg_splits(n);

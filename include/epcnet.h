@@ -117,20 +117,29 @@ int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx,
  * (64 MB per 4096-point cloud: for tests / op-level callers only; the fused path never builds it). */
 int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask, void* stream);
 
-/* models/epc-net.py:66-69 conv1 (3->64) + folded BN + ReLU. */
-int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* stream);
+/* models/epc-net.py:66-69 conv1 (3->64) + folded BN + ReLU.  Writes x (M,64) f32 and/or x16 (M,64) fp16 (either may
+ * be NULL): EPC-Net's blocks consume the fp16 rows, EPC-Net-L's the f32 rows. */
+int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16, void* stream);
 
 /* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
  *   xm = (sum_{j in nbr(i)} x_j) / knn ; t = xm - x ; t = conv_a(t) ; t = conv_b(t) ; out = t + xm ;
- *   x_next = conv_{b+1}(out) (when packed_next != NULL).
- * `out` is written with row stride `out_stride` floats at column offset `out_off` (the concat buffer of
- * models/epc-net.py:134). */
-int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
+ *   x_next = conv_{b+1}(out) (when has_next).
+ * `out` is written with row stride `out_stride` elements at column offset `out_off` (the concat buffer of
+ * models/epc-net.py:134).  Two forms, selected by x16 and matching the arch the weights were packed for:
+ *   x16 == NULL (EPC-Net-L pack): f32 rows x -> out, x_next (f32); split-bf16 (x3) MFMA layers, f32-accurate.
+ *   x16 != NULL (EPC-Net pack):   fp16 rows x16 -> out16, x_next16 (fp16; x, out, x_next are ignored): every tensor that
+ *     crosses HBM is fp16 and every MFMA operand is one fp16 value per activation against fp16 hi+lo weights; sums,
+ *     mean, xm - x, t + xm and the accumulators are f32.  The roundings are independent per point and channel and
+ *     average out in the VLAD aggregation (descriptor effect 6e-7). */
+int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const int32_t* idx, const int32_t* cnt,
                             const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
-                            int n, int knn, float* out, int out_stride, int out_off, float* x_next, void* stream);
+                            int n, int knn, float* out, void* out16, int out_stride, int out_off, float* x_next,
+                            void* x_next16, void* stream);
 
 /* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the soft
- * assignment, in split-bf16 (x3) MFMA arithmetic with f32 accumulation (f32-accurate).  cat (M, cin) ->
+ * assignment, in split fp16 MFMA arithmetic with f32 accumulation (one fp16 value per activation, weights as fp16
+ * hi + lo: DESIGN.md 2).  cat (M, cin): f32 when cat_fp16 == 0, fp16 (the blocks' out16) when cat_fp16 == 1 -- the
+ * kernel rounds f32 input to fp16 on load, so both give the same result ->
  *   feat_frag   (M/32, 32 chunks, 2 halves s, 64 lanes, 8 fp16) = 2 bytes per value: the UN-normalised conv5 output
  *               rounded to fp16, in the kernel's accumulator-fragment order: lane l of (tile g, chunk c, half s) holds
  *               point 32g + (l&31), element q = channel 32c + 16s + 8(q>>2) + 4(l>>5) + (q&3).  Range: values must be
@@ -140,8 +149,8 @@ int epc_proxyconv_block_fwd(const float* x, const float* xyz, const int32_t* idx
  *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, 64 lanes, 8 fp16): assign * 2^14 as B fragments (lane l of
  *               (tile g, t, s): cluster 32t + (l&31) at points 32g + 16s + 8(l>>5) + 0..7);
  *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276). */
-int epc_conv5_assign_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, void* feat_frag,
-                         float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
+int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5, int num_points_total,
+                         void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
 
 /* loupe.py:286-291: vlad[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] from the fragment-ordered operands (fp16
  * MFMA, f32 accumulate; the 2^14 of assign_frag is removed), written as `splits` partial slabs vpart

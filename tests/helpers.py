@@ -40,7 +40,10 @@ def make_engine(arch, weights, device="cuda", micro_batch=0):
 
 
 def run_stages(eng, xyz):
-    """Run the pipeline stage by stage through the C ABI, returning every intermediate as a torch tensor."""
+    """Run the pipeline stage by stage through the C ABI, returning every intermediate as a torch tensor.
+    EPC-Net's block chain runs on fp16 rows (x16 -> out16 / x_next16), EPC-Net-L's on f32 rows: `xs` / `cat` are
+    returned in the dtype the stage wrote."""
+    f16 = eng.arch == "epc-net"
     L = pkg("lib")
     E = pkg("engine")
     lib = L.lib()
@@ -60,14 +63,18 @@ def run_stages(eng, xyz):
     out.update(idx=idx, cnt=cnt, kth=kth)
     nblocks = 4 if eng.arch == "epc-net" else 2
     ccat = 64 * nblocks
-    xs = [torch.empty((nc, n, 64), dtype=torch.float32, device=dev) for _ in range(nblocks + 1)]
-    cat = torch.empty((nc, n, ccat), dtype=torch.float32, device=dev)
-    L.check(lib.epc_conv1_fwd(xyz.data_ptr(), off(0), M, xs[0].data_ptr(), st))
+    dt = torch.float16 if f16 else torch.float32
+    xs = [torch.empty((nc, n, 64), dtype=dt, device=dev) for _ in range(nblocks + 1)]
+    cat = torch.empty((nc, n, ccat), dtype=dt, device=dev)
+    a32 = lambda t: None if f16 else t.data_ptr()
+    a16 = lambda t: t.data_ptr() if f16 else None
+    L.check(lib.epc_conv1_fwd(xyz.data_ptr(), off(0), M, a32(xs[0]), a16(xs[0]), st))
     for b in range(1, nblocks + 1):
         has_next = 1 if b < nblocks else 0
-        L.check(lib.epc_proxyconv_block_fwd(xs[b - 1].data_ptr(), xyz.data_ptr(), idx.data_ptr(), cnt.data_ptr(),
-                                            kth.data_ptr(), L.EPC_KNN_CAP, off(b), has_next, nc, n, cfg.knn,
-                                            cat.data_ptr(), ccat, 64 * (b - 1), xs[b].data_ptr(), st))
+        L.check(lib.epc_proxyconv_block_fwd(a32(xs[b - 1]), a16(xs[b - 1]), xyz.data_ptr(), idx.data_ptr(),
+                                            cnt.data_ptr(), kth.data_ptr(), L.EPC_KNN_CAP, off(b), has_next, nc, n,
+                                            cfg.knn, a32(cat), a16(cat), ccat, 64 * (b - 1), a32(xs[b]), a16(xs[b]),
+                                            st))
     out.update(xs=xs, cat=cat)
     desc = torch.empty((nc, 256), dtype=torch.float32, device=dev)
     if eng.arch == "epc-net":
@@ -76,7 +83,7 @@ def run_stages(eng, xyz):
         assign = torch.empty((nc, n, 64), dtype=torch.float32, device=dev)
         assignf = torch.empty((M // 32, 2, 2, 64, 8), dtype=torch.float16, device=dev)
         apart = torch.empty((nc, n // 32, 64), dtype=torch.float32, device=dev)
-        L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
+        L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), 1, ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
                                          assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
         S = 4 if n % 128 == 0 else (2 if n % 64 == 0 else 1)
         vpart = torch.empty((nc, S, 1024, 64), dtype=torch.float32, device=dev)

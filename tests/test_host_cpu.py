@@ -35,7 +35,7 @@ def test_cfg_struct_layout_and_sizes():
     assert nbytes >= 4704832 * 4 - 4 * 10000          # folded weights: ~ the trainable matrices
     offs = [L.lib().epc_net_packed_offset(ctypes.byref(cfg), s) for s in range(7)]
     assert offs == sorted(offs) and offs[0] == 0 and all(o % 256 == 0 for o in offs)
-    assert L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64) > 64 * 4096 * 1024 * 4   # holds the conv5 map
+    assert L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64) > 64 * 4096 * 1024 * 2   # holds the fp16 conv5 map
     bad = E.make_cfg("epc-net", 4100, H.PARAMS)       # N not a multiple of 32
     assert L.lib().epc_net_packed_bytes(ctypes.byref(bad)) == 0
 
