@@ -106,6 +106,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
+    const bool wg_one_cloud = MODE == MODE_MAX && n % (C5_WAVES * 32) == 0;  // the workgroup's 8 tiles share a cloud
 
     // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7.
     // VLAD mode: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
@@ -150,14 +151,31 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 
     // one chunk; the LDS buffer index is a compile-time constant so that the compiler can see that the DMA destination
     // (the other buffer) never aliases the fragments being read (otherwise it drains vmcnt before every ds_read)
+    // max-pool mode: fold the 8 per-wave maxima of chunk c (written before the barrier that ended it) into wgmax
+    auto fold_chunk_max = [&](int c) {
+        if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
+            const float* red = lds + L::OFF_T + (c & 1) * 256 + tid;
+            float m = red[0];
+#pragma unroll
+            for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
+            lds[L::OFF_T + 512 + 32 * c + tid] = m;
+        }
+    };
     auto do_chunk = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
+        if (c > 0) fold_chunk_max(c - 1);
 #ifndef C5_ABL_NODMA
         if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
 #endif
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
         f32x16 acc;
-        {
+        if constexpr (MODE == MODE_MAX) {
+            // transposed product (operands swapped: D[point][channel]): channel = lane & 31, the 16 registers are 16 of
+            // the tile's points, so the max over points is a max over registers
+            const float bv = lds[L::OFF_B5 + 32 * c + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bv;
+        } else {
             const float* b = lds + L::OFF_B5 + 32 * c;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -185,9 +203,9 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                     acc = mfma_f16(fa[s & 1][1], xf[s], acc);  // lo part first, hi part last
                     acc = mfma_f16(fa[s & 1][0], xf[s], acc);
                 } else {
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][1]), xh[s], acc);
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][0]), xl[s], acc);
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s & 1][0]), xh[s], acc);
+                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s & 1][1]), acc);
+                    acc = mfma_bf16(xl[s], __builtin_bit_cast(bf16x8, fa[s & 1][0]), acc);
+                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s & 1][0]), acc);
                 }
             }
         }
@@ -243,18 +261,21 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 if (sp == 0) wf[0][0] = wn[0][0], wf[0][1] = wn[0][1], wf[1][0] = wn[1][0], wf[1][1] = wn[1][1];
             }
         } else if (kEpi) {
-            // max over the tile's 32 points (lanes of one half), then one atomic per channel
+            // max over the tile's 32 points (registers, then the two lane halves).  When the workgroup's 8 tiles lie in one cloud the
+            // per-wave maxima meet in LDS (red: two chunk-parity slabs of 8 waves x 32 channels, in the unused transpose
+            // area) and the workgroup's 1024 maxima leave as sixteen 256-B atomic wave-instructions at the very end;
+            // otherwise (n not a multiple of 256) each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
+            // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
+            float* red = lds + L::OFF_T + (c & 1) * 256 + wave * 32;
+            float m = acc[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float m = acc[r];
-                m = fmaxf(m, __shfl_xor(m, 1));
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
-                m = fmaxf(m, __shfl_xor(m, 8));
-                m = fmaxf(m, __shfl_xor(m, 16));
-                if (active && j == 0)
-                    atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + mfma_row(r, h)),
-                              __float_as_uint(m));
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            m = fmaxf(m, __shfl_xor(m, 32));  // the other 16 points of the tile
+            if (!active) m = 0.f;
+            if (wg_one_cloud) {
+                if (h == 0) red[j] = m;
+            } else if (active && h == 0) {
+                atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + j), __float_as_uint(m));
             }
         }
 
@@ -277,6 +298,12 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     for (int c = 0; c < 32; c += 2) {
         do_chunk(c, std::integral_constant<int, 0>{});
         do_chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (MODE == MODE_MAX && wg_one_cloud) {
+        fold_chunk_max(31);
+        __syncthreads();
+        unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
+        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_T + 512 + o]));
     }
 
     if (MODE == MODE_VLAD && active) {
