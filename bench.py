@@ -162,7 +162,7 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_current.json")))
         if args.arch == "epc-net" and args.batch == 64:
             traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm["kernels"].items()
-                           if k.startswith("void conv5_kernel<256, 0>"))
+                           if k.startswith("void conv5_kernel<256, 0"))
     except Exception:
         traffic = None
     clouds = world * args.batch * args.steps

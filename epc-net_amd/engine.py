@@ -29,8 +29,9 @@ def make_cfg(arch: str, num_points: int, params: Optional[dict], micro_batch: in
 
 class InferenceEngine:
     def __init__(self, arch: str, params: Optional[dict], store: VariableStore, outer: str = "query_triplets",
-                 micro_batch: int = 0):
+                 micro_batch: int = 0, backbone_scope: str = "fastdgcnn"):
         self.arch = arch
+        self.backbone_scope = backbone_scope   # 'BACKBONE' for the KD student (models/kd_epc-net-l.py:44)
         self.params = dict(params or {})
         self.store = store
         self.outer = outer
@@ -46,7 +47,10 @@ class InferenceEngine:
         for name, t in self.store.vars.items():
             if prefix and not name.startswith(prefix):
                 continue
-            out[name[len(prefix):]] = t
+            rel = name[len(prefix):]
+            if self.backbone_scope != "fastdgcnn" and rel.startswith(self.backbone_scope + "/"):
+                rel = "fastdgcnn/" + rel[len(self.backbone_scope) + 1:]   # the library looks variables up by the EPC-Net names
+            out[rel] = t
         return out
 
     def packed(self, cfg: L.EpcCfg) -> torch.Tensor:

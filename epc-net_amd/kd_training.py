@@ -1,0 +1,78 @@
+"""Knowledge distillation EPC-Net -> EPC-Net-L ("EPC-Net-L-D"; reference ``kd_train.py:255-425``,
+``configs/epc-net-l-d.yaml``) on the HIP operators.
+
+Teacher: ``models/kd_epc-net.py`` under scope ``teacher/query_triplets`` (checkpoint names get the ``teacher/`` prefix via
+``ckpt_transfer.py:28-35`` -> ``add_scope_prefix`` below), inference mode, never updated.  Student:
+``models/kd_epc-net-l.py`` under ``student/query_triplets`` (backbone scope ``BACKBONE``), trained with
+
+    loss = BETA * lazy_quadruplet(student) + ALPHA * loss_soft + GAMMA * loss_fea          (kd_train.py:387)
+    LOSS_TYPE square_error_sum : loss_soft = sum((soft_s - soft_t)^2), loss_fea = sum((fea_s - fea_t)^2)   (:376-380)
+              square_error_mean: the same with means                                                         (:381-383)
+    other LOSS_TYPE values leave ``loss_fea`` undefined in the reference (NameError at graph build, :387); same here.
+
+``soft`` = the (B*(1+P+N+1), 256) descriptors, ``fea`` = the L2-normalised per-point conv5 features.  With GAMMA = 0 (the
+shipped config) the feature term contributes nothing, so the teacher's descriptors come from the fused inference
+pipeline and its 4 GB feature map is never built; ``feature_loss_when_unused=True`` computes it anyway for logging."""
+from __future__ import annotations
+
+import importlib
+from typing import Dict, Optional
+
+import torch
+
+from .training import TrainStep
+from .variables import VariableStore, variable_scope
+
+
+def add_scope_prefix(state: Dict[str, object], prefix: str = "teacher") -> Dict[str, object]:
+    """ckpt_transfer.py:28-35: every variable of a checkpoint renamed ``<prefix>/<name>``."""
+    return {prefix + "/" + k: v for k, v in state.items()}
+
+
+class DistillStep(TrainStep):
+    def __init__(self, params: dict, store: Optional[VariableStore] = None, feature_loss_when_unused: bool = False):
+        super().__init__(params, store, outer="student/query_triplets",
+                         arch=params.get("ARCH_STUDENT", "kd_epc-net-l"))
+        self.teacher = importlib.import_module("epc-net_amd.models." + params.get("ARCH_TEACHER", "kd_epc-net"))
+        self.teacher_outer = "teacher/query_triplets"
+        self.loss_type = params.get("LOSS_TYPE", "square_error_sum")
+        self.alpha = float(params.get("ALPHA", 0.1))
+        self.beta = float(params.get("BETA", 1.0))
+        self.gamma = float(params.get("GAMMA", 0.0))
+        self.feature_loss_when_unused = feature_loss_when_unused
+
+    def teacher_outputs(self, vecs, need_features: bool):
+        """kd_train.py:262-275 with is_training=False: (features or None, soft labels (rows, 256)); no gradients."""
+        with torch.no_grad(), variable_scope(self.teacher_outer):
+            if need_features:
+                fea, out = self.teacher.forward(vecs, False, bn_decay=None, params=self.params)
+            else:
+                fea, out = None, self.teacher.descriptors(vecs, self.params)
+        return fea, out.reshape(-1, out.shape[-1])
+
+    def compute_loss(self, query, positives, negatives, other_neg, is_training: bool, bn_decay=None):
+        p = self.params
+        if self.loss_type not in ("square_error_sum", "square_error_mean"):
+            raise NameError("name 'loss_fea' is not defined")            # kd_train.py:387 for the other LOSS_TYPEs
+        vecs = torch.cat([query, positives, negatives, other_neg], 1)
+        need_fea = self.gamma != 0.0 or self.feature_loss_when_unused
+        fea_t, soft_t = self.teacher_outputs(vecs, need_fea)
+        with variable_scope(self.outer):
+            fea_s, out_vecs = self.model.forward(vecs, is_training, bn_decay=bn_decay, params=p)         # :365
+            q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
+                out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)
+            soft_s = out_vecs.reshape(-1, out_vecs.shape[-1])
+            loss_q = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
+                                                     p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))     # :371
+        red = torch.sum if self.loss_type == "square_error_sum" else torch.mean
+        loss_soft = red((soft_s - soft_t) ** 2)
+        if fea_t is not None:
+            d = fea_s - fea_t if self.gamma != 0.0 else (fea_s.detach() - fea_t)
+            loss_fea = red(d ** 2)
+        else:
+            loss_fea = torch.zeros((), device=soft_s.device)
+        loss = loss_q * self.beta + loss_soft * self.alpha + loss_fea * self.gamma                      # :387
+        self.last_aux = {"loss_q": loss_q.detach(), "loss_soft": loss_soft.detach(), "loss_fea": loss_fea.detach(),
+                         "q_vec": q_vec.detach(), "pos_vecs": pos_vecs.detach(), "neg_vecs": neg_vecs.detach(),
+                         "other_neg_vec": other_neg_vec.detach()}
+        return loss

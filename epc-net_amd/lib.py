@@ -35,7 +35,7 @@ EXPORTS = [
     "epc_morton_sort",
     "epc_gemm_f32", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
-    "epc_softmax64_bwd", "epc_adam_step",
+    "epc_softmax64_bwd", "epc_adam_step", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -65,6 +65,8 @@ _P = c_void_p
 _lib.epc_last_error.restype = c_char_p
 _lib.epc_last_error.argtypes = []
 _lib.epc_version.restype = c_int
+_lib.epc_crc32c.restype = ctypes.c_uint32
+_lib.epc_crc32c.argtypes = [ctypes.c_uint32, c_void_p, c_size_t]
 _lib.epc_net_packed_bytes.restype = c_size_t
 _lib.epc_net_packed_bytes.argtypes = [POINTER(EpcCfg)]
 _lib.epc_net_packed_offset.restype = c_size_t

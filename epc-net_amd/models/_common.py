@@ -10,13 +10,13 @@ from ..variables import default_store, outer_scope
 _engines = {}
 
 
-def engine_for(arch: str, params: dict) -> InferenceEngine:
+def engine_for(arch: str, params: dict, backbone_scope: str = "fastdgcnn") -> InferenceEngine:
     st = default_store()
-    key = (id(st), arch, outer_scope(), tuple(sorted((k, v) for k, v in (params or {}).items()
+    key = (id(st), arch, outer_scope(), backbone_scope, tuple(sorted((k, v) for k, v in (params or {}).items()
                                                        if k in ("CLUSTER_SIZE", "FEATURE_OUTPUT_DIM", "KNN", "INPUT_DIM", "GROUPS"))))
     eng = _engines.get(key)
     if eng is None:
-        eng = InferenceEngine(arch, params, st, outer=outer_scope())
+        eng = InferenceEngine(arch, params, st, outer=outer_scope(), backbone_scope=backbone_scope)
         _engines[key] = eng
     return eng
 

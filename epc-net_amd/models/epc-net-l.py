@@ -10,9 +10,9 @@ from ._common import LOSS_NAMES, engine_for, placeholder_inputs  # noqa: F401
 ARCH = "epc-net-l"
 
 
-def declare_variables(params, num_points):
+def declare_variables(params, num_points, backbone_scope='fastdgcnn'):
     """models/epc-net-l.py:44-95."""
-    with variable_scope('fastdgcnn'):
+    with variable_scope(backbone_scope):
         tf_util.declare_conv1d('conv1', params["INPUT_DIM"], 64)
         for b in (1, 2):
             if b > 1:
@@ -44,7 +44,7 @@ def forward(point_cloud, is_training, bn_decay=None, params=None):
     return output.reshape(batch_num_queries, num_pointclouds_per_query, OUTPUT_DIM)
 
 
-def forward_ops(point_cloud, is_training, bn_decay, params):
+def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fastdgcnn', return_features=False):
     """models/epc-net-l.py:44-98 op by op on the differentiable operators (training path / unfused cross-check)."""
     import torch
     from .. import loupe as lp
@@ -52,7 +52,7 @@ def forward_ops(point_cloud, is_training, bn_decay, params):
     num_points = int(point_cloud.shape[1])
     k = params["KNN"]
     point_cloud = ops.morton_sort(point_cloud)           # re-ordering only (permutation-invariant network)
-    with variable_scope('fastdgcnn'):
+    with variable_scope(backbone_scope):
         dpist = ops.KnnGraph(point_cloud)
         nmean = lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), dpist, k).reshape(x.shape)
         conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
@@ -68,6 +68,7 @@ def forward_ops(point_cloud, is_training, bn_decay, params):
             inp = t + xb
             outs.append(inp)
         x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
+        feats = x
         x = x.unsqueeze(2)                                               # :88
     with variable_scope('VLAD'):
         net = tf_util.max_pool2d(x, [num_points, 1], padding='VALID', scope='maxpool')
@@ -75,4 +76,6 @@ def forward_ops(point_cloud, is_training, bn_decay, params):
         output = tf_util.fully_connected(net, params["FEATURE_OUTPUT_DIM"], bn=True, is_training=is_training,
                                          scope="fc1", bn_decay=bn_decay)
         output = lp._l2_normalize(output, 1)
+    if return_features:                                                  # models/kd_epc-net-l.py:102
+        return ops.RowL2Normalize.apply(feats.reshape(-1, 1024)), output
     return output

@@ -17,10 +17,10 @@ from ._common import LOSS_NAMES, engine_for, placeholder_inputs  # noqa: F401
 ARCH = "epc-net"
 
 
-def declare_variables(params, num_points):
+def declare_variables(params, num_points, backbone_scope='fastdgcnn'):
     """Create every variable ``forward`` owns, in the reference's creation order (models/epc-net.py:62-149)."""
     input_dim = params["INPUT_DIM"]
-    with variable_scope('fastdgcnn'):
+    with variable_scope(backbone_scope):
         tf_util.declare_conv1d('conv1', input_dim, 64)
         for b in (1, 2, 3, 4):
             if b > 1:
@@ -57,16 +57,19 @@ def forward(point_cloud, is_training, bn_decay=None, params=None):
     return output.reshape(batch_num_queries, num_pointclouds_per_query, OUTPUT_DIM)
 
 
-def forward_ops(point_cloud, is_training, bn_decay, params):
+def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fastdgcnn', return_features=False):
     """The same graph built op by op from the differentiable operators, line for line as models/epc-net.py:62-155.
     Used for is_training=True (batch statistics, EMA updates, gradients); with is_training=False it is an
-    independent (unfused) second implementation of the inference path (tests cross-check the two)."""
+    independent (unfused) second implementation of the inference path (tests cross-check the two).
+    ``backbone_scope`` / ``return_features``: the KD variants (models/kd_epc-net.py).  NOTE the rows of the returned
+    point features follow the Morton order of each cloud (a per-cloud permutation of the input order); teacher and
+    student of a distillation step sort the same clouds the same way, so their rows correspond."""
     import torch
     from .. import ops
     num_points = int(point_cloud.shape[1])
     k = params["KNN"]
     point_cloud = ops.morton_sort(point_cloud)           # re-ordering only (permutation-invariant network)
-    with variable_scope('fastdgcnn'):
+    with variable_scope(backbone_scope):
         dpist = ops.KnnGraph(point_cloud)                    # tf_util.pairwise_distance_mask in index form (:63)
         nmean = lambda x: ops.NeighbourMean.apply(x.reshape(-1, 64), dpist, k).reshape(x.shape)  # matmul(dpist,x)/k
         conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
@@ -90,4 +93,6 @@ def forward_ops(point_cloud, is_training, bn_decay, params):
         net = ops.RowL2Normalize.apply(x.reshape(-1, 1024))  # :147-148
         output = NetVLAD.forward(net)
         output = lp._l2_normalize(output, 1)                 # :153
+    if return_features:                                      # models/kd_epc-net.py:158: (normalised point features, output)
+        return net, output
     return output

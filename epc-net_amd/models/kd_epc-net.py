@@ -1,0 +1,43 @@
+"""KD teacher model (reference ``models/kd_epc-net.py``): the same network as ``epc-net`` with the backbone under scope
+``fastdgcnn`` and a second return value, the L2-normalised per-point conv5 features ``(B*P*N, 1024)`` that the
+distillation loss of ``kd_train.py:371-387`` compares between teacher and student.
+
+``forward`` always builds the op-by-op graph (both outputs are needed); ``descriptors`` is the fused-engine shortcut
+for callers that only want the global descriptors in inference mode (the soft labels of a teacher when GAMMA = 0)."""
+from __future__ import annotations
+
+import importlib
+
+from ._common import *  # noqa: F401,F403
+from ._common import LOSS_NAMES, engine_for, placeholder_inputs  # noqa: F401
+
+_base = importlib.import_module("epc-net_amd.models.epc-net")
+ARCH = "epc-net"
+BACKBONE_SCOPE = "fastdgcnn"
+
+
+def declare_variables(params, num_points):
+    _base.declare_variables(params, num_points, backbone_scope=BACKBONE_SCOPE)
+
+
+def forward(point_cloud, is_training, bn_decay=None, params=None):
+    """models/kd_epc-net.py:29-158 -> (point features (B*P*N, 1024), output (B, P, FEATURE_OUTPUT_DIM))."""
+    if params is None:
+        raise TypeError("forward() needs the config dict as `params`")
+    if point_cloud.dim() != 4:
+        raise ValueError("point_cloud must be (B, P, N, INPUT_DIM), got %s" % (tuple(point_cloud.shape),))
+    b, p, n, dim = (int(s) for s in point_cloud.shape)
+    if dim != params["INPUT_DIM"]:
+        raise ValueError("last dimension %d != INPUT_DIM %d" % (dim, params["INPUT_DIM"]))
+    declare_variables(params, n)
+    feats, output = _base.forward_ops(point_cloud.reshape(b * p, n, dim), bool(is_training), bn_decay, params,
+                                      backbone_scope=BACKBONE_SCOPE, return_features=True)
+    return feats, output.reshape(b, p, params["FEATURE_OUTPUT_DIM"])
+
+
+def descriptors(point_cloud, params):
+    """Inference-mode global descriptors only, on the fused pipeline (same values as forward(...)[1])."""
+    b, p, n, dim = (int(s) for s in point_cloud.shape)
+    declare_variables(params, n)
+    eng = engine_for(ARCH, params, backbone_scope=BACKBONE_SCOPE)
+    return eng.forward(point_cloud.reshape(b * p, n, dim)).reshape(b, p, params["FEATURE_OUTPUT_DIM"])

@@ -1,4 +1,4 @@
-"""Pure-Python reader for TensorFlow "bundle" checkpoints (``*.ckpt.index`` + ``*.ckpt.data-*``).
+"""Reader and writer for TensorFlow "bundle" checkpoints (``*.ckpt.index`` + ``*.ckpt.data-*``), without TensorFlow.
 
 The reference saves/restores its weights with ``tf.train.Saver`` (reference ``train.py:280,309-315,611-617``;
 ``evaluate.py:264-268``).  TensorFlow is not available on MI355X boxes, so this module reads that on-disk
@@ -8,6 +8,11 @@ the raw little-endian tensor payload.
 
 Only what the EPC-Net checkpoints need is implemented: uncompressed blocks, DT_FLOAT / DT_INT32 / DT_INT64
 tensors, a single data shard, no tensor slices.
+
+``write_checkpoint`` is the inverse (``saver.save``, train.py:611-617): one data shard with the tensors in sorted name
+order, an index table in the layout the shipped ``.index`` files have (one data block, restart interval 16, empty
+metaindex, masked CRC-32C trailers -- the block checksums of those shipped files are this module's known-answer test
+for the checksum), so the files restore with ``tf.train.Saver`` as well as with ``load_checkpoint``.
 
 Known-answer data for this reader: ``tests/golden/ckpt_tables.json`` (generated from the reference's shipped
 ``exp/*/saved_model/*.ckpt.index`` files by ``scripts/make_ckpt_tables.py``).
@@ -224,3 +229,121 @@ def write_checkpoint_payload(prefix: str, tensors: Dict[str, np.ndarray]) -> Non
         blob[e.offset:e.offset + e.size] = arr.tobytes(order="C")
     with open(data_path_for(prefix), "wb") as f:
         f.write(bytes(blob))
+
+
+# ---- writer ------------------------------------------------------------------------------------------------------------
+_DTYPE_ENUM = {np.dtype("<f4"): 1, np.dtype("<f8"): 2, np.dtype("<i4"): 3, np.dtype("<i8"): 9, np.dtype(bool): 10}
+_RESTART_INTERVAL = 16
+_CRC_MASK_DELTA = 0xA282EAD8
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC-32C of ``data`` (host routine of libepcnet_hip.so: include/epcnet.h epc_crc32c)."""
+    from . import lib as L
+    return int(L.lib().epc_crc32c(crc, data, len(data)))
+
+
+def mask_crc(crc: int) -> int:
+    """tensorflow/core/lib/hash/crc32c.h Mask(): rotate right by 15 and add a constant."""
+    return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + _CRC_MASK_DELTA) & 0xFFFFFFFF
+
+
+def _put_varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _build_block(items: List[Tuple[bytes, bytes]]) -> bytes:
+    """LevelDB block: prefix-compressed entries, restart array, restart count."""
+    buf = bytearray()
+    restarts = []
+    last = b""
+    for n, (key, value) in enumerate(items):
+        shared = 0
+        if n % _RESTART_INTERVAL == 0:
+            restarts.append(len(buf))
+        else:
+            m = min(len(last), len(key))
+            while shared < m and last[shared] == key[shared]:
+                shared += 1
+        buf += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(value)) + key[shared:] + value
+        last = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        buf += struct.pack("<I", r)
+    buf += struct.pack("<I", len(restarts))
+    return bytes(buf)
+
+
+def _with_trailer(block: bytes) -> bytes:
+    return block + b"\x00" + struct.pack("<I", mask_crc(crc32c(block + b"\x00")))
+
+
+def _short_successor(key: bytes) -> bytes:
+    """leveldb BytewiseComparator::FindShortSuccessor: the index key of the last data block."""
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
+def _entry_proto(dtype: np.dtype, shape: Tuple[int, ...], offset: int, size: int, masked_crc: int) -> bytes:
+    """BundleEntryProto bytes as TensorFlow serialises them (proto3: zero-valued fields omitted)."""
+    dt = np.dtype(dtype).newbyteorder("<") if np.dtype(dtype).byteorder == ">" else np.dtype(dtype)
+    if dt not in _DTYPE_ENUM:
+        raise NotImplementedError("dtype %s cannot be written" % dtype)
+    out = bytearray()
+    out += b"\x08" + _put_varint(_DTYPE_ENUM[dt])
+    sh = bytearray()
+    for d in shape:
+        dim = b"\x08" + _put_varint(int(d))
+        sh += b"\x12" + _put_varint(len(dim)) + dim
+    out += b"\x12" + _put_varint(len(sh)) + bytes(sh)                 # TensorShapeProto (present even for scalars)
+    if offset:
+        out += b"\x20" + _put_varint(offset)
+    out += b"\x28" + _put_varint(size)
+    out += b"\x35" + struct.pack("<I", masked_crc)
+    return bytes(out)
+
+
+def build_index(entries: "OrderedDict[str, BundleEntry]") -> bytes:
+    """The ``.index`` file for the given entries (``crc32c`` fields already masked, as read_index returns them)."""
+    items: List[Tuple[bytes, bytes]] = [(b"", b"\x08\x01\x1a\x02\x08\x01")]   # BundleHeaderProto: 1 shard, version producer 1
+    for name in sorted(entries.keys(), key=lambda s: s.encode("utf-8")):
+        e = entries[name]
+        items.append((name.encode("utf-8"), _entry_proto(e.dtype, e.shape, e.offset, e.size, e.crc32c)))
+    data_block = _with_trailer(_build_block(items))
+    meta_off = len(data_block)
+    meta_block = _with_trailer(_build_block([]))
+    index_off = meta_off + len(meta_block)
+    handle = _put_varint(0) + _put_varint(len(data_block) - _BLOCK_TRAILER)
+    index_block = _with_trailer(_build_block([(_short_successor(items[-1][0]), handle)]))
+    footer = _put_varint(meta_off) + _put_varint(len(meta_block) - _BLOCK_TRAILER) + _put_varint(index_off) + \
+        _put_varint(len(index_block) - _BLOCK_TRAILER)
+    footer = footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _TABLE_MAGIC)
+    return data_block + meta_block + index_block + footer
+
+
+def write_checkpoint(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
+    """Write ``<prefix>.index`` and ``<prefix>.data-00000-of-00001`` holding ``tensors`` (sorted by name)."""
+    names = sorted(tensors.keys(), key=lambda s: s.encode("utf-8"))
+    entries: "OrderedDict[str, BundleEntry]" = OrderedDict()
+    offset = 0
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    with open(data_path_for(prefix), "wb") as f:
+        for name in names:
+            arr = np.asarray(tensors[name])
+            raw = arr.tobytes(order="C")
+            f.write(raw)
+            entries[name] = BundleEntry(name, arr.dtype, tuple(arr.shape), 0, offset, len(raw), mask_crc(crc32c(raw)))
+            offset += len(raw)
+    with open(prefix + ".index", "wb") as f:
+        f.write(build_index(entries))

@@ -33,12 +33,14 @@ def get_learning_rate(epoch: int, base_learning_rate: float) -> float:
 
 
 class TrainStep:
-    def __init__(self, params: dict, store: Optional[VariableStore] = None, outer: str = "query_triplets"):
+    def __init__(self, params: dict, store: Optional[VariableStore] = None, outer: str = "query_triplets",
+                 arch: Optional[str] = None):
         self.params = dict(params)
-        self.arch = params.get("ARCH", "epc-net")
+        self.arch = arch or params.get("ARCH", "epc-net")
         self.model = importlib.import_module("epc-net_amd.models." + self.arch)
         self.store = store or default_store()
-        self.outer = outer
+        self.outer = outer                        # every variable of the trained model lives under this scope
+        self.last_aux: Dict[str, torch.Tensor] = {}
         self.global_step = 0                      # tf.Variable(0) `batch`, train.py:246
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.m: Dict[str, torch.Tensor] = {}
@@ -50,15 +52,30 @@ class TrainStep:
         out = {"Variable": torch.tensor(self.global_step, dtype=torch.int32),
                "beta1_power": torch.tensor(self.beta1 ** (self.global_step + 1), dtype=torch.float32),
                "beta2_power": torch.tensor(self.beta2 ** (self.global_step + 1), dtype=torch.float32)}
-        for name in self.store.trainable:
+        for name in self.trainable_names():
             out[name + "/Adam"] = self.m.get(name, torch.zeros_like(self.store.vars[name]))
             out[name + "/Adam_1"] = self.v.get(name, torch.zeros_like(self.store.vars[name]))
         return out
 
+    def load_optimizer_state(self, state: Dict[str, object]) -> None:
+        """Inverse of optimizer_state (resume, train.py:308-315): global step and the Adam moments."""
+        self.global_step = int(torch.as_tensor(state["Variable"]).item())
+        for name in self.trainable_names():
+            for slot, dst in (("/Adam", self.m), ("/Adam_1", self.v)):
+                if name + slot in state:
+                    dst[name] = torch.as_tensor(state[name + slot], dtype=torch.float32).to(self.store.device).reshape(
+                        self.store.vars[name].shape).clone()
+
+    def trainable_names(self):
+        """The trainable variables under this step's scope (a second model in the same store -- the KD teacher -- is
+        left alone, as in kd_train.py where the loss does not depend on it)."""
+        pre = self.outer + "/" if self.outer else ""
+        return [n for n in self.store.trainable if n.startswith(pre)]
+
     def _ensure_built(self, num_points: int):
         with variable_scope(self.outer):
             self.model.declare_variables(self.params, num_points)
-        for name in self.store.trainable:
+        for name in self.trainable_names():
             self.store.vars[name].requires_grad_(True)
             if name not in self.m:
                 self.m[name] = torch.zeros_like(self.store.vars[name])
@@ -71,22 +88,31 @@ class TrainStep:
         self._ensure_built(int(query.shape[2]))
         bn_decay = get_bn_decay(self.global_step, p.get("BATCH_NUM_QUERIES", B), p.get("DECAY_STEP", 200000))
         lr = get_learning_rate(epoch, p.get("BASE_LEARNING_RATE", 5e-5))
-        for name in self.store.trainable:
+        for name in self.trainable_names():
             self.store.vars[name].grad = None
-        with variable_scope(self.outer):
-            vecs = torch.cat([query, positives, negatives, other_neg], 1)                               # train.py:252
-            out_vecs = self.model.forward(vecs, True, bn_decay=bn_decay, params=p)                       # :254
-            q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
-                out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)                  # :255
-            loss = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
-                                                   p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))       # :264
+        loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
         loss.backward()
         t = self.global_step + 1
         with torch.no_grad():
-            for name in self.store.trainable:
+            for name in self.trainable_names():
                 w = self.store.vars[name]
                 g = w.grad if w.grad is not None else torch.zeros_like(w)
                 ops.adam_step(w, self.m[name], self.v[name], g, lr, t, self.beta1, self.beta2, self.eps)  # :273-277
         self.store.version += 1
         self.global_step += 1
         return loss.detach(), lr, bn_decay
+
+    def compute_loss(self, query, positives, negatives, other_neg, is_training: bool, bn_decay=None):
+        """train.py:251-264: concat -> forward -> split -> lazy quadruplet loss.  ``is_training=False`` is the
+        evaluation loss of train.py:568-576 (stored statistics, no moving-average update)."""
+        p = self.params
+        with variable_scope(self.outer):
+            vecs = torch.cat([query, positives, negatives, other_neg], 1)                               # train.py:252
+            out_vecs = self.model.forward(vecs, is_training, bn_decay=bn_decay, params=p)                # :254
+            q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
+                out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)                  # :255
+            loss = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
+                                                   p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))       # :264
+        self.last_aux = {"q_vec": q_vec.detach(), "pos_vecs": pos_vecs.detach(), "neg_vecs": neg_vecs.detach(),
+                         "other_neg_vec": other_neg_vec.detach()}
+        return loss

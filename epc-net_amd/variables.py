@@ -63,7 +63,8 @@ class VariableStore:
         v = torch.as_tensor(np.asarray(value) if not torch.is_tensor(value) else value, dtype=torch.float32)
         if tuple(v.shape) != tuple(cur.shape):
             raise ValueError("%s: shape %s != %s" % (name, tuple(v.shape), tuple(cur.shape)))
-        cur.copy_(v.to(cur.device))
+        with torch.no_grad():
+            cur.copy_(v.to(cur.device))
         self.version += 1
 
     def load_state_dict(self, values: Dict[str, object], strict: bool = True) -> List[str]:
@@ -107,7 +108,8 @@ class VariableStore:
                 v = torch.rand(n, generator=g) + 0.5
             else:
                 continue
-            t.copy_(v.reshape(t.shape).to(t.device))
+            with torch.no_grad():
+                t.copy_(v.reshape(t.shape).to(t.device))
         self.version += 1
 
     def num_trainable_params(self) -> int:

@@ -53,6 +53,9 @@ typedef struct epc_cfg {
 
 const char* epc_last_error(void); /* thread-local, valid until the next failing call on this thread */
 int epc_version(void);
+/* Host utility: CRC-32C as stored by TensorFlow's checkpoint bundles (tf.train.Saver, train.py:611: per-tensor and
+ * per-table-block checksums).  crc = epc_crc32c(0, data, n); chainable over pieces. */
+uint32_t epc_crc32c(uint32_t crc, const void* data, size_t n);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* Whole-path entry points: replace `MODEL.forward(...)` inside `sess.run` for is_training=False           */
