@@ -13,7 +13,9 @@
 // Morton-sorts them first, sort.hip) a wave's 64 queries are neighbours and ~3/4 of the tiles are skipped; on
 // arbitrary order the bounds are loose and the kernel degrades gracefully to the full scan with identical results.
 // Pass 1 keeps the 20 largest a_ij in a sorted register file (v_max/v_min insertion network, skipped wave-wide when
-// no lane improves); pass 2 re-visits the surviving tiles in ascending order and emits the list.
+// no lane improves) and records, per wave, which 8-candidate batches produced a hit; pass 2 re-visits exactly those
+// batches in ascending order and emits the list.  (Packed-f32 distance arithmetic -- v_pk_mul/add_f32 on candidate
+// pairs -- was measured slower on gfx950: 0.35 vs 0.30 ms.)
 //
 // knn_topk_stream_kernel (any N): same two passes with candidates streamed through an LDS tile, no culling.
 #include "common.h"
@@ -58,6 +60,9 @@ __device__ __forceinline__ void topk_insert_key(int (&top)[KSEL], int v) {
 }
 
 #define KNN_BATCH 8
+// hit-mask words per wave: KNN_LDS_MAX_N / KNN_BATCH bits
+#define KNN_MASK_WORDS (KNN_LDS_MAX_N / KNN_BATCH / 32)
+static_assert(32 % (KNN_CT / KNN_BATCH) == 0, "a tile's batch bits must not straddle a mask word");
 
 #ifdef KNN_STATS  // tuning builds only (scripts/tune_knn.sh): wave-level event counters
 __device__ unsigned long long g_knn_stats[8];
@@ -84,6 +89,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     const int npad = ntiles * KNN_CT;
     float4* bb = cand + npad;                  // [2*ntiles] boxes, then one float4 holding the margin
     float* s_margin = reinterpret_cast<float*>(bb + 2 * ntiles);
+    // per wave: one bit per (tile, 8-candidate batch) that produced a hit in pass 1 (KNN_CT / KNN_BATCH bits per tile)
+    constexpr int BPT = KNN_CT / KNN_BATCH;
+    unsigned int* hitmask = reinterpret_cast<unsigned int*>(s_margin + 4) + (threadIdx.x >> 6) * KNN_MASK_WORDS;
     const int cloud = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pc = xyz + (size_t)cloud * n * 3;
@@ -135,6 +143,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     }
     __syncthreads();
     const float margin = *s_margin;
+    for (int o = lane; o < KNN_MASK_WORDS; o += 64) hitmask[o] = 0u;  // wave-private: no barrier needed
 
     const int i = blockIdx.x * KNN_THREADS + tid;
     const bool valid = i < n;
@@ -182,10 +191,14 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #pragma unroll
             for (int u = 0; u < KNN_BATCH; ++u) {
                 d[u] = pos_sq_dist(q[u]);
-                hit |= d[u] < thr;
+                hit |= valid && d[u] <= thr;   // non-strict: a batch without hits holds no member of any lane's final set
             }
             if (__any(hit)) {
                 KSTAT(2);
+                if (lane == 0) {
+                    const int bit = c * BPT + k0 / KNN_BATCH;
+                    hitmask[bit >> 5] |= 1u << (bit & 31);
+                }
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
                     const int key = fkey(0.0f - d[u]);  // a_ij with -0.0 folded into +0.0
@@ -214,12 +227,17 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     int count = 0;
     int32_t* my = idx + ((size_t)cloud * n + (valid ? i : 0)) * cap;
     const float dk = -kth;
+    // every member of a final set was a (non-strict) hit when pass 1 saw it (thresholds only tighten), so only the
+    // batches flagged in the wave's hit mask are re-visited, in ascending order -- no bounding-box tests here
     for (int c = 0; c < ntiles; ++c) {
-        if (!__any(valid && lower_bound(c) <= dk)) continue;
+        const int bit0 = c * BPT;
+        const unsigned int bits = (hitmask[bit0 >> 5] >> (bit0 & 31)) & ((1u << BPT) - 1u);
+        if (bits == 0u) continue;
         KSTAT(4);
         const float4* tp = cand + c * KNN_CT;
 #pragma unroll
         for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+            if (!((bits >> (k0 / KNN_BATCH)) & 1u)) continue;
             float4 q[KNN_BATCH];
 #pragma unroll
             for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
@@ -340,7 +358,8 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
     if (n <= KNN_LDS_MAX_N) {
         const int ntiles = (n + KNN_CT - 1) / KNN_CT;
-        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 1) * sizeof(float4);
+        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +
+                                 (size_t)KNN_WAVES * KNN_MASK_WORDS * sizeof(unsigned int);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
