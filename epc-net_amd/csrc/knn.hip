@@ -49,14 +49,33 @@ __device__ __forceinline__ void topk_insert(float (&top)[KSEL], float v) {
     }
 }
 
-template <int KSEL>
-__device__ __forceinline__ void topk_insert_key(int (&top)[KSEL], int v) {
-#pragma unroll
-    for (int s = 0; s < KSEL; ++s) {
-        const int hi = max(top[s], v);
-        v = min(top[s], v);
-        top[s] = hi;
-    }
+// The 20-slot network as ONE asm block: min into the spare register, max IN PLACE, the carried value alternating
+// between two registers.  (Left to itself hipcc writes each max one register further and shifts the whole file back
+// with 20 v_mov per insertion; slot-wise asm statements get an s_nop each from the hazard recogniser.)
+__device__ __forceinline__ void topk_insert_key(int (&top)[20], int v) {
+    int t;
+    asm(
+        "v_min_i32 %[t], %[k0], %[v]\n\tv_max_i32 %[k0], %[k0], %[v]\n\t"
+        "v_min_i32 %[v], %[k1], %[t]\n\tv_max_i32 %[k1], %[k1], %[t]\n\t"
+        "v_min_i32 %[t], %[k2], %[v]\n\tv_max_i32 %[k2], %[k2], %[v]\n\t"
+        "v_min_i32 %[v], %[k3], %[t]\n\tv_max_i32 %[k3], %[k3], %[t]\n\t"
+        "v_min_i32 %[t], %[k4], %[v]\n\tv_max_i32 %[k4], %[k4], %[v]\n\t"
+        "v_min_i32 %[v], %[k5], %[t]\n\tv_max_i32 %[k5], %[k5], %[t]\n\t"
+        "v_min_i32 %[t], %[k6], %[v]\n\tv_max_i32 %[k6], %[k6], %[v]\n\t"
+        "v_min_i32 %[v], %[k7], %[t]\n\tv_max_i32 %[k7], %[k7], %[t]\n\t"
+        "v_min_i32 %[t], %[k8], %[v]\n\tv_max_i32 %[k8], %[k8], %[v]\n\t"
+        "v_min_i32 %[v], %[k9], %[t]\n\tv_max_i32 %[k9], %[k9], %[t]\n\t"
+        "v_min_i32 %[t], %[k10], %[v]\n\tv_max_i32 %[k10], %[k10], %[v]\n\t"
+        "v_min_i32 %[v], %[k11], %[t]\n\tv_max_i32 %[k11], %[k11], %[t]\n\t"
+        "v_min_i32 %[t], %[k12], %[v]\n\tv_max_i32 %[k12], %[k12], %[v]\n\t"
+        "v_min_i32 %[v], %[k13], %[t]\n\tv_max_i32 %[k13], %[k13], %[t]\n\t"
+        "v_min_i32 %[t], %[k14], %[v]\n\tv_max_i32 %[k14], %[k14], %[v]\n\t"
+        "v_min_i32 %[v], %[k15], %[t]\n\tv_max_i32 %[k15], %[k15], %[t]\n\t"
+        "v_min_i32 %[t], %[k16], %[v]\n\tv_max_i32 %[k16], %[k16], %[v]\n\t"
+        "v_min_i32 %[v], %[k17], %[t]\n\tv_max_i32 %[k17], %[k17], %[t]\n\t"
+        "v_min_i32 %[t], %[k18], %[v]\n\tv_max_i32 %[k18], %[k18], %[v]\n\t"
+        "v_min_i32 %[v], %[k19], %[t]\n\tv_max_i32 %[k19], %[k19], %[t]\n\t"
+        : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
 }
 
 #define KNN_BATCH 8
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         zi = me.z;
         sqi = me.w;
     }
+    static_assert(KSEL == 20, "topk_insert_key is written for the 20-slot list");
     int top[KSEL];  // fkey() of the KSEL largest a_ij seen, descending
 #pragma unroll
     for (int s = 0; s < KSEL; ++s) top[s] = fkey(-INFINITY);
@@ -202,7 +222,13 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
                     const int key = fkey(0.0f - d[u]);  // a_ij with -0.0 folded into +0.0
-                    if (key > top[KSEL - 1]) topk_insert_key<KSEL>(top, key);
+                    // wave-UNIFORM branch; lanes without a hit push a key that falls straight through the network.
+                    // (A per-lane `if` makes every slot a conditional update: +1 v_mov per slot to merge the paths.)
+                    const bool better = key > top[KSEL - 1];
+                    if (__any(better)) {
+                        KSTAT(3);
+                        topk_insert_key(top, better ? key : (int)0x80000000);
+                    }
                 }
                 thr = -fkey_inv(top[KSEL - 1]);
             }
