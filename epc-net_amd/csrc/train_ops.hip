@@ -93,6 +93,142 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// GEMM on the bf16 MFMA with f32-level accuracy ("bf16x6"): every f32 operand is carried as THREE bf16 pieces
+// p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (24 significant bits) and a product is evaluated as
+// a2*b0 + a0*b2 + a1*b1 + a1*b0 + a0*b1 + a0*b0 (smallest terms first, f32 accumulation; the dropped terms are below
+// 2^-24 relative).  Six 32-cycle MFMAs per 16-deep k-step replace eight 64-cycle f32 MFMAs: 2.7x fewer matrix-pipe
+// cycles at the same accuracy.  (The two-piece form the inference path uses is 2^-16 per product: fine under a VLAD
+// sum, but it showed in the deepest gradients -- conv1: 9e-3 relative against a 5e-3 bar.)
+// Same interface and stride generality (NN / NT / TN, batched, split-K) as gemm_f32_kernel, which keeps the shapes
+// with a side below 64.  Tile (64*WM) x (64*WN) x 32, 256 threads = 2 x 2 waves of (32*WM) x (32*WN).  Operands are
+// split while they are staged: each thread fetches lane-fragments (8 consecutive k of one row / column: two float4
+// when k is the contiguous axis, 8 lane-coalesced scalars otherwise) and writes the three pieces as ready MFMA
+// fragments ([32-row block][k-step][piece][lane]).
+// ----------------------------------------------------------------------------------------------------------------
+#define S_BK 32
+
+__device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        p0[j] = (__bf16)v[j];
+        const float r1 = v[j] - (float)p0[j];
+        p1[j] = (__bf16)r1;
+        p2[j] = (__bf16)(r1 - (float)p1[j]);
+    }
+}
+
+template <int BLOCKS>  // 32-row blocks of this operand tile (2 * WM or 2 * WN)
+__device__ __forceinline__ void stage_split_fragments(const float* __restrict__ P, long s_outer, long s_k, int outer0,
+                                                      int outer_lim, int kt, int k_lim, u32x4 (*dst)[2][3][64], int tid) {
+    const bool k_contig = s_k == 1;
+    constexpr int ROWS = 32 * BLOCKS;
+#pragma unroll
+    for (int u = 0; u < (ROWS * 4) / 256; ++u) {
+        const int f = tid + 256 * u;  // ROWS x 4 lane-fragments (4 k-groups of 8)
+        const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
+        const int go = outer0 + row, gk = kt + 8 * kg;
+        float v[8];
+        const float* src = P + (size_t)go * s_outer + (size_t)gk * s_k;
+        if (go < outer_lim && gk + 8 <= k_lim && k_contig && ((reinterpret_cast<size_t>(src) & 15) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) v[jj] = (go < outer_lim && gk + jj < k_lim) ? src[(size_t)jj * s_k] : 0.f;
+        }
+        bf16x8 p0, p1, p2;
+        split8x3(v, p0, p1, p2);
+        const int l2 = (row & 31) + 32 * (kg & 1);
+        dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, p0);
+        dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, p1);
+        dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
+    }
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    __shared__ u32x4 As[2 * WM][2][3][64];  // 12 KB per WM
+    __shared__ u32x4 Bs[2 * WN][2][3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int batch = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
+    const float* A = g.A + (size_t)batch * g.bA;
+    const float* B = g.B + (size_t)batch * g.bB;
+    float* C = g.C + (size_t)batch * g.bC;
+    int kchunk = (g.K + g.splitk - 1) / g.splitk;
+    kchunk = (kchunk + S_BK - 1) / S_BK * S_BK;
+    const int k0 = ks * kchunk, k1 = min(g.K, k0 + kchunk);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int rb = 0; rb < WM; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+    for (int kt = k0; kt < k1; kt += S_BK) {
+        stage_split_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt, k1, As, tid);
+        stage_split_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt, k1, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[WM][3], b[WN][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                for (int rb = 0; rb < WM; ++rb) a[rb][pc] = __builtin_bit_cast(bf16x8, As[WM * wm + rb][s][pc][lane]);
+#pragma unroll
+                for (int cb = 0; cb < WN; ++cb) b[cb][pc] = __builtin_bit_cast(bf16x8, Bs[WN * wn + cb][s][pc][lane]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < WM; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < WN; ++cb) {
+                    f32x16 c = acc[rb][cb];
+                    c = mfma_bf16(a[rb][2], b[cb][0], c);
+                    c = mfma_bf16(a[rb][0], b[cb][2], c);
+                    c = mfma_bf16(a[rb][1], b[cb][1], c);
+                    c = mfma_bf16(a[rb][1], b[cb][0], c);
+                    c = mfma_bf16(a[rb][0], b[cb][1], c);
+                    c = mfma_bf16(a[rb][0], b[cb][0], c);
+                    acc[rb][cb] = c;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int cb = 0; cb < WN; ++cb) {
+        const int col = n0 + 32 * WN * wn + 32 * cb + i;
+        if (col >= g.N) continue;
+        const float bv = (g.bias && ks == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < WM; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 32 * WM * wm + 32 * rb + mfma_row(r, h);
+                if (row < g.M) {
+                    float* p = C + (size_t)row * g.ldc + col;
+                    const float v = acc[rb][cb][r] + bv;
+                    if (g.splitk > 1)
+                        atomicAdd(p, v);
+                    else
+                        *p = g.accumulate ? *p + v : v;
+                }
+            }
+    }
+}
+
+template <int WM, int WN>
+static void launch_gemm_split(const GemmArgs& g, int batch, hipStream_t st) {
+    dim3 grid((g.N + 64 * WN - 1) / (64 * WN), (g.M + 64 * WM - 1) / (64 * WM), batch * g.splitk);
+    hipLaunchKernelGGL((gemm_split_kernel<WM, WN>), grid, dim3(256), 0, st, g);
+}
+
 extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                             long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
                             int splitk, int accumulate, void* stream) {
@@ -111,6 +247,18 @@ extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const floa
         }
     }
     GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, bA, bB, bC, splitk, accumulate};
+#ifndef EPC_GEMM_F32_ONLY
+    // sides of at least 64: the split-bf16 kernel with the tile that fits; short sides stay on the f32 MFMA kernel
+    if (M >= 64 && N >= 64 && K >= 32) {
+        const bool bigm = M >= 128, bign = N >= 128;
+        if (bigm && bign) launch_gemm_split<2, 2>(g, batch, st);
+        else if (bigm) launch_gemm_split<2, 1>(g, batch, st);
+        else if (bign) launch_gemm_split<1, 2>(g, batch, st);
+        else launch_gemm_split<1, 1>(g, batch, st);
+        EPC_CHECK_LAUNCH();
+        return EPC_OK;
+    }
+#endif
     dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM, batch * splitk);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
     EPC_CHECK_LAUNCH();
@@ -513,6 +661,31 @@ __global__ void adam_kernel(float* __restrict__ w, float* __restrict__ m, float*
     m[o] = mi;
     v[o] = vi;
     w[o] = w[o] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+// the same update with lr_t read from device memory: a captured HIP graph of the training step is replayed with a new
+// learning rate / bias correction every step without re-recording
+__global__ void adam_dev_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                const float* __restrict__ g, long n, const float* __restrict__ lr_t_dev, float b1,
+                                float b2, float eps) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    const float lr_t = *lr_t_dev;
+    const float gi = g[o];
+    const float mi = b1 * m[o] + (1.0f - b1) * gi;
+    const float vi = b2 * v[o] + (1.0f - b2) * gi * gi;
+    m[o] = mi;
+    v[o] = vi;
+    w[o] = w[o] - lr_t * mi / (sqrtf(vi) + eps);
+}
+
+extern "C" int epc_adam_step_dev(float* w, float* m, float* v, const float* g, long n, const float* lr_t_dev,
+                                 float beta1, float beta2, float eps, void* stream) {
+    EPC_CHECK_ARG(w && m && v && g && lr_t_dev && n > 0, "bad argument");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, m, v, g,
+                       n, lr_t_dev, beta1, beta2, eps);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
 }
 
 extern "C" int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2,

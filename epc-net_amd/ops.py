@@ -56,7 +56,11 @@ class Linear(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return gemm(x, W, bias=b)
+        rows, cin = x.shape
+        # few output tiles but a deep K (the 16384-wide hidden projection on a handful of rows): split K over workgroups
+        tiles = ((rows + 63) // 64) * ((W.shape[1] + 63) // 64)
+        splitk = int(max(1, min(256 // tiles, cin // 256, 64))) if tiles <= 32 else 1
+        return gemm(x, W, bias=b, splitk=splitk)
 
     @staticmethod
     def backward(ctx, dy):
@@ -230,6 +234,11 @@ def morton_sort(xyz):
 
 
 def adam_step(w, m, v, g, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer update of one tensor, in place (train.py:273)."""
+    """tf.train.AdamOptimizer update of one tensor, in place (train.py:273).  ``lr`` may be a one-element device tensor
+    holding the bias-corrected rate lr_t (``t`` is then ignored): the form a captured HIP graph of the step uses."""
+    if torch.is_tensor(lr):
+        L.check(L.lib().epc_adam_step_dev(w.data_ptr(), m.data_ptr(), v.data_ptr(), g.contiguous().data_ptr(), w.numel(),
+                                          lr.data_ptr(), float(beta1), float(beta2), float(eps), _st()))
+        return
     L.check(L.lib().epc_adam_step(w.data_ptr(), m.data_ptr(), v.data_ptr(), g.contiguous().data_ptr(), w.numel(), float(lr),
                                   float(beta1), float(beta2), float(eps), int(t), _st()))

@@ -45,6 +45,7 @@ class TrainStep:
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.m: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
+        self._graph = None                        # captured HIP graph of one step (step(..., graph=True))
 
     # -- checkpoint-shaped optimizer state ---------------------------------------------------------------------------
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
@@ -81,26 +82,79 @@ class TrainStep:
                 self.m[name] = torch.zeros_like(self.store.vars[name])
                 self.v[name] = torch.zeros_like(self.store.vars[name])
 
-    def step(self, query, positives, negatives, other_neg, epoch: int = 0):
-        """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3)."""
+    def step(self, query, positives, negatives, other_neg, epoch: int = 0, graph: bool = False):
+        """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3).
+        ``graph=True`` records the whole step (forward, backward, 62 Adam updates, moving averages: ~670 kernel
+        launches) into one HIP graph on first use and replays it afterwards -- the step is launch-bound from Python
+        otherwise.  The schedule values (learning rate with Adam's bias correction, BN decay) live in device memory and
+        are refreshed before every replay, so replays follow train.py:138-157 exactly like eager steps."""
         p = self.params
         B = int(query.shape[0])
         self._ensure_built(int(query.shape[2]))
         bn_decay = get_bn_decay(self.global_step, p.get("BATCH_NUM_QUERIES", B), p.get("DECAY_STEP", 200000))
         lr = get_learning_rate(epoch, p.get("BASE_LEARNING_RATE", 5e-5))
+        t = self.global_step + 1
+        if graph:
+            loss = self._graphed_step(query, positives, negatives, other_neg, lr, bn_decay, t)
+        else:
+            loss = self._eager_step(query, positives, negatives, other_neg, lr, bn_decay, t)
+        self.store.version += 1
+        self.global_step += 1
+        return loss.detach(), lr, bn_decay
+
+    def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
         for name in self.trainable_names():
             self.store.vars[name].grad = None
         loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
         loss.backward()
-        t = self.global_step + 1
         with torch.no_grad():
             for name in self.trainable_names():
                 w = self.store.vars[name]
                 g = w.grad if w.grad is not None else torch.zeros_like(w)
                 ops.adam_step(w, self.m[name], self.v[name], g, lr, t, self.beta1, self.beta2, self.eps)  # :273-277
-        self.store.version += 1
-        self.global_step += 1
-        return loss.detach(), lr, bn_decay
+        return loss
+
+    # -- HIP-graph replay ------------------------------------------------------------------------------------------------
+    def _state_tensors(self):
+        out = [self.store.vars[n] for n in self.store.vars if n.startswith(self.outer + "/") or not self.outer]
+        out += [self.m[n] for n in self.trainable_names()] + [self.v[n] for n in self.trainable_names()]
+        return out
+
+    def _graphed_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
+        inputs = (query, positives, negatives, other_neg)
+        shapes = tuple(tuple(x.shape) for x in inputs)
+        g = self._graph
+        if g is None or g["shapes"] != shapes:
+            dev = query.device
+            g = {"shapes": shapes, "in": [torch.empty_like(x) for x in inputs],
+                 "lr_t": torch.zeros(1, dtype=torch.float32, device=dev),
+                 "bn_decay": torch.zeros((), dtype=torch.float32, device=dev)}
+            for dst, src in zip(g["in"], inputs):
+                dst.copy_(src)
+            g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
+            g["bn_decay"].fill_(bn_decay)
+            # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored
+            snap = [x.detach().clone() for x in self._state_tensors()]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._eager_step(*g["in"], g["lr_t"], g["bn_decay"], t)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            with torch.no_grad():
+                for x, s0 in zip(self._state_tensors(), snap):
+                    x.copy_(s0)
+            for name in self.trainable_names():
+                self.store.vars[name].grad = None
+            g["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["graph"]):
+                g["loss"] = self._eager_step(*g["in"], g["lr_t"], g["bn_decay"], t)
+            self._graph = g
+        for dst, src in zip(g["in"], inputs):
+            dst.copy_(src)
+        g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
+        g["bn_decay"].fill_(bn_decay)
+        g["graph"].replay()
+        return g["loss"]
 
     def compute_loss(self, query, positives, negatives, other_neg, is_training: bool, bn_decay=None):
         """train.py:251-264: concat -> forward -> split -> lazy quadruplet loss.  ``is_training=False`` is the

@@ -99,7 +99,7 @@ def knn_index(pc: torch.Tensor):
 def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay: float) -> None:
     """tf.train.ExponentialMovingAverage.apply / assign_moving_average: shadow -= (1 - decay) * (shadow - value)."""
     with torch.no_grad():
-        shadow.sub_((shadow - value) * (1.0 - float(decay)))
+        shadow.sub_((shadow - value) * (1.0 - (decay if torch.is_tensor(decay) else float(decay))))
     default_store().version += 1
 
 
@@ -113,7 +113,7 @@ def batch_norm_template(inputs, is_training, scope, moments_dims, bn_decay, acti
     x2 = inputs.reshape(-1, C)
     if is_training:
         y, mean, var = ops.BatchNormTrain.apply(x2, gamma, beta, 1e-3, int(activation_relu))
-        decay = 0.9 if bn_decay is None else float(bn_decay)
+        decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
         _ema_update(ema_mean, mean, decay)
         _ema_update(ema_var, var, decay)
     else:

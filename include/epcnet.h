@@ -222,6 +222,10 @@ int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void
 /* tf.train.AdamOptimizer.apply (train.py:273): t = 1-based step count for the bias correction. */
 int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2, float eps,
                   int t, void* stream);
+/* The same update with lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) read from device memory (one float), so that a captured
+ * HIP graph of the whole training step can be replayed with new schedule values. */
+int epc_adam_step_dev(float* w, float* m, float* v, const float* g, long n, const float* lr_t_dev, float beta1,
+                      float beta2, float eps, void* stream);
 
 /* Offsets (in bytes) of the per-stage sub-buffers inside the packed weight buffer, for the stage entry
  * points above.  stage: 0 conv1, 1..4 block b, 5 conv5(+assign), 6 head. */

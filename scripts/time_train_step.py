@@ -13,15 +13,16 @@ ts = TR.TrainStep(params, store, outer=bench.OUTER)
 g = torch.Generator().manual_seed(0)
 mk = lambda p: (torch.rand((1, p, 4096, 3), generator=g) * 2 - 1).to(dev)
 q, pos, ng, oth = mk(1), mk(2), mk(neg), mk(1)
+use_graph = os.environ.get("GRAPH", "1") == "1"
 for _ in range(3):
-    loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0)
+    loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0, graph=use_graph)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 K = 10
 for _ in range(K):
-    loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0)
+    loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0, graph=use_graph)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 ncl = 1 + 2 + neg + 1
-print("train step %s: %d clouds, %.2f ms/step, %.1f steps/s, %.0f clouds/s, loss %.4f, ~%.1f TFLOP/s (3x fwd FLOPs), peak mem %.2f GB"
-      % (arch, ncl, dt * 1e3, 1 / dt, ncl / dt, float(loss), 3 * bench.FLOPS_PER_CLOUD[arch] * ncl / dt / 1e12, torch.cuda.max_memory_allocated() / 2**30))
+print("train step %s (%s): %d clouds, %.2f ms/step, %.1f steps/s, %.0f clouds/s, loss %.4f, ~%.1f TFLOP/s (3x fwd FLOPs), peak mem %.2f GB"
+      % (arch, "HIP graph" if use_graph else "eager", ncl, dt * 1e3, 1 / dt, ncl / dt, float(loss), 3 * bench.FLOPS_PER_CLOUD[arch] * ncl / dt / 1e12, torch.cuda.max_memory_allocated() / 2**30))

@@ -131,3 +131,36 @@ def test_op_level_conv1d_and_g_vlad_api(dev):
     wts = {k[len("query_triplets/"):]: v.cpu().numpy() for k, v in st.vars.items() if "/VLAD/" in k}
     ref = O.g_vlad_forward(O.State(wts, np.float32), feats.cpu().numpy(), 256, 4, False)
     assert _rel(out.cpu().numpy(), ref) <= 1e-4
+
+
+def test_graphed_step_equals_eager_step(dev):
+    """step(graph=True) replays one captured HIP graph per step; schedule values are device-resident, so several replays
+    (different learning rates / bias corrections / BN decays / inputs) track the eager steps."""
+    TR = H.pkg("training")
+    arch, n = "epc-net-l", 256
+    w0 = O.seeded_weights(arch, 4)
+    params = dict(H.PARAMS, ARCH=arch, BATCH_NUM_QUERIES=1, DECAY_STEP=4, BASE_LEARNING_RATE=1e-3, MARGIN_1=0.5, MARGIN_2=0.2)
+    to = lambda a: torch.from_numpy(a).to(dev)
+    out = []
+    for use_graph in (False, True):
+        st = H.make_store(arch, w0, dev)
+        ts = TR.TrainStep(params, st, outer=H.OUTER)
+        losses = []
+        for i in range(4):
+            pcs = O.synthetic_clouds(10, n, 30 + i)
+            q, pos, neg, oth = to(pcs[None, :1]), to(pcs[None, 1:3]), to(pcs[None, 3:9]), to(pcs[None, 9:])
+            loss, lr, bd = ts.step(q, pos, neg, oth, epoch=5 * i, graph=use_graph)      # lr and bn_decay change every step
+            losses.append(float(loss))
+        out.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in st.vars.items()}, ts.global_step))
+    (l0, w_e, s0), (l1, w_g, s1) = out
+    assert s0 == s1 == 4
+    assert l0 == pytest.approx(l1, rel=1e-4, abs=1e-6)
+    # Adam's first steps are sign-like (update ~ lr * g / |g|): an element whose gradient sits at the rounding floor may
+    # move by O(lr) either way (split-K atomics make the two runs differ in the last bits), so the elementwise check is
+    # tight on the moving statistics (no optimizer in between) and bounded by the Adam step size on the trainables.
+    for k in w_e:
+        if "Squeeze_1/ExponentialMovingAverage" in k or "moving_variance" in k:
+            # (the moving MEANS follow the noise-driven drift of the zero-gradient biases in front of each BN)
+            assert np.abs(w_e[k] - w_g[k]).max() <= 1e-6 + 1e-3 * np.abs(w_e[k]).max(), k
+        else:
+            assert np.abs(w_e[k] - w_g[k]).max() <= 4 * 3.2 * 1e-3 + 1e-6, k
