@@ -174,7 +174,27 @@ def test_forward_api_full_size(dev, arch):
     out = out.cpu().numpy()
     assert np.allclose(np.linalg.norm(out, axis=-1), 1.0, atol=1e-5)
     err = np.linalg.norm(out - ref, axis=-1).max()
+    print("full-size descriptor L2 error %s: %.3e" % (arch, err))
     assert err <= DESC_TOL, "descriptor L2 error %.3e" % err
+
+
+@pytest.mark.parametrize("arch,nc,n,kind,micro", [
+    ("epc-net", 1, 8192, "uniform", 0),      # largest cloud the LDS-resident kNN / one-workgroup sort take
+    ("epc-net", 5, 96, "uniform", 2),        # N not a multiple of 64 / 128 / 256: tail tiles in every kernel, ragged micro-batches
+    ("epc-net-l", 3, 160, "lidar", 0),       # max-pool path with workgroups that straddle clouds (per-wave atomics)
+    ("epc-net-l", 2, 8192, "uniform", 1),
+    ("epc-net", 2, 32, "dup", 0),            # smallest legal cloud: every point is every point's neighbour
+])
+def test_edge_shapes(dev, arch, nc, n, kind, micro):
+    pc = O.synthetic_clouds(nc, n, 17, kind)
+    w = O.seeded_weights(arch, 6)
+    _, lists = O.knn_lists(pc)
+    ref, _ = O.forward(pc[:, None], w, arch=arch, formulation="lists", lists=lists)
+    eng, _ = H.make_engine(arch, w, dev, micro_batch=micro)
+    out = eng.forward(torch.from_numpy(pc).to(dev)).cpu().numpy()
+    err = np.linalg.norm(out - ref.reshape(nc, -1), axis=1).max()
+    print("edge shape %s %dx%d %s: descriptor L2 error %.3e" % (arch, nc, n, kind, err))
+    assert err <= DESC_TOL
 
 
 def test_micro_batching_is_invisible(dev):
