@@ -16,17 +16,33 @@ __global__ __launch_bounds__(256) void vlad_reduce_kernel(const float* __restric
     const int slab = blockIdx.x, cloud = blockIdx.y;
     const int k = threadIdx.x & 63, r = threadIdx.x >> 6;
     float asum = 0.f;
-    for (int s = r; s < asplits; s += 4) asum += apart[((size_t)cloud * asplits + s) * 64 + k];
+    {   // 8 independent loads in flight (the per-tile partials are a chain of exposed latencies otherwise)
+        int s = r;
+        for (; s + 28 < asplits; s += 32) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = apart[((size_t)cloud * asplits + s + 4 * u) * 64 + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) asum += t[u];
+        }
+        for (; s < asplits; s += 4) asum += apart[((size_t)cloud * asplits + s) * 64 + k];
+    }
     red[r][k] = asum;
     __syncthreads();
     asum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     __syncthreads();
     float ss = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int m = 0; m < 16; ++m) {
         const int f = 64 * slab + r + 4 * m;
         float acc = 0.f;
-        for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
+        if (splits == 4) {
+            const float* vp = vpart + (((size_t)cloud * 4) * 1024 + f) * 64 + k;
+            const float v0 = vp[0], v1 = vp[(size_t)1024 * 64], v2 = vp[(size_t)2 * 1024 * 64], v3 = vp[(size_t)3 * 1024 * 64];
+            acc = ((v0 + v1) + v2) + v3;
+        } else {
+            for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
+        }
         acc -= asum * centres[f * 64 + k];
         V[((size_t)cloud * 1024 + f) * 64 + k] = acc;
         ss += acc * acc;
@@ -127,8 +143,17 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restric
     const float* Wg = hp + 512;
     const float* g_s = Wg + 65536;
     const float* g_t = g_s + 256;
+    // (8 independent loads in flight per thread: the slice loop is otherwise a chain of `slices` exposed L2 latencies)
     float y = 0.f;
-    for (int s = 0; s < slices; ++s) y += Yp[((size_t)s * rows + cloud) * 256 + c];
+    int s = 0;
+    for (; s + 8 <= slices; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = Yp[((size_t)(s + u) * rows + cloud) * 256 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) y += t[u];
+    }
+    for (; s < slices; ++s) y += Yp[((size_t)s * rows + cloud) * 256 + c];
     const float val = y * bn_s[c] + (float)groups * bn_t[c];
     v[c] = val;
     __syncthreads();
