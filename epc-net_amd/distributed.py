@@ -10,6 +10,12 @@ The reference is single-process / single-GPU; this is new, MI355
   * each rank then ranks ITS query shard against the full database locally (``epc_pairwise_topk``) and only the
     (Q_r, 25) int32 neighbour lists travel back to rank 0 for the recall bookkeeping of evaluate.py:476-530.
 
+  * training: data-parallel over TUPLES -- every rank trains one 18-cloud tuple per step with its own
+    BatchNorm batch statistics (the reference's statistics are per tuple too, BATCH_NUM_QUERIES = 1), the 4.70 M f32
+    gradients (18.8 MB) are averaged with ONE flat all-reduce per bucket before the Adam update
+    (``all_reduce_gradients``; xGMI rings are per-link bound, so a few large messages, not 62 small ones), and the
+    BatchNorm moving averages are averaged the same way so that the ranks' variables stay identical.
+
 ``torch.distributed`` is plumbing here (process group, collectives); all arithmetic is in libepcnet_hip.so.
 """
 from __future__ import annotations
@@ -77,3 +83,37 @@ def sharded_knn(database_local: torch.Tensor, n_db: int, queries_local: torch.Te
         return idx.cpu().numpy()
     full = all_gather_rows(idx, n_q)       # (n_q, k) everywhere; tiny (25 ints per query)
     return full.cpu().numpy() if rank == 0 else None
+
+
+def all_reduce_gradients(tensors: Sequence[torch.Tensor], bucket_bytes: int = 32 << 20, average: bool = True) -> None:
+    """In-place mean (or sum) over the ranks of a list of same-dtype tensors, moved as flat buckets of about
+    ``bucket_bytes`` (default 32 MB: the whole 18.8-MB EPC-Net gradient is ONE message).  Order and shapes must be the
+    same on every rank.  No-op in a single process."""
+    rank, ws = world()
+    if ws == 1 or not tensors:
+        return
+    bucket: List[torch.Tensor] = []
+    size = 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= ws
+        o = 0
+        for t in bucket:
+            n = t.numel()
+            t.copy_(flat[o:o + n].reshape(t.shape))
+            o += n
+        bucket, size = [], 0
+
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if bucket and size + nbytes > bucket_bytes:
+            flush()
+        bucket.append(t)
+        size += nbytes
+    flush()

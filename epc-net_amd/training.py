@@ -95,6 +95,9 @@ class TrainStep:
         lr = get_learning_rate(epoch, p.get("BASE_LEARNING_RATE", 5e-5))
         t = self.global_step + 1
         if graph:
+            from . import distributed as D
+            graph = D.world()[1] == 1      # the gradient all-reduce of data-parallel runs is not captured: eager there
+        if graph:
             loss = self._graphed_step(query, positives, negatives, other_neg, lr, bn_decay, t)
         else:
             loss = self._eager_step(query, positives, negatives, other_neg, lr, bn_decay, t)
@@ -108,11 +111,27 @@ class TrainStep:
         loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
         loss.backward()
         with torch.no_grad():
-            for name in self.trainable_names():
+            names = self.trainable_names()
+            grads = []
+            for name in names:
                 w = self.store.vars[name]
-                g = w.grad if w.grad is not None else torch.zeros_like(w)
+                grads.append(w.grad if w.grad is not None else torch.zeros_like(w))
+            self._average_over_ranks(grads)
+            for name, g in zip(names, grads):
+                w = self.store.vars[name]
                 ops.adam_step(w, self.m[name], self.v[name], g, lr, t, self.beta1, self.beta2, self.eps)  # :273-277
         return loss
+
+    def _average_over_ranks(self, grads) -> None:
+        """Data parallelism over tuples: one flat all-reduce of the gradients, and of the BatchNorm moving
+        statistics this step updated, so that every rank applies the same update.  Single process: nothing to do."""
+        from . import distributed as D
+        if D.world()[1] == 1:
+            return
+        D.all_reduce_gradients(grads)
+        pre = self.outer + "/" if self.outer else ""
+        trainable = set(self.store.trainable)
+        D.all_reduce_gradients([v for k, v in self.store.vars.items() if k.startswith(pre) and k not in trainable])
 
     # -- HIP-graph replay ------------------------------------------------------------------------------------------------
     def _state_tensors(self):

@@ -88,3 +88,39 @@ def test_recall_bookkeeping_matches_oracle():
     a = R.recall_from_indices(ind, db, q, truth)
     b = O.get_recall(db, q, truth)
     assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.allclose(a[1], b[1])
+
+
+def _grad_worker(rank, ws, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    D = H.pkg("distributed")
+    shapes = [(1, 3, 64), (64,), (1, 256, 1024), (1024, 64), (16384, 8), ()]
+    g = torch.Generator().manual_seed(7)
+    base = [torch.randn(s, generator=g) for s in shapes]            # identical on both ranks
+    mine = [b * (rank + 1) for b in base]                             # rank r holds (r+1) * base
+    D.all_reduce_gradients(mine, bucket_bytes=300000)                 # several buckets, one tensor larger than a bucket
+    for m, b in zip(mine, base):
+        assert torch.allclose(m, b * (sum(range(1, ws + 1)) / ws), rtol=1e-6, atol=1e-7)
+    summed = [b * (rank + 1) for b in base]
+    D.all_reduce_gradients(summed, average=False)
+    for m, b in zip(summed, base):
+        assert torch.allclose(m, b * sum(range(1, ws + 1)), rtol=1e-6, atol=1e-7)
+    if rank == 0:
+        ret.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_world2_gloo():
+    """Data-parallel training: bucketed flat all-reduce leaves the per-rank mean in every tensor."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
