@@ -12,7 +12,8 @@
  *   - the caller owns every buffer; the library allocates nothing and keeps no mutable global state
  *     (except the thread-local last-error string).  Calls are asynchronous on `stream` and re-entrant
  *     across streams as long as workspaces are distinct.
- *   - tensors are contiguous row-major float32 (indices int32).
+ *   - tensors are contiguous row-major float32 (indices int32) unless a parameter is documented as fp16 (the
+ *     activation rows and MFMA fragments that travel between EPC-Net's stages; type void*).
  *   - return value: EPC_OK (0) or a negative epc_status.
  */
 #ifndef EPCNET_H

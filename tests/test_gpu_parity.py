@@ -278,3 +278,16 @@ def test_errors_are_loud(dev):
         eng.forward(torch.zeros((1, 64, 3)))                   # CPU tensor: no fallback
     with pytest.raises(L.EpcNetError):
         eng.forward(torch.zeros((1, 64, 4), device=dev))       # INPUT_DIM != 3
+
+
+def test_plain_c_caller(dev):
+    """The C ABI from a C99 program (examples/epcnet_forward.c): packs a seeded variable table, runs epc_net_forward,
+    checks unit-norm descriptors and bit-identical results for a repeated cloud; exit code 0 = all checks passed."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "examples")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(root, "examples", "epcnet_forward"), "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "5 clouds x 4096 points" in r.stdout

@@ -144,3 +144,14 @@ def test_unused_reference_ops_are_named_not_silently_missing():
     for name in ("conv2d", "conv3d", "dropout", "knn", "get_edge_feature", "pairwise_distance", "avg_pool2d"):
         with pytest.raises(NotImplementedError):
             getattr(tf_util, name)()
+
+
+def test_plain_c_example_builds_against_the_header():
+    """examples/epcnet_forward.c is a C99 program that uses the ABI without Python or torch: it must compile against
+    include/epcnet.h and link against the built library (no GPU needed for that)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", os.path.join(root, "examples")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(root, "examples", "epcnet_forward"))
