@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     if (c < C) {
         const float mu = (KIND >= 1) ? mean[c] : 0.f;
         const float rs = (KIND == 2) ? rstd[c] : 0.f;
+#pragma unroll 8
         for (int r = r0 + rsub; r < min(rows, r0 + CR_ROWS); r += 4) {
             const size_t o = (size_t)r * C + c;
             if (KIND == 0) {
@@ -309,18 +310,38 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                                                 int nq, float scale, float* __restrict__ out) {
-    __shared__ float red[4][64];
+// 1024 threads = 16 row groups x 64 columns; each group walks its partials 8 independent loads at a time (a 64-channel
+// layer is ONE workgroup here: with 4 groups and a dependent load chain this kernel was 17 us of pure latency, 77 times
+// per training step).  Fixed summation order: deterministic.
+#define CRF_GROUPS 16
+__global__ __launch_bounds__(64 * CRF_GROUPS) void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                                             int C, int nq, float scale,
+                                                                             float* __restrict__ out) {
+    __shared__ float red[CRF_GROUPS][64];
     const int l = threadIdx.x & 63, rsub = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
     for (int q = 0; q < nq; ++q) {
         float s = 0.f;
-        if (c < C)
-            for (int b = rsub; b < nblocks; b += 4) s += partial[((size_t)q * nblocks + b) * C + c];
+        if (c < C) {
+            const float* p = partial + (size_t)q * nblocks * C + c;
+            int b = rsub;
+            for (; b + 7 * CRF_GROUPS < nblocks; b += 8 * CRF_GROUPS) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(b + u * CRF_GROUPS) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += t[u];
+            }
+            for (; b < nblocks; b += CRF_GROUPS) s += p[(size_t)b * C];
+        }
         red[rsub][l] = s;
         __syncthreads();
-        if (rsub == 0 && c < C) out[(size_t)q * C + c] = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+        if (rsub == 0 && c < C) {
+            float tot = 0.f;
+#pragma unroll
+            for (int g = 0; g < CRF_GROUPS; ++g) tot += red[g][l];
+            out[(size_t)q * C + c] = tot * scale;
+        }
         __syncthreads();
     }
 }
@@ -344,9 +365,9 @@ extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, flo
     dim3 grid(nb, (C + 63) / 64);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, mean);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f / rows, mean);
     hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, st, x, nullptr, nullptr, mean, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f / rows, var);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f / rows, var);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -364,7 +385,7 @@ extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* wo
     float* part = (float*)workspace;
     hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
                        rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f, out);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -437,8 +458,8 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* y,
     hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, z, dy, y, mean, rstd_out, rows, C,
                        relu, part);
     // partial layout [2][nb][C] -> dbeta = q0, dgamma = q1; finalize writes out[q*C + c]: use a 2*C temp = part tail
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nb, C, 1, 1.0f, dbeta);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part + (size_t)nb * C, nb, C, 1,
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f, dbeta);
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part + (size_t)nb * C, nb, C, 1,
                        1.0f, dgamma);
     const long total = (long)rows * C;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, z, y, mean,
