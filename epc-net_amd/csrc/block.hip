@@ -3,17 +3,19 @@
 //   xm  = (sum_{j in nbr(i)} x_j) / k         gather over the kNN index lists (the reference multiplies a dense
 //                                             (N,N) 0/1 mask: 2.15 GFLOP per cloud and block; here 5.2 M adds)
 //   t   = xm - x
-//   t   = relu(bn(conv_a(t)))                 64x64, bf16x3 MFMA (f32-accurate), BN folded into the weights
+//   t   = relu(bn(conv_a(t)))                 64x64 on the half-precision MFMA, BN folded into the weights
 //   t   = relu(bn(conv_b(t)))                 B operand = the previous accumulators (no LDS round trip)
 //   out = t + xm                  -> concat buffer slice (models/epc-net.py:134)
 //   x'  = relu(bn(conv_{b+1}(out)))           the next block's leading conv, fused (grid-wide dependency sits
 //                                             only at the gather, so one launch per block is the minimum)
 //
-// Geometry: 512 threads = 8 waves; each wave owns 32 consecutive points (one MFMA column tile: point = lane&31).
+// Two kernels: proxyconv_block_f16_kernel (EPC-Net: fp16 rows in HBM, one fp16 value per activation
+// against fp16 hi+lo weights) and proxyconv_block_kernel (EPC-Net-L: f32 rows, split-bf16 x3 layers, f32-accurate at
+// every stage boundary).  Each wave owns 32 consecutive points (one MFMA column tile: point = lane&31).
 // Transposed orientation out^T[ch][pt] = W^T x^T so that a layer's accumulators (channel in the register index,
-// point on the lane) are directly the next layer's B operands.
-// The gather runs 16 lanes x float4 per point (full 256-B rows, 4 points per wave-instruction), results go
-// through a per-wave LDS staging tile to switch between the row layout and the MFMA layout.
+// point on the lane) are directly the next layer's B operands.  The gather runs whole rows (f32: 16 lanes x float4,
+// 4 points per wave-instruction; fp16: 8 lanes x 16 B, 8 points), results go through a per-wave LDS staging tile to
+// switch between the row layout and the MFMA layout.
 #include "common.h"
 
 #ifndef BLK_WAVES

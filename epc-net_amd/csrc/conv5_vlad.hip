@@ -1,23 +1,20 @@
-// conv5 (+BN+ReLU) fused with what consumes it, on the bf16 MFMA in split ("bf16x3") arithmetic.
+// conv5 (+BN+ReLU) fused with what consumes it, on the half-precision MFMA in split arithmetic (common.h).
 //
-// Arithmetic: every f32 operand x is carried as hi = bf16(x), lo = bf16(x - hi); a product a*b is evaluated as
-// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with f32 accumulation inside v_mfma_f32_32x32x16_bf16.  Three bf16 MFMAs replace
-// eight f32 MFMAs (32x32x2) per 16-deep k-step: 5.3x fewer matrix-pipe cycles, at f32-level accuracy (descriptor
-// error vs the f32 oracle 4e-7; the 1e-4 budget of BASELINE.json is not reachable with plain bf16: 1.7e-4).
-//
-// MODE_VLAD  (EPC-Net: models/epc-net.py:136-139,147-148 + loupe.py:249-272)
-//   feat^T chunk (32 ch x 32 pts) = W5f^T X^T; epilogue per chunk: ReLU, |feat|^2 partial, store feat (f32), split the
-//   accumulators into hi/lo bf16 and use them directly as the B operand of P^T (64 clusters x 32 pts) += Wc^T feat^T
+// MODE_VLAD  (EPC-Net: models/epc-net.py:136-139,147-148 + loupe.py:249-272) -- "f16x2": one fp16 value per activation,
+//   weights as fp16 hi + lo of W * 2^8: two v_mfma_f32_32x32x16_f16 per product, f32 accumulation.
+//   feat^T chunk (32 ch x 32 pts) = W5f^T X^T; epilogue per chunk: ReLU, 2^-8, |feat|^2 partial, rounding to fp16: that
+//   fragment is stored (feat, accumulator-fragment order) AND is the B operand of P^T (64 clusters x 32 pts) += Wc^T feat^T
 //   ((feat*rn) @ Wc == (feat @ Wc) * rn, so the assignment GEMM runs while the norm is still being accumulated).
-//   Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64.
-// MODE_MAX   (EPC-Net-L: models/epc-net-l.py:84-92)
-//   same conv5, epilogue = max over the 32 points of the tile, atomicMax into pooled (values are >= 0 after ReLU,
-//   so the uint ordering equals the float ordering and 0-initialisation is the identity).
+//   Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64; assign (f32) + fp16 fragments.
+// MODE_MAX   (EPC-Net-L: models/epc-net-l.py:84-92) -- "bf16x3": hi = bf16(x), lo = bf16(x - hi), products
+//   lo*hi + hi*lo + hi*hi (a max-pool keeps single points: no averaging of an activation rounding), operands swapped so
+//   that D = [point][channel]: max over the tile's points is register-wise; per-workgroup maxima leave as 256-B
+//   atomic-max instructions (values are >= 0 after ReLU, so the uint ordering equals the float ordering and
+//   0-initialisation is the identity).
 //
 // Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x CIN) lives in
-// registers as split B fragments (CIN/2 VGPRs hi + CIN/2 lo) for all 32 output chunks; W5 (hi+lo: 4 B per weight,
-// 1 MB) streams through a double-buffered LDS chunk shared by the 8 waves (one barrier per chunk).  feat is written as
-// the hi/lo bf16 fragments the assignment GEMM consumes anyway (4 coalesced 1-KB stores per chunk).
+// registers as B fragments for all 32 output chunks; W5 (hi+lo: 4 B per weight, 1 MB) streams through a
+// double-buffered LDS chunk shared by the 8 waves (LDS-DMA, one barrier per chunk).
 #include <type_traits>
 #include "common.h"
 
@@ -54,7 +51,7 @@ struct C5Lds {  // offsets in floats (4 B)
     static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
     static constexpr int OFF_CBN = OFF_B5 + 1024;
     static constexpr int OFF_T = OFF_CBN + 128;            // per-wave 32 x 32 f32 transpose tile, row stride 36
-    static constexpr int T_WAVE = 33 * 36;         // + one spare row (the tile's 32 rnorm values)
+    static constexpr int T_WAVE = 33 * 36;         // (+ one spare row; MODE_MAX keeps its per-wave / per-workgroup maxima here)
     static constexpr int TOTAL = OFF_T + 8 * T_WAVE;
 };
 
