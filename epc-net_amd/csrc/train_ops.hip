@@ -563,6 +563,152 @@ __global__ __launch_bounds__(256) void neighbour_scatter_kernel(const float* __r
     }
 }
 
+// ---- transposed graph: for every point j the list of points i whose neighbour list holds j ----------------------------
+// The scatter above is bound by the f32 atomic rate (20 x 256-B atomics per point, 4 times per step); the graph is the
+// same for every block of a step, so it is transposed ONCE (count -> per-cloud exclusive scan -> fill) and the backward
+// becomes a gather like the forward.  Rows with more than `cap` entries (exact ties: duplicated / zero-padded clouds)
+// are not listed; the scatter kernel adds their contributions afterwards.
+// Layout: cloud c owns rlist[c*n*cap .. +n*cap); roff[j] = start of j's list (absolute), rdeg[j] = its length.
+__global__ __launch_bounds__(256) void transpose_count_kernel(const int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ cnt, int cap, int total_points,
+                                                              int n, int32_t* __restrict__ rdeg) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= total_points) return;
+    const int c = cnt[g];
+    if (c > cap) return;
+    if (lane < c) atomicAdd(rdeg + (size_t)(g / n) * n + idx[(size_t)g * cap + lane], 1);
+}
+
+// one workgroup per cloud: roff = cloud base + exclusive scan of rdeg; cursor (fill positions) reset to 0
+__global__ __launch_bounds__(1024) void transpose_scan_kernel(const int32_t* __restrict__ rdeg, int n, int cap,
+                                                              int32_t* __restrict__ roff, int32_t* __restrict__ cursor) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int j = j0 + tid;
+        const int v = j < n ? rdeg[(size_t)cloud * n + j] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (j < n) {
+            roff[(size_t)cloud * n + j] = cloud * n * cap + before + incl - v;
+            cursor[(size_t)cloud * n + j] = 0;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_fill_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                             int cap, int total_points, int n,
+                                                             const int32_t* __restrict__ roff, int32_t* __restrict__ cursor,
+                                                             int32_t* __restrict__ rlist) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= total_points) return;
+    const int c = cnt[g];
+    if (c > cap) return;
+    if (lane < c) {
+        const size_t j = (size_t)(g / n) * n + idx[(size_t)g * cap + lane];
+        const int pos = atomicAdd(cursor + j, 1);
+        rlist[roff[j] + pos] = g;   // absolute row of the contributing point
+    }
+}
+
+extern "C" int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap, int num_clouds, int n, int32_t* rdeg,
+                                 int32_t* roff, int32_t* cursor, int32_t* rlist, void* stream) {
+    EPC_CHECK_ARG(idx && cnt && rdeg && roff && cursor && rlist, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
+    const long total = (long)num_clouds * n;
+    EPC_CHECK_ARG(total * cap < (1L << 31), "too many edges for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(rdeg, 0, (size_t)total * sizeof(int32_t), st) != hipSuccess) {
+        epc_set_error("epc_knn_transpose: hipMemsetAsync failed");
+        return EPC_EHIP;
+    }
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    hipLaunchKernelGGL(transpose_count_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, rdeg);
+    hipLaunchKernelGGL(transpose_scan_kernel, dim3(num_clouds), dim3(1024), 0, st, rdeg, n, cap, roff, cursor);
+    hipLaunchKernelGGL(transpose_fill_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, roff, cursor, rlist);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// gather form of the backward: one wave per point j, lane = channel; dx[j] = (sum over j's list of dxm[i]) / k
+__global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* __restrict__ dxm,
+                                                                   const int32_t* __restrict__ rdeg,
+                                                                   const int32_t* __restrict__ roff,
+                                                                   const int32_t* __restrict__ rlist, int total_points,
+                                                                   float kdiv, float* __restrict__ dx) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= total_points) return;
+    const int deg = rdeg[j];
+    const int32_t* lst = rlist + roff[j];
+    float acc = 0.f;
+    for (int m0 = 0; m0 < deg; m0 += 64) {
+        const int mine = (m0 + lane < deg) ? lst[m0 + lane] : 0;
+        const int lim = min(64, deg - m0);
+        int m = 0;
+        for (; m + 4 <= lim; m += 4) {   // 4 independent row loads in flight
+            const int i0 = __shfl(mine, m), i1 = __shfl(mine, m + 1), i2 = __shfl(mine, m + 2), i3 = __shfl(mine, m + 3);
+            const float v0 = dxm[(size_t)i0 * 64 + lane], v1 = dxm[(size_t)i1 * 64 + lane];
+            const float v2 = dxm[(size_t)i2 * 64 + lane], v3 = dxm[(size_t)i3 * 64 + lane];
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; m < lim; ++m) acc += dxm[(size_t)__shfl(mine, m) * 64 + lane];
+    }
+    dx[(size_t)j * 64 + lane] = acc / kdiv;
+}
+
+// scatter restricted to the rows the transposed graph does not list (cnt > cap)
+__global__ __launch_bounds__(256) void neighbour_scatter_overflow_kernel(const float* __restrict__ dxm,
+                                                                         const float* __restrict__ xyz,
+                                                                         const int32_t* __restrict__ cnt,
+                                                                         const float* __restrict__ kth, int cap,
+                                                                         int total_points, int n, float kdiv,
+                                                                         float* __restrict__ dx) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= total_points || cnt[g] <= cap) return;
+    const int cloud_base = (g / n) * n;
+    const float v = dxm[(size_t)g * 64 + lane] / kdiv;
+    const float* pc = xyz + (size_t)cloud_base * 3;
+    const int i = g - cloud_base;
+    const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
+    const float sqi = sq3(xi, yi, zi), kv = kth[g];
+    for (int j = 0; j < n; ++j) {
+        const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
+        if (neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj)) >= kv)
+            atomicAdd(dx + (size_t)(cloud_base + j) * 64 + lane, v);
+    }
+}
+
+// dx[j] = sum_{i : j in nbr(i)} dxm[i] / k from the transposed graph (epc_knn_transpose); dx is overwritten.
+extern "C" int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz, const int32_t* cnt, const float* kth,
+                                             int cap, const int32_t* rdeg, const int32_t* roff, const int32_t* rlist,
+                                             int num_clouds, int n, int knn, float* dx, void* stream) {
+    EPC_CHECK_ARG(dxm && xyz && cnt && kth && rdeg && roff && rlist && dx, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
+    const long total = (long)num_clouds * n;
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
+                       (float)knn, dx);
+    hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
+                       (int)total, n, (float)knn, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
 // dx[j] += sum_{i : j in nbr(i)} dxm[i] / k.  dx must be zero-initialised (or hold the other gradient path).
 extern "C" int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
                                       const float* kth, int cap, int num_clouds, int n, int knn, float* dx,

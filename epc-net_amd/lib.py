@@ -34,7 +34,7 @@ EXPORTS = [
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
     "epc_gemm_f32", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
-    "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
+    "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
     "epc_softmax64_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
@@ -100,6 +100,8 @@ _lib.epc_bn_apply_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_i
 _lib.epc_bn_apply_bwd.argtypes = [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]
 _lib.epc_neighbour_mean_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
 _lib.epc_neighbour_mean_bwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
+_lib.epc_knn_transpose.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]
+_lib.epc_neighbour_mean_bwd_gather.argtypes = [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]
 _lib.epc_rownorm_fwd.argtypes = [_P, c_int, c_int, _P, _P, _P]
 _lib.epc_rownorm_bwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P]
 _lib.epc_softmax64_fwd.argtypes = [_P, c_int, _P, _P]

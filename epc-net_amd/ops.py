@@ -133,6 +133,22 @@ class KnnGraph:
         self.xyz = xyz.contiguous().float()   # callers pass Z-ordered clouds (morton_sort) for speed; any order is exact
         self.num_clouds, self.n = int(xyz.shape[0]), int(xyz.shape[1])
         self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
+        self._transposed = None
+
+    def transposed(self):
+        """(rdeg, roff, rlist): for every point the points that list it (epc_knn_transpose), built on first use -- the
+        backward of every block of a step gathers over it."""
+        if self._transposed is None:
+            M = self.num_clouds * self.n
+            dev = self.xyz.device
+            rdeg = torch.empty(M, dtype=torch.int32, device=dev)
+            roff = torch.empty(M, dtype=torch.int32, device=dev)
+            cursor = torch.empty(M, dtype=torch.int32, device=dev)
+            rlist = torch.empty(M * L.EPC_KNN_CAP, dtype=torch.int32, device=dev)
+            L.check(L.lib().epc_knn_transpose(self.idx.data_ptr(), self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n,
+                                              rdeg.data_ptr(), roff.data_ptr(), cursor.data_ptr(), rlist.data_ptr(), _st()))
+            self._transposed = (rdeg, roff, rlist)
+        return self._transposed
 
 
 class NeighbourMean(torch.autograd.Function):
@@ -153,10 +169,11 @@ class NeighbourMean(torch.autograd.Function):
     def backward(ctx, dxm):
         g = ctx.graph
         dxm = dxm.contiguous()
-        dx = torch.zeros_like(dxm)
-        L.check(L.lib().epc_neighbour_mean_bwd(dxm.data_ptr(), g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(),
-                                               g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, ctx.k, dx.data_ptr(),
-                                               _st()))
+        dx = torch.empty_like(dxm)
+        rdeg, roff, rlist = g.transposed()
+        L.check(L.lib().epc_neighbour_mean_bwd_gather(dxm.data_ptr(), g.xyz.data_ptr(), g.cnt.data_ptr(), g.kth.data_ptr(),
+                                                      L.EPC_KNN_CAP, rdeg.data_ptr(), roff.data_ptr(), rlist.data_ptr(),
+                                                      g.num_clouds, g.n, ctx.k, dx.data_ptr(), _st()))
         return dx, None, None
 
 

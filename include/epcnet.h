@@ -212,6 +212,17 @@ int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx,
 int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
                            const float* kth, int cap, int num_clouds, int n, int knn, float* dx, void* stream);
 
+/* The kNN graph transposed: for every point j the points i whose neighbour list holds j (rows with more than `cap`
+ * entries are not listed).  rdeg, roff, cursor: (num_clouds*n) int32; rlist: (num_clouds*n*cap) int32 holding absolute
+ * row numbers, cloud c's lists inside [c*n*cap, (c+1)*n*cap).  Built once per step: the graph is the same for every block. */
+int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap, int num_clouds, int n, int32_t* rdeg,
+                      int32_t* roff, int32_t* cursor, int32_t* rlist, void* stream);
+/* Backward of the neighbour mean as a GATHER over the transposed graph (dx is overwritten; rows with cnt > cap are
+ * added by an exact scan): the atomic scatter of epc_neighbour_mean_bwd is bound by the f32 atomic rate. */
+int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz, const int32_t* cnt, const float* kth, int cap,
+                                  const int32_t* rdeg, const int32_t* roff, const int32_t* rlist, int num_clouds, int n,
+                                  int knn, float* dx, void* stream);
+
 /* tf.nn.l2_normalize over the last axis (models/epc-net.py:148): y = x*rn, rn = rsqrt(max(sum x^2, 1e-12)). */
 int epc_rownorm_fwd(const float* x, int rows, int C, float* y, float* rn, void* stream);
 int epc_rownorm_bwd(const float* dy, const float* y, const float* rn, int rows, int C, float* dx, void* stream);
