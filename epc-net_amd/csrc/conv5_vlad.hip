@@ -50,9 +50,14 @@ struct C5Lds {  // offsets in floats (4 B)
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
     static constexpr int OFF_CBN = OFF_B5 + 1024;
-    static constexpr int OFF_T = OFF_CBN + 128;            // per-wave 32 x 32 f32 transpose tile, row stride 36
-    static constexpr int T_WAVE = 33 * 36;         // (+ one spare row; MODE_MAX keeps its per-wave / per-workgroup maxima here)
-    static constexpr int TOTAL = OFF_T + 8 * T_WAVE;
+    // per-wave 32 x 32 f32 transpose tile (row stride 36) of the FINAL epilogue: it aliases the W5 stream buffers, which
+    // are dead by then (a barrier separates the last chunk from the first tile write) -- 38 KB less LDS, so that a
+    // kNN workgroup (65 KB) of another stream can share the CU.  MODE_MAX keeps its per-wave / per-workgroup maxima in
+    // a small area of its own.
+    static constexpr int OFF_T = OFF_W5;
+    static constexpr int T_WAVE = 33 * 36;
+    static constexpr int OFF_MAX = OFF_CBN + 128;          // MODE_MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
+    static constexpr int TOTAL = OFF_MAX + 1536;
 };
 
 // packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            float* __restrict__ pooled) {
     using L = C5Lds<CIN>;
     constexpr int STEPS = CIN / 16;
+    static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -151,11 +157,11 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     // max-pool mode: fold the 8 per-wave maxima of chunk c (written before the barrier that ended it) into wgmax
     auto fold_chunk_max = [&](int c) {
         if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
-            const float* red = lds + L::OFF_T + (c & 1) * 256 + tid;
+            const float* red = lds + L::OFF_MAX + (c & 1) * 256 + tid;
             float m = red[0];
 #pragma unroll
             for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
-            lds[L::OFF_T + 512 + 32 * c + tid] = m;
+            lds[L::OFF_MAX + 512 + 32 * c + tid] = m;
         }
     };
     auto do_chunk = [&](int c, auto bufc) {
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             // area) and the workgroup's 1024 maxima leave as sixteen 256-B atomic wave-instructions at the very end;
             // otherwise (n not a multiple of 256) each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
             // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
-            float* red = lds + L::OFF_T + (c & 1) * 256 + wave * 32;
+            float* red = lds + L::OFF_MAX + (c & 1) * 256 + wave * 32;
             float m = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         fold_chunk_max(31);
         __syncthreads();
         unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
-        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_T + 512 + o]));
+        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 512 + o]));
     }
 
     if (MODE == MODE_VLAD && active) {
