@@ -19,7 +19,7 @@
 #include "common.h"
 
 #ifndef BLK_WAVES
-#define BLK_WAVES 8
+#define BLK_WAVES 12  // f32 kernel: 12 x 8.7 KB staging tiles + the 49-KB weight pack = 154 KB (3 waves per SIMD)
 #endif
 #define BLK_THREADS (64 * BLK_WAVES)
 #define ST_STRIDE 68  // floats per staged row: 64 + 4 pad -> conflict-free b128 reads in both layouts
