@@ -107,3 +107,33 @@ def test_adam_matches_tensorflow_rule(dev):
     lr_t = 5e-5 * np.sqrt(1 - 0.999 ** 7) / (1 - 0.9 ** 7)
     assert rel(md, m2) <= 1e-6 and rel(vd, v2) <= 2e-5      # (1 - 0.999f) is 0.00100005 in f32, as in TensorFlow's kernel
     assert np.abs((wd.cpu().double() - (w64 - lr_t * m2 / (v2.sqrt() + 1e-8))).numpy()).max() <= 5e-7   # f32 ulp of |w| ~ 2 is 2.4e-7
+
+
+@pytest.mark.parametrize("cls,groups", [("G_VLAD", 4), ("G_VLAD", 1), ("NetVLAD", None)])
+@pytest.mark.parametrize("is_training", [False, True])
+def test_loupe_classes_match_oracle(dev, cls, groups, is_training):
+    """The pooling classes as op-level API (reference loupe.py:103-333): G_VLAD / NetVLAD(...).forward(features) on
+    random unit features against the oracle's restatement, inference and training mode (batch statistics)."""
+    V = H.pkg("variables")
+    lp = H.pkg("loupe")
+    B, N, F, C, D = 2, 256, 1024, 64, 256
+    rng = np.random.RandomState(3)
+    feats = rng.randn(B * N, F).astype(np.float32)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    st = V.reset_default_store(device=dev, seed=5)
+    with V.variable_scope("query_triplets"), V.variable_scope("VLAD"):
+        kw = dict(feature_size=F, max_samples=N, cluster_size=C, output_dim=D, gating=True, add_batch_norm=True,
+                  is_training=is_training)
+        pool = lp.G_VLAD(groups=groups, **kw) if cls == "G_VLAD" else lp.NetVLAD(**kw)
+        pool.declare_variables()
+        st.randomize_statistics(1)
+        w = {k[len("query_triplets/"):]: v.detach().cpu().numpy() for k, v in st.vars.items()}
+        with torch.no_grad():
+            out = pool.forward(torch.from_numpy(feats).to(dev)).cpu().numpy()
+    ost = O.State(w, np.float32)
+    if cls == "G_VLAD":
+        ref = O.g_vlad_forward(ost, feats, N, groups, is_training)
+    else:
+        ref = O.netvlad_forward(ost, feats, N, is_training)
+    assert out.shape == (B, D)
+    assert np.abs(out - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-6, np.abs(out - ref).max()
