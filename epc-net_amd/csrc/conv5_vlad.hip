@@ -338,13 +338,15 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 sum += e;
             }
         sum += __shfl_xor(sum, 32);
-        float* arow = assign + (size_t)(g0 + j) * 64 + 4 * h;
+        if (assign) {  // the f32 point-major copy is for op-level callers; the fused pipeline passes NULL (67 MB less HBM)
+            float* arow = assign + (size_t)(g0 + j) * 64 + 4 * h;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                st4(arow + 32 * t + 8 * g, make_float4(P[t][4 * g] / sum, P[t][4 * g + 1] / sum,
-                                                       P[t][4 * g + 2] / sum, P[t][4 * g + 3] / sum));
+                for (int g = 0; g < 4; ++g)
+                    st4(arow + 32 * t + 8 * g, make_float4(P[t][4 * g] / sum, P[t][4 * g + 1] / sum,
+                                                           P[t][4 * g + 2] / sum, P[t][4 * g + 3] / sum));
+        }
         if (h == 0) rnorm[g0 + j] = rn;
         // a * 2^14 as fp16 B fragments of the aggregate GEMM (cluster -> lane, 8 consecutive points -> fragment) and the
         // tile's partial a_sum (loupe.py:276).  The 2^14 keeps small assignments in fp16's normal range; it is exact
@@ -404,7 +406,7 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
 extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5,
                                     int num_points_total, void* feat_frag, float* rnorm, float* assign,
                                     void* assign_frag, float* apart, void* stream) {
-    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign && assign_frag && apart, "null pointer");
+    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;

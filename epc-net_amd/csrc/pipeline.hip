@@ -49,7 +49,6 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
     if (c->arch == EPC_ARCH_EPC_NET) {
         w.feat = take(M * 1024 * 2);   // fp16 fragments
         w.rnorm = take(M * 4);
-        w.assign = take(M * 64 * 4);
         w.afrag = take(M * 64 * 2);    // fp16 fragments
         w.vpart = take((size_t)mb * AGG_SPLITS * 65536 * 4);
         w.apart = take(M / 32 * 64 * 4);
@@ -193,12 +192,11 @@ extern "C" int epc_net_forward_profiled(const epc_cfg* cfg, const void* packed, 
         if (cfg->arch == EPC_ARCH_EPC_NET) {
             float* feat = (float*)(ws + w.feat);
             float* rnorm = (float*)(ws + w.rnorm);
-            float* assign = (float*)(ws + w.assign);
             float* vpart = (float*)(ws + w.vpart);
             float* apart = (float*)(ws + w.apart);
             TRY(mark(prof, EPC_STAGE_CONV5, stream));
             float* afrag = (float*)(ws + w.afrag);
-            TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, assign, afrag,
+            TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, nullptr, afrag,
                                      apart, stream));
             TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
             const int asp = agg_splits(n);

@@ -149,7 +149,8 @@ int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, c
  *               point 32g + (l&31), element q = channel 32c + 16s + 8(q>>2) + 4(l>>5) + (q&3).  Range: values must be
  *               below 65504 (a BN+ReLU output);
  *   rnorm (M)   rsqrt(max(|feat|^2, 1e-12)) from the f32 values;
- *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major (from the f32-accurate feat);
+ *   assign (M,64)  softmax(cluster_bn((feat*rnorm) @ cluster_weights)), f32, point-major; OPTIONAL (may be NULL: the
+ *               aggregate consumes assign_frag);
  *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, 64 lanes, 8 fp16): assign * 2^14 as B fragments (lane l of
  *               (tile g, t, s): cluster 32t + (l&31) at points 32g + 16s + 8(l>>5) + 0..7);
  *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276). */
