@@ -118,7 +118,7 @@ __device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& p0, bf16x8
     }
 }
 
-template <int BLOCKS>  // 32-row blocks of this operand tile (2 * WM or 2 * WN)
+template <int BLOCKS, int PIECES>  // 32-row blocks of this operand tile (2 * WM or 2 * WN); bf16 pieces kept (2 or 3)
 __device__ __forceinline__ void stage_split_fragments(const float* __restrict__ P, long s_outer, long s_k, int outer0,
                                                       int outer_lim, int kt, int k_lim, u32x4 (*dst)[2][3][64], int tid) {
     const bool k_contig = s_k == 1;
@@ -142,11 +142,11 @@ __device__ __forceinline__ void stage_split_fragments(const float* __restrict__ 
         const int l2 = (row & 31) + 32 * (kg & 1);
         dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, p0);
         dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, p1);
-        dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
+        if (PIECES == 3) dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int PIECES>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ u32x4 As[2 * WM][2][3][64];  // 12 KB per WM
@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 
     for (int kt = k0; kt < k1; kt += S_BK) {
-        stage_split_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt, k1, As, tid);
-        stage_split_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt, k1, Bs, tid);
+        stage_split_fragments<2 * WM, PIECES>(A, g.sAm, g.sAk, m0, g.M, kt, k1, As, tid);
+        stage_split_fragments<2 * WN, PIECES>(B, g.sBn, g.sBk, n0, g.N, kt, k1, Bs, tid);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[WM][3], b[WN][3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
+            for (int pc = 0; pc < PIECES; ++pc) {
 #pragma unroll
                 for (int rb = 0; rb < WM; ++rb) a[rb][pc] = __builtin_bit_cast(bf16x8, As[WM * wm + rb][s][pc][lane]);
 #pragma unroll
@@ -190,9 +190,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
                 for (int cb = 0; cb < WN; ++cb) {
                     f32x16 c = acc[rb][cb];
-                    c = mfma_bf16(a[rb][2], b[cb][0], c);
-                    c = mfma_bf16(a[rb][0], b[cb][2], c);
-                    c = mfma_bf16(a[rb][1], b[cb][1], c);
+                    if (PIECES == 3) {
+                        c = mfma_bf16(a[rb][2], b[cb][0], c);
+                        c = mfma_bf16(a[rb][0], b[cb][2], c);
+                        c = mfma_bf16(a[rb][1], b[cb][1], c);
+                    }
                     c = mfma_bf16(a[rb][1], b[cb][0], c);
                     c = mfma_bf16(a[rb][0], b[cb][1], c);
                     c = mfma_bf16(a[rb][0], b[cb][0], c);
@@ -224,14 +226,36 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 }
 
 template <int WM, int WN>
-static void launch_gemm_split(const GemmArgs& g, int batch, hipStream_t st) {
+static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStream_t st) {
     dim3 grid((g.N + 64 * WN - 1) / (64 * WN), (g.M + 64 * WM - 1) / (64 * WM), batch * g.splitk);
-    hipLaunchKernelGGL((gemm_split_kernel<WM, WN>), grid, dim3(256), 0, st, g);
+    if (pieces == 2)
+        hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 2>), grid, dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3>), grid, dim3(256), 0, st, g);
 }
+
+static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                     long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                     int pieces, void* stream);
 
 extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                             long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
                             int splitk, int accumulate, void* stream) {
+    return gemm_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk, accumulate, 3, stream);
+}
+
+// The same GEMM with TWO bf16 pieces per operand (three products: 2^-16 relative per product).  For the backward
+// GEMMs of the training step: they are linear in the incoming gradient, so the error stays at 1e-5 of the gradient
+// (the forward keeps three pieces: it decides ReLU masks and BatchNorm statistics).
+extern "C" int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                 long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
+                                 int splitk, int accumulate, void* stream) {
+    return gemm_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk, accumulate, 2, stream);
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                     long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                     int pieces, void* stream) {
     EPC_CHECK_ARG(A && B && C, "null pointer");
     EPC_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1 && ldc >= N, "bad shape");
     EPC_CHECK_ARG((long)batch * splitk <= 65535, "batch*splitk too large");
@@ -251,10 +275,10 @@ extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const floa
     // sides of at least 64: the split-bf16 kernel with the tile that fits; short sides stay on the f32 MFMA kernel
     if (M >= 64 && N >= 64 && K >= 32) {
         const bool bigm = M >= 128, bign = N >= 128;
-        if (bigm && bign) launch_gemm_split<2, 2>(g, batch, st);
-        else if (bigm) launch_gemm_split<2, 1>(g, batch, st);
-        else if (bign) launch_gemm_split<1, 2>(g, batch, st);
-        else launch_gemm_split<1, 1>(g, batch, st);
+        if (bigm && bign) launch_gemm_split<2, 2>(g, batch, pieces, st);
+        else if (bigm) launch_gemm_split<2, 1>(g, batch, pieces, st);
+        else if (bign) launch_gemm_split<1, 2>(g, batch, pieces, st);
+        else launch_gemm_split<1, 1>(g, batch, pieces, st);
         EPC_CHECK_LAUNCH();
         return EPC_OK;
     }

@@ -19,8 +19,9 @@ def _ws(rows, C, device):
     return torch.empty(n, dtype=torch.uint8, device=device), n
 
 
-def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False):
-    """out = op(A) @ op(B) (+ bias) on the f32 MFMA.  A, B: 2-D, or 3-D with a leading batch dim (same batch)."""
+def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False, fast=False):
+    """out = op(A) @ op(B) (+ bias).  A, B: 2-D, or 3-D with a leading batch dim (same batch).  f32-accurate split-bf16
+    MFMA arithmetic (three pieces per operand); ``fast`` = two pieces (backward GEMMs: linear in the gradient)."""
     L.require_gpu()
     batched = A.dim() == 3
     a2 = A[0] if batched else A
@@ -35,10 +36,10 @@ def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accu
     sb = b2.stride()
     sAm, sAk = (sa[1], sa[0]) if trans_a else (sa[0], sa[1])
     sBk, sBn = (sb[1], sb[0]) if trans_b else (sb[0], sb[1])
-    L.check(L.lib().epc_gemm_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                 M, N, K, sAm, sAk, sBk, sBn, out.stride(-2), nb, A.stride(0) if batched else 0,
-                                 B.stride(0) if batched else 0, out.stride(0) if batched else 0, int(splitk),
-                                 1 if accumulate else 0, _st()))
+    fn = L.lib().epc_gemm_f32_fast if fast else L.lib().epc_gemm_f32
+    L.check(fn(A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+             M, N, K, sAm, sAk, sBk, sBn, out.stride(-2), nb, A.stride(0) if batched else 0,
+             B.stride(0) if batched else 0, out.stride(0) if batched else 0, int(splitk), 1 if accumulate else 0, _st()))
     return out
 
 
@@ -68,8 +69,8 @@ class Linear(torch.autograd.Function):
         dy = dy.contiguous()
         rows, cin = x.shape
         cout = W.shape[1]
-        dx = gemm(dy, W, trans_b=True) if ctx.needs_input_grad[0] else None
-        dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows))
+        dx = gemm(dy, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
+        dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
         db = None
         if ctx.has_bias:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
@@ -233,8 +234,8 @@ class VladAggregate(torch.autograd.Function):
     def backward(ctx, dv):
         f, a = ctx.saved_tensors
         dv = dv.contiguous()
-        df = gemm(a, dv, trans_b=True)   # (B,N,C) @ (B,F,C)^T -> (B,N,F)
-        da = gemm(f, dv)                 # (B,N,F) @ (B,F,C)   -> (B,N,C)
+        df = gemm(a, dv, trans_b=True, fast=True)   # (B,N,C) @ (B,F,C)^T -> (B,N,F)
+        da = gemm(f, dv, fast=True)                 # (B,N,F) @ (B,F,C)   -> (B,N,C)
         return df, da
 
 

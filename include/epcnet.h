@@ -191,6 +191,11 @@ int epc_pairwise_topk(const float* database, int num_db, const float* queries, i
 int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
+/* Same interface, two bf16 pieces per operand instead of three (half the matrix-pipe work, 2^-16 relative per product):
+ * for GEMMs that are linear in a gradient (the backward of the training step). */
+int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                 long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                 void* stream);
 
 /* tf.nn.moments over the rows of x (rows, C): mean and POPULATION variance (utils/tf_util.py:472). */
 size_t epc_colreduce_workspace_bytes(int rows, int C);
