@@ -888,3 +888,137 @@ extern "C" int epc_adam_step(float* w, float* m, float* v, const float* g, long 
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Moving-average update of the BatchNorm statistics (tf.train.ExponentialMovingAverage.apply, utils/tf_util.py:474-487;
+// slim's assign_moving_average): shadow -= (1 - decay) * (shadow - value).  One launch per statistic instead of three
+// elementwise torch kernels (34 statistics per EPC-Net step); decay comes from device memory when decay_dev != NULL
+// (HIP-graph replay with a changing bn_decay).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void ema_update_kernel(float* __restrict__ shadow, const float* __restrict__ value, long n, float decay,
+                                  const float* __restrict__ decay_dev) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n) return;
+    const float d = decay_dev ? *decay_dev : decay;
+    const float sh = shadow[o];
+    shadow[o] = sh - (sh - value[o]) * (1.0f - d);
+}
+
+extern "C" int epc_ema_update(float* shadow, const float* value, long n, float decay, const float* decay_dev,
+                              void* stream) {
+    EPC_CHECK_ARG(shadow && value && n > 0, "bad argument");
+    hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, shadow,
+                       value, n, decay, decay_dev);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Many small tensors, one launch: the 62 Adam updates and the 34 moving-average updates of a step are each ~5 us of
+// fixed launch cost for a few KB of work.  The pointer table travels BY VALUE in the kernel arguments (up to
+// MT_MAX tensors per launch, 40 B each: inside the 4-KB kernarg segment), so nothing is staged through memory and the
+// launch can be captured in a HIP graph.  blk0[t] = first block of tensor t (256 elements per block).
+// ----------------------------------------------------------------------------------------------------------------
+#define MT_MAX 64
+struct MultiTensorArgs {
+    float* a[MT_MAX];        // adam: w      ema: shadow
+    float* b[MT_MAX];        // adam: m      ema: (unused)
+    float* c[MT_MAX];        // adam: v      ema: (unused)
+    const float* d[MT_MAX];  // adam: g      ema: value
+    int blk0[MT_MAX + 1];
+    int count;
+};
+
+struct MultiTensorLens {
+    long n[MT_MAX];
+};
+
+__device__ __forceinline__ int mt_find(const MultiTensorArgs& t, int block) {
+    int lo = 0, hi = t.count - 1;  // last tensor whose first block is <= block
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.blk0[mid] <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void adam_multi_kernel(MultiTensorArgs t, MultiTensorLens n, float lr_t, const float* __restrict__ lr_t_dev,
+                                  float b1, float b2, float eps) {
+    const int k = mt_find(t, blockIdx.x);
+    const long o = (long)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
+    if (o >= n.n[k]) return;
+    const float lr = lr_t_dev ? *lr_t_dev : lr_t;
+    const float gi = t.d[k][o];
+    const float mi = b1 * t.b[k][o] + (1.0f - b1) * gi;
+    const float vi = b2 * t.c[k][o] + (1.0f - b2) * gi * gi;
+    t.b[k][o] = mi;
+    t.c[k][o] = vi;
+    t.a[k][o] = t.a[k][o] - lr * mi / (sqrtf(vi) + eps);
+}
+
+// t.c[k] != NULL marks a statistic that follows the scheduled decay (tf_util BN); the others use the fixed one (slim BN)
+__global__ void ema_multi_kernel(MultiTensorArgs t, MultiTensorLens n, float fixed_decay, float sched_decay,
+                                 const float* __restrict__ sched_decay_dev) {
+    const int k = mt_find(t, blockIdx.x);
+    const long o = (long)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
+    if (o >= n.n[k]) return;
+    const float d = t.c[k] ? (sched_decay_dev ? *sched_decay_dev : sched_decay) : fixed_decay;
+    const float sh = t.a[k][o];
+    t.a[k][o] = sh - (sh - t.d[k][o]) * (1.0f - d);
+}
+
+static int mt_fill(MultiTensorArgs& t, MultiTensorLens& ln, int count, float* const* a, float* const* b, float* const* c,
+                   const float* const* d, const long* n) {
+    int blocks = 0;
+    t.count = count;
+    for (int k = 0; k < count; ++k) {
+        t.a[k] = a[k];
+        t.b[k] = b ? b[k] : nullptr;
+        t.c[k] = c ? c[k] : nullptr;
+        t.d[k] = d[k];
+        ln.n[k] = n[k];
+        t.blk0[k] = blocks;
+        blocks += (int)((n[k] + 255) / 256);
+    }
+    t.blk0[count] = blocks;
+    return blocks;
+}
+
+// epc_adam_step / epc_adam_step_dev over `count` tensors in ceil(count / 64) launches (host arrays of device pointers).
+extern "C" int epc_adam_multi(int count, float* const* w, float* const* m, float* const* v, const float* const* g,
+                              const long* n, float lr, float beta1, float beta2, float eps, int t,
+                              const float* lr_t_dev, void* stream) {
+    EPC_CHECK_ARG(count > 0 && w && m && v && g && n && (lr_t_dev || t >= 1), "bad argument");
+    const double lr_t = lr_t_dev ? 0.0 : (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    for (int k0 = 0; k0 < count; k0 += MT_MAX) {
+        MultiTensorArgs a;
+        MultiTensorLens ln;
+        const int c = count - k0 < MT_MAX ? count - k0 : MT_MAX;
+        for (int k = 0; k < c; ++k) EPC_CHECK_ARG(w[k0 + k] && m[k0 + k] && v[k0 + k] && g[k0 + k] && n[k0 + k] > 0, "null tensor");
+        const int blocks = mt_fill(a, ln, c, w + k0, m + k0, v + k0, g + k0, n + k0);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, ln, (float)lr_t, lr_t_dev,
+                           beta1, beta2, eps);
+    }
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// epc_ema_update over `count` statistics in one launch.  scheduled[k] != 0: the statistic uses sched_decay (read from
+// sched_decay_dev when that is not NULL); otherwise fixed_decay.
+extern "C" int epc_ema_multi(int count, float* const* shadow, const float* const* value, const long* n,
+                             const int* scheduled, float fixed_decay, float sched_decay, const float* sched_decay_dev,
+                             void* stream) {
+    EPC_CHECK_ARG(count > 0 && shadow && value && n && scheduled, "bad argument");
+    for (int k0 = 0; k0 < count; k0 += MT_MAX) {
+        MultiTensorArgs a;
+        MultiTensorLens ln;
+        const int c = count - k0 < MT_MAX ? count - k0 : MT_MAX;
+        for (int k = 0; k < c; ++k) EPC_CHECK_ARG(shadow[k0 + k] && value[k0 + k] && n[k0 + k] > 0, "null tensor");
+        const int blocks = mt_fill(a, ln, c, shadow + k0, nullptr, nullptr, value + k0, n + k0);
+        for (int k = 0; k < c; ++k) a.c[k] = scheduled[k0 + k] ? shadow[k0 + k] : nullptr;
+        hipLaunchKernelGGL(ema_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, ln, fixed_decay, sched_decay,
+                           sched_decay_dev);
+    }
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -35,7 +35,7 @@ EXPORTS = [
     "epc_morton_sort",
     "epc_gemm_f32", "epc_gemm_f32_fast", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
-    "epc_softmax64_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_crc32c",
+    "epc_softmax64_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -109,6 +109,9 @@ _lib.epc_softmax64_fwd.argtypes = [_P, c_int, _P, _P]
 _lib.epc_softmax64_bwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_adam_step.argtypes = [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]
 _lib.epc_adam_step_dev.argtypes = [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, _P]
+_lib.epc_ema_update.argtypes = [_P, _P, c_long, c_float, _P, _P]
+_lib.epc_adam_multi.argtypes = [c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P, _P]
+_lib.epc_ema_multi.argtypes = [c_int, _P, _P, _P, _P, c_float, c_float, _P, _P]
 _lib.epc_profile_create.argtypes = [POINTER(_P)]
 _lib.epc_profile_destroy.argtypes = [_P]
 _lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]

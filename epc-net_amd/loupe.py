@@ -39,8 +39,8 @@ def _slim_batch_norm(x2d, scope, is_training, fused):
     if is_training:
         y, mean, var = ops.BatchNormTrain.apply(x2d, gamma, beta, BN_EPS, 0)
         rows = int(x2d.shape[0])
-        _ema_update(mm, mean, SLIM_DECAY)
-        _ema_update(mv, var * (rows / max(rows - 1, 1)) if fused else var, SLIM_DECAY)
+        _ema_update(mm, mean, SLIM_DECAY, scheduled=False)
+        _ema_update(mv, var * (rows / max(rows - 1, 1)) if fused else var, SLIM_DECAY, scheduled=False)
         return y
     return ops.bn_inference(x2d, mm, mv, gamma, beta, BN_EPS, False)
 

@@ -260,3 +260,30 @@ def adam_step(w, m, v, g, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
         return
     L.check(L.lib().epc_adam_step(w.data_ptr(), m.data_ptr(), v.data_ptr(), g.contiguous().data_ptr(), w.numel(), float(lr),
                                   float(beta1), float(beta2), float(eps), int(t), _st()))
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def adam_multi(ws, ms, vs, gs, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """adam_step over lists of tensors in one launch per 64 tensors (epc_adam_multi)."""
+    import ctypes
+    gs = [g.contiguous() for g in gs]
+    n = (ctypes.c_long * len(ws))(*[w.numel() for w in ws])
+    dev_lr = lr.data_ptr() if torch.is_tensor(lr) else None
+    L.check(L.lib().epc_adam_multi(len(ws), _ptr_array(ws), _ptr_array(ms), _ptr_array(vs), _ptr_array(gs), n,
+                                   0.0 if torch.is_tensor(lr) else float(lr), float(beta1), float(beta2), float(eps),
+                                   int(t), dev_lr, _st()))
+
+
+def ema_multi(shadows, values, scheduled, fixed_decay, sched_decay):
+    """All moving-average updates of a step in one launch (epc_ema_multi).  ``sched_decay``: float or 0-d device tensor."""
+    import ctypes
+    values = [v.detach().contiguous() for v in values]
+    n = (ctypes.c_long * len(shadows))(*[s_.numel() for s_ in shadows])
+    flags = (ctypes.c_int * len(shadows))(*[1 if f else 0 for f in scheduled])
+    dev = sched_decay.data_ptr() if torch.is_tensor(sched_decay) else None
+    L.check(L.lib().epc_ema_multi(len(shadows), _ptr_array(shadows), _ptr_array(values), n, flags, float(fixed_decay),
+                                  0.0 if torch.is_tensor(sched_decay) else float(sched_decay), dev, _st()))

@@ -106,9 +106,16 @@ class TrainStep:
         return loss.detach(), lr, bn_decay
 
     def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
+        from .utils import tf_util
+        from .loupe import SLIM_DECAY
         for name in self.trainable_names():
             self.store.vars[name].grad = None
-        loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
+        tf_util.defer_ema_updates()                 # the 34 moving-average updates are applied in one launch below
+        try:
+            loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
+        except BaseException:
+            tf_util._deferred_ema = None            # a failed forward applies nothing
+            raise
         loss.backward()
         with torch.no_grad():
             names = self.trainable_names()
@@ -116,10 +123,11 @@ class TrainStep:
             for name in names:
                 w = self.store.vars[name]
                 grads.append(w.grad if w.grad is not None else torch.zeros_like(w))
+            # data-parallel runs average the moving statistics too: apply the updates first
+            tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9)
             self._average_over_ranks(grads)
-            for name, g in zip(names, grads):
-                w = self.store.vars[name]
-                ops.adam_step(w, self.m[name], self.v[name], g, lr, t, self.beta1, self.beta2, self.eps)  # :273-277
+            ops.adam_multi([self.store.vars[k] for k in names], [self.m[k] for k in names], [self.v[k] for k in names],
+                           grads, lr, t, self.beta1, self.beta2, self.eps)                                # :273-277
         return loss
 
     def _average_over_ranks(self, grads) -> None:

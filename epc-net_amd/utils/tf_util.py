@@ -96,10 +96,40 @@ def knn_index(pc: torch.Tensor):
     return kth, idx, cnt
 
 
-def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay: float) -> None:
-    """tf.train.ExponentialMovingAverage.apply / assign_moving_average: shadow -= (1 - decay) * (shadow - value)."""
-    with torch.no_grad():
-        shadow.sub_((shadow - value) * (1.0 - (decay if torch.is_tensor(decay) else float(decay))))
+# Moving-average updates can be deferred: a training step collects them (defer_ema_updates) and applies all of them in ONE
+# launch at its end (flush_ema_updates) -- 34 statistics per EPC-Net step, each a few hundred bytes.
+_deferred_ema = None
+
+
+def defer_ema_updates() -> None:
+    global _deferred_ema
+    _deferred_ema = []
+
+
+def flush_ema_updates(fixed_decay: float, sched_decay) -> None:
+    """Apply the collected updates: entries recorded with decay == fixed_decay use it, all others ``sched_decay``."""
+    global _deferred_ema
+    pend, _deferred_ema = _deferred_ema, None
+    if pend:
+        from .. import ops
+        ops.ema_multi([p[0] for p in pend], [p[1] for p in pend], [p[2] for p in pend], fixed_decay, sched_decay)
+        default_store().version += 1
+
+
+def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay, scheduled: bool = True) -> None:
+    """tf.train.ExponentialMovingAverage.apply / assign_moving_average: shadow -= (1 - decay) * (shadow - value), one
+    kernel (epc_ema_update).  ``decay`` is a float, or a 0-d device tensor when the step is replayed as a HIP graph.
+    ``scheduled``: the decay is the bn_decay schedule (tf_util BN) rather than slim's fixed 0.999."""
+    if _deferred_ema is not None:
+        _deferred_ema.append((shadow, value, scheduled))
+        return
+    value = value.detach().contiguous()
+    if torch.is_tensor(decay):
+        L.check(L.lib().epc_ema_update(shadow.data_ptr(), value.data_ptr(), shadow.numel(), 0.0, decay.data_ptr(),
+                                       L.current_stream()))
+    else:
+        L.check(L.lib().epc_ema_update(shadow.data_ptr(), value.data_ptr(), shadow.numel(), float(decay), None,
+                                       L.current_stream()))
     default_store().version += 1
 
 

@@ -245,6 +245,19 @@ int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr
 int epc_adam_step_dev(float* w, float* m, float* v, const float* g, long n, const float* lr_t_dev, float beta1,
                       float beta2, float eps, void* stream);
 
+/* BatchNorm moving-average update (utils/tf_util.py:474-487, slim assign_moving_average):
+ * shadow -= (1 - decay) * (shadow - value); decay is read from decay_dev (device, one float) when that is not NULL. */
+int epc_ema_update(float* shadow, const float* value, long n, float decay, const float* decay_dev, void* stream);
+
+/* Many small tensors, one launch (host arrays of `count` device pointers / element counts; the table travels in the
+ * kernel arguments, so the launch is HIP-graph capturable): epc_adam_step(_dev) over all trainables of a step, and
+ * epc_ema_update over all BatchNorm statistics (scheduled[k] != 0: statistic k follows sched_decay -- read from
+ * sched_decay_dev when not NULL --, otherwise fixed_decay). */
+int epc_adam_multi(int count, float* const* w, float* const* m, float* const* v, const float* const* g, const long* n,
+                   float lr, float beta1, float beta2, float eps, int t, const float* lr_t_dev, void* stream);
+int epc_ema_multi(int count, float* const* shadow, const float* const* value, const long* n, const int* scheduled,
+                  float fixed_decay, float sched_decay, const float* sched_decay_dev, void* stream);
+
 /* Offsets (in bytes) of the per-stage sub-buffers inside the packed weight buffer, for the stage entry
  * points above.  stage: 0 conv1, 1..4 block b, 5 conv5(+assign), 6 head. */
 size_t epc_net_packed_offset(const epc_cfg* cfg, int stage);
