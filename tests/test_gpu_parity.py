@@ -291,3 +291,34 @@ def test_plain_c_caller(dev):
     r = subprocess.run([os.path.join(root, "examples", "epcnet_forward"), "5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "5 clouds x 4096 points" in r.stdout
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] at full size (64 x 4096 x 3): properties that need no oracle run of that size.
+    (a) unit-norm, finite descriptors; (b) a cloud's descriptor does not depend on its batch (bit-identical alone, in a
+    batch of 64, and at another position); (c) kNN lists of sampled queries: ascending, self included, every listed j
+    satisfies a_ij >= kth and the count equals |{j : a_ij >= kth}| with a_ij evaluated by the oracle's formula."""
+    w = O.seeded_weights("epc-net", 0)
+    eng, _ = H.make_engine("epc-net", w, dev)
+    pc = O.synthetic_clouds(64, 4096, 123)
+    x = torch.from_numpy(pc).to(dev)
+    out = eng.forward(x)
+    assert bool(torch.isfinite(out).all()) and float((out.norm(dim=1) - 1).abs().max()) < 1e-5
+    alone = eng.forward(x[17:18])
+    assert torch.equal(alone[0], out[17])
+    rolled = eng.forward(torch.roll(x, shifts=5, dims=0))
+    assert torch.equal(rolled[22], out[17])
+    ops = H.pkg("ops")
+    tf_util = H.pkg("utils.tf_util")
+    srt = ops.morton_sort(x[:4])
+    kth, idx, cnt = tf_util.knn_index(srt)
+    s_np, kth, idx, cnt = srt.cpu().numpy(), kth.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    rng = np.random.RandomState(0)
+    for b in range(4):
+        a = O.neg_sq_dist(s_np[b:b + 1])[0]                      # (4096, 4096) in the reference's association
+        for i in rng.choice(4096, size=64, replace=False):
+            sel = np.nonzero(a[i] >= kth[b, i])[0]
+            assert cnt[b, i] == len(sel) >= 20
+            lst = idx[b, i, :min(cnt[b, i], 32)]
+            assert np.array_equal(lst, sel[:32]) and i in sel
+            assert kth[b, i] == np.sort(a[i])[-20]
