@@ -111,8 +111,8 @@ __host__ __device__ __forceinline__ constexpr size_t layer_pack_floats(int cin, 
 
 // conv5 / cluster_weights are consumed by the bf16 MFMA as split hi/lo fragments (same byte count as f32):
 //   W5p[chunk c][k-step s][part p (0 hi, 1 lo)][lane][8 bf16], value = part(W5f[16s + 8(lane>>5) + j][32c + (lane&31)])
-//   Wcp[chunk c][s' (2)][tile t (2)][part p][lane][8 bf16],
-//        value = part(Wc[32c + 16s' + 8(j>>2) + 4(lane>>5) + (j&3)][32t + (lane&31)])
+//   Wcp[chunk c][s' (2)][tile t (2)][lane][8 fp16] (ONE fp16 per cluster weight, x W5_SCALE),
+//        value = Wc[32c + 16s' + 8(j>>2) + 4(lane>>5) + (j&3)][32t + (lane&31)]
 //        (the k order of an accumulator tile used as B operand: element j of lane-half h is row 16s'+8(j>>2)+4h+(j&3))
 // Block pack: [conv_a SPLIT 64x64][conv_b ACC 64x64][conv_next SPLIT 64x64 (zeros when absent)]
 #define EPC_BLOCK_PACK_FLOATS (3 * (64 * 64 + 64))

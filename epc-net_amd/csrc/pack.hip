@@ -150,17 +150,15 @@ __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float*
     }
 }
 
+// cluster weights for the assignment GEMM: ONE fp16 per weight (x W5_SCALE), fragment order
+// [chunk c][k-step sp][cluster tile t][lane][8]: element j of lane l = Wc[32c + 16sp + 8(j>>2) + 4(l>>5) + (j&3)][32t + (l&31)]
 __global__ void pack_wc_f16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= 1024 * 64) return;
     const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
     const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)] * W5_SCALE;
-    const _Float16 hi = (_Float16)w;
-    const _Float16 lo = (_Float16)(w - (float)hi);
-    const size_t base = ((size_t)((c * 2 + sp) * 2 + t) * 2) * 512 + lane * 8 + j;
-    dst[base] = __builtin_bit_cast(unsigned short, hi);
-    dst[base + 512] = __builtin_bit_cast(unsigned short, lo);
+    const _Float16 h = (_Float16)(Wc[(size_t)ch * 64 + 32 * t + (lane & 31)] * W5_SCALE);
+    dst[o] = __builtin_bit_cast(unsigned short, h);
 }
 
 __global__ void bn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -305,7 +303,7 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
         EPC_CHECK_LAUNCH();
         const float *g, *b, *m, *vv;
         PACK_TRY(get_slim_bn(T, "VLAD/cluster_bn", &g, &b, &m, &vv));
-        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 64, s5 + 65536, s5 + 65536 + 64);
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 64, s5 + 32768, s5 + 32768 + 64);
         EPC_CHECK_LAUNCH();
 
         float* h = P + L.off[6];
