@@ -51,6 +51,15 @@ __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
 // product and the cloud's points: measured descriptor error 1e-6; a weight rounded to one fp16 would be a
 // systematic error (2e-5) -- hence the split on the weight side.
 #define W5_SCALE 256.0f
+// lo parts of the conv5 weights as fp8 e4m3: (W * W5_SCALE - hi) * 2^W5_LO_SHIFT (lo <= 2^-6 for |W * W5_SCALE| < 64, so the
+// shifted value stays below 64, far inside e4m3's range); the MFMA's E8M0 scale operand removes the shift.
+#define W5_LO_SHIFT 12
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+// four f32 -> four fp8 e4m3 bytes (v_cvt_pk_fp8_f32, round to nearest even, saturating), element 0 in the low byte
+__device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
 // scale of the fp16 assignment fragments between epc_conv5_assign_fwd and epc_vlad_aggregate_fwd (exact power of two)
 #define AGG_ASSIGN_SCALE 16384.0f
 

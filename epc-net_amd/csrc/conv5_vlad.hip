@@ -42,9 +42,12 @@ __device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_
                  : "memory");
 }
 
-template <int CIN>
+// F8LO (EPC-Net): per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][fp8 lo fragments:
+// CIN/64 k-steps x 2 KB] = 96*CIN bytes; otherwise (EPC-Net-L) bf16 hi and lo fragments interleaved per k-step: 128*CIN bytes.
+template <int CIN, bool F8LO>
 struct C5Lds {  // offsets in floats (4 B)
-    static constexpr int W5_CHUNK = 32 * CIN;  // 32 channels x CIN k x (2 B hi + 2 B lo)
+    static constexpr int W5_CHUNK = F8LO ? 24 * CIN : 32 * CIN;
+    static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp8 fragments inside a chunk
     static constexpr int WC_CHUNK = 1024;      // 32 ch x 64 clusters x 2 B (ONE fp16 per cluster weight, see the epilogue)
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            float* __restrict__ assign_frag,
                                                            float* __restrict__ apart,
                                                            float* __restrict__ pooled) {
-    using L = C5Lds<CIN>;
+    using L = C5Lds<CIN, MODE == MODE_VLAD>;
     constexpr int STEPS = CIN / 16;
     static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     constexpr bool kF16 = MODE == MODE_VLAD;
     constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
     f16x8 xf[kF16 ? STEPS : 1];
+    i32x8 x8[kF16 ? CIN / 64 : 1];   // the same inputs as fp8 e4m3 (B operand of the lo-term MFMA: 32 consecutive channels)
     bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
     if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
         static_assert(!CAT16 || MODE == MODE_VLAD, "fp16 input only feeds the fp16 arithmetic");
@@ -127,6 +131,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             u32x4 w = *reinterpret_cast<const u32x4*>(row + 16 * s);
             if (!active) w = u32x4{0u, 0u, 0u, 0u};
             xf[kF16 ? s : 0] = __builtin_bit_cast(f16x8, w);
+        }
+        if constexpr (kF16) {
+#pragma unroll
+            for (int ks = 0; ks < CIN / 64; ++ks) {   // channels 64ks + 32h .. +31 of the lane's point
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u32x4 w = *reinterpret_cast<const u32x4*>(row + 64 * ks + 24 * h + 8 * q4);   // row already holds +8h
+                    if (!active) w = u32x4{0u, 0u, 0u, 0u};
+                    const f16x8 hv = __builtin_bit_cast(f16x8, w);
+                    x8[ks][2 * q4] = pack_fp8x4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+                    x8[ks][2 * q4 + 1] = pack_fp8x4((float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]);
+                }
+            }
         }
     } else {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
@@ -142,6 +159,17 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             } else {
                 split8(v, xh[s], xl[s]);
             }
+        }
+        if constexpr (kF16) {
+            const float* row0 = row - 8 * h;   // channel 0 of the lane's point
+#pragma unroll
+            for (int ks = 0; ks < CIN / 64; ++ks)
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) {
+                    const float4 a = active ? ld4(row0 + 64 * ks + 32 * h + 4 * w8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // (round through fp16 first: the fp8 copy must describe the same input the hi term sees)
+                    x8[ks][w8] = pack_fp8x4((float)(_Float16)a.x, (float)(_Float16)a.y, (float)(_Float16)a.z, (float)(_Float16)a.w);
+                }
         }
     }
 
@@ -190,20 +218,35 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             }
         }
         {
+            if constexpr (kF16) {
+                // lo term first (small): W_lo as fp8 x 2^12 against the fp8 copy of the inputs, K = 64 per instruction at
+                // twice the bf16 rate (v_mfma_scale_f32_32x32x64_f8f6f4; E8M0 scales 2^-12 and 2^0) -- the lo term is a
+                // 2^-11 correction, so 3 mantissa bits on each side keep it to 2^-14 of the product
+                const float* wl = w5 + L::W5_LO8;
+#pragma unroll
+                for (int ks = 0; ks < CIN / 64; ++ks) {
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + (ks * 64 + lane) * 8);
+                    const u32x4 l1 = *reinterpret_cast<const u32x4*>(wl + (ks * 64 + lane) * 8 + 4);
+                    i32x8 wl8;
+                    wl8[0] = (int)l0[0], wl8[1] = (int)l0[1], wl8[2] = (int)l0[2], wl8[3] = (int)l0[3];
+                    wl8[4] = (int)l1[0], wl8[5] = (int)l1[1], wl8[6] = (int)l1[2], wl8[7] = (int)l1[3];
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8, x8[ks], acc, 0, 0, 0, 127 - W5_LO_SHIFT, 0, 127);
+                }
+            }
             // fragment reads run one k-step ahead of the MFMAs that consume them
             f16x8 fa[2][2];
+            constexpr int FS = kF16 ? 1 : 2;   // fragments per k-step in LDS (fp16 hi only / bf16 hi + lo)
             fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
-            fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
+            if (!kF16) fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 if (s + 1 < STEPS) {
-                    fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
-                    fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
+                    fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * FS + 0) * 64 + lane) * 4);
+                    if (!kF16) fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * FS + 1) * 64 + lane) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
                 if constexpr (kF16) {
-                    acc = mfma_f16(fa[s & 1][1], xf[s], acc);  // lo part first, hi part last
                     acc = mfma_f16(fa[s & 1][0], xf[s], acc);
                 } else {
                     acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s & 1][1]), acc);
@@ -387,7 +430,7 @@ template <int CIN, int MODE, bool CAT16>
 static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
                         float* assign, float* assign_frag, float* apart, float* pooled, hipStream_t stream,
                         const char* who) {
-    const size_t lds_bytes = C5Lds<CIN>::TOTAL * sizeof(float);
+    const size_t lds_bytes = C5Lds<CIN, MODE == MODE_VLAD>::TOTAL * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE, CAT16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {

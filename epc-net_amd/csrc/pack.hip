@@ -78,9 +78,10 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
     }
 }
 
-// conv5 weights as hi + lo fragments (layout + arithmetic: common.h).  One thread per (chunk, k-step, lane, j).
-// f16 = 1: fp16 parts of W * W5_SCALE, bias scaled alike (EPC-Net: conv5 feeds the VLAD aggregation);
-// f16 = 0: bf16 parts of W for the split-bf16 x3 form (EPC-Net-L: conv5 feeds the global max-pool).
+// conv5 weights as fragments (layout + arithmetic: common.h, conv5_vlad.hip C5Lds).  One thread per (chunk, k, channel).
+// f16 = 1 (EPC-Net: conv5 feeds the VLAD aggregation): per chunk [fp16 hi of W * W5_SCALE: k-step s (16 k), lane, 8]
+//         then [fp8 e4m3 of (W * W5_SCALE - hi) * 2^W5_LO_SHIFT: k-step ks (64 k), lane, 32]; bias scaled by W5_SCALE.
+// f16 = 0 (EPC-Net-L: conv5 feeds the global max-pool): bf16 hi and lo fragments interleaved per k-step (bf16x3 form).
 __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int cin, int f16,
@@ -93,19 +94,23 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
         const int s = rest % steps, c = rest / steps;
         const int k = 16 * s + 8 * (lane >> 5) + j, col = 32 * c + (lane & 31);
         const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col) * scale;
-        unsigned short hi, lo;
         if (f16) {
             const _Float16 h = (_Float16)w;
-            const _Float16 l = (_Float16)(w - (float)h);
-            hi = __builtin_bit_cast(unsigned short, h);
-            lo = __builtin_bit_cast(unsigned short, l);
+            const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
+            dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
+            // the same weight's lo part sits in k-step ks = k / 64 of the fp8 fragments: lane' = col-lane + 32 * ((k % 64) / 32),
+            // byte (k % 32)
+            const float lo = (w - (float)h) * (float)(1 << W5_LO_SHIFT);
+            const int ks = k >> 6, lane8 = (lane & 31) + 32 * ((k & 63) >> 5), byte = k & 31;
+            unsigned char* lo8 = reinterpret_cast<unsigned char*>(dstW + (size_t)c * chunk_halfs + (size_t)16 * cin * 2);
+            lo8[(size_t)ks * 2048 + lane8 * 32 + byte] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(lo, 0.0f, 0, false) & 0xff);
         } else {
-            hi = bf16_bits_rne(w);
-            lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+            const unsigned short hi = bf16_bits_rne(w);
+            const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+            const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
+            dstW[base] = hi;
+            dstW[base + 512] = lo;
         }
-        const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
-        dstW[base] = hi;
-        dstW[base + 512] = lo;
     }
     if (o < 1024) {
         const float inv = bn_inv(gamma, var, o);
