@@ -34,7 +34,7 @@ EVAL_BATCHES = 5       # train.py:527
 class Trainer:
     def __init__(self, step, train_queries: Dict[int, dict], train_data: np.ndarray,
                  test_queries: Optional[Dict[int, dict]] = None, test_data: Optional[np.ndarray] = None,
-                 save_path: Optional[str] = None, logger: Optional[logging.Logger] = None):
+                 save_path: Optional[str] = None, logger: Optional[logging.Logger] = None, graph: bool = False):
         """``step``: a TrainStep / DistillStep; ``*_queries``: the pickles of generate_training_tuples (key -> {'query',
         'positives', 'negatives'}); ``*_data``: (T, 4096, INPUT_DIM) float32 arrays in key order (train.py:159-190)."""
         self.step = step
@@ -42,6 +42,7 @@ class Trainer:
         self.TRAINING_QUERIES, self.train_data = train_queries, train_data
         self.TEST_QUERIES, self.test_data = test_queries, test_data
         self.save_path = save_path
+        self.graph = graph     # replay the step as one HIP graph (TrainStep.step(graph=True)): every tuple has the same shape
         self.log = logger or logging.getLogger("epcnet.train")
         self.HARD_NEGATIVES: Dict[int, List[int]] = {}      # train.py:97 (never filled by the reference either)
         self.TRAINING_LATENT_VECTORS = []                   # train.py:98
@@ -117,7 +118,7 @@ class Trainer:
             if batch is None:
                 self.log.info("Epoch: [%d/%d][%d/%d] %s!!!", epoch, self.max_epoch, i + 1, iter_num, why)
                 continue
-            loss, lr, _ = self.step.step(*batch, epoch=epoch)
+            loss, lr, _ = self.step.step(*batch, epoch=epoch, graph=self.graph) if self.graph else self.step.step(*batch, epoch=epoch)
             losses.append(float(loss))
             self.history.append({"epoch": epoch, "iter": i, "loss": losses[-1], "lr": lr})
             self.log.info("Epoch: [%d/%d][%d/%d] Loss %.4f lr %.8f", epoch, self.max_epoch, i + 1, iter_num, losses[-1], lr)

@@ -154,6 +154,11 @@ def test_training_loop_with_mining_and_resume(dev, tmp_path, arch):
     assert sorted(hard) == sorted(negs[np.argsort(d, kind="stable")[:10]].tolist())
     losses = tr.train_one_epoch(6, max_iters=4)
     assert len(losses) == 4 and all(np.isfinite(losses)) and ts.global_step == 4
+    tr.graph = True                                  # the same loop replaying the captured HIP graph of the step
+    losses_g = tr.train_one_epoch(6, max_iters=3)
+    assert len(losses_g) == 3 and all(np.isfinite(losses_g)) and ts.global_step == 7
+    tr.graph = False
+    ts.global_step = 4
     assert np.isfinite(tr.evaluate_loss(6))
     # save (train.py:611-617) -> a fresh process state -> restore (train.py:308-315) -> identical continuation
     prefix = tr.save(6, 101)
