@@ -118,9 +118,14 @@ __device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& p0, bf16x8
     }
 }
 
-template <int BLOCKS, int PIECES>  // 32-row blocks of this operand tile (2 * WM or 2 * WN); bf16 pieces kept (2 or 3)
-__device__ __forceinline__ void stage_split_fragments(const float* __restrict__ P, long s_outer, long s_k, int outer0,
-                                                      int outer_lim, int kt, int k_lim, u32x4 (*dst)[2][3][64], int tid) {
+// Staging is split in two so that the global loads of k-tile t+1 are in flight while the MFMAs of tile t run:
+// fetch_fragments() only loads (8 floats per lane-fragment, kept in registers), store_fragments() splits them into
+// bf16 pieces and writes the ready MFMA fragments.  PIECES = 3: f32-accurate (six products), 2: backward GEMMs (three
+// products), 1: plain bf16 operands with f32 accumulation (one product; BASELINE.json's "bf16" training configuration).
+template <int BLOCKS>  // 32-row blocks of this operand tile (2 * WM or 2 * WN)
+__device__ __forceinline__ void fetch_fragments(const float* __restrict__ P, long s_outer, long s_k, int outer0,
+                                                int outer_lim, int kt, int k_lim, float (&v)[(BLOCKS * 128) / 256][8],
+                                                int tid) {
     const bool k_contig = s_k == 1;
     constexpr int ROWS = 32 * BLOCKS;
 #pragma unroll
@@ -128,29 +133,47 @@ __device__ __forceinline__ void stage_split_fragments(const float* __restrict__ 
         const int f = tid + 256 * u;  // ROWS x 4 lane-fragments (4 k-groups of 8)
         const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
         const int go = outer0 + row, gk = kt + 8 * kg;
-        float v[8];
         const float* src = P + (size_t)go * s_outer + (size_t)gk * s_k;
         if (go < outer_lim && gk + 8 <= k_lim && k_contig && ((reinterpret_cast<size_t>(src) & 15) == 0)) {
             const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+            v[u][0] = a.x, v[u][1] = a.y, v[u][2] = a.z, v[u][3] = a.w;
+            v[u][4] = b.x, v[u][5] = b.y, v[u][6] = b.z, v[u][7] = b.w;
         } else {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) v[jj] = (go < outer_lim && gk + jj < k_lim) ? src[(size_t)jj * s_k] : 0.f;
+            for (int jj = 0; jj < 8; ++jj) v[u][jj] = (go < outer_lim && gk + jj < k_lim) ? src[(size_t)jj * s_k] : 0.f;
         }
-        bf16x8 p0, p1, p2;
-        split8x3(v, p0, p1, p2);
+    }
+}
+
+template <int BLOCKS, int PIECES>
+__device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) / 256][8], bool k_contig,
+                                                u32x4 (*dst)[2][PIECES][64], int tid) {
+    constexpr int ROWS = 32 * BLOCKS;
+#pragma unroll
+    for (int u = 0; u < (ROWS * 4) / 256; ++u) {
+        const int f = tid + 256 * u;
+        const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
         const int l2 = (row & 31) + 32 * (kg & 1);
-        dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, p0);
-        dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, p1);
-        if (PIECES == 3) dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
+        if constexpr (PIECES == 1) {
+            bf16x8 p0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p0[j] = (__bf16)v[u][j];
+            dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, p0);
+        } else {
+            bf16x8 p0, p1, p2;
+            split8x3(v[u], p0, p1, p2);
+            dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, p0);
+            dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, p1);
+            if constexpr (PIECES == 3) dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
+        }
     }
 }
 
 template <int WM, int WN, int PIECES>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ u32x4 As[2 * WM][2][3][64];  // 12 KB per WM
-    __shared__ u32x4 Bs[2 * WN][2][3][64];
+    __shared__ u32x4 As[2 * WM][2][PIECES][64];  // 4 KB per WM per piece
+    __shared__ u32x4 Bs[2 * WN][2][PIECES][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -162,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     int kchunk = (g.K + g.splitk - 1) / g.splitk;
     kchunk = (kchunk + S_BK - 1) / S_BK * S_BK;
     const int k0 = ks * kchunk, k1 = min(g.K, k0 + kchunk);
+    const bool a_kc = g.sAk == 1, b_kc = g.sBk == 1;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -171,13 +195,22 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 
+    float va[WM][8], vb[WN][8];  // the next k-tile's operand values (2*WM*128/256 = WM lane-fragments per thread)
+    if (k0 < k1) {
+        fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, k0, k1, va, tid);
+        fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0, k1, vb, tid);
+    }
     for (int kt = k0; kt < k1; kt += S_BK) {
-        stage_split_fragments<2 * WM, PIECES>(A, g.sAm, g.sAk, m0, g.M, kt, k1, As, tid);
-        stage_split_fragments<2 * WN, PIECES>(B, g.sBn, g.sBk, n0, g.N, kt, k1, Bs, tid);
+        store_fragments<2 * WM, PIECES>(va, a_kc, As, tid);
+        store_fragments<2 * WN, PIECES>(vb, b_kc, Bs, tid);
         __syncthreads();
+        if (kt + S_BK < k1) {  // in flight under this tile's MFMAs
+            fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + S_BK, k1, va, tid);
+            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + S_BK, k1, vb, tid);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[WM][3], b[WN][3];
+            bf16x8 a[WM][PIECES], b[WN][PIECES];
 #pragma unroll
             for (int pc = 0; pc < PIECES; ++pc) {
 #pragma unroll
@@ -190,13 +223,15 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
                 for (int cb = 0; cb < WN; ++cb) {
                     f32x16 c = acc[rb][cb];
-                    if (PIECES == 3) {
+                    if constexpr (PIECES == 3) {
                         c = mfma_bf16(a[rb][2], b[cb][0], c);
                         c = mfma_bf16(a[rb][0], b[cb][2], c);
                         c = mfma_bf16(a[rb][1], b[cb][1], c);
                     }
-                    c = mfma_bf16(a[rb][1], b[cb][0], c);
-                    c = mfma_bf16(a[rb][0], b[cb][1], c);
+                    if constexpr (PIECES >= 2) {
+                        c = mfma_bf16(a[rb][1], b[cb][0], c);
+                        c = mfma_bf16(a[rb][0], b[cb][1], c);
+                    }
                     c = mfma_bf16(a[rb][0], b[cb][0], c);
                     acc[rb][cb] = c;
                 }
@@ -228,7 +263,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 template <int WM, int WN>
 static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStream_t st) {
     dim3 grid((g.N + 64 * WN - 1) / (64 * WN), (g.M + 64 * WM - 1) / (64 * WM), batch * g.splitk);
-    if (pieces == 2)
+    if (pieces == 1)
+        hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1>), grid, dim3(256), 0, st, g);
+    else if (pieces == 2)
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 2>), grid, dim3(256), 0, st, g);
     else
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3>), grid, dim3(256), 0, st, g);
@@ -251,6 +288,13 @@ extern "C" int epc_gemm_f32_fast(const float* A, const float* B, float* C, const
                                  long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
                                  int splitk, int accumulate, void* stream) {
     return gemm_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk, accumulate, 2, stream);
+}
+
+// One bf16 value per operand (a single product): BASELINE.json's "bf16" training configuration.
+extern "C" int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                             long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
+                             int splitk, int accumulate, void* stream) {
+    return gemm_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk, accumulate, 1, stream);
 }
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
@@ -290,108 +334,215 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Column reductions over rows: out[q][c] = sum_rows f_q(...).  Deterministic: per-block partials, then a fixed-order
-// finalize.  kind 0: {x}; kind 1: {(x-mean)^2}; kind 2: {dyr, dyr*zhat} with dyr = dy * (y > 0 or no relu).
+// Column reductions over the rows of (rows, C) tensors, ONE launch each: every workgroup reduces a 256-row x 64-column
+// panel (float4 per lane, 16 row groups) to a partial, and the workgroup that finishes a column panel LAST (a counter
+// per panel, release/acquire fences around it) adds the partials in a fixed order and writes the result -- no separate
+// finalize launch, still deterministic.  The counters live at the head of the caller's workspace: they must be zero on
+// entry and are left zero on exit (a workspace is zeroed once and then reused; one workspace per stream).
+//   kind 0: sum_r x                         -> out0 = scale * sum                      (bias gradients)
+//   kind 1: sum_r (x - x0), sum_r (x - x0)^2 with x0 = row 0 of the column (one pass; the shift keeps the second
+//           moment free of cancellation)   -> out0 = mean, out1 = POPULATION variance (tf.nn.moments)
+//   kind 2: sum_r dyr, sum_r dyr * zhat, dyr = dy * [BN(z) > 0 or no relu], zhat = (z - mean) * rstd
+//                                           -> out0 = dbeta, out1 = dgamma            (BatchNorm backward)
+// C must be a multiple of 4 (every BatchNorm site of the network has 64, 256 or 1024 channels).
 // ----------------------------------------------------------------------------------------------------------------
-#define CR_ROWS 256  // rows per block
+#define CR_ROWS 256      // rows per workgroup
+#define CR_COUNTERS 64   // counter slots at the head of the workspace: C <= 4096
+
+struct BnAffine {  // y = z * s + t, the expression the forward and the backward mask must share bit for bit
+    float s, t;
+};
+__device__ __forceinline__ BnAffine bn_affine(float mean, float var, float gamma, float beta, float eps) {
+    BnAffine a;
+    a.s = (1.0f / sqrtf(var + eps)) * gamma;
+    a.t = beta - mean * a.s;
+    return a;
+}
+__device__ __forceinline__ float bn_value(float z, const BnAffine& a) { return z * a.s + a.t; }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ aux,
-                                                        const float* __restrict__ y, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, int rows, int C, int relu,
-                                                        float* __restrict__ partial) {
-    __shared__ float red[2][4][64];
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63), rsub = threadIdx.x >> 6;
-    const int r0 = blockIdx.x * CR_ROWS;
-    float s0 = 0.f, s1 = 0.f;
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int relu, int rows, int C, float scale,
+                                                        float* __restrict__ partial, unsigned int* __restrict__ counters,
+                                                        float* __restrict__ out0, float* __restrict__ out1) {
+    constexpr int NQ = KIND == 0 ? 1 : 2;
+    __shared__ float red[NQ][16][64];
+    __shared__ __attribute__((aligned(16))) float coef[4][64];   // kind 2: s, t (ReLU mask), mean, rstd per column
+    __shared__ int s_last;
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int c = blockIdx.y * 64 + 4 * l16;
+    const int r0 = blockIdx.x * CR_ROWS, r1 = min(rows, r0 + CR_ROWS);
+    const int nb = gridDim.x;
+    if (KIND == 2) {   // the square roots and divisions once per column, not once per thread
+        if (tid < 64 && blockIdx.y * 64 + tid < C) {
+            const int cc = blockIdx.y * 64 + tid;
+            const BnAffine a = bn_affine(mean[cc], var[cc], gamma[cc], beta[cc], eps);
+            coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mean[cc], coef[3][tid] = 1.0f / sqrtf(var[cc] + eps);
+        }
+        __syncthreads();
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const float mu = (KIND >= 1) ? mean[c] : 0.f;
-        const float rs = (KIND == 2) ? rstd[c] : 0.f;
-#pragma unroll 8
-        for (int r = r0 + rsub; r < min(rows, r0 + CR_ROWS); r += 4) {
+        float sh[4] = {0.f, 0.f, 0.f, 0.f}, mu[4], rs[4];
+        BnAffine af[4];
+        if (KIND == 1) {
+            const float4 v = *reinterpret_cast<const float4*>(x + c);
+            sh[0] = v.x, sh[1] = v.y, sh[2] = v.z, sh[3] = v.w;
+        }
+        if (KIND == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[q].s = coef[0][4 * l16 + q], af[q].t = coef[1][4 * l16 + q];
+                mu[q] = coef[2][4 * l16 + q], rs[q] = coef[3][4 * l16 + q];
+            }
+        }
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += 16) {
             const size_t o = (size_t)r * C + c;
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            const float in[4] = {v.x, v.y, v.z, v.w};
             if (KIND == 0) {
-                s0 += x[o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s0[q] += in[q];
             } else if (KIND == 1) {
-                const float d = x[o] - mu;
-                s0 += d * d;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = in[q] - sh[q];
+                    s0[q] += d;
+                    s1[q] += d * d;
+                }
             } else {
-                float d = aux[o];  // dy
-                if (relu && !(y[o] > 0.f)) d = 0.f;
-                s0 += d;
-                s1 += d * ((x[o] - mu) * rs);
+                const float4 g = *reinterpret_cast<const float4*>(dy + o);
+                const float gd[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = (relu && !(bn_value(in[q], af[q]) > 0.f)) ? 0.f : gd[q];
+                    s0[q] += d;
+                    s1[q] += d * ((in[q] - mu[q]) * rs[q]);
+                }
             }
         }
     }
-    red[0][rsub][threadIdx.x & 63] = s0;
-    red[1][rsub][threadIdx.x & 63] = s1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        red[0][rg][4 * l16 + q] = s0[q];
+        if (NQ == 2) red[1][rg][4 * l16 + q] = s1[q];
+    }
     __syncthreads();
-    if (rsub == 0 && c < C) {
-        const int l = threadIdx.x & 63;
-        partial[((size_t)0 * gridDim.x + blockIdx.x) * C + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-        if (KIND == 2)
-            partial[((size_t)1 * gridDim.x + blockIdx.x) * C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    // Partials cross workgroups (and XCDs, each with its own L2) through agent-scope stores and loads: they go to the
+    // memory side directly, so no L2 write-back / invalidate fence is needed (a __threadfence() here costs a whole-L2
+    // write-back per workgroup: the step was 3 ms slower with it) -- only that a workgroup's stores have been
+    // acknowledged (vmcnt(0)) before it bumps the panel's counter.
+    if (tid < 64 * NQ) {
+        const int q = tid >> 6, l = tid & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[q][g][l];
+        if (blockIdx.y * 64 + l < C)
+            __hip_atomic_store(&partial[((size_t)q * nb + blockIdx.x) * C + blockIdx.y * 64 + l], t, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
     }
-}
-
-// 1024 threads = 16 row groups x 64 columns; each group walks its partials 8 independent loads at a time (a 64-channel
-// layer is ONE workgroup here: with 4 groups and a dependent load chain this kernel was 17 us of pure latency, 77 times
-// per training step).  Fixed summation order: deterministic.
-#define CRF_GROUPS 16
-__global__ __launch_bounds__(64 * CRF_GROUPS) void colreduce_finalize_kernel(const float* __restrict__ partial, int nblocks,
-                                                                             int C, int nq, float scale,
-                                                                             float* __restrict__ out) {
-    __shared__ float red[CRF_GROUPS][64];
-    const int l = threadIdx.x & 63, rsub = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + l;
-    for (int q = 0; q < nq; ++q) {
-        float s = 0.f;
-        if (c < C) {
-            const float* p = partial + (size_t)q * nblocks * C + c;
-            int b = rsub;
-            for (; b + 7 * CRF_GROUPS < nblocks; b += 8 * CRF_GROUPS) {
-                float t[8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(&counters[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                 (unsigned)(nb - 1);
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup of this column panel finishes the reduction: 16 groups x (16 lanes x 4 columns), every group
+    // walks its share of the row panels 4 independent loads at a time, fixed order -> deterministic
+    float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float* p0 = partial + c;
+        const float* p1 = partial + (size_t)nb * C + c;
+        auto ld = [](const float* p, float (&o)[4]) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(b + u * CRF_GROUPS) * C];
+            for (int q = 0; q < 4; ++q) o[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        int bidx = rg;
+        for (; bidx + 48 < nb; bidx += 64) {
+            float u0[4][4], u1[4][4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += t[u];
+            for (int u = 0; u < 4; ++u) {
+                ld(p0 + (size_t)(bidx + 16 * u) * C, u0[u]);
+                if (NQ == 2) ld(p1 + (size_t)(bidx + 16 * u) * C, u1[u]);
             }
-            for (; b < nblocks; b += CRF_GROUPS) s += p[(size_t)b * C];
-        }
-        red[rsub][l] = s;
-        __syncthreads();
-        if (rsub == 0 && c < C) {
-            float tot = 0.f;
 #pragma unroll
-            for (int g = 0; g < CRF_GROUPS; ++g) tot += red[g][l];
-            out[(size_t)q * C + c] = tot * scale;
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    t0[q] += u0[u][q];
+                    if (NQ == 2) t1[q] += u1[u][q];
+                }
         }
-        __syncthreads();
+        for (; bidx < nb; bidx += 16) {
+            float u0[4], u1[4];
+            ld(p0 + (size_t)bidx * C, u0);
+            if (NQ == 2) ld(p1 + (size_t)bidx * C, u1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t0[q] += u0[q];
+                if (NQ == 2) t1[q] += u1[q];
+            }
+        }
     }
+    __syncthreads();   // red[] is reused
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        red[0][rg][4 * l16 + q] = t0[q];
+        if (NQ == 2) red[1][rg][4 * l16 + q] = t1[q];
+    }
+    __syncthreads();
+    const int l = tid & 63;
+    const int cc = blockIdx.y * 64 + l;
+    if (tid < 64 && cc < C) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            a0 += red[0][g][l];
+            if (NQ == 2) a1 += red[1][g][l];
+        }
+        if (KIND == 0) {
+            out0[cc] = a0 * scale;
+        } else if (KIND == 1) {
+            const float m1 = a0 * scale;                       // E[x - x0]
+            out0[cc] = x[cc] + m1;
+            out1[cc] = fmaxf(a1 * scale - m1 * m1, 0.f);
+        } else {
+            out0[cc] = a0;
+            out1[cc] = a1;
+        }
+    }
+    if (tid == 0) counters[blockIdx.y] = 0u;   // ready for the next launch on this workspace
 }
 
 extern "C" size_t epc_colreduce_workspace_bytes(int rows, int C) {
     const size_t nb = (rows + CR_ROWS - 1) / CR_ROWS;
-    return 2 * nb * (size_t)C * sizeof(float);
+    return CR_COUNTERS * sizeof(unsigned int) + 2 * nb * (size_t)C * sizeof(float);
+}
+
+static int colreduce_check(const char* who, int rows, int C, const void* workspace, size_t workspace_bytes) {
+    EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0 && C <= 64 * CR_COUNTERS, "C must be a multiple of 4, at most 4096");
+    EPC_CHECK_ARG(workspace && (reinterpret_cast<size_t>(workspace) & 15) == 0, "workspace must be 16-byte aligned");
+    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
+        epc_set_error(who);
+        return EPC_ENOMEM;
+    }
+    return EPC_OK;
 }
 
 // mean[c], var[c] (population) over `rows` rows of x (rows, C).  tf.nn.moments (utils/tf_util.py:472).
 extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, float* var, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    EPC_CHECK_ARG(x && mean && var && workspace, "null pointer");
-    EPC_CHECK_ARG(rows > 0 && C > 0, "bad shape");
-    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
-        epc_set_error("epc_col_moments: workspace too small");
-        return EPC_ENOMEM;
-    }
-    hipStream_t st = (hipStream_t)stream;
+    EPC_CHECK_ARG(x && mean && var, "null pointer");
+    if (int rc = colreduce_check("epc_col_moments: workspace too small", rows, C, workspace, workspace_bytes)) return rc;
     const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
-    dim3 grid(nb, (C + 63) / 64);
-    float* part = (float*)workspace;
-    hipLaunchKernelGGL(colreduce_kernel<0>, grid, dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f / rows, mean);
-    hipLaunchKernelGGL(colreduce_kernel<1>, grid, dim3(256), 0, st, x, nullptr, nullptr, mean, nullptr, rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f / rows, var);
+    unsigned int* counters = (unsigned int*)workspace;
+    float* part = (float*)(counters + CR_COUNTERS);
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f / rows, part, counters, mean, var);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -399,95 +550,125 @@ extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, flo
 // out[c] = sum over rows of x[:, c]  (bias gradients)
 extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* workspace, size_t workspace_bytes,
                            void* stream) {
-    EPC_CHECK_ARG(x && out && workspace && rows > 0 && C > 0, "bad argument");
-    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
-        epc_set_error("epc_col_sum: workspace too small");
-        return EPC_ENOMEM;
-    }
-    hipStream_t st = (hipStream_t)stream;
+    EPC_CHECK_ARG(x && out, "null pointer");
+    if (int rc = colreduce_check("epc_col_sum: workspace too small", rows, C, workspace, workspace_bytes)) return rc;
     const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
-    float* part = (float*)workspace;
-    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, x, nullptr, nullptr, nullptr, nullptr,
-                       rows, C, 0, part);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f, out);
+    unsigned int* counters = (unsigned int*)workspace;
+    float* part = (float*)(counters + CR_COUNTERS);
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f, part, counters, out, nullptr);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 
-// y = act(z*s + t), s = gamma*rsqrt(var+eps), t = beta - mean*s  (tf.nn.batch_normalization, utils/tf_util.py:490)
-__global__ void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
-                                    const float* __restrict__ var, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float eps, int relu, long total4, int C,
-                                    float* __restrict__ y) {
-    const long o4 = (long)blockIdx.x * 256 + threadIdx.x;
-    if (o4 >= total4) return;
-    const int c = (int)((o4 * 4) % C);
-    const float4 v = reinterpret_cast<const float4*>(z)[o4];
-    float in[4] = {v.x, v.y, v.z, v.w}, out[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float s = (1.0f / sqrtf(var[c + q] + eps)) * gamma[c + q];
-        const float r = in[q] * s + (beta[c + q] - mean[c + q] * s);
-        out[q] = relu ? fmaxf(r, 0.f) : r;
+// y = act(z*s + t), s = gamma*rsqrt(var+eps), t = beta - mean*s  (tf.nn.batch_normalization, utils/tf_util.py:490).
+// Panel kernels like the reductions above (256 rows x 64 columns per workgroup, float4 per lane): the per-column
+// coefficients -- a square root and a division each -- are computed by 64 threads once per panel and shared through
+// LDS.  (One thread per element with the coefficients recomputed in place made the backward VALU-bound: 445 us on the
+// conv5 activations instead of 300.)
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int relu, int rows,
+                                                           int C, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float coef[2][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    if (tid < 64 && blockIdx.y * 64 + tid < C) {
+        const int cc = blockIdx.y * 64 + tid;
+        const BnAffine a = bn_affine(mean[cc], var[cc], gamma[cc], beta[cc], eps);
+        coef[0][tid] = a.s, coef[1][tid] = a.t;
     }
-    reinterpret_cast<float4*>(y)[o4] = make_float4(out[0], out[1], out[2], out[3]);
+    __syncthreads();
+    const int c = blockIdx.y * 64 + 4 * l16;
+    if (c >= C) return;
+    BnAffine af[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) af[q].s = coef[0][4 * l16 + q], af[q].t = coef[1][4 * l16 + q];
+    const int r0 = blockIdx.x * CR_ROWS, r1 = min(rows, r0 + CR_ROWS);
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const size_t o = (size_t)r * C + c;
+        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = bn_value(in[q], af[q]);
+            out[q] = relu ? fmaxf(t, 0.f) : t;
+        }
+        *reinterpret_cast<float4*>(y + o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
 }
 
 extern "C" int epc_bn_apply_fwd(const float* z, const float* mean, const float* var, const float* gamma,
                                 const float* beta, float eps, int relu, int rows, int C, float* y, void* stream) {
     EPC_CHECK_ARG(z && mean && var && gamma && beta && y, "null pointer");
     EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "C must be a multiple of 4");
-    const long total4 = (long)rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z,
-                       mean, var, gamma, beta, eps, relu, total4, C, y);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((rows + CR_ROWS - 1) / CR_ROWS, (C + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows, C, y);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 
-// dz = gamma*rstd * (dyr - dbeta/rows - zhat * dgamma/rows)
-__global__ void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
-                                    const float* __restrict__ y, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_rows,
-                                    int relu, long total, int C, float* __restrict__ dz) {
-    const long o = (long)blockIdx.x * 256 + threadIdx.x;
-    if (o >= total) return;
-    const int c = (int)(o % C);
-    float d = dy[o];
-    if (relu && !(y[o] > 0.f)) d = 0.f;
-    const float zh = (z[o] - mean[c]) * rstd[c];
-    dz[o] = gamma[c] * rstd[c] * (d - dbeta[c] * inv_rows - zh * dgamma[c] * inv_rows);
-}
-
-__global__ void rstd_kernel(const float* __restrict__ var, float eps, int C, float* __restrict__ rstd) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
-}
-
-// Backward of training-mode BN (+ReLU).  Outputs dz (rows,C), dgamma (C), dbeta (C); rstd_out (C) is scratch.
-extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* y, const float* mean, const float* var,
-                                const float* gamma, float eps, int relu, int rows, int C, float* dz, float* dgamma,
-                                float* dbeta, float* rstd_out, void* workspace, size_t workspace_bytes, void* stream) {
-    EPC_CHECK_ARG(dy && z && mean && var && gamma && dz && dgamma && dbeta && rstd_out && workspace, "null pointer");
-    EPC_CHECK_ARG(!relu || y, "y required for the ReLU mask");
-    EPC_CHECK_ARG(rows > 0 && C > 0, "bad shape");
-    if (workspace_bytes < epc_colreduce_workspace_bytes(rows, C)) {
-        epc_set_error("epc_bn_apply_bwd: workspace too small");
-        return EPC_ENOMEM;
+// dz = gamma*rstd * (dyr - dbeta/rows - zhat * dgamma/rows); the ReLU mask is recomputed from z with the forward's
+// own expression (bn_value), so the forward output is neither stored for it nor read here.
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, float eps, float inv_rows,
+                                                           int relu, int rows, int C, float* __restrict__ dz) {
+    // per column: s, t (mask), mean, k1 = gamma*rstd, b = dbeta/rows, g = rstd*dgamma/rows:  dz = k1*(d - b - (z-mean)*g)
+    __shared__ __attribute__((aligned(16))) float coef[6][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    if (tid < 64 && blockIdx.y * 64 + tid < C) {
+        const int cc = blockIdx.y * 64 + tid;
+        const float mu = mean[cc], rs = 1.0f / sqrtf(var[cc] + eps), ga = gamma[cc];
+        const BnAffine a = bn_affine(mu, var[cc], ga, beta[cc], eps);
+        coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mu;
+        coef[3][tid] = ga * rs, coef[4][tid] = dbeta[cc] * inv_rows, coef[5][tid] = rs * (dgamma[cc] * inv_rows);
     }
+    __syncthreads();
+    const int c = blockIdx.y * 64 + 4 * l16;
+    if (c >= C) return;
+    BnAffine af[4];
+    float mu[4], k1[4], bb[4], gg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        af[q].s = coef[0][4 * l16 + q], af[q].t = coef[1][4 * l16 + q], mu[q] = coef[2][4 * l16 + q];
+        k1[q] = coef[3][4 * l16 + q], bb[q] = coef[4][4 * l16 + q], gg[q] = coef[5][4 * l16 + q];
+    }
+    const int r0 = blockIdx.x * CR_ROWS, r1 = min(rows, r0 + CR_ROWS);
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const size_t o = (size_t)r * C + c;
+        const float4 zv = *reinterpret_cast<const float4*>(z + o), gv = *reinterpret_cast<const float4*>(dy + o);
+        const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+        float out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = (relu && !(bn_value(zi[q], af[q]) > 0.f)) ? 0.f : gi[q];
+            out[q] = k1[q] * (d - bb[q] - (zi[q] - mu[q]) * gg[q]);
+        }
+        *reinterpret_cast<float4*>(dz + o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// Backward of training-mode BN (+ReLU).  Outputs dz (rows,C), dgamma (C), dbeta (C).  Two launches: the column sums
+// (dbeta, dgamma), then dz.
+extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const float* var,
+                                const float* gamma, const float* beta, float eps, int relu, int rows, int C, float* dz,
+                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(dy && z && mean && var && gamma && beta && dz && dgamma && dbeta, "null pointer");
+    if (int rc = colreduce_check("epc_bn_apply_bwd: workspace too small", rows, C, workspace, workspace_bytes)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
-    float* part = (float*)workspace;
-    hipLaunchKernelGGL(rstd_kernel, dim3((C + 255) / 256), dim3(256), 0, st, var, eps, C, rstd_out);
-    hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, z, dy, y, mean, rstd_out, rows, C,
-                       relu, part);
-    // partial layout [2][nb][C] -> dbeta = q0, dgamma = q1; finalize writes out[q*C + c]: use a 2*C temp = part tail
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part, nb, C, 1, 1.0f, dbeta);
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((C + 63) / 64), dim3(64 * CRF_GROUPS), 0, st, part + (size_t)nb * C, nb, C, 1,
-                       1.0f, dgamma);
-    const long total = (long)rows * C;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, z, y, mean,
-                       rstd_out, gamma, dbeta, dgamma, 1.0f / rows, relu, total, C, dz);
+    unsigned int* counters = (unsigned int*)workspace;
+    float* part = (float*)(counters + CR_COUNTERS);
+    const dim3 grid(nb, (C + 63) / 64);
+    hipLaunchKernelGGL(colreduce_kernel<2>, grid, dim3(256), 0, st, z, dy, mean, var, gamma, beta, eps, relu, rows, C, 1.0f,
+                       part, counters, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, dim3(256), 0, st, dy, z, mean, var, gamma, beta, dbeta, dgamma, eps,
+                       1.0f / rows, relu, rows, C, dz);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

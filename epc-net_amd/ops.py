@@ -14,14 +14,41 @@ def _st():
     return L.current_stream()
 
 
+_WORKSPACES = {}
+
+
 def _ws(rows, C, device):
+    """The column-reduction workspace of (device, current stream): zeroed when it is created or grown, reused afterwards
+    -- the kernels leave its completion counters at zero (include/epcnet.h, workspace contract)."""
     n = L.lib().epc_colreduce_workspace_bytes(int(rows), int(C))
-    return torch.empty(n, dtype=torch.uint8, device=device), n
+    key = (device.index, int(_st() or 0))
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf, buf.numel()
+
+
+# Arithmetic of the training step's GEMMs.  "bf16x6" (default): every f32 operand as three bf16 pieces, six products --
+# f32-accurate, what the reference's fp32 TensorFlow graph computes; backward GEMMs use two pieces.  "bf16": operands
+# rounded to one bf16 value, f32 accumulation, forward and backward (BASELINE.json configs[2] names this arithmetic for
+# the training step; set by TrainStep from params["TRAIN_PRECISION"]).
+_GEMM_PRECISION = "bf16x6"
+
+
+def set_gemm_precision(name: str) -> str:
+    """Select the GEMM arithmetic of the differentiable operators; returns the previous setting."""
+    global _GEMM_PRECISION
+    if name not in ("bf16x6", "bf16"):
+        raise ValueError("unknown GEMM precision %r (bf16x6 | bf16)" % (name,))
+    prev, _GEMM_PRECISION = _GEMM_PRECISION, name
+    return prev
 
 
 def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False, fast=False):
     """out = op(A) @ op(B) (+ bias).  A, B: 2-D, or 3-D with a leading batch dim (same batch).  f32-accurate split-bf16
-    MFMA arithmetic (three pieces per operand); ``fast`` = two pieces (backward GEMMs: linear in the gradient)."""
+    MFMA arithmetic (three pieces per operand); ``fast`` = two pieces (backward GEMMs: linear in the gradient);
+    one piece under set_gemm_precision("bf16")."""
     L.require_gpu()
     batched = A.dim() == 3
     a2 = A[0] if batched else A
@@ -36,7 +63,10 @@ def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accu
     sb = b2.stride()
     sAm, sAk = (sa[1], sa[0]) if trans_a else (sa[0], sa[1])
     sBk, sBn = (sb[1], sb[0]) if trans_b else (sb[0], sb[1])
-    fn = L.lib().epc_gemm_f32_fast if fast else L.lib().epc_gemm_f32
+    if _GEMM_PRECISION == "bf16":
+        fn = L.lib().epc_gemm_bf16
+    else:
+        fn = L.lib().epc_gemm_f32_fast if fast else L.lib().epc_gemm_f32
     L.check(fn(A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
              M, N, K, sAm, sAk, sBk, sBn, out.stride(-2), nb, A.stride(0) if batched else 0,
              B.stride(0) if batched else 0, out.stride(0) if batched else 0, int(splitk), 1 if accumulate else 0, _st()))
@@ -44,8 +74,12 @@ def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accu
 
 
 def _splitk_for(M, N, K):
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    return int(max(1, min(1024 // max(tiles, 1), K // 64, 512)))
+    """Split-K factor of a deep-K product (dW = x^T dy over all rows): about three workgroups per CU.  The kernel's
+    tile is 128 wide on a side of at least 128, 64 otherwise (gemm_impl); measured on the training shapes
+    (scripts/time_gemm.py): 256x1024x73728 16 -> 48 splits 550 -> 250 us; 64x64x73728 is best at 256."""
+    tile = lambda d: 128 if d >= 128 else 64
+    tiles = ((M + tile(M) - 1) // tile(M)) * ((N + tile(N) - 1) // tile(N))
+    return int(max(1, min(768 // max(tiles, 1), K // 128, 256)))
 
 
 class Linear(torch.autograd.Function):
@@ -95,24 +129,23 @@ class BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(z)
         L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                          float(eps), int(relu), rows, C, y.data_ptr(), _st()))
-        ctx.save_for_backward(z, y, mean, var, gamma)
+        ctx.save_for_backward(z, mean, var, gamma, beta)       # the ReLU mask is recomputed from z: y is not kept
         ctx.eps, ctx.relu = float(eps), int(relu)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
-        z, y, mean, var, gamma = ctx.saved_tensors
+        z, mean, var, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         rows, C = z.shape
         dz = torch.empty_like(z)
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
-        rstd = torch.empty(C, dtype=torch.float32, device=z.device)
         ws, n = _ws(rows, C, z.device)
-        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), y.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                                         gamma.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(), dgamma.data_ptr(),
-                                         dbeta.data_ptr(), rstd.data_ptr(), ws.data_ptr(), n, _st()))
+        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), ws.data_ptr(), n, _st()))
         return dz, dgamma, dbeta, None, None
 
 

@@ -46,6 +46,9 @@ class TrainStep:
         self.m: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
         self._graph = None                        # captured HIP graph of one step (step(..., graph=True))
+        # GEMM arithmetic of the step (ops.set_gemm_precision): "bf16x6" = f32-accurate like the reference's fp32 graph
+        # (default); "bf16" = one bf16 value per operand, the arithmetic BASELINE.json configs[2] names
+        self.precision = params.get("TRAIN_PRECISION", "bf16x6")
 
     # -- checkpoint-shaped optimizer state ---------------------------------------------------------------------------
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
@@ -111,12 +114,16 @@ class TrainStep:
         for name in self.trainable_names():
             self.store.vars[name].grad = None
         tf_util.defer_ema_updates()                 # the 34 moving-average updates are applied in one launch below
+        prev = ops.set_gemm_precision(self.precision)
         try:
-            loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
-        except BaseException:
-            tf_util._deferred_ema = None            # a failed forward applies nothing
-            raise
-        loss.backward()
+            try:
+                loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
+            except BaseException:
+                tf_util._deferred_ema = None        # a failed forward applies nothing
+                raise
+            loss.backward()
+        finally:
+            ops.set_gemm_precision(prev)
         with torch.no_grad():
             names = self.trainable_names()
             grads = []

@@ -197,19 +197,31 @@ int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bia
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
-/* tf.nn.moments over the rows of x (rows, C): mean and POPULATION variance (utils/tf_util.py:472). */
+/* Same interface, operands rounded to ONE bf16 value each (f32 data in memory, f32 accumulation, one product): the
+ * "bf16" training configuration of BASELINE.json configs[2].  2^-9 relative per operand. */
+int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                 long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                 void* stream);
+
+/* Column reductions over the rows of (rows, C) tensors, C a multiple of 4 (at most 4096).  Each is ONE launch: the
+ * workgroup that finishes a column panel last adds the per-panel partial sums in a fixed order (deterministic).
+ * WORKSPACE CONTRACT: epc_colreduce_workspace_bytes(rows, C) bytes, 16-byte aligned; its first 256 bytes are
+ * completion counters that must be ZERO on entry and are left zero on exit -- zero a workspace once, then reuse it for
+ * any number of calls on ONE stream (calls sharing a workspace must be stream-ordered).
+ * epc_col_moments: tf.nn.moments -- mean and POPULATION variance (utils/tf_util.py:472), one pass over x. */
 size_t epc_colreduce_workspace_bytes(int rows, int C);
 int epc_col_moments(const float* x, int rows, int C, float* mean, float* var, void* workspace, size_t workspace_bytes,
                     void* stream);
 int epc_col_sum(const float* x, int rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* tf.nn.batch_normalization (+ReLU) with given statistics, and its training-mode backward (statistics are functions
- * of z): dz, dgamma, dbeta.  utils/tf_util.py:490, loupe.py:257-263. */
+ * of z): dz, dgamma, dbeta.  utils/tf_util.py:490, loupe.py:257-263.  The backward recomputes the ReLU mask from z
+ * with the forward's own expression, so the forward output is not an input.  Workspace: contract above. */
 int epc_bn_apply_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                      float eps, int relu, int rows, int C, float* y, void* stream);
-int epc_bn_apply_bwd(const float* dy, const float* z, const float* y, const float* mean, const float* var,
-                     const float* gamma, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
-                     float* rstd_out, void* workspace, size_t workspace_bytes, void* stream);
+int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* xm = (mask @ x) / knn in index form (models/epc-net.py:70-71) for 64-channel x, and its transpose
  * dx += mask^T @ dxm / knn (dx pre-initialised by the caller). */

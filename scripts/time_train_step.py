@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 arch = os.environ.get("ARCH", "epc-net")
 store = bench.build_store(arch, dev, 0)
 TR = bench.pkg("training")
-params = dict(bench.PARAMS, ARCH=arch, BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5, MARGIN_2=0.2)
+params = dict(bench.PARAMS, ARCH=arch, TRAIN_PRECISION=os.environ.get("PRECISION", "bf16x6"), BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5, MARGIN_2=0.2)
 ts = TR.TrainStep(params, store, outer=bench.OUTER)
 g = torch.Generator().manual_seed(0)
 mk = lambda p: (torch.rand((1, p, 4096, 3), generator=g) * 2 - 1).to(dev)
@@ -24,5 +24,5 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 ncl = 1 + 2 + neg + 1
-print("train step %s (%s): %d clouds, %.2f ms/step, %.1f steps/s, %.0f clouds/s, loss %.4f, ~%.1f TFLOP/s (3x fwd FLOPs), peak mem %.2f GB"
+print(("train step %s (%s, " + params["TRAIN_PRECISION"] + "): %d clouds, %.2f ms/step, %.1f steps/s, %.0f clouds/s, loss %.4f, ~%.1f TFLOP/s (3x fwd FLOPs), peak mem %.2f GB")
       % (arch, "HIP graph" if use_graph else "eager", ncl, dt * 1e3, 1 / dt, ncl / dt, float(loss), 3 * bench.FLOPS_PER_CLOUD[arch] * ncl / dt / 1e12, torch.cuda.max_memory_allocated() / 2**30))

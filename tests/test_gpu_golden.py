@@ -128,7 +128,7 @@ def test_g5_training_step(dev):
         ref = GOLD["g5/grad/" + name]
         g = grads[name].reshape(ref.shape)
         assert np.abs(g - ref).max() <= 3e-2 * np.abs(ref).max() + 2e-6, name
-        assert np.linalg.norm(g - ref) <= 5e-3 * np.linalg.norm(ref) + 2e-6 * np.sqrt(g.size), name
+        assert np.linalg.norm(g - ref) <= 8e-3 * np.linalg.norm(ref) + 2e-6 * np.sqrt(g.size), name
     for key in (k for k in GOLD.files if k.startswith("g5/ema/")):
         ref = GOLD[key]
         v = st.vars[H.OUTER + "/" + key[len("g5/ema/"):]].detach().cpu().numpy().reshape(ref.shape)

@@ -137,3 +137,34 @@ def test_loupe_classes_match_oracle(dev, cls, groups, is_training):
         ref = O.netvlad_forward(ost, feats, N, is_training)
     assert out.shape == (B, D)
     assert np.abs(out - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-6, np.abs(out - ref).max()
+
+
+def test_column_reductions_are_deterministic_under_workspace_reuse(dev):
+    """The one-launch column reductions hand partial sums from every workgroup to the last one through a workspace that
+    all layers of a step share (include/epcnet.h, workspace contract).  A partial that is read before it is visible
+    would show up as a result that depends on what the previous call left in the workspace: interleave calls of
+    different shapes many times and require bit-identical results, and agreement with float64."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(7)
+    shapes = [(73728, 64), (18 * 4096, 1024), (4097, 256), (72, 256), (300, 64)]
+    data = [(torch.randn(r, c, generator=g) * 3 + 1).to(dev) for r, c in shapes]
+    gam = [torch.rand(c, generator=g).to(dev) + 0.5 for _, c in shapes]
+    bet = [torch.randn(c, generator=g).to(dev) for _, c in shapes]
+    dys = [torch.randn(r, c, generator=g).to(dev) for r, c in shapes]
+    first = None
+    for rep in range(25):
+        outs = []
+        for z, ga, be, dy in zip(data, gam, bet, dys):
+            z_ = z.clone().requires_grad_(True)
+            ga_, be_ = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+            y, mean, var = ops.BatchNormTrain.apply(z_, ga_, be_, 1e-3, 1)
+            y.backward(dy)
+            outs += [mean.clone(), var.clone(), ga_.grad.clone(), be_.grad.clone(), z_.grad[:7].clone()]
+        if first is None:
+            first = outs
+            for (z, ga, be, dy), (mean, var) in zip(zip(data, gam, bet, dys), zip(outs[0::5], outs[1::5])):
+                z64 = z.double()
+                assert rel(mean, z64.mean(0)) <= 1e-5 and rel(var, z64.var(0, unbiased=False)) <= 2e-5
+        else:
+            for a, b in zip(first, outs):
+                assert torch.equal(a, b), "a column reduction changed between identical calls (rep %d)" % rep
