@@ -82,15 +82,30 @@ def _splitk_for(M, N, K):
     return int(max(1, min(768 // max(tiles, 1), K // 128, 256)))
 
 
+_ZEROS = {}
+
+
+def _const_zeros(n, device):
+    """A shared read-only zero vector (gradients that are exactly zero by construction: no fill launch per step)."""
+    key = (device.index, int(n))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(int(n), dtype=torch.float32, device=device)
+    return z
+
+
 class Linear(torch.autograd.Function):
     """y = x @ W + b on (rows, Cin): tf.nn.conv1d with kernel_size 1 (utils/tf_util.py:94-99) / tf.matmul + bias_add
-    (:336-339)."""
+    (:336-339).  ``bias_before_batch_stats``: the layer feeds a training-mode BatchNorm, whose backward returns a dz
+    with zero column sums -- the bias gradient sum_rows dz is exactly 0 (the reference's BiasAddGrad evaluates the same
+    sum and gets rounding noise; the bias has no effect on the network's output there), so it is not computed."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, bias_before_batch_stats=False):
         x = x.contiguous()
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.zero_bias_grad = bool(bias_before_batch_stats)
         rows, cin = x.shape
         # few output tiles but a deep K (the 16384-wide hidden projection on a handful of rows): split K over workgroups
         tiles = ((rows + 63) // 64) * ((W.shape[1] + 63) // 64)
@@ -106,11 +121,13 @@ class Linear(torch.autograd.Function):
         dx = gemm(dy, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
         db = None
-        if ctx.has_bias:
+        if ctx.has_bias and ctx.zero_bias_grad:
+            db = _const_zeros(cout, x.device)
+        elif ctx.has_bias:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
             ws, n = _ws(rows, cout, x.device)
             L.check(L.lib().epc_col_sum(dy.data_ptr(), rows, cout, db.data_ptr(), ws.data_ptr(), n, _st()))
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class BatchNormTrain(torch.autograd.Function):

@@ -163,7 +163,7 @@ def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope):
 
 def _dense(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training):
     from .. import ops
-    z = ops.Linear.apply(inputs2d, w2d, b)
+    z = ops.Linear.apply(inputs2d, w2d, b, bool(bn and is_training))
     want_relu = activation_fn is not None
     if activation_fn not in (None, relu):
         raise NotImplementedError("only activation_fn=tf.nn.relu / None are used by EPC-Net")

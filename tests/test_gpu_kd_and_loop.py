@@ -102,7 +102,9 @@ def test_distill_step(dev):
     for k, v in teacher_before.items():
         assert torch.equal(st.vars[k], v), k
     moved = [k for k, v in student_before.items() if k in st.trainable and not torch.equal(st.vars[k], v)]
-    assert len(moved) >= 28
+    # the 8 biases sit in front of a training-mode BatchNorm: their gradient is exactly zero (ops.Linear) and they stay put
+    still = [k for k in student_before if k in st.trainable and k not in moved]
+    assert len(moved) >= 24 and all(k.endswith("/biases") for k in still), still
     slots = [k for k in ds.optimizer_state() if k.endswith("/Adam") or k.endswith("/Adam_1")]
     assert len(slots) == 64 and all(k.startswith("student/") for k in slots)
     # GAMMA != 0 builds the teacher's feature map and adds the feature term
