@@ -36,7 +36,8 @@ def run_pair(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
         assert rel(a.grad, b.grad) <= tol * 5, "grad of input %d: %.3e" % (i, rel(a.grad, b.grad))
 
 
-@pytest.mark.parametrize("rows,cin,cout", [(4096, 64, 64), (1000, 3, 64), (2048, 256, 1024), (72, 16384, 256), (300, 1024, 64)])
+@pytest.mark.parametrize("rows,cin,cout", [(4096, 64, 64), (1000, 3, 64), (2048, 256, 1024), (72, 16384, 256), (300, 1024, 64),
+                                           (333, 64, 64), (255, 64, 64)])   # 64 -> 64: the specialised layer kernel (ragged / just below its threshold)
 def test_linear(dev, rows, cin, cout):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(0)
