@@ -120,12 +120,10 @@ class _VladBase(PoolingBaseModel):
         activation = ops.Softmax64.apply(activation)                                             # :272
         activation = activation.reshape(-1, N, C)                                                # :274
         a_sum = activation.sum(dim=-2, keepdim=True)                                             # :276
-        a = a_sum * st[scoped("cluster_weights2")]                                               # :284
         vlad = ops.VladAggregate.apply(x.reshape(-1, N, F), activation)                          # :286-291 (B,F,C)
-        vlad = vlad - a                                                                          # :292
-        vlad = _l2_normalize(vlad, 1)                                                            # :295
-        vlad = vlad.reshape(-1, C * F)                                                           # :297
-        vlad = _l2_normalize(vlad, 1)                                                            # :298
+        # a = a_sum * cluster_weights2 (:284); vlad - a (:292); l2_normalize over F (:295); flatten, l2_normalize (:297-298)
+        vlad = ops.VladNormalize.apply(vlad, a_sum, st[scoped("cluster_weights2")])
+        vlad = vlad.reshape(-1, C * F)
         vlad = vlad.reshape(-1, C * F // G)                                                      # :302 (groups)
         vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                       # :322
         vlad = _slim_batch_norm(vlad, "bn", self.is_training, fused=True)                        # :323

@@ -94,7 +94,12 @@ def quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2):
 
 
 def lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2):
-    """:269-284 -- the loss train.py:264 uses."""
+    """:269-284 -- the loss train.py:264 uses.  float32 descriptors on the GPU take the one-launch operator
+    (ops.LazyQuadrupletLoss: the op-by-op composition below is ~60 launches forward and backward); anything else
+    (float64 checks, the other loss variants) runs the composition."""
+    if q_vec.is_cuda and q_vec.dtype == torch.float32 and pos_vecs.shape[1] <= 64 and neg_vecs.shape[1] <= 64:
+        from .. import ops
+        return ops.LazyQuadrupletLoss.apply(q_vec, pos_vecs, neg_vecs, other_neg, float(m1), float(m2))
     return lazy_triplet_loss(q_vec, pos_vecs, neg_vecs, m1) + \
         _neg_terms(q_vec, pos_vecs, neg_vecs, other_neg, m2).max(1).values.mean()
 

@@ -75,7 +75,7 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
         net = net.reshape(-1, 1024)
         output = tf_util.fully_connected(net, params["FEATURE_OUTPUT_DIM"], bn=True, is_training=is_training,
                                          scope="fc1", bn_decay=bn_decay)
-        output = lp._l2_normalize(output, 1)
+        output = ops.RowL2Normalize.apply(output)
     if return_features:                                                  # models/kd_epc-net-l.py:102
         return ops.RowL2Normalize.apply(feats.reshape(-1, 1024)), output
     return output

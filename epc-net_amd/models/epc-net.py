@@ -92,7 +92,7 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
                             add_batch_norm=True, is_training=is_training)
         net = ops.RowL2Normalize.apply(x.reshape(-1, 1024))  # :147-148
         output = NetVLAD.forward(net)
-        output = lp._l2_normalize(output, 1)                 # :153
+        output = ops.RowL2Normalize.apply(output)                 # :153
     if return_features:                                      # models/kd_epc-net.py:158: (normalised point features, output)
         return net, output
     return output

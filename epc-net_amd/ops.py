@@ -250,6 +250,67 @@ class RowL2Normalize(torch.autograd.Function):
         return dx
 
 
+class VladNormalize(torch.autograd.Function):
+    """(raw - a_sum * cluster_weights2) -> intra-normalisation over F -> L2 normalisation of the flattened vector
+    (loupe.py:284,292-298) in one launch; backward in one launch plus the cross-cloud cluster_weights2 sum.
+    raw (B,F,64), a_sum (B,1,64), w2 (1,F,64) -> (B,F,64)."""
+
+    @staticmethod
+    def forward(ctx, raw, a_sum, w2):
+        raw, a_sum, w2 = raw.contiguous(), a_sum.contiguous(), w2.contiguous()
+        B, F, C = raw.shape
+        out = torch.empty_like(raw)
+        r1 = torch.empty((B, C), dtype=torch.float32, device=raw.device)
+        r2 = torch.empty((B,), dtype=torch.float32, device=raw.device)
+        L.check(L.lib().epc_vlad_normalize_fwd(raw.data_ptr(), a_sum.data_ptr(), w2.data_ptr(), B, F, C, out.data_ptr(),
+                                               r1.data_ptr(), r2.data_ptr(), _st()))
+        ctx.save_for_backward(out, r1, r2, w2, a_sum)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, r1, r2, w2, a_sum = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, F, C = out.shape
+        draw = torch.empty_like(out)
+        da = torch.empty_like(a_sum)
+        L.check(L.lib().epc_vlad_normalize_bwd(dout.data_ptr(), out.data_ptr(), r1.data_ptr(), r2.data_ptr(), w2.data_ptr(),
+                                               B, F, C, draw.data_ptr(), da.data_ptr(), _st()))
+        dw2 = None
+        if ctx.needs_input_grad[2]:
+            dw2 = -(draw * a_sum.reshape(B, 1, C)).sum(0, keepdim=True).reshape(w2.shape)
+        return draw, da, dw2
+
+
+class LazyQuadrupletLoss(torch.autograd.Function):
+    """models/epc-net.py:269-284 as one launch forward and one backward (q (B,1,D), pos (B,P,D), neg (B,Nn,D),
+    other (B,1,D) -> scalar)."""
+
+    @staticmethod
+    def forward(ctx, q, pos, neg, other, m1, m2):
+        q, pos, neg, other = q.contiguous(), pos.contiguous(), neg.contiguous(), other.contiguous()
+        B, P, D = pos.shape
+        Nn = neg.shape[1]
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        sel = torch.empty((B, 3), dtype=torch.int32, device=q.device)
+        L.check(L.lib().epc_lazy_quadruplet_loss_fwd(q.data_ptr(), pos.data_ptr(), neg.data_ptr(), other.data_ptr(), B, P, Nn,
+                                                     D, float(m1), float(m2), loss.data_ptr(), sel.data_ptr(), _st()))
+        ctx.save_for_backward(q, pos, neg, other, sel)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        q, pos, neg, other, sel = ctx.saved_tensors
+        dloss = dloss.contiguous().float()
+        B, P, D = pos.shape
+        Nn = neg.shape[1]
+        dq, dpos, dneg, dother = (torch.empty_like(t) for t in (q, pos, neg, other))
+        L.check(L.lib().epc_lazy_quadruplet_loss_bwd(q.data_ptr(), pos.data_ptr(), neg.data_ptr(), other.data_ptr(),
+                                                     sel.data_ptr(), dloss.data_ptr(), B, P, Nn, D, dq.data_ptr(),
+                                                     dpos.data_ptr(), dneg.data_ptr(), dother.data_ptr(), _st()))
+        return dq, dpos, dneg, dother, None, None
+
+
 class Softmax64(torch.autograd.Function):
     """tf.nn.softmax over the 64 clusters (loupe.py:272)."""
 

@@ -223,6 +223,26 @@ int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const f
                      const float* beta, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* VLAD normalisations in one launch (loupe.py:284,292-298): v = raw - a_sum (x) w2; intra-normalisation over the F axis
+ * per (cloud, cluster); L2 normalisation of the flattened (F*C) vector per cloud.  raw, out: (num_clouds, F, C) with
+ * C == 64; a_sum: (num_clouds, C); w2: (F, C); r1: (num_clouds, C) and r2: (num_clouds) receive the two reciprocal
+ * norms (inputs of the backward).  Backward: d raw and d a_sum; the cluster_weights2 gradient crosses clouds
+ * (-sum_b a_sum[b][c] * draw[b][f][c]) and is left to the caller. */
+int epc_vlad_normalize_fwd(const float* raw, const float* a_sum, const float* w2, int num_clouds, int F, int C,
+                           float* out, float* r1, float* r2, void* stream);
+int epc_vlad_normalize_bwd(const float* dout, const float* out, const float* r1, const float* r2, const float* w2,
+                           int num_clouds, int F, int C, float* draw, float* da_sum, void* stream);
+
+/* lazy_quadruplet_loss (models/epc-net.py:269-284 with best_pos_distance :160-167) on descriptors q (B,1,D), pos (B,P,D),
+ * neg (B,Nn,D), other (B,1,D): loss[0] = mean_b max_n max(m1 + best_b - |neg_n - q|^2, 0) + mean_b max_n max(m2 + best_b -
+ * |neg_n - other|^2, 0).  sel (B,3) int32 receives the selected positive and the two selected negatives (-1: hinge
+ * inactive) for the backward, which writes all four gradients scaled by dloss[0] (a device scalar). */
+int epc_lazy_quadruplet_loss_fwd(const float* q, const float* pos, const float* neg, const float* other, int B, int P,
+                                 int Nn, int D, float m1, float m2, float* loss, int32_t* sel, void* stream);
+int epc_lazy_quadruplet_loss_bwd(const float* q, const float* pos, const float* neg, const float* other,
+                                 const int32_t* sel, const float* dloss, int B, int P, int Nn, int D, float* dq,
+                                 float* dpos, float* dneg, float* dother, void* stream);
+
 /* xm = (mask @ x) / knn in index form (models/epc-net.py:70-71) for 64-channel x, and its transpose
  * dx += mask^T @ dxm / knn (dx pre-initialised by the caller). */
 int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt, const float* kth,

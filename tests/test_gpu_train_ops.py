@@ -169,3 +169,54 @@ def test_column_reductions_are_deterministic_under_workspace_reuse(dev):
         else:
             for a, b in zip(first, outs):
                 assert torch.equal(a, b), "a column reduction changed between identical calls (rep %d)" % rep
+
+
+@pytest.mark.parametrize("degenerate", [False, True])
+def test_vlad_normalize(dev, degenerate):
+    """ops.VladNormalize against the op-by-op composition of loupe.py:284,292-298 in float64 (forward and the three
+    gradients); `degenerate` zeroes one cluster column of one cloud so that the inner 1e-12 clamp is active there."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(11)
+    B, F, C = 3, 1024, 64
+    raw = torch.randn(B, F, C, dtype=torch.float64, generator=g)
+    a_sum = torch.rand(B, 1, C, dtype=torch.float64, generator=g) * 50
+    w2 = torch.randn(1, F, C, dtype=torch.float64, generator=g) / 32
+    if degenerate:
+        raw[1, :, 5] = 0
+        a_sum[1, 0, 5] = 0
+
+    def ref(raw, a_sum, w2):
+        v = raw - a_sum * w2
+        v = v * torch.rsqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))
+        v = v.reshape(B, -1)
+        return (v * torch.rsqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))).reshape(B, F, C)
+
+    run_pair(lambda r, a, w: ops.VladNormalize.apply(r, a, w), ref, [raw, a_sum, w2], dev, tol=2e-5)
+
+
+@pytest.mark.parametrize("B,P,Nn,far", [(1, 2, 14, False), (1, 2, 18, False), (3, 2, 5, False), (2, 2, 6, True)])
+def test_lazy_quadruplet_loss_operator(dev, B, P, Nn, far):
+    """ops.LazyQuadrupletLoss against the op-by-op composition (models/_common.py, float64 on the CPU): value and the four
+    gradients; `far` = every hinge inactive (loss 0, all gradients 0)."""
+    ops, M = H.pkg("ops"), H.pkg("models._common")
+    g = torch.Generator().manual_seed(5)
+    D = 256
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    q, pos, neg, oth = (unit(torch.randn(B, n, D, dtype=torch.float64, generator=g)) for n in (1, P, Nn, 1))
+    if far:
+        pos = q.repeat(1, P, 1).clone()
+        neg = -q.repeat(1, Nn, 1) + 1e-3 * neg
+        oth = q.clone()
+    ins64 = [t.clone().requires_grad_(True) for t in (q, pos, neg, oth)]
+    ins32 = [t.float().to(dev).requires_grad_(True) for t in (q, pos, neg, oth)]
+    l64 = M.lazy_triplet_loss(ins64[0], ins64[1], ins64[2], 0.5) + \
+        M._neg_terms(ins64[0], ins64[1], ins64[2], ins64[3], 0.2).max(1).values.mean()
+    l32 = M.lazy_quadruplet_loss(*ins32, 0.5, 0.2)
+    assert l32.grad_fn is not None and type(l32.grad_fn).__name__.startswith("LazyQuadrupletLoss")
+    assert float(l32) == pytest.approx(float(l64), rel=1e-5, abs=1e-7)
+    (l64 * 1.7).backward()
+    (l32 * 1.7).backward()
+    if far:
+        assert float(l64) == 0.0
+    for a, b in zip(ins32, ins64):
+        assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-5 * max(b.grad.abs().max().item(), 1.0)
