@@ -85,12 +85,13 @@ def _splitk_for(M, N, K):
 _ZEROS = {}
 
 
-def _const_zeros(n, device):
-    """A shared read-only zero vector (gradients that are exactly zero by construction: no fill launch per step)."""
-    key = (device.index, int(n))
+def const_zeros_like(t):
+    """A shared READ-ONLY zero tensor of t's shape (gradients that are exactly zero by construction: no fill launch per
+    step).  Never write to it."""
+    key = (t.device.index, tuple(t.shape))
     z = _ZEROS.get(key)
     if z is None:
-        z = _ZEROS[key] = torch.zeros(int(n), dtype=torch.float32, device=device)
+        z = _ZEROS[key] = torch.zeros(tuple(t.shape), dtype=torch.float32, device=t.device)
     return z
 
 
@@ -120,10 +121,8 @@ class Linear(torch.autograd.Function):
         cout = W.shape[1]
         dx = gemm(dy, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
-        db = None
-        if ctx.has_bias and ctx.zero_bias_grad:
-            db = _const_zeros(cout, x.device)
-        elif ctx.has_bias:
+        db = None      # exactly zero in front of a training-mode BatchNorm: left undefined (TrainStep reads it as zeros)
+        if ctx.has_bias and not ctx.zero_bias_grad:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
             ws, n = _ws(rows, cout, x.device)
             L.check(L.lib().epc_col_sum(dy.data_ptr(), rows, cout, db.data_ptr(), ws.data_ptr(), n, _st()))
@@ -149,10 +148,13 @@ class BatchNormTrain(torch.autograd.Function):
         ctx.save_for_backward(z, mean, var, gamma, beta)       # the ReLU mask is recomputed from z: y is not kept
         ctx.eps, ctx.relu = float(eps), int(relu)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradients" of mean / var (two fill launches per layer)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
+        if dy is None:
+            return None, None, None, None, None
         z, mean, var, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         rows, C = z.shape

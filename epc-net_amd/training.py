@@ -129,7 +129,7 @@ class TrainStep:
             grads = []
             for name in names:
                 w = self.store.vars[name]
-                grads.append(w.grad if w.grad is not None else torch.zeros_like(w))
+                grads.append(w.grad if w.grad is not None else ops.const_zeros_like(w))
             # data-parallel runs average the moving statistics too: apply the updates first
             tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9)
             self._average_over_ranks(grads)
