@@ -682,7 +682,8 @@ __global__ __launch_bounds__(256) void neighbour_mean_kernel(const float* __rest
                                                              const int32_t* __restrict__ idx,
                                                              const int32_t* __restrict__ cnt,
                                                              const float* __restrict__ kth, int cap, int total_points,
-                                                             int n, float kdiv, float* __restrict__ dst) {
+                                                             int n, float kdiv, float* __restrict__ dst,
+                                                             float* __restrict__ diff) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int g = t >> 4, q = t & 15;
     if (g >= total_points) return;
@@ -722,6 +723,11 @@ __global__ __launch_bounds__(256) void neighbour_mean_kernel(const float* __rest
     if (!BWD) {
         acc.x /= kdiv, acc.y /= kdiv, acc.z /= kdiv, acc.w /= kdiv;
         reinterpret_cast<float4*>(dst)[(size_t)g * 16 + q] = acc;
+        if (diff) {   // xm - x (models/epc-net.py:72), written by the same launch
+            const float4 own = s4[(size_t)g * 16 + q];
+            reinterpret_cast<float4*>(diff)[(size_t)g * 16 + q] =
+                make_float4(acc.x - own.x, acc.y - own.y, acc.z - own.z, acc.w - own.w);
+        }
     }
 }
 
@@ -732,7 +738,20 @@ extern "C" int epc_neighbour_mean_fwd(const float* x, const float* xyz, const in
     EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT, "bad shape");
     const long total = (long)num_clouds * n;
     hipLaunchKernelGGL(neighbour_mean_kernel<false>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, xm);
+                       (hipStream_t)stream, x, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, xm, nullptr);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// xm as above and diff = xm - x (models/epc-net.py:70-72) in one launch
+extern "C" int epc_neighbour_mean_diff_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                                           const float* kth, int cap, int num_clouds, int n, int knn, float* xm,
+                                           float* diff, void* stream) {
+    EPC_CHECK_ARG(x && xyz && idx && cnt && kth && xm && diff, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT, "bad shape");
+    const long total = (long)num_clouds * n;
+    hipLaunchKernelGGL(neighbour_mean_kernel<false>, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, xm, diff);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -854,7 +873,10 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
                                                                    const int32_t* __restrict__ rdeg,
                                                                    const int32_t* __restrict__ roff,
                                                                    const int32_t* __restrict__ rlist, int total_points,
-                                                                   float kdiv, float* __restrict__ dx) {
+                                                                   float kdiv, const float* __restrict__ ddiff,
+                                                                   float* __restrict__ dx) {
+    // ddiff (optional): the gradient of diff = xm - x of the fused forward.  Then the rows gathered are dxm + ddiff and
+    // the point's own -ddiff is added:  dx[j] = (sum_i (dxm[i] + ddiff[i])) / k - ddiff[j]
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= total_points) return;
     const int deg = rdeg[j];
@@ -866,13 +888,21 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
         int m = 0;
         for (; m + 4 <= lim; m += 4) {   // 4 independent row loads in flight
             const int i0 = __shfl(mine, m), i1 = __shfl(mine, m + 1), i2 = __shfl(mine, m + 2), i3 = __shfl(mine, m + 3);
-            const float v0 = dxm[(size_t)i0 * 64 + lane], v1 = dxm[(size_t)i1 * 64 + lane];
-            const float v2 = dxm[(size_t)i2 * 64 + lane], v3 = dxm[(size_t)i3 * 64 + lane];
+            float v0 = dxm[(size_t)i0 * 64 + lane], v1 = dxm[(size_t)i1 * 64 + lane];
+            float v2 = dxm[(size_t)i2 * 64 + lane], v3 = dxm[(size_t)i3 * 64 + lane];
+            if (ddiff) {
+                v0 += ddiff[(size_t)i0 * 64 + lane], v1 += ddiff[(size_t)i1 * 64 + lane];
+                v2 += ddiff[(size_t)i2 * 64 + lane], v3 += ddiff[(size_t)i3 * 64 + lane];
+            }
             acc += (v0 + v1) + (v2 + v3);
         }
-        for (; m < lim; ++m) acc += dxm[(size_t)__shfl(mine, m) * 64 + lane];
+        for (; m < lim; ++m) {
+            const size_t o = (size_t)__shfl(mine, m) * 64 + lane;
+            acc += ddiff ? dxm[o] + ddiff[o] : dxm[o];
+        }
     }
-    dx[(size_t)j * 64 + lane] = acc / kdiv;
+    const float own = ddiff ? ddiff[(size_t)j * 64 + lane] : 0.f;
+    dx[(size_t)j * 64 + lane] = acc / kdiv - own;
 }
 
 // scatter restricted to the rows the transposed graph does not list (cnt > cap)
@@ -881,11 +911,12 @@ __global__ __launch_bounds__(256) void neighbour_scatter_overflow_kernel(const f
                                                                          const int32_t* __restrict__ cnt,
                                                                          const float* __restrict__ kth, int cap,
                                                                          int total_points, int n, float kdiv,
+                                                                         const float* __restrict__ ddiff,
                                                                          float* __restrict__ dx) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= total_points || cnt[g] <= cap) return;
     const int cloud_base = (g / n) * n;
-    const float v = dxm[(size_t)g * 64 + lane] / kdiv;
+    const float v = (dxm[(size_t)g * 64 + lane] + (ddiff ? ddiff[(size_t)g * 64 + lane] : 0.f)) / kdiv;
     const float* pc = xyz + (size_t)cloud_base * 3;
     const int i = g - cloud_base;
     const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
@@ -907,9 +938,27 @@ extern "C" int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz,
     const unsigned blocks = (unsigned)((total + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
-                       (float)knn, dx);
+                       (float)knn, (const float*)nullptr, dx);
     hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
-                       (int)total, n, (float)knn, dx);
+                       (int)total, n, (float)knn, (const float*)nullptr, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// Backward of epc_neighbour_mean_diff_fwd: dx = mask^T (dxm + ddiff) / k - ddiff, dx overwritten.
+extern "C" int epc_neighbour_mean_diff_bwd_gather(const float* dxm, const float* ddiff, const float* xyz,
+                                                  const int32_t* cnt, const float* kth, int cap, const int32_t* rdeg,
+                                                  const int32_t* roff, const int32_t* rlist, int num_clouds, int n,
+                                                  int knn, float* dx, void* stream) {
+    EPC_CHECK_ARG(dxm && ddiff && xyz && cnt && kth && rdeg && roff && rlist && dx, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
+    const long total = (long)num_clouds * n;
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
+                       (float)knn, ddiff, dx);
+    hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
+                       (int)total, n, (float)knn, ddiff, dx);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

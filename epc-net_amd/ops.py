@@ -230,6 +230,34 @@ class NeighbourMean(torch.autograd.Function):
         return dx, None, None
 
 
+class NeighbourMeanDiff(torch.autograd.Function):
+    """(xm, xm - x) with xm = matmul(mask, x) / float(k) (models/epc-net.py:70-72): the mean and the difference the block
+    feeds to conv_a, one launch forward, one gather backward (dx = mask^T (dxm + ddiff) / k - ddiff)."""
+
+    @staticmethod
+    def forward(ctx, x, graph, k):
+        x = x.contiguous()
+        ctx.graph, ctx.k = graph, int(k)
+        xm, diff = torch.empty_like(x), torch.empty_like(x)
+        g = graph
+        L.check(L.lib().epc_neighbour_mean_diff_fwd(x.data_ptr(), g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(),
+                                                    g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, int(k),
+                                                    xm.data_ptr(), diff.data_ptr(), _st()))
+        return xm, diff
+
+    @staticmethod
+    def backward(ctx, dxm, ddiff):
+        g = ctx.graph
+        dxm, ddiff = dxm.contiguous(), ddiff.contiguous()
+        dx = torch.empty_like(dxm)
+        rdeg, roff, rlist = g.transposed()
+        L.check(L.lib().epc_neighbour_mean_diff_bwd_gather(dxm.data_ptr(), ddiff.data_ptr(), g.xyz.data_ptr(),
+                                                           g.cnt.data_ptr(), g.kth.data_ptr(), L.EPC_KNN_CAP, rdeg.data_ptr(),
+                                                           roff.data_ptr(), rlist.data_ptr(), g.num_clouds, g.n, ctx.k,
+                                                           dx.data_ptr(), _st()))
+        return dx, None, None
+
+
 class RowL2Normalize(torch.autograd.Function):
     """tf.nn.l2_normalize(x, 1) on (rows, C) (models/epc-net.py:148)."""
 

@@ -250,6 +250,15 @@ int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx,
 int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
                            const float* kth, int cap, int num_clouds, int n, int knn, float* dx, void* stream);
 
+/* The two together as the blocks use them (models/epc-net.py:70-72): xm and diff = xm - x in one launch; backward
+ * dx = mask^T (dxm + ddiff) / knn - ddiff over the transposed graph (below), dx overwritten. */
+int epc_neighbour_mean_diff_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt,
+                                const float* kth, int cap, int num_clouds, int n, int knn, float* xm, float* diff,
+                                void* stream);
+int epc_neighbour_mean_diff_bwd_gather(const float* dxm, const float* ddiff, const float* xyz, const int32_t* cnt,
+                                       const float* kth, int cap, const int32_t* rdeg, const int32_t* roff,
+                                       const int32_t* rlist, int num_clouds, int n, int knn, float* dx, void* stream);
+
 /* The kNN graph transposed: for every point j the points i whose neighbour list holds j (rows with more than `cap`
  * entries are not listed).  rdeg, roff, cursor: (num_clouds*n) int32; rlist: (num_clouds*n*cap) int32 holding absolute
  * row numbers, cloud c's lists inside [c*n*cap, (c+1)*n*cap).  Built once per step: the graph is the same for every block. */

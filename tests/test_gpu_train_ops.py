@@ -77,6 +77,28 @@ def test_neighbour_mean(dev, kind, n):
              lambda x: torch.matmul(mask, x) / 20.0, [x], dev)
 
 
+@pytest.mark.parametrize("kind,n", [("uniform", 256), ("lattice", 512), ("zeros", 64)])
+def test_neighbour_mean_and_diff(dev, kind, n):
+    """ops.NeighbourMeanDiff = (mask @ x / k, mask @ x / k - x) (models/epc-net.py:70-72): both outputs carry gradient
+    (the block adds xm back after conv_b); lattice / zeros clouds take the overflow (cnt > cap) path."""
+    ops = H.pkg("ops")
+    pc = O.synthetic_clouds(2, n, 0, kind)
+    mask = torch.tensor(O.pairwise_distance_mask(pc), dtype=torch.float64)
+    graph = ops.KnnGraph(torch.from_numpy(pc).to(dev))
+    x = torch.randn(2, n, 64, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    w = torch.randn(2, n, 64, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+
+    def fused(x):
+        xm, d = ops.NeighbourMeanDiff.apply(x.reshape(-1, 64), graph, 20)
+        return (xm.reshape(2, n, 64) * 0.7 + d.reshape(2, n, 64) * w.to(x.dtype).to(x.device))
+
+    def ref(x):
+        xm = torch.matmul(mask, x) / 20.0
+        return xm * 0.7 + (xm - x) * w
+
+    run_pair(fused, ref, [x], dev)
+
+
 def test_rownorm_and_softmax(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(3)
