@@ -185,7 +185,8 @@ int epc_pairwise_topk(const float* database, int num_db, const float* queries, i
 /* BatchNorm needs batch statistics between layers (utils/tf_util.py:454-491), so nothing is folded here.     */
 /* ------------------------------------------------------------------------------------------------------ */
 
-/* C (M,N; row stride ldc) = op(A) op(B) (+ bias[N]) in exact f32 (MFMA).  A(m,k) = A[m*sAm + k*sAk], B(k,n) =
+/* C (M,N; row stride ldc) = op(A) op(B) (+ bias[N]) at f32 accuracy: bf16 MFMA on three bf16 pieces per f32 operand,
+ * six products, f32 accumulation (shapes with a side below 64: the f32 MFMA).  A(m,k) = A[m*sAm + k*sAk], B(k,n) =
  * B[k*sBk + n*sBn]: y = x W (tf.nn.conv1d k=1 / tf.matmul, utils/tf_util.py:94,336; loupe.py:255,290,322), dx = dy W^T,
  * dW = x^T dy (split-K: f32 atomics into a zeroed C).  `batch` strided problems (bA, bB, bC elements apart). */
 int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
