@@ -609,6 +609,65 @@ extern "C" int epc_bn_apply_fwd(const float* z, const float* mean, const float* 
     return EPC_OK;
 }
 
+// conv5's tail in one pass (models/epc-net.py:136-148): f = l2_normalize(relu(bn(z)), over the channels) and rn, the
+// reciprocal norm, for C == 1024.  The BatchNorm output itself is never materialised: its backward recomputes the mask
+// from z, and everything downstream (assignment product, aggregation, row-norm backward) takes f.  16 rows per workgroup
+// (4 per wave), the 1024 (s, t) pairs computed once per workgroup into LDS.
+#define BRN_C 1024
+#define BRN_ROWS 16
+__global__ __launch_bounds__(256) void bn_relu_rownorm_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                                  const float* __restrict__ var,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, int rows,
+                                                                  float* __restrict__ f, float* __restrict__ rn_out) {
+    __shared__ __attribute__((aligned(16))) float cs[BRN_C], ct[BRN_C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < BRN_C; c += 256) {
+        const BnAffine a = bn_affine(mean[c], var[c], gamma[c], beta[c], eps);
+        cs[c] = a.s, ct[c] = a.t;
+    }
+    __syncthreads();
+    for (int q = 0; q < BRN_ROWS / 4; ++q) {
+        const int row = blockIdx.x * BRN_ROWS + wave * (BRN_ROWS / 4) + q;
+        if (row >= rows) return;
+        const float* pz = z + (size_t)row * BRN_C;
+        float y[16];
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = 256 * u + 4 * lane;
+            const float4 v = *reinterpret_cast<const float4*>(pz + c);
+            const float4 s4 = *reinterpret_cast<const float4*>(cs + c), t4 = *reinterpret_cast<const float4*>(ct + c);
+            BnAffine a;
+            a.s = s4.x, a.t = t4.x, y[4 * u + 0] = fmaxf(bn_value(v.x, a), 0.f);
+            a.s = s4.y, a.t = t4.y, y[4 * u + 1] = fmaxf(bn_value(v.y, a), 0.f);
+            a.s = s4.z, a.t = t4.z, y[4 * u + 2] = fmaxf(bn_value(v.z, a), 0.f);
+            a.s = s4.w, a.t = t4.w, y[4 * u + 3] = fmaxf(bn_value(v.w, a), 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss += y[4 * u + e] * y[4 * u + e];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+        const float rn = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        float* pf = f + (size_t)row * BRN_C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            *reinterpret_cast<float4*>(pf + 256 * u + 4 * lane) =
+                make_float4(y[4 * u] * rn, y[4 * u + 1] * rn, y[4 * u + 2] * rn, y[4 * u + 3] * rn);
+        if (lane == 0) rn_out[row] = rn;
+    }
+}
+
+extern "C" int epc_bn_relu_rownorm_fwd(const float* z, const float* mean, const float* var, const float* gamma,
+                                       const float* beta, float eps, int rows, int C, float* f, float* rn, void* stream) {
+    EPC_CHECK_ARG(z && mean && var && gamma && beta && f && rn, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C == BRN_C, "implemented for the 1024 channels of conv5");
+    hipLaunchKernelGGL(bn_relu_rownorm_fwd_kernel, dim3((rows + BRN_ROWS - 1) / BRN_ROWS), dim3(256), 0, (hipStream_t)stream,
+                       z, mean, var, gamma, beta, eps, rows, f, rn);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
 // dz = gamma*rstd * (dyr - dbeta/rows - zhat * dgamma/rows); the ReLU mask is recomputed from z with the forward's
 // own expression (bn_value), so the forward output is neither stored for it nor read here.
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,

@@ -86,12 +86,12 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
             inp = t + xb
             outs.append(inp)
         x = torch.cat(outs, dim=-1)                          # :134
-        x = conv(x, 1024, 'conv5')                           # :136-139
+        # conv5 (:136-139) and the per-point l2_normalize of :147-148 (which the reference applies inside the VLAD scope)
+        net = tf_util.conv1d_l2_normalized(x, 1024, 'conv5', bn_decay=bn_decay, is_training=is_training)
     with variable_scope('VLAD'):
         NetVLAD = lp.G_VLAD(feature_size=1024, max_samples=num_points, cluster_size=params["CLUSTER_SIZE"],
                             output_dim=params["FEATURE_OUTPUT_DIM"], groups=params["GROUPS"], gating=True,
                             add_batch_norm=True, is_training=is_training)
-        net = ops.RowL2Normalize.apply(x.reshape(-1, 1024))  # :147-148
         output = NetVLAD.forward(net)
         output = ops.RowL2Normalize.apply(output)                 # :153
     if return_features:                                      # models/kd_epc-net.py:158: (normalised point features, output)

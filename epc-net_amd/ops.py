@@ -168,6 +168,47 @@ class BatchNormTrain(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None
 
 
+class BatchNormReluRowNorm(torch.autograd.Function):
+    """l2_normalize(relu(batch_norm_train(z)), 1) for conv5's 1024 channels (models/epc-net.py:136-148) without
+    materialising the BatchNorm output: (f, mean, var).  Backward = row-norm backward, then the BatchNorm backward."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps):
+        z = z.contiguous()
+        rows, C = z.shape
+        mean = torch.empty(C, dtype=torch.float32, device=z.device)
+        var = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, n = _ws(rows, C, z.device)
+        L.check(L.lib().epc_col_moments(z.data_ptr(), rows, C, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
+        f = torch.empty_like(z)
+        rn = torch.empty(rows, dtype=torch.float32, device=z.device)
+        L.check(L.lib().epc_bn_relu_rownorm_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                                beta.data_ptr(), float(eps), rows, C, f.data_ptr(), rn.data_ptr(), _st()))
+        ctx.save_for_backward(z, mean, var, gamma, beta, f, rn)
+        ctx.eps = float(eps)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        return f, mean, var
+
+    @staticmethod
+    def backward(ctx, df, _dm, _dv):
+        if df is None:
+            return None, None, None, None
+        z, mean, var, gamma, beta, f, rn = ctx.saved_tensors
+        df = df.contiguous()
+        rows, C = z.shape
+        dy = torch.empty_like(z)
+        L.check(L.lib().epc_rownorm_bwd(df.data_ptr(), f.data_ptr(), rn.data_ptr(), rows, C, dy.data_ptr(), _st()))
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, n = _ws(rows, C, z.device)
+        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), ctx.eps, 1, rows, C, dz.data_ptr(), dgamma.data_ptr(),
+                                         dbeta.data_ptr(), ws.data_ptr(), n, _st()))
+        return dz, dgamma, dbeta, None
+
+
 def bn_inference(z, mean, var, gamma, beta, eps=BN_EPS, relu=False):
     """Inference-mode BN with stored statistics (no gradient path is needed by the reference in this mode)."""
     z = z.contiguous()

@@ -186,6 +186,29 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
     return y.reshape(tuple(inputs.shape[:-1]) + (num_output_channels,))
 
 
+def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None):
+    """conv1d(kernel 1, bn=True, relu) followed by tf.nn.l2_normalize over the channels of every point -- the pair
+    models/epc-net.py:136-148 applies to conv5's output -- returned as (B*L, C).  Not a function of the reference's
+    tf_util: a fusion point.  In training the BatchNorm apply, the ReLU and the row norm are one pass over the
+    (rows, 1024) activations (ops.BatchNormReluRowNorm) and the un-normalised map is never written."""
+    from .. import ops
+    cin = int(inputs.shape[-1])
+    if not (is_training and num_output_channels == 1024):
+        y = conv1d(inputs, num_output_channels, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
+                   scope=scope, bn_decay=bn_decay)
+        return ops.RowL2Normalize.apply(y.reshape(-1, num_output_channels))
+    L.require_gpu()
+    w, b, _ = declare_conv1d(scope, cin, num_output_channels, 1, True, 1e-3, True)
+    with variable_scope(scope):
+        z = ops.Linear.apply(inputs.reshape(-1, cin), w.reshape(cin, num_output_channels), b, True)
+        beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
+        f, mean, var = ops.BatchNormReluRowNorm.apply(z, gamma, beta, 1e-3)
+        decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+        _ema_update(ema_mean, mean, decay)
+        _ema_update(ema_var, var, decay)
+    return f
+
+
 def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=0.0,
                     activation_fn=relu, bn=False, bn_decay=None, is_training=None):
     """utils/tf_util.py:310-346: (B, Cin) -> (B, num_outputs), BN over axis 0, ReLU by default."""

@@ -224,6 +224,12 @@ int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const f
                      const float* beta, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv5's tail in one pass (models/epc-net.py:136-148), C == 1024: f = l2_normalize(relu(batch_norm(z))) over the
+ * channels and rn (rows) = the reciprocal row norm; the BatchNorm output is not materialised.  Backward: epc_rownorm_bwd
+ * on (df, f, rn), then epc_bn_apply_bwd with relu = 1 (it recomputes the mask from z). */
+int epc_bn_relu_rownorm_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                            float eps, int rows, int C, float* f, float* rn, void* stream);
+
 /* VLAD normalisations in one launch (loupe.py:284,292-298): v = raw - a_sum (x) w2; intra-normalisation over the F axis
  * per (cloud, cluster); L2 normalisation of the flattened (F*C) vector per cloud.  raw, out: (num_clouds, F, C) with
  * C == 64; a_sum: (num_clouds, C); w2: (F, C); r1: (num_clouds, C) and r2: (num_clouds) receive the two reciprocal
