@@ -494,13 +494,13 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 #ifndef AGG_FT
 #define AGG_FT 4
 #endif
-#define AGG_ROW 40  // fp16 per LDS row: 32 points + 8 pad
+#define AGG_ROW 36  // fp16 per LDS row: 32 channels + 4 pad (72 B: conflict-free 8-byte stores, 8-byte aligned rows)
 
-__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
+__global__ __launch_bounds__(AGG_THREADS, 2) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
                                                                      const float* __restrict__ assign_frag,
                                                                      const float* __restrict__ rnorm, int n, int splits,
                                                                      float* __restrict__ vpart) {
-    __shared__ __attribute__((aligned(16))) unsigned short xt[4][32 * AGG_ROW];  // [wave][ch][pt]
+    __shared__ __attribute__((aligned(16))) unsigned short xt[4][32 * AGG_ROW];  // [wave][point][channel], 72-B rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int fg = blockIdx.x * 4 + wave;  // group of AGG_FT chunks (32 features each)
@@ -515,44 +515,92 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 
-    for (int tt = 0; tt < per; ++tt) {
+    // Ping-pong over the tiles: tile t+1's loads (8 KB of feat, 4 KB of assignment fragments per wave) are issued before
+    // tile t is scaled, transposed and multiplied, so the wave always has a tile in flight (a pure streaming read reaches
+    // 6.9 TB/s on this device with as little as 16 KB in flight per CU -- scripts/probe/read_bw.hip -- and this kernel
+    // was at 4.3: its waves alternated between waiting for a tile and working on it).
+    struct Tile {
+        u32x4 raw[AGG_FT][2];  // [chunk][s']
+        u32x4 bfr[2][2];       // [cluster tile][k-step]
+        float rn;
+    };
+    auto load = [&](Tile& t, int tt) {
         const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4;
         const float* fb = assign_frag + (gt0 + tt) * 1024 + lane * 4;
-        u32x4 raw[AGG_FT][2];  // [chunk][s']: all of the tile's feat loads are issued first
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) raw[c][q] = *reinterpret_cast<const u32x4*>(fa + (size_t)c * 512 + q * 256);
-        const float rn = rnorm[(gt0 + tt) * 32 + j];
-        f16x8 bf[2][2];  // [cluster tile][k-step]
+            for (int q = 0; q < 2; ++q)
+                // read exactly once: non-temporal, so the 0.54-GB stream does not evict the assignment fragments (read
+                // by 8 waves) from L2 -- 0.155 -> 0.119 ms per 64 clouds
+                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 512 + q * 256));
+        t.rn = rnorm[(gt0 + tt) * 32 + j];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                bf[t][ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(fb + (t * 2 + ks) * 256));
+#ifdef AGG_NT_B
+                t.bfr[ct][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256));
+#else
+                t.bfr[ct][ks] = *reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256);
+#endif
+    };
+    // Transposition lane = point -> lane = channel: every lane stores its 4-channel groups (8 bytes) into a
+    // [point][channel] image and the A fragments (lane = channel, 8 consecutive points) come back through the hardware
+    // transposing read ds_read_b64_tr_b16 (per 16-lane group a 4-point x 16-channel block, delivered channel-major).
+    // 16 8-byte stores and 16 transposing reads per tile; the first version wrote the image element by element
+    // (64 ds_write_b16 per tile) and that LDS traffic, not HBM, bounded the kernel (0.151 ms at any occupancy).
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    unsigned short* img = xt[wave];
+    const int li = lane & 15;
+    // transposing-read address of this lane: block row q = li >> 2 (point), columns 16*((lane >> 4) & 1) + 4*(li & 3)
+    const int tr_off = (8 * h + (li >> 2)) * AGG_ROW + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+    auto process = [&](const Tile& t) {
+#ifdef AGG_ABL_NOCOMPUTE
+#pragma unroll
+        for (int c = 0; c < AGG_FT; ++c) { acc[c][0][0] += __builtin_bit_cast(float, t.raw[c][0][0] ^ t.raw[c][1][1]) + t.rn; acc[c][1][1] += __builtin_bit_cast(float, t.bfr[c & 1][c >> 1][0]); }
+        return;
+#endif
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c) {
-            // scale + transpose: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) at point j
+            // scale: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) of point j
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const f16x8 fv = __builtin_bit_cast(f16x8, raw[c][s2]);
+                const f16x8 fv = __builtin_bit_cast(f16x8, t.raw[c][s2]);
+                f16x8 y;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const _Float16 y = (_Float16)((float)fv[q] * rn);
-                    const int row = 16 * s2 + 8 * (q >> 2) + 4 * h + (q & 3);
-                    xt[wave][row * AGG_ROW + j] = __builtin_bit_cast(unsigned short, y);
-                }
+                for (int q = 0; q < 8; ++q) y[q] = (_Float16)((float)fv[q] * t.rn);
+                const u32x4 packed = __builtin_bit_cast(u32x4, y);
+                unsigned short* dst = img + j * AGG_ROW + 16 * s2 + 4 * h;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(packed[0], packed[1]);       // channels 16s' + 4h + 0..3
+                *reinterpret_cast<uint2*>(dst + 8) = make_uint2(packed[2], packed[3]);   // channels 16s' + 8 + 4h + 0..3
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 af = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(&xt[wave][j * AGG_ROW + 16 * ks + 8 * h]));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off + (16 * ks) * AGG_ROW));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off + (16 * ks + 4) * AGG_ROW));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 af = __builtin_bit_cast(f16x8, both);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[c][t] = mfma_f16(af, bf[t][ks], acc[c][t]);
+                for (int ct = 0; ct < 2; ++ct) acc[c][ct] = mfma_f16(af, __builtin_bit_cast(f16x8, t.bfr[ct][ks]), acc[c][ct]);
             }
         }
+    };
+    Tile t0, t1;
+    load(t0, 0);
+    for (int tt = 0; tt < per; tt += 2) {
+        if (tt + 1 < per) load(t1, tt + 1);
+        process(t0);
+        if (tt + 2 < per) load(t0, tt + 2);
+        if (tt + 1 < per) process(t1);
     }
     float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
     constexpr float unscale = 1.0f / AGG_ASSIGN_SCALE;
+#ifdef AGG_ABL_NOSTORE
+    if (acc[0][0][0] != 123.f) return;
+#endif
 #pragma unroll
     for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
