@@ -16,7 +16,11 @@ Extra objects on the JSON line:
                lo product on the K=64 scaled fp8 MFMA; f32 accumulate; descriptor error 1.5e-6 against the f32 oracle), so it is priced against the dense
                bf16/fp16 peak (2.5 PFLOP/s): achieved = ALGORITHMIC FLOPs per launch (2.684 GFLOP per cloud,
                DESIGN.md) / its average duration, measured with HIP events recorded by the library on the launch
-               stream inside the timed region; the matrix pipe executes 1.4x that in bf16-rate units (frac is capped at 0.71).
+               stream inside the timed region (on every --profile-every-th step); the matrix pipe executes 1.4x that
+               in bf16-rate units (frac is capped at 0.71).
+  overlapped   a second timed region after the first: the same K steps with --in-flight (2) of them in flight on the
+               engine's HIP streams (InferenceEngine.submit).  Reported beside `value`, never as `value`: kernels that
+               share the chip take longer individually, so the roofline figures belong to the one-stream region.
   cpu_baseline the CPU oracle (numpy restatement of the reference's dense (N,N)-mask formulation, batch = 1 cloud per
                call as evaluate.py:86-90 does) timed on this box's host cores on a bounded sample.  Rank 0, N = 1 only.
                It is NOT TensorFlow (not installable here) -- kind "port".
@@ -96,6 +100,10 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=400.0, help="extra untimed steps after the warm-up (0 = none)")
     ap.add_argument("--batch", type=int, default=64, help="clouds per step per GPU (configs[1]: 64)")
     ap.add_argument("--arch", default="epc-net", choices=["epc-net", "epc-net-l"])
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="steps kept in flight on the engine's HIP streams (InferenceEngine.submit); 1 = one stream")
+    ap.add_argument("--profile-every", type=int, default=8,
+                    help="record the stage-boundary HIP events on every n-th timed step (the events cost ~5 %% of a step)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-clouds", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,16 +127,19 @@ def main():
 
     E = pkg("engine")
     store = build_store(args.arch, device, seed=0)            # same weights on every rank
-    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch)
+    lanes = max(1, args.in_flight)
+    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch, in_flight=lanes)
     g = torch.Generator(device="cpu")
     g.manual_seed(100 + rank)                                  # every rank extracts different clouds
     xyz = (torch.rand((args.batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
-    out = torch.empty((args.batch, 256), dtype=torch.float32, device=device)
+    outs = [torch.empty((args.batch, 256), dtype=torch.float32, device=device) for _ in range(lanes)]
+    out = outs[0]
 
-    profiles = [E.StageProfile() for _ in range(args.steps)]
+    every = max(1, args.profile_every)
+    profiles = {k: E.StageProfile() for k in range(0, args.steps, every)}
     scratch = E.StageProfile()
-    for _ in range(max(args.warmup, 0)):
-        eng.forward(xyz, out=out, profile=scratch)           # the same (event-recording) entry point the timed steps use
+    for k in range(max(args.warmup, 0)):
+        eng.forward(xyz, out=out, profile=scratch if k % every == 0 else None)   # the entry point the timed steps use
     if args.warmup > 0:
         torch.cuda.synchronize()
         scratch.elapsed_ms()                                   # first event query happens outside the timed region
@@ -137,7 +148,7 @@ def main():
         # Keep issuing UNTIMED steps until the device has been busy for --settle-ms since the first launch.
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            eng.forward(xyz, out=out, profile=scratch)
+            eng.forward(xyz, out=out)
             torch.cuda.synchronize()
 
     def fence():
@@ -146,25 +157,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the timed region: K steps on ONE stream; stage-boundary HIP events on every `every`-th step -------------
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        eng.forward(xyz, out=out, profile=profiles[k])
+        eng.forward(xyz, out=out, profile=profiles.get(k))
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     norms = out.norm(dim=1)
     if not bool(torch.isfinite(out).all()) or float((norms - 1).abs().max()) > 1e-3:
         raise SystemExit("descriptors are not unit-norm / finite: refusing to report a number")
 
+    # ---- second, separately reported region: the same K steps with `lanes` of them in flight ----------------------
+    # InferenceEngine.submit deals successive steps over the engine's own HIP streams (own workspace and output buffer
+    # each): step k+1's kNN (VALU-bound) then runs beside step k's conv5 / aggregate (MFMA- / HBM-bound).  Every step
+    # still does the whole path.  Kernels that share the chip take longer individually, so per-kernel roofline figures
+    # come from the one-stream region above and this region only reports its step rate.
+    overlapped = None
+    if lanes > 1:
+        for k in range(4 * lanes):
+            eng.submit(xyz, out=outs[k % lanes])
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            eng.submit(xyz, out=outs[k % lanes])
+        fence()
+        el2 = max_over_ranks(time.perf_counter() - t1)
+        if not all(torch.equal(out, o) for o in outs[1:]):
+            raise SystemExit("lanes disagree with the one-stream descriptors: refusing to report a number")
+        overlapped = {"steps_in_flight_per_gpu": lanes, "value": round(world * args.batch * args.steps / el2, 2),
+                      "unit": "clouds/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                      "how": "InferenceEngine.submit: successive steps on %d HIP streams, same kernels, same results" % lanes}
+
     stage = {}
-    for pr in profiles:
+    for pr in profiles.values():
         for k, v in pr.elapsed_ms().items():
-            stage[k] = stage.get(k, 0.0) + v / args.steps
+            stage[k] = stage.get(k, 0.0) + v / len(profiles)
     conv5_ms = stage["conv5"]
     conv5_flops = (CONV5_ASSIGN_FLOPS if args.arch == "epc-net" else 2.0 * N_POINTS * 128 * 1024) * args.batch
     achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12
@@ -191,7 +227,8 @@ def main():
                                    "(BASELINE.json configs[1])" % (args.arch, args.batch, N_POINTS),
                        "clouds_per_step_per_gpu": args.batch, "num_points": N_POINTS,
                        "weights": "seeded random init of the architecture (no checkpoint payloads exist)",
-                       "parallelism": "independent clouds sharded over %d GPU(s), no data-path collective" % world},
+                       "parallelism": "independent clouds sharded over %d GPU(s), no data-path collective" % world,
+                       "stage_events_on_every_nth_step": every},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "executed_tflops": round(achieved * SPLIT_PRODUCTS[args.arch], 3),
@@ -204,6 +241,8 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
             "pipeline_tflops": round(value / world * FLOPS_PER_CLOUD[args.arch] / 1e12, 3),
         }
+        if overlapped is not None:
+            line["overlapped"] = overlapped
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, store, args.cpu_budget_s, args.cpu_clouds)
         print(json.dumps(line), flush=True)

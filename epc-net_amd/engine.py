@@ -29,8 +29,11 @@ def make_cfg(arch: str, num_points: int, params: Optional[dict], micro_batch: in
 
 class InferenceEngine:
     def __init__(self, arch: str, params: Optional[dict], store: VariableStore, outer: str = "query_triplets",
-                 micro_batch: int = 0, backbone_scope: str = "fastdgcnn"):
+                 micro_batch: int = 0, backbone_scope: str = "fastdgcnn", in_flight: int = 2):
         self.arch = arch
+        self.in_flight = max(1, min(int(in_flight), 8))   # passes kept in flight on separate HIP streams (submit / long calls)
+        self._lanes = None                                 # [(torch.cuda.Stream, workspace tensor or None, last event or None)]
+        self._next_lane = 0
         self.backbone_scope = backbone_scope   # 'BACKBONE' for the KD student (models/kd_epc-net-l.py:44)
         self.params = dict(params or {})
         self.store = store
@@ -96,11 +99,70 @@ class InferenceEngine:
         packed = self.packed(cfg)
         if out is None:
             out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
+        mb = L.micro_batch_of(cfg, nc)
+        if profile is None and self.in_flight > 1 and nc > mb:
+            # several passes: deal them over this stream and the auxiliary lanes (epc_net_forward_overlapped)
+            lanes = min(self.in_flight, (nc + mb - 1) // mb)
+            need = L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), nc) * lanes
+            if self._ws is None or self._ws.numel() < need or self._ws.device != xyz.device:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+            aux = [ln[0] for ln in self._get_lanes(xyz.device)[:lanes - 1]]
+            arr = (ctypes.c_void_p * max(len(aux), 1))(*[a.cuda_stream for a in aux])
+            L.check(L.lib().epc_net_forward_overlapped(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
+                                                       self._ws.data_ptr(), self._ws.numel(), L.current_stream(), arr,
+                                                       len(aux)))
+            return out
         ws = self.workspace(cfg, max(nc, 1), xyz.device)
         L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                  ws.data_ptr(), ws.numel(), L.current_stream(),
                                                  profile.handle if profile is not None else None))
         return out
+
+
+    # ---- throughput mode: independent batches in flight on the engine's own streams ---------------------------
+    def _get_lanes(self, device):
+        if self._lanes is None or self._lanes[0][0].device != device:
+            self._lanes = [[torch.cuda.Stream(device=device), None, None] for _ in range(self.in_flight)]
+        return self._lanes
+
+    def submit(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None, profile: "Optional[StageProfile]" = None):
+        """Asynchronous ``forward``: the batch runs on one of the engine's ``in_flight`` HIP streams (round-robin, own
+        workspace each), ordered after everything already enqueued on the current stream.  Returns ``(out, event)``;
+        ``out`` is valid once ``event`` has completed -- ``event.wait()`` orders the current stream after it,
+        ``drain()`` after every submitted batch.  Batches submitted back to back overlap (the stages of a pass are
+        bound by different units of the chip), which is where the throughput above a single stream comes from."""
+        if xyz.dim() != 3 or xyz.shape[-1] != 3 or xyz.dtype != torch.float32:
+            raise L.EpcNetError(-1, "expected float32 (num_clouds, N, 3) points, got %s %s" % (xyz.dtype, tuple(xyz.shape)))
+        L.require_gpu()
+        xyz = xyz.contiguous()
+        nc, n = int(xyz.shape[0]), int(xyz.shape[1])
+        cfg = make_cfg(self.arch, n, self.params, self.micro_batch)
+        packed = self.packed(cfg)
+        if out is None:
+            out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
+        lanes = self._get_lanes(xyz.device)
+        lane = lanes[self._next_lane % len(lanes)]
+        self._next_lane += 1
+        stream = lane[0]
+        need = L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), max(nc, 1))
+        if lane[1] is None or lane[1].numel() < need:
+            if lane[2] is not None:
+                lane[2].synchronize()            # the lane's previous batch may still be using the old workspace
+            lane[1] = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+        stream.wait_stream(torch.cuda.current_stream(xyz.device))
+        xyz.record_stream(stream)
+        out.record_stream(stream)
+        L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
+                                                 lane[1].data_ptr(), lane[1].numel(), ctypes.c_void_p(stream.cuda_stream),
+                                                 profile.handle if profile is not None else None))
+        lane[2] = stream.record_event()
+        return out, lane[2]
+
+    def drain(self) -> None:
+        """Order the current stream after every batch submitted so far."""
+        for lane in self._lanes or []:
+            if lane[2] is not None:
+                lane[2].wait()
 
 
 class StageProfile:

@@ -80,6 +80,16 @@ size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds);
 int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Throughput form of epc_net_forward for num_clouds > micro_batch: successive passes (micro_batch clouds each) are
+ * dealt round-robin over `stream` and `num_aux` (0..7) auxiliary streams of the caller, so that the passes' stages --
+ * bound by different units of the chip: kNN by VALU issue, conv5 by the MFMA pipe, the VLAD aggregate by HBM --
+ * overlap.  Same results as epc_net_forward (passes are independent: evaluate.py:351-452 extracts one cloud per
+ * sess.run).  Stream-ordered on `stream`: the auxiliary streams are made to wait for it before the first launch and
+ * it waits for them at the end.  workspace_bytes >= min(passes, 1 + num_aux) * epc_net_workspace_bytes(cfg, n). */
+int epc_net_forward_overlapped(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
+                               void* workspace, size_t workspace_bytes, void* stream, void* const* aux_streams,
+                               int num_aux);
+
 /* Stage profile: same launches as epc_net_forward, plus HIP events recorded on `stream` at the stage boundaries
  * (measurement only; SURVEY.md 5 "tracing": the reference wraps sess.run in RunOptions(FULL_TRACE),
  * evaluate.py:275,385-390).  One profile covers one pass (num_clouds <= micro_batch).  Read the per-stage

@@ -10,11 +10,11 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-args="bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+args="bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1"
 python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err"        # the un-profiled line: bench.py's own defaults
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $root/$args > "$out/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$out/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 > "$out/pmc_write.log" 2>&1
 cd "$root"
 python3 scripts/summarise_profiles.py "$tag"

@@ -5,7 +5,8 @@ P = ctypes.c_void_p
 lib.epc_knn_topk.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, P, P, P]
 lib.epc_morton_sort.argtypes = [P, ctypes.c_int, ctypes.c_int, P, P, P]
 dev = torch.device("cuda:0")
-B, N = 64, 4096
+import os
+B, N = int(os.environ.get("BATCH", "64")), 4096
 for kind in ("uniform", "unsorted"):
     g = torch.Generator().manual_seed(0)
     xyz = (torch.rand((B, N, 3), generator=g) * 2 - 1).to(dev)
@@ -25,7 +26,7 @@ for kind in ("uniform", "unsorted"):
     for _ in range(10):
         lib.epc_knn_topk(srt.data_ptr(), B, N, 32, idx.data_ptr(), cnt.data_ptr(), kth.data_ptr(), st)
     e1.record(); torch.cuda.synchronize()
-    print("%-24s %-9s %.3f ms / 64 clouds   (cnt sum %d)" % (sys.argv[2], kind, e0.elapsed_time(e1) / 10, int(cnt.sum())))
+    print("%-24s %-9s %.3f ms / %d clouds   (cnt sum %d)" % (sys.argv[2], kind, e0.elapsed_time(e1) / 10, B, int(cnt.sum())))
     if hasattr(lib, "epc_debug_knn_stats"):
         st8 = (ctypes.c_ulonglong * 8)()
         lib.epc_debug_knn_stats(st8, 1)

@@ -3,6 +3,8 @@
 Bars: bit-exact for the kNN graph (integer / selection work); descriptor L2 error <= 1e-4 in fp32
 (BASELINE.json north_star) -- measured error is ~1e-6, the fp32-vs-fp64 budget of the oracle itself is ~2e-7.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -207,6 +209,50 @@ def test_micro_batching_is_invisible(dev):
     a = H.make_engine("epc-net", w, dev)[0].forward(pc).cpu()
     b = H.make_engine("epc-net", w, dev, micro_batch=2)[0].forward(pc).cpu()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
+def test_overlapped_passes_and_submit_match_single_stream(dev, arch):
+    """epc_net_forward_overlapped (passes dealt over several HIP streams) and InferenceEngine.submit (independent
+    batches in flight) return bit-identical descriptors to the one-stream path."""
+    E = H.pkg("engine")
+    w = O.seeded_weights(arch, 0)
+    pc = torch.from_numpy(O.synthetic_clouds(7, 256, 3)).to(dev)
+    st = H.make_store(arch, w, dev)
+    serial = E.InferenceEngine(arch, H.PARAMS, st, outer=H.OUTER, micro_batch=2, in_flight=1).forward(pc)
+    for lanes in (2, 3, 8):
+        eng = E.InferenceEngine(arch, H.PARAMS, st, outer=H.OUTER, micro_batch=2, in_flight=lanes)
+        for _ in range(2):                                  # second call: lanes and workspace are reused
+            assert torch.equal(eng.forward(pc), serial)
+    eng = E.InferenceEngine(arch, H.PARAMS, st, outer=H.OUTER, in_flight=2)
+    pending = [eng.submit(pc[i:i + 2]) for i in range(0, 6, 2)] + [eng.submit(pc[6:7])]
+    eng.drain()
+    got = torch.cat([o for o, _ in pending])
+    assert torch.equal(got, serial)
+    o, ev = eng.submit(pc[:3])
+    ev.synchronize()
+    assert torch.equal(o, serial[:3])
+
+
+def test_overlapped_rejects_short_workspace(dev):
+    L = H.pkg("lib")
+    E = H.pkg("engine")
+    eng, _ = H.make_engine("epc-net", O.seeded_weights("epc-net", 0), dev, micro_batch=2)
+    cfg = E.make_cfg("epc-net", 64, H.PARAMS, 2)
+    packed = eng.packed(cfg)
+    one = L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 4)
+    ws = torch.empty(one, dtype=torch.uint8, device=dev)       # two lanes need 2 x one
+    xyz = torch.zeros((4, 64, 3), device=dev)
+    out = torch.empty((4, 256), device=dev)
+    aux = torch.cuda.Stream()
+    arr = (ctypes.c_void_p * 1)(aux.cuda_stream)
+    rc = L.lib().epc_net_forward_overlapped(ctypes.byref(cfg), packed.data_ptr(), xyz.data_ptr(), 4, out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), L.current_stream(), arr, 1)
+    assert rc == -2 and b"lanes" in L.lib().epc_last_error()
+    rc = L.lib().epc_net_forward_overlapped(ctypes.byref(cfg), packed.data_ptr(), xyz.data_ptr(), 4, out.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), L.current_stream(), None, 0)
+    assert rc == 0                                              # no auxiliary streams: plain serial passes
+    torch.cuda.synchronize()
 
 
 def test_permutation_invariance(dev):
