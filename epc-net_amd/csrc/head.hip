@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict
     const float* a1p = U + (size_t)min(r1, rows - 1) * kh + k0 + 4 * h;
     const float z0 = r0 < rows ? 1.f : 0.f, z1 = r1 < rows ? 1.f : 0.f;
     const float* bp = H + (size_t)(k0 + 4 * h) * 256 + nb + j;
-#pragma unroll 4
+#pragma unroll 8
     for (int q = 0; q < 32; ++q) {
         const float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * q);
         const float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * q);
@@ -132,64 +132,77 @@ __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict
 }
 
 // ---- H3: sum slices, BN (folded, summed over groups), context gating, final L2 -------------------------------
-__global__ __launch_bounds__(256) void head_finish_kernel(const float* __restrict__ Yp, int slices, int rows,
-                                                          const float* __restrict__ hp, int groups,
-                                                          float* __restrict__ out) {
+// 1024 threads per cloud: thread (c = tid & 255, part = tid >> 8) takes a quarter of the slice sum and a quarter of the
+// 256-long gating dot product, so a thread's chain of dependent L2 round trips is 4 + 4 deep instead of 8 + 32 (the
+// kernel has one workgroup per cloud: it is latency, not bandwidth, that it pays for).
+__global__ __launch_bounds__(1024) void head_finish_kernel(const float* __restrict__ Yp, int slices, int rows,
+                                                           const float* __restrict__ hp, int groups,
+                                                           float* __restrict__ out) {
+    __shared__ float part_y[4][256];
     __shared__ float v[256];
     __shared__ float red[4];
-    const int cloud = blockIdx.x, c = threadIdx.x;
+    const int cloud = blockIdx.x, c = threadIdx.x & 255, part = threadIdx.x >> 8;
     const float* bn_s = hp;
     const float* bn_t = hp + 256;
     const float* Wg = hp + 512;
     const float* g_s = Wg + 65536;
     const float* g_t = g_s + 256;
-    // (8 independent loads in flight per thread: the slice loop is otherwise a chain of `slices` exposed L2 latencies)
+    // slices part, part + 4, ...: 8 independent loads in flight per thread
     float y = 0.f;
-    int s = 0;
-    for (; s + 8 <= slices; s += 8) {
+    int s = part;
+    for (; s + 28 < slices; s += 32) {
         float t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = Yp[((size_t)(s + u) * rows + cloud) * 256 + c];
+        for (int u = 0; u < 8; ++u) t[u] = Yp[((size_t)(s + 4 * u) * rows + cloud) * 256 + c];
 #pragma unroll
         for (int u = 0; u < 8; ++u) y += t[u];
     }
-    for (; s < slices; ++s) y += Yp[((size_t)s * rows + cloud) * 256 + c];
-    const float val = y * bn_s[c] + (float)groups * bn_t[c];
-    v[c] = val;
+    for (; s < slices; s += 4) y += Yp[((size_t)s * rows + cloud) * 256 + c];
+    part_y[part][c] = y;
+    __syncthreads();
+    const float val = ((part_y[0][c] + part_y[1][c]) + (part_y[2][c] + part_y[3][c])) * bn_s[c] + (float)groups * bn_t[c];
+    if (part == 0) v[c] = val;
     __syncthreads();
     float g = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 256; ++k) g += v[k] * Wg[k * 256 + c];
+#pragma unroll 16
+    for (int k = 64 * part; k < 64 * part + 64; ++k) g += v[k] * Wg[k * 256 + c];
+    part_y[part][c] = g;
+    __syncthreads();
+    g = (part_y[0][c] + part_y[1][c]) + (part_y[2][c] + part_y[3][c]);
     g = g * g_s[c] + g_t[c];
     const float o = val * (1.0f / (1.0f + expf(-g)));
     float ss = o * o;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if ((c & 63) == 0) red[c >> 6] = ss;
+    if (part == 0 && (c & 63) == 0) red[c >> 6] = ss;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    out[(size_t)cloud * 256 + c] = o * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+    if (part == 0) out[(size_t)cloud * 256 + c] = o * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
 }
 
 // ---- EPC-Net-L head: fc1 (1024->256, folded BN) + ReLU + L2.  packed: [Wf 1024*256][bf 256] ------------------
-__global__ __launch_bounds__(256) void fc_head_kernel(const float* __restrict__ pooled,
-                                                      const float* __restrict__ pack, float* __restrict__ out) {
+// 1024 threads per cloud: thread (c, part) takes a quarter of the 1024-long dot product (see head_finish_kernel).
+__global__ __launch_bounds__(1024) void fc_head_kernel(const float* __restrict__ pooled,
+                                                       const float* __restrict__ pack, float* __restrict__ out) {
     __shared__ float m[1024];
+    __shared__ float part_y[4][256];
     __shared__ float red[4];
-    const int cloud = blockIdx.x, c = threadIdx.x;
-    for (int o = c; o < 1024; o += 256) m[o] = pooled[(size_t)cloud * 1024 + o];
+    const int cloud = blockIdx.x, c = threadIdx.x & 255, part = threadIdx.x >> 8;
+    m[threadIdx.x] = pooled[(size_t)cloud * 1024 + threadIdx.x];
     __syncthreads();
     float y = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < 1024; ++k) y += m[k] * pack[k * 256 + c];
-    y = fmaxf(y + pack[1024 * 256 + c], 0.f);
+#pragma unroll 16
+    for (int k = 256 * part; k < 256 * part + 256; ++k) y += m[k] * pack[k * 256 + c];
+    part_y[part][c] = y;
+    __syncthreads();
+    y = fmaxf(((part_y[0][c] + part_y[1][c]) + (part_y[2][c] + part_y[3][c])) + pack[1024 * 256 + c], 0.f);
     float ss = y * y;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if ((c & 63) == 0) red[c >> 6] = ss;
+    if (part == 0 && (c & 63) == 0) red[c >> 6] = ss;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    out[(size_t)cloud * 256 + c] = y * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+    if (part == 0) out[(size_t)cloud * 256 + c] = y * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -250,7 +263,7 @@ extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int spl
     hipLaunchKernelGGL(hidden_gemm_kernel, dim3(8, slices, (num_clouds + 63) / 64), dim3(64), 0, st, U, Hw,
                        num_clouds, kh, Yp);
     EPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_finish_kernel, dim3(num_clouds), dim3(256), 0, st, Yp, slices, num_clouds, tail,
+    hipLaunchKernelGGL(head_finish_kernel, dim3(num_clouds), dim3(1024), 0, st, Yp, slices, num_clouds, tail,
                        groups, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -261,7 +274,7 @@ extern "C" int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int n
     EPC_CHECK_ARG(pooled && packed_fc && out, "null pointer");
     EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
     if (num_clouds == 0) return EPC_OK;
-    hipLaunchKernelGGL(fc_head_kernel, dim3(num_clouds), dim3(256), 0, (hipStream_t)stream, pooled,
+    hipLaunchKernelGGL(fc_head_kernel, dim3(num_clouds), dim3(1024), 0, (hipStream_t)stream, pooled,
                        (const float*)packed_fc, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
