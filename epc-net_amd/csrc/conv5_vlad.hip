@@ -223,6 +223,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 // twice the bf16 rate (v_mfma_scale_f32_32x32x64_f8f6f4; E8M0 scales 2^-12 and 2^0) -- the lo term is a
                 // 2^-11 correction, so 3 mantissa bits on each side keep it to 2^-14 of the product
                 const float* wl = w5 + L::W5_LO8;
+#ifndef CONV5_ABL_NO_LO
 #pragma unroll
                 for (int ks = 0; ks < CIN / 64; ++ks) {
                     const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + (ks * 64 + lane) * 8);
@@ -230,8 +231,13 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                     i32x8 wl8;
                     wl8[0] = (int)l0[0], wl8[1] = (int)l0[1], wl8[2] = (int)l0[2], wl8[3] = (int)l0[3];
                     wl8[4] = (int)l1[0], wl8[5] = (int)l1[1], wl8[6] = (int)l1[2], wl8[7] = (int)l1[3];
+#ifdef CONV5_ABL_FP4_TIMING   // timing only (wrong numerics): the same instruction with both operands declared fp4
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8, x8[ks], acc, 4, 4, 0, 127 - W5_LO_SHIFT, 0, 127);
+#else
                     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8, x8[ks], acc, 0, 0, 0, 127 - W5_LO_SHIFT, 0, 127);
+#endif
                 }
+#endif
             }
             // fragment reads run one k-step ahead of the MFMAs that consume them
             f16x8 fa[2][2];
