@@ -12,12 +12,12 @@ SURVEY.md 8e) -> weak scaling; value = clouds all ranks processed / max-over-ran
 
 Extra objects on the JSON line:
   roofline     dominant kernel = conv5 + L2 + soft-assignment (conv5_kernel<256,VLAD>), bound = MFMA.  It runs on the
-               half-precision MFMA in split arithmetic (one fp16 value per activation; weights as fp16 hi + fp8 lo, the
-               lo product on the K=64 scaled fp8 MFMA; f32 accumulate; descriptor error 1.5e-6 against the f32 oracle), so it is priced against the dense
+               half-precision MFMA in split arithmetic (one fp16 value per activation; weights as fp16 hi + MX-fp6 lo, the
+               lo product on the K=64 scaled f8f6f4 MFMA; f32 accumulate; descriptor error 1.5e-6 against the f32 oracle), so it is priced against the dense
                bf16/fp16 peak (2.5 PFLOP/s): achieved = ALGORITHMIC FLOPs per launch (2.684 GFLOP per cloud,
                DESIGN.md) / its average duration, measured with HIP events recorded by the library on the launch
-               stream inside the timed region (on every --profile-every-th step); the matrix pipe executes 1.4x that
-               in bf16-rate units (frac is capped at 0.71).
+               stream inside the timed region (on every --profile-every-th step); the matrix pipe executes 1.2x that
+               in bf16-rate units (frac is capped at 0.83).
   overlapped   a second timed region after the first: the same K steps with --in-flight (2) of them in flight on the
                engine's HIP streams (InferenceEngine.submit).  Reported beside `value`, never as `value`: kernels that
                share the chip take longer individually, so the roofline figures belong to the one-stream region.
@@ -46,13 +46,13 @@ CONV5_ASSIGN_FLOPS = 2.0 * N_POINTS * 256 * 1024 + 2.0 * N_POINTS * 1024 * 64
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16 MFMA (the 5 PF headline includes 2:1 sparsity)
 # Matrix-pipe work of the dominant kernel in units of one bf16/fp16 MFMA product per algorithmic product: conv5 = fp16
-# hi product (1) + fp8 lo product on the K=64 scaled MFMA, which runs at twice the bf16 rate (0.5); assignment = 1
-# (single-fp16 cluster weights): (1.5 x 2147.5 + 536.9) / 2684.4 = 1.4, so `frac` (algorithmic / half-precision peak) is
-# capped at 0.71.  (EPC-Net-L's conv5 feeds a max-pool and stays on the 3-product split-bf16 form.)
-SPLIT_PRODUCTS = {"epc-net": 1.4, "epc-net-l": 3}
+# hi product (1) + MX-fp6 lo product on the K=64 scaled MFMA, which runs at four times the bf16 rate (0.25); assignment = 1
+# (single-fp16 cluster weights): (1.25 x 2147.5 + 536.9) / 2684.4 = 1.2, so `frac` (algorithmic / half-precision peak) is
+# capped at 0.83.  (EPC-Net-L's conv5 feeds a max-pool and stays on the 3-product split-bf16 form.)
+SPLIT_PRODUCTS = {"epc-net": 1.2, "epc-net-l": 3}
 FLOPS_PER_CLOUD = {"epc-net": 3.747e9, "epc-net-l": 1.355e9}
 # arithmetic of the dominant kernel (not a precision claim: results are f32-accurate, tests/test_gpu_parity.py)
-DTYPE = {"epc-net": "f16+f8", "epc-net-l": "bf16x3"}
+DTYPE = {"epc-net": "f16+f6", "epc-net-l": "bf16x3"}
 
 
 def pkg(name=""):

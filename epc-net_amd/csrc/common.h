@@ -51,18 +51,27 @@ __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
 // product and the cloud's points: measured descriptor error 1e-6; a weight rounded to one fp16 would be a
 // systematic error (2e-5) -- hence the split on the weight side.
 #define W5_SCALE 256.0f
-// lo parts of the conv5 weights as fp8 e4m3: (W * W5_SCALE - hi) * 2^W5_LO_SHIFT (lo <= 2^-6 for |W * W5_SCALE| < 64, so the
-// shifted value stays below 64, far inside e4m3's range); the MFMA's E8M0 scale operand removes the shift.
-#define W5_LO_SHIFT 12
+// lo parts of the conv5 weights as MX fp6 (e2m3): lo = W * W5_SCALE - hi is stored per (output channel, block of 32 input
+// channels) as 32 six-bit values q with one E8M0 block scale, lo ~ q * 2^e, |q| <= 7.5.  The lo term is a 2^-11
+// correction, so e2m3's 4 significant bits keep it to 2^-15 of the product -- as good as the fp8 e4m3 form it replaced --
+// while v_mfma_scale_f32_32x32x64_f8f6f4 runs fp6 operands in 8 passes instead of fp8's 16.  Operand facts pinned by
+// scripts/probe/mfma_fp6_probe.hip: lane l supplies row / column l & 31 and k = 32 * (l >> 5) + j, value j in bits
+// [6j, 6j + 6) of the lane's six dwords; each lane passes its own scale byte (2^(byte - 127)), the byte of the scale
+// dword is picked by op_sel.  Six dwords per lane per 64-wide k-step, kept in LDS as 16 B + 8 B pieces.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-// four f32 -> four fp8 e4m3 bytes (v_cvt_pk_fp8_f32, round to nearest even, saturating), element 0 in the low byte
-__device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+#define FP6_MAX 7.5f
+// exponent e (clamped to [lo_e, hi_e]) with m * 2^-e <= 7.5 and > 3.75 when not clamped: e = ceil(log2(m / 7.5))
+__device__ __forceinline__ int fp6_block_exponent(float m, int lo_e, int hi_e) {
+    const int bits = __float_as_int(m * (1.0f / FP6_MAX));
+    const int e = ((bits >> 23) & 0xff) - 127 + ((bits & 0x7fffff) ? 1 : 0);
+    return min(max(e, lo_e), hi_e);
 }
+__device__ __forceinline__ float exp2i(int e) { return __int_as_float((127 + e) << 23); }   // 2^e, -126 <= e <= 127
+
 // scale of the fp16 assignment fragments between epc_conv5_assign_fwd and epc_vlad_aggregate_fwd (exact power of two)
 #define AGG_ASSIGN_SCALE 16384.0f
-
 // Split-bf16 ("bf16x3") arithmetic: x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi);
 // a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, accumulated in f32 by the MFMA.  Measured on the whole network this
 // keeps the descriptor within 4e-7 of the f32 oracle (plain bf16: 1.7e-4, over the 1e-4 budget) -- DESIGN.md 4.

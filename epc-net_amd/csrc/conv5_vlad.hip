@@ -42,12 +42,15 @@ __device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_
                  : "memory");
 }
 
-// F8LO (EPC-Net): per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][fp8 lo fragments:
-// CIN/64 k-steps x 2 KB] = 96*CIN bytes; otherwise (EPC-Net-L) bf16 hi and lo fragments interleaved per k-step: 128*CIN bytes.
+// F8LO (EPC-Net): per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][MX fp6 lo fragments:
+// CIN/64 k-steps x (1 KB + 512 B), then 256 B of block scales; pack.hip pack_conv5_lo6_kernel] inside 96*CIN bytes;
+// otherwise (EPC-Net-L) bf16 hi and lo fragments interleaved per k-step: 128*CIN bytes.
 template <int CIN, bool F8LO>
 struct C5Lds {  // offsets in floats (4 B)
     static constexpr int W5_CHUNK = F8LO ? 24 * CIN : 32 * CIN;
-    static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp8 fragments inside a chunk
+    static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp6 lo fragments inside a chunk
+    static constexpr int LO6_KS = 384;         // floats per k-step of lo fragments (1 KB of 16-B pieces + 512 B of 8-B pieces)
+    static constexpr int W5_LOSC = W5_LO8 + (CIN / 64) * LO6_KS;   // the block-scale dwords (one per lane)
     static constexpr int WC_CHUNK = 1024;      // 32 ch x 64 clusters x 2 B (ONE fp16 per cluster weight, see the epilogue)
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
@@ -121,7 +124,25 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     constexpr bool kF16 = MODE == MODE_VLAD;
     constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
     f16x8 xf[kF16 ? STEPS : 1];
-    i32x8 x8[kF16 ? CIN / 64 : 1];   // the same inputs as fp8 e4m3 (B operand of the lo-term MFMA: 32 consecutive channels)
+    // the same inputs as MX fp6 (B operand of the lo-term MFMA): per 64-wide k-step the lane's 32 consecutive channels
+    // 64ks + 32h .. +31 in six dwords, their block scale in byte ks of xsc
+    i32x6 x6[kF16 ? CIN / 64 : 1];
+    int xsc = 0;
+    auto to_fp6 = [&](f16x32 v, int ks) {
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+        const u32x16 w = __builtin_bit_cast(u32x16, v);
+        u16x2 m2 = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)   // |fp16| orders like its bit pattern: packed 16-bit max
+            m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, w[i] & 0x7fff7fffu));
+        const unsigned short mb = m2[0] > m2[1] ? m2[0] : m2[1];
+        const float m = (float)__builtin_bit_cast(_Float16, mb);
+        const int e = fp6_block_exponent(m, -12, 14);          // 2^-e stays an fp16 normal: the scaling below is exact
+        const _Float16 down = (_Float16)exp2i(-e);
+        x6[ks] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v * down, 1.0f);
+        xsc |= (127 + e) << (8 * ks);
+    };
     bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
     if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
         static_assert(!CAT16 || MODE == MODE_VLAD, "fp16 input only feeds the fp16 arithmetic");
@@ -135,14 +156,15 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         if constexpr (kF16) {
 #pragma unroll
             for (int ks = 0; ks < CIN / 64; ++ks) {   // channels 64ks + 32h .. +31 of the lane's point
+                typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+                u32x16 w16;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     u32x4 w = *reinterpret_cast<const u32x4*>(row + 64 * ks + 24 * h + 8 * q4);   // row already holds +8h
                     if (!active) w = u32x4{0u, 0u, 0u, 0u};
-                    const f16x8 hv = __builtin_bit_cast(f16x8, w);
-                    x8[ks][2 * q4] = pack_fp8x4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
-                    x8[ks][2 * q4 + 1] = pack_fp8x4((float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]);
+                    w16[4 * q4] = w[0], w16[4 * q4 + 1] = w[1], w16[4 * q4 + 2] = w[2], w16[4 * q4 + 3] = w[3];
                 }
+                to_fp6(__builtin_bit_cast(f16x32, w16), ks);
             }
         }
     } else {
@@ -163,13 +185,16 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         if constexpr (kF16) {
             const float* row0 = row - 8 * h;   // channel 0 of the lane's point
 #pragma unroll
-            for (int ks = 0; ks < CIN / 64; ++ks)
+            for (int ks = 0; ks < CIN / 64; ++ks) {
+                f16x32 v;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) {
                     const float4 a = active ? ld4(row0 + 64 * ks + 32 * h + 4 * w8) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    // (round through fp16 first: the fp8 copy must describe the same input the hi term sees)
-                    x8[ks][w8] = pack_fp8x4((float)(_Float16)a.x, (float)(_Float16)a.y, (float)(_Float16)a.z, (float)(_Float16)a.w);
+                    // (through fp16: the fp6 copy must describe the same input the hi term sees)
+                    v[4 * w8] = (_Float16)a.x, v[4 * w8 + 1] = (_Float16)a.y, v[4 * w8 + 2] = (_Float16)a.z, v[4 * w8 + 3] = (_Float16)a.w;
                 }
+                to_fp6(v, ks);
+            }
         }
     }
 
@@ -219,24 +244,27 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
         {
             if constexpr (kF16) {
-                // lo term first (small): W_lo as fp8 x 2^12 against the fp8 copy of the inputs, K = 64 per instruction at
-                // twice the bf16 rate (v_mfma_scale_f32_32x32x64_f8f6f4; E8M0 scales 2^-12 and 2^0) -- the lo term is a
-                // 2^-11 correction, so 3 mantissa bits on each side keep it to 2^-14 of the product
+                // lo term first (small): W_lo and the inputs as MX fp6, K = 64 per instruction in 8 passes (the fp16 K = 16
+                // instruction takes 8 as well) -- the lo term is a 2^-11 correction, so 4 significant bits on each side keep it
+                // to 2^-15 of the product.  Block scales: byte ks of the lanes' scale dwords (op_sel).
                 const float* wl = w5 + L::W5_LO8;
 #ifndef CONV5_ABL_NO_LO
-#pragma unroll
-                for (int ks = 0; ks < CIN / 64; ++ks) {
-                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + (ks * 64 + lane) * 8);
-                    const u32x4 l1 = *reinterpret_cast<const u32x4*>(wl + (ks * 64 + lane) * 8 + 4);
-                    i32x8 wl8;
-                    wl8[0] = (int)l0[0], wl8[1] = (int)l0[1], wl8[2] = (int)l0[2], wl8[3] = (int)l0[3];
-                    wl8[4] = (int)l1[0], wl8[5] = (int)l1[1], wl8[6] = (int)l1[2], wl8[7] = (int)l1[3];
-#ifdef CONV5_ABL_FP4_TIMING   // timing only (wrong numerics): the same instruction with both operands declared fp4
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8, x8[ks], acc, 4, 4, 0, 127 - W5_LO_SHIFT, 0, 127);
-#else
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wl8, x8[ks], acc, 0, 0, 0, 127 - W5_LO_SHIFT, 0, 127);
-#endif
-                }
+                const int wsc = __float_as_int(w5[L::W5_LOSC + lane]);
+                auto lo_step = [&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value;
+                    if constexpr (ks < CIN / 64) {
+                        const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + ks * L::LO6_KS + lane * 4);
+                        const uint2 l1 = *reinterpret_cast<const uint2*>(wl + ks * L::LO6_KS + 256 + lane * 2);
+                        const i32x8 a = {(int)l0[0], (int)l0[1], (int)l0[2], (int)l0[3], (int)l1.x, (int)l1.y, 0, 0};
+                        const i32x8 b = {x6[ks][0], x6[ks][1], x6[ks][2], x6[ks][3], x6[ks][4], x6[ks][5], 0, 0};
+                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 2, 2, ks, wsc, ks, xsc);
+                    }
+                };
+                lo_step(std::integral_constant<int, 0>{});
+                lo_step(std::integral_constant<int, 1>{});
+                lo_step(std::integral_constant<int, 2>{});
+                lo_step(std::integral_constant<int, 3>{});
+                static_assert(CIN / 64 <= 4, "one scale dword holds four block scales");
 #endif
             }
             // fragment reads run one k-step ahead of the MFMAs that consume them

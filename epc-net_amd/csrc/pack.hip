@@ -80,7 +80,7 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
 
 // conv5 weights as fragments (layout + arithmetic: common.h, conv5_vlad.hip C5Lds).  One thread per (chunk, k, channel).
 // f16 = 1 (EPC-Net: conv5 feeds the VLAD aggregation): per chunk [fp16 hi of W * W5_SCALE: k-step s (16 k), lane, 8]
-//         then [fp8 e4m3 of (W * W5_SCALE - hi) * 2^W5_LO_SHIFT: k-step ks (64 k), lane, 32]; bias scaled by W5_SCALE.
+//         then the MX fp6 lo fragments written by pack_conv5_lo6_kernel; bias scaled by W5_SCALE.
 // f16 = 0 (EPC-Net-L: conv5 feeds the global max-pool): bf16 hi and lo fragments interleaved per k-step (bf16x3 form).
 __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -98,12 +98,6 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
             const _Float16 h = (_Float16)w;
             const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
             dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
-            // the same weight's lo part sits in k-step ks = k / 64 of the fp8 fragments: lane' = col-lane + 32 * ((k % 64) / 32),
-            // byte (k % 32)
-            const float lo = (w - (float)h) * (float)(1 << W5_LO_SHIFT);
-            const int ks = k >> 6, lane8 = (lane & 31) + 32 * ((k & 63) >> 5), byte = k & 31;
-            unsigned char* lo8 = reinterpret_cast<unsigned char*>(dstW + (size_t)c * chunk_halfs + (size_t)16 * cin * 2);
-            lo8[(size_t)ks * 2048 + lane8 * 32 + byte] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(lo, 0.0f, 0, false) & 0xff);
         } else {
             const unsigned short hi = bf16_bits_rne(w);
             const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
@@ -116,6 +110,41 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
         const float inv = bn_inv(gamma, var, o);
         dstB[o] = (b[o] * inv + (beta[o] - mean[o] * inv)) * scale;
     }
+}
+
+// lo parts of the EPC-Net conv5 weights as MX fp6 (common.h): one thread per (chunk c, 64-wide k-step ks, lane l) = the 32
+// weights W[64ks + 32(l>>5) + j][32c + (l&31)], j < 32, that lane l feeds to the lo-term MFMA of that k-step.  Inside a
+// chunk (byte offsets from the start of the lo area, 64*cin bytes into the chunk):
+//   k-step ks: [lane][16 B: dwords 0-3] at 1536 ks, [lane][8 B: dwords 4-5] at 1536 ks + 1024;
+//   block scales: [lane][4 B: byte ks = 127 + e] at 1536 * (cin / 64).
+__global__ void pack_conv5_lo6_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                      const float* __restrict__ var, int cin, unsigned short* __restrict__ dstW) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const int nks = cin / 64;
+    if (o >= 32 * nks * 64) return;
+    const int lane = o & 63, ks = (o >> 6) % nks, c = (o >> 6) / nks;
+    const int col = 32 * c + (lane & 31), k0 = 64 * ks + 32 * (lane >> 5);
+    const float inv = bn_inv(gamma, var, col) * W5_SCALE;
+    float lo[32];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float w = W[(size_t)(k0 + j) * 1024 + col] * inv;   // the same expression fold_pack_conv5_kernel rounds to hi
+        lo[j] = w - (float)(_Float16)w;
+        m = fmaxf(m, fabsf(lo[j]));
+    }
+    const int e = fp6_block_exponent(m, -100, 20);
+    const float down = exp2i(-e);
+    f16x32 q;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) q[j] = (_Float16)(lo[j] * down);   // |q| <= 7.5: exact scaling, then fp16 -> e2m3 below
+    const i32x6 bits = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(q, 1.0f);
+    char* chunk = reinterpret_cast<char*>(dstW) + (size_t)c * 96 * cin + (size_t)64 * cin;   // past the 64*cin bytes of hi fragments
+    int* p0 = reinterpret_cast<int*>(chunk + 1536 * ks + 16 * lane);
+    int* p1 = reinterpret_cast<int*>(chunk + 1536 * ks + 1024 + 8 * lane);
+    p0[0] = bits[0], p0[1] = bits[1], p0[2] = bits[2], p0[3] = bits[3];
+    p1[0] = bits[4], p1[1] = bits[5];
+    reinterpret_cast<unsigned char*>(chunk + 1536 * nks + 4 * lane)[ks] = (unsigned char)(127 + e);
 }
 
 // 64x64 block layer as hi + lo fragments: Wp[tile t (2)][k-step s (4)][part (hi,lo)][lane][8 x 16 bit] + bias.
@@ -293,6 +322,11 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
                        v.mean, v.var, c5in, cfg->arch == EPC_ARCH_EPC_NET ? 1 : 0, (unsigned short*)(P + L.off[5]),
                        P + L.off[5] + (size_t)c5in * 1024);
     EPC_CHECK_LAUNCH();
+    if (cfg->arch == EPC_ARCH_EPC_NET) {
+        hipLaunchKernelGGL(pack_conv5_lo6_kernel, dim3((32 * (c5in / 64) * 64 + 255) / 256), dim3(256), 0, st, v.W, v.gamma,
+                           v.var, c5in, (unsigned short*)(P + L.off[5]));
+        EPC_CHECK_LAUNCH();
+    }
 
     if (cfg->arch == EPC_ARCH_EPC_NET) {
         float* s5 = P + L.off[5] + (size_t)c5in * 1024 + 1024;
