@@ -478,19 +478,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ xy
     const float px = xyz[3 * (size_t)g], py = xyz[3 * (size_t)g + 1], pz = xyz[3 * (size_t)g + 2];
     const float4 w0 = ld4(pack + 4 * q), w1 = ld4(pack + 64 + 4 * q), w2 = ld4(pack + 128 + 4 * q);
     const float4 b = ld4(pack + 192 + 4 * q);
-    float4 y;
-    y.x = fmaxf(((px * w0.x + py * w1.x) + pz * w2.x) + b.x, 0.f);
-    y.y = fmaxf(((px * w0.y + py * w1.y) + pz * w2.y) + b.y, 0.f);
-    y.z = fmaxf(((px * w0.z + py * w1.z) + pz * w2.z) + b.z, 0.f);
-    y.w = fmaxf(((px * w0.w + py * w1.w) + pz * w2.w) + b.w, 0.f);
+    const float4 y = conv1_quad(px, py, pz, w0, w1, w2, b);
     if (x) st4(x + (size_t)g * 64 + 4 * q, y);
-    if (x16) {  // fp16 copy of the rows: block 1's gather source (proxyconv_block_kernel<true>)
-        const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
-        uint2 w;
-        w.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-        w.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
-        reinterpret_cast<uint2*>(x16)[(size_t)g * 16 + q] = w;
-    }
+    if (x16) reinterpret_cast<uint2*>(x16)[(size_t)g * 16 + q] = pack_half4(y);  // fp16 rows: block 1's gather source
 }
 
 extern "C" int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,

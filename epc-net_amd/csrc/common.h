@@ -136,3 +136,22 @@ __host__ __device__ __forceinline__ constexpr size_t layer_pack_floats(int cin, 
 #define EPC_BLOCK_PACK_FLOATS (3 * (64 * 64 + 64))
 // conv1 pack: Wf[3][64] + bf[64]
 #define EPC_CONV1_PACK_FLOATS (3 * 64 + 64)
+// conv1 (models/epc-net.py:66-69: 3 -> 64, folded BN, ReLU) for four consecutive output channels of one point; ONE
+// definition shared by conv1_kernel (block.hip) and the fused form inside the kNN kernel (knn.hip), so both round alike.
+__device__ __forceinline__ float4 conv1_quad(float px, float py, float pz, const float4& w0, const float4& w1,
+                                             const float4& w2, const float4& b) {
+    float4 y;
+    y.x = fmaxf(((px * w0.x + py * w1.x) + pz * w2.x) + b.x, 0.f);
+    y.y = fmaxf(((px * w0.y + py * w1.y) + pz * w2.y) + b.y, 0.f);
+    y.z = fmaxf(((px * w0.z + py * w1.z) + pz * w2.z) + b.z, 0.f);
+    y.w = fmaxf(((px * w0.w + py * w1.w) + pz * w2.w) + b.w, 0.f);
+    return y;
+}
+// the four channels as fp16, packed for an 8-byte store (the fp16 row layout of EPC-Net's block chain)
+__device__ __forceinline__ uint2 pack_half4(const float4& y) {
+    const _Float16 h0 = (_Float16)y.x, h1 = (_Float16)y.y, h2 = (_Float16)y.z, h3 = (_Float16)y.w;
+    uint2 w;
+    w.x = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    w.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
+    return w;
+}

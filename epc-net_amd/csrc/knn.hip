@@ -98,11 +98,17 @@ extern "C" int epc_debug_knn_stats(unsigned long long* host_out, int reset) {
 #define KSTAT(i) do { } while (0)
 #endif
 
-template <int KSEL>
+// CONV1: the workgroup also produces conv1 (3 -> 64, models/epc-net.py:66-69) of its own KNN_THREADS points from the
+// cloud image it has just put in LDS -- 16 lanes x 4 channels per point, whole rows per store like conv1_kernel, ~1.5 %
+// more VALU work for this kernel instead of a separate 15-us launch that re-reads the cloud.
+template <int KSEL, bool CONV1>
 __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const float* __restrict__ xyz, int n, int cap,
                                                                       int32_t* __restrict__ idx,
                                                                       int32_t* __restrict__ cnt,
-                                                                      float* __restrict__ kth_out) {
+                                                                      float* __restrict__ kth_out,
+                                                                      const float* __restrict__ conv1_pack,
+                                                                      float* __restrict__ x32,
+                                                                      unsigned short* __restrict__ x16) {
     extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, then 2 float4 per tile (lo, hi)
     const int ntiles = (n + KNN_CT - 1) / KNN_CT;
     const int npad = ntiles * KNN_CT;
@@ -126,6 +132,23 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         cand[j] = v;
     }
     __syncthreads();
+    if constexpr (CONV1) {
+        const int q = tid & 15;   // KNN_THREADS is a multiple of 16: a thread keeps its channel quad
+        const float4 w0 = *reinterpret_cast<const float4*>(conv1_pack + 4 * q);
+        const float4 w1 = *reinterpret_cast<const float4*>(conv1_pack + 64 + 4 * q);
+        const float4 w2 = *reinterpret_cast<const float4*>(conv1_pack + 128 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(conv1_pack + 192 + 4 * q);
+        const int p0 = blockIdx.x * KNN_THREADS;
+        const int np = min(KNN_THREADS, n - p0);
+        for (int t = tid; t < np * 16; t += KNN_THREADS) {
+            const int g = p0 + (t >> 4);
+            const float4 pt = cand[g];
+            const float4 y = conv1_quad(pt.x, pt.y, pt.z, w0, w1, w2, b);
+            const size_t row = (size_t)cloud * n + g;
+            if (x32) *reinterpret_cast<float4*>(x32 + row * 64 + 4 * q) = y;
+            if (x16) reinterpret_cast<uint2*>(x16)[row * 16 + q] = pack_half4(y);
+        }
+    }
     // tile bounding boxes: KNN_CT lanes per tile, shuffle min/max
     for (int t = wave * (64 / KNN_CT) + lane / KNN_CT; t < ntiles; t += KNN_WAVES * (64 / KNN_CT)) {
         const float4 v = cand[t * KNN_CT + (lane % KNN_CT)];
@@ -375,6 +398,34 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
     mask[((size_t)cloud * n + i) * n + j] = (a >= kth[(size_t)cloud * n + i]) ? 1.0f : 0.0f;
 }
 
+static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
+                      const float* conv1_pack, float* x32, void* x16, void* stream, const char* who) {
+    dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
+    if (n <= KNN_LDS_MAX_N) {
+        const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +
+                                 (size_t)KNN_WAVES * KNN_MASK_WORDS * sizeof(unsigned int);
+        const void* fn = conv1_pack ? reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT, true>)
+                                    : reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+            return EPC_EHIP;
+        }
+        if (conv1_pack)
+            hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, true>), grid, dim3(KNN_THREADS), lds_bytes,
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16);
+        else
+            hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, false>), grid, dim3(KNN_THREADS), lds_bytes,
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr);
+    } else {
+        hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
+                           xyz, n, cap, idx, cnt, kth);
+    }
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
 extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt,
                             float* kth, void* stream) {
     EPC_CHECK_ARG(xyz && idx && cnt && kth, "null pointer");
@@ -382,25 +433,22 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
                   "need num_points >= 20 (tf.nn.top_k k=20)");
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
-    dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
-    if (n <= KNN_LDS_MAX_N) {
-        const int ntiles = (n + KNN_CT - 1) / KNN_CT;
-        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +
-                                 (size_t)KNN_WAVES * KNN_MASK_WORDS * sizeof(unsigned int);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) {
-            epc_set_error("epc_knn_topk: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return EPC_EHIP;
-        }
-        hipLaunchKernelGGL(knn_topk_culled_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), lds_bytes,
-                           (hipStream_t)stream, xyz, n, cap, idx, cnt, kth);
-    } else {
-        hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
-                           xyz, n, cap, idx, cnt, kth);
+    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, stream, __func__);
+}
+
+extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt,
+                                  float* kth, const void* packed_conv1, float* x, void* x16, void* stream) {
+    EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_conv1 && (x || x16), "null pointer");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT,
+                  "need num_points >= 20 (tf.nn.top_k k=20)");
+    EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
+    if (num_clouds == 0) return EPC_OK;
+    if (n > KNN_LDS_MAX_N) {   // the streaming kNN kernel keeps no cloud image: two launches
+        int rc = launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, stream, __func__);
+        if (rc != EPC_OK) return rc;
+        return epc_conv1_fwd(xyz, packed_conv1, num_clouds * n, x, x16, stream);
     }
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
+    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, (const float*)packed_conv1, x, x16, stream, __func__);
 }
 
 extern "C" int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask,

@@ -1,6 +1,6 @@
 // Whole-path orchestration: xyz -> descriptors.  Replaces MODEL.forward(...) executed by sess.run with
 // is_training=False (train.py:254, evaluate.py:250-251).  Launch sequence per micro-batch (one HIP stream):
-//   sort -> knn -> conv1 -> block x4 (x2 for EPC-Net-L) -> conv5+assign -> aggregate -> head      (EPC-Net)
+//   sort -> knn+conv1 -> block x4 (x2 for EPC-Net-L) -> conv5+assign -> aggregate -> head      (EPC-Net)
 //                                               -> conv5+maxpool -> fc head               (EPC-Net-L)
 #include "common.h"
 
@@ -154,9 +154,9 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
         pc = sorted;
     }
     TRY(mark(prof, EPC_STAGE_KNN, stream));
-    TRY(epc_knn_topk(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, stream));
-    TRY(mark(prof, EPC_STAGE_CONV1, stream));
-    TRY(epc_conv1_fwd(pc, pk + epc_net_packed_offset(cfg, 0), nc * n, xs[0], xs16[0], stream));
+    // kNN graph + conv1 in one launch (the kNN workgroup already holds the cloud in LDS); a stage profile therefore
+    // reports conv1 inside the kNN stage
+    TRY(epc_knn_topk_conv1(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, pk + epc_net_packed_offset(cfg, 0), xs[0], xs16[0], stream));
     for (int b = 1; b <= nblocks; ++b) {
         TRY(mark(prof, EPC_STAGE_BLOCK1 + b - 1, stream));
         const int has_next = b < nblocks;

@@ -28,7 +28,7 @@ STATUS_NAMES = {0: "EPC_OK", -1: "EPC_EINVAL", -2: "EPC_ENOMEM", -3: "EPC_EHIP",
 # every symbol include/epcnet.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "epc_last_error", "epc_version", "epc_net_packed_bytes", "epc_net_pack_weights", "epc_net_workspace_bytes",
-    "epc_net_forward", "epc_net_forward_overlapped", "epc_knn_topk", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
+    "epc_net_forward", "epc_net_forward_overlapped", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
@@ -78,6 +78,7 @@ _lib.epc_net_workspace_bytes.argtypes = [POINTER(EpcCfg), c_int]
 _lib.epc_net_forward.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P]
 _lib.epc_net_forward_overlapped.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, POINTER(_P), c_int]
 _lib.epc_knn_topk.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P]
+_lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]
 _lib.epc_knn_mask.argtypes = [_P, _P, c_int, c_int, _P, _P]
 _lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
 _lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,

@@ -134,6 +134,10 @@ int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, floa
 /* models/epc-net.py:66-69 conv1 (3->64) + folded BN + ReLU.  Writes x (M,64) f32 and/or x16 (M,64) fp16 (either may
  * be NULL): EPC-Net's blocks consume the fp16 rows, EPC-Net-L's the f32 rows. */
 int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16, void* stream);
+/* epc_knn_topk and epc_conv1_fwd of the same (sorted) clouds in ONE launch: the kNN workgroup holds the cloud in LDS, so
+ * conv1 costs it ~1.5 % more work instead of a launch of its own.  Bit-identical to the two separate calls. */
+int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
+                       const void* packed_conv1, float* x, void* x16, void* stream);
 
 /* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
  *   xm = (sum_{j in nbr(i)} x_j) / knn ; t = xm - x ; t = conv_a(t) ; t = conv_b(t) ; out = t + xm ;

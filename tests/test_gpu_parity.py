@@ -234,6 +234,37 @@ def test_overlapped_passes_and_submit_match_single_stream(dev, arch):
     assert torch.equal(o, serial[:3])
 
 
+@pytest.mark.parametrize("nc,n", [(3, 4096), (2, 96), (1, 8192 + 64)])
+def test_knn_conv1_fused_launch_is_bit_identical(dev, nc, n):
+    """epc_knn_topk_conv1 (one launch) against epc_knn_topk + epc_conv1_fwd: lists, counts, thresholds and both row
+    formats of conv1 (f32 for EPC-Net-L, fp16 for EPC-Net) must match bit for bit."""
+    L = H.pkg("lib")
+    E = H.pkg("engine")
+    lib = L.lib()
+    eng, _ = H.make_engine("epc-net", O.seeded_weights("epc-net", 0), dev)
+    cfg = E.make_cfg("epc-net", n, H.PARAMS)
+    pk = eng.packed(cfg).data_ptr() + lib.epc_net_packed_offset(ctypes.byref(cfg), 0)
+    xyz = torch.from_numpy(O.synthetic_clouds(nc, n, 5)).to(dev)
+    st = L.current_stream()
+
+    def buffers():
+        return (torch.zeros((nc, n, 32), dtype=torch.int32, device=dev), torch.zeros((nc, n), dtype=torch.int32, device=dev),
+                torch.zeros((nc, n), device=dev), torch.zeros((nc * n, 64), device=dev),
+                torch.zeros((nc * n, 64), dtype=torch.float16, device=dev))
+    i0, c0, k0, x0, h0 = buffers()
+    L.check(lib.epc_knn_topk(xyz.data_ptr(), nc, n, 32, i0.data_ptr(), c0.data_ptr(), k0.data_ptr(), st))
+    L.check(lib.epc_conv1_fwd(xyz.data_ptr(), pk, nc * n, x0.data_ptr(), h0.data_ptr(), st))
+    i1, c1, k1, x1, h1 = buffers()
+    L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, i1.data_ptr(), c1.data_ptr(), k1.data_ptr(), pk,
+                                   x1.data_ptr(), h1.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(c0, c1) and torch.equal(k0, k1)
+    m = torch.arange(32, device=dev)[None, None, :] < c0.clamp(max=32)[..., None]
+    assert torch.equal(i0 * m, i1 * m)
+    assert torch.equal(x0, x1) and torch.equal(h0.view(torch.int16), h1.view(torch.int16))
+    assert float(x1.abs().sum()) > 0
+
+
 def test_overlapped_rejects_short_workspace(dev):
     L = H.pkg("lib")
     E = H.pkg("engine")
