@@ -267,25 +267,35 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 static_assert(CIN / 64 <= 4, "one scale dword holds four block scales");
 #endif
             }
-            // fragment reads run one k-step ahead of the MFMAs that consume them
-            f16x8 fa[2][2];
+            // fragment reads run C5_PF k-steps ahead of the MFMAs that consume them: eight waves share the LDS port, so a
+            // read returns after ~8 other 1-KB reads (64+ cycles) while a k-step's MFMA takes 32 -- with one read in flight
+            // per wave the port idles
+#ifndef C5_PF
+#define C5_PF 1   // measured 1, 2, 3, 4, 6: 0.258-0.260 ms alike, so the shallowest (fewest registers) stays
+#endif
+            constexpr int PF = C5_PF < STEPS ? C5_PF : STEPS - 1;
+            constexpr int RING = PF + 1;
+            f16x8 fa[RING][2];
             constexpr int FS = kF16 ? 1 : 2;   // fragments per k-step in LDS (fp16 hi only / bf16 hi + lo)
-            fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
-            if (!kF16) fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                fa[s][0] = ldfrag16(w5 + ((s * FS + 0) * 64 + lane) * 4);
+                if (!kF16) fa[s][1] = ldfrag16(w5 + ((s * FS + 1) * 64 + lane) * 4);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
-                if (s + 1 < STEPS) {
-                    fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * FS + 0) * 64 + lane) * 4);
-                    if (!kF16) fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * FS + 1) * 64 + lane) * 4);
+                if (s + PF < STEPS) {
+                    fa[(s + PF) % RING][0] = ldfrag16(w5 + (((s + PF) * FS + 0) * 64 + lane) * 4);
+                    if (!kF16) fa[(s + PF) % RING][1] = ldfrag16(w5 + (((s + PF) * FS + 1) * 64 + lane) * 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
                 if constexpr (kF16) {
-                    acc = mfma_f16(fa[s & 1][0], xf[s], acc);
+                    acc = mfma_f16(fa[s % RING][0], xf[s], acc);
                 } else {
-                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s & 1][1]), acc);
-                    acc = mfma_bf16(xl[s], __builtin_bit_cast(bf16x8, fa[s & 1][0]), acc);
-                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s & 1][0]), acc);
+                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][1]), acc);
+                    acc = mfma_bf16(xl[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
+                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
                 }
             }
         }
