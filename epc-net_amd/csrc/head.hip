@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void vlad_reduce_kernel(const float* __restric
             const float* vp = vpart + (((size_t)cloud * 4) * 1024 + f) * 64 + k;
             const float v0 = vp[0], v1 = vp[(size_t)1024 * 64], v2 = vp[(size_t)2 * 1024 * 64], v3 = vp[(size_t)3 * 1024 * 64];
             acc = ((v0 + v1) + v2) + v3;
+        } else if (splits == 2) {
+            const float* vp = vpart + (((size_t)cloud * 2) * 1024 + f) * 64 + k;
+            acc = vp[0] + vp[(size_t)1024 * 64];
         } else {
             for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
         }
