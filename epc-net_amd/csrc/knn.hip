@@ -78,7 +78,9 @@ __device__ __forceinline__ void topk_insert_key(int (&top)[20], int v) {
         : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
 }
 
+#ifndef KNN_BATCH
 #define KNN_BATCH 8
+#endif
 // hit-mask words per wave: KNN_LDS_MAX_N / KNN_BATCH bits
 #define KNN_MASK_WORDS (KNN_LDS_MAX_N / KNN_BATCH / 32)
 static_assert(32 % (KNN_CT / KNN_BATCH) == 0, "a tile's batch bits must not straddle a mask word");
