@@ -525,33 +525,57 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n (feat[n][f] * rnorm[n]) * a[n][k] per cloud, as an fp16 MFMA GEMM
-// (f32 accumulate) with the point index as K.  a arrives as ready-made fp16 B fragments (scaled by 2^14, removed at the
-// store); feat arrives as fp16 in conv5's accumulator-fragment order (lane = point, 8 channels per fragment): each lane
-// multiplies its 8 values by its point's rnorm in f32 (the normalised feature is <= 1: no range concern), rounds to fp16
-// and the wave transposes them into A fragments (lane = channel, 8 consecutive points) through a per-wave 32x32 LDS tile
-// (row stride 80 B: conflict-free b128 reads).  The kernel streams feat once from HBM (8.4 MB per cloud) and is bound by
-// that read; the scaling and transposition ride on idle VALU/LDS.
-// One wave = AGG_FT 32-feature chunks x 64 clusters over a `splits`-th of the cloud's 32-point tiles.
+// VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n (feat[n][f] * rnorm[n]) * a[n][k] - a_sum[k] * centres[f][k] per
+// cloud, and the per-cluster sums of squares of V that the intra-normalisation (:295) needs.  The product is an fp16
+// MFMA GEMM (f32 accumulate) with the point index as K.  a arrives as ready-made fp16 B fragments (scaled by 2^14,
+// removed at the end); feat arrives as fp16 in conv5's accumulator-fragment order (lane = point, 8 channels per
+// fragment): each lane multiplies its 8 values by its point's rnorm in f32 (the normalised feature is <= 1: no range
+// concern), rounds to fp16 and the wave transposes them into A fragments (lane = channel, 8 consecutive points).  The
+// kernel streams feat once from HBM (8.4 MB per cloud) and is bound by that read.
+// One workgroup = 8 waves = 4 feature groups of 64 (AGG_FT = 2 chunks of 32: one slab of the column norms) x the two
+// halves of the cloud's 32-point tiles; the halves meet in LDS at the end, so no partial slabs travel through HBM and
+// the centre subtraction and the column norms need no kernel of their own.
 // ---------------------------------------------------------------------------------------------------------------
-#define AGG_THREADS 256
-#ifndef AGG_FT
-#define AGG_FT 4
-#endif
+#define AGG_THREADS 512
+#define AGG_FT 2
 #define AGG_ROW 36  // fp16 per LDS row: 32 channels + 4 pad (72 B: conflict-free 8-byte stores, 8-byte aligned rows)
+#define AGG_XCH_FLOATS (4 * AGG_FT * 2 * 16 * 64)   // the second half's accumulators: [wave][register][lane]
 
-__global__ __launch_bounds__(AGG_THREADS, 2) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
+__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float* __restrict__ feat_frag,
                                                                      const float* __restrict__ assign_frag,
-                                                                     const float* __restrict__ rnorm, int n, int splits,
-                                                                     float* __restrict__ vpart) {
-    __shared__ __attribute__((aligned(16))) unsigned short xt[4][32 * AGG_ROW];  // [wave][point][channel], 72-B rows
+                                                                     const float* __restrict__ rnorm,
+                                                                     const float* __restrict__ apart,
+                                                                     const float* __restrict__ centres, int n,
+                                                                     float* __restrict__ V, float* __restrict__ colss) {
+    extern __shared__ __attribute__((aligned(16))) float agg_lds[];
+    float* xch = agg_lds;                                    // [4][AGG_FT * 2 * 16][64] f32
+    float* s_asum = agg_lds + AGG_XCH_FLOATS;                // [8][64]
+    unsigned short* xt = reinterpret_cast<unsigned short*>(s_asum + 8 * 64);   // [8 waves][32 points][AGG_ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int fg = blockIdx.x * 4 + wave;  // group of AGG_FT chunks (32 features each)
-    const int sp = blockIdx.y;
-    const int cloud = blockIdx.z;
-    const int tiles = n / 32, per = tiles / splits;
-    const size_t gt0 = (size_t)cloud * tiles + (size_t)sp * per;
+    const int fg = blockIdx.x * 4 + (wave & 3);  // group of AGG_FT chunks (32 features each): 64 features, 16 groups
+    const int sp = wave >> 2;                    // which half of the cloud's tiles
+    const int cloud = blockIdx.y;
+    const int tiles = n / 32, half = (tiles + 1) / 2;
+    const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
+    const size_t gt0 = (size_t)cloud * tiles + t_begin;
+
+    // a_sum partials (loupe.py:276): wave w adds the per-tile sums of its eighth of the tiles, 8 loads in flight
+    {
+        const int t8 = (tiles + 7) / 8, ta = wave * t8, tb = min(tiles, ta + t8);
+        const float* ap = apart + (size_t)cloud * tiles * 64 + lane;
+        float sum = 0.f;
+        int t = ta;
+        for (; t + 8 <= tb; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ap[(size_t)(t + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; t < tb; ++t) sum += ap[(size_t)t * 64];
+        s_asum[wave * 64 + lane] = sum;
+    }
 
     f32x16 acc[AGG_FT][2];
 #pragma unroll
@@ -559,10 +583,9 @@ __global__ __launch_bounds__(AGG_THREADS, 2) void vlad_aggregate_kernel(const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 
-    // Ping-pong over the tiles: tile t+1's loads (8 KB of feat, 4 KB of assignment fragments per wave) are issued before
+    // Ping-pong over the tiles: tile t+1's loads (4 KB of feat, 4 KB of assignment fragments per wave) are issued before
     // tile t is scaled, transposed and multiplied, so the wave always has a tile in flight (a pure streaming read reaches
-    // 6.9 TB/s on this device with as little as 16 KB in flight per CU -- scripts/probe/read_bw.hip -- and this kernel
-    // was at 4.3: its waves alternated between waiting for a tile and working on it).
+    // 6.9 TB/s on this device with as little as 16 KB in flight per CU -- scripts/probe/read_bw.hip).
     struct Tile {
         u32x4 raw[AGG_FT][2];  // [chunk][s']
         u32x4 bfr[2][2];       // [cluster tile][k-step]
@@ -576,36 +599,24 @@ __global__ __launch_bounds__(AGG_THREADS, 2) void vlad_aggregate_kernel(const fl
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 // read exactly once: non-temporal, so the 0.54-GB stream does not evict the assignment fragments (read
-                // by 8 waves) from L2 -- 0.155 -> 0.119 ms per 64 clouds
+                // by the 16 waves that share a tile stream) from L2
                 t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 512 + q * 256));
         t.rn = rnorm[(gt0 + tt) * 32 + j];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#ifdef AGG_NT_B
-                t.bfr[ct][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256));
-#else
-                t.bfr[ct][ks] = *reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256);
-#endif
+            for (int ks = 0; ks < 2; ++ks) t.bfr[ct][ks] = *reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256);
     };
     // Transposition lane = point -> lane = channel: every lane stores its 4-channel groups (8 bytes) into a
     // [point][channel] image and the A fragments (lane = channel, 8 consecutive points) come back through the hardware
     // transposing read ds_read_b64_tr_b16 (per 16-lane group a 4-point x 16-channel block, delivered channel-major).
-    // 16 8-byte stores and 16 transposing reads per tile; the first version wrote the image element by element
-    // (64 ds_write_b16 per tile) and that LDS traffic, not HBM, bounded the kernel (0.151 ms at any occupancy).
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    unsigned short* img = xt[wave];
+    unsigned short* img = xt + wave * 32 * AGG_ROW;
     const int li = lane & 15;
     // transposing-read address of this lane: block row q = li >> 2 (point), columns 16*((lane >> 4) & 1) + 4*(li & 3)
     const int tr_off = (8 * h + (li >> 2)) * AGG_ROW + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
     auto process = [&](const Tile& t) {
-#ifdef AGG_ABL_NOCOMPUTE
-#pragma unroll
-        for (int c = 0; c < AGG_FT; ++c) { acc[c][0][0] += __builtin_bit_cast(float, t.raw[c][0][0] ^ t.raw[c][1][1]) + t.rn; acc[c][1][1] += __builtin_bit_cast(float, t.bfr[c & 1][c >> 1][0]); }
-        return;
-#endif
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c) {
             // scale: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) of point j
@@ -633,36 +644,71 @@ __global__ __launch_bounds__(AGG_THREADS, 2) void vlad_aggregate_kernel(const fl
         }
     };
     Tile t0, t1;
-    load(t0, 0);
+    if (per > 0) load(t0, 0);
     for (int tt = 0; tt < per; tt += 2) {
         if (tt + 1 < per) load(t1, tt + 1);
         process(t0);
         if (tt + 2 < per) load(t0, tt + 2);
         if (tt + 1 < per) process(t1);
     }
-    float* vout = vpart + ((size_t)cloud * splits + sp) * 1024 * 64;
+
+    // ---- the two halves meet: V = (first + second) * 2^-14 - a_sum * centres, column sums of squares ----
+    if (sp == 1) {
+#pragma unroll
+        for (int c = 0; c < AGG_FT; ++c)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xch[(((wave & 3) * AGG_FT * 2 + c * 2 + ct) * 16 + r) * 64 + lane] = acc[c][ct][r];
+    }
+    __syncthreads();
+    if (sp == 1) return;
+    float asum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        asum[0] += s_asum[w * 64 + j];
+        asum[1] += s_asum[w * 64 + 32 + j];
+    }
     constexpr float unscale = 1.0f / AGG_ASSIGN_SCALE;
-#ifdef AGG_ABL_NOSTORE
-    if (acc[0][0][0] != 123.f) return;
-#endif
+    float* vout = V + (size_t)cloud * 1024 * 64;
+    float ss[2] = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = (fg * AGG_FT + c) * 32 + mfma_row(r, h);
-            vout[(size_t)f * 64 + j] = acc[c][0][r] * unscale;
-            vout[(size_t)f * 64 + 32 + j] = acc[c][1][r] * unscale;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float other = xch[((wave * AGG_FT * 2 + c * 2 + ct) * 16 + r) * 64 + lane];
+                const float v = (acc[c][ct][r] + other) * unscale - asum[ct] * centres[f * 64 + 32 * ct + j];
+                vout[(size_t)f * 64 + 32 * ct + j] = v;
+                ss[ct] += v * v;
+            }
         }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        ss[ct] += __shfl_xor(ss[ct], 32);   // the other 16 of the 32 feature rows of every chunk
+        if (h == 0) colss[((size_t)cloud * 16 + fg) * 64 + 32 * ct + j] = ss[ct];
+    }
 }
 
 extern "C" int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm,
-                                      int num_clouds, int n, int splits, float* vpart, void* stream) {
-    EPC_CHECK_ARG(feat_frag && assign_frag && rnorm && vpart, "null pointer");
-    EPC_CHECK_ARG(splits >= 1 && n > 0 && n % (32 * splits) == 0, "num_points must be a multiple of 32*splits");
-    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && splits <= 65535, "bad shape");
+                                      const float* apart, const float* centres, int num_clouds, int n, float* V,
+                                      float* colss, void* stream) {
+    EPC_CHECK_ARG(feat_frag && assign_frag && rnorm && apart && centres && V && colss, "null pointer");
+    EPC_CHECK_ARG(n > 0 && n % 32 == 0, "num_points must be a multiple of 32");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535, "bad shape");
     if (num_clouds == 0) return EPC_OK;
-    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(8 / AGG_FT, splits, num_clouds), dim3(AGG_THREADS), 0,
-                       (hipStream_t)stream, (const float*)feat_frag, (const float*)assign_frag, rnorm, n, splits, vpart);
+    const size_t lds_bytes = (AGG_XCH_FLOATS + 8 * 64) * sizeof(float) + 8 * 32 * AGG_ROW * sizeof(unsigned short);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_aggregate_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        epc_set_error("epc_vlad_aggregate_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(4, num_clouds), dim3(AGG_THREADS), lds_bytes, (hipStream_t)stream,
+                       (const float*)feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, V, colss);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -1,59 +1,13 @@
 // Descriptor heads.
-//   EPC-Net  : loupe.py:292-331 + models/epc-net.py:153  (three small kernels, ~0.9 % of the FLOPs)
+//   EPC-Net  : loupe.py:295-331 + models/epc-net.py:153  (three small kernels, ~0.9 % of the FLOPs)
 //   EPC-Net-L: models/epc-net-l.py:95-98                  (one kernel)
 #include "common.h"
 
 // packed head stage (floats): [C 1024*64][H KH*256][bn_s 256][bn_t 256][Wg 256*256][gbn_s 256][gbn_t 256]
 // with KH = 65536 / groups.
 
-// ---- H1a: V = sum of the aggregate's partial slabs - a_sum * centres; per-cluster sum of squares (partial) ----------
-// grid (16 row slabs, clouds) x 256 threads: thread (k = tid & 63, r = tid >> 6) owns rows 64*slab + r + 4m, m < 16.
-__global__ __launch_bounds__(256) void vlad_reduce_kernel(const float* __restrict__ vpart,
-                                                          const float* __restrict__ apart, int splits, int asplits,
-                                                          const float* __restrict__ centres,
-                                                          float* __restrict__ V, float* __restrict__ colss) {
-    __shared__ float red[4][64];
-    const int slab = blockIdx.x, cloud = blockIdx.y;
-    const int k = threadIdx.x & 63, r = threadIdx.x >> 6;
-    float asum = 0.f;
-    {   // 8 independent loads in flight (the per-tile partials are a chain of exposed latencies otherwise)
-        int s = r;
-        for (; s + 28 < asplits; s += 32) {
-            float t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = apart[((size_t)cloud * asplits + s + 4 * u) * 64 + k];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) asum += t[u];
-        }
-        for (; s < asplits; s += 4) asum += apart[((size_t)cloud * asplits + s) * 64 + k];
-    }
-    red[r][k] = asum;
-    __syncthreads();
-    asum = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    __syncthreads();
-    float ss = 0.f;
-#pragma unroll 8
-    for (int m = 0; m < 16; ++m) {
-        const int f = 64 * slab + r + 4 * m;
-        float acc = 0.f;
-        if (splits == 4) {
-            const float* vp = vpart + (((size_t)cloud * 4) * 1024 + f) * 64 + k;
-            const float v0 = vp[0], v1 = vp[(size_t)1024 * 64], v2 = vp[(size_t)2 * 1024 * 64], v3 = vp[(size_t)3 * 1024 * 64];
-            acc = ((v0 + v1) + v2) + v3;
-        } else if (splits == 2) {
-            const float* vp = vpart + (((size_t)cloud * 2) * 1024 + f) * 64 + k;
-            acc = vp[0] + vp[(size_t)1024 * 64];
-        } else {
-            for (int s = 0; s < splits; ++s) acc += vpart[(((size_t)cloud * splits + s) * 1024 + f) * 64 + k];
-        }
-        acc -= asum * centres[f * 64 + k];
-        V[((size_t)cloud * 1024 + f) * 64 + k] = acc;
-        ss += acc * acc;
-    }
-    red[r][k] = ss;
-    __syncthreads();
-    if (r == 0) colss[((size_t)cloud * 16 + slab) * 64 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-}
+// (V = aggregate - a_sum * centres and its per-cluster sums of squares `colss` (16 slabs of 64 features per cloud) come
+// from epc_vlad_aggregate_fwd, conv5_vlad.hip.)
 
 // ---- H1b: intra-norm over the 1024 features of each cluster, global norm, group fold ---------------------------
 // In inference the grouped projection sum_g BN(v_g W) equals s * ((sum_g v_g) W) + G t (one shared W, affine BN),
@@ -215,18 +169,14 @@ extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
     const size_t kh = 65536 / groups;
     const size_t u = align_up((size_t)num_clouds * kh * sizeof(float), 256);
     const size_t yp = align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
-    const size_t v = align_up((size_t)num_clouds * 65536 * sizeof(float), 256);
-    const size_t cs = align_up((size_t)num_clouds * 16 * 64 * sizeof(float), 256);
-    return u + yp + v + cs;
+    return u + yp;
 }
 
-extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, int asplits,
-                                 const void* packed_head,
-                                 int groups, int num_clouds, float* out, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
-    EPC_CHECK_ARG(vpart && apart && packed_head && out && workspace, "null pointer");
+extern "C" int epc_vlad_head_fwd(const float* V, const float* colss, const void* packed_head, int groups,
+                                 int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(V && colss && packed_head && out && workspace, "null pointer");
     EPC_CHECK_ARG(groups > 0 && 64 % groups == 0, "GROUPS must divide 64");
-    EPC_CHECK_ARG(splits >= 1 && asplits >= 1 && num_clouds >= 0, "bad shape");
+    EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     if (workspace_bytes < epc_vlad_head_workspace_bytes(num_clouds, groups)) {
         epc_set_error("epc_vlad_head_fwd: workspace too small");
@@ -234,22 +184,14 @@ extern "C" int epc_vlad_head_fwd(const float* vpart, const float* apart, int spl
     }
     const int kh = 65536 / groups;
     const float* hp = (const float*)packed_head;
-    const float* centres = hp;
-    const float* Hw = hp + 65536;
+    const float* Hw = hp + 65536;   // past the centres (epc_vlad_aggregate_fwd's operand)
     const float* tail = Hw + (size_t)kh * 256;
     char* wsp = (char*)workspace;
     float* U = (float*)wsp;
     wsp += align_up((size_t)num_clouds * kh * sizeof(float), 256);
     float* Yp = (float*)wsp;
-    wsp += align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
-    float* V = (float*)wsp;
-    wsp += align_up((size_t)num_clouds * 65536 * sizeof(float), 256);
-    float* colss = (float*)wsp;
     hipStream_t st = (hipStream_t)stream;
     EPC_CHECK_ARG(num_clouds <= 65535, "too many clouds per call");
-    hipLaunchKernelGGL(vlad_reduce_kernel, dim3(16, num_clouds), dim3(256), 0, st, vpart, apart, splits, asplits, centres, V,
-                       colss);
-    EPC_CHECK_LAUNCH();
     switch (groups) {
 #define EPC_VF(G)                                                                                                  \
     case G:                                                                                                        \

@@ -4,18 +4,6 @@
 //                                               -> conv5+maxpool -> fc head               (EPC-Net-L)
 #include "common.h"
 
-#define AGG_SPLITS 4  // upper bound (workspace); the split actually used must divide the cloud's n/32 tiles
-static int agg_splits(int n) {
-    const int tiles = n / 32;
-#ifdef AGG_SPLITS_FORCE   // tuning builds only
-    if (tiles % AGG_SPLITS_FORCE == 0) return AGG_SPLITS_FORCE;
-#endif
-    // two halves of a cloud per (cloud, feature group): 256 workgroups of 4 waves keep enough tiles in flight to stream
-    // feat at the HBM rate, and the partial slabs the head has to sum are half of what four splits write
-    // (measured at 64 x 4096: aggregate 0.120 -> 0.108-0.114 ms; one split: 0.153)
-    return tiles % 2 == 0 ? 2 : 1;
-}
-
 static inline size_t al(size_t v) { return (v + 255) / 256 * 256; }
 
 static int micro_batch(const epc_cfg* c, int num_clouds) {
@@ -24,7 +12,7 @@ static int micro_batch(const epc_cfg* c, int num_clouds) {
 }
 
 struct WsLayout {
-    size_t sorted, idx, cnt, kth, xa, xb, xa16, xb16, cat, feat, rnorm, assign, afrag, vpart, apart, head, pooled, total;
+    size_t sorted, idx, cnt, kth, xa, xb, xa16, xb16, cat, feat, rnorm, assign, afrag, vlad, colss, apart, head, pooled, total;
 };
 
 static WsLayout ws_layout(const epc_cfg* c, int mb) {
@@ -51,12 +39,13 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
         w.xb = take(M * 64 * 4);
         w.cat = take(M * 128 * 4);
     }
-    w.feat = w.rnorm = w.assign = w.afrag = w.vpart = w.apart = w.head = w.pooled = 0;
+    w.feat = w.rnorm = w.assign = w.afrag = w.vlad = w.colss = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
         w.feat = take(M * 1024 * 2);   // fp16 fragments
         w.rnorm = take(M * 4);
         w.afrag = take(M * 64 * 2);    // fp16 fragments
-        w.vpart = take((size_t)mb * AGG_SPLITS * 65536 * 4);
+        w.vlad = take((size_t)mb * 65536 * 4);
+        w.colss = take((size_t)mb * 16 * 64 * 4);
         w.apart = take(M / 32 * 64 * 4);
         w.head = take(epc_vlad_head_workspace_bytes(mb, c->groups));
     } else {
@@ -174,18 +163,18 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
     if (cfg->arch == EPC_ARCH_EPC_NET) {
         float* feat = (float*)(ws + w.feat);
         float* rnorm = (float*)(ws + w.rnorm);
-        float* vpart = (float*)(ws + w.vpart);
+        float* vlad = (float*)(ws + w.vlad);
+        float* colss = (float*)(ws + w.colss);
         float* apart = (float*)(ws + w.apart);
         TRY(mark(prof, EPC_STAGE_CONV5, stream));
         float* afrag = (float*)(ws + w.afrag);
         TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, nullptr, afrag,
                                  apart, stream));
         TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
-        const int asp = agg_splits(n);
-        TRY(epc_vlad_aggregate_fwd(feat, afrag, rnorm, nc, n, asp, vpart, stream));
+        const char* head_pack = pk + epc_net_packed_offset(cfg, 6);   // starts with the cluster centres
+        TRY(epc_vlad_aggregate_fwd(feat, afrag, rnorm, apart, (const float*)head_pack, nc, n, vlad, colss, stream));
         TRY(mark(prof, EPC_STAGE_HEAD, stream));
-        TRY(epc_vlad_head_fwd(vpart, apart, asp, n / 32, pk + epc_net_packed_offset(cfg, 6), cfg->groups, nc, o,
-                              ws + w.head, w.total - w.head, stream));
+        TRY(epc_vlad_head_fwd(vlad, colss, head_pack, cfg->groups, nc, o, ws + w.head, w.total - w.head, stream));
     } else {
         float* pooled = (float*)(ws + w.pooled);
         TRY(mark(prof, EPC_STAGE_CONV5, stream));

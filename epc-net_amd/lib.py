@@ -84,10 +84,10 @@ _lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
 _lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,
                                          c_int, _P, _P, _P]
 _lib.epc_conv5_assign_fwd.argtypes = [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
-_lib.epc_vlad_aggregate_fwd.argtypes = [_P, _P, _P, c_int, c_int, c_int, _P, _P]
+_lib.epc_vlad_aggregate_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]
 _lib.epc_vlad_head_workspace_bytes.restype = c_size_t
 _lib.epc_vlad_head_workspace_bytes.argtypes = [c_int, c_int]
-_lib.epc_vlad_head_fwd.argtypes = [_P, _P, c_int, c_int, _P, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_vlad_head_fwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]
 _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
 _lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]

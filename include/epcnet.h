@@ -171,18 +171,19 @@ int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, c
 int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5, int num_points_total,
                          void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
 
-/* loupe.py:286-291: vlad[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] from the fragment-ordered operands (fp16
- * MFMA, f32 accumulate; the 2^14 of assign_frag is removed), written as `splits` partial slabs vpart
- * (num_clouds, splits, 1024, 64) (summed, and the a_sum*centres term of :292 applied, by epc_vlad_head_fwd). */
-int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, int num_clouds, int n,
-                           int splits, float* vpart, void* stream);
+/* loupe.py:276-292: V[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] - a_sum[k] * centres[f][k] from the
+ * fragment-ordered operands (fp16 MFMA, f32 accumulate; the 2^14 of assign_frag is removed), a_sum = the sum of the
+ * n/32 per-tile partials `apart` of epc_conv5_assign_fwd, centres = cluster_weights2 (1024, 64) (the first 65536 floats of
+ * the packed head stage).  Outputs V (num_clouds, 1024, 64) and colss (num_clouds, 16, 64): per cluster the sums of
+ * V^2 over each slab of 64 features (what the intra-normalisation of :295 needs). */
+int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
+                           const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
 
-/* loupe.py:292-331 + models/epc-net.py:153: centre subtraction, intra-normalisation, flatten + L2, grouped
- * hidden projection with the shared weight (+BN, summed over groups), context gating, final L2.
- * apart holds `asplits` a_sum partials per cloud. */
+/* loupe.py:295-331 + models/epc-net.py:153: intra-normalisation, flatten + L2, grouped hidden projection with the
+ * shared weight (+BN, summed over groups), context gating, final L2. */
 size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups);
-int epc_vlad_head_fwd(const float* vpart, const float* apart, int splits, int asplits, const void* packed_head,
-                      int groups, int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int epc_vlad_head_fwd(const float* V, const float* colss, const void* packed_head, int groups, int num_clouds,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* models/epc-net-l.py:84-98: conv5 (128->1024)+BN+ReLU, global max over N, fc1 (1024->256)+BN+ReLU, L2. */
 int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,

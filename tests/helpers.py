@@ -85,21 +85,21 @@ def run_stages(eng, xyz):
         apart = torch.empty((nc, n // 32, 64), dtype=torch.float32, device=dev)
         L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), 1, ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
                                          assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
-        S = 4 if n % 128 == 0 else (2 if n % 64 == 0 else 1)
-        vpart = torch.empty((nc, S, 1024, 64), dtype=torch.float32, device=dev)
-        L.check(lib.epc_vlad_aggregate_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(), nc, n, S,
-                                           vpart.data_ptr(), st))
+        vlad = torch.empty((nc, 1024, 64), dtype=torch.float32, device=dev)
+        colss = torch.empty((nc, 16, 64), dtype=torch.float32, device=dev)
+        L.check(lib.epc_vlad_aggregate_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(), apart.data_ptr(),
+                                           off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
         wsb = lib.epc_vlad_head_workspace_bytes(nc, cfg.groups)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        L.check(lib.epc_vlad_head_fwd(vpart.data_ptr(), apart.data_ptr(), S, n // 32, off(6), cfg.groups, nc,
-                                      desc.data_ptr(), ws.data_ptr(), wsb, st))
+        L.check(lib.epc_vlad_head_fwd(vlad.data_ptr(), colss.data_ptr(), off(6), cfg.groups, nc, desc.data_ptr(),
+                                      ws.data_ptr(), wsb, st))
         # unpack the fragment order (include/epcnet.h): [tile g][chunk c][half s][lane l][q] ->
         # feat[32g + (l&31)][32c + 16s + 8(q>>2) + 4(l>>5) + (q&3)]   (fp16: 11 significant bits)
         ff = featf.float().reshape(M // 32, 32, 2, 2, 32, 2, 4)        # (g, c, s, h, j, q>>2, q&3)
         feat = ff.permute(0, 4, 1, 2, 5, 3, 6).reshape(nc, n, 1024)    # (g, j, c, s, q>>2, h, q&3) -> point-major
         af = assignf.float().reshape(M // 32, 2, 2, 2, 32, 8) / 16384.0
         aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)   # assign * rnorm
-        out.update(feat=feat, rnorm=rnorm, assign=assign, aprime=aprime, vpart=vpart, apart=apart)
+        out.update(feat=feat, rnorm=rnorm, assign=assign, aprime=aprime, vlad=vlad, colss=colss, apart=apart)
     else:
         pooled = torch.empty((nc, 1024), dtype=torch.float32, device=dev)
         L.check(lib.epc_conv5_maxpool_fwd(cat.data_ptr(), ccat, off(5), nc, n, pooled.data_ptr(), st))

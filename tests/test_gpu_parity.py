@@ -147,11 +147,11 @@ def test_stages_against_oracle(dev, arch, kind, n):
         close(got["assign"].reshape(-1, 64), st.taps["vlad_assign"], 1e-4, "assign")
         close(got["aprime"], got["assign"].cpu().numpy() * got["rnorm"].cpu().numpy()[..., None], 2.0 ** -11,
               "assign fragments (fp16)")
-        v = got["vpart"].sum(1).cpu().numpy()
-        asum = got["apart"].sum(1).cpu().numpy()
-        v = v - asum[:, None, :] * eng.store.vars["query_triplets/VLAD/cluster_weights2"].cpu().numpy()
+        v = got["vlad"].cpu().numpy()      # aggregate - a_sum * centres (loupe.py:286-292)
         # worst case = the all-zero padding cloud (every point identical: the fp16 rounding of feat does not average out)
         close(v, st.taps["vlad_raw"], 2e-3 if kind == "zeros" else 2.0 ** -11, "vlad")
+        colss = (got["vlad"].double() ** 2).reshape(v.shape[0], 16, 64, 64).sum(2)
+        close(got["colss"], colss.cpu().numpy(), 1e-5, "column sums of squares")
     else:
         close(got["pooled"], st.taps["maxpool"], 2e-5, "maxpool")
     err = np.linalg.norm(got["desc"].cpu().numpy() - ref, axis=1).max()
