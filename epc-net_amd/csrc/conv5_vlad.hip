@@ -526,7 +526,7 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
 
 // ---------------------------------------------------------------------------------------------------------------
 // VLAD aggregate (loupe.py:276-292): V[f][k] = sum_n (feat[n][f] * rnorm[n]) * a[n][k] - a_sum[k] * centres[f][k] per
-// cloud, and the per-cluster sums of squares of V that the intra-normalisation (:295) needs.  The product is an fp16
+// cloud, and the per-cluster sums of squares of V (per 32-feature chunk) that the intra-normalisation (:295) needs.  The product is an fp16
 // MFMA GEMM (f32 accumulate) with the point index as K.  a arrives as ready-made fp16 B fragments (scaled by 2^14,
 // removed at the end); feat arrives as fp16 in conv5's accumulator-fragment order (lane = point, 8 channels per
 // fragment): each lane multiplies its 8 values by its point's rnorm in f32 (the normalised feature is <= 1: no range
@@ -653,17 +653,18 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     }
 
     // ---- the two halves meet: V = (first + second) * 2^-14 - a_sum * centres, column sums of squares ----
-    if (sp == 1) {
+    // The wave of half `sp` finishes chunk c = sp of its feature group and hands its accumulators of the other chunk to
+    // its partner wave (same feature group, other half) through LDS: all eight waves share the epilogue.
+    static_assert(AGG_FT == 2, "one chunk per half in the epilogue");
+    const int w3 = wave & 3;
 #pragma unroll
-        for (int c = 0; c < AGG_FT; ++c)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    xch[(((wave & 3) * AGG_FT * 2 + c * 2 + ct) * 16 + r) * 64 + lane] = acc[c][ct][r];
-    }
+        for (int r = 0; r < 16; ++r) {
+            const float mine0 = acc[0][ct][r], mine1 = acc[1][ct][r];
+            xch[(((w3 * 2 + sp) * 2 + ct) * 16 + r) * 64 + lane] = sp ? mine0 : mine1;   // the chunk the partner finishes
+        }
     __syncthreads();
-    if (sp == 1) return;
     float asum[2] = {0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
@@ -673,23 +674,24 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     constexpr float unscale = 1.0f / AGG_ASSIGN_SCALE;
     float* vout = V + (size_t)cloud * 1024 * 64;
     float ss[2] = {0.f, 0.f};
+    const int chunk = fg * AGG_FT + sp;   // 32 features
 #pragma unroll
-    for (int c = 0; c < AGG_FT; ++c)
+    for (int r = 0; r < 16; ++r) {
+        const int f = chunk * 32 + mfma_row(r, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = (fg * AGG_FT + c) * 32 + mfma_row(r, h);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float other = xch[((wave * AGG_FT * 2 + c * 2 + ct) * 16 + r) * 64 + lane];
-                const float v = (acc[c][ct][r] + other) * unscale - asum[ct] * centres[f * 64 + 32 * ct + j];
-                vout[(size_t)f * 64 + 32 * ct + j] = v;
-                ss[ct] += v * v;
-            }
+        for (int ct = 0; ct < 2; ++ct) {
+            const float other = xch[(((w3 * 2 + (sp ^ 1)) * 2 + ct) * 16 + r) * 64 + lane];
+            const float own = sp ? acc[1][ct][r] : acc[0][ct][r];
+            const float first = sp ? other : own, second = sp ? own : other;   // fixed order: first half + second half
+            const float v = (first + second) * unscale - asum[ct] * centres[f * 64 + 32 * ct + j];
+            vout[(size_t)f * 64 + 32 * ct + j] = v;
+            ss[ct] += v * v;
         }
+    }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        ss[ct] += __shfl_xor(ss[ct], 32);   // the other 16 of the 32 feature rows of every chunk
-        if (h == 0) colss[((size_t)cloud * 16 + fg) * 64 + 32 * ct + j] = ss[ct];
+        ss[ct] += __shfl_xor(ss[ct], 32);   // the other 16 of the chunk's 32 feature rows
+        if (h == 0) colss[((size_t)cloud * 32 + chunk) * 64 + 32 * ct + j] = ss[ct];
     }
 }
 

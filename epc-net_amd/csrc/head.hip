@@ -6,7 +6,7 @@
 // packed head stage (floats): [C 1024*64][H KH*256][bn_s 256][bn_t 256][Wg 256*256][gbn_s 256][gbn_t 256]
 // with KH = 65536 / groups.
 
-// (V = aggregate - a_sum * centres and its per-cluster sums of squares `colss` (16 slabs of 64 features per cloud) come
+// (V = aggregate - a_sum * centres and its per-cluster sums of squares `colss` (32 chunks of 32 features per cloud) come
 // from epc_vlad_aggregate_fwd, conv5_vlad.hip.)
 
 // ---- H1b: intra-norm over the 1024 features of each cluster, global norm, group fold ---------------------------
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void vlad_fold_kernel(const float* __restrict_
     if (r == 0) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += colss[((size_t)cloud * 16 + g) * 64 + k];
+        for (int g = 0; g < 32; ++g) t += colss[((size_t)cloud * 32 + g) * 64 + k];
         const float inv = 1.0f / sqrtf(fmaxf(t, 1e-12f));
         cn[k] = inv;
         gsum[k] = t * inv * inv;  // squared norm of the normalised column (1 unless the column is ~0)
@@ -46,7 +46,12 @@ __global__ __launch_bounds__(256) void vlad_fold_kernel(const float* __restrict_
     }
 }
 
-// ---- H2: Yp[slice][row][256] = U[row][slice*256 .. +256] @ H[slice*256 .. +256][256]  (split-K, f32 MFMA) --------
+// ---- H2: Yp[slice][row][256] = U[row][slice*HSL .. +HSL] @ H[slice*HSL .. +HSL][256]  (split-K, f32 MFMA) --------
+// HSL = 128 k per slice: a wave's serial work is 128 f32 MFMAs (4 us) and 2 rounds of 8 k-steps of loads; with 64 rows
+// (clouds) there are only two row tiles per column tile, so the K split is what fills the chip (1024 waves).
+#ifndef HSL
+#define HSL 128
+#endif
 // One wave per (32-column tile, K slice, 64-row group).  A (row on lane) is read as float4 along K: k-step (q,c) takes
 // k = 8q + c from lane-half 0 and k = 8q + 4 + c from lane-half 1; B rows are read to match.
 __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict__ U, const float* __restrict__ H,
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict
     const int nb = blockIdx.x * 32;
     const int slice = blockIdx.y;
     const int m0 = blockIdx.z * 64;
-    const int k0 = slice * 256;
+    const int k0 = slice * HSL;
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict
     const float z0 = r0 < rows ? 1.f : 0.f, z1 = r1 < rows ? 1.f : 0.f;
     const float* bp = H + (size_t)(k0 + 4 * h) * 256 + nb + j;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) {
+    for (int q = 0; q < HSL / 8; ++q) {
         const float4 a0 = *reinterpret_cast<const float4*>(a0p + 8 * q);
         const float4 a1 = *reinterpret_cast<const float4*>(a1p + 8 * q);
         const float b0 = bp[(size_t)(8 * q + 0) * 256], b1 = bp[(size_t)(8 * q + 1) * 256];
@@ -168,7 +173,7 @@ extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
     if (num_clouds <= 0 || groups <= 0 || 64 % groups) return 0;
     const size_t kh = 65536 / groups;
     const size_t u = align_up((size_t)num_clouds * kh * sizeof(float), 256);
-    const size_t yp = align_up((kh / 256) * (size_t)num_clouds * 256 * sizeof(float), 256);
+    const size_t yp = align_up((kh / HSL) * (size_t)num_clouds * 256 * sizeof(float), 256);
     return u + yp;
 }
 
@@ -204,7 +209,7 @@ extern "C" int epc_vlad_head_fwd(const float* V, const float* colss, const void*
             return EPC_EINVAL;
     }
     EPC_CHECK_LAUNCH();
-    const int slices = kh / 256;
+    const int slices = kh / HSL;
     hipLaunchKernelGGL(hidden_gemm_kernel, dim3(8, slices, (num_clouds + 63) / 64), dim3(64), 0, st, U, Hw,
                        num_clouds, kh, Yp);
     EPC_CHECK_LAUNCH();

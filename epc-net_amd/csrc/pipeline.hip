@@ -45,7 +45,7 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
         w.rnorm = take(M * 4);
         w.afrag = take(M * 64 * 2);    // fp16 fragments
         w.vlad = take((size_t)mb * 65536 * 4);
-        w.colss = take((size_t)mb * 16 * 64 * 4);
+        w.colss = take((size_t)mb * 32 * 64 * 4);
         w.apart = take(M / 32 * 64 * 4);
         w.head = take(epc_vlad_head_workspace_bytes(mb, c->groups));
     } else {

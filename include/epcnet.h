@@ -174,8 +174,8 @@ int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* pac
 /* loupe.py:276-292: V[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] - a_sum[k] * centres[f][k] from the
  * fragment-ordered operands (fp16 MFMA, f32 accumulate; the 2^14 of assign_frag is removed), a_sum = the sum of the
  * n/32 per-tile partials `apart` of epc_conv5_assign_fwd, centres = cluster_weights2 (1024, 64) (the first 65536 floats of
- * the packed head stage).  Outputs V (num_clouds, 1024, 64) and colss (num_clouds, 16, 64): per cluster the sums of
- * V^2 over each slab of 64 features (what the intra-normalisation of :295 needs). */
+ * the packed head stage).  Outputs V (num_clouds, 1024, 64) and colss (num_clouds, 32, 64): per cluster the sums of
+ * V^2 over each chunk of 32 features (what the intra-normalisation of :295 needs). */
 int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
                            const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
 

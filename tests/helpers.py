@@ -86,7 +86,7 @@ def run_stages(eng, xyz):
         L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), 1, ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
                                          assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
         vlad = torch.empty((nc, 1024, 64), dtype=torch.float32, device=dev)
-        colss = torch.empty((nc, 16, 64), dtype=torch.float32, device=dev)
+        colss = torch.empty((nc, 32, 64), dtype=torch.float32, device=dev)
         L.check(lib.epc_vlad_aggregate_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(), apart.data_ptr(),
                                            off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
         wsb = lib.epc_vlad_head_workspace_bytes(nc, cfg.groups)

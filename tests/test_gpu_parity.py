@@ -150,7 +150,7 @@ def test_stages_against_oracle(dev, arch, kind, n):
         v = got["vlad"].cpu().numpy()      # aggregate - a_sum * centres (loupe.py:286-292)
         # worst case = the all-zero padding cloud (every point identical: the fp16 rounding of feat does not average out)
         close(v, st.taps["vlad_raw"], 2e-3 if kind == "zeros" else 2.0 ** -11, "vlad")
-        colss = (got["vlad"].double() ** 2).reshape(v.shape[0], 16, 64, 64).sum(2)
+        colss = (got["vlad"].double() ** 2).reshape(v.shape[0], 32, 32, 64).sum(2)
         close(got["colss"], colss.cpu().numpy(), 1e-5, "column sums of squares")
     else:
         close(got["pooled"], st.taps["maxpool"], 2e-5, "maxpool")
