@@ -346,7 +346,9 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
 //                                           -> out0 = dbeta, out1 = dgamma            (BatchNorm backward)
 // C must be a multiple of 4 (every BatchNorm site of the network has 64, 256 or 1024 channels).
 // ----------------------------------------------------------------------------------------------------------------
+#ifndef CR_ROWS
 #define CR_ROWS 256      // rows per workgroup
+#endif
 #define CR_COUNTERS 64   // counter slots at the head of the workspace: C <= 4096
 
 struct BnAffine {  // y = z * s + t, the expression the forward and the backward mask must share bit for bit
