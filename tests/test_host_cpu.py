@@ -109,6 +109,29 @@ def test_forward_fails_loudly_without_gpu():
         M.forward(x, False, params=H.PARAMS)
 
 
+def test_submit_fails_loudly_without_gpu_and_micro_batch_mirror():
+    """The throughput entry point has no CPU fallback either; lib.micro_batch_of mirrors micro_batch() of pipeline.hip
+    (the workspace the library asks for is per pass, so it stops growing at the micro-batch)."""
+    import ctypes
+    L, E, V = H.pkg("lib"), H.pkg("engine"), H.pkg("variables")
+    for arch, default in (("epc-net", 64), ("epc-net-l", 256)):
+        cfg = E.make_cfg(arch, 4096, H.PARAMS)
+        assert [L.micro_batch_of(cfg, n) for n in (1, default - 1, default, 10 * default)] == [1, default - 1, default, default]
+        ws = [L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), n) for n in (default - 1, default, 10 * default)]
+        assert ws[0] < ws[1] == ws[2]
+        cfg2 = E.make_cfg(arch, 4096, H.PARAMS, micro_batch=8)
+        assert L.micro_batch_of(cfg2, 100) == 8 and L.micro_batch_of(cfg2, 3) == 3
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    st = V.reset_default_store(device="cpu", seed=0)
+    eng = E.InferenceEngine("epc-net", H.PARAMS, st, in_flight=2)
+    with pytest.raises(L.EpcNetError):
+        eng.submit(torch.zeros(1, 64, 3))
+    with pytest.raises(L.EpcNetError):
+        eng.submit(torch.zeros(1, 64, 4))          # INPUT_DIM != 3 is rejected before any device work
+    eng.drain()                                    # nothing submitted: a no-op
+
+
 def test_forward_argument_errors():
     V = H.pkg("variables")
     V.reset_default_store(device="cpu", seed=0)
