@@ -73,6 +73,76 @@ __device__ __forceinline__ void bitonic_registers(KEY* __restrict__ keys, int ti
     __syncthreads();
 }
 
+// n <= 4096: two-level sort of the (unique: the low 12 bits are the point index) 32-bit keys in place of the 78-stage
+// network.  Level 1 is a counting sort by the top 12 bits (4096 buckets, LDS atomics: the order INSIDE a bucket is
+// whatever the atomics made it); level 2 ranks every key inside its bucket by counting the smaller keys there (a bucket
+// holds ~1 key on volumetric clouds, ~16 on planes).  Unique keys make the result independent of the atomics' order, i.e.
+// identical to the network's.  Returns false, with keysA untouched, when a bucket holds more than SORT_BUCKET_MAX keys
+// (degenerate clouds: many points in one cell) -- the caller then runs the network.  Keys of the padding (index >= n)
+// are not sorted: they are ~0u and follow the n real keys.
+#define SORT_BUCKET_MAX 64
+__device__ __forceinline__ bool bucket_sort_4096(unsigned int* __restrict__ keysA, unsigned int* __restrict__ keysB,
+                                                 unsigned int* __restrict__ hist /* 4097 */, int n, int tid) {
+    __shared__ unsigned int wave_tot[SORT_THREADS / 64];
+    __shared__ unsigned int s_max;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist[tid + i * SORT_THREADS] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    unsigned int k[4], slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = tid + i * SORT_THREADS;
+        k[i] = keysA[j];
+        slot[i] = j < n ? atomicAdd(&hist[k[i] >> 20], 1u) : 0u;
+    }
+    __syncthreads();
+    // exclusive scan of the 4096 counts: thread t owns buckets 4t .. 4t+3
+    unsigned int c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = hist[4 * tid + q];
+    const unsigned int local = (c[0] + c[1]) + (c[2] + c[3]);
+    unsigned int mx = max(max(c[0], c[1]), max(c[2], c[3]));
+    unsigned int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+        mx = max(mx, (unsigned int)__shfl_xor(mx, off));
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    if (s_max > SORT_BUCKET_MAX) return false;   // the same answer in every thread
+    unsigned int base = incl - local;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    hist[4 * tid] = base;
+    hist[4 * tid + 1] = base + c[0];
+    hist[4 * tid + 2] = base + c[0] + c[1];
+    hist[4 * tid + 3] = base + c[0] + c[1] + c[2];
+    if (tid == SORT_THREADS - 1) hist[4 * SORT_THREADS] = base + local;   // = n
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (tid + i * SORT_THREADS < n) keysB[hist[k[i] >> 20] + slot[i]] = k[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = tid + i * SORT_THREADS;
+        if (j < n) {
+            const unsigned int b = k[i] >> 20, lo = hist[b], hi = hist[b + 1];
+            unsigned int rank = 0;
+            for (unsigned int q = lo; q < hi; ++q) rank += keysB[q] < k[i] ? 1u : 0u;
+            keysA[lo + rank] = k[i];
+        } else {
+            keysA[j] = ~0u;   // (j >= n: a padding slot stays a padding slot)
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
 __global__ __launch_bounds__(SORT_THREADS) void morton_sort_kernel(const float* __restrict__ xyz, int n, int npow2,
                                                                    float* __restrict__ xyz_sorted,
                                                                    int32_t* __restrict__ perm) {
@@ -140,7 +210,9 @@ __global__ __launch_bounds__(SORT_THREADS) void morton_sort_kernel(const float* 
     }
     __syncthreads();
     if (narrow) {
-        bitonic_registers<4, unsigned int>(keys32, tid);
+        // (the LDS behind the 4-B keys holds the second key array and, past the 8-B key area, the 4097 bucket counters)
+        if (!bucket_sort_4096(keys32, keys32 + npow2, reinterpret_cast<unsigned int*>(keys + npow2), n, tid))
+            bitonic_registers<4, unsigned int>(keys32, tid);
     } else if (npow2 == 8 * SORT_THREADS) {
         bitonic_registers<8, unsigned long long>(keys, tid);
     } else if (npow2 == 16 * SORT_THREADS) {
@@ -178,7 +250,9 @@ extern "C" int epc_morton_sort(const float* xyz, int num_clouds, int n, float* x
     if (num_clouds == 0) return EPC_OK;
     int npow2 = 2;
     while (npow2 < n) npow2 <<= 1;
-    const size_t lds_bytes = (size_t)npow2 * sizeof(unsigned long long);
+    // keys (8 B each; the n <= 4096 path splits the area into two 4-B key arrays) + that path's 4097 bucket counters
+    const size_t lds_bytes = (size_t)npow2 * sizeof(unsigned long long) +
+                             (npow2 == 4 * SORT_THREADS ? (size_t)(npow2 + 4) * sizeof(unsigned int) : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(morton_sort_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
