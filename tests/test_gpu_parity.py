@@ -52,8 +52,35 @@ def _morton_sort(pc, dev):
     return out.cpu().numpy(), perm.cpu().numpy()
 
 
+def _hilbert30(q):
+    """30-bit Hilbert-curve index of 10-bit cells (Skilling's transpose algorithm), numpy restatement of sort.hip."""
+    X = [q[:, 0].astype(np.uint32).copy(), q[:, 1].astype(np.uint32).copy(), q[:, 2].astype(np.uint32).copy()]
+    Q = 512
+    while Q > 1:
+        P = np.uint32(Q - 1)
+        for i in range(3):
+            m = (X[i] & np.uint32(Q)) != 0
+            X[0] = np.where(m, X[0] ^ P, X[0])
+            t = np.where(~m, (X[0] ^ X[i]) & P, 0).astype(np.uint32)
+            X[0] = X[0] ^ t
+            X[i] = X[i] ^ t
+        Q >>= 1
+    X[1] = X[1] ^ X[0]
+    X[2] = X[2] ^ X[1]
+    t = np.zeros_like(X[0])
+    Q = 512
+    while Q > 1:
+        t = np.where((X[2] & np.uint32(Q)) != 0, t ^ np.uint32(Q - 1), t)
+        Q >>= 1
+    code = np.zeros(len(t), dtype=np.uint64)
+    for bit in range(10):
+        for d in range(3):          # X[0] carries the most significant bit of every triple
+            code |= (((X[d] ^ t) >> np.uint32(bit)) & np.uint32(1)).astype(np.uint64) << np.uint64(3 * bit + (2 - d))
+    return code
+
+
 @pytest.mark.parametrize("kind,n", [("uniform", 4096), ("lidar", 4096), ("uniform", 100), ("zeros", 64), ("dup", 256)])
-def test_morton_sort_is_a_z_order_permutation(dev, kind, n):
+def test_spatial_sort_is_a_hilbert_order_permutation(dev, kind, n):
     pc = O.synthetic_clouds(2, n, 3, kind)
     srt, perm = _morton_sort(pc, dev)
     for b in range(2):
@@ -63,10 +90,7 @@ def test_morton_sort_is_a_z_order_permutation(dev, kind, n):
         ext = hi - lo
         scale = np.where(ext > 0, np.float32(1023.0) / np.where(ext > 0, ext, 1), 0).astype(np.float32)
         q = np.clip(((srt[b] - lo) * scale), 0, 1023).astype(np.uint32)
-        code = np.zeros(n, dtype=np.uint64)
-        for bit in range(10):
-            for d in range(3):
-                code |= ((q[:, d] >> bit) & 1).astype(np.uint64) << np.uint64(3 * bit + d)
+        code = _hilbert30(q)
         npow2 = 1 << int(np.ceil(np.log2(max(n, 2))))
         if npow2 == 4096:    # sort.hip: 32-bit keys = top 20 bits of the code | 12-bit index
             key = ((code >> np.uint64(10)) << np.uint64(12)) | perm[b].astype(np.uint64)
