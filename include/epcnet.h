@@ -113,7 +113,8 @@ int epc_profile_elapsed_ms(epc_profile* prof, float* stage_ms /* host, EPC_NUM_S
 /* Stage entry points (what epc_net_forward chains; exported for parity tests and for op-level callers).    */
 /* ------------------------------------------------------------------------------------------------------ */
 
-/* Morton (Z-order) sort of each cloud's points: xyz (num_clouds,N,3) -> xyz_sorted, optional perm (num_clouds,N)
+/* Spatial sort of each cloud's points along the 3-D Hilbert curve (10-bit cells of the cloud's bounding box; ties by
+ * point index; the entry point keeps its first name): xyz (num_clouds,N,3) -> xyz_sorted, optional perm (num_clouds,N)
  * with xyz_sorted[r] = xyz[perm[r]].  No reference counterpart: descriptors are permutation-invariant, the
  * pipeline sorts first so that kNN tiles are spatially tight and gathers are cache-local.  N <= 16384. */
 int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm, void* stream);
