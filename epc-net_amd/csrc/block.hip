@@ -118,6 +118,36 @@ __device__ __forceinline__ void stage_to_bop(const float* st, bf16x8 (&bh)[4], b
 }
 
 // ---- shared pieces of the two block kernels ------------------------------------------------------------------
+// A point's first 20 neighbour indices from its list row of `cap` slots: 4-byte entries (epc_knn_topk) or 2-byte entries
+// (the fused pipeline, epc_knn_topk_conv1 with idx_u16: 64-B rows, half the index traffic).  `u16` is wave-uniform.
+__device__ __forceinline__ void load_nb20(const char* lists, unsigned row, int cap, bool u16, int (&nb)[EPC_KNN_SELECT]) {
+    static_assert(EPC_KNN_SELECT == 20, "five int4 / two int4 + one int2 per row");
+    if (u16) {
+        const char* r = lists + (size_t)row * cap * 2;
+        const uint4 a = *reinterpret_cast<const uint4*>(r), b = *reinterpret_cast<const uint4*>(r + 16);
+        const uint2 c = *reinterpret_cast<const uint2*>(r + 32);
+        const unsigned int w[10] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y};
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            nb[2 * k] = (int)(w[k] & 0xffffu);
+            nb[2 * k + 1] = (int)(w[k] >> 16);
+        }
+    } else {
+        const int4* il = reinterpret_cast<const int4*>(lists + (size_t)row * cap * 4);
+#pragma unroll
+        for (int m4 = 0; m4 < EPC_KNN_SELECT / 4; ++m4) {
+            const int4 t = il[m4];
+            nb[4 * m4] = t.x;
+            nb[4 * m4 + 1] = t.y;
+            nb[4 * m4 + 2] = t.z;
+            nb[4 * m4 + 3] = t.w;
+        }
+    }
+}
+__device__ __forceinline__ int list_entry(const void* lists, size_t slot, bool u16) {
+    return u16 ? (int)reinterpret_cast<const unsigned short*>(lists)[slot] : reinterpret_cast<const int32_t*>(lists)[slot];
+}
+
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so
 // giving each group a CONTIGUOUS range of tiles keeps all tiles of a cloud -- which gather from the same rows of x --
 // behind one L2 instead of eight.  Speed only: any mapping is correct.
@@ -132,7 +162,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
 
 // ---- f32 rows, split-bf16 layers (EPC-Net-L; f32-accurate at every stage boundary) -------------------------------
 __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
-    const float* __restrict__ x, const float* __restrict__ xyz, const int32_t* __restrict__ idx,
+    const float* __restrict__ x, const float* __restrict__ xyz, const void* __restrict__ idx, int idx_u16,
     const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
     int has_next, int total_points, int n, float kdiv, float* __restrict__ out, int out_stride, int out_off,
     float* __restrict__ x_next) {
@@ -157,7 +187,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const char* xc = reinterpret_cast<const char*>(x) + (size_t)cloud_base * 256;  // 256-B rows
     auto row32 = [&](int row) { return *reinterpret_cast<const float4*>(xc + (unsigned)(row * 256 + q * 16)); };
     const int wg0 = __builtin_amdgcn_readfirstlane(g0);
-    const int32_t* idx_w = idx + (size_t)wg0 * cap;  // this wave's 32 index rows
+    const bool u16 = idx_u16 != 0;
     const float rk = 1.0f / kdiv;
     // a / kdiv, correctly rounded for ordinary operands: quotient estimate + one exact-remainder correction
     auto div_k = [&](float a) {
@@ -173,18 +203,10 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
         const int c = cnt[g];
         const bool ovf = c > cap;
         // every row holds >= 20 valid entries (cnt >= 20 by construction); ties beyond 20 are the rare tail
-        const int4* il = reinterpret_cast<const int4*>(idx_w + (unsigned)((4 * s + p) * cap));
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ovf) {
             int nb[EPC_KNN_SELECT];
-#pragma unroll
-            for (int m4 = 0; m4 < EPC_KNN_SELECT / 4; ++m4) {
-                const int4 t = il[m4];
-                nb[4 * m4] = t.x;
-                nb[4 * m4 + 1] = t.y;
-                nb[4 * m4 + 2] = t.z;
-                nb[4 * m4 + 3] = t.w;
-            }
+            load_nb20(reinterpret_cast<const char*>(idx), (unsigned)(wg0 + 4 * s + p), cap, u16, nb);
             float4 v[EPC_KNN_SELECT];
 #pragma unroll
             for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(nb[m]);
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
                 acc.w += v[m].w;
             }
             for (int m = EPC_KNN_SELECT; m < c; ++m) {
-                const float4 w = row32(idx[(size_t)g * cap + m]);
+                const float4 w = row32(list_entry(idx, (size_t)g * cap + m, u16));
                 acc.x += w.x;
                 acc.y += w.y;
                 acc.z += w.z;
@@ -334,7 +356,7 @@ __device__ __forceinline__ void stage16_to_bop(const unsigned short* st, f16x8 (
 #define BLK16_LDS_BYTES (BLK_PACK * 4 + BLK16_WAVES * 32 * ST16 * 2)
 
 __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
-    const unsigned short* __restrict__ x16, const float* __restrict__ xyz, const int32_t* __restrict__ idx,
+    const unsigned short* __restrict__ x16, const float* __restrict__ xyz, const void* __restrict__ idx, int idx_u16,
     const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
     int has_next, int total_points, int n, float kdiv, unsigned short* __restrict__ out16, int out_stride, int out_off,
     unsigned short* __restrict__ x_next16) {
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
         }
     };
     const int wg0 = __builtin_amdgcn_readfirstlane(g0);
-    const int32_t* idx_w = idx + (size_t)wg0 * cap;
+    const bool u16 = idx_u16 != 0;
     const float rk = 1.0f / kdiv;
     auto div_k = [&](float a) {
         const float q0 = a * rk;
@@ -381,26 +403,18 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
         const int g = g0 + 8 * s + p;
         const int c = cnt[g];
         const bool ovf = c > cap;
-        const int4* il = reinterpret_cast<const int4*>(idx_w + (unsigned)((8 * s + p) * cap));
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         if (!ovf) {
             int nb[EPC_KNN_SELECT];
-#pragma unroll
-            for (int m4 = 0; m4 < EPC_KNN_SELECT / 4; ++m4) {
-                const int4 t = il[m4];
-                nb[4 * m4] = t.x;
-                nb[4 * m4 + 1] = t.y;
-                nb[4 * m4 + 2] = t.z;
-                nb[4 * m4 + 3] = t.w;
-            }
+            load_nb20(reinterpret_cast<const char*>(idx), (unsigned)(wg0 + 8 * s + p), cap, u16, nb);
             u32x4 raw[EPC_KNN_SELECT];
 #pragma unroll
             for (int m = 0; m < EPC_KNN_SELECT; ++m) raw[m] = row16(nb[m]);
 #pragma unroll
             for (int m = 0; m < EPC_KNN_SELECT; ++m) add_row(acc, raw[m]);  // ascending j, one rounding per add
-            for (int m = EPC_KNN_SELECT; m < c; ++m) add_row(acc, row16(idx[(size_t)g * cap + m]));
+            for (int m = EPC_KNN_SELECT; m < c; ++m) add_row(acc, row16(list_entry(idx, (size_t)g * cap + m, u16)));
         }
         if (__any(ovf)) {
             // more than `cap` entries satisfy a_ij >= kth (ties / zero-padded cloud): exact scan of the row
@@ -495,7 +509,7 @@ extern "C" int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num
     return EPC_OK;
 }
 
-extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const int32_t* idx,
+extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const void* idx, int idx_u16,
                                        const int32_t* cnt, const float* kth, int cap, const void* packed_block,
                                        int has_next, int num_clouds, int n, int knn, float* out, void* out16,
                                        int out_stride, int out_off, float* x_next, void* x_next16, void* stream) {
@@ -526,12 +540,12 @@ extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const fl
     const unsigned blocks = (unsigned)((total + wpb * 32 - 1) / (wpb * 32));
     if (f16)
         hipLaunchKernelGGL(proxyconv_block_f16_kernel, dim3(blocks), dim3(BLK16_THREADS), lds_bytes, (hipStream_t)stream,
-                           (const unsigned short*)x16, xyz, idx, cnt, kth, cap, (const float*)packed_block, has_next,
+                           (const unsigned short*)x16, xyz, idx, idx_u16, cnt, kth, cap, (const float*)packed_block, has_next,
                            (int)total, n, (float)knn, (unsigned short*)out16, out_stride, out_off,
                            (unsigned short*)x_next16);
     else
         hipLaunchKernelGGL(proxyconv_block_kernel, dim3(blocks), dim3(BLK_THREADS), lds_bytes, (hipStream_t)stream, x,
-                           xyz, idx, cnt, kth, cap, (const float*)packed_block, has_next, (int)total, n, (float)knn,
+                           xyz, idx, idx_u16, cnt, kth, cap, (const float*)packed_block, has_next, (int)total, n, (float)knn,
                            out, out_stride, out_off, x_next);
     EPC_CHECK_LAUNCH();
     return EPC_OK;

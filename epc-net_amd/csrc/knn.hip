@@ -110,7 +110,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                                                                       float* __restrict__ kth_out,
                                                                       const float* __restrict__ conv1_pack,
                                                                       float* __restrict__ x32,
-                                                                      unsigned short* __restrict__ x16) {
+                                                                      unsigned short* __restrict__ x16, int idx_u16) {
     extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, then 2 float4 per tile (lo, hi)
     const int ntiles = (n + KNN_CT - 1) / KNN_CT;
     const int npad = ntiles * KNN_CT;
@@ -278,6 +278,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     // ---- pass 2: emit {j : a_ij >= kth} = {j : d'_ij <= -kth} ascending ----
     int count = 0;
     int32_t* my = idx + ((size_t)cloud * n + (valid ? i : 0)) * cap;
+    // idx_u16 (wave-uniform): the lists are written as 2-byte entries (the fused pipeline's format: half the list
+    // traffic of the kNN kernel and of every block kernel; n <= 65535)
+    unsigned short* my16 = reinterpret_cast<unsigned short*>(idx) + ((size_t)cloud * n + (valid ? i : 0)) * cap;
     const float dk = -kth;
     // every member of a final set was a (non-strict) hit when pass 1 saw it (thresholds only tighten), so only the
     // batches flagged in the wave's hit mask are re-visited, in ascending order -- no bounding-box tests here
@@ -305,7 +308,12 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u)
                     if (d[u] <= dk) {
-                        if (valid && count < cap) my[count] = c * KNN_CT + k0 + u;
+                        if (valid && count < cap) {
+                            if (idx_u16)
+                                my16[count] = (unsigned short)(c * KNN_CT + k0 + u);
+                            else
+                                my[count] = c * KNN_CT + k0 + u;
+                        }
                         ++count;
                     }
             }
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
 }
 
 static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
-                      const float* conv1_pack, float* x32, void* x16, void* stream, const char* who) {
+                      const float* conv1_pack, float* x32, void* x16, int idx_u16, void* stream, const char* who) {
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
     if (n <= KNN_LDS_MAX_N) {
         const int ntiles = (n + KNN_CT - 1) / KNN_CT;
@@ -416,10 +424,10 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
         }
         if (conv1_pack)
             hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, true>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16);
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16, idx_u16);
         else
             hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, false>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr);
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0);
     } else {
         hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
                            xyz, n, cap, idx, cnt, kth);
@@ -435,22 +443,24 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
                   "need num_points >= 20 (tf.nn.top_k k=20)");
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
-    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, stream, __func__);
+    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, stream, __func__);
 }
 
-extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt,
+extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt,
                                   float* kth, const void* packed_conv1, float* x, void* x16, void* stream) {
     EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_conv1 && (x || x16), "null pointer");
+    EPC_CHECK_ARG(!idx_u16 || (n <= 65535 && n <= KNN_LDS_MAX_N), "2-byte lists need num_points <= 8192 (the LDS kernel)");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT,
                   "need num_points >= 20 (tf.nn.top_k k=20)");
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
     if (n > KNN_LDS_MAX_N) {   // the streaming kNN kernel keeps no cloud image: two launches
-        int rc = launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, stream, __func__);
+        int rc = launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, nullptr, nullptr, nullptr, 0, stream, __func__);
         if (rc != EPC_OK) return rc;
         return epc_conv1_fwd(xyz, packed_conv1, num_clouds * n, x, x16, stream);
     }
-    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, (const float*)packed_conv1, x, x16, stream, __func__);
+    return launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, (const float*)packed_conv1, x, x16, idx_u16, stream,
+                      __func__);
 }
 
 extern "C" int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask,

@@ -151,11 +151,17 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
     TRY(mark(prof, EPC_STAGE_KNN, stream));
     // kNN graph + conv1 in one launch (the kNN workgroup already holds the cloud in LDS); a stage profile therefore
     // reports conv1 inside the kNN stage
-    TRY(epc_knn_topk_conv1(pc, nc, n, EPC_KNN_CAP, idx, cnt, kth, pk + epc_net_packed_offset(cfg, 0), xs[0], xs16[0], stream));
+#ifdef PIPE_NO_U16
+    const int idx_u16 = 0;
+#else
+    const int idx_u16 = n <= 8192;   // 2-byte neighbour lists wherever the LDS kNN kernel runs
+#endif
+    TRY(epc_knn_topk_conv1(pc, nc, n, EPC_KNN_CAP, idx, idx_u16, cnt, kth, pk + epc_net_packed_offset(cfg, 0), xs[0], xs16[0],
+                           stream));
     for (int b = 1; b <= nblocks; ++b) {
         TRY(mark(prof, EPC_STAGE_BLOCK1 + b - 1, stream));
         const int has_next = b < nblocks;
-        TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], xs16[(b - 1) & 1], pc, idx, cnt, kth, EPC_KNN_CAP,
+        TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], xs16[(b - 1) & 1], pc, idx, idx_u16, cnt, kth, EPC_KNN_CAP,
                                     pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn,
                                     f16 ? nullptr : cat, f16 ? (void*)cat : nullptr, ccat, 64 * (b - 1), xs[b & 1],
                                     xs16[b & 1], stream));

@@ -78,11 +78,11 @@ _lib.epc_net_workspace_bytes.argtypes = [POINTER(EpcCfg), c_int]
 _lib.epc_net_forward.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P]
 _lib.epc_net_forward_overlapped.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, POINTER(_P), c_int]
 _lib.epc_knn_topk.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P]
-_lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]
+_lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
 _lib.epc_knn_mask.argtypes = [_P, _P, c_int, c_int, _P, _P]
 _lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
-_lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int,
-                                         c_int, _P, _P, _P]
+_lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P,
+                                         c_int, c_int, _P, _P, _P]
 _lib.epc_conv5_assign_fwd.argtypes = [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
 _lib.epc_vlad_aggregate_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]
 _lib.epc_vlad_head_workspace_bytes.restype = c_size_t

@@ -136,8 +136,10 @@ int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, floa
  * be NULL): EPC-Net's blocks consume the fp16 rows, EPC-Net-L's the f32 rows. */
 int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16, void* stream);
 /* epc_knn_topk and epc_conv1_fwd of the same (sorted) clouds in ONE launch: the kNN workgroup holds the cloud in LDS, so
- * conv1 costs it ~1.5 % more work instead of a launch of its own.  Bit-identical to the two separate calls. */
-int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
+ * conv1 costs it ~1.5 % more work instead of a launch of its own.  Bit-identical to the two separate calls.
+ * idx_u16 != 0: the lists are written as uint16 entries (cap slots per point; n <= 8192) -- the pipeline's format, half
+ * the list bytes for this kernel and for every epc_proxyconv_block_fwd that reads them. */
+int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
                        const void* packed_conv1, float* x, void* x16, void* stream);
 
 /* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
@@ -150,8 +152,10 @@ int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, int32_t
  *     crosses HBM is fp16 and every MFMA operand is one fp16 value per activation against fp16 hi+lo weights; sums,
  *     mean, xm - x, t + xm and the accumulators are f32.  The roundings are independent per point and channel and
  *     average out in the VLAD aggregation (descriptor effect 6e-7). */
-int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const int32_t* idx, const int32_t* cnt,
-                            const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
+/* idx: the neighbour lists of epc_knn_topk (int32 entries, idx_u16 = 0) or of epc_knn_topk_conv1 with idx_u16 = 1
+ * (uint16 entries, cap slots per point either way). */
+int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const void* idx, int idx_u16,
+                            const int32_t* cnt, const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
                             int n, int knn, float* out, void* out16, int out_stride, int out_off, float* x_next,
                             void* x_next16, void* stream);
 

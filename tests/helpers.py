@@ -61,6 +61,7 @@ def run_stages(eng, xyz):
     kth = torch.empty((nc, n), dtype=torch.float32, device=dev)
     L.check(lib.epc_knn_topk(xyz.data_ptr(), nc, n, L.EPC_KNN_CAP, idx.data_ptr(), cnt.data_ptr(), kth.data_ptr(), st))
     out.update(idx=idx, cnt=cnt, kth=kth)
+    idx16 = idx.clamp(0, 32767).to(torch.int16)     # the pipeline's 2-byte list format (entries past cnt are never read)
     nblocks = 4 if eng.arch == "epc-net" else 2
     ccat = 64 * nblocks
     dt = torch.float16 if f16 else torch.float32
@@ -71,7 +72,10 @@ def run_stages(eng, xyz):
     L.check(lib.epc_conv1_fwd(xyz.data_ptr(), off(0), M, a32(xs[0]), a16(xs[0]), st))
     for b in range(1, nblocks + 1):
         has_next = 1 if b < nblocks else 0
-        L.check(lib.epc_proxyconv_block_fwd(a32(xs[b - 1]), a16(xs[b - 1]), xyz.data_ptr(), idx.data_ptr(),
+        # (lists: the int32 form for odd blocks, the pipeline's uint16 form for even ones -- both must give the same rows)
+        u16 = (b % 2 == 0) and n <= 8192
+        L.check(lib.epc_proxyconv_block_fwd(a32(xs[b - 1]), a16(xs[b - 1]), xyz.data_ptr(),
+                                            (idx16 if u16 else idx).data_ptr(), 1 if u16 else 0,
                                             cnt.data_ptr(), kth.data_ptr(), L.EPC_KNN_CAP, off(b), has_next, nc, n,
                                             cfg.knn, a32(cat), a16(cat), ccat, 64 * (b - 1), a32(xs[b]), a16(xs[b]),
                                             st))

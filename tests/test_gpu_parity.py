@@ -279,12 +279,23 @@ def test_knn_conv1_fused_launch_is_bit_identical(dev, nc, n):
     L.check(lib.epc_knn_topk(xyz.data_ptr(), nc, n, 32, i0.data_ptr(), c0.data_ptr(), k0.data_ptr(), st))
     L.check(lib.epc_conv1_fwd(xyz.data_ptr(), pk, nc * n, x0.data_ptr(), h0.data_ptr(), st))
     i1, c1, k1, x1, h1 = buffers()
-    L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, i1.data_ptr(), c1.data_ptr(), k1.data_ptr(), pk,
+    L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, i1.data_ptr(), 0, c1.data_ptr(), k1.data_ptr(), pk,
                                    x1.data_ptr(), h1.data_ptr(), st))
     torch.cuda.synchronize()
     assert torch.equal(c0, c1) and torch.equal(k0, k1)
     m = torch.arange(32, device=dev)[None, None, :] < c0.clamp(max=32)[..., None]
     assert torch.equal(i0 * m, i1 * m)
+    if n <= 8192:    # the pipeline's 2-byte lists hold the same entries
+        i2 = torch.zeros((nc, n, 32), dtype=torch.int16, device=dev)
+        _, c2, k2, x2, h2 = buffers()
+        L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, i2.data_ptr(), 1, c2.data_ptr(), k2.data_ptr(), pk,
+                                       x2.data_ptr(), h2.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert torch.equal(c0, c2) and torch.equal(k0, k2) and torch.equal(i0 * m, i2.int() * m)
+    else:
+        rc = lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, i1.data_ptr(), 1, c1.data_ptr(), k1.data_ptr(), pk,
+                                    x1.data_ptr(), h1.data_ptr(), st)
+        assert rc == -1                      # 2-byte lists only with the LDS kernel (n <= 8192)
     assert torch.equal(x0, x1) and torch.equal(h0.view(torch.int16), h1.view(torch.int16))
     assert float(x1.abs().sum()) > 0
 
