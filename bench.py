@@ -21,6 +21,8 @@ Extra objects on the JSON line:
   overlapped   a second timed region after the first: the same K steps with --in-flight (2) of them in flight on the
                engine's HIP streams (InferenceEngine.submit).  Reported beside `value`, never as `value`: kernels that
                share the chip take longer individually, so the roofline figures belong to the one-stream region.
+  pipeline_hbm HBM bytes one step moves (PMC counters of the committed profile x launches per step) over the step time,
+               against 8 TB/s -- the north_star's "fraction of the HBM roofline"; secondary, the path is not HBM-bound.
   cpu_baseline the CPU oracle (numpy restatement of the reference's dense (N,N)-mask formulation, batch = 1 cloud per
                call as evaluate.py:86-90 does) timed on this box's host cores on a bounded sample.  Rank 0, N = 1 only.
                It is NOT TensorFlow (not installable here) -- kind "port".  `index_form`: the same oracle with neighbour
@@ -226,6 +228,19 @@ def main():
                            if k.startswith("void conv5_kernel<256, 0"))
     except Exception:
         traffic = None
+    # HBM bytes of ONE step = the PMC bytes per launch of the pipeline's kernels (profiles/pmc_hbm_current.json, collected
+    # by scripts/collect_profiles.sh on this configuration) x their launches per step: the figure behind "fraction of the
+    # HBM roofline" (north_star); the path is MFMA / VALU-bound, so it is a secondary number.
+    hbm_step = None
+    try:
+        per_step = {"morton_sort_kernel": 1, "void knn_topk_culled_kernel": 1, "proxyconv_block_f16_kernel": 4,
+                    "void conv5_kernel<256, 0": 1, "vlad_aggregate_kernel": 1, "void vlad_fold_kernel": 1,
+                    "hidden_gemm_kernel": 1, "head_finish_kernel": 1}
+        if args.arch == "epc-net" and args.batch == 64:
+            hbm_step = sum(v["hbm_bytes_per_launch_corrected"] * m for k, v in pm["kernels"].items()
+                           for pre, m in per_step.items() if k.startswith(pre))
+    except Exception:
+        hbm_step = None
     clouds = world * args.batch * args.steps
     value = clouds / elapsed
 
@@ -253,6 +268,11 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage.items()},
             "pipeline_tflops": round(value / world * FLOPS_PER_CLOUD[args.arch] / 1e12, 3),
         }
+        if hbm_step:
+            gbps = hbm_step / (elapsed / args.steps) / 1e9
+            line["pipeline_hbm"] = {"bytes_per_step": int(hbm_step), "achieved_GBps": round(gbps, 1), "peak_GBps": 8000.0,
+                                    "frac": round(gbps / 8000.0, 4),
+                                    "how": "PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/) x launches per step / ms_per_step"}
         if overlapped is not None:
             line["overlapped"] = overlapped
         if world == 1 and not args.no_cpu_baseline:
