@@ -78,6 +78,37 @@ __device__ __forceinline__ void topk_insert_key(int (&top)[20], int v) {
         : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
 }
 
+// The same network on the distances themselves: the list holds the 20 SMALLEST d' ascending (min in place, max carried
+// on), so the current threshold is top[19] as it stands and no candidate needs an order-preserving integer key (3
+// instructions per candidate of every hit batch).  v_min_f32 / v_max_f32 are single instructions in asm -- the extra
+// canonicalising v_max per slot that made the float form slower belongs to the compiler's fminf / fmaxf, not to the
+// hardware; no NaN can occur, d' = +0 for coincident points (never -0), and lanes without a hit push +inf.
+__device__ __forceinline__ void topk_insert_dist(float (&top)[20], float v) {
+    float t;
+    asm(
+        "v_max_f32 %[t], %[k0], %[v]\n\tv_min_f32 %[k0], %[k0], %[v]\n\t"
+        "v_max_f32 %[v], %[k1], %[t]\n\tv_min_f32 %[k1], %[k1], %[t]\n\t"
+        "v_max_f32 %[t], %[k2], %[v]\n\tv_min_f32 %[k2], %[k2], %[v]\n\t"
+        "v_max_f32 %[v], %[k3], %[t]\n\tv_min_f32 %[k3], %[k3], %[t]\n\t"
+        "v_max_f32 %[t], %[k4], %[v]\n\tv_min_f32 %[k4], %[k4], %[v]\n\t"
+        "v_max_f32 %[v], %[k5], %[t]\n\tv_min_f32 %[k5], %[k5], %[t]\n\t"
+        "v_max_f32 %[t], %[k6], %[v]\n\tv_min_f32 %[k6], %[k6], %[v]\n\t"
+        "v_max_f32 %[v], %[k7], %[t]\n\tv_min_f32 %[k7], %[k7], %[t]\n\t"
+        "v_max_f32 %[t], %[k8], %[v]\n\tv_min_f32 %[k8], %[k8], %[v]\n\t"
+        "v_max_f32 %[v], %[k9], %[t]\n\tv_min_f32 %[k9], %[k9], %[t]\n\t"
+        "v_max_f32 %[t], %[k10], %[v]\n\tv_min_f32 %[k10], %[k10], %[v]\n\t"
+        "v_max_f32 %[v], %[k11], %[t]\n\tv_min_f32 %[k11], %[k11], %[t]\n\t"
+        "v_max_f32 %[t], %[k12], %[v]\n\tv_min_f32 %[k12], %[k12], %[v]\n\t"
+        "v_max_f32 %[v], %[k13], %[t]\n\tv_min_f32 %[k13], %[k13], %[t]\n\t"
+        "v_max_f32 %[t], %[k14], %[v]\n\tv_min_f32 %[k14], %[k14], %[v]\n\t"
+        "v_max_f32 %[v], %[k15], %[t]\n\tv_min_f32 %[k15], %[k15], %[t]\n\t"
+        "v_max_f32 %[t], %[k16], %[v]\n\tv_min_f32 %[k16], %[k16], %[v]\n\t"
+        "v_max_f32 %[v], %[k17], %[t]\n\tv_min_f32 %[k17], %[k17], %[t]\n\t"
+        "v_max_f32 %[t], %[k18], %[v]\n\tv_min_f32 %[k18], %[k18], %[v]\n\t"
+        "v_max_f32 %[v], %[k19], %[t]\n\tv_min_f32 %[k19], %[k19], %[t]\n\t"
+        : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
+}
+
 #ifndef KNN_BATCH
 #define KNN_BATCH 8
 #endif
@@ -200,9 +231,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         sqi = me.w;
     }
     static_assert(KSEL == 20, "topk_insert_key is written for the 20-slot list");
-    int top[KSEL];  // fkey() of the KSEL largest a_ij seen, descending
+    float top[KSEL];  // the KSEL smallest d' = -a_ij seen, ascending: top[KSEL-1] is the current threshold
 #pragma unroll
-    for (int s = 0; s < KSEL; ++s) top[s] = fkey(-INFINITY);
+    for (int s = 0; s < KSEL; ++s) top[s] = INFINITY;
 
     auto lower_bound = [&](int c) {
         const float4 lo = bb[2 * c], hi = bb[2 * c + 1];
@@ -221,7 +252,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         // separate multiply and add (one instruction less per candidate)
         return __builtin_fmaf(-2.0f, inner, sqi) + q.w;
     };
-    float thr = INFINITY;  // current 20th smallest d' (= -a of top[KSEL-1]); candidates must be strictly below it
+#define thr top[KSEL - 1]   // current 20th smallest d'; candidates must be strictly below it
     auto scan1 = [&](int c) {
         KSTAT(0);
         if (!__any(valid && lower_bound(c) <= thr)) return;
@@ -247,16 +278,14 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                 }
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
-                    const int key = fkey(0.0f - d[u]);  // a_ij with -0.0 folded into +0.0
-                    // wave-UNIFORM branch; lanes without a hit push a key that falls straight through the network.
+                    // wave-UNIFORM branch; lanes without a hit push +inf, which falls straight through the network.
                     // (A per-lane `if` makes every slot a conditional update: +1 v_mov per slot to merge the paths.)
-                    const bool better = key > top[KSEL - 1];
+                    const bool better = d[u] < top[KSEL - 1];
                     if (__any(better)) {
                         KSTAT(3);
-                        topk_insert_key(top, better ? key : (int)0x80000000);
+                        topk_insert_dist(top, better ? d[u] : INFINITY);
                     }
                 }
-                thr = -fkey_inv(top[KSEL - 1]);
             }
         }
     };
@@ -272,8 +301,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         if (cl >= 0 && cl < ntiles) scan1(cl);
         if (cr < ntiles) scan1(cr);
     }
-    const int kkey = top[KSEL - 1];
-    const float kth = fkey_inv(kkey);
+#undef thr
+    const float kth = 0.0f - top[KSEL - 1];   // a = -d' (exact); +0 for coincident points
 
     // ---- pass 2: emit {j : a_ij >= kth} = {j : d'_ij <= -kth} ascending ----
     int count = 0;
