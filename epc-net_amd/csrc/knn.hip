@@ -82,7 +82,7 @@ __device__ __forceinline__ void topk_insert_key(int (&top)[20], int v) {
 // on), so the current threshold is top[19] as it stands and no candidate needs an order-preserving integer key (3
 // instructions per candidate of every hit batch).  v_min_f32 / v_max_f32 are single instructions in asm -- the extra
 // canonicalising v_max per slot that made the float form slower belongs to the compiler's fminf / fmaxf, not to the
-// hardware; no NaN can occur, d' = +0 for coincident points (never -0), and lanes without a hit push +inf.
+// hardware; no NaN can occur, d' = +0 for coincident points (never -0), and a value that is not below top[19] falls through.
 __device__ __forceinline__ void topk_insert_dist(float (&top)[20], float v) {
     float t;
     asm(
@@ -278,12 +278,12 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                 }
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
-                    // wave-UNIFORM branch; lanes without a hit push +inf, which falls straight through the network.
-                    // (A per-lane `if` makes every slot a conditional update: +1 v_mov per slot to merge the paths.)
-                    const bool better = d[u] < top[KSEL - 1];
-                    if (__any(better)) {
+                    // wave-UNIFORM branch; every lane pushes its d': one that is not below the lane's threshold is >= all 20
+                    // entries and falls straight through the network (min leaves each slot as it is), so no masking.
+                    // (A per-lane `if` would make every slot a conditional update: +1 v_mov per slot to merge the paths.)
+                    if (__any(d[u] < top[KSEL - 1])) {
                         KSTAT(3);
-                        topk_insert_dist(top, better ? d[u] : INFINITY);
+                        topk_insert_dist(top, d[u]);
                     }
                 }
             }
