@@ -109,6 +109,10 @@ __device__ __forceinline__ void topk_insert_dist(float (&top)[20], float v) {
         : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
 }
 
+// wave vote straight from the compare's lane mask (HIP's __any goes through an integer predicate: a v_cndmask and a second
+// compare per vote)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 #ifndef KNN_BATCH
 #define KNN_BATCH 8
 #endif
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #define thr top[KSEL - 1]   // current 20th smallest d'; candidates must be strictly below it
     auto scan1 = [&](int c) {
         KSTAT(0);
-        if (!__any(valid && lower_bound(c) <= thr)) return;
+        if (!wave_any(valid && lower_bound(c) <= thr)) return;
         KSTAT(1);
         const float4* tp = cand + c * KNN_CT;
 #pragma unroll
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                 d[u] = pos_sq_dist(q[u]);
                 hit |= valid && d[u] <= thr;   // non-strict: a batch without hits holds no member of any lane's final set
             }
-            if (__any(hit)) {
+            if (wave_any(hit)) {
                 KSTAT(2);
                 if (lane == 0) {
                     const int bit = c * BPT + k0 / KNN_BATCH;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                     // wave-UNIFORM branch; every lane pushes its d': one that is not below the lane's threshold is >= all 20
                     // entries and falls straight through the network (min leaves each slot as it is), so no masking.
                     // (A per-lane `if` would make every slot a conditional update: +1 v_mov per slot to merge the paths.)
-                    if (__any(d[u] < top[KSEL - 1])) {
+                    if (wave_any(d[u] < top[KSEL - 1])) {
                         KSTAT(3);
                         topk_insert_dist(top, d[u]);
                     }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                 d[u] = pos_sq_dist(q[u]);
                 hit |= d[u] <= dk;
             }
-            if (__any(hit)) {
+            if (wave_any(hit)) {
                 KSTAT(5);
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u)
