@@ -309,51 +309,61 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     const float kth = 0.0f - top[KSEL - 1];   // a = -d' (exact); +0 for coincident points
 
     // ---- pass 2: emit {j : a_ij >= kth} = {j : d'_ij <= -kth} ascending ----
-    int count = 0;
-    int32_t* my = idx + ((size_t)cloud * n + (valid ? i : 0)) * cap;
-    // idx_u16 (wave-uniform): the lists are written as 2-byte entries (the fused pipeline's format: half the list
-    // traffic of the kNN kernel and of every block kernel; n <= 65535)
-    unsigned short* my16 = reinterpret_cast<unsigned short*>(idx) + ((size_t)cloud * n + (valid ? i : 0)) * cap;
+    // The lists are 4-byte or (idx_u16, wave-uniform: the fused pipeline's format, half the list traffic of this kernel and
+    // of every block kernel) 2-byte entries; the loop is instantiated for each so that no format test sits on the emit path.
+    // A lane's slot address is its row start (a 32-bit byte offset from the cloud's lists, wave-uniform base) + the count.
+    unsigned int count = 0;
+    char* lists = reinterpret_cast<char*>(idx) + (size_t)cloud * n * cap * (idx_u16 ? 2 : 4);
     const float dk = -kth;
+    const unsigned int ucap = (unsigned int)cap;
     // every member of a final set was a (non-strict) hit when pass 1 saw it (thresholds only tighten), so only the
     // batches flagged in the wave's hit mask are re-visited, in ascending order -- no bounding-box tests here
-    for (int c = 0; c < ntiles; ++c) {
-        const int bit0 = c * BPT;
-        const unsigned int bits = (hitmask[bit0 >> 5] >> (bit0 & 31)) & ((1u << BPT) - 1u);
-        if (bits == 0u) continue;
-        KSTAT(4);
-        const float4* tp = cand + c * KNN_CT;
+    auto pass2 = [&](auto wide) {
+        constexpr int ESZ = decltype(wide)::value ? 4 : 2;
+        const unsigned int row = (unsigned int)(valid ? i : 0) * ucap * ESZ;
+        for (int c = 0; c < ntiles; ++c) {
+            const int bit0 = c * BPT;
+            const unsigned int bits = (hitmask[bit0 >> 5] >> (bit0 & 31)) & ((1u << BPT) - 1u);
+            if (bits == 0u) continue;
+            KSTAT(4);
+            const float4* tp = cand + c * KNN_CT;
 #pragma unroll
-        for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
-            if (!((bits >> (k0 / KNN_BATCH)) & 1u)) continue;
-            float4 q[KNN_BATCH];
+            for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+                if (!((bits >> (k0 / KNN_BATCH)) & 1u)) continue;
+                float4 q[KNN_BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
-            float d[KNN_BATCH];
-            bool hit = false;
+                for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
+                float d[KNN_BATCH];
+                bool hit = false;
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) {
-                d[u] = pos_sq_dist(q[u]);
-                hit |= d[u] <= dk;
-            }
-            if (wave_any(hit)) {
-                KSTAT(5);
+                for (int u = 0; u < KNN_BATCH; ++u) {
+                    d[u] = pos_sq_dist(q[u]);
+                    hit |= d[u] <= dk;
+                }
+                if (wave_any(hit)) {
+                    KSTAT(5);
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u)
-                    if (d[u] <= dk) {
-                        if (valid && count < cap) {
-                            if (idx_u16)
-                                my16[count] = (unsigned short)(c * KNN_CT + k0 + u);
-                            else
-                                my[count] = c * KNN_CT + k0 + u;
+                    for (int u = 0; u < KNN_BATCH; ++u)
+                        if (d[u] <= dk) {
+                            if (valid && count < ucap) {
+                                char* slot = lists + (row + count * ESZ);
+                                if (ESZ == 4)
+                                    *reinterpret_cast<int32_t*>(slot) = c * KNN_CT + k0 + u;
+                                else
+                                    *reinterpret_cast<unsigned short*>(slot) = (unsigned short)(c * KNN_CT + k0 + u);
+                            }
+                            ++count;
                         }
-                        ++count;
-                    }
+                }
             }
         }
-    }
+    };
+    if (idx_u16)
+        pass2(std::false_type{});
+    else
+        pass2(std::true_type{});
     if (valid) {
-        cnt[(size_t)cloud * n + i] = count;
+        cnt[(size_t)cloud * n + i] = (int32_t)count;
         kth_out[(size_t)cloud * n + i] = kth;
     }
 }
