@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=400.0, help="extra untimed steps after the warm-up (0 = none)")
     ap.add_argument("--batch", type=int, default=64, help="clouds per step per GPU (configs[1]: 64)")
     ap.add_argument("--arch", default="epc-net", choices=["epc-net", "epc-net-l"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "fast"],
+                    help="arithmetic of the EPC-Net path (include/epcnet.h EPC_PRECISION_*)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="steps kept in flight on the engine's HIP streams (InferenceEngine.submit); 1 = one stream")
     ap.add_argument("--profile-every", type=int, default=8,
@@ -142,7 +144,8 @@ def main():
     E = pkg("engine")
     store = build_store(args.arch, device, seed=0)            # same weights on every rank
     lanes = max(1, args.in_flight)
-    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch, in_flight=lanes)
+    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch, in_flight=lanes,
+                            precision=args.precision)
     g = torch.Generator(device="cpu")
     g.manual_seed(100 + rank)                                  # every rank extracts different clouds
     xyz = (torch.rand((args.batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)

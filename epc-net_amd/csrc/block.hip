@@ -318,6 +318,17 @@ __device__ __forceinline__ void layer_f16(const float* lw, const float* lbias, c
     }
 }
 
+// fp16 range guard (EPC_STATUS_FP16_RANGE): every value this kernel rounds to fp16 passes through range_track, which
+// keeps the packed maximum of the |bit patterns| (|fp16| orders like its bit pattern; Inf = 0x7c00, NaN above it) -- two
+// VALU instructions per pair of values; one compare per lane at the end decides.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void range_track(u16x2_t& m, unsigned int packed_pair) {
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_t, packed_pair & 0x7fff7fffu));
+}
+__device__ __forceinline__ void range_track4(u16x2_t& m, const u32x4& w) {
+    range_track(m, w[0]), range_track(m, w[1]), range_track(m, w[2]), range_track(m, w[3]);
+}
+
 // ReLU + removal of W5_SCALE + rounding to fp16 of 4 consecutive accumulator registers (= 4 consecutive channels)
 __device__ __forceinline__ uint2 relu_descale_pack4(const f32x16& a, int r0) {
     _Float16 hv[4];
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
     const unsigned short* __restrict__ x16, const float* __restrict__ xyz, const void* __restrict__ idx, int idx_u16,
     const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
     int has_next, int total_points, int n, float kdiv, unsigned short* __restrict__ out16, int out_stride, int out_off,
-    unsigned short* __restrict__ x_next16) {
+    unsigned short* __restrict__ x_next16, int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int o = tid * 4; o < BLK_PACK; o += BLK16_THREADS * 4) st4(lds + o, ld4(pack + o));
@@ -396,6 +407,11 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
         return __builtin_fmaf(__builtin_fmaf(-q0, kdiv, a), rk, q0);
     };
 
+    u16x2_t rmax = {0, 0};
+    auto report_range = [&]() {   // wave-uniform cloud: one atomic per wave, and only when something overflowed
+        const bool over = max(rmax[0], rmax[1]) >= 0x7c00;
+        if (status && __builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(status + g0 / n, EPC_STATUS_FP16_RANGE);
+    };
     // ---- gather-mean, 8 points per pass; t = xm - x staged as fp16 rows ----
     float xm[4][8];
 #pragma unroll
@@ -438,7 +454,9 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
             xm[s][e] = div_k(acc[e]);
             t16[e] = (_Float16)(xm[s][e] - (float)self[e]);
         }
-        *reinterpret_cast<u32x4*>(st + (8 * s + p) * ST16 + 8 * q) = __builtin_bit_cast(u32x4, t16);
+        const u32x4 tw = __builtin_bit_cast(u32x4, t16);
+        range_track4(rmax, tw);
+        *reinterpret_cast<u32x4*>(st + (8 * s + p) * ST16 + 8 * q) = tw;
     }
 
     // ---- conv_a, conv_b ----
@@ -452,6 +470,7 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
             const uint2 lo = relu_descale_pack4(a1[k4 >> 1], 8 * (k4 & 1)), hi = relu_descale_pack4(a1[k4 >> 1], 8 * (k4 & 1) + 4);
             u32x4 w;
             w[0] = lo.x, w[1] = lo.y, w[2] = hi.x, w[3] = hi.y;
+            range_track4(rmax, w);
             bop[k4] = __builtin_bit_cast(f16x8, w);
         }
     }
@@ -462,30 +481,40 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         unsigned short* row = st + (8 * s + p) * ST16 + 8 * q;
-        const f16x8 t16 = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(row));
+        const u32x4 t16w = *reinterpret_cast<const u32x4*>(row);   // conv_b's activations as acc_to_stage16 rounded them
+        const f16x8 t16 = __builtin_bit_cast(f16x8, t16w);
         f16x8 o16;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o16[e] = (_Float16)((float)t16[e] + xm[s][e]);
         const u32x4 ow = __builtin_bit_cast(u32x4, o16);
+        range_track4(rmax, t16w);
+        range_track4(rmax, ow);
         *reinterpret_cast<u32x4*>(out16 + (size_t)(g0 + 8 * s + p) * out_stride + out_off + 8 * q) = ow;
         *reinterpret_cast<u32x4*>(row) = ow;
     }
-    if (!has_next) return;
+    if (!has_next) {
+        report_range();
+        return;
+    }
 
     // ---- next block's leading conv -> fp16 rows ----
     stage16_to_bop(st, bop, lane);
     layer_f16(wn, bn, bop, a1, lane);
     acc_to_stage16(st, a1, lane);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        *reinterpret_cast<u32x4*>(x_next16 + (size_t)(g0 + 8 * s + p) * 64 + 8 * q) =
-            *reinterpret_cast<const u32x4*>(st + (8 * s + p) * ST16 + 8 * q);
+    for (int s = 0; s < 4; ++s) {
+        const u32x4 xw = *reinterpret_cast<const u32x4*>(st + (8 * s + p) * ST16 + 8 * q);
+        range_track4(rmax, xw);
+        *reinterpret_cast<u32x4*>(x_next16 + (size_t)(g0 + 8 * s + p) * 64 + 8 * q) = xw;
+    }
+    report_range();
 }
 
 // conv1 (models/epc-net.py:66-69): 3 -> 64, folded BN, ReLU.  16 lanes x float4 per point.
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ xyz, const float* __restrict__ pack,
                                                     int total_points, float* __restrict__ x,
-                                                    unsigned short* __restrict__ x16) {
+                                                    unsigned short* __restrict__ x16, int32_t* __restrict__ status,
+                                                    int n) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int g = t >> 4, q = t & 15;
     if (g >= total_points) return;
@@ -494,25 +523,35 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ xy
     const float4 b = ld4(pack + 192 + 4 * q);
     const float4 y = conv1_quad(px, py, pz, w0, w1, w2, b);
     if (x) st4(x + (size_t)g * 64 + 4 * q, y);
-    if (x16) reinterpret_cast<uint2*>(x16)[(size_t)g * 16 + q] = pack_half4(y);  // fp16 rows: block 1's gather source
+    if (x16) {
+        reinterpret_cast<uint2*>(x16)[(size_t)g * 16 + q] = pack_half4(y);  // fp16 rows: block 1's gather source
+        if (status && fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)) > 65504.0f) atomicOr(status + g / n, EPC_STATUS_FP16_RANGE);
+    }
+}
+
+// (library-internal form: with the per-cloud status words of the pipeline; n = points per cloud)
+int epc_conv1_launch(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
+                     int32_t* status, int n, void* stream) {
+    EPC_CHECK_ARG(xyz && packed_conv1 && (x || x16), "null pointer");
+    EPC_CHECK_ARG(num_points_total >= 0 && (!status || n > 0), "bad shape");
+    if (num_points_total == 0) return EPC_OK;
+    const long threads = (long)num_points_total * 16;
+    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       xyz, (const float*)packed_conv1, num_points_total, x, (unsigned short*)x16, status, n);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
 }
 
 extern "C" int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
                              void* stream) {
-    EPC_CHECK_ARG(xyz && packed_conv1 && (x || x16), "null pointer");
-    EPC_CHECK_ARG(num_points_total >= 0, "bad shape");
-    if (num_points_total == 0) return EPC_OK;
-    const long threads = (long)num_points_total * 16;
-    hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       xyz, (const float*)packed_conv1, num_points_total, x, (unsigned short*)x16);
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
+    return epc_conv1_launch(xyz, packed_conv1, num_points_total, x, x16, nullptr, 0, stream);
 }
 
 extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const void* idx, int idx_u16,
                                        const int32_t* cnt, const float* kth, int cap, const void* packed_block,
                                        int has_next, int num_clouds, int n, int knn, float* out, void* out16,
-                                       int out_stride, int out_off, float* x_next, void* x_next16, void* stream) {
+                                       int out_stride, int out_off, float* x_next, void* x_next16, int32_t* status,
+                                       void* stream) {
     const bool f16 = x16 != nullptr;
     EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_block, "null pointer");
     if (f16) {
@@ -542,7 +581,7 @@ extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const fl
         hipLaunchKernelGGL(proxyconv_block_f16_kernel, dim3(blocks), dim3(BLK16_THREADS), lds_bytes, (hipStream_t)stream,
                            (const unsigned short*)x16, xyz, idx, idx_u16, cnt, kth, cap, (const float*)packed_block, has_next,
                            (int)total, n, (float)knn, (unsigned short*)out16, out_stride, out_off,
-                           (unsigned short*)x_next16);
+                           (unsigned short*)x_next16, status);
     else
         hipLaunchKernelGGL(proxyconv_block_kernel, dim3(blocks), dim3(BLK_THREADS), lds_bytes, (hipStream_t)stream, x,
                            xyz, idx, idx_u16, cnt, kth, cap, (const float*)packed_block, has_next, (int)total, n, (float)knn,

@@ -94,6 +94,11 @@ __host__ __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
 }
 
 void epc_set_error(const char* fmt, ...);
+// library-internal launchers (not part of the C ABI)
+int epc_conv1_launch(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
+                     int32_t* status, int n, void* stream);
+int epc_sort_launch(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm, int32_t* status_zero,
+                    void* stream);
 
 #define EPC_CHECK_ARG(cond, msg)                                  \
     do {                                                          \

@@ -48,10 +48,12 @@ __device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_
 template <int CIN, bool F8LO>
 struct C5Lds {  // offsets in floats (4 B)
     static constexpr int W5_CHUNK = F8LO ? 24 * CIN : 32 * CIN;
+    static constexpr int FEAT_STORES = F8LO ? 2 : 4;   // 16-B feat stores per lane per chunk (VLAD mode)
     static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp6 lo fragments inside a chunk
     static constexpr int LO6_KS = 384;         // floats per k-step of lo fragments (1 KB of 16-B pieces + 512 B of 8-B pieces)
     static constexpr int W5_LOSC = W5_LO8 + (CIN / 64) * LO6_KS;   // the block-scale dwords (one per lane)
-    static constexpr int WC_CHUNK = 1024;      // 32 ch x 64 clusters x 2 B (ONE fp16 per cluster weight, see the epilogue)
+    // cluster-weight chunk: 32 ch x 64 clusters x 2 B (FAST: ONE fp16 per cluster weight, see the epilogue) or bf16 hi + lo
+    static constexpr int WC_CHUNK = F8LO ? 1024 : 2048;
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
@@ -68,7 +70,8 @@ struct C5Lds {  // offsets in floats (4 B)
 
 // packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
 //                                    [W5p CIN*1024][b5f 1024]                                     (MAX)
-template <int CIN, int MODE, bool CAT16>
+// FAST (MODE_VLAD only): the f16 + f6 arithmetic of EPC_PRECISION_FAST; otherwise split-bf16 x3 (f32-equivalent).
+template <int CIN, int MODE, bool CAT16, bool FAST>
 __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restrict__ cat,
                                                            const float* __restrict__ pack, int total_points,
                                                            int n, float* __restrict__ feat,
@@ -76,8 +79,10 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            float* __restrict__ assign,
                                                            float* __restrict__ assign_frag,
                                                            float* __restrict__ apart,
-                                                           float* __restrict__ pooled) {
-    using L = C5Lds<CIN, MODE == MODE_VLAD>;
+                                                           float* __restrict__ pooled,
+                                                           int32_t* __restrict__ status) {
+    static_assert(!FAST || MODE == MODE_VLAD, "the fast arithmetic exists for the VLAD form only");
+    using L = C5Lds<CIN, FAST>;
     constexpr int STEPS = CIN / 16;
     static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     const float* gw5 = pack;
     const float* gb5 = pack + (size_t)CIN * 1024;
     const float* gwc = gb5 + 1024;
-    const float* gcbn = gwc + 1024 * 32;   // 1024 x 64 fp16
+    const float* gcbn = gwc + (FAST ? 1024 * 32 : 1024 * 64);   // past 1024 x 64 fp16 / bf16 hi + lo
 
     // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction writes 1 KB at a
     // wave-uniform LDS base + lane*16, which is exactly the packed fragment order), so no VGPRs are spent on staging
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
                    lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
         }
-        if (MODE == MODE_VLAD && wave_u < 4)   // 4 KB per chunk: one 1-KB piece from each of four waves
+        if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256)   // 4 (8) KB per chunk: one 1-KB piece from each of four (eight) waves
             glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
                    lds_base + 4u * (L::OFF_WC + buf * L::WC_CHUNK + wave_u * 256));
     };
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     // VLAD mode: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
     // common.h) -- the input rounding averages out over the cloud's points in the aggregation.  Max-pool mode keeps one
     // point's value per channel, so nothing averages: it stays on the f32-accurate split-bf16 form (three MFMAs).
-    constexpr bool kF16 = MODE == MODE_VLAD;
+    constexpr bool kF16 = FAST;
     constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
     f16x8 xf[kF16 ? STEPS : 1];
     // the same inputs as MX fp6 (B operand of the lo-term MFMA): per 64-wide k-step the lane's 32 consecutive channels
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     };
     bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
     if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
-        static_assert(!CAT16 || MODE == MODE_VLAD, "fp16 input only feeds the fp16 arithmetic");
+        static_assert(!CAT16 || FAST, "fp16 input only feeds the fp16 arithmetic");
         const unsigned short* row = reinterpret_cast<const unsigned short*>(cat) + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
@@ -312,7 +317,36 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #else
         constexpr bool kEpi = true;
 #endif
-        if (kEpi && MODE == MODE_VLAD) {
+        if constexpr (kEpi && MODE == MODE_VLAD && !FAST) {
+            // f32-equivalent form: feat leaves as f32 in accumulator order ([quad r][lane][4]: 1 KB per wave-instruction;
+            // element e of quad r = channel 32c + 8r + 4h + e), and the assignment GEMM takes the accumulators split into
+            // bf16 hi + lo against hi + lo cluster weights (three products).
+            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
+            auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
+            if (active) {
+                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    st4(fdst + r4 * 256, make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]));
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
+                bf16x8 fh, fl;
+                split8(v, fh, fl);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 wh = wfrag(sp, t, 0), wl = wfrag(sp, t, 1);
+                    P[t] = mfma_bf16(wl, fh, P[t]);
+                    P[t] = mfma_bf16(wh, fl, P[t]);
+                    P[t] = mfma_bf16(wh, fh, P[t]);
+                }
+            }
+        } else if constexpr (kEpi && MODE == MODE_VLAD) {
             const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
             // The cluster weights are ONE fp16 value each (x 2^8): the soft assignment only enters through a softmax whose
             // logits tolerate a 2^-12 weight rounding -- emulated descriptor effect 5e-9 on top of the 9.4e-7 of the
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #endif
                 if (sp == 0) wf[0] = wn[0], wf[1] = wn[1];
             }
-        } else if (kEpi) {
+        } else if constexpr (kEpi) {
             // max over the tile's 32 points (registers, then the two lane halves).  When the workgroup's 8 tiles lie in one cloud the
             // per-wave maxima meet in LDS (red: two chunk-parity slabs of 8 waves x 32 channels, in the unused transpose
             // area) and the workgroup's 1024 maxima leave as sixteen 256-B atomic wave-instructions at the very end;
@@ -379,8 +413,12 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #else
         if (MODE == MODE_VLAD && active)
 #endif
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else
+        {
+            if constexpr (L::FEAT_STORES == 2)
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef C5_ABL_NOBARRIER
@@ -401,12 +439,17 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     if (MODE == MODE_VLAD && active) {
         // per-point inverse norm (models/epc-net.py:148)
         ss += __shfl_xor(ss, 32);
+        if constexpr (FAST) {
+            // fp16 range guard: no element of the row exceeds 65504 unless |feat|^2 does (NaN / Inf rows fail the compare too)
+            const bool over = !(ss <= 65504.0f * 65504.0f);
+            if (status && __builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(status + g0 / n, EPC_STATUS_FP16_RANGE);
+        }
         const float rn = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
         // cluster_bn (folded: logit*s + t) then softmax over the 64 clusters (32 here, 32 in lane^32)
         const float* cs = lds + L::OFF_CBN;
         const float* ct = cs + 64;
         float mx = -INFINITY;
-        const float rn_w = rn * (1.0f / W5_SCALE);  // the cluster weights are packed scaled as well
+        const float rn_w = FAST ? rn * (1.0f / W5_SCALE) : rn;  // (fast form: the cluster weights are packed scaled as well)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -441,7 +484,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         // tile's partial a_sum (loupe.py:276).  The 2^14 keeps small assignments in fp16's normal range; it is exact
         // and the aggregate kernel removes it.  rnorm is applied on the feature side there.
         float* T = lds + L::OFF_T + wave * L::T_WAVE;
-        float* fdst = assign_frag + (size_t)(g0 >> 5) * 1024 + lane * 4;
+        float* fdst = assign_frag + (size_t)(g0 >> 5) * (FAST ? 1024 : 2048) + lane * 4;
         float asum[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -453,13 +496,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 float v[8];
                 const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
                 v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
-                f16x8 th;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s_ += v[q];
-                    th[q] = (_Float16)(v[q] * AGG_ASSIGN_SCALE);
+                for (int q = 0; q < 8; ++q) s_ += v[q];
+                if constexpr (FAST) {
+                    f16x8 th;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) th[q] = (_Float16)(v[q] * AGG_ASSIGN_SCALE);
+                    *reinterpret_cast<u32x4*>(fdst + (t * 2 + ks) * 256) = __builtin_bit_cast(u32x4, th);
+                } else {   // bf16 hi + lo fragments (no scale: bf16 has f32's range)
+                    bf16x8 ah, al;
+                    split8(v, ah, al);
+                    *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 0) * 256) = __builtin_bit_cast(u32x4, ah);
+                    *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 1) * 256) = __builtin_bit_cast(u32x4, al);
                 }
-                *reinterpret_cast<u32x4*>(fdst + (t * 2 + ks) * 256) = __builtin_bit_cast(u32x4, th);
             }
             asum[t] = s_ + __shfl_xor(s_, 32);
         }
@@ -470,20 +519,20 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     }
 }
 
-template <int CIN, int MODE, bool CAT16>
+template <int CIN, int MODE, bool CAT16, bool FAST>
 static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
-                        float* assign, float* assign_frag, float* apart, float* pooled, hipStream_t stream,
-                        const char* who) {
-    const size_t lds_bytes = C5Lds<CIN, MODE == MODE_VLAD>::TOTAL * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE, CAT16>),
+                        float* assign, float* assign_frag, float* apart, float* pooled, int32_t* status,
+                        hipStream_t stream, const char* who) {
+    const size_t lds_bytes = C5Lds<CIN, FAST>::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE, CAT16, FAST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
         return EPC_EHIP;
     }
     const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
-    hipLaunchKernelGGL((conv5_kernel<CIN, MODE, CAT16>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
-                       (int)total, n, feat, rnorm, assign, assign_frag, apart, pooled);
+    hipLaunchKernelGGL((conv5_kernel<CIN, MODE, CAT16, FAST>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
+                       (int)total, n, feat, rnorm, assign, assign_frag, apart, pooled, status);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
@@ -493,19 +542,34 @@ static int launch_conv5(const float* cat, const float* pack, long total, int n, 
 }
 
 extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5,
-                                    int num_points_total, void* feat_frag, float* rnorm, float* assign,
-                                    void* assign_frag, float* apart, void* stream) {
+                                    int num_points_total, int n, void* feat_frag, float* rnorm, float* assign,
+                                    void* assign_frag, float* apart, int32_t* status, void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
+    EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
+    EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
+    EPC_CHECK_ARG(!status || (n > 0 && n % 32 == 0 && num_points_total % n == 0),
+                  "status needs the points per cloud (a multiple of 32 dividing the point count)");
+    if (num_points_total == 0) return EPC_OK;
+    if (!status) n = 32;   // (only used to find a tile's status word)
+    if (cat_fp16)
+        return launch_conv5<256, MODE_VLAD, true, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n,
+                                                        (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart,
+                                                        nullptr, status, (hipStream_t)stream, __func__);
+    return launch_conv5<256, MODE_VLAD, false, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n,
+                                                     (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
+                                                     status, (hipStream_t)stream, __func__);
+}
+
+extern "C" int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
+                                        float* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
+                                        void* stream) {
     EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    if (cat_fp16)
-        return launch_conv5<256, MODE_VLAD, true>((const float*)cat, (const float*)packed_conv5, num_points_total, 0,
-                                                  (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
-                                                  (hipStream_t)stream, __func__);
-    return launch_conv5<256, MODE_VLAD, false>((const float*)cat, (const float*)packed_conv5, num_points_total, 0,
-                                               (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
-                                               (hipStream_t)stream, __func__);
+    return launch_conv5<256, MODE_VLAD, false, false>(cat, (const float*)packed_conv5, num_points_total, 32, feat_frag,
+                                                      rnorm, assign, (float*)assign_frag, apart, nullptr, nullptr,
+                                                      (hipStream_t)stream, __func__);
 }
 
 extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
@@ -520,8 +584,8 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
         epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    return launch_conv5<128, MODE_MAX, false>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr, pooled,
-                                       (hipStream_t)stream, __func__);
+    return launch_conv5<128, MODE_MAX, false, false>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr,
+                                                     nullptr, nullptr, pooled, nullptr, (hipStream_t)stream, __func__);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -711,6 +775,189 @@ extern "C" int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_
     }
     hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(4, num_clouds), dim3(AGG_THREADS), lds_bytes, (hipStream_t)stream,
                        (const float*)feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, V, colss);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// EPC_PRECISION_F32 form of the aggregate: feat arrives as f32 (accumulator order, epc_conv5_assign_f32_fwd), the
+// assignments as bf16 hi + lo B fragments.  (feat * rnorm) is split into bf16 hi + lo per lane, both halves go through
+// their own [point][channel] LDS image and come back as A fragments via the transposing read; three products per
+// k-step (lo*hi + hi*lo + hi*hi, f32 accumulate).  Same workgroup geometry, epilogue and outputs as the fp16 form; it
+// streams twice the bytes (16 MB of feat per cloud) and is bound by that read.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const float* __restrict__ feat_frag,
+                                                                         const float* __restrict__ assign_frag,
+                                                                         const float* __restrict__ rnorm,
+                                                                         const float* __restrict__ apart,
+                                                                         const float* __restrict__ centres, int n,
+                                                                         float* __restrict__ V,
+                                                                         float* __restrict__ colss) {
+    extern __shared__ __attribute__((aligned(16))) float agg_lds[];
+    float* xch = agg_lds;                                    // [4][AGG_FT * 2 * 16][64] f32
+    float* s_asum = agg_lds + AGG_XCH_FLOATS;                // [8][64]
+    unsigned short* xt = reinterpret_cast<unsigned short*>(s_asum + 8 * 64);   // [8 waves][hi, lo][32 points][AGG_ROW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int fg = blockIdx.x * 4 + (wave & 3);
+    const int sp = wave >> 2;
+    const int cloud = blockIdx.y;
+    const int tiles = n / 32, half = (tiles + 1) / 2;
+    const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
+    const size_t gt0 = (size_t)cloud * tiles + t_begin;
+
+    {
+        const int t8 = (tiles + 7) / 8, ta = wave * t8, tb = min(tiles, ta + t8);
+        const float* ap = apart + (size_t)cloud * tiles * 64 + lane;
+        float sum = 0.f;
+        int t = ta;
+        for (; t + 8 <= tb; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ap[(size_t)(t + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; t < tb; ++t) sum += ap[(size_t)t * 64];
+        s_asum[wave * 64 + lane] = sum;
+    }
+
+    f32x16 acc[AGG_FT][2];
+#pragma unroll
+    for (int t = 0; t < AGG_FT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
+
+    struct Tile {
+        u32x4 raw[AGG_FT][4];  // [chunk][quad r]: f32 values of channels 8r + 4h + 0..3 of point j
+        u32x4 bfr[2][2][2];    // [cluster tile][k-step][hi, lo]
+        float rn;
+    };
+    auto load = [&](Tile& t, int tt) {
+        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 1024 + lane * 4;
+        const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
+#pragma unroll
+        for (int c = 0; c < AGG_FT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 1024 + q * 256));
+        t.rn = rnorm[(gt0 + tt) * 32 + j];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    t.bfr[ct][ks][part] = *reinterpret_cast<const u32x4*>(fb + ((ct * 2 + ks) * 2 + part) * 256);
+    };
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    unsigned short* img_hi = xt + (wave * 2 + 0) * 32 * AGG_ROW;
+    unsigned short* img_lo = xt + (wave * 2 + 1) * 32 * AGG_ROW;
+    const int li = lane & 15;
+    const int tr_off = (8 * h + (li >> 2)) * AGG_ROW + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+    auto tr_read = [&](const unsigned short* img, int ks) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off + (16 * ks) * AGG_ROW));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off + (16 * ks + 4) * AGG_ROW));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, both);
+    };
+    auto process = [&](const Tile& t) {
+#pragma unroll
+        for (int c = 0; c < AGG_FT; ++c) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                unsigned short hb[4], lb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = __uint_as_float(t.raw[c][r4][e]) * t.rn;
+                    const __bf16 yh = (__bf16)y;
+                    const __bf16 yl = (__bf16)(y - (float)yh);
+                    hb[e] = __builtin_bit_cast(unsigned short, yh);
+                    lb[e] = __builtin_bit_cast(unsigned short, yl);
+                }
+                const int off = j * AGG_ROW + 8 * r4 + 4 * h;   // channels 8r + 4h + 0..3 of point j
+                *reinterpret_cast<uint2*>(img_hi + off) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+                *reinterpret_cast<uint2*>(img_lo + off) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = tr_read(img_hi, ks), al = tr_read(img_lo, ks);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, t.bfr[ct][ks][0]), bl = __builtin_bit_cast(bf16x8, t.bfr[ct][ks][1]);
+                    acc[c][ct] = mfma_bf16(al, bh, acc[c][ct]);
+                    acc[c][ct] = mfma_bf16(ah, bl, acc[c][ct]);
+                    acc[c][ct] = mfma_bf16(ah, bh, acc[c][ct]);
+                }
+            }
+        }
+    };
+    Tile t0, t1;
+    if (per > 0) load(t0, 0);
+    for (int tt = 0; tt < per; tt += 2) {
+        if (tt + 1 < per) load(t1, tt + 1);
+        process(t0);
+        if (tt + 2 < per) load(t0, tt + 2);
+        if (tt + 1 < per) process(t1);
+    }
+
+    static_assert(AGG_FT == 2, "one chunk per half in the epilogue");
+    const int w3 = wave & 3;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float mine0 = acc[0][ct][r], mine1 = acc[1][ct][r];
+            xch[(((w3 * 2 + sp) * 2 + ct) * 16 + r) * 64 + lane] = sp ? mine0 : mine1;
+        }
+    __syncthreads();
+    float asum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        asum[0] += s_asum[w * 64 + j];
+        asum[1] += s_asum[w * 64 + 32 + j];
+    }
+    float* vout = V + (size_t)cloud * 1024 * 64;
+    float ss[2] = {0.f, 0.f};
+    const int chunk = fg * AGG_FT + sp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = chunk * 32 + mfma_row(r, h);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const float other = xch[(((w3 * 2 + (sp ^ 1)) * 2 + ct) * 16 + r) * 64 + lane];
+            const float own = sp ? acc[1][ct][r] : acc[0][ct][r];
+            const float first = sp ? other : own, second = sp ? own : other;
+            const float v = (first + second) - asum[ct] * centres[f * 64 + 32 * ct + j];
+            vout[(size_t)f * 64 + 32 * ct + j] = v;
+            ss[ct] += v * v;
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        ss[ct] += __shfl_xor(ss[ct], 32);
+        if (h == 0) colss[((size_t)cloud * 32 + chunk) * 64 + 32 * ct + j] = ss[ct];
+    }
+}
+
+extern "C" int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* assign_frag, const float* rnorm,
+                                          const float* apart, const float* centres, int num_clouds, int n, float* V,
+                                          float* colss, void* stream) {
+    EPC_CHECK_ARG(feat_frag && assign_frag && rnorm && apart && centres && V && colss, "null pointer");
+    EPC_CHECK_ARG(n > 0 && n % 32 == 0, "num_points must be a multiple of 32");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535, "bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    const size_t lds_bytes = (AGG_XCH_FLOATS + 8 * 64) * sizeof(float) + 2 * 8 * 32 * AGG_ROW * sizeof(unsigned short);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_aggregate_f32_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        epc_set_error("epc_vlad_aggregate_f32_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(vlad_aggregate_f32_kernel, dim3(4, num_clouds), dim3(AGG_THREADS), lds_bytes, (hipStream_t)stream,
+                       feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, V, colss);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64) void hidden_gemm_kernel(const float* __restrict
 // kernel has one workgroup per cloud: it is latency, not bandwidth, that it pays for).
 __global__ __launch_bounds__(1024) void head_finish_kernel(const float* __restrict__ Yp, int slices, int rows,
                                                            const float* __restrict__ hp, int groups,
+                                                           const int32_t* __restrict__ status,
                                                            float* __restrict__ out) {
     __shared__ float part_y[4][256];
     __shared__ float v[256];
@@ -139,13 +140,16 @@ __global__ __launch_bounds__(1024) void head_finish_kernel(const float* __restri
     if (part == 0 && (c & 63) == 0) red[c >> 6] = ss;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    if (part == 0) out[(size_t)cloud * 256 + c] = o * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+    // a flagged cloud (EPC_STATUS_*: non-finite coordinate, fp16 range) leaves as NaN, never as a wrong finite vector
+    const bool poisoned = status && status[cloud] != 0;
+    if (part == 0) out[(size_t)cloud * 256 + c] = poisoned ? __int_as_float(0x7fc00000) : o * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
 }
 
 // ---- EPC-Net-L head: fc1 (1024->256, folded BN) + ReLU + L2.  packed: [Wf 1024*256][bf 256] ------------------
 // 1024 threads per cloud: thread (c, part) takes a quarter of the 1024-long dot product (see head_finish_kernel).
 __global__ __launch_bounds__(1024) void fc_head_kernel(const float* __restrict__ pooled,
-                                                       const float* __restrict__ pack, float* __restrict__ out) {
+                                                       const float* __restrict__ pack,
+                                                       const int32_t* __restrict__ status, float* __restrict__ out) {
     __shared__ float m[1024];
     __shared__ float part_y[4][256];
     __shared__ float red[4];
@@ -164,7 +168,8 @@ __global__ __launch_bounds__(1024) void fc_head_kernel(const float* __restrict__
     if (part == 0 && (c & 63) == 0) red[c >> 6] = ss;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    if (part == 0) out[(size_t)cloud * 256 + c] = y * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
+    const bool poisoned = status && status[cloud] != 0;
+    if (part == 0) out[(size_t)cloud * 256 + c] = poisoned ? __int_as_float(0x7fc00000) : y * (1.0f / sqrtf(fmaxf(tot, 1e-12f)));
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -178,7 +183,8 @@ extern "C" size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups) {
 }
 
 extern "C" int epc_vlad_head_fwd(const float* V, const float* colss, const void* packed_head, int groups,
-                                 int num_clouds, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int num_clouds, float* out, const int32_t* status, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
     EPC_CHECK_ARG(V && colss && packed_head && out && workspace, "null pointer");
     EPC_CHECK_ARG(groups > 0 && 64 % groups == 0, "GROUPS must divide 64");
     EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
@@ -214,18 +220,18 @@ extern "C" int epc_vlad_head_fwd(const float* V, const float* colss, const void*
                        num_clouds, kh, Yp);
     EPC_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_finish_kernel, dim3(num_clouds), dim3(1024), 0, st, Yp, slices, num_clouds, tail,
-                       groups, out);
+                       groups, status, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 
 extern "C" int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, float* out,
-                               void* stream) {
+                               const int32_t* status, void* stream) {
     EPC_CHECK_ARG(pooled && packed_fc && out, "null pointer");
     EPC_CHECK_ARG(num_clouds >= 0, "bad shape");
     if (num_clouds == 0) return EPC_OK;
     hipLaunchKernelGGL(fc_head_kernel, dim3(num_clouds), dim3(1024), 0, (hipStream_t)stream, pooled,
-                       (const float*)packed_fc, out);
+                       (const float*)packed_fc, status, out);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
                                                                       float* __restrict__ kth_out,
                                                                       const float* __restrict__ conv1_pack,
                                                                       float* __restrict__ x32,
-                                                                      unsigned short* __restrict__ x16, int idx_u16) {
+                                                                      unsigned short* __restrict__ x16, int idx_u16,
+                                                                      int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, then 2 float4 per tile (lo, hi)
     const int ntiles = (n + KNN_CT - 1) / KNN_CT;
     const int npad = ntiles * KNN_CT;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pc = xyz + (size_t)cloud * n * 3;
 
+    bool bad = false;   // a NaN / Inf coordinate (or one whose square overflows): |p|^2 is not a finite number
     for (int j = tid; j < npad; j += KNN_THREADS) {
         float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);
         if (j < n) {
@@ -165,9 +167,12 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
             v.y = pc[3 * j + 1];
             v.z = pc[3 * j + 2];
             v.w = sq3(v.x, v.y, v.z);
+            bad |= !(v.w <= 3.4028234664e38f);
         }
         cand[j] = v;
     }
+    // every workgroup of the cloud has seen the whole cloud: the first one reports (EPC_STATUS_NONFINITE_INPUT)
+    if (status && blockIdx.x == 0 && wave_any(bad) && lane == 0) atomicOr(status + cloud, EPC_STATUS_NONFINITE_INPUT);
     __syncthreads();
     if constexpr (CONV1) {
         const int q = tid & 15;   // KNN_THREADS is a multiple of 16: a thread keeps its channel quad
@@ -177,14 +182,19 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         const float4 b = *reinterpret_cast<const float4*>(conv1_pack + 192 + 4 * q);
         const int p0 = blockIdx.x * KNN_THREADS;
         const int np = min(KNN_THREADS, n - p0);
+        bool ovf = false;   // a conv1 output that does not fit the fp16 row (outputs are >= 0 after the ReLU)
         for (int t = tid; t < np * 16; t += KNN_THREADS) {
             const int g = p0 + (t >> 4);
             const float4 pt = cand[g];
             const float4 y = conv1_quad(pt.x, pt.y, pt.z, w0, w1, w2, b);
             const size_t row = (size_t)cloud * n + g;
             if (x32) *reinterpret_cast<float4*>(x32 + row * 64 + 4 * q) = y;
-            if (x16) reinterpret_cast<uint2*>(x16)[row * 16 + q] = pack_half4(y);
+            if (x16) {
+                reinterpret_cast<uint2*>(x16)[row * 16 + q] = pack_half4(y);
+                ovf |= fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)) > 65504.0f;
+            }
         }
+        if (status && x16 && wave_any(ovf) && lane == 0) atomicOr(status + cloud, EPC_STATUS_FP16_RANGE);
     }
     // tile bounding boxes: KNN_CT lanes per tile, shuffle min/max
     for (int t = wave * (64 / KNN_CT) + lane / KNN_CT; t < ntiles; t += KNN_WAVES * (64 / KNN_CT)) {
@@ -362,6 +372,18 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         pass2(std::false_type{});
     else
         pass2(std::true_type{});
+    // A row can be short only when a coordinate is NaN / Inf (a_ij >= kth is then false for the pairs involved): its unused
+    // slots get the point's own index so that the 20 entries every consumer reads are valid row numbers (the cloud's
+    // descriptor is NaN anyway: EPC_STATUS_NONFINITE_INPUT).
+    if (valid && count < (unsigned int)KSEL) {
+        const size_t row = ((size_t)cloud * n + i) * cap;
+        for (unsigned int c = count; c < (unsigned int)KSEL; ++c) {
+            if (idx_u16)
+                reinterpret_cast<unsigned short*>(idx)[row + c] = (unsigned short)i;
+            else
+                idx[row + c] = i;
+        }
+    }
     if (valid) {
         cnt[(size_t)cloud * n + i] = (int32_t)count;
         kth_out[(size_t)cloud * n + i] = kth;
@@ -372,8 +394,10 @@ template <int KSEL>
 __global__ __launch_bounds__(KNN_THREADS) void knn_topk_stream_kernel(const float* __restrict__ xyz, int n, int cap,
                                                                       int32_t* __restrict__ idx,
                                                                       int32_t* __restrict__ cnt,
-                                                                      float* __restrict__ kth_out) {
+                                                                      float* __restrict__ kth_out,
+                                                                      int32_t* __restrict__ status) {
     __shared__ float4 tile[KNN_TILE];
+    bool bad = false;
     const int cloud = blockIdx.y;
     const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
     const bool valid = i < n;
@@ -399,6 +423,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_stream_kernel(const floa
                 v.y = pc[3 * j + 1];
                 v.z = pc[3 * j + 2];
                 v.w = sq3(v.x, v.y, v.z);
+                bad |= !(v.w <= 3.4028234664e38f);
             }
             tile[c] = v;
         }
@@ -431,6 +456,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_stream_kernel(const floa
             }
         }
     }
+    if (status && blockIdx.x == 0 && wave_any(bad) && (threadIdx.x & 63) == 0) atomicOr(status + cloud, EPC_STATUS_NONFINITE_INPUT);
+    if (valid)   // short rows (non-finite coordinates): pad with the point's own index, see the LDS kernel
+        for (int c = count; c < KSEL; ++c) my[c] = i;
     if (valid) {
         cnt[(size_t)cloud * n + i] = count;
         kth_out[(size_t)cloud * n + i] = kth;
@@ -452,7 +480,8 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
 }
 
 static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
-                      const float* conv1_pack, float* x32, void* x16, int idx_u16, void* stream, const char* who) {
+                      const float* conv1_pack, float* x32, void* x16, int idx_u16, int32_t* status, void* stream,
+                      const char* who) {
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
     if (n <= KNN_LDS_MAX_N) {
         const int ntiles = (n + KNN_CT - 1) / KNN_CT;
@@ -467,13 +496,13 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
         }
         if (conv1_pack)
             hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, true>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16, idx_u16);
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16, idx_u16, status);
         else
             hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, false>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0);
+                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, status);
     } else {
         hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
-                           xyz, n, cap, idx, cnt, kth);
+                           xyz, n, cap, idx, cnt, kth, status);
     }
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -486,11 +515,12 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
                   "need num_points >= 20 (tf.nn.top_k k=20)");
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
-    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, stream, __func__);
+    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, nullptr, stream, __func__);
 }
 
 extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt,
-                                  float* kth, const void* packed_conv1, float* x, void* x16, void* stream) {
+                                  float* kth, const void* packed_conv1, float* x, void* x16, int32_t* status,
+                                  void* stream) {
     EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_conv1 && (x || x16), "null pointer");
     EPC_CHECK_ARG(!idx_u16 || (n <= 65535 && n <= KNN_LDS_MAX_N), "2-byte lists need num_points <= 8192 (the LDS kernel)");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT,
@@ -498,12 +528,12 @@ extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int c
     EPC_CHECK_ARG(cap >= EPC_KNN_SELECT, "list capacity must be >= 20");
     if (num_clouds == 0) return EPC_OK;
     if (n > KNN_LDS_MAX_N) {   // the streaming kNN kernel keeps no cloud image: two launches
-        int rc = launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, nullptr, nullptr, nullptr, 0, stream, __func__);
+        int rc = launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, nullptr, nullptr, nullptr, 0, status, stream, __func__);
         if (rc != EPC_OK) return rc;
-        return epc_conv1_fwd(xyz, packed_conv1, num_clouds * n, x, x16, stream);
+        return epc_conv1_launch(xyz, packed_conv1, num_clouds * n, x, x16, status, n, stream);   // (f32 rows: EPC-Net-L / F32 precision run at this size)
     }
-    return launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, (const float*)packed_conv1, x, x16, idx_u16, stream,
-                      __func__);
+    return launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, (const float*)packed_conv1, x, x16, idx_u16, status,
+                      stream, __func__);
 }
 
 extern "C" int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask,

@@ -11,13 +11,18 @@ static inline size_t align64(size_t v) { return (v + 63) / 64 * 64; }
 
 struct StageLayout {
     size_t off[8];  // float offsets of stages 0..6, off[7] = total
+    size_t guard;   // 64 floats after the stages: word 0 = max |packed 16-bit operand| bit pattern (fp16 range guard)
 };
+
+// EPC-Net in EPC_PRECISION_FAST packs fp16 operands (scaled by W5_SCALE); everything else packs split-bf16 operands
+static bool cfg_fast(const epc_cfg* c) { return c->arch == EPC_ARCH_EPC_NET && c->precision == EPC_PRECISION_FAST; }
 
 static bool cfg_ok(const epc_cfg* c) {
     if (!c) return false;
     if (c->arch != EPC_ARCH_EPC_NET && c->arch != EPC_ARCH_EPC_NET_L) return false;
     if (c->num_points < 32 || c->num_points % 32) return false;
     if (c->input_dim != 3 || c->output_dim != 256 || c->knn <= 0) return false;
+    if (c->precision != EPC_PRECISION_F32 && c->precision != EPC_PRECISION_FAST) return false;
     if (c->arch == EPC_ARCH_EPC_NET) {
         if (c->cluster_size != 64) return false;
         if (!(c->groups == 1 || c->groups == 2 || c->groups == 4 || c->groups == 8 || c->groups == 16)) return false;
@@ -46,6 +51,8 @@ static StageLayout stage_layout(const epc_cfg* c) {
         L.off[6] = o;
         o += align64((size_t)1024 * 256 + 256);
     }
+    L.guard = o;
+    o += 64;
     L.off[7] = o;
     return L;
 }
@@ -63,6 +70,13 @@ extern "C" size_t epc_net_packed_offset(const epc_cfg* cfg, int stage) {
 // ---- device kernels ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bn_inv(const float* gamma, const float* var, int c) {
     return (1.0f / sqrtf(var[c] + BN_EPS)) * gamma[c];
+}
+
+// fp16 range guard of EPC_PRECISION_FAST: the largest |value| that is about to be rounded to fp16, as a bit pattern
+// (|f32| orders like its bit pattern; NaN sorts above Inf), one atomic per wave that holds a new maximum candidate.
+__device__ __forceinline__ void guard_track(unsigned int* guard, float v) {
+    const unsigned int bits = __float_as_uint(v) & 0x7fffffffu;
+    if (bits > 0x47000000u) atomicMax(guard, bits);   // only values above 32768 can matter: no atomics in the normal case
 }
 
 // Row-major [cin][cout] with folded BN (conv1 3x64, fc1 1024x256).
@@ -85,7 +99,8 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
 __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int cin, int f16,
-                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB,
+                                       unsigned int* __restrict__ guard) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int steps = cin / 16;
     const float scale = f16 ? W5_SCALE : 1.0f;
@@ -96,6 +111,7 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
         const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col) * scale;
         if (f16) {
             const _Float16 h = (_Float16)w;
+            guard_track(guard, w);
             const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
             dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
         } else {
@@ -109,6 +125,7 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
     if (o < 1024) {
         const float inv = bn_inv(gamma, var, o);
         dstB[o] = (b[o] * inv + (beta[o] - mean[o] * inv)) * scale;
+        if (f16) guard_track(guard, dstB[o] * (1.0f / W5_SCALE));   // the bias enters an fp16 activation un-scaled
     }
 }
 
@@ -155,7 +172,8 @@ __global__ void pack_conv5_lo6_kernel(const float* __restrict__ W, const float* 
 __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int mode, int f16,
-                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB) {
+                                       unsigned short* __restrict__ dstW, float* __restrict__ dstB,
+                                       unsigned int* __restrict__ guard) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const float scale = f16 ? W5_SCALE : 1.0f;
     if (o < 4096) {
@@ -166,6 +184,7 @@ __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float*
         const float w = W[(size_t)k * 64 + col] * bn_inv(gamma, var, col) * scale;
         unsigned short hi, lo;
         if (f16) {
+            guard_track(guard, w);
             const _Float16 hh = (_Float16)w;
             const _Float16 ll = (_Float16)(w - (float)hh);
             hi = __builtin_bit_cast(unsigned short, hh);
@@ -181,18 +200,37 @@ __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float*
     if (o < 64) {
         const float inv = bn_inv(gamma, var, o);
         dstB[o] = (b[o] * inv + (beta[o] - mean[o] * inv)) * scale;
+        if (f16) guard_track(guard, dstB[o] * (1.0f / W5_SCALE));
     }
 }
 
 // cluster weights for the assignment GEMM: ONE fp16 per weight (x W5_SCALE), fragment order
 // [chunk c][k-step sp][cluster tile t][lane][8]: element j of lane l = Wc[32c + 16sp + 8(j>>2) + 4(l>>5) + (j&3)][32t + (l&31)]
-__global__ void pack_wc_f16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
+__global__ void pack_wc_f16_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst,
+                                   unsigned int* __restrict__ guard) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= 1024 * 64) return;
     const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
     const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-    const _Float16 h = (_Float16)(Wc[(size_t)ch * 64 + 32 * t + (lane & 31)] * W5_SCALE);
+    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)] * W5_SCALE;
+    guard_track(guard, w);
+    const _Float16 h = (_Float16)w;
     dst[o] = __builtin_bit_cast(unsigned short, h);
+}
+
+// EPC_PRECISION_F32: the same fragments as bf16 hi + lo, un-scaled:
+// [chunk c][k-step sp][cluster tile t][part (hi, lo)][lane][8]
+__global__ void pack_wc_bf16x2_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= 1024 * 64) return;
+    const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
+    const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
+    const unsigned short hi = bf16_bits_rne(w);
+    const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+    const size_t base = ((size_t)((c * 2 + sp) * 2 + t) * 2) * 512 + lane * 8 + j;
+    dst[base] = hi;
+    dst[base + 512] = lo;
 }
 
 __global__ void bn_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -268,10 +306,11 @@ static int get_slim_bn(const NameTable& T, const std::string& scope, const float
         if (rc__ != EPC_OK) return rc__; \
     } while (0)
 
-static int launch_layer(const ConvVars& v, int cin, int cout, int mode, int f16, float* dst, hipStream_t st) {
+static int launch_layer(const ConvVars& v, int cin, int cout, int mode, int f16, float* dst, unsigned int* guard,
+                        hipStream_t st) {
     EPC_CHECK_ARG(cin == 64 && cout == 64, "block layers are 64x64");
     hipLaunchKernelGGL(fold_pack_block_kernel, dim3(16), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var,
-                       mode, f16, (unsigned short*)dst, dst + 4096);
+                       mode, f16, (unsigned short*)dst, dst + 4096, guard);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -289,7 +328,15 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
     float* P = (float*)packed;
     hipStream_t st = (hipStream_t)stream;
     const int nblocks = cfg->arch == EPC_ARCH_EPC_NET ? 4 : 2;
-    const int f16 = cfg->arch == EPC_ARCH_EPC_NET ? 1 : 0;  // EPC-Net: fp16 activations (common.h); EPC-Net-L: split-bf16
+    const int f16 = cfg_fast(cfg) ? 1 : 0;  // EPC-Net FAST: fp16 activations (common.h); otherwise split-bf16
+    unsigned int* guard = (unsigned int*)(P + L.guard);
+    {
+        hipError_t e = hipMemsetAsync(guard, 0, 64 * sizeof(float), st);
+        if (e != hipSuccess) {
+            epc_set_error("epc_net_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e));
+            return EPC_EHIP;
+        }
+    }
     ConvVars v;
 
     PACK_TRY(get_conv(T, "fastdgcnn/conv1", &v));
@@ -301,12 +348,12 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
         float* dst = P + L.off[b];
         const std::string base = "fastdgcnn/conv" + std::to_string(b);
         PACK_TRY(get_conv(T, base + "_a", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst, guard, st));
         PACK_TRY(get_conv(T, base + "_b", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, f16, dst + 4160, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, f16, dst + 4160, guard, st));
         if (b < nblocks) {
             PACK_TRY(get_conv(T, "fastdgcnn/conv" + std::to_string(b + 1), &v));
-            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst + 8320, st));
+            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst + 8320, guard, st));
         } else {
             hipError_t e = hipMemsetAsync(dst + 8320, 0, 4160 * sizeof(float), st);
             if (e != hipSuccess) {
@@ -319,10 +366,10 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
     PACK_TRY(get_conv(T, "fastdgcnn/conv5", &v));
     const int c5in = 64 * nblocks;
     hipLaunchKernelGGL(fold_pack_conv5_kernel, dim3(c5in * 1024 / 256), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta,
-                       v.mean, v.var, c5in, cfg->arch == EPC_ARCH_EPC_NET ? 1 : 0, (unsigned short*)(P + L.off[5]),
-                       P + L.off[5] + (size_t)c5in * 1024);
+                       v.mean, v.var, c5in, f16, (unsigned short*)(P + L.off[5]),
+                       P + L.off[5] + (size_t)c5in * 1024, guard);
     EPC_CHECK_LAUNCH();
-    if (cfg->arch == EPC_ARCH_EPC_NET) {
+    if (f16) {
         hipLaunchKernelGGL(pack_conv5_lo6_kernel, dim3((32 * (c5in / 64) * 64 + 255) / 256), dim3(256), 0, st, v.W, v.gamma,
                            v.var, c5in, (unsigned short*)(P + L.off[5]));
         EPC_CHECK_LAUNCH();
@@ -338,11 +385,15 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
             epc_set_error("epc_net_pack_weights: VLAD weight matrices are incomplete");
             return EPC_ENOTFOUND;
         }
-        hipLaunchKernelGGL(pack_wc_f16_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5);
+        if (f16)
+            hipLaunchKernelGGL(pack_wc_f16_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5, guard);
+        else
+            hipLaunchKernelGGL(pack_wc_bf16x2_kernel, dim3(256), dim3(256), 0, st, Wc, (unsigned short*)s5);
         EPC_CHECK_LAUNCH();
         const float *g, *b, *m, *vv;
         PACK_TRY(get_slim_bn(T, "VLAD/cluster_bn", &g, &b, &m, &vv));
-        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 64, s5 + 32768, s5 + 32768 + 64);
+        float* cbn = s5 + (f16 ? 32768 : 65536);   // past the cluster-weight fragments (conv5_vlad.hip: gcbn)
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(1), dim3(256), 0, st, g, b, m, vv, 64, cbn, cbn + 64);
         EPC_CHECK_LAUNCH();
 
         float* h = P + L.off[6];
@@ -368,6 +419,24 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
         hipLaunchKernelGGL(fold_rowmajor_kernel, dim3(1024), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean,
                            v.var, 1024, 256, f, f + 1024 * 256);
         EPC_CHECK_LAUNCH();
+    }
+    if (f16) {
+        // fp16 range guard: read the maximum back (this is why FAST packing synchronises the stream) and refuse to hand
+        // out a buffer that holds an Inf.  65504 = the largest finite fp16; NaN / Inf patterns sort above it.
+        unsigned int bits = 0;
+        hipError_t e = hipMemcpyAsync(&bits, guard, sizeof(bits), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            epc_set_error("epc_net_pack_weights: reading the range guard: %s", hipGetErrorString(e));
+            return EPC_EHIP;
+        }
+        if (bits > 0x477fe000u) {
+            float m;
+            memcpy(&m, &bits, sizeof(m));
+            epc_set_error("epc_net_pack_weights: a folded weight or bias leaves fp16's range in EPC_PRECISION_FAST "
+                          "(max |W' * 256| = %g > 65504: small moving variance or large gamma); pack with EPC_PRECISION_F32", m);
+            return EPC_ERANGE;
+        }
     }
     return EPC_OK;
 }

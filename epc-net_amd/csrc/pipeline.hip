@@ -11,8 +11,11 @@ static int micro_batch(const epc_cfg* c, int num_clouds) {
     return num_clouds < mb ? num_clouds : mb;
 }
 
+// EPC-Net in EPC_PRECISION_FAST: fp16 rows / fragments between the stages; otherwise f32 tensors, split-bf16 kernels
+static bool fast_path(const epc_cfg* c) { return c->arch == EPC_ARCH_EPC_NET && c->precision == EPC_PRECISION_FAST; }
+
 struct WsLayout {
-    size_t sorted, idx, cnt, kth, xa, xb, xa16, xb16, cat, feat, rnorm, assign, afrag, vlad, colss, apart, head, pooled, total;
+    size_t status, sorted, idx, cnt, kth, xa, xb, xa16, xb16, cat, feat, rnorm, assign, afrag, vlad, colss, apart, head, pooled, total;
 };
 
 static WsLayout ws_layout(const epc_cfg* c, int mb) {
@@ -24,26 +27,28 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
         o += al(bytes);
         return at;
     };
+    w.status = take((size_t)mb * 4);   // per-cloud EPC_STATUS_* words: offset 0 (epc_net_last_status)
     w.sorted = take(M * 3 * 4);
     w.idx = take(M * EPC_KNN_CAP * 4);
     w.cnt = take(M * 4);
     w.kth = take(M * 4);
     // EPC-Net: the block chain's tensors are fp16 rows (block.hip); EPC-Net-L: f32 rows
     w.xa = w.xb = w.xa16 = w.xb16 = 0;
-    if (c->arch == EPC_ARCH_EPC_NET) {
+    const bool fast = fast_path(c);
+    if (fast) {
         w.xa16 = take(M * 64 * 2);
         w.xb16 = take(M * 64 * 2);
         w.cat = take(M * 256 * 2);
     } else {
         w.xa = take(M * 64 * 4);
         w.xb = take(M * 64 * 4);
-        w.cat = take(M * 128 * 4);
+        w.cat = take(M * (c->arch == EPC_ARCH_EPC_NET ? 256 : 128) * 4);
     }
     w.feat = w.rnorm = w.assign = w.afrag = w.vlad = w.colss = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
-        w.feat = take(M * 1024 * 2);   // fp16 fragments
+        w.feat = take(M * 1024 * (fast ? 2 : 4));   // fp16 / f32 fragments
         w.rnorm = take(M * 4);
-        w.afrag = take(M * 64 * 2);    // fp16 fragments
+        w.afrag = take(M * 64 * (fast ? 2 : 4));    // fp16 / bf16 hi + lo fragments
         w.vlad = take((size_t)mb * 65536 * 4);
         w.colss = take((size_t)mb * 32 * 64 * 4);
         w.apart = take(M / 32 * 64 * 4);
@@ -137,7 +142,8 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
     int32_t* cnt = (int32_t*)(ws + w.cnt);
     float* kth = (float*)(ws + w.kth);
     float* xs[2] = {(float*)(ws + w.xa), (float*)(ws + w.xb)};
-    const bool f16 = cfg->arch == EPC_ARCH_EPC_NET;
+    const bool f16 = fast_path(cfg);
+    int32_t* status = (int32_t*)(ws + w.status);
     void* xs16[2] = {f16 ? (void*)(ws + w.xa16) : nullptr, f16 ? (void*)(ws + w.xb16) : nullptr};
     if (f16) xs[0] = xs[1] = nullptr;
     float* cat = (float*)(ws + w.cat);
@@ -145,8 +151,14 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
     TRY(mark(prof, EPC_STAGE_SORT, stream));
     if (n <= 16384) {  // descriptors are permutation-invariant: run the whole pipeline on the Z-ordered cloud
         float* sorted = (float*)(ws + w.sorted);
-        TRY(epc_morton_sort(pc, nc, n, sorted, nullptr, stream));
+        TRY(epc_sort_launch(pc, nc, n, sorted, nullptr, status, stream));   // (also zeroes the status words)
         pc = sorted;
+    } else {
+        hipError_t e = hipMemsetAsync(status, 0, (size_t)nc * sizeof(int32_t), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            epc_set_error("epc_net_forward: hipMemsetAsync: %s", hipGetErrorString(e));
+            return EPC_EHIP;
+        }
     }
     TRY(mark(prof, EPC_STAGE_KNN, stream));
     // kNN graph + conv1 in one launch (the kNN workgroup already holds the cloud in LDS); a stage profile therefore
@@ -157,14 +169,14 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
     const int idx_u16 = n <= 8192;   // 2-byte neighbour lists wherever the LDS kNN kernel runs
 #endif
     TRY(epc_knn_topk_conv1(pc, nc, n, EPC_KNN_CAP, idx, idx_u16, cnt, kth, pk + epc_net_packed_offset(cfg, 0), xs[0], xs16[0],
-                           stream));
+                           status, stream));
     for (int b = 1; b <= nblocks; ++b) {
         TRY(mark(prof, EPC_STAGE_BLOCK1 + b - 1, stream));
         const int has_next = b < nblocks;
         TRY(epc_proxyconv_block_fwd(xs[(b - 1) & 1], xs16[(b - 1) & 1], pc, idx, idx_u16, cnt, kth, EPC_KNN_CAP,
                                     pk + epc_net_packed_offset(cfg, b), has_next, nc, n, cfg->knn,
                                     f16 ? nullptr : cat, f16 ? (void*)cat : nullptr, ccat, 64 * (b - 1), xs[b & 1],
-                                    xs16[b & 1], stream));
+                                    xs16[b & 1], status, stream));
     }
     if (cfg->arch == EPC_ARCH_EPC_NET) {
         float* feat = (float*)(ws + w.feat);
@@ -174,21 +186,46 @@ static int forward_pass(const epc_cfg* cfg, const char* pk, const float* pc, int
         float* apart = (float*)(ws + w.apart);
         TRY(mark(prof, EPC_STAGE_CONV5, stream));
         float* afrag = (float*)(ws + w.afrag);
-        TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, nullptr, afrag,
-                                 apart, stream));
-        TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
         const char* head_pack = pk + epc_net_packed_offset(cfg, 6);   // starts with the cluster centres
-        TRY(epc_vlad_aggregate_fwd(feat, afrag, rnorm, apart, (const float*)head_pack, nc, n, vlad, colss, stream));
+        if (f16) {
+            TRY(epc_conv5_assign_fwd(cat, 1, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, n, feat, rnorm, nullptr, afrag,
+                                     apart, status, stream));
+            TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
+            TRY(epc_vlad_aggregate_fwd(feat, afrag, rnorm, apart, (const float*)head_pack, nc, n, vlad, colss, stream));
+        } else {
+            TRY(epc_conv5_assign_f32_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc * n, feat, rnorm, nullptr, afrag,
+                                         apart, stream));
+            TRY(mark(prof, EPC_STAGE_AGGREGATE, stream));
+            TRY(epc_vlad_aggregate_f32_fwd(feat, afrag, rnorm, apart, (const float*)head_pack, nc, n, vlad, colss, stream));
+        }
         TRY(mark(prof, EPC_STAGE_HEAD, stream));
-        TRY(epc_vlad_head_fwd(vlad, colss, head_pack, cfg->groups, nc, o, ws + w.head, w.total - w.head, stream));
+        TRY(epc_vlad_head_fwd(vlad, colss, head_pack, cfg->groups, nc, o, status, ws + w.head, w.total - w.head, stream));
     } else {
         float* pooled = (float*)(ws + w.pooled);
         TRY(mark(prof, EPC_STAGE_CONV5, stream));
         TRY(epc_conv5_maxpool_fwd(cat, ccat, pk + epc_net_packed_offset(cfg, 5), nc, n, pooled, stream));
         TRY(mark(prof, EPC_STAGE_HEAD, stream));
-        TRY(epc_fc_head_fwd(pooled, pk + epc_net_packed_offset(cfg, 6), nc, o, stream));
+        TRY(epc_fc_head_fwd(pooled, pk + epc_net_packed_offset(cfg, 6), nc, o, status, stream));
     }
     return mark(prof, EPC_NUM_STAGES, stream);
+}
+
+extern "C" int epc_net_last_status(const epc_cfg* cfg, const void* workspace, int num_clouds, int32_t* status_host,
+                                   void* stream) {
+    EPC_CHECK_ARG(epc_net_packed_bytes(cfg) != 0, "unsupported configuration");
+    EPC_CHECK_ARG(workspace && status_host && num_clouds >= 0, "null pointer / bad shape");
+    if (num_clouds == 0) return EPC_OK;
+    const int mb = micro_batch(cfg, num_clouds);
+    const int last = num_clouds % mb ? num_clouds % mb : mb;   // clouds of the last pass
+    const WsLayout w = ws_layout(cfg, mb);
+    hipError_t e = hipMemcpyAsync(status_host, (const char*)workspace + w.status, (size_t)last * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) {
+        epc_set_error("epc_net_last_status: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    return EPC_OK;
 }
 
 extern "C" int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,

@@ -178,8 +178,11 @@ __device__ __forceinline__ bool bucket_sort_4096(unsigned int* __restrict__ keys
 
 __global__ __launch_bounds__(SORT_THREADS) void morton_sort_kernel(const float* __restrict__ xyz, int n, int npow2,
                                                                    float* __restrict__ xyz_sorted,
-                                                                   int32_t* __restrict__ perm) {
+                                                                   int32_t* __restrict__ perm,
+                                                                   int32_t* __restrict__ status_zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    // the pipeline's per-cloud status word starts every pass at 0 (this is the pass's first kernel: no memset launch)
+    if (status_zero && threadIdx.x == 0) status_zero[blockIdx.x] = 0;
     __shared__ float red[6][SORT_THREADS / 64];
     __shared__ float box[6];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -279,6 +282,11 @@ __global__ __launch_bounds__(SORT_THREADS) void morton_sort_kernel(const float* 
 
 extern "C" int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm,
                                void* stream) {
+    return epc_sort_launch(xyz, num_clouds, n, xyz_sorted, perm, nullptr, stream);
+}
+
+int epc_sort_launch(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm, int32_t* status_zero,
+                    void* stream) {
     EPC_CHECK_ARG(xyz && xyz_sorted, "null pointer");
     EPC_CHECK_ARG(num_clouds >= 0 && n > 0 && n <= SORT_MAX_N, "num_points must be in 1..16384");
     EPC_CHECK_ARG(xyz != xyz_sorted, "in-place sort is not supported");
@@ -295,7 +303,7 @@ extern "C" int epc_morton_sort(const float* xyz, int num_clouds, int n, float* x
         return EPC_EHIP;
     }
     hipLaunchKernelGGL(morton_sort_kernel, dim3(num_clouds), dim3(SORT_THREADS), lds_bytes, (hipStream_t)stream, xyz,
-                       n, npow2, xyz_sorted, perm);
+                       n, npow2, xyz_sorted, perm, status_zero);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -15,22 +15,41 @@ from .variables import VariableStore
 ARCH_IDS = {"epc-net": L.EPC_ARCH_EPC_NET, "epc-net-l": L.EPC_ARCH_EPC_NET_L}
 
 DEFAULT_PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INPUT_DIM": 3, "GROUPS": 4}
+# Arithmetic of the inference path when neither the engine nor params["PRECISION"] names one (include/epcnet.h:
+# EPC_PRECISION_*).  "f32" = the reference's class of arithmetic (float32 graph, models/epc-net.py:24-26) on split-bf16
+# MFMA; "fast" = EPC-Net's f16 + f6 path; "auto" = fast when the folded weights fit fp16, f32 otherwise.
+DEFAULT_PRECISION = "f32"
 
 
-def make_cfg(arch: str, num_points: int, params: Optional[dict], micro_batch: int = 0) -> L.EpcCfg:
+def resolve_precision(params: Optional[dict], precision: Optional[str] = None) -> str:
+    name = precision or (params or {}).get("PRECISION") or DEFAULT_PRECISION
+    name = str(name).lower()
+    if name not in ("f32", "fast", "auto"):
+        raise ValueError("PRECISION must be 'f32', 'fast' or 'auto', got %r" % (name,))
+    return name
+
+
+def make_cfg(arch: str, num_points: int, params: Optional[dict], micro_batch: int = 0,
+             precision: Optional[str] = None) -> L.EpcCfg:
     p = dict(DEFAULT_PARAMS)
     p.update(params or {})
     if arch not in ARCH_IDS:
         raise ValueError("unknown ARCH %r" % arch)
+    prec = resolve_precision(p, precision)
+    if prec == "auto":
+        prec = "fast"      # what 'auto' tries first (InferenceEngine.packed falls back on EPC_ERANGE)
     return L.EpcCfg(arch=ARCH_IDS[arch], num_points=int(num_points), input_dim=int(p["INPUT_DIM"]),
                     knn=int(p["KNN"]), cluster_size=int(p["CLUSTER_SIZE"]), output_dim=int(p["FEATURE_OUTPUT_DIM"]),
-                    groups=int(p.get("GROUPS", 4)), micro_batch=int(micro_batch))
+                    groups=int(p.get("GROUPS", 4)), micro_batch=int(micro_batch), precision=L.PRECISION_IDS[prec])
 
 
 class InferenceEngine:
     def __init__(self, arch: str, params: Optional[dict], store: VariableStore, outer: str = "query_triplets",
-                 micro_batch: int = 0, backbone_scope: str = "fastdgcnn", in_flight: int = 2):
+                 micro_batch: int = 0, backbone_scope: str = "fastdgcnn", in_flight: int = 2,
+                 precision: Optional[str] = None):
         self.arch = arch
+        self.precision = resolve_precision(params, precision)   # 'f32' | 'fast' | 'auto' (as requested)
+        self.resolved_precision: Optional[str] = None          # what the packed weights hold ('auto' decides at pack time)
         self.in_flight = max(1, min(int(in_flight), 8))   # passes kept in flight on separate HIP streams (submit / long calls)
         self._lanes = None                                 # [(torch.cuda.Stream, workspace tensor or None, last event or None)]
         self._next_lane = 0
@@ -42,6 +61,8 @@ class InferenceEngine:
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._ws: Optional[torch.Tensor] = None
+        self._last_cfg: Optional[L.EpcCfg] = None
+        self._fallback: "Optional[InferenceEngine]" = None   # f32-equivalent engine for clouds the fast path flags
 
     # ------------------------------------------------------------------------------------------------------
     def _relative_tensors(self) -> Dict[str, torch.Tensor]:
@@ -56,9 +77,17 @@ class InferenceEngine:
             out[rel] = t
         return out
 
+    def cfg_for(self, num_points: int) -> L.EpcCfg:
+        """The epc_cfg of a call on clouds of ``num_points`` points, in the precision the packed weights hold."""
+        prec = self.resolved_precision if self.precision == "auto" and self.resolved_precision else self.precision
+        return make_cfg(self.arch, num_points, self.params, self.micro_batch, precision=prec)
+
     def packed(self, cfg: L.EpcCfg) -> torch.Tensor:
-        key = (self.store.version, cfg.num_points, cfg.groups, cfg.knn)
+        # keyed on the version of THIS model's variables: a frozen teacher that shares the store with a student being
+        # trained (kd_train.py:467-497) is not re-folded every step
+        key = (self.store.version_of(self.outer), cfg.num_points, cfg.groups, cfg.knn, self.precision)
         if self._packed is not None and self._packed_key == key:
+            cfg.precision = L.PRECISION_IDS[self.resolved_precision]
             return self._packed
         L.require_gpu()
         nbytes = L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
@@ -73,8 +102,22 @@ class InferenceEngine:
         c_names = (ctypes.c_char_p * len(names))(*[n.encode() for n in names])
         c_ptrs = (ctypes.c_void_p * len(names))(*[t.data_ptr() for t in tensors])
         buf = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
-        L.check(L.lib().epc_net_pack_weights(ctypes.byref(cfg), c_names, c_ptrs, len(names), buf.data_ptr(), nbytes,
-                                             L.current_stream()))
+        rc = L.lib().epc_net_pack_weights(ctypes.byref(cfg), c_names, c_ptrs, len(names), buf.data_ptr(), nbytes,
+                                          L.current_stream())
+        if rc == L.EPC_ERANGE and self.precision == "auto":
+            # a folded weight does not fit fp16 (small moving variance / large gamma): the f32-equivalent arithmetic
+            cfg.precision = L.EPC_PRECISION_F32
+            nbytes = L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=tensors[0].device)
+            rc = L.lib().epc_net_pack_weights(ctypes.byref(cfg), c_names, c_ptrs, len(names), buf.data_ptr(), nbytes,
+                                              L.current_stream())
+        L.check(rc)
+        if self._packed is not None:
+            # batches submitted on the engine's lanes may still be reading the previous buffer: keep it alive until their
+            # streams have passed this point (the caching allocator would otherwise hand it out again)
+            for lane in self._lanes or []:
+                self._packed.record_stream(lane[0])
+        self.resolved_precision = "fast" if cfg.precision == L.EPC_PRECISION_FAST else "f32"
         self._packed, self._packed_key = buf, key
         return buf
 
@@ -84,10 +127,28 @@ class InferenceEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
 
-    def forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None, profile: "Optional[StageProfile]" = None
-                ) -> torch.Tensor:
+    def forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor] = None, profile: "Optional[StageProfile]" = None,
+                check: Optional[bool] = None) -> torch.Tensor:
         """xyz (num_clouds, N, 3) float32 on the GPU -> (num_clouds, FEATURE_OUTPUT_DIM).
-        ``profile``: record HIP events at the stage boundaries of this pass (same launches, same stream)."""
+        ``profile``: record HIP events at the stage boundaries of this pass (same launches, same stream).
+        ``check`` (default: True for precision 'auto'): when the call ran in the fast arithmetic, look at the result
+        (this synchronises) and re-extract in the f32-equivalent arithmetic every cloud the kernels flagged (NaN
+        descriptor: an activation left fp16's range, include/epcnet.h EPC_STATUS_FP16_RANGE).  A cloud that is still NaN
+        afterwards has a NaN / Inf coordinate -- the reference returns NaN for it as well."""
+        out = self._forward(xyz, out, profile)
+        if check is None:
+            check = self.precision == "auto"
+        if check and self.arch == "epc-net" and self.resolved_precision == "fast":
+            bad = torch.isnan(out).any(dim=1).nonzero().flatten()
+            if bad.numel():
+                if self._fallback is None:
+                    self._fallback = InferenceEngine(self.arch, self.params, self.store, outer=self.outer,
+                                                     micro_batch=self.micro_batch, backbone_scope=self.backbone_scope,
+                                                     in_flight=1, precision="f32")
+                out[bad] = self._fallback._forward(xyz.contiguous()[bad], None, None)
+        return out
+
+    def _forward(self, xyz: torch.Tensor, out: Optional[torch.Tensor], profile: "Optional[StageProfile]") -> torch.Tensor:
         if xyz.dim() != 3 or xyz.shape[-1] != 3:
             raise L.EpcNetError(-1, "expected (num_clouds, N, 3) points, got %s" % (tuple(xyz.shape),))
         if xyz.dtype != torch.float32:
@@ -95,7 +156,7 @@ class InferenceEngine:
         L.require_gpu()
         xyz = xyz.contiguous()
         nc, n = int(xyz.shape[0]), int(xyz.shape[1])
-        cfg = make_cfg(self.arch, n, self.params, self.micro_batch)
+        cfg = self.cfg_for(n)
         packed = self.packed(cfg)
         if out is None:
             out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
@@ -113,11 +174,25 @@ class InferenceEngine:
                                                        len(aux)))
             return out
         ws = self.workspace(cfg, max(nc, 1), xyz.device)
+        self._last_cfg = cfg
         L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                  ws.data_ptr(), ws.numel(), L.current_stream(),
                                                  profile.handle if profile is not None else None))
         return out
 
+
+    def last_status(self, xyz_or_count) -> "list[int]":
+        """Per-cloud EPC_STATUS_* words of the last pass of the most recent ``forward`` call on this engine's own
+        workspace (include/epcnet.h: epc_net_last_status; synchronises the stream).  A non-zero word = that cloud's
+        descriptor is NaN: bit 0 a NaN / Inf coordinate, bit 1 (fast precision) an activation outside fp16's range."""
+        nc = int(xyz_or_count.shape[0]) if torch.is_tensor(xyz_or_count) else int(xyz_or_count)
+        if self._ws is None or self._last_cfg is None or nc <= 0:
+            return []
+        mb = L.micro_batch_of(self._last_cfg, nc)
+        last = nc % mb or mb
+        arr = (ctypes.c_int32 * last)()
+        L.check(L.lib().epc_net_last_status(ctypes.byref(self._last_cfg), self._ws.data_ptr(), nc, arr, L.current_stream()))
+        return [int(v) for v in arr]
 
     # ---- throughput mode: independent batches in flight on the engine's own streams ---------------------------
     def _get_lanes(self, device):
@@ -136,7 +211,7 @@ class InferenceEngine:
         L.require_gpu()
         xyz = xyz.contiguous()
         nc, n = int(xyz.shape[0]), int(xyz.shape[1])
-        cfg = make_cfg(self.arch, n, self.params, self.micro_batch)
+        cfg = self.cfg_for(n)
         packed = self.packed(cfg)
         if out is None:
             out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
@@ -152,6 +227,7 @@ class InferenceEngine:
         stream.wait_stream(torch.cuda.current_stream(xyz.device))
         xyz.record_stream(stream)
         out.record_stream(stream)
+        packed.record_stream(stream)
         L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                  lane[1].data_ptr(), lane[1].numel(), ctypes.c_void_p(stream.cuda_stream),
                                                  profile.handle if profile is not None else None))

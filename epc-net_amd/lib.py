@@ -23,12 +23,21 @@ EPC_ARCH_EPC_NET = 0
 EPC_ARCH_EPC_NET_L = 1
 EPC_KNN_SELECT = 20
 EPC_KNN_CAP = 32
-STATUS_NAMES = {0: "EPC_OK", -1: "EPC_EINVAL", -2: "EPC_ENOMEM", -3: "EPC_EHIP", -4: "EPC_ENOTFOUND"}
+EPC_ERANGE = -5
+STATUS_NAMES = {0: "EPC_OK", -1: "EPC_EINVAL", -2: "EPC_ENOMEM", -3: "EPC_EHIP", -4: "EPC_ENOTFOUND", -5: "EPC_ERANGE"}
+# epc_cfg.precision (include/epcnet.h): f32-equivalent split-bf16 arithmetic / EPC-Net's f16 + f6 fast arithmetic
+EPC_PRECISION_F32 = 0
+EPC_PRECISION_FAST = 1
+PRECISION_IDS = {"f32": EPC_PRECISION_F32, "fast": EPC_PRECISION_FAST}
+# per-cloud status bits (a flagged cloud's descriptor is NaN)
+EPC_STATUS_NONFINITE_INPUT = 1
+EPC_STATUS_FP16_RANGE = 2
 
 # every symbol include/epcnet.h declares (tests check the library exports exactly these)
 EXPORTS = [
     "epc_last_error", "epc_version", "epc_net_packed_bytes", "epc_net_pack_weights", "epc_net_workspace_bytes",
-    "epc_net_forward", "epc_net_forward_overlapped", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
+    "epc_net_forward", "epc_net_forward_overlapped", "epc_net_last_status", "epc_conv5_assign_f32_fwd",
+    "epc_vlad_aggregate_f32_fwd", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
@@ -52,7 +61,7 @@ class EpcCfg(ctypes.Structure):
     """``struct epc_cfg`` of include/epcnet.h."""
     _fields_ = [("arch", c_int32), ("num_points", c_int32), ("input_dim", c_int32), ("knn", c_int32),
                 ("cluster_size", c_int32), ("output_dim", c_int32), ("groups", c_int32),
-                ("micro_batch", c_int32)]
+                ("micro_batch", c_int32), ("precision", c_int32)]
 
 
 if not os.path.exists(LIB_PATH):
@@ -78,18 +87,21 @@ _lib.epc_net_workspace_bytes.argtypes = [POINTER(EpcCfg), c_int]
 _lib.epc_net_forward.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P]
 _lib.epc_net_forward_overlapped.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, POINTER(_P), c_int]
 _lib.epc_knn_topk.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P]
-_lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
+_lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P]
+_lib.epc_net_last_status.argtypes = [POINTER(EpcCfg), _P, c_int, POINTER(c_int32), _P]
 _lib.epc_knn_mask.argtypes = [_P, _P, c_int, c_int, _P, _P]
 _lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
 _lib.epc_proxyconv_block_fwd.argtypes = [_P, _P, _P, _P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P,
-                                         c_int, c_int, _P, _P, _P]
-_lib.epc_conv5_assign_fwd.argtypes = [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
+                                         c_int, c_int, _P, _P, _P, _P]
+_lib.epc_conv5_assign_fwd.argtypes = [_P, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]
+_lib.epc_conv5_assign_f32_fwd.argtypes = [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]
 _lib.epc_vlad_aggregate_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]
+_lib.epc_vlad_aggregate_f32_fwd.argtypes = _lib.epc_vlad_aggregate_fwd.argtypes
 _lib.epc_vlad_head_workspace_bytes.restype = c_size_t
 _lib.epc_vlad_head_workspace_bytes.argtypes = [c_int, c_int]
-_lib.epc_vlad_head_fwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_vlad_head_fwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P, _P, c_size_t, _P]
 _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
-_lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P]
+_lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_morton_sort.argtypes = [_P, c_int, c_int, _P, _P, _P]
 from ctypes import c_long  # noqa: E402

@@ -13,7 +13,7 @@ _engines = {}
 def engine_for(arch: str, params: dict, backbone_scope: str = "fastdgcnn") -> InferenceEngine:
     st = default_store()
     key = (id(st), arch, outer_scope(), backbone_scope, tuple(sorted((k, v) for k, v in (params or {}).items()
-                                                       if k in ("CLUSTER_SIZE", "FEATURE_OUTPUT_DIM", "KNN", "INPUT_DIM", "GROUPS"))))
+                                                       if k in ("CLUSTER_SIZE", "FEATURE_OUTPUT_DIM", "KNN", "INPUT_DIM", "GROUPS", "PRECISION"))))
     eng = _engines.get(key)
     if eng is None:
         eng = InferenceEngine(arch, params, st, outer=outer_scope(), backbone_scope=backbone_scope)

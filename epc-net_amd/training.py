@@ -104,7 +104,7 @@ class TrainStep:
             loss = self._graphed_step(query, positives, negatives, other_neg, lr, bn_decay, t)
         else:
             loss = self._eager_step(query, positives, negatives, other_neg, lr, bn_decay, t)
-        self.store.version += 1
+        self.store.bump(self.outer or None)
         self.global_step += 1
         return loss.detach(), lr, bn_decay
 
@@ -131,7 +131,7 @@ class TrainStep:
                 w = self.store.vars[name]
                 grads.append(w.grad if w.grad is not None else ops.const_zeros_like(w))
             # data-parallel runs average the moving statistics too: apply the updates first
-            tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9)
+            tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9, scope=self.outer or None)
             self._average_over_ranks(grads)
             ops.adam_multi([self.store.vars[k] for k in names], [self.m[k] for k in names], [self.v[k] for k in names],
                            grads, lr, t, self.beta1, self.beta2, self.eps)                                # :273-277

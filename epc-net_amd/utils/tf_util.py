@@ -106,14 +106,14 @@ def defer_ema_updates() -> None:
     _deferred_ema = []
 
 
-def flush_ema_updates(fixed_decay: float, sched_decay) -> None:
+def flush_ema_updates(fixed_decay: float, sched_decay, scope: str = None) -> None:
     """Apply the collected updates: entries recorded with decay == fixed_decay use it, all others ``sched_decay``."""
     global _deferred_ema
     pend, _deferred_ema = _deferred_ema, None
     if pend:
         from .. import ops
         ops.ema_multi([p[0] for p in pend], [p[1] for p in pend], [p[2] for p in pend], fixed_decay, sched_decay)
-        default_store().version += 1
+        default_store().bump(scope)
 
 
 def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay, scheduled: bool = True) -> None:
@@ -130,7 +130,8 @@ def _ema_update(shadow: torch.Tensor, value: torch.Tensor, decay, scheduled: boo
     else:
         L.check(L.lib().epc_ema_update(shadow.data_ptr(), value.data_ptr(), shadow.numel(), float(decay), None,
                                        L.current_stream()))
-    default_store().version += 1
+    from ..variables import current_scope
+    default_store().bump(current_scope() or None)
 
 
 def batch_norm_template(inputs, is_training, scope, moments_dims, bn_decay, activation_relu=False):

@@ -32,9 +32,27 @@ class VariableStore:
         self.vars: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self.trainable: List[str] = []
         self.version = 0  # bumped whenever a value changes: engines re-pack their folded weights
+        self._all_version = 0                     # last change that may have touched any scope
+        self._scope_version: Dict[str, int] = {}  # top-level scope -> version of its last change (version_of)
         self._gen = torch.Generator(device="cpu")
         if seed is not None:
             self._gen.manual_seed(int(seed))  # the reference itself never seeds (MANUAL_SEED is a dead key)
+
+    def bump(self, scope: Optional[str] = None) -> None:
+        """Record that values changed: under the top-level scope of ``scope`` (a variable or scope name), or anywhere."""
+        self.version += 1
+        if scope:
+            self._scope_version[scope.split("/", 1)[0]] = self.version
+        else:
+            self._all_version = self.version
+
+    def version_of(self, scope: Optional[str]) -> int:
+        """Version of the last change that can have touched variables under ``scope``: a frozen model that shares the
+        store with a model being trained (the KD teacher, kd_train.py:467-497) keeps its version -- and its packed
+        inference weights -- while the other one steps."""
+        if not scope:
+            return self.version
+        return max(self._all_version, self._scope_version.get(scope.split("/", 1)[0], 0))
 
     # -- creation --------------------------------------------------------------------------------------------
     def get_variable(self, name: str, shape: Iterable[int], initializer: Callable[[Tuple[int, ...], torch.Generator], torch.Tensor],
@@ -49,7 +67,7 @@ class VariableStore:
         self.vars[name] = t
         if trainable:
             self.trainable.append(name)
-        self.version += 1
+        self.bump(name)
         return t
 
     # -- state dict -------------------------------------------------------------------------------------------
@@ -65,7 +83,7 @@ class VariableStore:
             raise ValueError("%s: shape %s != %s" % (name, tuple(v.shape), tuple(cur.shape)))
         with torch.no_grad():
             cur.copy_(v.to(cur.device))
-        self.version += 1
+        self.bump(name)
 
     def load_state_dict(self, values: Dict[str, object], strict: bool = True) -> List[str]:
         """Assign every matching name; returns the names of ``values`` that were not used (Adam slots etc.)."""
@@ -110,7 +128,7 @@ class VariableStore:
                 continue
             with torch.no_grad():
                 t.copy_(v.reshape(t.shape).to(t.device))
-        self.version += 1
+        self.bump()
 
     def num_trainable_params(self) -> int:
         """``count_params()`` of train.py:202-206."""

@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
     cfg.cluster_size = 64;
     cfg.output_dim = 256;
     cfg.groups = 4;
+    cfg.precision = argc > 2 && strcmp(argv[2], "fast") == 0 ? EPC_PRECISION_FAST : EPC_PRECISION_F32;
     if (num_clouds < 2) {
         fprintf(stderr, "need at least 2 clouds\n");
         return 1;

@@ -31,11 +31,32 @@ typedef enum epc_status {
     EPC_EINVAL = -1, /* bad shape / alignment / unsupported configuration */
     EPC_ENOMEM = -2, /* workspace or packed-weight buffer too small       */
     EPC_EHIP = -3,   /* a HIP runtime call failed: see epc_last_error()   */
-    EPC_ENOTFOUND = -4 /* a required named tensor is missing              */
+    EPC_ENOTFOUND = -4, /* a required named tensor is missing             */
+    EPC_ERANGE = -5    /* EPC_PRECISION_FAST: a folded weight leaves fp16's range (use EPC_PRECISION_F32) */
 } epc_status;
 
 #define EPC_ARCH_EPC_NET 0   /* models/epc-net.py   */
 #define EPC_ARCH_EPC_NET_L 1 /* models/epc-net-l.py */
+
+/* Arithmetic of the inference path (epc_cfg.precision).  The reference computes in float32 (models/epc-net.py:24-26
+ * tf.placeholder(tf.float32 ...), every op of utils/tf_util.py:52-107).
+ *   EPC_PRECISION_F32  f32-equivalent: every dense contraction runs on the bf16 MFMA with BOTH operands split
+ *                      hi = bf16(x), lo = bf16(x - hi) and three products (lo*hi + hi*lo + hi*hi, f32 accumulate: 2^-16
+ *                      relative per product); every tensor that crosses HBM is float32.  No range restriction beyond
+ *                      float32's.  EPC-Net-L always runs in this arithmetic.
+ *   EPC_PRECISION_FAST EPC-Net only: one fp16 value per activation, weights fp16 hi + MX-fp6 lo, fp16 tensors in HBM
+ *                      (DESIGN.md 2).  Folded weights must satisfy |W' * 256| <= 65504 (checked by
+ *                      epc_net_pack_weights: EPC_ERANGE) and activations must stay inside fp16's range (checked by the
+ *                      kernels per cloud: EPC_STATUS_FP16_RANGE, the cloud's descriptor is returned as NaN, never as a
+ *                      wrong finite vector). */
+#define EPC_PRECISION_F32 0
+#define EPC_PRECISION_FAST 1
+
+/* Per-cloud status bits (int32 per cloud; epc_net_forward keeps them in its workspace and epc_net_forward_status copies
+ * them out).  A cloud with a non-zero status gets a NaN descriptor: the reference returns NaN for a cloud with a NaN/Inf
+ * coordinate as well (every a_ij of utils/tf_util.py:651-656 involving the point is NaN). */
+#define EPC_STATUS_NONFINITE_INPUT 1 /* a coordinate of the cloud is NaN or +-Inf                                 */
+#define EPC_STATUS_FP16_RANGE 2      /* EPC_PRECISION_FAST: an activation left fp16's range (|v| > 65504)         */
 
 #define EPC_KNN_SELECT 20 /* utils/tf_util.py:660: tf.nn.top_k(a, k=20), hard-coded */
 #define EPC_KNN_CAP 32    /* neighbour-list slots per point; rows with more ties take the exact scan path */
@@ -50,6 +71,7 @@ typedef struct epc_cfg {
     int32_t output_dim;    /* FEATURE_OUTPUT_DIM, must be 256              */
     int32_t groups;        /* GROUPS, must divide 1024   (EPC-Net only)    */
     int32_t micro_batch;   /* clouds processed per internal pass (<= 0: library default) */
+    int32_t precision;     /* EPC_PRECISION_* (EPC-Net-L: ignored, always f32-equivalent) */
 } epc_cfg;
 
 const char* epc_last_error(void); /* thread-local, valid until the next failing call on this thread */
@@ -63,13 +85,17 @@ uint32_t epc_crc32c(uint32_t crc, const void* data, size_t n);
 /* (train.py:254, evaluate.py:250-251 -> models/epc-net.py:29-157, models/epc-net-l.py:29-102).             */
 /* ------------------------------------------------------------------------------------------------------ */
 
-/* Bytes of the packed inference-weight buffer (BN folded, MFMA operand order). */
+/* Bytes of the packed inference-weight buffer (BN folded, MFMA operand order; depends on cfg->precision). */
 size_t epc_net_packed_bytes(const epc_cfg* cfg);
 
 /* Fold + pack the reference's variables.  `names[i]` are the checkpoint names relative to the outer
  * `query_triplets/` scope (e.g. "fastdgcnn/conv1/weights", "VLAD/cluster_bn/moving_mean" -- table in
  * tests/golden/ckpt_tables.json); `tensors[i]` the matching float32 DEVICE buffers in the reference's shapes.
- * `names`/`tensors` are HOST arrays.  EPC_ENOTFOUND if a variable the architecture needs is absent. */
+ * `names`/`tensors` are HOST arrays.  EPC_ENOTFOUND if a variable the architecture needs is absent.
+ * EPC_PRECISION_FAST: the call additionally checks that every folded weight and bias fits fp16 after the 2^8 packing
+ * scale (a small moving variance or a large gamma can make |W'| exceed 255.9) and returns EPC_ERANGE otherwise -- it
+ * never packs an Inf.  That check reads one word back, so in FAST precision the call synchronises `stream`; callers that
+ * want automatic selection pack FAST first and fall back to EPC_PRECISION_F32 on EPC_ERANGE (epc-net_amd/engine.py). */
 int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names, const float* const* tensors, int n,
                          void* packed, size_t packed_bytes, void* stream);
 
@@ -79,6 +105,11 @@ size_t epc_net_workspace_bytes(const epc_cfg* cfg, int num_clouds);
  * models/epc-net.py:153-155).  num_clouds = B*P of the reference's (B,P,N,3) placeholder. */
 int epc_net_forward(const epc_cfg* cfg, const void* packed, const float* xyz, int num_clouds, float* out,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-cloud status words (EPC_STATUS_*) of the LAST pass that ran in `workspace` (the last min(num_clouds, micro_batch)
+ * clouds of the call), copied to the HOST array status_host; synchronises `stream`.  A non-zero word means that cloud's
+ * descriptor was returned as NaN. */
+int epc_net_last_status(const epc_cfg* cfg, const void* workspace, int num_clouds, int32_t* status_host, void* stream);
 
 /* Throughput form of epc_net_forward for num_clouds > micro_batch: successive passes (micro_batch clouds each) are
  * dealt round-robin over `stream` and `num_aux` (0..7) auxiliary streams of the caller, so that the passes' stages --
@@ -138,9 +169,13 @@ int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_tot
 /* epc_knn_topk and epc_conv1_fwd of the same (sorted) clouds in ONE launch: the kNN workgroup holds the cloud in LDS, so
  * conv1 costs it ~1.5 % more work instead of a launch of its own.  Bit-identical to the two separate calls.
  * idx_u16 != 0: the lists are written as uint16 entries (cap slots per point; n <= 8192) -- the pipeline's format, half
- * the list bytes for this kernel and for every epc_proxyconv_block_fwd that reads them. */
+ * the list bytes for this kernel and for every epc_proxyconv_block_fwd that reads them.
+ * status (num_clouds int32, may be NULL): OVERWRITTEN with EPC_STATUS_NONFINITE_INPUT / 0 per cloud, and
+ * EPC_STATUS_FP16_RANGE is added when a conv1 output does not fit the fp16 row (x16).  Rows of points with a non-finite
+ * coordinate have fewer than 20 selected entries; their unused list slots hold the point's own index, so every list
+ * entry any consumer reads is a valid row number. */
 int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
-                       const void* packed_conv1, float* x, void* x16, void* stream);
+                       const void* packed_conv1, float* x, void* x16, int32_t* status, void* stream);
 
 /* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
  *   xm = (sum_{j in nbr(i)} x_j) / knn ; t = xm - x ; t = conv_a(t) ; t = conv_b(t) ; out = t + xm ;
@@ -153,11 +188,13 @@ int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* i
  *     mean, xm - x, t + xm and the accumulators are f32.  The roundings are independent per point and channel and
  *     average out in the VLAD aggregation (descriptor effect 6e-7). */
 /* idx: the neighbour lists of epc_knn_topk (int32 entries, idx_u16 = 0) or of epc_knn_topk_conv1 with idx_u16 = 1
- * (uint16 entries, cap slots per point either way). */
+ * (uint16 entries, cap slots per point either way).
+ * status (num_clouds int32, may be NULL): the fp16 form ORs EPC_STATUS_FP16_RANGE into a cloud's word when one of the
+ * values it rounds to fp16 (xm - x, the conv_a activations, out, x_next) is outside fp16's range. */
 int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, const void* idx, int idx_u16,
                             const int32_t* cnt, const float* kth, int cap, const void* packed_block, int has_next, int num_clouds,
                             int n, int knn, float* out, void* out16, int out_stride, int out_off, float* x_next,
-                            void* x_next16, void* stream);
+                            void* x_next16, int32_t* status, void* stream);
 
 /* models/epc-net.py:136-139,147-148 + loupe.py:249-272: conv5 (+BN+ReLU), per-point L2 normalisation and the soft
  * assignment, in split fp16 MFMA arithmetic with f32 accumulation (one fp16 value per activation, weights as fp16
@@ -172,9 +209,22 @@ int epc_proxyconv_block_fwd(const float* x, const void* x16, const float* xyz, c
  *               aggregate consumes assign_frag);
  *   assign_frag (M/32, 2 cluster tiles, 2 k-steps, 64 lanes, 8 fp16): assign * 2^14 as B fragments (lane l of
  *               (tile g, t, s): cluster 32t + (l&31) at points 32g + 16s + 8(l>>5) + 0..7);
- *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276). */
-int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5, int num_points_total,
-                         void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
+ *   apart (M/32, 64)  per-tile sums of assign over its 32 points (a_sum partials, loupe.py:276).
+ * status (M/n int32, may be NULL; n = points per cloud): EPC_STATUS_FP16_RANGE is ORed into a cloud's word when a
+ * conv5 output of one of its points does not fit fp16 (detected on the f32 row norm: |feat|^2 > 65504^2). */
+int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* packed_conv5, int num_points_total, int n,
+                         void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart, int32_t* status,
+                         void* stream);
+
+/* The same stage in EPC_PRECISION_F32 (weights packed for that precision): cat (M, 256) f32 ->
+ *   feat_frag   (M/32, 32 chunks, 4 quads r, 64 lanes, 4 f32): the un-normalised conv5 output in f32, accumulator
+ *               order: lane l of (tile g, chunk c, quad r) holds point 32g + (l&31), element e = channel
+ *               32c + 8r + 4(l>>5) + e;
+ *   rnorm, assign, apart as above;
+ *   assign_frag (M/32, 2 cluster tiles t, 2 k-steps s, 2 parts (hi, lo), 64 lanes, 8 bf16): assign split as
+ *               hi = bf16(a), lo = bf16(a - hi), B fragments (lane l: cluster 32t + (l&31), points 32g + 16s + 8(l>>5) + 0..7). */
+int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat_frag,
+                             float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
 
 /* loupe.py:276-292: V[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] - a_sum[k] * centres[f][k] from the
  * fragment-ordered operands (fp16 MFMA, f32 accumulate; the 2^14 of assign_frag is removed), a_sum = the sum of the
@@ -183,17 +233,23 @@ int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* pac
  * V^2 over each chunk of 32 features (what the intra-normalisation of :295 needs). */
 int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
                            const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
+/* EPC_PRECISION_F32 form: operands in the layouts of epc_conv5_assign_f32_fwd; (feat * rnorm) is split into bf16 hi + lo
+ * and multiplied with the hi + lo assignments in three products (f32-equivalent). */
+int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
+                               const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
 
 /* loupe.py:295-331 + models/epc-net.py:153: intra-normalisation, flatten + L2, grouped hidden projection with the
  * shared weight (+BN, summed over groups), context gating, final L2. */
 size_t epc_vlad_head_workspace_bytes(int num_clouds, int groups);
+/* status (num_clouds int32, may be NULL): a cloud whose word is non-zero gets a NaN descriptor (see EPC_STATUS_*). */
 int epc_vlad_head_fwd(const float* V, const float* colss, const void* packed_head, int groups, int num_clouds,
-                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+                      float* out, const int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* models/epc-net-l.py:84-98: conv5 (128->1024)+BN+ReLU, global max over N, fc1 (1024->256)+BN+ReLU, L2. */
 int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
                           float* pooled, void* stream);
-int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, float* out, void* stream);
+int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, float* out, const int32_t* status,
+                    void* stream);
 
 /* evaluate.py:463,481: exact k nearest database descriptors per query by Euclidean distance (replaces
  * sklearn KDTree.query(k=25)); ties -> lower database index first.  idx (Q,k) int32, dist (Q,k) float32. */

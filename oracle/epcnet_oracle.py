@@ -152,6 +152,61 @@ def seeded_weights(arch: str = "epc-net", seed: int = 0, params: Optional[dict] 
     return w
 
 
+def adversarial_weights(arch: str = "epc-net", seed: int = 0, calibrate_on: Optional[np.ndarray] = None,
+                        params: Optional[dict] = None, outer: str = "query_triplets", gamma_range=(0.1, 10.0),
+                        floor_frac: float = 0.05) -> "OrderedDict[str, np.ndarray]":
+    """Weights that stress reduced-precision arithmetic, for the adversarial parity set (tests/test_gpu_adversarial.py):
+
+    * conv / fc / VLAD matrices: Student-t (3 degrees of freedom: heavy tails) at the standard deviation of the reference's
+      initialiser, with 1 % of the OUTPUT channels (at least one) multiplied by 50 (outlier channels);
+    * BatchNorm gamma log-uniform in ``gamma_range`` ([0.1, 10]), beta N(0, 0.3), biases N(0, 0.1);
+    * moving statistics: ``calibrate_on`` = None draws the variance log-uniform in [1e-4, 1.5] and the mean N(0, 0.1)
+      (un-trained-like: the folded weights W * gamma / sqrt(var + 1e-3) reach the hundreds and grow the activations layer by
+      layer); ``calibrate_on`` = clouds (B, N, 3) sets every moving mean / variance to the float64 batch statistics of that
+      layer on those clouds (what a trained checkpoint holds: normalised activations whatever the weights' scale), then
+      floors a random ``floor_frac`` (5 %) of each layer's variances at 1e-4 * (1 + their value) and leaves the others --
+      near-constant channels with a large 1 / sqrt(var).
+    """
+    rng = np.random.RandomState(100003 + seed)
+    w = seeded_weights(arch, seed, params, "trained", outer)
+    table = variable_table(arch, params, outer)
+    for name, (shape, kind) in table.items():
+        if kind == "weight":
+            std = float(np.std(w[name])) or 1.0
+            t = rng.standard_t(3, size=shape) / math.sqrt(3.0) * std
+            cout = shape[-1]
+            hot = rng.choice(cout, size=max(1, cout // 100), replace=False)
+            t[..., hot] *= 50.0
+            w[name] = t.astype(np.float32)
+        elif kind == "gamma":
+            w[name] = np.exp(rng.uniform(math.log(gamma_range[0]), math.log(gamma_range[1]), size=shape)).astype(np.float32)
+        elif kind == "beta":
+            w[name] = (rng.randn(*shape) * 0.3).astype(np.float32)
+        elif kind == "bias":
+            w[name] = (rng.randn(*shape) * 0.1).astype(np.float32)
+        elif kind == "var":
+            w[name] = np.exp(rng.uniform(math.log(1e-4), math.log(1.5), size=shape)).astype(np.float32)
+        elif kind == "mean":
+            w[name] = (rng.randn(*shape) * 0.1).astype(np.float32)
+    if calibrate_on is not None:
+        pc = np.asarray(calibrate_on, dtype=np.float32)
+        _, st = forward(pc[:, None], w, is_training=True, bn_decay=0.0, arch=arch, dtype=np.float64, params=params,
+                        outer=outer)
+        for name, val in st.new_stats.items():          # decay 0: the shadow becomes the batch statistic
+            w[name] = np.asarray(val, dtype=np.float32)
+        for scope, (mean, var) in st.batch_stats.items():   # slim layers (decay fixed at 0.999): take the statistics
+            if scope + "/moving_mean" in w:
+                w[scope + "/moving_mean"] = np.asarray(mean, dtype=np.float32)
+                w[scope + "/moving_variance"] = np.asarray(var, dtype=np.float32)
+        for name, (shape, kind) in table.items():
+            if kind == "var" and floor_frac > 0:
+                v = w[name]
+                low = rng.choice(v.size, size=max(1, int(v.size * floor_frac)), replace=False)
+                v[low] = 1e-4 * (1.0 + v[low])
+                w[name] = v
+    return w
+
+
 # --------------------------------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md 8d)
 # --------------------------------------------------------------------------------------------------------------
@@ -186,6 +241,18 @@ def synthetic_clouds(batch: int, n: int, seed: int, kind: str = "uniform") -> np
         pc = np.concatenate([base, base[:, : n - n // 2]], 1)
     elif kind == "zeros":  # evaluate.py:425-430 / train.py:834-844 padding clouds
         pc = np.zeros((batch, n, 3))
+    elif kind.startswith("repeat"):  # repeatNN: NN % of the points are copies of ONE point of the cloud (a clump of
+        # identical rows: nothing averages over them), the rest uniform; shuffled
+        frac = int(kind[len("repeat"):]) / 100.0
+        pc = rng.uniform(-1.0, 1.0, size=(batch, n, 3))
+        m = int(round(frac * n))
+        for b in range(batch):
+            pc[b, :m] = pc[b, n - 1]
+            pc[b] = pc[b][rng.permutation(n)]
+    elif kind.startswith("zeropad"):  # zeropadNN: the last NN % of the points are (0,0,0) (a partially padded cloud)
+        frac = int(kind[len("zeropad"):]) / 100.0
+        pc = rng.uniform(-1.0, 1.0, size=(batch, n, 3))
+        pc[:, n - int(round(frac * n)):] = 0.0
     else:
         raise ValueError(kind)
     return np.ascontiguousarray(pc, dtype=np.float32)

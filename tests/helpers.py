@@ -33,29 +33,31 @@ def make_store(arch, weights, device):
     return st
 
 
-def make_engine(arch, weights, device="cuda", micro_batch=0):
+def make_engine(arch, weights, device="cuda", micro_batch=0, precision="fast"):
+    """`precision`: 'fast' (EPC-Net's f16 + f6 kernels; EPC-Net-L ignores it) / 'f32' (split-bf16 everywhere) / 'auto'."""
     E = pkg("engine")
     st = make_store(arch, weights, device)
-    return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch), st
+    return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch, precision=precision), st
 
 
 def run_stages(eng, xyz):
     """Run the pipeline stage by stage through the C ABI, returning every intermediate as a torch tensor.
     EPC-Net's block chain runs on fp16 rows (x16 -> out16 / x_next16), EPC-Net-L's on f32 rows: `xs` / `cat` are
     returned in the dtype the stage wrote."""
-    f16 = eng.arch == "epc-net"
     L = pkg("lib")
     E = pkg("engine")
     lib = L.lib()
     nc, n, _ = xyz.shape
-    cfg = E.make_cfg(eng.arch, n, eng.params)
+    cfg = eng.cfg_for(n)
     packed = eng.packed(cfg)
+    f16 = eng.arch == "epc-net" and cfg.precision == L.EPC_PRECISION_FAST
     base = packed.data_ptr()
     off = lambda s: base + lib.epc_net_packed_offset(ctypes.byref(cfg), s)
     dev = xyz.device
     st = L.current_stream()
     M = nc * n
     out = {}
+    status = torch.zeros((nc,), dtype=torch.int32, device=dev)
     idx = torch.empty((nc, n, L.EPC_KNN_CAP), dtype=torch.int32, device=dev)
     cnt = torch.empty((nc, n), dtype=torch.int32, device=dev)
     kth = torch.empty((nc, n), dtype=torch.float32, device=dev)
@@ -78,37 +80,52 @@ def run_stages(eng, xyz):
                                             (idx16 if u16 else idx).data_ptr(), 1 if u16 else 0,
                                             cnt.data_ptr(), kth.data_ptr(), L.EPC_KNN_CAP, off(b), has_next, nc, n,
                                             cfg.knn, a32(cat), a16(cat), ccat, 64 * (b - 1), a32(xs[b]), a16(xs[b]),
-                                            st))
+                                            status.data_ptr(), st))
     out.update(xs=xs, cat=cat)
     desc = torch.empty((nc, 256), dtype=torch.float32, device=dev)
     if eng.arch == "epc-net":
-        featf = torch.empty((M // 32, 32, 2, 64, 8), dtype=torch.float16, device=dev)
         rnorm = torch.empty((nc, n), dtype=torch.float32, device=dev)
         assign = torch.empty((nc, n, 64), dtype=torch.float32, device=dev)
-        assignf = torch.empty((M // 32, 2, 2, 64, 8), dtype=torch.float16, device=dev)
         apart = torch.empty((nc, n // 32, 64), dtype=torch.float32, device=dev)
-        L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), 1, ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
-                                         assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
         vlad = torch.empty((nc, 1024, 64), dtype=torch.float32, device=dev)
         colss = torch.empty((nc, 32, 64), dtype=torch.float32, device=dev)
-        L.check(lib.epc_vlad_aggregate_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(), apart.data_ptr(),
-                                           off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
+        if f16:
+            featf = torch.empty((M // 32, 32, 2, 64, 8), dtype=torch.float16, device=dev)
+            assignf = torch.empty((M // 32, 2, 2, 64, 8), dtype=torch.float16, device=dev)
+            L.check(lib.epc_conv5_assign_fwd(cat.data_ptr(), 1, ccat, off(5), M, n, featf.data_ptr(), rnorm.data_ptr(),
+                                             assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), status.data_ptr(), st))
+            L.check(lib.epc_vlad_aggregate_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(), apart.data_ptr(),
+                                               off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
+            # unpack the fragment order (include/epcnet.h): [tile g][chunk c][half s][lane l][q] ->
+            # feat[32g + (l&31)][32c + 16s + 8(q>>2) + 4(l>>5) + (q&3)]   (fp16: 11 significant bits)
+            ff = featf.float().reshape(M // 32, 32, 2, 2, 32, 2, 4)        # (g, c, s, h, j, q>>2, q&3)
+            feat = ff.permute(0, 4, 1, 2, 5, 3, 6).reshape(nc, n, 1024)    # (g, j, c, s, q>>2, h, q&3) -> point-major
+            af = assignf.float().reshape(M // 32, 2, 2, 2, 32, 8) / 16384.0
+            aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)   # assign * rnorm
+        else:
+            featf = torch.empty((M // 32, 32, 4, 64, 4), dtype=torch.float32, device=dev)
+            assignf = torch.empty((M // 32, 2, 2, 2, 64, 8), dtype=torch.bfloat16, device=dev)
+            L.check(lib.epc_conv5_assign_f32_fwd(cat.data_ptr(), ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
+                                                 assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
+            L.check(lib.epc_vlad_aggregate_f32_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(),
+                                                   apart.data_ptr(), off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
+            # [tile g][chunk c][quad r][lane l][e] -> feat[32g + (l&31)][32c + 8r + 4(l>>5) + e]
+            ff = featf.reshape(M // 32, 32, 4, 2, 32, 4)                   # (g, c, r, h, j, e)
+            feat = ff.permute(0, 4, 1, 2, 3, 5).reshape(nc, n, 1024)       # (g, j, c, r, h, e)
+            # [tile g][t][s][part][lane l][q] -> a[32g + 16s + 8(l>>5) + q][32t + (l&31)], hi + lo
+            af = assignf.float().sum(3).reshape(M // 32, 2, 2, 2, 32, 8)   # (g, t, s, h, j, q)
+            aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)
         wsb = lib.epc_vlad_head_workspace_bytes(nc, cfg.groups)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         L.check(lib.epc_vlad_head_fwd(vlad.data_ptr(), colss.data_ptr(), off(6), cfg.groups, nc, desc.data_ptr(),
-                                      ws.data_ptr(), wsb, st))
-        # unpack the fragment order (include/epcnet.h): [tile g][chunk c][half s][lane l][q] ->
-        # feat[32g + (l&31)][32c + 16s + 8(q>>2) + 4(l>>5) + (q&3)]   (fp16: 11 significant bits)
-        ff = featf.float().reshape(M // 32, 32, 2, 2, 32, 2, 4)        # (g, c, s, h, j, q>>2, q&3)
-        feat = ff.permute(0, 4, 1, 2, 5, 3, 6).reshape(nc, n, 1024)    # (g, j, c, s, q>>2, h, q&3) -> point-major
-        af = assignf.float().reshape(M // 32, 2, 2, 2, 32, 8) / 16384.0
-        aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)   # assign * rnorm
+                                      status.data_ptr(), ws.data_ptr(), wsb, st))
         out.update(feat=feat, rnorm=rnorm, assign=assign, aprime=aprime, vlad=vlad, colss=colss, apart=apart)
     else:
         pooled = torch.empty((nc, 1024), dtype=torch.float32, device=dev)
         L.check(lib.epc_conv5_maxpool_fwd(cat.data_ptr(), ccat, off(5), nc, n, pooled.data_ptr(), st))
-        L.check(lib.epc_fc_head_fwd(pooled.data_ptr(), off(6), nc, desc.data_ptr(), st))
+        L.check(lib.epc_fc_head_fwd(pooled.data_ptr(), off(6), nc, desc.data_ptr(), status.data_ptr(), st))
         out.update(pooled=pooled)
     out["desc"] = desc
+    out["status"] = status
     torch.cuda.synchronize()
     return out

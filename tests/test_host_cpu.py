@@ -29,8 +29,19 @@ def test_library_exports_every_declared_symbol():
 def test_cfg_struct_layout_and_sizes():
     import ctypes
     L, E = H.pkg("lib"), H.pkg("engine")
-    assert ctypes.sizeof(L.EpcCfg) == 32
-    cfg = E.make_cfg("epc-net", 4096, H.PARAMS)
+    assert ctypes.sizeof(L.EpcCfg) == 36               # nine int32 fields (include/epcnet.h: epc_cfg, `precision` last)
+    assert E.make_cfg("epc-net", 4096, H.PARAMS).precision == L.EPC_PRECISION_F32      # the package default: the reference's class
+    assert E.make_cfg("epc-net", 4096, dict(H.PARAMS, PRECISION="fast")).precision == L.EPC_PRECISION_FAST
+    with pytest.raises(ValueError):
+        E.make_cfg("epc-net", 4096, dict(H.PARAMS, PRECISION="fp8"))
+    f32 = E.make_cfg("epc-net", 4096, H.PARAMS, precision="f32")
+    cfg = E.make_cfg("epc-net", 4096, H.PARAMS, precision="fast")
+    # the f32-equivalent path keeps f32 tensors between its stages: about twice the workspace of the fp16 path
+    assert L.lib().epc_net_workspace_bytes(ctypes.byref(f32), 64) > 1.8 * L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64)
+    assert L.lib().epc_net_packed_bytes(ctypes.byref(f32)) == L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
+    badp = E.make_cfg("epc-net", 4096, H.PARAMS)
+    badp.precision = 7
+    assert L.lib().epc_net_packed_bytes(ctypes.byref(badp)) == 0
     nbytes = L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
     assert nbytes >= 4704832 * 4 - 4 * 10000          # folded weights: ~ the trainable matrices
     offs = [L.lib().epc_net_packed_offset(ctypes.byref(cfg), s) for s in range(7)]
