@@ -297,10 +297,14 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
                 if constexpr (kF16) {
                     acc = mfma_f16(fa[s % RING][0], xf[s], acc);
-                } else {
+                } else if constexpr (MODE == MODE_MAX) {   // operands swapped: D[point][channel]
                     acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][1]), acc);
                     acc = mfma_bf16(xl[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
                     acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
+                } else {                                   // D[channel][point], split-bf16 x3
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][1]), xh[s], acc);
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][0]), xl[s], acc);
+                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][0]), xh[s], acc);
                 }
             }
         }

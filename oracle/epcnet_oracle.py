@@ -154,11 +154,11 @@ def seeded_weights(arch: str = "epc-net", seed: int = 0, params: Optional[dict] 
 
 def adversarial_weights(arch: str = "epc-net", seed: int = 0, calibrate_on: Optional[np.ndarray] = None,
                         params: Optional[dict] = None, outer: str = "query_triplets", gamma_range=(0.1, 10.0),
-                        floor_frac: float = 0.05) -> "OrderedDict[str, np.ndarray]":
+                        floor_frac: float = 0.05, outlier: float = 50.0) -> "OrderedDict[str, np.ndarray]":
     """Weights that stress reduced-precision arithmetic, for the adversarial parity set (tests/test_gpu_adversarial.py):
 
     * conv / fc / VLAD matrices: Student-t (3 degrees of freedom: heavy tails) at the standard deviation of the reference's
-      initialiser, with 1 % of the OUTPUT channels (at least one) multiplied by 50 (outlier channels);
+      initialiser, with 1 % of the OUTPUT channels (at least one) multiplied by ``outlier`` = 50 (outlier channels);
     * BatchNorm gamma log-uniform in ``gamma_range`` ([0.1, 10]), beta N(0, 0.3), biases N(0, 0.1);
     * moving statistics: ``calibrate_on`` = None draws the variance log-uniform in [1e-4, 1.5] and the mean N(0, 0.1)
       (un-trained-like: the folded weights W * gamma / sqrt(var + 1e-3) reach the hundreds and grow the activations layer by
@@ -176,7 +176,7 @@ def adversarial_weights(arch: str = "epc-net", seed: int = 0, calibrate_on: Opti
             t = rng.standard_t(3, size=shape) / math.sqrt(3.0) * std
             cout = shape[-1]
             hot = rng.choice(cout, size=max(1, cout // 100), replace=False)
-            t[..., hot] *= 50.0
+            t[..., hot] *= outlier
             w[name] = t.astype(np.float32)
         elif kind == "gamma":
             w[name] = np.exp(rng.uniform(math.log(gamma_range[0]), math.log(gamma_range[1]), size=shape)).astype(np.float32)
