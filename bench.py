@@ -2,61 +2,76 @@
 """bench.py -- clouds/s of EPC-Net 256-d global-descriptor extraction on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1 from a plain shell: the script launches itself (one process per GPU, torch.distributed.run, RCCL) BEFORE touching
+  the GPU and relays rank 0's JSON line; under an existing torchrun (WORLD_SIZE set) it is the rank process.
 
-A "step" = one pass of the hot path (epc_net_forward: kNN graph -> ProxyConv blocks -> conv5 -> G_VLAD -> 256-d
-descriptor) over one batch of synthetic clouds per GPU.  Workload at any N = BASELINE.json configs[1]: EPC-Net
-inference, batch 64 x 4096 x 3 fp32 per GPU, NetVLAD K=64, 256-D output; inputs are resident in HBM before the timed
-region.  Descriptor extraction shards over GPUs with no data-path collective (clouds are independent in inference,
-SURVEY.md 8e) -> weak scaling; value = clouds all ranks processed / max-over-ranks time.
+A "step" = one pass of the hot path (epc_net_forward: sort -> kNN graph -> ProxyConv blocks -> conv5 -> G_VLAD -> 256-d
+descriptor) over one batch of synthetic clouds per GPU.  Workload at any N = BASELINE.json configs[1]: EPC-Net inference,
+batch 64 x 4096 x 3 fp32 per GPU, NetVLAD K=64, 256-D output; inputs are resident in HBM before the timed region.
+Descriptor extraction shards over GPUs with no data-path collective (clouds are independent in inference)
+-> weak scaling; value = clouds all ranks processed / max-over-ranks time.
 
-Extra objects on the JSON line:
-  roofline     dominant kernel = conv5 + L2 + soft-assignment (conv5_kernel<256,VLAD>), bound = MFMA.  It runs on the
-               half-precision MFMA in split arithmetic (one fp16 value per activation; weights as fp16 hi + MX-fp6 lo, the
-               lo product on the K=64 scaled f8f6f4 MFMA; f32 accumulate; descriptor error 1.5e-6 against the f32 oracle), so it is priced against the dense
-               bf16/fp16 peak (2.5 PFLOP/s): achieved = ALGORITHMIC FLOPs per launch (2.684 GFLOP per cloud,
-               DESIGN.md) / its average duration, measured with HIP events recorded by the library on the launch
-               stream inside the timed region (on every --profile-every-th step); the matrix pipe executes 1.2x that
-               in bf16-rate units (frac is capped at 0.83).
-  overlapped   a second timed region after the first: the same K steps with --in-flight (2) of them in flight on the
-               engine's HIP streams (InferenceEngine.submit).  Reported beside `value`, never as `value`: kernels that
-               share the chip take longer individually, so the roofline figures belong to the one-stream region.
+`value` / `dtype` / `roofline` belong to EPC_PRECISION_F32 (include/epcnet.h): the f32-equivalent arithmetic (both MFMA
+operands split into bf16 hi + lo, three products, f32 accumulate, f32 tensors in HBM) -- the arithmetic class of the
+reference's float32 graph, the one that meets the 1e-4 bar on the whole adversarial parity set
+(tests/test_gpu_adversarial.py).  The same timed region is then repeated in EPC_PRECISION_FAST (one fp16 value per
+activation, weights fp16 hi + MX-fp6 lo; right-or-refuses outside fp16's range) and reported in the `fast` object with its
+own roofline -- never as `value`.
+
+Objects on the JSON line:
+  roofline     dominant kernel = conv5 + L2 norm + soft-assignment (conv5_kernel<256,VLAD>), bound = MFMA, priced against
+               the dense bf16 peak (2.5 PFLOP/s): achieved = ALGORITHMIC FLOPs per launch (2.684 GFLOP per cloud)
+               / its average duration from HIP events the library records on the launch stream inside the timed region
+               (every --profile-every-th step).  executed_* = the matrix-pipe work in bf16-rate units (3 products per
+               algorithmic product in f32-equivalent arithmetic; 1.2 in the fast one); mfma_util = the MFMA-busy fraction from
+               the committed rocprofv3 PMC pass of this command (profiles/pmc_compute_current.json), null when absent.
+  fast         the EPC_PRECISION_FAST region: value, ms_per_step, stage_ms, roofline, overlapped (two steps in flight).
+  configs      bounded legs for the other BASELINE.json configs, each timed like the main region (barrier + synchronize on
+               both sides, max over ranks):
+               train_step      configs[2]: one quadruplet step (1 + 2 + 14 + 1 clouds x 4096, train.py:238-277, 484-495), a
+                               FRESH tuple every step (the loss stays non-zero), HIP-graph replay at N = 1, data-parallel over
+                               tuples with one flat RCCL all-reduce at N > 1;
+               epc_net_l_b256  configs[3]: EPC-Net-L inference at batch 256 per GPU, with its own roofline;
+               retrieval       configs[4]: 11 960 synthetic descriptors (23 runs x (400 + 120), Oxford scale) sharded over the
+                               ranks, ONE RCCL all-gather of the shards, every rank ranks its query shard against the full
+                               database (epc_pairwise_topk, k = 25), the (Q, 25) index lists gathered to rank 0
+                               (evaluate.py:293-332).
   pipeline_hbm HBM bytes one step moves (PMC counters of the committed profile x launches per step) over the step time,
                against 8 TB/s -- the north_star's "fraction of the HBM roofline"; secondary, the path is not HBM-bound.
   cpu_baseline the CPU oracle (numpy restatement of the reference's dense (N,N)-mask formulation, batch = 1 cloud per
                call as evaluate.py:86-90 does) timed on this box's host cores on a bounded sample.  Rank 0, N = 1 only.
                It is NOT TensorFlow (not installable here) -- kind "port".  `index_form`: the same oracle with neighbour
-               lists + gathers (this repo's formulation) instead of the dense mask, so that the algorithmic gain can be
-               told from the hardware gain.
+               lists + gathers (this repo's formulation) instead of the dense mask.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INPUT_DIM": 3, "GROUPS": 4}
 OUTER = "query_triplets"
 N_POINTS = 4096
 # algorithmic FLOPs per cloud of the dominant kernel: conv5 256->1024 + assignment 1024->64 (SURVEY.md 8d)
 CONV5_ASSIGN_FLOPS = 2.0 * N_POINTS * 256 * 1024 + 2.0 * N_POINTS * 1024 * 64
+CONV5_L_FLOPS = 2.0 * N_POINTS * 128 * 1024
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16 MFMA (the 5 PF headline includes 2:1 sparsity)
-# Matrix-pipe work of the dominant kernel in units of one bf16/fp16 MFMA product per algorithmic product: conv5 = fp16
-# hi product (1) + MX-fp6 lo product on the K=64 scaled MFMA, which runs at four times the bf16 rate (0.25); assignment = 1
-# (single-fp16 cluster weights): (1.25 x 2147.5 + 536.9) / 2684.4 = 1.2, so `frac` (algorithmic / half-precision peak) is
-# capped at 0.83.  (EPC-Net-L's conv5 feeds a max-pool and stays on the 3-product split-bf16 form.)
-SPLIT_PRODUCTS = {"epc-net": 1.2, "epc-net-l": 3}
+# Matrix-pipe work of the dominant kernel in units of one bf16/fp16 MFMA product per algorithmic product:
+#   f32-equivalent: conv5 and the assignment both run hi*hi + hi*lo + lo*hi                                  -> 3
+#   fast: conv5 = fp16 hi product (1) + MX-fp6 lo product on the K=64 scaled MFMA at four times the rate (0.25),
+#         assignment = 1 (single-fp16 cluster weights): (1.25 x 2147.5 + 536.9) / 2684.4                     -> 1.2
+SPLIT_PRODUCTS = {("epc-net", "f32"): 3.0, ("epc-net", "fast"): 1.2, ("epc-net-l", "f32"): 3.0}
 FLOPS_PER_CLOUD = {"epc-net": 3.747e9, "epc-net-l": 1.355e9}
-# arithmetic of the dominant kernel (not a precision claim: results are f32-accurate, tests/test_gpu_parity.py)
-DTYPE = {"epc-net": "f16+f6", "epc-net-l": "bf16x3"}
+# arithmetic of the dominant kernel (not a precision claim: tests/test_gpu_parity.py, tests/test_gpu_adversarial.py)
+DTYPE = {("epc-net", "f32"): "bf16x3", ("epc-net", "fast"): "f16+f6", ("epc-net-l", "f32"): "bf16x3"}
+CONV5_KERNEL = {("epc-net", "f32"): "void conv5_kernel<256, 0, false, false>", ("epc-net", "fast"): "void conv5_kernel<256, 0, true, true>",
+                ("epc-net-l", "f32"): "void conv5_kernel<128, 1, false, false>"}
 
 
 def pkg(name=""):
@@ -106,16 +121,258 @@ def cpu_baseline(arch, store, budget_s, max_clouds):
                       % (done, N_POINTS, dt, os.cpu_count() or 0)}
 
 
+def self_launch(args, argv):
+    """--gpus N > 1 from a plain shell: start one rank process per GPU and relay rank 0's line.  Runs BEFORE this process
+    makes any HIP call (torch.cuda.device_count() does not initialise the runtime on this image) and starts the ranks as
+    CHILDREN -- a process that has initialised the GPU must never be replaced by exec."""
+    import torch
+    have = torch.cuda.device_count()
+    n = min(args.gpus, have) if have > 0 else 0
+    if n < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    child_argv = [a for a in argv]
+    if n != args.gpus:   # degrade cleanly: run on what the box has and say so
+        out, skip = [], False
+        for a in child_argv:
+            if skip:
+                skip = False
+                continue
+            if a == "--gpus":
+                skip = True
+                continue
+            if a.startswith("--gpus="):
+                continue
+            out.append(a)
+        child_argv = out + ["--gpus", str(n), "--requested-gpus", str(args.gpus)]
+    if n == 1:
+        cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
+    else:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + child_argv
+    env = dict(os.environ, EPC_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
+class Harness:
+    """Timing discipline shared by every leg: barrier + synchronize on both sides, max over ranks."""
+
+    def __init__(self, device, dist, world, rank):
+        self.device, self.dist, self.world, self.rank = device, dist, world, rank
+
+    def fence(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        import torch
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps):
+        """K calls of fn(k) between fences; returns max-over-ranks seconds."""
+        self.fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            fn(k)
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+def pmc_summary(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def kernel_entry(summary, prefix):
+    if not summary:
+        return None
+    for k, v in summary.get("kernels", {}).items():
+        if k.startswith(prefix):
+            return v
+    return None
+
+
+def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms, every, lanes):
+    """The timed region of one (arch, precision): K steps on ONE stream (stage-boundary HIP events on every `every`-th
+    step), then -- separately reported -- the same K steps with `lanes` of them in flight."""
+    import torch
+    device = H.device
+    eng = E.InferenceEngine(arch, PARAMS, store, outer=OUTER, micro_batch=batch, in_flight=max(1, lanes), precision=precision)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(100 + H.rank)                                  # every rank extracts different clouds
+    xyz = (torch.rand((batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
+    outs = [torch.empty((batch, 256), dtype=torch.float32, device=device) for _ in range(max(1, lanes))]
+    out = outs[0]
+    profiles = {k: E.StageProfile() for k in range(0, steps, every)}
+    scratch = E.StageProfile()
+    for k in range(max(warmup, 0)):
+        eng.forward(xyz, out=out, profile=scratch if k % every == 0 else None, check=False)   # the entry point the timed steps use
+    if warmup > 0:
+        torch.cuda.synchronize()
+        scratch.elapsed_ms()                                   # first event query happens outside the timed region
+        # Settle: a process that starts right after another GPU process has exited (pytest, then this) can see one
+        # 70-80 ms dispatch stall while the driver tears the old process down -- observed as a single slow kNN launch.
+        # Keep issuing UNTIMED steps until the device has been busy for --settle-ms since the first launch.
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
+            eng.forward(xyz, out=out, check=False)
+            torch.cuda.synchronize()
+    elapsed = H.timed(lambda k: eng.forward(xyz, out=out, profile=profiles.get(k), check=False), steps)
+    norms = out.norm(dim=1)
+    if not bool(torch.isfinite(out).all()) or float((norms - 1).abs().max()) > 1e-3:
+        raise SystemExit("descriptors are not unit-norm / finite: refusing to report a number")
+
+    # second, separately reported region: the same K steps with `lanes` of them in flight (InferenceEngine.submit deals
+    # successive steps over the engine's own HIP streams, own workspace and output buffer each: step k+1's kNN (VALU-bound)
+    # runs beside step k's conv5 / aggregate).  Kernels that share the chip take longer individually, so per-kernel
+    # roofline figures come from the one-stream region and this region only reports its step rate.
+    overlapped = None
+    if lanes > 1:
+        for k in range(4 * lanes):
+            eng.submit(xyz, out=outs[k % lanes])
+        el2 = H.timed(lambda k: eng.submit(xyz, out=outs[k % lanes]), steps)
+        if not all(torch.equal(out, o) for o in outs[1:]):
+            raise SystemExit("lanes disagree with the one-stream descriptors: refusing to report a number")
+        overlapped = {"steps_in_flight_per_gpu": lanes, "value": round(H.world * batch * steps / el2, 2),
+                      "unit": "clouds/s", "ms_per_step": round(el2 / steps * 1e3, 4),
+                      "how": "InferenceEngine.submit: successive steps on %d HIP streams, same kernels, same results" % lanes}
+    stage = {}
+    for pr in profiles.values():
+        for k, v in pr.elapsed_ms().items():
+            stage[k] = stage.get(k, 0.0) + v / len(profiles)
+    conv5_ms = stage["conv5"]
+    conv5_flops = (CONV5_ASSIGN_FLOPS if arch == "epc-net" else CONV5_L_FLOPS) * batch
+    achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12
+    key = (arch, precision)
+    # HBM bytes / MFMA-busy fraction per launch of the dominant kernel from the committed rocprofv3 PMC summaries of this
+    # same command (profiles/; collected by scripts/collect_profiles.sh at batch 64 / 256)
+    std_batch = batch == (64 if arch == "epc-net" else 256)
+    hbm = kernel_entry(pmc_summary("pmc_hbm_current.json"), CONV5_KERNEL[key]) if std_batch else None
+    comp = kernel_entry(pmc_summary("pmc_compute_current.json"), CONV5_KERNEL[key]) if std_batch else None
+    split = SPLIT_PRODUCTS[key]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                "traffic": hbm["hbm_bytes_per_launch_corrected"] if hbm else None,
+                "executed_tflops": round(achieved * split, 3),
+                "executed_frac": round(achieved * split / BF16_MFMA_PEAK_TFLOPS, 4),
+                "mfma_util": comp.get("mfma_util") if comp else None,
+                "vs_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                "kernel": "%s (conv5 + %s), %s MFMA, f32 accumulate"
+                          % (CONV5_KERNEL[key][5:], "L2 + soft-assignment" if arch == "epc-net" else "global max-pool", DTYPE[key]),
+                "avg_launch_ms": round(conv5_ms, 4), "algorithmic_flops_per_launch": conv5_flops}
+    res = {"value": round(H.world * batch * steps / elapsed, 2), "unit": "clouds/s", "dtype": DTYPE[key],
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "roofline": roofline,
+           "stage_ms": {k: round(v, 4) for k, v in stage.items()},
+           "pipeline_tflops": round(batch * steps / elapsed * FLOPS_PER_CLOUD[arch] / 1e12, 3)}
+    if overlapped is not None:
+        res["overlapped"] = overlapped
+    return res, elapsed
+
+
+def train_step_leg(H, steps, warmup):
+    """configs[2]: the quadruplet step at full size, a fresh tuple every step."""
+    import torch
+    TR = pkg("training")
+    store = build_store("epc-net", H.device, 0)                # every rank starts from the same weights
+    params = dict(PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5,
+                  MARGIN_2=0.2)
+    ts = TR.TrainStep(params, store, outer=OUTER)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7000 + H.rank)                               # data-parallel over tuples: every rank its own tuples
+    n_tuples = 8
+    tuples = [(torch.rand((18, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(H.device) for _ in range(n_tuples)]
+    use_graph = H.world == 1
+    losses = []
+
+    def one(k):
+        t = tuples[k % n_tuples]
+        loss, _, _ = ts.step(t[None, 0:1], t[None, 1:3], t[None, 3:17], t[None, 17:18], epoch=0, graph=use_graph)
+        losses.append(loss.clone() if use_graph else loss)
+
+    for k in range(warmup):
+        one(k)
+    del losses[:]
+    elapsed = H.timed(one, steps)
+    loss_vals = [float(x) for x in losses]
+    flops = 3.0 * FLOPS_PER_CLOUD["epc-net"] * 18
+    return {"workload": "EPC-Net quadruplet training step, 1 + 2 + 14 + 1 clouds x 4096 pts per GPU (BASELINE.json configs[2]; "
+                        "train.py:238-277, 484-495), fresh tuple every step, %s"
+                        % ("HIP-graph replay" if use_graph else "eager launches + one flat RCCL all-reduce of gradients and moving statistics"),
+            "value": round(H.world * steps / elapsed, 2), "unit": "tuples/s (18 clouds each)", "steps": steps,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": "bf16x6 forward / bf16x3 backward GEMMs (f32-accurate)",
+            "tflops": round(flops * steps / elapsed / 1e12, 2), "algorithmic_flops_per_step": flops,
+            "loss_first": round(loss_vals[0], 5), "loss_last": round(loss_vals[-1], 5),
+            "loss_mean": round(sum(loss_vals) / len(loss_vals), 5)}
+
+
+def retrieval_leg(H, steps, warmup):
+    """configs[4]: descriptors sharded over the ranks, one RCCL all-gather, local top-25, index gather."""
+    import torch
+    D, R = pkg("distributed"), pkg("retrieval")
+    n_db, n_q, k = 23 * 400, 23 * 120, 25
+    rank, world = H.rank, H.world
+    g = torch.Generator(device="cpu")
+    g.manual_seed(31)                                          # the same global set on every rank; each keeps its shard
+
+    def unit(n):
+        v = torch.randn((n, 256), generator=g)
+        return (v / v.norm(dim=1, keepdim=True)).float()
+    db_all, q_all = unit(n_db), unit(n_q)
+    a, b = D.shard_bounds(n_db, rank, world)
+    qa, qb = D.shard_bounds(n_q, rank, world)
+    db_local, q_local = db_all[a:b].to(H.device), q_all[qa:qb].to(H.device)
+    result = {}
+
+    def one(_k):
+        result["idx"] = D.sharded_knn(db_local, n_db, q_local, n_q, k, R.knn_search)
+
+    for i in range(warmup):
+        one(i)
+    elapsed = H.timed(one, steps)
+    if rank == 0:
+        # exactness against a float64 brute force on a sample of the queries (host, after the timed region)
+        idx = result["idx"]
+        sample = list(range(0, n_q, 97))
+        d = torch.cdist(q_all[sample].double(), db_all.double())
+        ref = torch.topk(d, k, dim=1, largest=False).indices.numpy()
+        if not (idx[sample] == ref).all():
+            raise SystemExit("retrieval leg: neighbour lists differ from the brute force: refusing to report a number")
+    gathered = (world - 1) * n_db * 256 * 4 // world if world > 1 else 0    # bytes each rank RECEIVES in the all-gather
+    ms = elapsed / steps * 1e3
+    return {"workload": "Oxford-scale retrieval, %d database + %d query descriptors (256-d, synthetic unit vectors) sharded over "
+                        "%d rank(s): all-gather of the database shards, local exact top-%d of the rank's queries, index gather "
+                        "(BASELINE.json configs[4]; evaluate.py:293-332, 463, 481)" % (n_db, n_q, world, k),
+            "rccl_ranks": world, "value": round(n_q * steps / elapsed, 1), "unit": "queries/s", "steps": steps,
+            "ms_per_step": round(ms, 4), "all_gather_bytes_received_per_rank": gathered,
+            "all_gather_GBps_per_rank_lower_bound": round(gathered / (ms * 1e-3) / 1e9, 2) if gathered else None,
+            "pair_distances_per_s": round(n_q * n_db * steps / elapsed / 1e9, 2), "pair_unit": "G pairs/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--requested-gpus", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle-ms", type=float, default=400.0, help="extra untimed steps after the warm-up (0 = none)")
     ap.add_argument("--batch", type=int, default=64, help="clouds per step per GPU (configs[1]: 64)")
     ap.add_argument("--arch", default="epc-net", choices=["epc-net", "epc-net-l"])
-    ap.add_argument("--precision", default="f32", choices=["f32", "fast"],
-                    help="arithmetic of the EPC-Net path (include/epcnet.h EPC_PRECISION_*)")
+    ap.add_argument("--precision", default="both", choices=["both", "f32", "fast"],
+                    help="EPC-Net arithmetic(s) to time (include/epcnet.h EPC_PRECISION_*); `value` is always the f32-equivalent "
+                         "one unless only `fast` is asked for (then the line says so in dtype)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="steps kept in flight on the engine's HIP streams (InferenceEngine.submit); 1 = one stream")
     ap.add_argument("--profile-every", type=int, default=8,
@@ -123,14 +380,18 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-clouds", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the train_step / epc_net_l_b256 / retrieval legs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])                        # does not return
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -140,148 +401,77 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
+    H = Harness(device, dist, world, rank)
     E = pkg("engine")
-    store = build_store(args.arch, device, seed=0)            # same weights on every rank
-    lanes = max(1, args.in_flight)
-    eng = E.InferenceEngine(args.arch, PARAMS, store, outer=OUTER, micro_batch=args.batch, in_flight=lanes,
-                            precision=args.precision)
-    g = torch.Generator(device="cpu")
-    g.manual_seed(100 + rank)                                  # every rank extracts different clouds
-    xyz = (torch.rand((args.batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
-    outs = [torch.empty((args.batch, 256), dtype=torch.float32, device=device) for _ in range(lanes)]
-    out = outs[0]
-
     every = max(1, args.profile_every)
-    profiles = {k: E.StageProfile() for k in range(0, args.steps, every)}
-    scratch = E.StageProfile()
-    for k in range(max(args.warmup, 0)):
-        eng.forward(xyz, out=out, profile=scratch if k % every == 0 else None)   # the entry point the timed steps use
-    if args.warmup > 0:
-        torch.cuda.synchronize()
-        scratch.elapsed_ms()                                   # first event query happens outside the timed region
-        # Settle: a process that starts right after another GPU process has exited (pytest, then this) can see one
-        # 70-80 ms dispatch stall while the driver tears the old process down -- observed as a single slow kNN launch.
-        # Keep issuing UNTIMED steps until the device has been busy for --settle-ms since the first launch.
-        t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            eng.forward(xyz, out=out)
-            torch.cuda.synchronize()
+    lanes = max(1, args.in_flight)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    store = build_store(args.arch, device, seed=0)             # same weights on every rank
+    precisions = ["f32"] if args.arch == "epc-net-l" else (["f32", "fast"] if args.precision == "both" else [args.precision])
+    legs = {}
+    for prec in precisions:
+        legs[prec], _ = extraction_leg(H, E, store, args.arch, prec, args.batch, args.steps, args.warmup, args.settle_ms,
+                                       every, lanes)
+    head_prec = precisions[0]
+    head = legs[head_prec]
 
-    def max_over_ranks(seconds):
-        if dist is None:
-            return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    configs = {}
+    if not args.no_configs and args.arch == "epc-net":
+        configs["train_step"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12)
+        stl = build_store("epc-net-l", device, seed=0)
+        leg, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 256, max(10, min(50, args.steps)), min(args.warmup, 10), 0.0,
+                                every, 1)
+        leg["workload"] = "EPC-Net-L inference, batch 256x4096x3 fp32 per GPU (BASELINE.json configs[3]; models/epc-net-l.py:29-102)"
+        configs["epc_net_l_b256"] = leg
+        configs["retrieval"] = retrieval_leg(H, steps=max(5, min(20, args.steps)), warmup=3)
 
-    # ---- the timed region: K steps on ONE stream; stage-boundary HIP events on every `every`-th step -------------
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        eng.forward(xyz, out=out, profile=profiles.get(k))
-    fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-
-    norms = out.norm(dim=1)
-    if not bool(torch.isfinite(out).all()) or float((norms - 1).abs().max()) > 1e-3:
-        raise SystemExit("descriptors are not unit-norm / finite: refusing to report a number")
-
-    # ---- second, separately reported region: the same K steps with `lanes` of them in flight ----------------------
-    # InferenceEngine.submit deals successive steps over the engine's own HIP streams (own workspace and output buffer
-    # each): step k+1's kNN (VALU-bound) then runs beside step k's conv5 / aggregate (MFMA- / HBM-bound).  Every step
-    # still does the whole path.  Kernels that share the chip take longer individually, so per-kernel roofline figures
-    # come from the one-stream region above and this region only reports its step rate.
-    overlapped = None
-    if lanes > 1:
-        for k in range(4 * lanes):
-            eng.submit(xyz, out=outs[k % lanes])
-        fence()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            eng.submit(xyz, out=outs[k % lanes])
-        fence()
-        el2 = max_over_ranks(time.perf_counter() - t1)
-        if not all(torch.equal(out, o) for o in outs[1:]):
-            raise SystemExit("lanes disagree with the one-stream descriptors: refusing to report a number")
-        overlapped = {"steps_in_flight_per_gpu": lanes, "value": round(world * args.batch * args.steps / el2, 2),
-                      "unit": "clouds/s", "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                      "how": "InferenceEngine.submit: successive steps on %d HIP streams, same kernels, same results" % lanes}
-
-    stage = {}
-    for pr in profiles.values():
-        for k, v in pr.elapsed_ms().items():
-            stage[k] = stage.get(k, 0.0) + v / len(profiles)
-    conv5_ms = stage["conv5"]
-    conv5_flops = (CONV5_ASSIGN_FLOPS if args.arch == "epc-net" else 2.0 * N_POINTS * 128 * 1024) * args.batch
-    achieved = conv5_flops / (conv5_ms * 1e-3) / 1e12
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
-    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/): measured at batch 64 only.
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_current.json")))
-        if args.arch == "epc-net" and args.batch == 64:
-            traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm["kernels"].items()
-                           if k.startswith("void conv5_kernel<256, 0"))
-    except Exception:
-        traffic = None
     # HBM bytes of ONE step = the PMC bytes per launch of the pipeline's kernels (profiles/pmc_hbm_current.json, collected
     # by scripts/collect_profiles.sh on this configuration) x their launches per step: the figure behind "fraction of the
     # HBM roofline" (north_star); the path is MFMA / VALU-bound, so it is a secondary number.
     hbm_step = None
-    try:
-        per_step = {"morton_sort_kernel": 1, "void knn_topk_culled_kernel": 1, "proxyconv_block_f16_kernel": 4,
-                    "void conv5_kernel<256, 0": 1, "vlad_aggregate_kernel": 1, "void vlad_fold_kernel": 1,
-                    "hidden_gemm_kernel": 1, "head_finish_kernel": 1}
-        if args.arch == "epc-net" and args.batch == 64:
+    pm = pmc_summary("pmc_hbm_current.json")
+    if pm and args.arch == "epc-net" and args.batch == 64 and head_prec in pm.get("launches_per_step", {}):
+        try:
             hbm_step = sum(v["hbm_bytes_per_launch_corrected"] * m for k, v in pm["kernels"].items()
-                           for pre, m in per_step.items() if k.startswith(pre))
-    except Exception:
-        hbm_step = None
-    clouds = world * args.batch * args.steps
-    value = clouds / elapsed
+                           for pre, m in pm["launches_per_step"][head_prec].items() if k.startswith(pre))
+        except Exception:
+            hbm_step = None
 
     if rank == 0:
         line = {
             "metric": "point-clouds/sec (4096 pts) descriptor extraction",
-            "value": round(value, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.arch], "data": "synthetic",
+            "value": head["value"], "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
             "config": {"workload": "%s inference, batch %dx%dx3 fp32 per GPU, NetVLAD K=64, 256-D output "
                                    "(BASELINE.json configs[1])" % (args.arch, args.batch, N_POINTS),
                        "clouds_per_step_per_gpu": args.batch, "num_points": N_POINTS,
+                       "precision": "EPC_PRECISION_%s (include/epcnet.h)" % head_prec.upper(),
                        "weights": "seeded random init of the architecture (no checkpoint payloads exist)",
                        "parallelism": "independent clouds sharded over %d GPU(s), no data-path collective" % world,
                        "stage_events_on_every_nth_step": every},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "executed_tflops": round(achieved * SPLIT_PRODUCTS[args.arch], 3),
-                         "executed_frac": round(achieved * SPLIT_PRODUCTS[args.arch] / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "vs_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                         "kernel": "conv5_kernel (conv5 + L2 + soft-assignment), split half-precision MFMA (%s), "
-                                   "f32 accumulate" % DTYPE[args.arch],
-                         "avg_launch_ms": round(conv5_ms, 4),
-                         "algorithmic_flops_per_launch": conv5_flops},
-            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
-            "pipeline_tflops": round(value / world * FLOPS_PER_CLOUD[args.arch] / 1e12, 3),
+            "roofline": head["roofline"], "stage_ms": head["stage_ms"], "pipeline_tflops": head["pipeline_tflops"],
         }
+        if args.requested_gpus and args.requested_gpus != world:
+            line["config"]["requested_gpus"] = args.requested_gpus
+            line["config"]["note"] = "the box shows %d GPU(s): ran on those" % world
         if hbm_step:
-            gbps = hbm_step / (elapsed / args.steps) / 1e9
+            gbps = hbm_step / (head["ms_per_step"] * 1e-3) / 1e9
             line["pipeline_hbm"] = {"bytes_per_step": int(hbm_step), "achieved_GBps": round(gbps, 1), "peak_GBps": 8000.0,
                                     "frac": round(gbps / 8000.0, 4),
                                     "how": "PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/) x launches per step / ms_per_step"}
-        if overlapped is not None:
-            line["overlapped"] = overlapped
+        if "overlapped" in head:
+            line["overlapped"] = head["overlapped"]
+        if "fast" in legs and head_prec != "fast":
+            line["fast"] = legs["fast"]
+        if configs:
+            line["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.arch, store, args.cpu_budget_s, args.cpu_clouds)
+            line["cpu_baseline"] = cpu_baseline(args.arch, store if args.arch != "epc-net" or not configs else build_store(args.arch, device, 0),
+                                                args.cpu_budget_s, args.cpu_clouds)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
