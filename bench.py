@@ -344,11 +344,13 @@ def retrieval_leg(H, steps, warmup):
     elapsed = H.timed(one, steps)
     if rank == 0:
         # exactness against a float64 brute force on a sample of the queries (host, after the timed region)
-        idx = result["idx"]
+        # (distances, not indices: two database rows whose float32 distances tie can order differently in float64)
+        idx = torch.as_tensor(result["idx"]).long()
         sample = list(range(0, n_q, 97))
         d = torch.cdist(q_all[sample].double(), db_all.double())
-        ref = torch.topk(d, k, dim=1, largest=False).indices.numpy()
-        if not (idx[sample] == ref).all():
+        ref = torch.topk(d, k, dim=1, largest=False).values
+        got = torch.gather(d, 1, idx[sample])
+        if idx.shape != (n_q, k) or float((got - ref).abs().max()) > 1e-6:
             raise SystemExit("retrieval leg: neighbour lists differ from the brute force: refusing to report a number")
     gathered = (world - 1) * n_db * 256 * 4 // world if world > 1 else 0    # bytes each rank RECEIVES in the all-gather
     ms = elapsed / steps * 1e3

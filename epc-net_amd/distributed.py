@@ -117,3 +117,29 @@ def all_reduce_gradients(tensors: Sequence[torch.Tensor], bucket_bytes: int = 32
         bucket.append(t)
         size += nbytes
     flush()
+
+
+def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0) -> None:
+    """In-place broadcast of a list of same-dtype tensors from rank ``src`` as ONE flat message.  No-op in a single process."""
+    rank, ws = world()
+    if ws == 1 or not tensors:
+        return
+    flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+    dist.broadcast(flat, src=src)
+    o = 0
+    for t in tensors:
+        n = t.numel()
+        t.detach().copy_(flat[o:o + n].reshape(t.shape))
+        o += n
+
+
+def all_true(flag: bool, device=None) -> bool:
+    """Logical AND of a per-rank condition (one tiny all-reduce): used to make every rank take the same branch -- e.g. to skip
+    a training iteration together when ANY rank drew a faulty tuple, so that no rank waits in a collective the others never
+    enter.  Single process: the flag itself."""
+    rank, ws = world()
+    if ws == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))

@@ -190,8 +190,11 @@ def data_path_for(prefix: str, shard: int = 0, num_shards: int = 1) -> str:
     return "%s.data-%05d-of-%05d" % (prefix, shard, num_shards)
 
 
-def load_checkpoint(prefix: str) -> Dict[str, np.ndarray]:
+def load_checkpoint(prefix: str, verify_crc: bool = True) -> Dict[str, np.ndarray]:
     """Load every tensor of ``<prefix>.index`` / ``<prefix>.data-00000-of-00001``.
+
+    ``verify_crc``: check every payload against the masked CRC-32C its index entry records, as TensorFlow's BundleReader
+    does -- a corrupted payload raises ValueError instead of loading silently.
 
     Mirrors the reference's refusal to run with an incomplete checkpoint (``evaluate.py:264-266``):
     raises FileNotFoundError when the data shard is missing (it is, for every checkpoint shipped in
@@ -210,6 +213,8 @@ def load_checkpoint(prefix: str) -> Dict[str, np.ndarray]:
         raw = blob[e.offset:e.offset + e.size]
         if len(raw) != e.size or e.size != e.numel * e.dtype.itemsize:
             raise ValueError("%s: payload size mismatch" % name)
+        if verify_crc and mask_crc(crc32c(raw)) != e.crc32c:
+            raise ValueError("%s: payload checksum mismatch (corrupt checkpoint %s)" % (name, dpath))
         out[name] = np.frombuffer(raw, dtype=e.dtype).reshape(e.shape).copy()
     return out
 

@@ -108,15 +108,26 @@ class Trainer:
     # ---- one epoch -------------------------------------------------------------------------------------------------------
     def train_one_epoch(self, epoch: int, max_iters: Optional[int] = None) -> List[float]:
         """train.py:330-617.  ``max_iters`` truncates the epoch (tests / smoke runs); None = the whole epoch."""
+        from . import distributed as D
+        rank, world = D.world()
         idxs = np.arange(0, len(self.TRAINING_QUERIES.keys()))
         np.random.shuffle(idxs)
-        iter_num = len(idxs) // self.B
+        if world > 1:
+            # data-parallel over tuples (SURVEY.md 8e): every rank must walk the SAME permutation (rank 0's) and take its own
+            # slice of every global batch of world * B queries; the ranks step -- or skip -- together
+            perm = torch.as_tensor(idxs, dtype=torch.int64, device=self.device)
+            D.broadcast_tensors([perm], src=0)
+            idxs = perm.cpu().numpy()
+        iter_num = len(idxs) // (self.B * world)
         losses = []
         for i in range(iter_num if max_iters is None else min(iter_num, max_iters)):
-            keys = idxs[i * self.B:(i + 1) * self.B]
+            base = (i * world + rank) * self.B
+            keys = idxs[base:base + self.B]
             batch, why = self._tuples(keys, self.TRAINING_QUERIES, self.train_data, self._hard_negatives)
-            if batch is None:
-                self.log.info("Epoch: [%d/%d][%d/%d] %s!!!", epoch, self.max_epoch, i + 1, iter_num, why)
+            if not D.all_true(batch is not None, self.device):
+                # a rank that skipped alone would leave the others waiting in the gradient all-reduce
+                self.log.info("Epoch: [%d/%d][%d/%d] %s!!!", epoch, self.max_epoch, i + 1, iter_num,
+                              why or "another rank drew a faulty tuple")
                 continue
             loss, lr, _ = self.step.step(*batch, epoch=epoch, graph=self.graph) if self.graph else self.step.step(*batch, epoch=epoch)
             losses.append(float(loss))
@@ -127,8 +138,8 @@ class Trainer:
             if epoch > 5 and i % (1400 // self.B) == 29:                                        # train.py:597-602
                 self.TRAINING_LATENT_VECTORS = self.get_latent_vectors()
                 self.log.info("Updated cached feature vectors")
-            if i % (6000 // self.B) == 101 and self.save_path:                                  # train.py:605-617
-                self.log.info("Model saved in file: %s", self.save(epoch, i))
+            if i % (6000 // self.B) == 101 and self.save_path and rank == 0:                    # train.py:605-617
+                self.log.info("Model saved in file: %s", self.save(epoch, i))     # (the ranks hold identical variables)
         return losses
 
     def evaluate_loss(self, epoch: int) -> float:
@@ -153,10 +164,14 @@ class Trainer:
     def checkpoint_tensors(self) -> Dict[str, np.ndarray]:
         """Everything tf.train.Saver() writes at train.py:611: model variables + step + Adam slots.  The optimizer
         scalars live at the graph root (``Variable``, ``beta1_power``, ``beta2_power``), or under ``student/`` for KD."""
-        out = {k: v.detach().cpu().numpy() for k, v in self.step.store.state_dict().items()}
         root = self.step.outer.split("/")[0] + "/" if "/" in self.step.outer else ""
+        # plain training: tf.train.Saver() covers the whole graph.  KD: student_saver covers scope `student` only
+        # (kd_train.py:525-526) -- no teacher/* variables, and the two beta powers live at the graph root, outside it
+        out = {k: v.detach().cpu().numpy() for k, v in self.step.store.state_dict().items() if k.startswith(root)}
         for k, v in self.step.optimizer_state().items():
             if k in ("Variable", "beta1_power", "beta2_power"):
+                if root and k != "Variable":
+                    continue
                 k = root + k
             out[k] = v.detach().cpu().numpy()
         return out
@@ -171,12 +186,17 @@ class Trainer:
         """train.py:308-315 (RESTORE): model variables, global step and Adam moments."""
         state = tf_bundle.load_checkpoint(prefix)
         self.step._ensure_built(int(self.train_data.shape[1]))
-        names = set(self.step.store.vars.keys())
+        root_scope = self.step.outer.split("/")[0] + "/" if "/" in self.step.outer else ""
+        names = set(k for k in self.step.store.vars.keys() if k.startswith(root_scope))
+        missing = sorted(names - set(state.keys()))
+        if missing:       # model variables are mandatory (only optimizer slots may be absent: a weights-only checkpoint)
+            raise KeyError("checkpoint %s lacks %d model variables, e.g. %s" % (prefix, len(missing), missing[:3]))
         self.step.store.load_state_dict({k: v for k, v in state.items() if k in names}, strict=False)
         root = self.step.outer.split("/")[0] + "/" if "/" in self.step.outer else ""
         opt = {k[len(root):] if k.startswith(root) and k[len(root):] in ("Variable", "beta1_power", "beta2_power")
                else k: v for k, v in state.items()}
         self.step.load_optimizer_state(opt)
+        self.step.sync_initial_state()
 
     def train(self, start_epoch: int = 1, max_iters: Optional[int] = None) -> None:
         """train.py:330-338."""

@@ -67,8 +67,13 @@ class TrainStep:
         for name in self.trainable_names():
             for slot, dst in (("/Adam", self.m), ("/Adam_1", self.v)):
                 if name + slot in state:
-                    dst[name] = torch.as_tensor(state[name + slot], dtype=torch.float32).to(self.store.device).reshape(
-                        self.store.vars[name].shape).clone()
+                    val = torch.as_tensor(state[name + slot], dtype=torch.float32).to(self.store.device).reshape(
+                        self.store.vars[name].shape)
+                    if name in dst:
+                        with torch.no_grad():
+                            dst[name].copy_(val)      # in place: a captured HIP graph of the step updates THESE buffers
+                    else:
+                        dst[name] = val.clone()
 
     def trainable_names(self):
         """The trainable variables under this step's scope (a second model in the same store -- the KD teacher -- is
@@ -79,11 +84,33 @@ class TrainStep:
     def _ensure_built(self, num_points: int):
         with variable_scope(self.outer):
             self.model.declare_variables(self.params, num_points)
+        fresh = False
         for name in self.trainable_names():
             self.store.vars[name].requires_grad_(True)
             if name not in self.m:
                 self.m[name] = torch.zeros_like(self.store.vars[name])
                 self.v[name] = torch.zeros_like(self.store.vars[name])
+                fresh = True
+        if fresh:
+            self.sync_initial_state()
+
+    def sync_initial_state(self) -> None:
+        """Data-parallel runs: every rank starts from RANK 0's variables, Adam moments and step count (the stores are
+        un-seeded by default -- the reference never seeds, MANUAL_SEED is a dead key -- so without this the ranks would
+        average gradients of different models).  Called once when the step is first built and after ``restore``; one flat
+        broadcast per dtype.  Single process: nothing to do."""
+        from . import distributed as D
+        if D.world()[1] == 1:
+            return
+        pre = self.outer + "/" if self.outer else ""
+        tensors = [v for k, v in self.store.vars.items() if k.startswith(pre)]
+        tensors += [self.m[n] for n in self.trainable_names()] + [self.v[n] for n in self.trainable_names()]
+        with torch.no_grad():
+            D.broadcast_tensors(tensors, src=0)
+            step = torch.tensor([self.global_step], dtype=torch.int64, device=self.store.device)
+            D.broadcast_tensors([step], src=0)
+        self.global_step = int(step.item())
+        self.store.bump(self.outer or None)
 
     def step(self, query, positives, negatives, other_neg, epoch: int = 0, graph: bool = False):
         """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3).
@@ -106,7 +133,8 @@ class TrainStep:
             loss = self._eager_step(query, positives, negatives, other_neg, lr, bn_decay, t)
         self.store.bump(self.outer or None)
         self.global_step += 1
-        return loss.detach(), lr, bn_decay
+        # (the graphed path returns the replayed graph's static output buffer: clone it, or the next replay overwrites it)
+        return (loss.detach().clone() if graph else loss.detach()), lr, bn_decay
 
     def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
         from .utils import tf_util

@@ -99,10 +99,11 @@ class VariableStore:
                 raise KeyError("checkpoint lacks %d variables, e.g. %s" % (len(missing), missing[:3]))
         return unused
 
-    def load_checkpoint(self, prefix: str) -> List[str]:
-        """``saver.restore`` (train.py:309-315, evaluate.py:268) from a TF bundle, without TensorFlow."""
+    def load_checkpoint(self, prefix: str, verify_crc: bool = True) -> List[str]:
+        """``saver.restore`` (train.py:309-315, evaluate.py:268) from a TF bundle, without TensorFlow.  Payload checksums are
+        verified like TensorFlow's BundleReader does (``verify_crc``)."""
         from . import tf_bundle
-        return self.load_state_dict(tf_bundle.load_checkpoint(prefix), strict=True)
+        return self.load_state_dict(tf_bundle.load_checkpoint(prefix, verify_crc=verify_crc), strict=True)
 
     def randomize_statistics(self, seed: int = 0) -> None:
         """Synthetic 'trained-like' values for everything the reference initialises to a constant (biases 0,

@@ -34,7 +34,7 @@ def make_store(arch, weights, device):
 
 
 def make_engine(arch, weights, device="cuda", micro_batch=0, precision="fast"):
-    """`precision`: 'fast' (EPC-Net's f16 + f6 kernels; EPC-Net-L ignores it) / 'f32' (split-bf16 everywhere) / 'auto'."""
+    """`precision`: 'fast' (EPC-Net's f16 + f6 kernels; EPC-Net-L ignores it) / 'f32' (f32-equivalent split arithmetic everywhere)."""
     E = pkg("engine")
     st = make_store(arch, weights, device)
     return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch, precision=precision), st

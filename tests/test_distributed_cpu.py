@@ -124,3 +124,55 @@ def test_gradient_averaging_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == "ok"
+
+
+def _sync_worker(rank, ws, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    D, TR, V = H.pkg("distributed"), H.pkg("training"), H.pkg("variables")
+    # un-seeded stores, as the reference's training is (MANUAL_SEED is a dead key): the ranks start from DIFFERENT inits
+    st = V.reset_default_store(device="cpu", seed=1000 + rank)
+    ts = TR.TrainStep(dict(H.PARAMS, ARCH="epc-net-l"), st, outer=H.OUTER, arch="epc-net-l")
+    ts.global_step = 5 * rank
+    ts._ensure_built(256)                                  # declares the variables, creates the Adam slots, broadcasts
+    flat = torch.cat([v.detach().reshape(-1) for v in st.vars.values()] +
+                     [ts.m[n].reshape(-1) for n in ts.trainable_names()])
+    both = [torch.zeros_like(flat) for _ in range(ws)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "variables / Adam moments differ between the ranks after the initial sync"
+    assert ts.global_step == 0                             # rank 0's step count
+    # gradient + moving-statistics averaging as TrainStep applies it (the Adam kernel then sees identical inputs everywhere)
+    g = torch.Generator().manual_seed(3 + rank)
+    grads = [torch.randn(st.vars[n].shape, generator=g) for n in ts.trainable_names()]
+    with torch.no_grad():
+        for k, v in st.vars.items():
+            if k not in st.trainable:
+                v.add_(float(rank + 1))                    # pretend this step updated the moving statistics differently
+    ts._average_over_ranks(grads)
+    flat = torch.cat([x.reshape(-1) for x in grads] + [v.detach().reshape(-1) for v in st.vars.values()])
+    both = [torch.zeros_like(flat) for _ in range(ws)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    # the skip vote: one rank with a faulty tuple makes every rank skip
+    assert D.all_true(True) is True
+    assert D.all_true(rank != 1) is False
+    if rank == 0:
+        ret.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_state_sync_and_skip_vote_world2_gloo():
+    """data-parallel TrainStep ranks must start from rank 0's weights / Adam moments / step count, average
+    gradients AND moving statistics, and skip an iteration together."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"

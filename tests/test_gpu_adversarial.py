@@ -18,8 +18,10 @@ it stays below that).  The bar is therefore applied where it is meaningful and a
   * always:  |ours - float64 oracle| <= max(1e-4, 4 * gap)  -- never worse than float32 arithmetic itself.
 
 The fast arithmetic has a range (fp16 activations, |W' * 256| <= 65504): outside it the library must REFUSE (EPC_ERANGE at
-pack time, NaN descriptor + status bit per cloud at run time), never return a wrong finite vector; precision 'auto'
-must return the f32-equivalent result for those clouds.
+pack time, NaN descriptor + status bit per cloud at run time) and `forward(check=True)` must return the f32-equivalent
+result for the refused clouds.  INSIDE its range it is only as good as its 11-bit activations: on the heavy-tailed weight
+sets it returns finite vectors that are 1e-2 off (measured; test_fast_arithmetic_limits_are_what_the_docs_say pins that), which
+is why it is an explicit opt-in and the f32-equivalent arithmetic is the package default and the bench headline.
 """
 import ctypes
 
@@ -99,10 +101,10 @@ def test_f32_equivalent_arithmetic_everywhere(dev, arch, level):
     assert eng.last_status(len(pc)) == [0] * len(pc)
 
 
-@pytest.mark.parametrize("level", list(LEVELS))
+@pytest.mark.parametrize("level", ["benign", "hard"])
 def test_fast_arithmetic_is_right_or_refuses(dev, level):
-    """EPC_PRECISION_FAST: every cloud is either within the bar or flagged (NaN descriptor + status bit); a weight set that
-    does not fit fp16 is refused at pack time.  Nothing in between."""
+    """EPC_PRECISION_FAST on ordinary weights (and on the set that drives it out of range): every cloud is either within the
+    bar or flagged (NaN descriptor + status bit); a weight set that does not fit fp16 is refused at pack time."""
     L = H.pkg("lib")
     w, pc, ref, ref64 = case("epc-net", level)
     eng, _ = H.make_engine("epc-net", w, dev, precision="fast")
@@ -117,7 +119,7 @@ def test_fast_arithmetic_is_right_or_refuses(dev, level):
     report("adversarial epc-net/fast %s:" % level, e32, e64, gap, status)
     # Ordinary clouds must be TAKEN (with ordinary or mildly adversarial weights).  The clumped / padded 4096-point clouds are
     # refused even with benign weights: 1024+ identical points make the neighbour mean (count / 20) * x = 51 x .. 205 x, four
-    # blocks compound it past 65504 -- the fast arithmetic's documented limit (include/epcnet.h); 'auto' re-runs them in f32.
+    # blocks compound it past 65504 -- the fast arithmetic's documented limit (include/epcnet.h); forward(check=True) re-runs them in f32.
     if level != "hard":
         assert status[0] == 0 and status[1] == 0
     for i, k in enumerate(KINDS):
@@ -127,20 +129,35 @@ def test_fast_arithmetic_is_right_or_refuses(dev, level):
             assert np.isfinite(out[i]).all() and within_bar(e32[i], e64[i], gap[i]), "%s: %.3e / %.3e" % (k, e32[i], e64[i])
 
 
-@pytest.mark.parametrize("level", list(LEVELS))
-def test_auto_precision_meets_the_bar_everywhere(dev, level):
+@pytest.mark.parametrize("level", ["benign", "hard"])
+def test_fast_with_check_reextracts_refused_clouds(dev, level):
+    """forward(check=True): the clouds the fast arithmetic refuses (here: the clumped / padded ones, or all of them) come back
+    in the f32-equivalent arithmetic."""
     w, pc, ref, ref64 = case("epc-net", level)
-    eng, _ = H.make_engine("epc-net", w, dev, precision="auto")
-    out = eng.forward(torch.from_numpy(pc).to(dev)).cpu().numpy()
+    eng, _ = H.make_engine("epc-net", w, dev, precision="fast")
+    out = eng.forward(torch.from_numpy(pc).to(dev), check=True).cpu().numpy()
     e32, e64, gap = errors(out, ref, ref64)
-    report("adversarial epc-net/auto (%s) %s:" % (eng.resolved_precision, level), e32, e64, gap)
+    report("adversarial epc-net/fast+check %s:" % level, e32, e64, gap)
     assert np.isfinite(out).all() and all(within_bar(*t) for t in zip(e32, e64, gap))
+
+
+def test_fast_arithmetic_limits_are_what_the_docs_say(dev):
+    """Heavy-tailed weights that stay inside fp16's range ("mild"): the fast arithmetic is NOT within the bar on ordinary
+    clouds (1e-2 on the uniform cloud when this was written) -- the documented reason it is opt-in.  If a later fast kernel
+    passes here, this test should be turned into a parity test and the documentation changed."""
+    w, pc, ref, ref64 = case("epc-net", "mild")
+    eng, _ = H.make_engine("epc-net", w, dev, precision="fast")
+    out = eng.forward(torch.from_numpy(pc[:2]).to(dev)).cpu().numpy()
+    err = np.linalg.norm(np.nan_to_num(out) - ref[:2], axis=1)
+    print("fast arithmetic on mildly adversarial weights: uniform %.1e lidar %.1e (bar 1e-4)" % (err[0], err[1]))
+    assert np.isfinite(out).all()            # in range: nothing is flagged, the vectors are finite
+    assert err.max() > DESC_TOL
 
 
 def test_uncalibrated_outlier_weights_never_give_inf(dev):
     """Weights whose moving variances are NOT calibrated (variance down to 1e-4 with gamma up to 10 on un-normalised
     activations): float32 itself is ill-conditioned there, so there is no parity bar -- but the fast arithmetic must refuse
-    (EPC_ERANGE: |W' * 256| > 65504), 'auto' must resolve to f32 and the f32-equivalent path must stay finite and unit-norm."""
+    (EPC_ERANGE: |W' * 256| > 65504) and the f32-equivalent path must stay finite and unit-norm."""
     L = H.pkg("lib")
     w = O.adversarial_weights("epc-net", 3, calibrate_on=None)
     pc = torch.from_numpy(O.synthetic_clouds(2, 512, 1)).to(dev)
@@ -148,9 +165,8 @@ def test_uncalibrated_outlier_weights_never_give_inf(dev):
     with pytest.raises(L.EpcNetError) as ei:
         eng.forward(pc)
     assert ei.value.status == L.EPC_ERANGE
-    eng, _ = H.make_engine("epc-net", w, dev, precision="auto")
+    eng, _ = H.make_engine("epc-net", w, dev, precision="f32")
     out = eng.forward(pc)
-    assert eng.resolved_precision == "f32"
     assert bool(torch.isfinite(out).all()) and float((out.norm(dim=1) - 1).abs().max()) < 1e-4
 
 
@@ -176,7 +192,7 @@ def test_non_finite_coordinates_poison_only_their_cloud(dev, arch, prec):
 
 def test_fp16_range_flag_on_large_activations(dev):
     """Benign weights, coordinates scaled by 1e6: conv1's output leaves fp16 -- the fast path flags the cloud (status bit,
-    NaN descriptor), the f32-equivalent path and 'auto' return the oracle's descriptor."""
+    NaN descriptor), the f32-equivalent path and forward(check=True) return the oracle's descriptor."""
     L = H.pkg("lib")
     w = O.seeded_weights("epc-net", 1)
     pc = O.synthetic_clouds(2, 512, 3)
@@ -188,7 +204,8 @@ def test_fp16_range_flag_on_large_activations(dev):
     out = fast.forward(x, check=False)
     assert fast.last_status(2) == [0, L.EPC_STATUS_FP16_RANGE]
     assert bool(torch.isnan(out[1]).all()) and np.linalg.norm(out[0].cpu().numpy() - ref[0]) <= DESC_TOL
-    for prec in ("f32", "auto"):
-        eng, _ = H.make_engine("epc-net", w, dev, precision=prec)
-        got = eng.forward(x).cpu().numpy()
-        assert np.linalg.norm(got - ref, axis=1).max() <= DESC_TOL, prec
+    got = fast.forward(x, check=True).cpu().numpy()                      # re-extracts the flagged cloud in f32
+    assert np.linalg.norm(got - ref, axis=1).max() <= DESC_TOL
+    eng, _ = H.make_engine("epc-net", w, dev, precision="f32")
+    got = eng.forward(x).cpu().numpy()
+    assert np.linalg.norm(got - ref, axis=1).max() <= DESC_TOL
