@@ -11,10 +11,11 @@ batch 64 x 4096 x 3 fp32 per GPU, NetVLAD K=64, 256-D output; inputs are residen
 Descriptor extraction shards over GPUs with no data-path collective (clouds are independent in inference)
 -> weak scaling; value = clouds all ranks processed / max-over-ranks time.
 
-`value` / `dtype` / `roofline` belong to EPC_PRECISION_F32 (include/epcnet.h): the f32-equivalent arithmetic (both MFMA
-operands split into bf16 hi + lo, three products, f32 accumulate, f32 tensors in HBM) -- the arithmetic class of the
-reference's float32 graph, the one that meets the 1e-4 bar on the whole adversarial parity set
-(tests/test_gpu_adversarial.py).  The same timed region is then repeated in EPC_PRECISION_FAST (one fp16 value per
+`value` / `dtype` / `roofline` belong to EPC_PRECISION_F32 (include/epcnet.h): the f32-equivalent arithmetic (conv layers:
+both MFMA operands scaled by a per-row / per-column power of two and split into fp16 hi + lo, three products, f32 accumulate
+= 2^-21 per product; f32 tensors in HBM) -- the arithmetic class of the reference's float32 graph, the one that meets the
+1e-4 bar on the whole adversarial parity set (tests/test_gpu_adversarial.py: closer to the float64 result than numpy's
+float32 on the ill-conditioned cases).  The same timed region is then repeated in EPC_PRECISION_FAST (one fp16 value per
 activation, weights fp16 hi + MX-fp6 lo; right-or-refuses outside fp16's range) and reported in the `fast` object with its
 own roofline -- never as `value`.
 
@@ -69,7 +70,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16 MFMA (the 5 PF
 SPLIT_PRODUCTS = {("epc-net", "f32"): 3.0, ("epc-net", "fast"): 1.2, ("epc-net-l", "f32"): 3.0}
 FLOPS_PER_CLOUD = {"epc-net": 3.747e9, "epc-net-l": 1.355e9}
 # arithmetic of the dominant kernel (not a precision claim: tests/test_gpu_parity.py, tests/test_gpu_adversarial.py)
-DTYPE = {("epc-net", "f32"): "bf16x3", ("epc-net", "fast"): "f16+f6", ("epc-net-l", "f32"): "bf16x3"}
+DTYPE = {("epc-net", "f32"): "f16x3", ("epc-net", "fast"): "f16+f6", ("epc-net-l", "f32"): "f16x3"}
 CONV5_KERNEL = {("epc-net", "f32"): "void conv5_kernel<256, 0, false, false>", ("epc-net", "fast"): "void conv5_kernel<256, 0, true, true>",
                 ("epc-net-l", "f32"): "void conv5_kernel<128, 1, false, false>"}
 

@@ -24,7 +24,8 @@
 #define BLK_THREADS (64 * BLK_WAVES)
 #define ST_STRIDE 68  // floats per staged row: 64 + 4 pad -> conflict-free b128 reads in both layouts
 #define BLK_PACK EPC_BLOCK_PACK_FLOATS
-#define BLK_LDS_FLOATS (BLK_PACK + BLK_WAVES * 32 * ST_STRIDE)
+#define BLK_PACK_S EPC_BLOCK_PACK_FLOATS_S   // f32 kernel: the three layers' inverse column scales follow the layer packs
+#define BLK_LDS_FLOATS (BLK_PACK_S + BLK_WAVES * 32 * ST_STRIDE)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -40,6 +41,14 @@ __device__ __forceinline__ void acc_init_bias(f32x16& acc, const float* bias32, 
     }
 }
 
+// compensated summation step: sum += v with the rounding error carried in comp (no fast-math: not re-associated)
+__device__ __forceinline__ void kahan_add(float& sum, float& comp, float v) {
+    const float y = v - comp;
+    const float t = sum + y;
+    comp = (t - sum) - y;
+    sum = t;
+}
+
 __device__ __forceinline__ void relu16(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
@@ -49,50 +58,61 @@ __device__ __forceinline__ bf16x8 ldfrag(const float* p) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
 }
 
-// The three 64x64 layers run on the bf16 MFMA in split (bf16x3) arithmetic like conv5: 24 MFMAs of 32
-// cycles per layer instead of 64 f32 MFMAs of 64 cycles.  Weight fragments: pack.hip fold_pack_block_bf16_kernel.
-// 64->64 layer whose B operand comes from a staged [pt][64] row: k-step s = channels 16s + 8h .. +7 of the lane's point.
-__device__ __forceinline__ void layer_split64(const float* lw, const float* lbias, const bf16x8 (&bh)[4],
-                                              const bf16x8 (&bl)[4], f32x16 (&acc)[2], int lane) {
+// The three 64x64 layers of the f32 kernel run on the fp16 MFMA in SCALED split-fp16 arithmetic (common.h: every point's
+// 64-channel row and every output channel's weight column scaled by a power of two into [2^14, 2^15), hi + lo fp16 parts,
+// three products): 24 MFMAs of 32 cycles per layer instead of 64 f32 MFMAs of 64 cycles, 2^-21 per product.  Weight
+// fragments: pack.hip fold_pack_block_kernel (f16 = 0); `ltinv` = the layer's 64 inverse column scales.
+__device__ __forceinline__ f16x8 ldfrag_h(const float* p) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
+}
+// the three products of one layer on ready B fragments, then out = acc * (inv_row * inv_col[ch]) + bias[ch]
+__device__ __forceinline__ void layer_s64(const float* lw, const float* lbias, const float* ltinv, const f16x8 (&bh)[4],
+                                          const f16x8 (&bl)[4], float inv_row, f32x16 (&acc)[2], int lane) {
     const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        acc_init_bias(acc[t], lbias + 32 * t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 ah = ldfrag(lw + (((t * 4 + s) * 2 + 0) * 64 + lane) * 4);
-            const bf16x8 al = ldfrag(lw + (((t * 4 + s) * 2 + 1) * 64 + lane) * 4);
-            acc[t] = mfma_bf16(al, bh[s], acc[t]);
-            acc[t] = mfma_bf16(ah, bl[s], acc[t]);
-            acc[t] = mfma_bf16(ah, bh[s], acc[t]);
+            const f16x8 ah = ldfrag_h(lw + (((t * 4 + s) * 2 + 0) * 64 + lane) * 4);
+            const f16x8 al = ldfrag_h(lw + (((t * 4 + s) * 2 + 1) * 64 + lane) * 4);
+            acc[t] = mfma_f16(al, bh[s], acc[t]);
+            acc[t] = mfma_f16(ah, bl[s], acc[t]);
+            acc[t] = mfma_f16(ah, bh[s], acc[t]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 ti = ld4(ltinv + 32 * t + 8 * g + 4 * h), b = ld4(lbias + 32 * t + 8 * g + 4 * h);
+            acc[t][4 * g + 0] = __builtin_fmaf(acc[t][4 * g + 0], inv_row * ti.x, b.x);
+            acc[t][4 * g + 1] = __builtin_fmaf(acc[t][4 * g + 1], inv_row * ti.y, b.y);
+            acc[t][4 * g + 2] = __builtin_fmaf(acc[t][4 * g + 2], inv_row * ti.z, b.z);
+            acc[t][4 * g + 3] = __builtin_fmaf(acc[t][4 * g + 3], inv_row * ti.w, b.w);
         }
     }
 }
 
 // 64->64 layer whose B operand is the previous layer's accumulators: k-step (tin, s') = registers 8s'..8s'+7 of tile tin.
-__device__ __forceinline__ void layer_acc64(const float* lw, const float* lbias, const f32x16 (&in)[2],
+// The lane holds 32 of its point's 64 channels, lane ^ 32 the others: the row maximum is one exchange.
+__device__ __forceinline__ void layer_acc64(const float* lw, const float* lbias, const float* ltinv, const f32x16 (&in)[2],
                                             f32x16 (&acc)[2], int lane) {
-    const int h = lane >> 5;
-    bf16x8 fh[4], fl[4];
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(in[t][r]));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc, inv_row;
+    row_scale_pow2(m, sc, inv_row);
+    f16x8 fh[4], fl[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = in[st >> 1][8 * (st & 1) + q];
-        split8(v, fh[st], fl[st]);
+        split8_f16s(v, sc, fh[st], fl[st]);
     }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        acc_init_bias(acc[t], lbias + 32 * t, h);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const bf16x8 ah = ldfrag(lw + (((t * 4 + st) * 2 + 0) * 64 + lane) * 4);
-            const bf16x8 al = ldfrag(lw + (((t * 4 + st) * 2 + 1) * 64 + lane) * 4);
-            acc[t] = mfma_bf16(al, fh[st], acc[t]);
-            acc[t] = mfma_bf16(ah, fl[st], acc[t]);
-            acc[t] = mfma_bf16(ah, fh[st], acc[t]);
-        }
-    }
+    layer_s64(lw, lbias, ltinv, fh, fl, inv_row, acc, lane);
 }
 
 // accumulators (channel in register, point on lane) -> staged [pt][64] rows
@@ -106,15 +126,25 @@ __device__ __forceinline__ void acc_to_stage(float* st, const f32x16 (&acc)[2], 
                 make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]));
 }
 
-// staged [pt][64] row of the lane's point -> split B fragments (k-step s = channels 16s + 8h .. +7)
-__device__ __forceinline__ void stage_to_bop(const float* st, bf16x8 (&bh)[4], bf16x8 (&bl)[4], int lane) {
+// staged [pt][64] row of the lane's point -> scaled split B fragments (k-step s = channels 16s + 8h .. +7); returns the
+// row's inverse scale
+__device__ __forceinline__ float stage_to_bop(const float* st, f16x8 (&bh)[4], f16x8 (&bl)[4], int lane) {
     const int j = lane & 31, h = lane >> 5;
+    float v[4][8];
+    float m = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float4 a = ld4(st + j * ST_STRIDE + 16 * s + 8 * h), b = ld4(st + j * ST_STRIDE + 16 * s + 8 * h + 4);
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        split8(v, bh[s], bl[s]);
+        v[s][0] = a.x, v[s][1] = a.y, v[s][2] = a.z, v[s][3] = a.w, v[s][4] = b.x, v[s][5] = b.y, v[s][6] = b.z, v[s][7] = b.w;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(v[s][q]));
     }
+    m = fmaxf(m, __shfl_xor(m, 32));   // the other 32 channels of the point
+    float sc, inv_row;
+    row_scale_pow2(m, sc, inv_row);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) split8_f16s(v[s], sc, bh[s], bl[s]);
+    return inv_row;
 }
 
 // ---- shared pieces of the two block kernels ------------------------------------------------------------------
@@ -160,7 +190,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
 #endif
 }
 
-// ---- f32 rows, split-bf16 layers (EPC-Net-L; f32-accurate at every stage boundary) -------------------------------
+// ---- f32 rows, scaled split-fp16 layers (EPC_PRECISION_F32 and EPC-Net-L; f32-equivalent at every stage boundary) ----
 __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* __restrict__ x, const float* __restrict__ xyz, const void* __restrict__ idx, int idx_u16,
     const int32_t* __restrict__ cnt, const float* __restrict__ kth, int cap, const float* __restrict__ pack,
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     float* __restrict__ x_next) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int o = tid * 4; o < BLK_PACK; o += BLK_THREADS * 4) st4(lds + o, ld4(pack + o));
+    for (int o = tid * 4; o < BLK_PACK_S; o += BLK_THREADS * 4) st4(lds + o, ld4(pack + o));
     __syncthreads();
     const float* wa = lds;
     const float* ba = lds + 4096;
@@ -176,7 +206,10 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* bb = lds + 4160 + 4096;
     const float* wn = lds + 8320;
     const float* bn = lds + 8320 + 4096;
-    float* st = lds + BLK_PACK + wave * 32 * ST_STRIDE;
+    const float* tia = lds + BLK_PACK;        // inverse column scales of conv_a, conv_b, conv_next
+    const float* tib = tia + 64;
+    const float* tin = tia + 128;
+    float* st = lds + BLK_PACK_S + wave * 32 * ST_STRIDE;
 
     const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int g0 = (bid * BLK_WAVES + wave) * 32;
@@ -233,15 +266,19 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
                 const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
                 const float sqi = sq3(xi, yi, zi);
                 const float kv = kth[g];
+                // hundreds to thousands of rows (clumps of identical points, zero padding): compensated (Kahan) summation, so
+                // that the sum is as good as the reference's blocked matmul(mask, x) -- a plain running f32 sum of 3072 rows
+                // is 50x noisier, and on ill-conditioned weights the blocks amplify that to 3e-4 of the descriptor
+                float4 comp = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int j = 0; j < n; ++j) {
                     const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
                     const float a = neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj));
                     if (a >= kv) {
                         const float4 w = row32(j);
-                        acc.x += w.x;
-                        acc.y += w.y;
-                        acc.z += w.z;
-                        acc.w += w.w;
+                        kahan_add(acc.x, comp.x, w.x);
+                        kahan_add(acc.y, comp.y, w.y);
+                        kahan_add(acc.z, comp.z, w.z);
+                        kahan_add(acc.w, comp.w, w.w);
                     }
                 }
             }
@@ -254,13 +291,13 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     }
 
     // ---- conv_a, conv_b ----
-    bf16x8 bh[4], bl[4];
+    f16x8 bh[4], bl[4];
     f32x16 a1[2], a2[2];
-    stage_to_bop(st, bh, bl, lane);
-    layer_split64(wa, ba, bh, bl, a1, lane);
+    float inv_row = stage_to_bop(st, bh, bl, lane);
+    layer_s64(wa, ba, tia, bh, bl, inv_row, a1, lane);
     relu16(a1[0]);
     relu16(a1[1]);
-    layer_acc64(wb, bb, a1, a2, lane);
+    layer_acc64(wb, bb, tib, a1, a2, lane);
     relu16(a2[0]);
     relu16(a2[1]);
 
@@ -277,8 +314,8 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     if (!has_next) return;
 
     // ---- next block's leading conv ----
-    stage_to_bop(st, bh, bl, lane);
-    layer_split64(wn, bn, bh, bl, a1, lane);
+    inv_row = stage_to_bop(st, bh, bl, lane);
+    layer_s64(wn, bn, tin, bh, bl, inv_row, a1, lane);
     relu16(a1[0]);
     relu16(a1[1]);
     acc_to_stage(st, a1, lane);
@@ -443,7 +480,7 @@ __global__ __launch_bounds__(BLK16_THREADS) void proxyconv_block_f16_kernel(
                 for (int j = 0; j < n; ++j) {
                     const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
                     const float a = neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj));
-                    if (a >= kv) add_row(acc, row16(j));
+                    if (a >= kv) add_row(acc, row16(j));   // (fast arithmetic: plain running sum, its rows are fp16 anyway)
                 }
             }
         }

@@ -82,6 +82,29 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
         lo[j] = (__bf16)(v[j] - (float)hi[j]);
     }
 }
+// Scaled split-fp16 ("f16x3s") arithmetic -- the f32-equivalent form of EPC_PRECISION_F32's conv layers: every ROW of the
+// activation operand and every COLUMN of the weight operand is multiplied by a power of two that brings its largest
+// magnitude into [2^14, 2^15) (exact), then split as hi = fp16(v), lo = fp16(v - hi): 22 significant bits for every element
+// within 2^-28 of its row's maximum (smaller ones lose bits gradually -- their share of any dot product is below float32's
+// own rounding of it), no range restriction.  Products lo*hi + hi*lo + hi*hi on the fp16 MFMA (f32 accumulate): 2^-21
+// relative per product against 2^-16.5 for the split-bf16 form at the same three MFMAs -- which is what an ill-conditioned
+// network needs (heavy-tailed weights: split-bf16 layers land 2.6e-4 from the float64 result where float32 itself is at
+// 2e-5; this form at 2e-5; tests/test_gpu_adversarial.py).  The accumulator is un-scaled by inv_row * inv_col afterwards.
+__device__ __forceinline__ void row_scale_pow2(float maxabs, float& s, float& inv_s) {
+    int E = ((__float_as_int(maxabs) >> 23) & 0xff) - 127;   // maxabs >= 0: floor(log2) for normal numbers
+    E = min(max(E, -100), 112);                                // all-zero / denormal rows; Inf / NaN rows (flagged elsewhere)
+    s = exp2i(14 - E);
+    inv_s = exp2i(E - 14);
+}
+__device__ __forceinline__ void split8_f16s(const float (&v)[8], float s, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = v[j] * s;
+        hi[j] = (_Float16)xs;
+        lo[j] = (_Float16)(xs - (float)hi[j]);
+    }
+}
+
 __host__ __device__ __forceinline__ unsigned short bf16_bits_rne(float f) {
     union { float f; unsigned int u; } c;
     c.f = f;
@@ -137,8 +160,10 @@ __host__ __device__ __forceinline__ constexpr size_t layer_pack_floats(int cin, 
 //   Wcp[chunk c][s' (2)][tile t (2)][lane][8 fp16] (ONE fp16 per cluster weight, x W5_SCALE),
 //        value = Wc[32c + 16s' + 8(j>>2) + 4(lane>>5) + (j&3)][32t + (lane&31)]
 //        (the k order of an accumulator tile used as B operand: element j of lane-half h is row 16s'+8(j>>2)+4h+(j&3))
-// Block pack: [conv_a SPLIT 64x64][conv_b ACC 64x64][conv_next SPLIT 64x64 (zeros when absent)]
+// Block pack: [conv_a SPLIT 64x64][conv_b ACC 64x64][conv_next SPLIT 64x64 (zeros when absent)], then (scaled split-fp16
+// form only) the three layers' inverse column scales [3][64]
 #define EPC_BLOCK_PACK_FLOATS (3 * (64 * 64 + 64))
+#define EPC_BLOCK_PACK_FLOATS_S (EPC_BLOCK_PACK_FLOATS + 3 * 64)
 // conv1 pack: Wf[3][64] + bf[64]
 #define EPC_CONV1_PACK_FLOATS (3 * 64 + 64)
 // conv1 (models/epc-net.py:66-69: 3 -> 64, folded BN, ReLU) for four consecutive output channels of one point; ONE

@@ -64,8 +64,10 @@ struct C5Lds {  // offsets in floats (4 B)
     // a small area of its own.
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
-    static constexpr int OFF_MAX = OFF_CBN + 128;          // MODE_MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
-    static constexpr int TOTAL = OFF_MAX + 1536;
+    static constexpr int OFF_TI = OFF_CBN + 128;           // scaled split-fp16 form: the 1024 inverse column scales
+    static constexpr int OFF_MAX = OFF_TI + 1024;          // MODE_MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
+    static constexpr int OFF_IS = OFF_MAX + 1536;          // MODE_MAX: per wave the 32 inverse row scales of its tile
+    static constexpr int TOTAL = OFF_IS + 256;
 };
 
 // packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
@@ -92,6 +94,8 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     const float* gb5 = pack + (size_t)CIN * 1024;
     const float* gwc = gb5 + 1024;
     const float* gcbn = gwc + (FAST ? 1024 * 32 : 1024 * 64);   // past 1024 x 64 fp16 / bf16 hi + lo
+    // inverse column scales of the scaled split-fp16 form (pack.hip colscale_kernel): the last 1024 floats of the stage
+    const float* gti = MODE == MODE_VLAD ? gcbn + 128 : gb5 + 1024;
 
     // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction writes 1 KB at a
     // wave-uniform LDS base + lane*16, which is exactly the packed fragment order), so no VGPRs are spent on staging
@@ -117,15 +121,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     stage_chunk(0, std::integral_constant<int, 0>{});
     for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_B5 + o] = gb5[o];
     if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
+    if constexpr (!FAST)
+        for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_TI + o] = gti[o];
 
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
     const bool wg_one_cloud = MODE == MODE_MAX && n % (C5_WAVES * 32) == 0;  // the workgroup's 8 tiles share a cloud
 
     // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7.
-    // VLAD mode: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
-    // common.h) -- the input rounding averages out over the cloud's points in the aggregation.  Max-pool mode keeps one
-    // point's value per channel, so nothing averages: it stays on the f32-accurate split-bf16 form (three MFMAs).
+    // FAST: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
+    // common.h) -- the input rounding averages out over the cloud's points in the aggregation.  Otherwise (f32-equivalent
+    // arithmetic; the max-pool form always: it keeps one point's value per channel, nothing averages) the scaled
+    // split-fp16 form of common.h: the point's row scaled by a power of two, hi + lo parts, three MFMAs.
     constexpr bool kF16 = FAST;
     constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
     f16x8 xf[kF16 ? STEPS : 1];
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         x6[ks] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v * down, 1.0f);
         xsc |= (127 + e) << (8 * ks);
     };
-    bf16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
+    f16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
+    float inv_row = 1.0f;   // inverse of the row's power-of-two scale (scaled split-fp16 form)
     if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
         static_assert(!CAT16 || FAST, "fp16 input only feeds the fp16 arithmetic");
         const unsigned short* row = reinterpret_cast<const unsigned short*>(cat) + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
@@ -174,6 +182,20 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
     } else {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
+        float row_s = 1.0f;
+        if constexpr (!kF16) {
+            // pass 1 over the lane's half of the row: its largest magnitude (the other half sits in lane ^ 32); the values
+            // are re-read below (L1 / L2 hits) rather than kept: 128 more registers would not fit
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                m = fmaxf(fmaxf(fmaxf(m, fabsf(a.x)), fmaxf(fabsf(a.y), fabsf(a.z))), fmaxf(fmaxf(fabsf(a.w), fabsf(b.x)), fmaxf(fabsf(b.y), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            }
+            m = fmaxf(m, __shfl_xor(m, 32));
+            row_scale_pow2(m, row_s, inv_row);
+        }
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             float v[8];
@@ -184,7 +206,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #pragma unroll
                 for (int q = 0; q < 8; ++q) xf[s][q] = (_Float16)v[q];
             } else {
-                split8(v, xh[s], xl[s]);
+                split8_f16s(v, row_s, xh[s], xl[s]);
             }
         }
         if constexpr (kF16) {
@@ -203,6 +225,12 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
     }
 
+    // max-pool form (operands swapped): register r of this lane belongs to point mfma_row(r, h) of the tile -- its inverse
+    // row scale lives in the lane of that point
+    // (kept in a wave-private LDS row and re-read per chunk: 16 more live registers would cost this kernel a wave per SIMD)
+    if constexpr (MODE == MODE_MAX) {
+        if (h == 0) lds[L::OFF_IS + wave * 32 + j] = inv_row;
+    }
     f32x16 P[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) P[0][r] = P[1][r] = 0.f;
@@ -230,12 +258,10 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #endif
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
         f32x16 acc;
-        if constexpr (MODE == MODE_MAX) {
-            // transposed product (operands swapped: D[point][channel]): channel = lane & 31, the 16 registers are 16 of
-            // the tile's points, so the max over points is a max over registers
-            const float bv = lds[L::OFF_B5 + 32 * c + j];
+        if constexpr (!kF16) {
+            // scaled split-fp16 form: the accumulator holds the product of the SCALED operands; bias and un-scaling follow
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bv;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         } else {
             const float* b = lds + L::OFF_B5 + 32 * c;
 #pragma unroll
@@ -298,13 +324,40 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 if constexpr (kF16) {
                     acc = mfma_f16(fa[s % RING][0], xf[s], acc);
                 } else if constexpr (MODE == MODE_MAX) {   // operands swapped: D[point][channel]
-                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][1]), acc);
-                    acc = mfma_bf16(xl[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
-                    acc = mfma_bf16(xh[s], __builtin_bit_cast(bf16x8, fa[s % RING][0]), acc);
-                } else {                                   // D[channel][point], split-bf16 x3
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][1]), xh[s], acc);
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][0]), xl[s], acc);
-                    acc = mfma_bf16(__builtin_bit_cast(bf16x8, fa[s % RING][0]), xh[s], acc);
+                    acc = mfma_f16(xh[s], fa[s % RING][1], acc);
+                    acc = mfma_f16(xl[s], fa[s % RING][0], acc);
+                    acc = mfma_f16(xh[s], fa[s % RING][0], acc);
+                } else {                                   // D[channel][point], scaled split-fp16 x3
+                    acc = mfma_f16(fa[s % RING][1], xh[s], acc);
+                    acc = mfma_f16(fa[s % RING][0], xl[s], acc);
+                    acc = mfma_f16(fa[s % RING][0], xh[s], acc);
+                }
+            }
+        }
+        if constexpr (!kF16) {
+            // out = acc * (inverse row scale * inverse column scale) + bias
+            if constexpr (MODE == MODE_MAX) {
+                // transposed product: channel = lane & 31, the 16 registers are 16 of the tile's points
+                const float ti = lds[L::OFF_TI + 32 * c + j], bv = lds[L::OFF_B5 + 32 * c + j];
+                const float* isr = lds + L::OFF_IS + wave * 32 + 4 * h;   // rows mfma_row(4g + e, h) = 8g + 4h + e
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 iv = ld4(isr + 8 * g);
+                    acc[4 * g] = __builtin_fmaf(acc[4 * g], iv.x * ti, bv);
+                    acc[4 * g + 1] = __builtin_fmaf(acc[4 * g + 1], iv.y * ti, bv);
+                    acc[4 * g + 2] = __builtin_fmaf(acc[4 * g + 2], iv.z * ti, bv);
+                    acc[4 * g + 3] = __builtin_fmaf(acc[4 * g + 3], iv.w * ti, bv);
+                }
+            } else {
+                const float* b = lds + L::OFF_B5 + 32 * c;
+                const float* ti = lds + L::OFF_TI + 32 * c;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = ld4(b + 8 * g + 4 * h), tv = ld4(ti + 8 * g + 4 * h);
+                    acc[4 * g] = __builtin_fmaf(acc[4 * g], inv_row * tv.x, bv.x);
+                    acc[4 * g + 1] = __builtin_fmaf(acc[4 * g + 1], inv_row * tv.y, bv.y);
+                    acc[4 * g + 2] = __builtin_fmaf(acc[4 * g + 2], inv_row * tv.z, bv.z);
+                    acc[4 * g + 3] = __builtin_fmaf(acc[4 * g + 3], inv_row * tv.w, bv.w);
                 }
             }
         }

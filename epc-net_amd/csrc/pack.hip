@@ -38,16 +38,16 @@ static StageLayout stage_layout(const epc_cfg* c) {
     o += align64(EPC_CONV1_PACK_FLOATS);
     for (int b = 1; b <= 4; ++b) {
         L.off[b] = o;
-        if (b <= nblocks) o += align64(EPC_BLOCK_PACK_FLOATS);
+        if (b <= nblocks) o += align64(EPC_BLOCK_PACK_FLOATS_S);
     }
     L.off[5] = o;
     if (c->arch == EPC_ARCH_EPC_NET) {
-        o += align64((size_t)256 * 1024 + 1024 + 1024 * 64 + 128);
+        o += align64((size_t)256 * 1024 + 1024 + 1024 * 64 + 128 + 1024);   // W5, b5, Wc, cluster_bn, inverse column scales
         L.off[6] = o;
         const size_t kh = 65536 / c->groups;
         o += align64((size_t)65536 + kh * 256 + 512 + 65536 + 512);
     } else {
-        o += align64((size_t)128 * 1024 + 1024);
+        o += align64((size_t)128 * 1024 + 1024 + 1024);                    // W5, b5, inverse column scales
         L.off[6] = o;
         o += align64((size_t)1024 * 256 + 256);
     }
@@ -92,15 +92,30 @@ __global__ void fold_rowmajor_kernel(const float* __restrict__ W, const float* _
     }
 }
 
+// Inverse column scales of the scaled split-fp16 form (common.h): tinv[c] = 2^(E - 14), E = floor(log2(max_k |W'[k][c]|)),
+// W' = W * bn_inv -- so that W' / tinv lies in [2^14, 2^15) at its largest.  One thread per output channel.
+__global__ void colscale_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ var,
+                                int cin, int cout, float* __restrict__ tinv) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cout) return;
+    const float inv = bn_inv(gamma, var, c);
+    float m = 0.f;
+    for (int k = 0; k < cin; ++k) m = fmaxf(m, fabsf(W[(size_t)k * cout + c] * inv));
+    float s, is;
+    row_scale_pow2(m, s, is);
+    tinv[c] = is;
+}
+
 // conv5 weights as fragments (layout + arithmetic: common.h, conv5_vlad.hip C5Lds).  One thread per (chunk, k, channel).
 // f16 = 1 (EPC-Net: conv5 feeds the VLAD aggregation): per chunk [fp16 hi of W * W5_SCALE: k-step s (16 k), lane, 8]
 //         then the MX fp6 lo fragments written by pack_conv5_lo6_kernel; bias scaled by W5_SCALE.
-// f16 = 0 (EPC-Net-L: conv5 feeds the global max-pool): bf16 hi and lo fragments interleaved per k-step (bf16x3 form).
+// f16 = 0 (f32-equivalent arithmetic): fp16 hi and lo fragments of W' / tinv[col] interleaved per k-step (scaled
+//         split-fp16 form, common.h); bias un-scaled.
 __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int cin, int f16,
                                        unsigned short* __restrict__ dstW, float* __restrict__ dstB,
-                                       unsigned int* __restrict__ guard) {
+                                       unsigned int* __restrict__ guard, const float* __restrict__ tinv) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int steps = cin / 16;
     const float scale = f16 ? W5_SCALE : 1.0f;
@@ -115,11 +130,12 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
             const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
             dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
         } else {
-            const unsigned short hi = bf16_bits_rne(w);
-            const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+            const float ws = w * (1.0f / tinv[col]);   // exact: a power of two
+            const _Float16 hh = (_Float16)ws;
+            const _Float16 ll = (_Float16)(ws - (float)hh);
             const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
-            dstW[base] = hi;
-            dstW[base + 512] = lo;
+            dstW[base] = __builtin_bit_cast(unsigned short, hh);
+            dstW[base + 512] = __builtin_bit_cast(unsigned short, ll);
         }
     }
     if (o < 1024) {
@@ -165,15 +181,15 @@ __global__ void pack_conv5_lo6_kernel(const float* __restrict__ W, const float* 
 }
 
 // 64x64 block layer as hi + lo fragments: Wp[tile t (2)][k-step s (4)][part (hi,lo)][lane][8 x 16 bit] + bias.
-// f16 = 0: bf16 parts for the split-bf16 x3 form (EPC-Net-L); f16 = 1: fp16 parts of W * W5_SCALE, bias scaled alike
-// (EPC-Net: fp16 activations, two MFMAs per product -- common.h).
+// f16 = 0: fp16 parts of W' / tinv[col] for the scaled split-fp16 form (f32-equivalent arithmetic, common.h), bias un-scaled;
+// f16 = 1: fp16 parts of W * W5_SCALE, bias scaled alike (EPC-Net fast: fp16 activations, two MFMAs per product).
 // mode PACK_SPLIT: k-step s covers input channels 16s + 8h + q (B operand read from a staged [pt][ch] row);
 // mode PACK_ACC  : k-step s = 2*tin + s' covers 32tin + 16s' + 8(q>>2) + 4h + (q&3) (B = accumulators of the previous layer).
 __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int mode, int f16,
                                        unsigned short* __restrict__ dstW, float* __restrict__ dstB,
-                                       unsigned int* __restrict__ guard) {
+                                       unsigned int* __restrict__ guard, const float* __restrict__ tinv) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const float scale = f16 ? W5_SCALE : 1.0f;
     if (o < 4096) {
@@ -190,8 +206,11 @@ __global__ void fold_pack_block_kernel(const float* __restrict__ W, const float*
             hi = __builtin_bit_cast(unsigned short, hh);
             lo = __builtin_bit_cast(unsigned short, ll);
         } else {
-            hi = bf16_bits_rne(w);
-            lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
+            const float ws = w * (1.0f / tinv[col]);   // exact: a power of two
+            const _Float16 hh = (_Float16)ws;
+            const _Float16 ll = (_Float16)(ws - (float)hh);
+            hi = __builtin_bit_cast(unsigned short, hh);
+            lo = __builtin_bit_cast(unsigned short, ll);
         }
         const size_t base = ((size_t)(t * 4 + st) * 2) * 512 + lane * 8 + q;
         dstW[base] = hi;
@@ -307,10 +326,14 @@ static int get_slim_bn(const NameTable& T, const std::string& scope, const float
     } while (0)
 
 static int launch_layer(const ConvVars& v, int cin, int cout, int mode, int f16, float* dst, unsigned int* guard,
-                        hipStream_t st) {
+                        float* tinv, hipStream_t st) {
     EPC_CHECK_ARG(cin == 64 && cout == 64, "block layers are 64x64");
+    if (!f16) {
+        hipLaunchKernelGGL(colscale_kernel, dim3(1), dim3(256), 0, st, v.W, v.gamma, v.var, 64, 64, tinv);
+        EPC_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(fold_pack_block_kernel, dim3(16), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta, v.mean, v.var,
-                       mode, f16, (unsigned short*)dst, dst + 4096, guard);
+                       mode, f16, (unsigned short*)dst, dst + 4096, guard, tinv);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -348,14 +371,15 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
         float* dst = P + L.off[b];
         const std::string base = "fastdgcnn/conv" + std::to_string(b);
         PACK_TRY(get_conv(T, base + "_a", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst, guard, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst, guard, dst + EPC_BLOCK_PACK_FLOATS, st));
         PACK_TRY(get_conv(T, base + "_b", &v));
-        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, f16, dst + 4160, guard, st));
+        PACK_TRY(launch_layer(v, 64, 64, PACK_ACC, f16, dst + 4160, guard, dst + EPC_BLOCK_PACK_FLOATS + 64, st));
         if (b < nblocks) {
             PACK_TRY(get_conv(T, "fastdgcnn/conv" + std::to_string(b + 1), &v));
-            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst + 8320, guard, st));
+            PACK_TRY(launch_layer(v, 64, 64, PACK_SPLIT, f16, dst + 8320, guard, dst + EPC_BLOCK_PACK_FLOATS + 128, st));
         } else {
             hipError_t e = hipMemsetAsync(dst + 8320, 0, 4160 * sizeof(float), st);
+            if (e == hipSuccess) e = hipMemsetAsync(dst + EPC_BLOCK_PACK_FLOATS + 128, 0, 64 * sizeof(float), st);
             if (e != hipSuccess) {
                 epc_set_error("epc_net_pack_weights: hipMemsetAsync: %s", hipGetErrorString(e));
                 return EPC_EHIP;
@@ -365,9 +389,15 @@ extern "C" int epc_net_pack_weights(const epc_cfg* cfg, const char* const* names
 
     PACK_TRY(get_conv(T, "fastdgcnn/conv5", &v));
     const int c5in = 64 * nblocks;
+    // inverse column scales of conv5 (scaled split-fp16 form): the last 1024 floats of the stage
+    float* t5inv = P + L.off[6] - 1024;
+    if (!f16) {
+        hipLaunchKernelGGL(colscale_kernel, dim3(4), dim3(256), 0, st, v.W, v.gamma, v.var, c5in, 1024, t5inv);
+        EPC_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(fold_pack_conv5_kernel, dim3(c5in * 1024 / 256), dim3(256), 0, st, v.W, v.b, v.gamma, v.beta,
                        v.mean, v.var, c5in, f16, (unsigned short*)(P + L.off[5]),
-                       P + L.off[5] + (size_t)c5in * 1024, guard);
+                       P + L.off[5] + (size_t)c5in * 1024, guard, t5inv);
     EPC_CHECK_LAUNCH();
     if (f16) {
         hipLaunchKernelGGL(pack_conv5_lo6_kernel, dim3((32 * (c5in / 64) * 64 + 255) / 256), dim3(256), 0, st, v.W, v.gamma,

@@ -4,7 +4,9 @@
                                       (gfx950: FETCH_SIZE counts 128-B requests as 64 B => x2; WRITE_SIZE exact;
                                       MI355X_MICROARCH.md, HBM section)
    profiles/<tag>_bench_line.json    the un-profiled bench line of the same command
-and refresh profiles/pmc_hbm_current.json (what bench.py's roofline.traffic reads)."""
+   profiles/<tag>_pmc_compute.json   per-kernel means of the SQ / GRBM counters of the two compute passes and the ratios
+                                      derived from them (mfma_util, VALU active-lane fraction, LDS conflict share, wait shares)
+and refresh profiles/pmc_hbm_current.json / pmc_compute_current.json (what bench.py's roofline.traffic / mfma_util read)."""
 import csv, glob, json, os, shutil, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +56,79 @@ if kernels:
     for name in (tag + "_pmc_hbm.json", "pmc_hbm_current.json"):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
+# ---- compute-side counters -------------------------------------------------------------------------------------------
+# the launches of one bench step, per arithmetic (bench.py's pipeline_hbm sums bytes over them)
+LAUNCHES = {"f32": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel": 1, "proxyconv_block_kernel": 4,
+                    "void conv5_kernel<256, 0, false, false>": 1, "vlad_aggregate_f32_kernel": 1, "void vlad_fold_kernel": 1,
+                    "hidden_gemm_kernel": 1, "head_finish_kernel": 1},
+            "fast": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel": 1, "proxyconv_block_f16_kernel": 4,
+                     "void conv5_kernel<256, 0, true, true>": 1, "vlad_aggregate_kernel": 1, "void vlad_fold_kernel": 1,
+                     "hidden_gemm_kernel": 1, "head_finish_kernel": 1}}
+for name in (tag + "_pmc_hbm.json", "pmc_hbm_current.json"):
+    path = os.path.join(dst, name)
+    if kernels and os.path.exists(path):
+        doc = json.load(open(path))
+        doc["launches_per_step"] = LAUNCHES
+        json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+
+
+def all_counter_means(sub):
+    path = find(sub, "counter_collection.csv")
+    acc = {}
+    if not path:
+        return acc
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            key = (row["Kernel_Name"], row.get("Counter_Name"))
+            s, n = acc.get(key, (0.0, 0))
+            acc[key] = (s + float(row["Counter_Value"]), n + 1)
+    out = {}
+    for (k, c), (s, n) in acc.items():
+        out.setdefault(k, {})[c] = s / n
+        out[k]["launches"] = n
+    return out
+
+
+NUM_SIMD = 256 * 4      # MI355X: 256 CUs x 4 SIMDs
+comp = {}
+for sub in ("pmc_compA", "pmc_compB"):
+    for k, d in all_counter_means(sub).items():
+        comp.setdefault(k, {}).update(d)
+for k, d in comp.items():
+    g = d.get("GRBM_GUI_ACTIVE")
+    r = {}
+    if g and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+        # SQ_VALU_MFMA_BUSY_CYCLES: cycles a SIMD's matrix pipe is busy, summed over the SIMDs (32 per v_mfma_f32_32x32x16_*:
+        # MI355X_MICROARCH.md, cycle constants); GRBM_GUI_ACTIVE: the kernel's duration in shader cycles
+        r["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * NUM_SIMD), 4)
+    if d.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in d:
+        # both in quad-cycles: thread-cycles / (instruction-cycles x 64 lanes) = the share of lanes doing work per VALU issue
+        r["valu_active_lane_fraction"] = round(d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+    if d.get("SQ_WAVE_CYCLES"):
+        w = d["SQ_WAVE_CYCLES"]
+        for c, nm in (("SQ_ACTIVE_INST_VALU", "valu_issue_share_of_wave_cycles"), ("SQ_WAIT_ANY", "wait_any_share"),
+                      ("SQ_WAIT_INST_ANY", "wait_inst_share"), ("SQ_ACTIVE_INST_ANY", "active_inst_share")):
+            if c in d:
+                r[nm] = round(d[c] / w, 4)
+    if d.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in d:
+        r["lds_bank_conflict_share"] = round(d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"], 4)
+    d.update(r)
+if comp:
+    sets = ""
+    try:
+        sets = open(os.path.join(src, "pmc_compute_sets.txt")).read()
+    except Exception:
+        pass
+    doc = {"command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
+                      "--no-cpu-baseline --in-flight 1 --no-configs (two passes; scripts/collect_profiles.sh)",
+           "tag": tag, "counter_sets": sets,
+           "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); valu_active_lane_fraction = "
+                      "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); *_share = counter / SQ_WAVE_CYCLES; means per launch",
+           "kernels": {k: {c: (round(v, 1) if isinstance(v, float) and v > 10 else v) for c, v in d.items()} for k, d in sorted(comp.items())}}
+    for name in (tag + "_pmc_compute.json", "pmc_compute_current.json"):
+        with open(os.path.join(dst, name), "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
 line = os.path.join(src, "bench_line.json")
 if os.path.exists(line) and os.path.getsize(line):
     shutil.copy(line, os.path.join(dst, tag + "_bench_line.json"))
-print("summaries written for", tag, "kernels with counters:", len(kernels), "stats:", bool(stats))
+print("summaries written for", tag, "kernels with HBM counters:", len(kernels), "with compute counters:", len(comp), "stats:", bool(stats))
