@@ -1,5 +1,14 @@
 // Descriptor retrieval -- replaces sklearn KDTree(database).query(q, k=25) of evaluate.py:463,481.
-// One wave per query.  Exact Euclidean distances sum_c (q_c - d_c)^2 in f32 (no ||q||^2+||d||^2-2q.d cancellation),
+//
+// Two forms with identical results (exact k nearest rows by Euclidean distance, ties -> lower database index):
+//   epc_pairwise_topk      no workspace: one wave per query, distances of the whole database in LDS (<= ~40 k rows);
+//   epc_pairwise_topk_ws   the pairwise matrix as a tiled f32-MFMA GEMM (d2 = |q|^2 + |d|^2 - 2 q.d into the caller's
+//                          workspace, any database size), per query the k + 8 smallest of its row, those candidates re-ranked
+//                          by the EXACT sum_c (q_c - d_c)^2 the first form uses, and a proof per query that no other row can
+//                          belong to the answer (the k-th exact distance lies below the last candidate's GEMM value by more
+//                          than the GEMM's rounding bound); the rare query without proof (many near-ties) is redone exactly.
+//
+// First form: one wave per query.  Exact Euclidean distances sum_c (q_c - d_c)^2 in f32 (no ||q||^2+||d||^2-2q.d cancellation),
 // kept in LDS; then k rounds of wave-wide arg-min (ties -> lower database index), so the result is the sorted
 // k-nearest list.  Database sizes on this path are 10^2..10^4 rows (Oxford runs hold ~400 submaps each).
 #include "common.h"
@@ -74,5 +83,265 @@ extern "C" int epc_pairwise_topk(const float* database, int num_db, const float*
     hipLaunchKernelGGL(pairwise_topk_kernel, dim3(num_q), dim3(64), lds_bytes, (hipStream_t)stream, database,
                        num_db, queries, dim, k, idx, dist);
     EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Workspace form.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RT_EXTRA 8          // candidates beyond k whose GEMM distances bracket the answer
+#define RT_MAXC 64          // k + RT_EXTRA <= one lane per candidate
+
+__global__ __launch_bounds__(256) void rownorm2_kernel(const float* __restrict__ x, int rows, int dim,
+                                                       float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * dim + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[r] = s;
+}
+
+// S[q][d] = max(|q|^2 + |d|^2 - 2 q.d, 0): 128 x 128 tile per workgroup, 64 x 64 per wave (four 32x32 f32-MFMA accumulators).
+// Both operands are row-major (rows, dim) with the row on the lane -- exactly the A[i][k] / B[k][j] lane layouts of
+// v_mfma_f32_32x32x2_f32 when a lane reads a float4 along K (k = 8b + 4 (lane >> 5) + c for component c of block b), so the
+// fragments come straight from global memory (L2): no LDS, 4 float4 loads per 16 MFMAs.
+__global__ __launch_bounds__(256) void pairdist_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ D,
+                                                            const float* __restrict__ qn, const float* __restrict__ dn,
+                                                            int nq, int nd, int dim, float* __restrict__ S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.y * 128 + (wave >> 1) * 64, d0 = blockIdx.x * 128 + (wave & 1) * 64;
+    if (q0 >= nq || d0 >= nd) return;
+    const float* a0 = Q + (size_t)min(q0 + j, nq - 1) * dim + 4 * h;
+    const float* a1 = Q + (size_t)min(q0 + 32 + j, nq - 1) * dim + 4 * h;
+    const float* b0 = D + (size_t)min(d0 + j, nd - 1) * dim + 4 * h;
+    const float* b1 = D + (size_t)min(d0 + 32 + j, nd - 1) * dim + 4 * h;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = 0.f;
+    for (int k = 0; k < dim; k += 8) {
+        const float4 x0 = *reinterpret_cast<const float4*>(a0 + k), x1 = *reinterpret_cast<const float4*>(a1 + k);
+        const float4 y0 = *reinterpret_cast<const float4*>(b0 + k), y1 = *reinterpret_cast<const float4*>(b1 + k);
+        const float xa[4] = {x0.x, x0.y, x0.z, x0.w}, xb[4] = {x1.x, x1.y, x1.z, x1.w};
+        const float ya[4] = {y0.x, y0.y, y0.z, y0.w}, yb[4] = {y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc[0][0] = mfma32(xa[c], ya[c], acc[0][0]);
+            acc[0][1] = mfma32(xa[c], yb[c], acc[0][1]);
+            acc[1][0] = mfma32(xb[c], ya[c], acc[1][0]);
+            acc[1][1] = mfma32(xb[c], yb[c], acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int d = d0 + 32 * tj + j;
+            if (d >= nd) continue;
+            const float dnv = dn[d];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + 32 * ti + mfma_row(r, h);
+                if (q < nq) {
+                    // rounding can leave a tiny negative value for coincident rows: 0; a NaN / Inf descriptor (a flagged cloud):
+                    // +Inf, never selected -- as in the exact form, where a NaN distance never wins a comparison
+                    const float v = (qn[q] + dnv) - 2.0f * acc[ti][tj][r];
+                    S[(size_t)q * nd + d] = v >= 0.f ? (v <= 3.0e38f ? v : INFINITY) : (v < 0.f ? 0.f : INFINITY);
+                }
+            }
+        }
+}
+
+// exact squared distance, the arithmetic of pairwise_topk_kernel (sequential over c, one rounding per operation)
+__device__ __forceinline__ float exact_d2(const float* __restrict__ q, const float* __restrict__ row, int dim) {
+    float acc = 0.f;
+    for (int c = 0; c < dim; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + c);
+        const float4 u = *reinterpret_cast<const float4*>(q + c);
+        const float e0 = u.x - v.x, e1 = u.y - v.y, e2 = u.z - v.z, e3 = u.w - v.w;
+        acc += e0 * e0;
+        acc += e1 * e1;
+        acc += e2 * e2;
+        acc += e3 * e3;
+    }
+    return acc;
+}
+
+// lexicographic (value, index) minimum over the wave
+__device__ __forceinline__ void wave_argmin(float& best, int& bi) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov < best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+}
+
+// One wave per query: the kc = min(k + RT_EXTRA, nd) smallest entries of its row of S in (value, index) order, their exact
+// distances, the k best of those; flag[q] = 1 when the bracket does not prove the answer.
+__global__ __launch_bounds__(64) void select_rerank_kernel(const float* __restrict__ S, const float* __restrict__ Q,
+                                                           const float* __restrict__ D, const float* __restrict__ qn,
+                                                           int nd, int dim, int k, int rows_in_lds,
+                                                           int32_t* __restrict__ idx, float* __restrict__ dist,
+                                                           int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    const int lane = threadIdx.x, qi = blockIdx.x;
+    const float* grow = S + (size_t)qi * nd;
+    const float* row = grow;
+    if (rows_in_lds) {
+        for (int d = lane; d < nd; d += 64) srow[d] = grow[d];
+        __syncthreads();
+        row = srow;
+    }
+    const int kc = min(k + RT_EXTRA, nd);
+    float lv = -1.f;      // last selected (value, index): values are >= 0
+    int li = -1;
+    int my_cand = -1;
+    float my_approx = 0.f;
+    for (int r = 0; r < kc; ++r) {
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int d = lane; d < nd; d += 64) {
+            const float v = row[d];
+            const bool after = v > lv || (v == lv && d > li);
+            if (after && v < best) {   // ascending d within a lane: strict < keeps the lower index on ties
+                best = v;
+                bi = d;
+            }
+        }
+        wave_argmin(best, bi);
+        lv = best;
+        li = bi;
+        if (lane == r) {
+            my_cand = bi < nd ? bi : 0x7fffff00 + lane;   // fewer than kc finite rows: a unique invalid index that sorts last
+            my_approx = best;
+        }
+    }
+    // exact distances of the candidates, one per lane
+    const float* qrow = Q + (size_t)qi * dim;
+    float e = INFINITY;
+    if (lane < kc && my_cand < nd) e = exact_d2(qrow, D + (size_t)my_cand * dim, dim);
+    if (!(e <= 3.0e38f)) e = INFINITY;   // NaN distance (NaN query): sorts last, like the comparisons of the exact form
+    // rank by (exact, index) among the candidates
+    int rank = 0;
+    for (int c = 0; c < kc; ++c) {
+        const float oe = __shfl(e, c);
+        const int oi = __shfl(my_cand, c);
+        if (lane < kc && (oe < e || (oe == e && oi < my_cand))) ++rank;
+    }
+    if (lane < kc && rank < k) {
+        idx[(size_t)qi * k + rank] = my_cand < nd ? my_cand : -1;
+        dist[(size_t)qi * k + rank] = sqrtf(e);
+    }
+    // proof: every row outside the candidates has a GEMM value >= the last candidate's (m), hence an exact distance
+    // >= m - eps; the answer stands if the k-th exact distance is below that.  eps bounds the f32 rounding of the GEMM form
+    // (128 sequential pair-additions of the dot product, the norms, the final combination) for THIS query against any row
+    // whose norm is of the same order: 2^-14 of the magnitudes involved.
+    float kth_exact = (lane < kc && rank == k - 1) ? e : -INFINITY;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) kth_exact = fmaxf(kth_exact, __shfl_xor(kth_exact, off));
+    const float m = __shfl(my_approx, kc - 1);
+    if (lane == 0) {
+        const float eps = 6.1e-5f * (qn[qi] + m + 1e-30f);
+        flag[qi] = (kc < nd && !(kth_exact + eps < m)) ? 1 : 0;
+    }
+}
+
+// flagged queries only: exact distances of the whole database into the query's row of S, then k rounds of arg-min
+__global__ __launch_bounds__(64) void exact_fallback_kernel(float* __restrict__ S, const float* __restrict__ Q,
+                                                            const float* __restrict__ D, int nd, int dim, int k,
+                                                            const int32_t* __restrict__ flag, int32_t* __restrict__ idx,
+                                                            float* __restrict__ dist) {
+    const int lane = threadIdx.x, qi = blockIdx.x;
+    if (!flag[qi]) return;
+    float* row = S + (size_t)qi * nd;
+    const float* qrow = Q + (size_t)qi * dim;
+    for (int d = lane; d < nd; d += 64) row[d] = exact_d2(qrow, D + (size_t)d * dim, dim);
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int d = lane; d < nd; d += 64) {
+            const float v = row[d];
+            if (v < best) {
+                best = v;
+                bi = d;
+            }
+        }
+        wave_argmin(best, bi);
+        if (lane == 0) {
+            idx[(size_t)qi * k + r] = bi;
+            dist[(size_t)qi * k + r] = sqrtf(best);
+            row[bi] = INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+static inline size_t rt_align(size_t v) { return (v + 255) / 256 * 256; }
+// queries per pass: the pairwise matrix of one pass stays below 1 GiB
+static int rt_chunk(int num_db, int num_q) {
+    long per = (1L << 28) / (num_db > 0 ? num_db : 1);
+    if (per < 128) per = 128;
+    return (int)(per < num_q ? per : num_q);
+}
+
+extern "C" size_t epc_pairwise_topk_workspace_bytes(int num_db, int num_q) {
+    if (num_db <= 0 || num_q <= 0) return 0;
+    const int ch = rt_chunk(num_db, num_q);
+    return rt_align((size_t)ch * num_db * 4) + rt_align((size_t)num_db * 4) + rt_align((size_t)num_q * 4) + rt_align((size_t)num_q * 4);
+}
+
+extern "C" int epc_pairwise_topk_ws(const float* database, int num_db, const float* queries, int num_q, int dim, int k,
+                                    int32_t* idx, float* dist, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(database && queries && idx && dist && workspace, "null pointer");
+    EPC_CHECK_ARG(dim > 0 && dim % 8 == 0, "descriptor dim must be a multiple of 8");
+    EPC_CHECK_ARG(k > 0 && k <= num_db && k + RT_EXTRA <= RT_MAXC, "need 0 < k <= min(num_db, 56)");
+    EPC_CHECK_ARG(num_q >= 0, "bad shape");
+    if (num_q == 0) return EPC_OK;
+    if (workspace_bytes < epc_pairwise_topk_workspace_bytes(num_db, num_q)) {
+        epc_set_error("epc_pairwise_topk_ws: workspace too small");
+        return EPC_ENOMEM;
+    }
+    const int ch = rt_chunk(num_db, num_q);
+    char* w = (char*)workspace;
+    float* S = (float*)w;
+    w += rt_align((size_t)ch * num_db * 4);
+    float* dn = (float*)w;
+    w += rt_align((size_t)num_db * 4);
+    float* qn = (float*)w;
+    w += rt_align((size_t)num_q * 4);
+    int32_t* flag = (int32_t*)w;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((num_db + 3) / 4), dim3(256), 0, st, database, num_db, dim, dn);
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((num_q + 3) / 4), dim3(256), 0, st, queries, num_q, dim, qn);
+    EPC_CHECK_LAUNCH();
+    const int in_lds = (size_t)num_db * 4 <= 150 * 1024;
+    const size_t lds_bytes = in_lds ? (size_t)num_db * 4 : 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_rerank_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
+    if (e != hipSuccess) {
+        epc_set_error("epc_pairwise_topk_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    for (int q0 = 0; q0 < num_q; q0 += ch) {
+        const int nq = (num_q - q0) < ch ? (num_q - q0) : ch;
+        const float* Qc = queries + (size_t)q0 * dim;
+        hipLaunchKernelGGL(pairdist_gemm_kernel, dim3((num_db + 127) / 128, (nq + 127) / 128), dim3(256), 0, st, Qc, database,
+                           qn + q0, dn, nq, num_db, dim, S);
+        hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(64), lds_bytes, st, S, Qc, database, qn + q0, num_db, dim, k,
+                           in_lds, idx + (size_t)q0 * k, dist + (size_t)q0 * k, flag + q0);
+        hipLaunchKernelGGL(exact_fallback_kernel, dim3(nq), dim3(64), 0, st, S, Qc, database, num_db, dim, k, flag + q0,
+                           idx + (size_t)q0 * k, dist + (size_t)q0 * k);
+        EPC_CHECK_LAUNCH();
+    }
     return EPC_OK;
 }

@@ -39,7 +39,8 @@ EXPORTS = [
     "epc_net_forward", "epc_net_forward_overlapped", "epc_net_last_status", "epc_conv5_assign_f32_fwd",
     "epc_vlad_aggregate_f32_fwd", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
-    "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_net_packed_offset",
+    "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_pairwise_topk_workspace_bytes",
+    "epc_pairwise_topk_ws", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
     "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
@@ -103,6 +104,9 @@ _lib.epc_vlad_head_fwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P, _P, c_size_
 _lib.epc_conv5_maxpool_fwd.argtypes = [_P, c_int, _P, c_int, c_int, _P, _P]
 _lib.epc_fc_head_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
 _lib.epc_pairwise_topk.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P]
+_lib.epc_pairwise_topk_workspace_bytes.restype = c_size_t
+_lib.epc_pairwise_topk_workspace_bytes.argtypes = [c_int, c_int]
+_lib.epc_pairwise_topk_ws.argtypes = [_P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]
 _lib.epc_morton_sort.argtypes = [_P, c_int, c_int, _P, _P, _P]
 from ctypes import c_long  # noqa: E402
 _lib.epc_gemm_f32.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int, c_int, c_long,

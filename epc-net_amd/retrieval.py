@@ -46,8 +46,19 @@ def knn_search(database: torch.Tensor, queries: torch.Tensor, k: int = NUM_NEIGH
     k = min(k, d)
     idx = torch.empty((q, k), dtype=torch.int32, device=queries.device)
     dist = torch.empty((q, k), dtype=torch.float32, device=queries.device)
-    L.check(L.lib().epc_pairwise_topk(L.ptr(database), d, L.ptr(queries), q, int(database.shape[1]), k, L.ptr(idx),
-                                      L.ptr(dist), L.current_stream()))
+    dim = int(database.shape[1])
+    if q == 0:
+        return dist, idx
+    if dim % 8 == 0 and k <= 56:
+        # pairwise matrix on the matrix pipe + exact re-rank of the candidates (epc_pairwise_topk_ws): any database size
+        need = L.lib().epc_pairwise_topk_workspace_bytes(d, q)
+        ws = torch.empty(need, dtype=torch.uint8, device=queries.device)
+        L.check(L.lib().epc_pairwise_topk_ws(L.ptr(database), d, L.ptr(queries), q, dim, k, L.ptr(idx), L.ptr(dist),
+                                             ws.data_ptr(), need, L.current_stream()))
+        ws.record_stream(torch.cuda.current_stream(queries.device))
+    else:
+        L.check(L.lib().epc_pairwise_topk(L.ptr(database), d, L.ptr(queries), q, dim, k, L.ptr(idx), L.ptr(dist),
+                                          L.current_stream()))
     return dist, idx
 
 

@@ -255,6 +255,15 @@ int epc_fc_head_fwd(const float* pooled, const void* packed_fc, int num_clouds, 
  * sklearn KDTree.query(k=25)); ties -> lower database index first.  idx (Q,k) int32, dist (Q,k) float32. */
 int epc_pairwise_topk(const float* database, int num_db, const float* queries, int num_q, int dim, int k,
                       int32_t* idx, float* dist, void* stream);
+/* The same result for any database size, at matrix-pipe speed: the pairwise matrix |q|^2 + |d|^2 - 2 q.d as a tiled f32-MFMA
+ * GEMM into the caller's workspace (queries are processed in passes of at most 2^28 / num_db rows), per query the k + 8
+ * smallest entries of its row, re-ranked by the exact sum (q_c - d_c)^2 of epc_pairwise_topk; a query whose candidates do not
+ * PROVE the answer (the k-th exact distance is not below the last candidate's GEMM value by more than the GEMM's rounding
+ * bound: dozens of near-tied rows) is redone exactly over the whole database.  idx / dist are bit-identical to
+ * epc_pairwise_topk's.  k <= 56, dim a multiple of 8. */
+size_t epc_pairwise_topk_workspace_bytes(int num_db, int num_q);
+int epc_pairwise_topk_ws(const float* database, int num_db, const float* queries, int num_q, int dim, int k, int32_t* idx,
+                         float* dist, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------ */
 /* Training-step operators (config c3; train.py:251-277).  Per-layer forward/backward pairs: training-mode    */

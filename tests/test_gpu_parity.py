@@ -362,6 +362,64 @@ def test_pairwise_topk(dev):
     assert np.allclose(dist.cpu().numpy(), dist_ref, atol=1e-5)
 
 
+def _topk_both(L, db, q, k, dev):
+    """(idx, dist) of the LDS form and of the workspace (MFMA + exact re-rank) form."""
+    tdb, tq = torch.from_numpy(db).to(dev), torch.from_numpy(q).to(dev)
+    out = []
+    for ws_form in (False, True):
+        idx = torch.full((len(q), k), -7, dtype=torch.int32, device=dev)
+        dist = torch.full((len(q), k), -7.0, dtype=torch.float32, device=dev)
+        if ws_form:
+            need = L.lib().epc_pairwise_topk_workspace_bytes(len(db), len(q))
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            L.check(L.lib().epc_pairwise_topk_ws(tdb.data_ptr(), len(db), tq.data_ptr(), len(q), db.shape[1], k,
+                                                 idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), need, L.current_stream()))
+        elif len(db) * 4 + db.shape[1] * 4 <= 160 * 1024:
+            L.check(L.lib().epc_pairwise_topk(tdb.data_ptr(), len(db), tq.data_ptr(), len(q), db.shape[1], k, idx.data_ptr(),
+                                              dist.data_ptr(), L.current_stream()))
+        else:
+            out.append(None)
+            continue
+        torch.cuda.synchronize()
+        out.append((idx.cpu().numpy(), dist.cpu().numpy()))
+    return out
+
+
+@pytest.mark.parametrize("n_db,n_q,kind", [(500, 50, "unit"), (9200, 300, "unit"), (40000, 64, "unit"), (1000, 40, "clumped"),
+                                           (300, 20, "identical"), (130, 7, "scaled")])
+def test_pairwise_topk_workspace_form_is_the_exact_answer(dev, n_db, n_q, kind):
+    """epc_pairwise_topk_ws (f32-MFMA pairwise matrix + exact re-rank + proof / fallback) against the LDS form (bit-identical
+    indices AND distances) and the oracle's brute force: G6-sized, Oxford-sized, 40 000 rows (past the LDS form's cap),
+    descriptors in tight clumps (near-ties by the dozen: the fallback path), all-identical rows (ties -> lower index), and
+    un-normalised rows of very different norms."""
+    L = H.pkg("lib")
+    rng = np.random.RandomState(n_db)
+    db = rng.randn(n_db, 256).astype(np.float32)
+    if kind == "clumped":          # 20 centres, members 1e-4 apart: far more than k + 8 rows inside any rounding band
+        db = (db[:20][rng.randint(0, 20, n_db)] + 1e-4 * rng.randn(n_db, 256)).astype(np.float32)
+    if kind == "identical":
+        db[:] = db[0]
+    if kind != "scaled":
+        db /= np.linalg.norm(db, axis=1, keepdims=True)
+    else:
+        db *= np.exp(rng.uniform(-3, 3, size=(n_db, 1))).astype(np.float32)
+    q = db[rng.randint(0, n_db, n_q)] + (0.3 if kind != "clumped" else 1e-4) * rng.randn(n_q, 256).astype(np.float32)
+    if kind != "scaled":
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    q[0] = db[min(3, n_db - 1)]                       # an exact match: distance 0, not sqrt(rounding)
+    lds, ws = _topk_both(L, db, q, 25, dev)
+    if lds is not None:
+        assert np.array_equal(ws[0], lds[0]) and np.array_equal(ws[1], lds[1])
+    assert ws[1][0, 0] == 0.0 and (np.diff(ws[1], axis=1) >= 0).all()
+    if kind in ("unit", "scaled"):
+        dist_ref, idx_ref = O.knn_bruteforce(db, q, 25)
+        assert np.array_equal(ws[0], idx_ref)
+        assert np.allclose(ws[1], dist_ref, rtol=1e-5, atol=1e-5)
+    if kind == "identical":
+        assert np.array_equal(ws[0], np.tile(np.arange(25, dtype=np.int32), (n_q, 1)))
+
+
 def test_evaluate_protocol_single_rank(dev):
     """get_latent_vectors + get_recall/evaluate_runs (evaluate.py:293-332, 351-537) on synthetic runs: GPU neighbour
     search + host bookkeeping must reproduce the oracle's recall numbers on the same descriptors."""
@@ -445,3 +503,26 @@ def test_full_size_properties(dev, prec):
             lst = idx[b, i, :min(cnt[b, i], 32)]
             assert np.array_equal(lst, sel[:32]) and i in sel
             assert kth[b, i] == np.sort(a[i])[-20]
+
+
+def test_epc_net_l_batch_256_full_size(dev):
+    """BASELINE.json configs[3]: EPC-Net-L at batch 256 x 4096 x 3 (models/epc-net-l.py:29-102; the library's default
+    micro-batch for this architecture).  (a) finite unit-norm descriptors; (b) a cloud's descriptor does not depend on its
+    batch: bit-identical alone, in the batch of 256 and at another position of it; (c) four sampled clouds against the oracle."""
+    w = O.seeded_weights("epc-net-l", 0)
+    eng, _ = H.make_engine("epc-net-l", w, dev)
+    pc = O.synthetic_clouds(256, 4096, 321)
+    x = torch.from_numpy(pc).to(dev)
+    out = eng.forward(x)
+    assert tuple(out.shape) == (256, 256)
+    assert bool(torch.isfinite(out).all()) and float((out.norm(dim=1) - 1).abs().max()) < 1e-5
+    assert eng.last_status(256) == [0] * 256
+    for i in (0, 131, 255):
+        assert torch.equal(eng.forward(x[i:i + 1])[0], out[i])
+    rolled = eng.forward(torch.roll(x, shifts=37, dims=0))
+    assert torch.equal(rolled[(131 + 37) % 256], out[131]) and torch.equal(rolled[36], out[255])
+    sel = [3, 77, 190, 255]
+    ref, _ = O.forward(pc[sel][:, None], w, arch="epc-net-l")
+    err = np.linalg.norm(out[sel].cpu().numpy() - ref.reshape(4, -1), axis=1).max()
+    print("EPC-Net-L 256 x 4096: descriptor L2 error on 4 sampled clouds %.3e" % err)
+    assert err <= DESC_TOL

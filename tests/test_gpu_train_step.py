@@ -22,10 +22,12 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-@pytest.mark.parametrize("arch,nneg", [("epc-net", 14), ("epc-net", 18), ("epc-net-l", 14)])
-def test_train_step_matches_gradient_oracle(dev, arch, nneg):
+@pytest.mark.parametrize("arch,nneg,n", [("epc-net", 14, 256), ("epc-net", 18, 256), ("epc-net-l", 14, 256),
+                                         # BASELINE.json configs[2] at FULL size: 18 x 4096 (the reference's tuple,
+                                         # configs/epc-net.yaml:28-34) and 22 x 4096 (BASELINE.json's "18 neg")
+                                         ("epc-net", 14, 4096), ("epc-net", 18, 4096)])
+def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
     import epcnet_oracle_torch as T
-    n = 256
     ncl = 1 + 2 + nneg + 1                                   # 18 (reference config) or 22 (BASELINE.json "18 neg")
     w0 = O.seeded_weights(arch, 4)
     pcs = O.synthetic_clouds(ncl, n, 9)
@@ -68,14 +70,34 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg):
     # (5.2e-3 was seen on one BN gamma when only the summation order of the batch statistics changed)
     # per tensor and max error <= 3e-2 of the tensor's max.  Biases in front of a training-mode BN have an exactly-zero
     # gradient (sum of dz is 0): both sides hold rounding noise there, hence the absolute floor.
+    # At full size (16x the activations, 16x the mask flips) the bars calibrate themselves: the same step in FLOAT32 torch
+    # gives the noise float32 arithmetic itself has on this tuple; the HIP step may be at most three times as far from the
+    # float64 gradients as that (and never needs to be closer than the small-size bars).
+    noise = {}
+    if n == 4096:
+        ref32 = T.train_step(w0, q, pos, neg, oth, step=step0, epoch=epoch, arch=arch, dtype=torch.float32)
+        for k, g_ref in ref["grads"].items():
+            d = ref32["grads"][k].astype(np.float64) - g_ref
+            noise[k] = (np.abs(d).max() / max(np.abs(g_ref).max(), 1e-30), np.linalg.norm(d) / max(np.linalg.norm(g_ref), 1e-30))
+    worst = (0.0, "")
     for k, g_ref in ref["grads"].items():
         g = grads[H.OUTER + "/" + k].reshape(g_ref.shape)
         gmax = np.abs(g_ref).max()
         floor = 5e-5 if k.endswith("/biases") else 2e-6
-        assert np.abs(g - g_ref).max() <= 3e-2 * gmax + floor, "gradient of %s: max error %.3e (|g|max %.3e)" % (
+        # (max error: one ReLU-mask flip moves a few elements of one channel by 2-4 % of the tensor's max; 16x the activations
+        # of the small case see 16x the flips)
+        bar_max = max(5e-2 if n == 4096 else 3e-2, 3.0 * noise.get(k, (0.0, 0.0))[0])
+        bar_l2 = max(8e-3, 3.0 * noise.get(k, (0.0, 0.0))[1])
+        rel_l2 = np.linalg.norm(g - g_ref) / max(np.linalg.norm(g_ref), 1e-30)
+        if not k.endswith("/biases"):          # (exactly-zero true gradient in front of a training-mode BN: no relative error)
+            worst = max(worst, (rel_l2, k))
+        assert np.abs(g - g_ref).max() <= bar_max * gmax + floor, "gradient of %s: max error %.3e (|g|max %.3e)" % (
             k, np.abs(g - g_ref).max(), gmax)
-        assert np.linalg.norm(g - g_ref) <= 8e-3 * np.linalg.norm(g_ref) + floor * np.sqrt(g.size), \
-            "gradient of %s: relative L2 error %.3e" % (k, np.linalg.norm(g - g_ref) / max(np.linalg.norm(g_ref), 1e-30))
+        assert np.linalg.norm(g - g_ref) <= bar_l2 * np.linalg.norm(g_ref) + floor * np.sqrt(g.size), \
+            "gradient of %s: relative L2 error %.3e (float32 torch: %.3e)" % (k, rel_l2, noise.get(k, (0, 0))[1])
+    print("train step %s %dx%d: worst gradient relative L2 error %.2e (%s)%s" % (
+        arch, ncl, n, worst[0], worst[1],
+        "; float32 torch on the same tensor: %.2e" % noise[worst[1]][1] if noise else ""))
     # Moving averages are updated by the same run and must match tightly.  Adam-updated weights: the first steps of
     # Adam are sign-like (update ~ 3.2 lr sign(g)), so an element whose gradient sits at the f32 noise floor may move by
     # O(lr) in a different direction; elements with a clearly non-zero gradient must match the oracle tightly.
@@ -96,6 +118,30 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg):
         assert np.abs(v - v_ref).max() <= 8 * lr_t + 2e-5 * np.abs(v_ref).max(), k
     state = ts.optimizer_state()
     assert int(state["Variable"]) == step0 + 1 and len([k for k in state if k.endswith("/Adam")]) == len(ref["grads"])
+    if n == 4096:
+        # repeatability: the same step from the same state agrees to float32 rounding -- not bit for bit: the split-K partial
+        # sums of the long-K GEMMs (the VLAD aggregation over 4096 points in the forward, every dW in the backward) meet in
+        # f32 atomics, whose order varies from run to run
+        first = {k: v.copy() for k, v in grads.items()}
+        d_first = ts.last_aux["q_vec"].clone()
+        st2 = H.make_store(arch, w0, dev)
+        ts2 = TR.TrainStep(params, st2, outer=H.OUTER)
+        ts2.global_step = step0
+        grads.clear()
+        st = st2                      # (the spy looks the variables up in `st`)
+        H.pkg("ops").adam_multi = spy
+        TR.ops.adam_multi = spy
+        try:
+            loss2, _, _ = ts2.step(to(q), to(pos), to(neg), to(oth), epoch=epoch)
+        finally:
+            H.pkg("ops").adam_multi = orig
+            TR.ops.adam_multi = orig
+        torch.cuda.synchronize()
+        assert abs(float(loss2) - float(loss)) <= 2e-6 * abs(float(loss))
+        assert float((ts2.last_aux["q_vec"] - d_first).abs().max()) <= 1e-6
+        for k in ("fastdgcnn/conv1/weights", "fastdgcnn/conv5/weights", "VLAD/hidden1_weights"):
+            a, b = first[H.OUTER + "/" + k], grads[H.OUTER + "/" + k]
+            assert np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-30), k
 
 
 @pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
