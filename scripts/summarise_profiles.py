@@ -89,7 +89,9 @@ def all_counter_means(sub):
     return out
 
 
-NUM_SIMD = 256 * 4      # MI355X: 256 CUs x 4 SIMDs
+# GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (a 0.512-ms conv5 launch reads 8.37 M = 8 x 1.05 M cycles at ~2.04 GHz), the SQ
+# counters summed over all SIMDs: busy cycles per SIMD = counter / 1024, kernel cycles = GUI_ACTIVE / 8
+NUM_SIMD = 256 * 4 // 8  # SIMDs per unit of GRBM_GUI_ACTIVE
 comp = {}
 for sub in ("pmc_compA", "pmc_compB"):
     for k, d in all_counter_means(sub).items():
@@ -122,7 +124,7 @@ if comp:
     doc = {"command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
                       "--no-cpu-baseline --in-flight 1 --no-configs (two passes; scripts/collect_profiles.sh)",
            "tag": tag, "counter_sets": sets,
-           "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); valu_active_lane_fraction = "
+           "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); valu_active_lane_fraction = "
                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); *_share = counter / SQ_WAVE_CYCLES; means per launch",
            "kernels": {k: {c: (round(v, 1) if isinstance(v, float) and v > 10 else v) for c, v in d.items()} for k, d in sorted(comp.items())}}
     for name in (tag + "_pmc_compute.json", "pmc_compute_current.json"):
