@@ -667,16 +667,22 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
                                                                      const float* __restrict__ rnorm,
                                                                      const float* __restrict__ apart,
                                                                      const float* __restrict__ centres, int n,
-                                                                     float* __restrict__ V, float* __restrict__ colss) {
+                                                                     int num_clouds, float* __restrict__ V,
+                                                                     float* __restrict__ colss) {
     extern __shared__ __attribute__((aligned(16))) float agg_lds[];
     float* xch = agg_lds;                                    // [4][AGG_FT * 2 * 16][64] f32
     float* s_asum = agg_lds + AGG_XCH_FLOATS;                // [8][64]
     unsigned short* xt = reinterpret_cast<unsigned short*>(s_asum + 8 * 64);   // [8 waves][32 points][AGG_ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int fg = blockIdx.x * 4 + (wave & 3);  // group of AGG_FT chunks (32 features each): 64 features, 16 groups
+    // Workgroup -> (cloud, 256-feature group): the four workgroups of a cloud read the same assignment fragments, so they are
+    // placed behind ONE L2: workgroups are dealt round-robin over the 8 XCDs, hence ids i, i + 8, i + 16, i + 24 share an XCD
+    // (speed only; any bijection is correct).  Grid = 4 * clouds, padded to a multiple of 32 with idle workgroups.
+    const int wg = blockIdx.x, fgi = (wg >> 3) & 3;
+    const int cloud = (wg >> 5) * 8 + (wg & 7);
+    if (cloud >= num_clouds) return;
+    const int fg = fgi * 4 + (wave & 3);         // group of AGG_FT chunks (32 features each): 64 features, 16 groups
     const int sp = wave >> 2;                    // which half of the cloud's tiles
-    const int cloud = blockIdx.y;
     const int tiles = n / 32, half = (tiles + 1) / 2;
     const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
     const size_t gt0 = (size_t)cloud * tiles + t_begin;
@@ -830,8 +836,9 @@ extern "C" int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_
         epc_set_error("epc_vlad_aggregate_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(4, num_clouds), dim3(AGG_THREADS), lds_bytes, (hipStream_t)stream,
-                       (const float*)feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, V, colss);
+    hipLaunchKernelGGL(vlad_aggregate_kernel, dim3(32 * ((num_clouds + 7) / 8)), dim3(AGG_THREADS), lds_bytes,
+                       (hipStream_t)stream, (const float*)feat_frag, (const float*)assign_frag, rnorm, apart, centres, n,
+                       num_clouds, V, colss);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -848,7 +855,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
                                                                          const float* __restrict__ rnorm,
                                                                          const float* __restrict__ apart,
                                                                          const float* __restrict__ centres, int n,
-                                                                         float* __restrict__ V,
+                                                                         int num_clouds, float* __restrict__ V,
                                                                          float* __restrict__ colss) {
     extern __shared__ __attribute__((aligned(16))) float agg_lds[];
     float* xch = agg_lds;                                    // [4][AGG_FT * 2 * 16][64] f32
@@ -856,9 +863,11 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     unsigned short* xt = reinterpret_cast<unsigned short*>(s_asum + 8 * 64);   // [8 waves][hi, lo][32 points][AGG_ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int fg = blockIdx.x * 4 + (wave & 3);
+    const int wg = blockIdx.x, fgi = (wg >> 3) & 3;      // XCD-aware (cloud, feature group) mapping: see vlad_aggregate_kernel
+    const int cloud = (wg >> 5) * 8 + (wg & 7);
+    if (cloud >= num_clouds) return;
+    const int fg = fgi * 4 + (wave & 3);
     const int sp = wave >> 2;
-    const int cloud = blockIdx.y;
     const int tiles = n / 32, half = (tiles + 1) / 2;
     const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
     const size_t gt0 = (size_t)cloud * tiles + t_begin;
@@ -1013,8 +1022,8 @@ extern "C" int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* as
         epc_set_error("epc_vlad_aggregate_f32_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    hipLaunchKernelGGL(vlad_aggregate_f32_kernel, dim3(4, num_clouds), dim3(AGG_THREADS), lds_bytes, (hipStream_t)stream,
-                       feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, V, colss);
+    hipLaunchKernelGGL(vlad_aggregate_f32_kernel, dim3(32 * ((num_clouds + 7) / 8)), dim3(AGG_THREADS), lds_bytes,
+                       (hipStream_t)stream, feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, num_clouds, V, colss);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
