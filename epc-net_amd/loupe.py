@@ -77,7 +77,9 @@ class PoolingBaseModel(object):
         if self.add_batch_norm:
             _slim_bn_variables("gating_bn", input_dim)
         else:
-            raise NotImplementedError("add_batch_norm=False (gating_biases, loupe.py:88-93) is not used by EPC-Net")
+            # loupe.py:88-92 builds gating_biases with `initializer=tf.random_normal(stddev=...)` -- the FUNCTION called without
+            # its `shape`, not the initializer class -- so the reference raises this TypeError when the graph is built
+            raise TypeError("random_normal() missing 1 required positional argument: 'shape'")
 
     def context_gating(self, input_layer):
         """loupe.py:61-101: input * sigmoid(BN(input @ gating_weights))."""
@@ -94,12 +96,13 @@ class _VladBase(PoolingBaseModel):
     groups = 1
 
     def declare_variables(self):
-        if not self.add_batch_norm:
-            raise NotImplementedError("add_batch_norm=False (cluster_biases, loupe.py:264-270) is not used by EPC-Net")
         st = default_store()
         F, C, O, G = self.feature_size, self.cluster_size, self.output_dim, self.groups
         st.get_variable(scoped("cluster_weights"), (F, C), random_normal(1 / math.sqrt(F)))
-        _slim_bn_variables("cluster_bn", C)
+        if self.add_batch_norm:
+            _slim_bn_variables("cluster_bn", C)
+        else:                                                                          # loupe.py:264-270
+            st.get_variable(scoped("cluster_biases"), (C,), random_normal(1 / math.sqrt(F)))
         st.get_variable(scoped("cluster_weights2"), (1, F, C), random_normal(1 / math.sqrt(F)))
         st.get_variable(scoped("hidden1_weights"), (C * F // G, O), random_normal(1 / math.sqrt(C)))
         _slim_bn_variables("bn", O)
@@ -115,8 +118,11 @@ class _VladBase(PoolingBaseModel):
         if C != 64:
             raise NotImplementedError("cluster_size must be 64 (configs/*.yaml CLUSTER_SIZE)")
         x = reshaped_input.reshape(-1, F)
-        activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255
-        activation = _slim_batch_norm(activation, "cluster_bn", self.is_training, fused=False)   # :257-263
+        if self.add_batch_norm:
+            activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255
+            activation = _slim_batch_norm(activation, "cluster_bn", self.is_training, fused=False)   # :257-263
+        else:
+            activation = ops.Linear.apply(x, st[scoped("cluster_weights")], st[scoped("cluster_biases")])   # :264-270
         activation = ops.Softmax64.apply(activation)                                             # :272
         activation = activation.reshape(-1, N, C)                                                # :274
         a_sum = activation.sum(dim=-2, keepdim=True)                                             # :276

@@ -398,12 +398,15 @@ def context_gating(st: State, x, is_training, scope="VLAD"):
     return x * gates
 
 
-def _vlad_core(st: State, feats, n_points, is_training, scope="VLAD"):
+def _vlad_core(st: State, feats, n_points, is_training, scope="VLAD", add_batch_norm=True):
     """Shared by NetVLAD.forward (loupe.py:121-193) and G_VLAD.forward (loupe.py:233-298)."""
     C = st.w[scope + "/cluster_weights"].shape[1]
     F = feats.shape[1]
     act = np.matmul(feats, st.w[scope + "/cluster_weights"])                       # loupe.py:255
-    act = slim_batch_norm(st, act, scope + "/cluster_bn", is_training, fused=False)  # :257-263
+    if add_batch_norm:
+        act = slim_batch_norm(st, act, scope + "/cluster_bn", is_training, fused=False)  # :257-263
+    else:
+        act = act + st.w[scope + "/cluster_biases"]                                  # :264-270
     act = act - np.max(act, axis=1, keepdims=True)                                 # softmax :272
     act = np.exp(act)
     act = act / np.sum(act, axis=1, keepdims=True)
@@ -424,9 +427,9 @@ def _vlad_core(st: State, feats, n_points, is_training, scope="VLAD"):
     return vlad
 
 
-def g_vlad_forward(st: State, feats, n_points, groups, is_training, gating=True, scope="VLAD"):
+def g_vlad_forward(st: State, feats, n_points, groups, is_training, gating=True, scope="VLAD", add_batch_norm=True):
     """loupe.py:233-333."""
-    vlad = _vlad_core(st, feats, n_points, is_training, scope)
+    vlad = _vlad_core(st, feats, n_points, is_training, scope, add_batch_norm)
     O = st.w[scope + "/hidden1_weights"].shape[1]
     vlad = vlad.reshape(-1, vlad.shape[1] // groups)                               # :302
     vlad = np.matmul(vlad, st.w[scope + "/hidden1_weights"])                       # :322
@@ -439,9 +442,9 @@ def g_vlad_forward(st: State, feats, n_points, groups, is_training, gating=True,
     return vlad
 
 
-def netvlad_forward(st: State, feats, n_points, is_training, gating=True, scope="VLAD"):
+def netvlad_forward(st: State, feats, n_points, is_training, gating=True, scope="VLAD", add_batch_norm=True):
     """loupe.py:121-214 (ungrouped; hidden1_weights is (C*F, O))."""
-    vlad = _vlad_core(st, feats, n_points, is_training, scope)
+    vlad = _vlad_core(st, feats, n_points, is_training, scope, add_batch_norm)
     vlad = np.matmul(vlad, st.w[scope + "/hidden1_weights"])
     vlad = slim_batch_norm(st, vlad, scope + "/bn", is_training, fused=True)
     if gating:

@@ -162,6 +162,35 @@ def test_loupe_classes_match_oracle(dev, cls, groups, is_training):
     assert np.abs(out - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-6, np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("cls", ["G_VLAD", "NetVLAD"])
+def test_loupe_without_batch_norm(dev, cls):
+    """add_batch_norm=False (loupe.py:264-270: cluster_biases instead of cluster_bn).  With gating the reference cannot even
+    build its graph -- gating_biases is given tf.random_normal(stddev=...) (the function, called without a shape) as its
+    initializer, loupe.py:88-92: TypeError -- and neither can this."""
+    V, lp = H.pkg("variables"), H.pkg("loupe")
+    B, N, F, C, D = 2, 128, 1024, 64, 256
+    rng = np.random.RandomState(4)
+    feats = rng.randn(B * N, F).astype(np.float32)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    st = V.reset_default_store(device=dev, seed=6)
+    with V.variable_scope("query_triplets"), V.variable_scope("VLAD"):
+        kw = dict(feature_size=F, max_samples=N, cluster_size=C, output_dim=D, gating=False, add_batch_norm=False, is_training=False)
+        pool = lp.G_VLAD(groups=4, **kw) if cls == "G_VLAD" else lp.NetVLAD(**kw)
+        pool.declare_variables()
+        st.randomize_statistics(2)
+        assert "query_triplets/VLAD/cluster_biases" in st.vars and "query_triplets/VLAD/cluster_bn/gamma" not in st.vars
+        w = {k[len("query_triplets/"):]: v.detach().cpu().numpy() for k, v in st.vars.items()}
+        with torch.no_grad():
+            out = pool.forward(torch.from_numpy(feats).to(dev)).cpu().numpy()
+        gated = (lp.G_VLAD(groups=4, **dict(kw, gating=True)) if cls == "G_VLAD" else lp.NetVLAD(**dict(kw, gating=True)))
+        with pytest.raises(TypeError, match="shape"):
+            gated.forward(torch.from_numpy(feats).to(dev))
+    ost = O.State(w, np.float32)
+    ref = (O.g_vlad_forward(ost, feats, N, 4, False, gating=False, add_batch_norm=False) if cls == "G_VLAD"
+           else O.netvlad_forward(ost, feats, N, False, gating=False, add_batch_norm=False))
+    assert np.abs(out - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6) + 1e-6
+
+
 def test_column_reductions_are_deterministic_under_workspace_reuse(dev):
     """The one-launch column reductions hand partial sums from every workgroup to the last one through a workspace that
     all layers of a step share (include/epcnet.h, workspace contract).  A partial that is read before it is visible
