@@ -390,6 +390,311 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     }
 }
 
+#ifdef KNN_COLLECT   // built and measured in round 2, NOT the default: see the verdict at the end of this comment
+// ---------------------------------------------------------------------------------------------------------------------
+// knn_collect_kernel (round 2): bound, collect, select.  Same inputs / outputs / bit-exact semantics as the culled kernel
+// above, without the insertion network inside the candidate scan:
+//   pass 0  the wave's own two tiles through the 20-slot network (all 64 lanes useful): B_i = the 20th smallest d' among
+//           the query's 64 Hilbert neighbours -- an upper bound of its true 20th distance;
+//   pass 1  every tile in ASCENDING order, culled by its bounding box against the FIXED bounds B_i; a candidate with
+//           d' <= B_i is appended to the lane's list (u16 indices in LDS, [slot][thread]: conflict-free) -- one compare, one
+//           predicated ds_write and an add instead of a 40-instruction network pass;
+//           when a lane's list is nearly full the wave compacts: the exact 20th smallest of every lane's list (the network,
+//           run once over the stored candidates) becomes its new, tighter B_i -- still an upper bound: the 20th smallest of
+//           a subset -- and entries above it are dropped in place;
+//   select  the network once more over the final lists: kth; emit {j : d' <= kth} in list order (= ascending j), count.
+// A lane whose list cannot shrink below the trigger (more than that many candidates TIED at or below its 20th distance:
+// duplicated points, zero padding) is "saturated"; a wave with a saturated lane falls back to the exact un-culled two-scan
+// (network over all tiles, then count / emit), which is what such clouds cost in the culled kernel as well.
+// One workgroup handles CHUNKS consecutive groups of THREADS queries with one copy of the cloud in LDS.
+//
+// MEASURED (64 Hilbert-ordered 4096-point clouds, scripts/tune_knn_collect.sh; bit-identical lists in all 64 parity / golden
+// tests): 0.478 ms at 512 threads x 2 chunks x 64 slots, 0.542 at 1024 x 1 x 40, 0.511 at 512 x 1 x 64, 0.788 at 256 x 4 x 64,
+// against 0.234 ms for the culled kernel above.  Per wave (KNN_STATS): 31.6 tiles scanned (26.6 adaptive), 66 hit batches,
+// 3.1 compactions and 218 list entries through the network -- the bound from 64 Hilbert neighbours is loose enough that the
+// 56-entry trigger fires three times per wave, and a compaction (recompute + network + filter per entry) costs what ~90 of
+// the old network passes cost; with the lists in LDS only 2 waves per SIMD fit beside the 64-KB cloud image (the culled kernel
+// runs 4 and is VALU-throughput-bound there).  Tightening the bound first with the adaptive network on the nearest tiles
+// turns this into the culled kernel plus ~10 %.  Kept for reference behind -DKNN_COLLECT.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef KC_THREADS
+#define KC_THREADS 512
+#endif
+#ifndef KC_CHUNKS
+#define KC_CHUNKS 2
+#endif
+#ifndef KC_CAP
+#define KC_CAP 64
+#endif
+#define KC_TRIG (KC_CAP - KNN_BATCH)   // compaction trigger: a batch appends at most KNN_BATCH entries
+
+template <int KSEL, bool CONV1>
+__global__ __launch_bounds__(KC_THREADS) void knn_collect_kernel(const float* __restrict__ xyz, int n, int cap,
+                                                                 int32_t* __restrict__ idx, int32_t* __restrict__ cnt,
+                                                                 float* __restrict__ kth_out,
+                                                                 const float* __restrict__ conv1_pack,
+                                                                 float* __restrict__ x32, unsigned short* __restrict__ x16,
+                                                                 int idx_u16, int32_t* __restrict__ status) {
+    static_assert(KSEL == 20, "topk_insert_dist is written for the 20-slot list");
+    extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, 2 float4 per tile, the margin, the lists
+    const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+    const int npad = ntiles * KNN_CT;
+    float4* bb = cand + npad;
+    float* s_margin = reinterpret_cast<float*>(bb + 2 * ntiles);
+    unsigned short* lists = reinterpret_cast<unsigned short*>(s_margin + 4);   // [KC_CAP][KC_THREADS]
+    const int cloud = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int WAVES = KC_THREADS / 64;
+    const float* pc = xyz + (size_t)cloud * n * 3;
+
+    bool bad = false;
+    for (int j = tid; j < npad; j += KC_THREADS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);
+        if (j < n) {
+            v.x = pc[3 * j + 0];
+            v.y = pc[3 * j + 1];
+            v.z = pc[3 * j + 2];
+            v.w = sq3(v.x, v.y, v.z);
+            bad |= !(v.w <= 3.4028234664e38f);
+        }
+        cand[j] = v;
+    }
+    if (status && blockIdx.x == 0 && wave_any(bad) && lane == 0) atomicOr(status + cloud, EPC_STATUS_NONFINITE_INPUT);
+    __syncthreads();
+    const int p0 = blockIdx.x * (KC_THREADS * KC_CHUNKS);   // first point of this workgroup
+    if constexpr (CONV1) {
+        const int q = tid & 15;
+        const float4 w0 = *reinterpret_cast<const float4*>(conv1_pack + 4 * q);
+        const float4 w1 = *reinterpret_cast<const float4*>(conv1_pack + 64 + 4 * q);
+        const float4 w2 = *reinterpret_cast<const float4*>(conv1_pack + 128 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(conv1_pack + 192 + 4 * q);
+        const int np = min(KC_THREADS * KC_CHUNKS, n - p0);
+        bool ovf = false;
+        for (int t = tid; t < np * 16; t += KC_THREADS) {
+            const int g = p0 + (t >> 4);
+            const float4 pt = cand[g];
+            const float4 y = conv1_quad(pt.x, pt.y, pt.z, w0, w1, w2, b);
+            const size_t row = (size_t)cloud * n + g;
+            if (x32) *reinterpret_cast<float4*>(x32 + row * 64 + 4 * q) = y;
+            if (x16) {
+                reinterpret_cast<uint2*>(x16)[row * 16 + q] = pack_half4(y);
+                ovf |= fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)) > 65504.0f;
+            }
+        }
+        if (status && x16 && wave_any(ovf) && lane == 0) atomicOr(status + cloud, EPC_STATUS_FP16_RANGE);
+    }
+    for (int t = wave * (64 / KNN_CT) + lane / KNN_CT; t < ntiles; t += WAVES * (64 / KNN_CT)) {
+        const float4 v = cand[t * KNN_CT + (lane % KNN_CT)];
+        const bool ok = v.w != INFINITY;
+        float lx = ok ? v.x : INFINITY, ly = ok ? v.y : INFINITY, lz = ok ? v.z : INFINITY;
+        float hx = ok ? v.x : -INFINITY, hy = ok ? v.y : -INFINITY, hz = ok ? v.z : -INFINITY;
+#pragma unroll
+        for (int off = KNN_CT / 2; off >= 1; off >>= 1) {
+            lx = fminf(lx, __shfl_xor(lx, off));
+            ly = fminf(ly, __shfl_xor(ly, off));
+            lz = fminf(lz, __shfl_xor(lz, off));
+            hx = fmaxf(hx, __shfl_xor(hx, off));
+            hy = fmaxf(hy, __shfl_xor(hy, off));
+            hz = fmaxf(hz, __shfl_xor(hz, off));
+        }
+        if ((lane % KNN_CT) == 0) {
+            bb[2 * t] = make_float4(lx, ly, lz, 0.f);
+            bb[2 * t + 1] = make_float4(hx, hy, hz, 0.f);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float m = 0.f;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float4 lo = bb[2 * t], hi = bb[2 * t + 1];
+            const float ax = fmaxf(fabsf(lo.x), fabsf(hi.x)), ay = fmaxf(fabsf(lo.y), fabsf(hi.y)),
+                        az = fmaxf(fabsf(lo.z), fabsf(hi.z));
+            m = fmaxf(m, ax * ax + ay * ay + az * az);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) *s_margin = m * (256.0f * 5.9604645e-08f);
+    }
+    __syncthreads();
+    const float margin = *s_margin;
+    unsigned short* mylist = lists + tid;   // slot e at mylist[e * KC_THREADS]
+
+    for (int chunk = 0; chunk < KC_CHUNKS; ++chunk) {
+        const int wave_first = p0 + chunk * KC_THREADS + wave * 64;   // wave-uniform
+        if (wave_first >= n) break;
+        const int i = wave_first + lane;
+        const bool valid = i < n;
+        float xi = 0.f, yi = 0.f, zi = 0.f, sqi = 0.f;
+        if (valid) {
+            const float4 me = cand[i];
+            xi = me.x, yi = me.y, zi = me.z, sqi = me.w;
+        }
+        auto lower_bound = [&](int c) {
+            const float4 lo = bb[2 * c], hi = bb[2 * c + 1];
+            const float dx = fmaxf(fmaxf(lo.x - xi, xi - hi.x), 0.f);
+            const float dy = fmaxf(fmaxf(lo.y - yi, yi - hi.y), 0.f);
+            const float dz = fmaxf(fmaxf(lo.z - zi, zi - hi.z), 0.f);
+            return dx * dx + dy * dy + dz * dz - margin;
+        };
+        auto pos_sq_dist = [&](const float4& q) {
+#pragma clang fp contract(off)
+            const float inner = (xi * q.x + yi * q.y) + zi * q.z;
+            return __builtin_fmaf(-2.0f, inner, sqi) + q.w;   // (-2 * inner is exact: one rounding, like the reference's mul + add)
+        };
+        float top[KSEL];
+        auto reset_top = [&]() {
+#pragma unroll
+            for (int s = 0; s < KSEL; ++s) top[s] = INFINITY;
+        };
+        // a whole tile through the network (pass 0, and the exact fallback)
+        auto scan_net = [&](int c) {
+            const float4* tp = cand + c * KNN_CT;
+#pragma unroll
+            for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+                float4 q[KNN_BATCH];
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
+                float d[KNN_BATCH];
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) {
+                    d[u] = pos_sq_dist(q[u]);
+                    hit |= valid && d[u] < top[KSEL - 1];
+                }
+                if (wave_any(hit)) {
+#pragma unroll
+                    for (int u = 0; u < KNN_BATCH; ++u)
+                        if (wave_any(d[u] < top[KSEL - 1])) topk_insert_dist(top, d[u]);
+                }
+            }
+        };
+        // the exact 20 smallest d' of every lane's list -> top[]
+        auto select_from_list = [&](int count) {
+            reset_top();
+            for (int e = 0; wave_any(e < count); ++e) {
+                KSTAT(4);
+                const bool have = e < count;
+                const int j = have ? (int)mylist[e * KC_THREADS] : 0;
+                const float d = have ? pos_sq_dist(cand[j]) : INFINITY;
+                if (wave_any(d < top[KSEL - 1])) topk_insert_dist(top, d);
+            }
+        };
+
+        // ---- pass 0: own tiles ----
+        reset_top();
+        const int t0 = wave_first / KNN_CT;
+        constexpr int OWN = 64 / KNN_CT;
+#pragma unroll
+        for (int o = 0; o < OWN; ++o)
+            if (t0 + o < ntiles) scan_net(t0 + o);
+        float B = top[KSEL - 1];        // upper bound of the query's 20th smallest d'
+        int count = 0;
+        bool sat = false;
+
+        // ---- pass 1: collect, ascending ----
+        for (int c = 0; c < ntiles; ++c) {
+            KSTAT(0);
+            if (!wave_any(valid && !sat && lower_bound(c) <= B)) continue;
+            KSTAT(1);
+            const float4* tp = cand + c * KNN_CT;
+#pragma unroll
+            for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
+                float4 q[KNN_BATCH];
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
+                float d[KNN_BATCH];
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) {
+                    d[u] = pos_sq_dist(q[u]);
+                    hit |= d[u] <= B;
+                }
+                hit = hit && valid && !sat;
+                if (wave_any(hit)) {
+                    KSTAT(2);
+#pragma unroll
+                    for (int u = 0; u < KNN_BATCH; ++u)
+                        if (hit && d[u] <= B) {
+                            mylist[count * KC_THREADS] = (unsigned short)(c * KNN_CT + k0 + u);
+                            ++count;
+                        }
+                    if (wave_any(count >= KC_TRIG && !sat)) {
+                        // compaction: tighten every lane's bound to the 20th smallest of its list, drop what is above it
+                        KSTAT(3);
+                        select_from_list(count);
+                        const float nb = top[KSEL - 1];
+                        if (nb < B) B = nb;   // (lanes with fewer than 20 entries keep their bound: top[19] is +Inf there)
+                        int kept = 0;
+                        for (int e = 0; wave_any(e < count); ++e) {
+                            if (e < count) {
+                                const int j = (int)mylist[e * KC_THREADS];
+                                if (pos_sq_dist(cand[j]) <= B) {
+                                    mylist[kept * KC_THREADS] = (unsigned short)j;
+                                    ++kept;
+                                }
+                            }
+                        }
+                        count = kept;
+                        sat = sat || count >= KC_TRIG;   // more than that many candidates tied at / below the 20th distance
+                    }
+                }
+            }
+        }
+
+        float kth;
+        unsigned int total = 0;
+        const unsigned int ucap = (unsigned int)cap;
+        char* out_lists = reinterpret_cast<char*>(idx) + (size_t)cloud * n * cap * (idx_u16 ? 2 : 4);
+        auto emit = [&](unsigned int slot, int j) {
+            if (idx_u16)
+                *reinterpret_cast<unsigned short*>(out_lists + ((size_t)i * ucap + slot) * 2) = (unsigned short)j;
+            else
+                *reinterpret_cast<int32_t*>(out_lists + ((size_t)i * ucap + slot) * 4) = j;
+        };
+        if (!wave_any(sat)) {
+            // ---- select + emit from the lists ----
+            select_from_list(count);
+            kth = 0.0f - top[KSEL - 1];
+            const float dk = top[KSEL - 1];
+            for (int e = 0; wave_any(e < count); ++e) {
+                if (e < count) {
+                    const int j = (int)mylist[e * KC_THREADS];
+                    if (pos_sq_dist(cand[j]) <= dk) {
+                        if (valid && total < ucap) emit(total, j);
+                        ++total;
+                    }
+                }
+            }
+        } else {
+            // ---- exact fallback for the wave: un-culled two-scan ----
+            KSTAT(5);
+            reset_top();
+            for (int c = 0; c < ntiles; ++c) scan_net(c);
+            kth = 0.0f - top[KSEL - 1];
+            const float dk = top[KSEL - 1];
+            for (int c = 0; c < ntiles; ++c) {
+                const float4* tp = cand + c * KNN_CT;
+                for (int k = 0; k < KNN_CT; ++k) {
+                    const float d = pos_sq_dist(tp[k]);
+                    if (d <= dk) {
+                        if (valid && total < ucap) emit(total, c * KNN_CT + k);
+                        ++total;
+                    }
+                }
+            }
+        }
+        if (valid && total < (unsigned int)KSEL) {   // NaN / Inf coordinates: pad with the point's own index (see the culled kernel)
+            for (unsigned int c = total; c < (unsigned int)KSEL; ++c) emit(c, i);
+        }
+        if (valid) {
+            cnt[(size_t)cloud * n + i] = (int32_t)total;
+            kth_out[(size_t)cloud * n + i] = kth;
+        }
+    }
+}
+
+#endif  // KNN_COLLECT
+
 template <int KSEL>
 __global__ __launch_bounds__(KNN_THREADS) void knn_topk_stream_kernel(const float* __restrict__ xyz, int n, int cap,
                                                                       int32_t* __restrict__ idx,
@@ -483,6 +788,33 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
                       const float* conv1_pack, float* x32, void* x16, int idx_u16, int32_t* status, void* stream,
                       const char* who) {
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
+#ifdef KNN_COLLECT
+    {
+        // bound / collect / select form (knn_collect_kernel) wherever its LDS image fits: cloud + boxes + the per-lane lists
+        const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+        const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 1) * sizeof(float4) +
+                                 (size_t)KC_CAP * KC_THREADS * sizeof(unsigned short);
+        if (lds_bytes <= 160 * 1024 && n <= 65535) {
+            const void* fn = conv1_pack ? reinterpret_cast<const void*>(knn_collect_kernel<EPC_KNN_SELECT, true>)
+                                        : reinterpret_cast<const void*>(knn_collect_kernel<EPC_KNN_SELECT, false>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) {
+                epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+                return EPC_EHIP;
+            }
+            dim3 cgrid((n + KC_THREADS * KC_CHUNKS - 1) / (KC_THREADS * KC_CHUNKS), num_clouds);
+            if (conv1_pack)
+                hipLaunchKernelGGL((knn_collect_kernel<EPC_KNN_SELECT, true>), cgrid, dim3(KC_THREADS), lds_bytes,
+                                   (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16, idx_u16,
+                                   status);
+            else
+                hipLaunchKernelGGL((knn_collect_kernel<EPC_KNN_SELECT, false>), cgrid, dim3(KC_THREADS), lds_bytes,
+                                   (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, status);
+            EPC_CHECK_LAUNCH();
+            return EPC_OK;
+        }
+    }
+#endif
     if (n <= KNN_LDS_MAX_N) {
         const int ntiles = (n + KNN_CT - 1) / KNN_CT;
         const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +

@@ -33,5 +33,6 @@ for kind in ("uniform", "unsorted"):
         lib.epc_knn_topk(srt.data_ptr(), B, N, 32, idx.data_ptr(), cnt.data_ptr(), kth.data_ptr(), st); torch.cuda.synchronize()
         lib.epc_debug_knn_stats(st8, 1)
         waves = B * N / 64
-        print("    per wave: p1 tiles tested %.1f scanned %.1f | batches w/ insert %.1f, network passes %.1f | p2 tiles scanned %.1f, batches w/ emit %.1f"
+        print("    per wave: counters 0..5 = %.1f %.1f | %.1f %.2f | %.1f %.3f   (culled kernel: tiles tested, scanned | batches w/ insert, network passes | "
+              "p2 tiles, batches w/ emit;  collect kernel: tiles tested, scanned | hit batches, compactions | select-loop entries, fallback waves)"
               % tuple(st8[i] / waves for i in range(6)))
