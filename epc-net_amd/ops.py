@@ -168,6 +168,81 @@ class BatchNormTrain(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None
 
 
+def _gemm_with_stats(x, W, b):
+    """z = x @ W + b and the batch moments of z from the GEMM's own epilogue (epc_gemm_f32_stats): (z, mean, var)."""
+    rows, cin = x.shape
+    cout = W.shape[1]
+    z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+    var = torch.empty(cout, dtype=torch.float32, device=x.device)
+    tiles = L.lib().epc_gemm_stats_tiles(rows)
+    stats = torch.empty(tiles * 2 * cout, dtype=torch.float32, device=x.device)
+    L.check(L.lib().epc_gemm_f32_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
+                                       rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
+                                       stats.data_ptr(), stats.numel(), mean.data_ptr(), var.data_ptr(), _st()))
+    return z, mean, var
+
+
+def fused_linear_bn_ok(rows, cin, cout):
+    """Shapes the statistics epilogue covers (the split-bf16 GEMM kernel) in the f32-accurate arithmetic."""
+    return _GEMM_PRECISION == "bf16x6" and rows >= 64 and cout >= 64 and cin >= 32
+
+
+class LinearBatchNormTrain(torch.autograd.Function):
+    """Linear followed by BatchNormTrain (utils/tf_util.py:94-106 in training mode) as ONE node: the batch statistics come out
+    of the GEMM's epilogue instead of a pass over z.  ``rownorm``: conv5's tail -- l2_normalize(relu(bn(z))) over the channels
+    (models/epc-net.py:136-148), the BatchNorm output not materialised.  Returns (y, mean, var); the backward is the BatchNorm
+    backward (ReLU mask recomputed from z) followed by the two GEMMs of the linear layer; the bias gradient in front of a
+    training-mode BatchNorm is exactly zero and is not computed."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm):
+        x = x.contiguous()
+        z, mean, var = _gemm_with_stats(x, W, b)
+        rows, C = z.shape
+        if rownorm:
+            y = torch.empty_like(z)
+            rn = torch.empty(rows, dtype=torch.float32, device=z.device)
+            L.check(L.lib().epc_bn_relu_rownorm_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                                    beta.data_ptr(), float(eps), rows, C, y.data_ptr(), rn.data_ptr(), _st()))
+            ctx.save_for_backward(x, W, z, mean, var, gamma, beta, y, rn)
+        else:
+            y = torch.empty_like(z)
+            L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             float(eps), int(relu), rows, C, y.data_ptr(), _st()))
+            ctx.save_for_backward(x, W, z, mean, var, gamma, beta)
+        ctx.eps, ctx.relu, ctx.rownorm = float(eps), int(relu), bool(rownorm)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        if dy is None:
+            return (None,) * 8
+        if ctx.rownorm:
+            x, W, z, mean, var, gamma, beta, f, rn = ctx.saved_tensors
+        else:
+            x, W, z, mean, var, gamma, beta = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C = z.shape
+        cin = x.shape[1]
+        if ctx.rownorm:
+            d = torch.empty_like(z)
+            L.check(L.lib().epc_rownorm_bwd(dy.data_ptr(), f.data_ptr(), rn.data_ptr(), rows, C, d.data_ptr(), _st()))
+            dy = d
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, n = _ws(rows, C, z.device)
+        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), ctx.eps, 1 if ctx.rownorm else ctx.relu, rows, C, dz.data_ptr(),
+                                         dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, _st()))
+        dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
+        dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True)
+        return dx, dW, None, dgamma, dbeta, None, None, None
+
+
 class BatchNormReluRowNorm(torch.autograd.Function):
     """l2_normalize(relu(batch_norm_train(z)), 1) for conv5's 1024 channels (models/epc-net.py:136-148) without
     materialising the BatchNorm output: (f, mean, var).  Backward = row-norm backward, then the BatchNorm backward."""

@@ -167,12 +167,27 @@ def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope):
     return batch_norm_template(inputs, is_training, scope, [0, 1], bn_decay)
 
 
+def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=False):
+    """Linear + training-mode BatchNorm (+ReLU, + conv5's row norm) as one autograd node whose batch statistics come from the
+    GEMM's epilogue (ops.LinearBatchNormTrain), with the moving-average updates of batch_norm_template."""
+    from .. import ops
+    C = int(w2d.shape[1])
+    beta, gamma, ema_mean, ema_var = _bn_variables(scope_bn, C)
+    y, mean, var = ops.LinearBatchNormTrain.apply(inputs2d, w2d, b, gamma, beta, 1e-3, int(relu_flag), bool(rownorm))
+    decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+    _ema_update(ema_mean, mean, decay)
+    _ema_update(ema_var, var, decay)
+    return y
+
+
 def _dense(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training):
     from .. import ops
-    z = ops.Linear.apply(inputs2d, w2d, b, bool(bn and is_training))
     want_relu = activation_fn is not None
     if activation_fn not in (None, relu):
         raise NotImplementedError("only activation_fn=tf.nn.relu / None are used by EPC-Net")
+    if bn and is_training and ops.fused_linear_bn_ok(int(inputs2d.shape[0]), int(w2d.shape[0]), int(w2d.shape[1])):
+        return _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, want_relu)
+    z = ops.Linear.apply(inputs2d, w2d, b, bool(bn and is_training))
     if bn:
         return batch_norm_template(z, bool(is_training), scope_bn, None, bn_decay, activation_relu=want_relu)
     return torch.relu(z) if want_relu else z
@@ -206,7 +221,10 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     L.require_gpu()
     w, b, _ = declare_conv1d(scope, cin, num_output_channels, 1, True, 1e-3, True)
     with variable_scope(scope):
-        z = ops.Linear.apply(inputs.reshape(-1, cin), w.reshape(cin, num_output_channels), b, True)
+        x2 = inputs.reshape(-1, cin)
+        if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
+            return _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True)
+        z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)
         beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
         f, mean, var = ops.BatchNormReluRowNorm.apply(z, gamma, beta, 1e-3)
         decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))

@@ -283,6 +283,15 @@ int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bia
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
+/* y = x W + b (the f32-accurate three-piece arithmetic of epc_gemm_f32, one problem, no split-K) TOGETHER with the batch
+ * statistics a training-mode BatchNorm on y needs (utils/tf_util.py:472 tf.nn.moments over the rows): mean[N] and POPULATION
+ * var[N].  The GEMM's epilogue leaves per row tile the column sums of the product and of its square in `stats`
+ * (epc_gemm_stats_tiles(M) * 2 * N floats), a second tiny launch adds them in tile order in double precision -- no pass of
+ * epc_col_moments over y.  M, N >= 64, K >= 32. */
+int epc_gemm_stats_tiles(int M);
+int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                       long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, void* stream);
+
 /* Same interface, operands rounded to ONE bf16 value each (f32 data in memory, f32 accumulation, one product): the
  * "bf16" training configuration of BASELINE.json configs[2].  2^-9 relative per operand. */
 int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
