@@ -91,8 +91,8 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
         # the small-size bar's headroom; 22 x 4096 showed 1.4e-2 on one BN beta where float32 torch happened to see 2.6e-3)
         bar_l2 = max(2e-2 if n == 4096 else 8e-3, 3.0 * noise.get(k, (0.0, 0.0))[1])
         rel_l2 = np.linalg.norm(g - g_ref) / max(np.linalg.norm(g_ref), 1e-30)
-        # (exactly-zero true gradients -- a bias in front of a training-mode BN, EPC-Net-L's conv5 beta under... -- have no
-        # relative error: they are held by the absolute floor above only)
+        # (exactly-zero true gradients -- a bias in front of a training-mode BN; every tensor when the hinge is inactive and the
+        # loss is 0 -- have no relative error: they are held by the absolute floor above only)
         if not k.endswith("/biases") and np.linalg.norm(g_ref) > 1e-12:
             worst = max(worst, (rel_l2, k))
         assert np.abs(g - g_ref).max() <= bar_max * gmax + floor, "gradient of %s: max error %.3e (|g|max %.3e)" % (
