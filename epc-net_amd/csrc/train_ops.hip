@@ -34,6 +34,8 @@ struct GemmArgs {
     long bA, bB, bC;
     int splitk, accumulate;
     float* stats;   // optional (split kernel, splitk == 1, batch == 1): per row tile the column sums of A.B and of (A.B)^2
+    float* partial; // optional (splitk > 1): slice blockIdx.z stores its (M, N) partial product here instead of adding it to C
+                    // atomically; splitk_reduce_kernel then adds the slices in ascending order (deterministic split-K)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             if (row < g.M) {
                 float* p = C + (size_t)row * g.ldc + col;
                 const float v = acc[r] + bv;
-                if (g.splitk > 1)
+                if (g.partial)
+                    g.partial[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
+                else if (g.splitk > 1)
                     atomicAdd(p, v);
                 else
                     *p = g.accumulate ? *p + v : v;
@@ -289,7 +293,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
                 if (row < g.M) {
                     float* p = C + (size_t)row * g.ldc + col;
                     const float v = acc[rb][cb][r] + bv;
-                    if (g.splitk > 1)
+                    if (g.partial)
+                        g.partial[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[rb][cb][r];
+                    else if (g.splitk > 1)
                         atomicAdd(p, v);
                     else
                         *p = g.accumulate ? *p + v : v;
@@ -311,7 +317,31 @@ static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStrea
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                      long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
-                     int pieces, void* stream);
+                     int pieces, void* stream, float* partial = nullptr, size_t partial_floats = 0);
+
+// C[b](m, n) = bias(n) + sum over the split-K slices IN ASCENDING ORDER of their partial products: the deterministic
+// counterpart of the atomic epilogue (same bits on every run), one float4 of C per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int M, int N, int ldc, long bC, int splitk,
+                                                            int accumulate) {
+    const size_t per = (size_t)M * N;
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= per) return;
+    const int batch = blockIdx.y;
+    const float* p = partial + (size_t)batch * splitk * per + e;
+    const int row = (int)(e / N), col = (int)(e % N);
+    float4 s = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splitk; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * per);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(C + (size_t)batch * bC + (size_t)row * ldc + col);
+    if (accumulate) {
+        const float4 c = *o;
+        s.x += c.x, s.y += c.y, s.z += c.z, s.w += c.w;
+    }
+    *o = s;
+}
 
 extern "C" int epc_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                             long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
@@ -337,12 +367,17 @@ extern "C" int epc_gemm_bf16(const float* A, const float* B, float* C, const flo
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                      long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
-                     int pieces, void* stream) {
+                     int pieces, void* stream, float* partial, size_t partial_floats) {
     EPC_CHECK_ARG(A && B && C, "null pointer");
     EPC_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1 && ldc >= N, "bad shape");
     EPC_CHECK_ARG((long)batch * splitk <= 65535, "batch*splitk too large");
     hipStream_t st = (hipStream_t)stream;
-    if (splitk > 1 && !accumulate) {  // split-K partial sums are added atomically into a zeroed C
+    if (splitk == 1) partial = nullptr;
+    if (partial) {
+        EPC_CHECK_ARG(partial_floats >= (size_t)batch * splitk * M * N, "split-K workspace too small (batch * splitk * M * N floats)");
+        EPC_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && bC % 4 == 0, "deterministic split-K needs N, ldc and the batch stride of C in multiples of 4");
+    }
+    if (splitk > 1 && !accumulate && !partial) {  // split-K partial sums are added atomically into a zeroed C
         if (ldc == N && (batch == 1 || bC == (long)M * N)) {
             if (hipMemsetAsync(C, 0, (size_t)batch * M * N * sizeof(float), st) != hipSuccess) {
                 epc_set_error("epc_gemm_f32: hipMemsetAsync failed");
@@ -352,7 +387,15 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
             EPC_CHECK_ARG(false, "split-K needs a dense C (ldc == N, contiguous batches) or accumulate=1");
         }
     }
-    GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, bA, bB, bC, splitk, accumulate, nullptr};
+    GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, bA, bB, bC, splitk, accumulate, nullptr, partial};
+    auto finish = [&]() -> int {
+        if (partial) {
+            dim3 rgrid((unsigned)(((size_t)M * N / 4 + 255) / 256), batch);
+            hipLaunchKernelGGL(splitk_reduce_kernel, rgrid, dim3(256), 0, st, partial, bias, C, M, N, ldc, bC, splitk, accumulate);
+            EPC_CHECK_LAUNCH();
+        }
+        return EPC_OK;
+    };
 #ifndef EPC_GEMM_F32_ONLY
     // sides of at least 64: the split-bf16 kernel with the tile that fits; short sides stay on the f32 MFMA kernel
     if (M >= 64 && N >= 64 && K >= 32) {
@@ -362,13 +405,27 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         else if (bign) launch_gemm_split<1, 2>(g, batch, pieces, st);
         else launch_gemm_split<1, 1>(g, batch, pieces, st);
         EPC_CHECK_LAUNCH();
-        return EPC_OK;
+        return finish();
     }
 #endif
     dim3 grid((N + G_BN - 1) / G_BN, (M + G_BM - 1) / G_BM, batch * splitk);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
     EPC_CHECK_LAUNCH();
-    return EPC_OK;
+    return finish();
+}
+
+// Split-K WITHOUT atomics: every slice stores its partial product in the caller's workspace (batch * splitk * M * N floats) and a
+// second launch adds the slices in ascending order -- the same bits on every run, which the FORWARD products of the training
+// step want (a last-bit difference in an activation can flip a ReLU mask and move a whole gradient tensor by 1e-3).
+// pieces: 3 = the f32-accurate arithmetic of epc_gemm_f32, 2 = epc_gemm_f32_fast, 1 = epc_gemm_bf16.
+extern "C" int epc_gemm_splitk_det(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                   long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
+                                   int splitk, int accumulate, int pieces, float* workspace, size_t workspace_floats,
+                                   void* stream) {
+    EPC_CHECK_ARG(pieces >= 1 && pieces <= 3, "pieces must be 1, 2 or 3");
+    EPC_CHECK_ARG(workspace || splitk == 1, "null workspace");
+    return gemm_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk, accumulate, pieces, stream,
+                     workspace, workspace_floats);
 }
 
 // ---- y = x W + b together with the batch statistics a training-mode BatchNorm on y needs -------------------------------
@@ -426,7 +483,7 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     const int tiles = epc_gemm_stats_tiles(M);
     EPC_CHECK_ARG(stats_floats >= (size_t)tiles * 2 * N, "statistics buffer too small (epc_gemm_stats_tiles(M) * 2 * N floats)");
     hipStream_t st = (hipStream_t)stream;
-    GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, 0, 0, 0, 1, 0, stats};
+    GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, 0, 0, 0, 1, 0, stats, nullptr};
     const bool bigm = M >= 128, bign = N >= 128;
     if (bigm && bign) launch_gemm_split<2, 2>(g, 1, 3, st);
     else if (bigm) launch_gemm_split<2, 1>(g, 1, 3, st);

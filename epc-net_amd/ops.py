@@ -45,10 +45,25 @@ def set_gemm_precision(name: str) -> str:
     return prev
 
 
-def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False, fast=False):
+_SPLITK_WS = {}
+
+
+def _splitk_ws(floats, device):
+    """The split-K partial-product workspace of (device, current stream) for the deterministic forward GEMMs."""
+    key = (device.index, int(_st() or 0))
+    buf = _SPLITK_WS.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = _SPLITK_WS[key] = torch.empty(max(int(floats), 1 << 18), dtype=torch.float32, device=device)
+    return buf
+
+
+def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accumulate=False, fast=False,
+         deterministic=False):
     """out = op(A) @ op(B) (+ bias).  A, B: 2-D, or 3-D with a leading batch dim (same batch).  f32-accurate split-bf16
     MFMA arithmetic (three pieces per operand); ``fast`` = two pieces (backward GEMMs: linear in the gradient);
-    one piece under set_gemm_precision("bf16")."""
+    one piece under set_gemm_precision("bf16").  ``deterministic``: a split-K product adds its slices in a fixed order
+    (epc_gemm_splitk_det) instead of with f32 atomics -- the forward products use it, so that a step's activations, ReLU masks
+    and loss are the same bits on every run."""
     L.require_gpu()
     batched = A.dim() == 3
     a2 = A[0] if batched else A
@@ -63,6 +78,15 @@ def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accu
     sb = b2.stride()
     sAm, sAk = (sa[1], sa[0]) if trans_a else (sa[0], sa[1])
     sBk, sBn = (sb[1], sb[0]) if trans_b else (sb[0], sb[1])
+    if deterministic and splitk > 1:
+        pieces = 1 if _GEMM_PRECISION == "bf16" else (2 if fast else 3)
+        ws = _splitk_ws(nb * int(splitk) * M * N, A.device)
+        L.check(L.lib().epc_gemm_splitk_det(
+            A.data_ptr(), B.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+            M, N, K, sAm, sAk, sBk, sBn, out.stride(-2), nb, A.stride(0) if batched else 0,
+            B.stride(0) if batched else 0, out.stride(0) if batched else 0, int(splitk), 1 if accumulate else 0, pieces,
+            ws.data_ptr(), ws.numel(), _st()))
+        return out
     if _GEMM_PRECISION == "bf16":
         fn = L.lib().epc_gemm_bf16
     else:
@@ -111,7 +135,7 @@ class Linear(torch.autograd.Function):
         # few output tiles but a deep K (the 16384-wide hidden projection on a handful of rows): split K over workgroups
         tiles = ((rows + 63) // 64) * ((W.shape[1] + 63) // 64)
         splitk = int(max(1, min(256 // tiles, cin // 256, 64))) if tiles <= 32 else 1
-        return gemm(x, W, bias=b, splitk=splitk)
+        return gemm(x, W, bias=b, splitk=splitk, deterministic=True)
 
     @staticmethod
     def backward(ctx, dy):
@@ -485,7 +509,7 @@ class VladAggregate(torch.autograd.Function):
     def forward(ctx, f, a):
         f, a = f.contiguous(), a.contiguous()
         ctx.save_for_backward(f, a)
-        return gemm(f, a, trans_a=True, splitk=max(1, min(8, f.shape[1] // 256)))
+        return gemm(f, a, trans_a=True, splitk=max(1, min(8, f.shape[1] // 256)), deterministic=True)
 
     @staticmethod
     def backward(ctx, dv):

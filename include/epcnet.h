@@ -298,6 +298,14 @@ int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, i
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
+/* Split-K WITHOUT atomics (the forward products of the training step: the same bits on every run).  Every K slice stores its
+ * partial product in `workspace` (batch * splitk * M * N floats) and a second launch adds the slices in ascending order (+ bias,
+ * + C when accumulate).  pieces: 3 = the arithmetic of epc_gemm_f32, 2 = epc_gemm_f32_fast, 1 = epc_gemm_bf16.  N, ldc and bC
+ * must be multiples of 4.  Replaces the same tf.matmul sites as epc_gemm_f32 (loupe.py:286-291, 306; utils/tf_util.py:336). */
+int epc_gemm_splitk_det(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                        long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
+                        int pieces, float* workspace, size_t workspace_floats, void* stream);
+
 /* Column reductions over the rows of (rows, C) tensors, C a multiple of 4 (at most 4096).  Each is ONE launch: the
  * workgroup that finishes a column panel last adds the per-panel partial sums in a fixed order (deterministic).
  * WORKSPACE CONTRACT: epc_colreduce_workspace_bytes(rows, C) bytes, 16-byte aligned; its first 256 bytes are

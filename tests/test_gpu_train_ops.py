@@ -117,6 +117,32 @@ def test_vlad_aggregate(dev):
     run_pair(lambda f, a: ops.VladAggregate.apply(f, a), lambda f, a: torch.matmul(f.transpose(1, 2), a), [f, a], dev)
 
 
+@pytest.mark.parametrize("shape", [("nn", 18, 16384, 256, 1, 64), ("tn", 1024, 4096, 64, 3, 8), ("nn", 40, 700, 64, 1, 5)])
+def test_deterministic_split_k(dev, shape):
+    """epc_gemm_splitk_det: the split-K slices are added in a fixed order -- equal to float64 within the f32-accurate bar, the
+    SAME BITS on every run and in every split-K workspace state, bias and accumulate included (the atomic form differs from run
+    to run in the last bits, which is what the training step's forward must not do)."""
+    ops = H.pkg("ops")
+    form, M, K, N, nb, splitk = shape
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn((nb, K, M) if form == "tn" else (nb, M, K), dtype=torch.float64, generator=g)
+    B = torch.randn(nb, K, N, dtype=torch.float64, generator=g) / np.sqrt(K)
+    bias = torch.randn(N, dtype=torch.float64, generator=g)
+    ref = (A.transpose(1, 2) if form == "tn" else A) @ B + bias
+    Ag, Bg, bg = A.float().to(dev), B.float().to(dev), bias.float().to(dev)
+    if nb == 1:
+        Ag, Bg, ref = Ag[0], Bg[0], ref[0]
+    runs = []
+    for _ in range(3):
+        ops._SPLITK_WS.clear()                         # a fresh (uninitialised) workspace each time
+        runs.append(ops.gemm(Ag, Bg, bias=bg, trans_a=form == "tn", splitk=splitk, deterministic=True))
+    assert rel(runs[0], ref) <= 2e-6
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    acc = runs[0].clone()
+    ops.gemm(Ag, Bg, out=acc, trans_a=form == "tn", splitk=splitk, accumulate=True, deterministic=True)
+    assert rel(acc, 2 * ref - bias) <= 2e-6
+
+
 def test_adam_matches_tensorflow_rule(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(5)

@@ -123,9 +123,10 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
     state = ts.optimizer_state()
     assert int(state["Variable"]) == step0 + 1 and len([k for k in state if k.endswith("/Adam")]) == len(ref["grads"])
     if n == 4096:
-        # repeatability: the same step from the same state agrees to float32 rounding -- not bit for bit: the split-K partial
-        # sums of the long-K GEMMs (the VLAD aggregation over 4096 points in the forward, every dW in the backward) meet in
-        # f32 atomics, whose order varies from run to run
+        # repeatability: the FORWARD of the same step from the same state is bit-identical (its split-K products add their slices
+        # in a fixed order, epc_gemm_splitk_det; column reductions are ordered too), so the loss, the descriptors and every ReLU
+        # mask repeat exactly; the backward's dW products (K = all rows) still meet in f32 atomics, whose order varies from run
+        # to run: gradients repeat to float32 rounding, not bit for bit
         first = {k: v.copy() for k, v in grads.items()}
         d_first = ts.last_aux["q_vec"].clone()
         st2 = H.make_store(arch, w0, dev)
@@ -141,13 +142,11 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
             H.pkg("ops").adam_multi = orig
             TR.ops.adam_multi = orig
         torch.cuda.synchronize()
-        assert abs(float(loss2) - float(loss)) <= 2e-6 * abs(float(loss))
-        assert float((ts2.last_aux["q_vec"] - d_first).abs().max()) <= 5e-6
-        # (gradients: a forward that differs in the last bit can flip a ReLU mask, so single elements may move like they do
-        # against the oracle; the tensors as a whole must agree closely)
+        assert float(loss2) == float(loss)
+        assert torch.equal(ts2.last_aux["q_vec"], d_first)
         for k in ("fastdgcnn/conv1/weights", "fastdgcnn/conv5/weights", "VLAD/hidden1_weights"):
             a, b = first[H.OUTER + "/" + k], grads[H.OUTER + "/" + k]
-            assert np.linalg.norm(a - b) <= 2e-3 * max(np.linalg.norm(a), 1e-30), k
+            assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-30), k
 
 
 @pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
