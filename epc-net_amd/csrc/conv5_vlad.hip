@@ -55,8 +55,11 @@ struct C5Lds {  // offsets in floats (4 B)
     // cluster-weight chunk: 32 ch x 64 clusters x 2 B (FAST: ONE fp16 per cluster weight, see the epilogue) or bf16 hi + lo
     static constexpr int WC_CHUNK = F8LO ? 1024 : 2048;
     static constexpr int OFF_W5 = 0;
+    // cluster-weight slots: 2 (chunk parity) in the fast form; 4 in the f32-equivalent form, whose second wave group runs its
+    // epilogue half a chunk interval late (C5_STAGGER) and still reads chunk c's slot while chunk c + 2 is landing
+    static constexpr int WC_SLOTS = F8LO ? 2 : 4;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
-    static constexpr int OFF_B5 = OFF_WC + 2 * WC_CHUNK;
+    static constexpr int OFF_B5 = OFF_WC + WC_SLOTS * WC_CHUNK;
     static constexpr int OFF_CBN = OFF_B5 + 1024;
     // per-wave 32 x 32 f32 transpose tile (row stride 36) of the FINAL epilogue: it aliases the W5 stream buffers, which
     // are dead by then (a barrier separates the last chunk from the first tile write) -- 38 KB less LDS, so that a
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
         if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256)   // 4 (8) KB per chunk: one 1-KB piece from each of four (eight) waves
             glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
-                   lds_base + 4u * (L::OFF_WC + buf * L::WC_CHUNK + wave_u * 256));
+                   lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
     };
 
     stage_chunk(0, std::integral_constant<int, 0>{});
@@ -187,12 +190,16 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             // pass 1 over the lane's half of the row: its largest magnitude (the other half sits in lane ^ 32); the values
             // are re-read below (L1 / L2 hits) rather than kept: 128 more registers would not fit
             float m = 0.f;
+#ifdef C5_ABL_NOROWPASS
+            m = 4.0f;
+#else
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 m = fmaxf(fmaxf(fmaxf(m, fabsf(a.x)), fmaxf(fabsf(a.y), fabsf(a.z))), fmaxf(fmaxf(fabsf(a.w), fabsf(b.x)), fmaxf(fabsf(b.y), fmaxf(fabsf(b.z), fabsf(b.w)))));
             }
+#endif
             m = fmaxf(m, __shfl_xor(m, 32));
             row_scale_pow2(m, row_s, inv_row);
         }
@@ -250,14 +257,14 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             lds[L::OFF_MAX + 512 + 32 * c + tid] = m;
         }
     };
-    auto do_chunk = [&](int c, auto bufc) {
+    // A chunk is three pieces: its MFMA chain (chunk_mfma: fragments from the LDS buffer, accumulator left in `acc`), its
+    // epilogue (chunk_epi: un-scaling, bias, ReLU, |feat|^2, feat stores, the assignment GEMM's share) and the wait that lets
+    // the next chunk's weights land (chunk_wait).  do_chunk runs them back to back; the staggered schedule below runs the
+    // epilogue of one wave group beside the MFMA chain of the other.
+    f32x16 acc;
+    auto chunk_mfma = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (c > 0) fold_chunk_max(c - 1);
-#ifndef C5_ABL_NODMA
-        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
-#endif
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
-        f32x16 acc;
         if constexpr (!kF16) {
             // scaled split-fp16 form: the accumulator holds the product of the SCALED operands; bias and un-scaling follow
 #pragma unroll
@@ -316,10 +323,14 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
+#ifdef C5_ABL_NOLDSREAD
+                if (s + PF < STEPS) fa[(s + PF) % RING][0] = fa[s % RING][0], fa[(s + PF) % RING][1] = fa[s % RING][1];
+#else
                 if (s + PF < STEPS) {
                     fa[(s + PF) % RING][0] = ldfrag16(w5 + (((s + PF) * FS + 0) * 64 + lane) * 4);
                     if (!kF16) fa[(s + PF) % RING][1] = ldfrag16(w5 + (((s + PF) * FS + 1) * 64 + lane) * 4);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
                 if constexpr (kF16) {
                     acc = mfma_f16(fa[s % RING][0], xf[s], acc);
@@ -334,6 +345,8 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 }
             }
         }
+    };
+    auto chunk_epi = [&](int c) {
         if constexpr (!kF16) {
             // out = acc * (inverse row scale * inverse column scale) + bias
             if constexpr (MODE == MODE_MAX) {
@@ -378,16 +391,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             // f32-equivalent form: feat leaves as f32 in accumulator order ([quad r][lane][4]: 1 KB per wave-instruction;
             // element e of quad r = channel 32c + 8r + 4h + e), and the assignment GEMM takes the accumulators split into
             // bf16 hi + lo against hi + lo cluster weights (three products).
-            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
+            const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
             auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
+#ifndef C5_ABL_NOSTORE
             if (active) {
                 float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
                     st4(fdst + r4 * 256, make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]));
             }
+#endif
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 float v[8];
@@ -397,14 +412,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 split8(v, fh, fl);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+#ifndef C5_ABL_NOASSIGN
                     const bf16x8 wh = wfrag(sp, t, 0), wl = wfrag(sp, t, 1);
                     P[t] = mfma_bf16(wl, fh, P[t]);
                     P[t] = mfma_bf16(wh, fl, P[t]);
                     P[t] = mfma_bf16(wh, fh, P[t]);
+#else
+                    asm volatile("" :: "v"(fh), "v"(fl));
+#endif
                 }
             }
         } else if constexpr (kEpi && MODE == MODE_VLAD) {
-            const float* wc = lds + L::OFF_WC + buf * L::WC_CHUNK;
+            const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
             // The cluster weights are ONE fp16 value each (x 2^8): the soft assignment only enters through a softmax whose
             // logits tolerate a 2^-12 weight rounding -- emulated descriptor effect 5e-9 on top of the 9.4e-7 of the
             // two-product conv5 -- so the lo product of the hi+lo form is not spent here.
@@ -462,13 +481,15 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             }
         }
 
-        // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 2 feat
-        // stores issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of
-        // the grid) and the atomic-max variant drain everything.
+    };
+    // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 2 (4) feat
+    // stores issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of
+    // the grid) and the atomic-max variant drain everything.
+    auto chunk_wait = [&](bool stores_younger_than_dma) {
 #ifdef C5_ABL_NOSTORE
         if (false)
 #else
-        if (MODE == MODE_VLAD && active)
+        if (MODE == MODE_VLAD && active && stores_younger_than_dma)
 #endif
         {
             if constexpr (L::FEAT_STORES == 2)
@@ -478,13 +499,66 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto do_chunk = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (c > 0) fold_chunk_max(c - 1);
+#ifndef C5_ABL_NODMA
+        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+#endif
+        chunk_mfma(c, bufc);
+        chunk_epi(c);
+        chunk_wait(true);
 #ifndef C5_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif
     };
-    for (int c = 0; c < 32; c += 2) {
-        do_chunk(c, std::integral_constant<int, 0>{});
-        do_chunk(c + 1, std::integral_constant<int, 1>{});
+#ifndef C5_STAGGER
+#define C5_STAGGER 1
+#endif
+    constexpr bool kStagger = C5_STAGGER && MODE == MODE_VLAD && !FAST;
+    if constexpr (!kStagger) {
+        for (int c = 0; c < 32; c += 2) {
+            do_chunk(c, std::integral_constant<int, 0>{});
+            do_chunk(c + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        // Staggered schedule (f32-equivalent VLAD form).  The eight waves are two groups, one wave of each per SIMD (waves w and
+        // w + 4 share a SIMD); a chunk interval is two half intervals separated by barriers:
+        //     half 1:  group A runs the MFMA chain of chunk c   |  group B runs the EPILOGUE of chunk c - 1
+        //     half 2:  group A runs the epilogue of chunk c     |  group B runs the MFMA chain of chunk c
+        // so each SIMD always pairs one wave on the matrix pipe with one on the VALU / store side (in lock step both waves
+        // of a SIMD fight for the matrix pipe and then leave it idle together: MFMA busy 0.47).  Chunk c's weight buffer is
+        // read in both halves of interval c and chunk c + 1 lands in the other buffer meanwhile, exactly as before; group
+        // B's late epilogue is why the cluster weights sit in four slots.  Every wave issues its DMA pieces of chunk c + 1 at
+        // the start of interval c -- before its feat stores of that interval, so the counted vmcnt still proves them landed.
+        auto interval = [&](int c, auto bufc) {
+            constexpr int buf = decltype(bufc)::value;
+#ifndef C5_ABL_NODMA
+            if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+#endif
+            if (wave_u < 4) {
+                chunk_mfma(c, bufc);
+                __builtin_amdgcn_s_barrier();
+                chunk_epi(c);
+                chunk_wait(true);
+                __builtin_amdgcn_s_barrier();
+            } else {
+                if (c > 0) chunk_epi(c - 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                chunk_mfma(c, bufc);
+                chunk_wait(c > 0);
+                __builtin_amdgcn_s_barrier();
+            }
+        };
+        for (int c = 0; c < 32; c += 2) {
+            interval(c, std::integral_constant<int, 0>{});
+            interval(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (wave_u >= 4) chunk_epi(31);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // group B's last epilogue reads the cluster weights; the transpose tiles below alias W5 only, but keep the groups together
     }
     if (MODE == MODE_MAX && wg_one_cloud) {
         fold_chunk_max(31);

@@ -78,12 +78,13 @@ __device__ __forceinline__ void topk_insert_key(int (&top)[20], int v) {
         : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
 }
 
-// The same network on the distances themselves: the list holds the 20 SMALLEST d' ascending (min in place, max carried
+// The network on the distances themselves: the list holds the 20 SMALLEST d' ascending (formerly: min in place, max carried
 // on), so the current threshold is top[19] as it stands and no candidate needs an order-preserving integer key (3
 // instructions per candidate of every hit batch).  v_min_f32 / v_max_f32 are single instructions in asm -- the extra
 // canonicalising v_max per slot that made the float form slower belongs to the compiler's fminf / fmaxf, not to the
 // hardware; no NaN can occur, d' = +0 for coincident points (never -0), and a value that is not below top[19] falls through.
 __device__ __forceinline__ void topk_insert_dist(float (&top)[20], float v) {
+#ifdef KNN_MINMAX_NETWORK   // the former 40-instruction form: max carried on, min in place
     float t;
     asm(
         "v_max_f32 %[t], %[k0], %[v]\n\tv_min_f32 %[k0], %[k0], %[v]\n\t"
@@ -107,6 +108,35 @@ __device__ __forceinline__ void topk_insert_dist(float (&top)[20], float v) {
         "v_max_f32 %[t], %[k18], %[v]\n\tv_min_f32 %[k18], %[k18], %[v]\n\t"
         "v_max_f32 %[v], %[k19], %[t]\n\tv_min_f32 %[k19], %[k19], %[t]\n\t"
         : [v] "+v"(v), [t] "=&v"(t), [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19]));
+#else
+    // Sorted insertion is a MEDIAN per slot: new[s] = med3(old[s-1], old[s], v) -- old[s] when v lies above it, old[s-1] when v
+    // lies below that, v itself in between -- and new[0] = min(old[0], v).  Done from the top slot down, in place, each slot
+    // still reads its lower neighbour's OLD value: 20 independent instructions instead of 20 dependent min / max pairs
+    // (v_med3_f32 issues at the rate of v_min_f32).  Same list bit for bit: a median only ever returns one of its operands.
+    asm(
+        "v_med3_f32 %[k19], %[k18], %[k19], %[v]\n\t"
+        "v_med3_f32 %[k18], %[k17], %[k18], %[v]\n\t"
+        "v_med3_f32 %[k17], %[k16], %[k17], %[v]\n\t"
+        "v_med3_f32 %[k16], %[k15], %[k16], %[v]\n\t"
+        "v_med3_f32 %[k15], %[k14], %[k15], %[v]\n\t"
+        "v_med3_f32 %[k14], %[k13], %[k14], %[v]\n\t"
+        "v_med3_f32 %[k13], %[k12], %[k13], %[v]\n\t"
+        "v_med3_f32 %[k12], %[k11], %[k12], %[v]\n\t"
+        "v_med3_f32 %[k11], %[k10], %[k11], %[v]\n\t"
+        "v_med3_f32 %[k10], %[k9], %[k10], %[v]\n\t"
+        "v_med3_f32 %[k9], %[k8], %[k9], %[v]\n\t"
+        "v_med3_f32 %[k8], %[k7], %[k8], %[v]\n\t"
+        "v_med3_f32 %[k7], %[k6], %[k7], %[v]\n\t"
+        "v_med3_f32 %[k6], %[k5], %[k6], %[v]\n\t"
+        "v_med3_f32 %[k5], %[k4], %[k5], %[v]\n\t"
+        "v_med3_f32 %[k4], %[k3], %[k4], %[v]\n\t"
+        "v_med3_f32 %[k3], %[k2], %[k3], %[v]\n\t"
+        "v_med3_f32 %[k2], %[k1], %[k2], %[v]\n\t"
+        "v_med3_f32 %[k1], %[k0], %[k1], %[v]\n\t"
+        "v_min_f32 %[k0], %[k0], %[v]\n\t"
+        : [k0] "+v"(top[0]), [k1] "+v"(top[1]), [k2] "+v"(top[2]), [k3] "+v"(top[3]), [k4] "+v"(top[4]), [k5] "+v"(top[5]), [k6] "+v"(top[6]), [k7] "+v"(top[7]), [k8] "+v"(top[8]), [k9] "+v"(top[9]), [k10] "+v"(top[10]), [k11] "+v"(top[11]), [k12] "+v"(top[12]), [k13] "+v"(top[13]), [k14] "+v"(top[14]), [k15] "+v"(top[15]), [k16] "+v"(top[16]), [k17] "+v"(top[17]), [k18] "+v"(top[18]), [k19] "+v"(top[19])
+        : [v] "v"(v));
+#endif
 }
 
 // wave vote straight from the compare's lane mask (HIP's __any goes through an integer predicate: a v_cndmask and a second
@@ -246,8 +276,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     }
     static_assert(KSEL == 20, "topk_insert_key is written for the 20-slot list");
     float top[KSEL];  // the KSEL smallest d' = -a_ij seen, ascending: top[KSEL-1] is the current threshold
+    // (a lane past the end of the cloud starts from -inf: no bound and no candidate is ever <= its threshold, and a value pushed
+    // through its network leaves the list as it is -- so the scan loops need no `valid` test)
 #pragma unroll
-    for (int s = 0; s < KSEL; ++s) top[s] = INFINITY;
+    for (int s = 0; s < KSEL; ++s) top[s] = valid ? INFINITY : -INFINITY;
 
     auto lower_bound = [&](int c) {
         const float4 lo = bb[2 * c], hi = bb[2 * c + 1];
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #define thr top[KSEL - 1]   // current 20th smallest d'; candidates must be strictly below it
     auto scan1 = [&](int c) {
         KSTAT(0);
-        if (!wave_any(valid && lower_bound(c) <= thr)) return;
+        if (!wave_any(lower_bound(c) <= thr)) return;
         KSTAT(1);
         const float4* tp = cand + c * KNN_CT;
 #pragma unroll
@@ -278,12 +310,22 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
 #pragma unroll
             for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
             float d[KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) d[u] = pos_sq_dist(q[u]);
+            // one compare on the batch's smallest d' (v_min3_f32 in asm: four instructions for eight values, no canonicalising
+            // v_max from fminf) instead of eight compares and eight mask ORs.  Non-strict: a batch without hits holds no
+            // member of any lane's final set.  (Lanes past the cloud's end hold a list of -inf: nothing is ever <= it.)
+#if defined(KNN_BATCH_CMP_EACH) || KNN_BATCH != 8
             bool hit = false;
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) {
-                d[u] = pos_sq_dist(q[u]);
-                hit |= valid && d[u] <= thr;   // non-strict: a batch without hits holds no member of any lane's final set
-            }
+            for (int u = 0; u < KNN_BATCH; ++u) hit |= d[u] <= thr;
+#else
+            float dmin;
+            asm("v_min3_f32 %0, %1, %2, %3\n\tv_min3_f32 %0, %0, %4, %5\n\tv_min3_f32 %0, %0, %6, %7\n\tv_min_f32 %0, %0, %8"
+                : "=&v"(dmin)
+                : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+            const bool hit = dmin <= thr;
+#endif
             if (wave_any(hit)) {
                 KSTAT(2);
                 if (lane == 0) {

@@ -8,7 +8,8 @@ E = bench.pkg("engine")
 dev = torch.device("cuda:0")
 arch = os.environ.get("ARCH", "epc-net")
 store = bench.build_store(arch, dev, 0)
-eng = E.InferenceEngine(arch, bench.PARAMS, store, outer=bench.OUTER, micro_batch=int(os.environ.get("MICRO", os.environ.get("BATCH", "64"))))
+eng = E.InferenceEngine(arch, bench.PARAMS, store, outer=bench.OUTER, micro_batch=int(os.environ.get("MICRO", os.environ.get("BATCH", "64"))),
+                        precision=os.environ.get("PRECISION") or None)
 B = int(os.environ.get("BATCH", "64"))
 xyz = (torch.rand((B, 4096, 3)) * 2 - 1).to(dev)
 for _ in range(5):
