@@ -514,7 +514,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #endif
     };
 #ifndef C5_STAGGER
-#define C5_STAGGER 1
+#define C5_STAGGER 0   // measured (round 2): 0.542 vs 0.511 ms in lock step -- the pairing costs more than it hides; see DESIGN.md
 #endif
     constexpr bool kStagger = C5_STAGGER && MODE == MODE_VLAD && !FAST;
     if constexpr (!kStagger) {
