@@ -48,7 +48,7 @@ __device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_
 template <int CIN, bool F8LO>
 struct C5Lds {  // offsets in floats (4 B)
     static constexpr int W5_CHUNK = F8LO ? 24 * CIN : 32 * CIN;
-    static constexpr int FEAT_STORES = F8LO ? 2 : 4;   // 16-B feat stores per lane per chunk (VLAD mode)
+    static constexpr int FEAT_STORES = F8LO ? 2 : 3;   // 16-B feat stores per lane per chunk (VLAD mode): fp16 / 3-byte values
     static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp6 lo fragments inside a chunk
     static constexpr int LO6_KS = 384;         // floats per k-step of lo fragments (1 KB of 16-B pieces + 512 B of 8-B pieces)
     static constexpr int W5_LOSC = W5_LO8 + (CIN / 64) * LO6_KS;   // the block-scale dwords (one per lane)
@@ -185,35 +185,58 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         }
     } else {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
-        float row_s = 1.0f;
         if constexpr (!kF16) {
-            // pass 1 over the lane's half of the row: its largest magnitude (the other half sits in lane ^ 32); the values
-            // are re-read below (L1 / L2 hits) rather than kept: 128 more registers would not fit
+            // ONE pass over the lane's half of the row: all of it is loaded (32 independent 16-B loads in flight), the largest
+            // magnitude taken (the other half sits in lane ^ 32), and every eight raw values are then split IN PLACE into the
+            // four + four registers of their hi and lo fragments -- the raw row and the fragments never coexist, so the 128
+            // registers are the fragments' own.  (The first form read the row twice: 217 MB more traffic per launch and a second
+            // round of load latency in a prologue nothing overlaps.)
+#ifndef C5_ROW_TWO_PASS
+            float raw[STEPS][8];
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                raw[s][0] = a.x, raw[s][1] = a.y, raw[s][2] = a.z, raw[s][3] = a.w;
+                raw[s][4] = b.x, raw[s][5] = b.y, raw[s][6] = b.z, raw[s][7] = b.w;
+            }
             float m = 0.f;
-#ifdef C5_ABL_NOROWPASS
-            m = 4.0f;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) m = fmaxf(fmaxf(m, fabsf(raw[s][q])), fabsf(raw[s][q + 1]));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float row_s = 1.0f;
+            row_scale_pow2(m, row_s, inv_row);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) split8_f16s(raw[s], row_s, xh[s], xl[s]);
 #else
+            float row_s = 1.0f;
+            float m = 0.f;
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 m = fmaxf(fmaxf(fmaxf(m, fabsf(a.x)), fmaxf(fabsf(a.y), fabsf(a.z))), fmaxf(fmaxf(fabsf(a.w), fabsf(b.x)), fmaxf(fabsf(b.y), fmaxf(fabsf(b.z), fabsf(b.w)))));
             }
-#endif
             m = fmaxf(m, __shfl_xor(m, 32));
             row_scale_pow2(m, row_s, inv_row);
-        }
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            float v[8];
-            const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-            if constexpr (kF16) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) xf[s][q] = (_Float16)v[q];
-            } else {
+            for (int s = 0; s < STEPS; ++s) {
+                float v[8];
+                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
                 split8_f16s(v, row_s, xh[s], xl[s]);
+            }
+#endif
+        } else {
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xf[s][0] = (_Float16)a.x, xf[s][1] = (_Float16)a.y, xf[s][2] = (_Float16)a.z, xf[s][3] = (_Float16)a.w;
+                xf[s][4] = (_Float16)b.x, xf[s][5] = (_Float16)b.y, xf[s][6] = (_Float16)b.z, xf[s][7] = (_Float16)b.w;
             }
         }
         if constexpr (kF16) {
@@ -396,11 +419,25 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
 #ifndef C5_ABL_NOSTORE
+            // feat leaves as 3-BYTE values (the upper 24 bits of the float, rounded: sign, exponent, 15 fraction bits = 16
+            // significant bits).  Its only reader, the aggregate, multiplies by rnorm and splits the product into bf16 hi + lo
+            // -- 16 significant bits as well -- so a fourth byte would be dropped there anyway; without it the round trip that
+            // dominates the step's HBM traffic (conv5 writes, the aggregate reads) is 25 % shorter.  The lane's 16 values
+            // (accumulator order) are 12 dwords = three 16-B stores, 1 KB per wave-instruction: [tile][chunk][piece][lane][16 B].
             if (active) {
-                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 1024 + lane * 4;
+                unsigned int w[12];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    st4(fdst + r4 * 256, make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]));
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned int a = __float_as_uint(acc[4 * g]) + 0x80u, b = __float_as_uint(acc[4 * g + 1]) + 0x80u;
+                    const unsigned int cc = __float_as_uint(acc[4 * g + 2]) + 0x80u, d = __float_as_uint(acc[4 * g + 3]) + 0x80u;
+                    w[3 * g] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
+                    w[3 * g + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
+                    w[3 * g + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
+                }
+                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 768 + lane * 4;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<u32x4*>(fdst + p * 256) = u32x4{w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]};
             }
 #endif
 #pragma unroll
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             if constexpr (L::FEAT_STORES == 2)
                 asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -692,13 +729,13 @@ extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, cons
 }
 
 extern "C" int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
-                                        float* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
+                                        void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
                                         void* stream) {
     EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    return launch_conv5<256, MODE_VLAD, false, false>(cat, (const float*)packed_conv5, num_points_total, 32, feat_frag,
+    return launch_conv5<256, MODE_VLAD, false, false>(cat, (const float*)packed_conv5, num_points_total, 32, (float*)feat_frag,
                                                       rnorm, assign, (float*)assign_frag, apart, nullptr, nullptr,
                                                       (hipStream_t)stream, __func__);
 }
@@ -918,7 +955,7 @@ extern "C" int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// EPC_PRECISION_F32 form of the aggregate: feat arrives as f32 (accumulator order, epc_conv5_assign_f32_fwd), the
+// EPC_PRECISION_F32 form of the aggregate: feat arrives as 3-byte values (accumulator order, epc_conv5_assign_f32_fwd), the
 // assignments as bf16 hi + lo B fragments.  (feat * rnorm) is split into bf16 hi + lo per lane, both halves go through
 // their own [point][channel] LDS image and come back as A fragments via the transposing read; three products per
 // k-step (lo*hi + hi*lo + hi*hi, f32 accumulate).  Same workgroup geometry, epilogue and outputs as the fp16 form; it
@@ -969,18 +1006,18 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 
     struct Tile {
-        u32x4 raw[AGG_FT][4];  // [chunk][quad r]: f32 values of channels 8r + 4h + 0..3 of point j
+        u32x4 raw[AGG_FT][3];  // [chunk][piece]: the lane's 16 three-byte values of a chunk (value 4r + e = channel 8r + 4h + e of point j)
         u32x4 bfr[2][2][2];    // [cluster tile][k-step][hi, lo]
         float rn;
     };
     auto load = [&](Tile& t, int tt) {
-        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 1024 + lane * 4;
+        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4;
         const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 1024 + q * 256));
+            for (int q = 0; q < 3; ++q)
+                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 768 + q * 256));
         t.rn = rnorm[(gt0 + tt) * 32 + j];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -1009,9 +1046,14 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 unsigned short hb[4], lb[4];
+                // dwords 3r .. 3r + 2 of the lane's twelve hold values 4r .. 4r + 3 (conv5's packing)
+                const unsigned int w0 = t.raw[c][(3 * r4) >> 2][(3 * r4) & 3], w1 = t.raw[c][(3 * r4 + 1) >> 2][(3 * r4 + 1) & 3],
+                                   w2 = t.raw[c][(3 * r4 + 2) >> 2][(3 * r4 + 2) & 3];
+                const unsigned int fv[4] = {w0 << 8, __builtin_amdgcn_perm(w1, w0, 0x0504030cu),
+                                            __builtin_amdgcn_perm(w2, w1, 0x0403020cu), w2 & 0xffffff00u};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = __uint_as_float(t.raw[c][r4][e]) * t.rn;
+                    const float y = __uint_as_float(fv[e]) * t.rn;
                     const __bf16 yh = (__bf16)y;
                     const __bf16 yl = (__bf16)(y - (float)yh);
                     hb[e] = __builtin_bit_cast(unsigned short, yh);
@@ -1082,7 +1124,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     }
 }
 
-extern "C" int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* assign_frag, const float* rnorm,
+extern "C" int epc_vlad_aggregate_f32_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm,
                                           const float* apart, const float* centres, int num_clouds, int n, float* V,
                                           float* colss, void* stream) {
     EPC_CHECK_ARG(feat_frag && assign_frag && rnorm && apart && centres && V && colss, "null pointer");
@@ -1097,7 +1139,8 @@ extern "C" int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* as
         return EPC_EHIP;
     }
     hipLaunchKernelGGL(vlad_aggregate_f32_kernel, dim3(32 * ((num_clouds + 7) / 8)), dim3(AGG_THREADS), lds_bytes,
-                       (hipStream_t)stream, feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, num_clouds, V, colss);
+                       (hipStream_t)stream, (const float*)feat_frag, (const float*)assign_frag, rnorm, apart, centres, n, num_clouds, V,
+                       colss);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -46,7 +46,7 @@ static WsLayout ws_layout(const epc_cfg* c, int mb) {
     }
     w.feat = w.rnorm = w.assign = w.afrag = w.vlad = w.colss = w.apart = w.head = w.pooled = 0;
     if (c->arch == EPC_ARCH_EPC_NET) {
-        w.feat = take(M * 1024 * (fast ? 2 : 4));   // fp16 / f32 fragments
+        w.feat = take(M * 1024 * (fast ? 2 : 3));   // fp16 / 3-byte fragments
         w.rnorm = take(M * 4);
         w.afrag = take(M * 64 * (fast ? 2 : 4));    // fp16 / bf16 hi + lo fragments
         w.vlad = take((size_t)mb * 65536 * 4);

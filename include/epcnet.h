@@ -217,13 +217,15 @@ int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* pac
                          void* stream);
 
 /* The same stage in EPC_PRECISION_F32 (weights packed for that precision): cat (M, 256) f32 ->
- *   feat_frag   (M/32, 32 chunks, 4 quads r, 64 lanes, 4 f32): the un-normalised conv5 output in f32, accumulator
- *               order: lane l of (tile g, chunk c, quad r) holds point 32g + (l&31), element e = channel
- *               32c + 8r + 4(l>>5) + e;
+ *   feat_frag   (M/32, 32 chunks, 3 pieces, 64 lanes, 16 bytes): the un-normalised conv5 output as 3-BYTE values -- the upper
+ *               24 bits of the float32 (sign, exponent, 15 fraction bits), rounded to nearest: the 16 significant bits the
+ *               aggregate's bf16 hi + lo split keeps.  Accumulator order: the 48 bytes of lane l of (tile g, chunk c), pieces
+ *               concatenated, are 16 values, little-endian, value 4r + e = point 32g + (l&31), channel 32c + 8r + 4(l>>5) + e.
+ *               3 KB per point (M * 3072 bytes);
  *   rnorm, assign, apart as above;
  *   assign_frag (M/32, 2 cluster tiles t, 2 k-steps s, 2 parts (hi, lo), 64 lanes, 8 bf16): assign split as
  *               hi = bf16(a), lo = bf16(a - hi), B fragments (lane l: cluster 32t + (l&31), points 32g + 16s + 8(l>>5) + 0..7). */
-int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, float* feat_frag,
+int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total, void* feat_frag,
                              float* rnorm, float* assign, void* assign_frag, float* apart, void* stream);
 
 /* loupe.py:276-292: V[f][k] = sum_n (feat[n][f]*rnorm[n]) * assign[n][k] - a_sum[k] * centres[f][k] from the
@@ -235,7 +237,7 @@ int epc_vlad_aggregate_fwd(const void* feat_frag, const void* assign_frag, const
                            const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
 /* EPC_PRECISION_F32 form: operands in the layouts of epc_conv5_assign_f32_fwd; (feat * rnorm) is split into bf16 hi + lo
  * and multiplied with the hi + lo assignments in three products (f32-equivalent). */
-int epc_vlad_aggregate_f32_fwd(const float* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
+int epc_vlad_aggregate_f32_fwd(const void* feat_frag, const void* assign_frag, const float* rnorm, const float* apart,
                                const float* centres, int num_clouds, int n, float* V, float* colss, void* stream);
 
 /* loupe.py:295-331 + models/epc-net.py:153: intra-normalisation, flatten + L2, grouped hidden projection with the

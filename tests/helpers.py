@@ -103,15 +103,18 @@ def run_stages(eng, xyz):
             af = assignf.float().reshape(M // 32, 2, 2, 2, 32, 8) / 16384.0
             aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)   # assign * rnorm
         else:
-            featf = torch.empty((M // 32, 32, 4, 64, 4), dtype=torch.float32, device=dev)
+            featf = torch.empty((M // 32, 32, 3, 64, 16), dtype=torch.uint8, device=dev)
             assignf = torch.empty((M // 32, 2, 2, 2, 64, 8), dtype=torch.bfloat16, device=dev)
             L.check(lib.epc_conv5_assign_f32_fwd(cat.data_ptr(), ccat, off(5), M, featf.data_ptr(), rnorm.data_ptr(),
                                                  assign.data_ptr(), assignf.data_ptr(), apart.data_ptr(), st))
             L.check(lib.epc_vlad_aggregate_f32_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(),
                                                    apart.data_ptr(), off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
-            # [tile g][chunk c][quad r][lane l][e] -> feat[32g + (l&31)][32c + 8r + 4(l>>5) + e]
-            ff = featf.reshape(M // 32, 32, 4, 2, 32, 4)                   # (g, c, r, h, j, e)
-            feat = ff.permute(0, 4, 1, 2, 3, 5).reshape(nc, n, 1024)       # (g, j, c, r, h, e)
+            # 3-byte values (include/epcnet.h): the 48 bytes of lane l of (tile g, chunk c) -- its three 16-byte pieces
+            # concatenated -- are 16 little-endian values, value 4r + e -> feat[32g + (l&31)][32c + 8r + 4(l>>5) + e]
+            by = featf.permute(0, 1, 3, 2, 4).reshape(M // 32, 32, 64, 16, 3).to(torch.int32)       # (g, c, l, value, byte)
+            bits = (by[..., 0] << 8) | (by[..., 1] << 16) | (by[..., 2] << 24)
+            ff = bits.view(torch.float32).reshape(M // 32, 32, 2, 32, 4, 4)                           # (g, c, h, j, r, e)
+            feat = ff.permute(0, 3, 1, 4, 2, 5).reshape(nc, n, 1024)                                  # (g, j, c, r, h, e)
             # [tile g][t][s][part][lane l][q] -> a[32g + 16s + 8(l>>5) + q][32t + (l&31)], hi + lo
             af = assignf.float().sum(3).reshape(M // 32, 2, 2, 2, 32, 8)   # (g, t, s, h, j, q)
             aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)
