@@ -897,6 +897,247 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* me
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// Backward of a 64 -> 64 layer + training-mode BatchNorm (+ReLU) in ONE pass over its rows (utils/tf_util.py:94-106 seen
+// from the gradient side).  The thin layers of the backbone (conv*_a, conv*_b, conv2..4: 11 of them) each took four launches
+// -- BatchNorm sums, dz, dX = dz W^T, dW = x^T dz -- that are bound by launch structure, not by bytes (a read + write of one
+// (rows, 64) tensor takes 5 us on this device; the four launches took ~80).  After the column sums (dbeta, dgamma: they need
+// every row) one kernel does the rest: a wave takes 32 rows at a time and
+//   * forms dz = gamma rstd (dy [z-mask] - dbeta/rows - zhat dgamma/rows) in registers, in the row layout (lane = row, eight
+//     consecutive channels per k-step) -- which IS the B operand of dx^T = W dz^T: dx leaves as whole float4s per lane;
+//   * forms dz again in the column layout (lane = channel, eight consecutive ROWS per k-step: eight coalesced dword loads) next to
+//     x in the same layout: the operands of dW = x^T dz with the rows as K.  dz is never written;
+//   * keeps its 64 x 64 dW partial in registers over its rows; the four waves meet in LDS (fixed order) and the workgroup
+//     stores ONE partial.  partial_sum_kernel adds the partials in ascending order: dW is the same bits on every run.
+// GEMM arithmetic: two bf16 pieces per operand, three products (that of epc_gemm_f32_fast, the other backward GEMMs).
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef LB_TILES_PER_WAVE
+#define LB_TILES_PER_WAVE 2
+#endif
+#define LB_ROWS_PER_WG (4 * 32 * LB_TILES_PER_WAVE)
+
+__global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ W,
+    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float eps,
+    float inv_rows, int relu, int rows, float* __restrict__ dx, float* __restrict__ dWpart) {
+    __shared__ __attribute__((aligned(16))) float coef[6][64];          // s, t (mask), mean, k1, dbeta/rows, rstd dgamma/rows
+    __shared__ u32x4 Wf[2][4][2][64];                                    // W as A fragments: [in tile][k-step][hi, lo][lane]
+    __shared__ __attribute__((aligned(16))) float red[2][4][16][64];     // parked dW partials: [slot][tile][register][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    if (tid < 64) {
+        const float mu = mean[tid], rs = 1.0f / sqrtf(var[tid] + eps), ga = gamma[tid];
+        const BnAffine a = bn_affine(mu, var[tid], ga, beta[tid], eps);
+        coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mu;
+        coef[3][tid] = ga * rs, coef[4][tid] = dbeta[tid] * inv_rows, coef[5][tid] = rs * (dgamma[tid] * inv_rows);
+    }
+    // W (in, out) row-major: A[m = in][k = out]; lane (m = 32 mt + i, k group h) of k-step s holds W[m][16 s + 8 h .. + 7]
+    for (int f = tid; f < 2 * 4 * 64; f += 256) {
+        const int l = f & 63, s4 = (f >> 6) & 3, mt = f >> 8;
+        const float* src = W + (size_t)(32 * mt + (l & 31)) * 64 + 16 * s4 + 8 * (l >> 5);
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8 ph, pl;
+        split8(v, ph, pl);
+        Wf[mt][s4][0][l] = __builtin_bit_cast(u32x4, ph);
+        Wf[mt][s4][1][l] = __builtin_bit_cast(u32x4, pl);
+    }
+    __syncthreads();
+
+    f32x16 accW[2][2];   // [in tile mt][out tile nt]: register 4g + e = in channel 32 mt + 8 g + 4 h + e, lane = out channel 32 nt + i
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[mt][nt][r] = 0.f;
+
+    auto dz_of = [&](float dyv, float zv, float cs, float ct, float mu, float k1, float bb, float gg) {
+        const float d = (relu && !(zv * cs + ct > 0.f)) ? 0.f : dyv;   // the forward's own expression (bn_value)
+        return k1 * (d - bb - (zv - mu) * gg);
+    };
+
+    for (int t = 0; t < LB_TILES_PER_WAVE; ++t) {
+        const int base = blockIdx.x * LB_ROWS_PER_WG + (wave * LB_TILES_PER_WAVE + t) * 32;   // wave-uniform
+        if (base >= rows) break;
+        // ---- row layout: dz as B fragments (n = row base + i, k = out channel), dx^T = W dz^T ----
+        if (dx) {
+            const int row = base + i;
+            const bool ok = row < rows;
+            const size_t o = (size_t)(ok ? row : 0) * 64 + 8 * h;
+            bf16x8 zh[4], zl[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float4 g0 = *reinterpret_cast<const float4*>(dy + o + 16 * s4), g1 = *reinterpret_cast<const float4*>(dy + o + 16 * s4 + 4);
+                const float4 z0 = *reinterpret_cast<const float4*>(z + o + 16 * s4), z1 = *reinterpret_cast<const float4*>(z + o + 16 * s4 + 4);
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float zv[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+                float dzv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c = 16 * s4 + 8 * h + q;
+                    const float v = dz_of(gv[q], zv[q], coef[0][c], coef[1][c], coef[2][c], coef[3][c], coef[4][c], coef[5][c]);
+                    dzv[q] = ok ? v : 0.f;
+                }
+                split8(dzv, zh[s4], zl[s4]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, Wf[mt][s4][0][lane]), wl = __builtin_bit_cast(bf16x8, Wf[mt][s4][1][lane]);
+                    acc = mfma_bf16(wl, zh[s4], acc);
+                    acc = mfma_bf16(wh, zl[s4], acc);
+                    acc = mfma_bf16(wh, zh[s4], acc);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(dx + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h) =
+                            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                }
+            }
+        }
+        // ---- column layout: lane = channel, k = rows base + 16 s + 8 h + q;  dW += x^T dz ----
+        bf16x8 xh[2][2], xl[2][2];   // [in tile][k-step]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = base + 16 * s2 + 8 * h + q;
+                    v[q] = r < rows ? x[(size_t)r * 64 + 32 * mt + i] : 0.f;
+                }
+                split8(v, xh[mt][s2], xl[mt][s2]);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = 32 * nt + i;
+            const float cs = coef[0][c], ct = coef[1][c], mu = coef[2][c], k1 = coef[3][c], bb = coef[4][c], gg = coef[5][c];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = base + 16 * s2 + 8 * h + q;
+                    const bool ok = r < rows;
+                    const size_t o = (size_t)(ok ? r : 0) * 64 + c;
+                    const float d = dz_of(dy[o], z[o], cs, ct, mu, k1, bb, gg);
+                    v[q] = ok ? d : 0.f;
+                }
+                bf16x8 dh, dl;
+                split8(v, dh, dl);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    accW[mt][nt] = mfma_bf16(xl[mt][s2], dh, accW[mt][nt]);
+                    accW[mt][nt] = mfma_bf16(xh[mt][s2], dl, accW[mt][nt]);
+                    accW[mt][nt] = mfma_bf16(xh[mt][s2], dh, accW[mt][nt]);
+                }
+            }
+        }
+    }
+    // ---- the four waves' partials meet pairwise, ((w0 + w1) + (w2 + w3)): a fixed order; wave 0 stores the workgroup's ----
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[slot][mt * 2 + nt][r][lane] = accW[mt][nt][r];
+    };
+    auto take = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[mt][nt][r] += red[slot][mt * 2 + nt][r][lane];
+    };
+    if (wave & 1) park(wave >> 1);
+    __syncthreads();
+    if (!(wave & 1)) take(wave >> 1);
+    __syncthreads();
+    if (wave == 2) park(0);
+    __syncthreads();
+    if (wave == 0) {
+        take(0);
+        float* out = dWpart + (size_t)blockIdx.x * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(32 * mt + mfma_row(r, h)) * 64 + 32 * nt + i] = accW[mt][nt][r];
+    }
+}
+
+// out[e] = sum over p < P of part[p][e], added in ascending p whatever the launch geometry (16 groups of a workgroup take
+// every 16th partial each, their sums meet in LDS in group order: a fixed tree): the ordered counterpart of an atomic
+// reduction.  E is a multiple of 4; one float4 column per (lane, group).
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ part, int P, int E,
+                                                          float* __restrict__ out) {
+    __shared__ float4 acc[16][16];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e4 = blockIdx.x * 16 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 * 4 < E) {
+        const float4* src = reinterpret_cast<const float4*>(part) + e4;
+        const size_t stride = (size_t)E / 4;
+        int p = grp;
+        for (; p + 48 < P; p += 64) {
+            const float4 a = src[(size_t)p * stride], b = src[(size_t)(p + 16) * stride], c = src[(size_t)(p + 32) * stride],
+                         d = src[(size_t)(p + 48) * stride];
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            s.x += b.x, s.y += b.y, s.z += b.z, s.w += b.w;
+            s.x += c.x, s.y += c.y, s.z += c.z, s.w += c.w;
+            s.x += d.x, s.y += d.y, s.z += d.z, s.w += d.w;
+        }
+        for (; p < P; p += 16) {
+            const float4 a = src[(size_t)p * stride];
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+        }
+    }
+    acc[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && e4 * 4 < E) {
+        float4 t = acc[0][col];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t.x += acc[g][col].x, t.y += acc[g][col].y, t.z += acc[g][col].z, t.w += acc[g][col].w;
+        reinterpret_cast<float4*>(out)[e4] = t;
+    }
+}
+
+extern "C" size_t epc_linear_bn_bwd64_partial_floats(int rows) {
+    return rows > 0 ? (size_t)((rows + LB_ROWS_PER_WG - 1) / LB_ROWS_PER_WG) * 4096 : 0;
+}
+
+extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float* x, const float* W, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, float eps, int relu, int rows,
+                                   float* dx, float* dW, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                   float* dw_partials, size_t dw_partial_floats, void* stream) {
+    EPC_CHECK_ARG(dy && z && x && W && mean && var && gamma && beta && dW && dgamma && dbeta && dw_partials, "null pointer");
+    if (int rc = colreduce_check("epc_linear_bn_bwd64: workspace too small", rows, 64, workspace, workspace_bytes)) return rc;
+    EPC_CHECK_ARG(dw_partial_floats >= epc_linear_bn_bwd64_partial_floats(rows), "dW partial buffer too small (epc_linear_bn_bwd64_partial_floats)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    unsigned int* counters = (unsigned int*)workspace;
+    float* part = (float*)(counters + CR_COUNTERS);
+    hipLaunchKernelGGL(colreduce_kernel<2>, dim3(nb, 1), dim3(256), 0, st, z, dy, mean, var, gamma, beta, eps, relu, rows, 64, 1.0f,
+                       part, counters, dbeta, dgamma);
+    const int wgs = (rows + LB_ROWS_PER_WG - 1) / LB_ROWS_PER_WG;
+    hipLaunchKernelGGL(linear_bn_bwd64_kernel, dim3(wgs), dim3(256), 0, st, dy, z, x, W, mean, var, gamma, beta, dbeta, dgamma, eps,
+                       1.0f / rows, relu, rows, dx, dw_partials);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(4096 / 4 / 16), dim3(256), 0, st, dw_partials, wgs, 4096, dW);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Neighbour mean over the kNN index lists (64 channels): forward gather, backward scatter (f32 atomics).
 // Rows with more than `cap` selected entries take the exact scan (same rule as the fused block kernel).
 // ----------------------------------------------------------------------------------------------------------------

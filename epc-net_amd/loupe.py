@@ -118,15 +118,24 @@ class _VladBase(PoolingBaseModel):
         if C != 64:
             raise NotImplementedError("cluster_size must be 64 (configs/*.yaml CLUSTER_SIZE)")
         x = reshaped_input.reshape(-1, F)
-        if self.add_batch_norm:
-            activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255
-            activation = _slim_batch_norm(activation, "cluster_bn", self.is_training, fused=False)   # :257-263
+        if self.add_batch_norm and self.is_training:
+            # :255-263, :272-274, :286-291 as one autograd node (the two gradients of x are one product: ops.VladAssignAggregate)
+            from .utils.tf_util import _ema_update
+            beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)
+            vlad, activation, mean, var = ops.VladAssignAggregate.apply(x, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N)
+            _ema_update(mm, mean, SLIM_DECAY, scheduled=False)
+            _ema_update(mv, var, SLIM_DECAY, scheduled=False)          # (the unfused slim op: population variance)
+            a_sum = activation.sum(dim=-2, keepdim=True)                                         # :276
         else:
-            activation = ops.Linear.apply(x, st[scoped("cluster_weights")], st[scoped("cluster_biases")])   # :264-270
-        activation = ops.Softmax64.apply(activation)                                             # :272
-        activation = activation.reshape(-1, N, C)                                                # :274
-        a_sum = activation.sum(dim=-2, keepdim=True)                                             # :276
-        vlad = ops.VladAggregate.apply(x.reshape(-1, N, F), activation)                          # :286-291 (B,F,C)
+            if self.add_batch_norm:
+                activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255
+                activation = _slim_batch_norm(activation, "cluster_bn", self.is_training, fused=False)   # :257-263
+            else:
+                activation = ops.Linear.apply(x, st[scoped("cluster_weights")], st[scoped("cluster_biases")])   # :264-270
+            activation = ops.Softmax64.apply(activation)                                             # :272
+            activation = activation.reshape(-1, N, C)                                                # :274
+            a_sum = activation.sum(dim=-2, keepdim=True)                                             # :276
+            vlad = ops.VladAggregate.apply(x.reshape(-1, N, F), activation)                          # :286-291 (B,F,C)
         # a = a_sum * cluster_weights2 (:284); vlad - a (:292); l2_normalize over F (:295); flatten, l2_normalize (:297-298)
         vlad = ops.VladNormalize.apply(vlad, a_sum, st[scoped("cluster_weights2")])
         vlad = vlad.reshape(-1, C * F)

@@ -300,6 +300,19 @@ int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, i
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
+/* Backward of a 64 -> 64 layer followed by a training-mode BatchNorm (+ReLU) (utils/tf_util.py:94-106 from the gradient side:
+ * the thin layers conv*_a / conv*_b / conv2..4 of models/epc-net.py:66-132) in three launches instead of four GEMM-sized ones:
+ * the BatchNorm column sums (dbeta, dgamma), ONE pass over the rows that forms dz in registers and produces dx = dz W^T
+ * (dx may be NULL) and the per-workgroup partials of dW = x^T dz (dz is never written), and an ORDERED sum of the partials:
+ * dW is the same bits on every run.  dy, z, x: (rows, 64) row-major; W: (64 in, 64 out); `workspace`: the column-reduction
+ * workspace (epc_colreduce_workspace_bytes(rows, 64), zero counters: workspace contract above); `dw_partials`:
+ * epc_linear_bn_bwd64_partial_floats(rows) floats of scratch.  Two bf16 pieces per operand (epc_gemm_f32_fast's arithmetic). */
+size_t epc_linear_bn_bwd64_partial_floats(int rows);
+int epc_linear_bn_bwd64(const float* dy, const float* z, const float* x, const float* W, const float* mean, const float* var,
+                        const float* gamma, const float* beta, float eps, int relu, int rows, float* dx, float* dW,
+                        float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, float* dw_partials,
+                        size_t dw_partial_floats, void* stream);
+
 /* Split-K WITHOUT atomics (the forward products of the training step: the same bits on every run).  Every K slice stores its
  * partial product in `workspace` (batch * splitk * M * N floats) and a second launch adds the slices in ascending order (+ bias,
  * + C when accumulate).  pieces: 3 = the arithmetic of epc_gemm_f32, 2 = epc_gemm_f32_fast, 1 = epc_gemm_bf16.  N, ldc and bC

@@ -47,6 +47,50 @@ def test_linear(dev, rows, cin, cout):
     run_pair(lambda x, W, b: ops.Linear.apply(x, W, b), lambda x, W, b: x @ W + b, [x, W, b], dev)
 
 
+@pytest.mark.parametrize("rows,cin,cout,relu,need_dx", [(4096, 64, 64, 1, True), (1000, 64, 64, 0, True), (333, 64, 64, 1, True),
+                                                         (8192, 64, 64, 1, False), (2048, 256, 1024, 1, True),
+                                                         (600, 64, 128, 1, True)])
+def test_linear_batch_norm_train_node(dev, rows, cin, cout, relu, need_dx):
+    """ops.LinearBatchNormTrain (utils/tf_util.py:94-106 in training mode as ONE autograd node; 64 -> 64 layers take the fused
+    backward epc_linear_bn_bwd64, the others the operator chain) against float64: output, batch moments, and the gradients of
+    x, W, gamma, beta -- twice, bit-identical for the 64 -> 64 case (its dW partials are added in a fixed order)."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(rows, cin, dtype=torch.float64, generator=g)
+    W = torch.randn(cin, cout, dtype=torch.float64, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, dtype=torch.float64, generator=g)
+    gamma = torch.rand(cout, dtype=torch.float64, generator=g) + 0.5
+    beta = torch.randn(cout, dtype=torch.float64, generator=g) * 0.3
+    up = torch.randn(rows, cout, dtype=torch.float64, generator=g)
+
+    def ref(x, W, gamma, beta):
+        z = x @ W + b
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        y = gamma * (z - mean) / torch.sqrt(var + 1e-3) + beta
+        return (torch.relu(y) if relu else y), mean, var
+
+    r_in = [t.clone().requires_grad_(True) for t in (x, W, gamma, beta)]
+    yr, mr, vr = ref(*r_in)
+    (yr * up).sum().backward()
+    runs = []
+    for _ in range(2):
+        xg = x.float().to(dev).requires_grad_(need_dx)
+        g_in = [xg] + [t.float().to(dev).requires_grad_(True) for t in (W, gamma, beta)]
+        y, mean, var = ops.LinearBatchNormTrain.apply(g_in[0], g_in[1], b.float().to(dev), g_in[2], g_in[3], 1e-3, relu, False)
+        (y * up.float().to(dev)).sum().backward()
+        runs.append((y.detach(), [t.grad for t in g_in]))
+        assert rel(y, yr) <= 2e-5 and rel(mean, mr) <= 2e-5 and rel(var, vr) <= 2e-5
+        for name, a, r in zip(("x", "W", "gamma", "beta"), g_in, r_in):
+            if name == "x" and not need_dx:
+                assert a.grad is None
+                continue
+            assert rel(a.grad, r.grad) <= 1e-4, "grad of %s: %.3e" % (name, rel(a.grad, r.grad))
+    if cin == 64 and cout == 64:
+        assert torch.equal(runs[0][0], runs[1][0])
+        for a, bb in zip(runs[0][1], runs[1][1]):
+            assert (a is None and bb is None) or torch.equal(a, bb)
+
+
 @pytest.mark.parametrize("rows,C,relu", [(8192, 64, 1), (5000, 1024, 1), (72, 256, 0), (18, 256, 0), (4096, 64, 0)])
 def test_batch_norm_train(dev, rows, C, relu):
     ops = H.pkg("ops")
