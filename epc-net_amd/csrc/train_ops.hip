@@ -174,7 +174,11 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
     }
 }
 
-template <int WM, int WN, int PIECES>
+// SWAP: the MFMA operands trade places (D' = B^T A^T), so a lane holds ONE row of C and four consecutive columns per register
+// quad: the epilogue is float4 stores -- a quarter of the store instructions of the lane = column layout, whose 64 dword stores
+// per wave made the wide-output products (conv5 forward, the VLAD feature gradient: 302 MB written) store-issue-bound.  Used for
+// plain outputs (no statistics epilogue, which wants a column per lane; no split-K; N, ldc multiples of 4).
+template <int WM, int WN, int PIECES, bool SWAP = false>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ u32x4 As[2 * WM][2][PIECES][64];  // 4 KB per WM per piece
@@ -228,16 +232,17 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
                 for (int cb = 0; cb < WN; ++cb) {
                     f32x16 c = acc[rb][cb];
+                    auto mm = [&](int pa, int pb) { c = SWAP ? mfma_bf16(b[cb][pb], a[rb][pa], c) : mfma_bf16(a[rb][pa], b[cb][pb], c); };
                     if constexpr (PIECES == 3) {
-                        c = mfma_bf16(a[rb][2], b[cb][0], c);
-                        c = mfma_bf16(a[rb][0], b[cb][2], c);
-                        c = mfma_bf16(a[rb][1], b[cb][1], c);
+                        mm(2, 0);
+                        mm(0, 2);
+                        mm(1, 1);
                     }
                     if constexpr (PIECES >= 2) {
-                        c = mfma_bf16(a[rb][1], b[cb][0], c);
-                        c = mfma_bf16(a[rb][0], b[cb][1], c);
+                        mm(1, 0);
+                        mm(0, 1);
                     }
-                    c = mfma_bf16(a[rb][0], b[cb][0], c);
+                    mm(0, 0);
                     acc[rb][cb] = c;
                 }
         }
@@ -280,6 +285,63 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
             }
         }
     }
+    // With the statistics epilogue the lane = column layout stays (column sums are in-lane), but its plain stores -- 16 dword
+    // store instructions per 32 x 32 tile -- go through a per-wave LDS tile (the operand buffers are free now) and leave as
+    // float4 rows: 4 store instructions per tile, each writing eight whole 128-B rows.
+    if constexpr (!SWAP && WM == 2 && PIECES == 3) {
+        if (g.stats && g.N % 4 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<size_t>(C) & 15) == 0 &&
+            (!g.bias || (reinterpret_cast<size_t>(g.bias) & 15) == 0)) {
+            float* stg = reinterpret_cast<float*>(&As[0][0][0][0]) + wave * (32 * 36);   // 4 x 4.6 KB of the 24-KB A buffer
+#pragma unroll
+            for (int rb = 0; rb < WM; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < WN; ++cb) {
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stg[mfma_row(r, h) * 36 + i] = acc[rb][cb][r];
+                    __syncthreads();
+                    const int col = n0 + 32 * WN * wn + 32 * cb + 4 * (lane & 7);
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.bias && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rl = (lane >> 3) + 8 * it, row = m0 + 32 * WM * wm + 32 * rb + rl;
+                        if (row < g.M && col < g.N) {
+                            float4 v = *reinterpret_cast<const float4*>(stg + rl * 36 + 4 * (lane & 7));
+                            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                            *reinterpret_cast<float4*>(C + (size_t)row * g.ldc + col) = v;
+                        }
+                    }
+                }
+            return;
+        }
+    }
+    if constexpr (SWAP) {   // register 4g + e of (rb, cb) = C[m0 + .. + 32 rb + i][n0 + .. + 32 cb + 8g + 4h + e]
+#pragma unroll
+        for (int rb = 0; rb < WM; ++rb) {
+            const int row = m0 + 32 * WM * wm + 32 * rb + i;
+            if (row >= g.M) continue;
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = n0 + 32 * WN * wn + 32 * cb + 8 * q + 4 * h;
+                    if (col >= g.N) continue;
+                    float4 v = make_float4(acc[rb][cb][4 * q], acc[rb][cb][4 * q + 1], acc[rb][cb][4 * q + 2], acc[rb][cb][4 * q + 3]);
+                    if (g.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    }
+                    float4* p = reinterpret_cast<float4*>(C + (size_t)row * g.ldc + col);
+                    if (g.accumulate) {
+                        const float4 o = *p;
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    *p = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int cb = 0; cb < WN; ++cb) {
         const int col = n0 + 32 * WN * wn + 32 * cb + i;
@@ -307,6 +369,21 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 template <int WM, int WN>
 static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStream_t st) {
     dim3 grid((g.N + 64 * WN - 1) / (64 * WN), (g.M + 64 * WM - 1) / (64 * WM), batch * g.splitk);
+#ifndef EPC_GEMM_NO_SWAP
+    const bool swap = !g.stats && !g.partial && g.splitk == 1 && g.N % 4 == 0 && g.ldc % 4 == 0 && g.bC % 4 == 0 &&
+                      (reinterpret_cast<size_t>(g.C) & 15) == 0 && (!g.bias || (reinterpret_cast<size_t>(g.bias) & 15) == 0);
+#else
+    const bool swap = false;
+#endif
+    if (swap) {
+        if (pieces == 1)
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1, true>), grid, dim3(256), 0, st, g);
+        else if (pieces == 2)
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 2, true>), grid, dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3, true>), grid, dim3(256), 0, st, g);
+        return;
+    }
     if (pieces == 1)
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1>), grid, dim3(256), 0, st, g);
     else if (pieces == 2)
