@@ -12,6 +12,7 @@
 //   epc_adam_step           tf.train.AdamOptimizer update (train.py:273), one fused pass per tensor
 //
 // Arithmetic is plain f32 throughout (the reference trains in fp32).
+#include <type_traits>
 #include "common.h"
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -178,7 +179,7 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
 // quad: the epilogue is float4 stores -- a quarter of the store instructions of the lane = column layout, whose 64 dword stores
 // per wave made the wide-output products (conv5 forward, the VLAD feature gradient: 302 MB written) store-issue-bound.  Used for
 // plain outputs (no statistics epilogue, which wants a column per lane; no split-K; N, ldc multiples of 4).
-template <int WM, int WN, int PIECES, bool SWAP = false>
+template <int WM, int WN, int PIECES, bool SWAP = false, int G_PF = 1>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ u32x4 As[2 * WM][2][PIECES][64];  // 4 KB per WM per piece
@@ -204,18 +205,26 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 
-    float va[WM][8], vb[WN][8];  // the next k-tile's operand values (2*WM*128/256 = WM lane-fragments per thread)
-    if (k0 < k1) {
-        fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, k0, k1, va, tid);
-        fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0, k1, vb, tid);
-    }
-    for (int kt = k0; kt < k1; kt += S_BK) {
-        store_fragments<2 * WM, PIECES>(va, a_kc, As, tid);
-        store_fragments<2 * WN, PIECES>(vb, b_kc, Bs, tid);
+    // operand values of the next G_PF k-tiles, in registers (WM + WN lane-fragments per thread and tile): a tile's global loads
+    // are issued G_PF iterations before store_fragments() consumes them.  One tile ahead leaves a load one MFMA phase
+    // (768 cycles with three products) to land and every iteration then waits out the rest of the memory latency -- 2.6 us
+    // per k-tile on the K = 73 728 products; two ahead cover it (G_PF = 2: the split-K products; it costs 64 registers, i.e. a
+    // wave per SIMD, which the short-K products -- whose loads the other workgroups of the CU cover -- do not get back).
+    float va[G_PF][WM][8], vb[G_PF][WN][8];
+#pragma unroll
+    for (int pf = 0; pf < G_PF; ++pf)
+        if (k0 + pf * S_BK < k1) {
+            fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, k0 + pf * S_BK, k1, va[pf], tid);
+            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0 + pf * S_BK, k1, vb[pf], tid);
+        }
+    auto k_tile = [&](int kt, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+        store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid);
+        store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid);
         __syncthreads();
-        if (kt + S_BK < k1) {  // in flight under this tile's MFMAs
-            fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + S_BK, k1, va, tid);
-            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + S_BK, k1, vb, tid);
+        if (kt + G_PF * S_BK < k1) {  // in flight under the MFMAs of this tile and of the G_PF - 1 after it
+            fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + G_PF * S_BK, k1, va[slot], tid);
+            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + G_PF * S_BK, k1, vb[slot], tid);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -247,6 +256,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
                 }
         }
         __syncthreads();
+    };
+    // (the register slot is a compile-time constant: a runtime index would send va / vb to scratch memory)
+    for (int kt = k0; kt < k1; kt += G_PF * S_BK) {
+        k_tile(kt, std::integral_constant<int, 0>{});
+        if constexpr (G_PF > 1)
+            if (kt + S_BK < k1) k_tile(kt + S_BK, std::integral_constant<int, 1>{});
     }
     // Column statistics of the product for a training-mode BatchNorm that follows (epc_gemm_f32_stats): per row tile the sums
     // of acc and acc^2 over the tile's valid rows -- of the product WITHOUT the bias, i.e. already shifted by the column's
@@ -384,6 +399,18 @@ static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStrea
             hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3, true>), grid, dim3(256), 0, st, g);
         return;
     }
+#ifndef EPC_GEMM_NO_DEEP_PREFETCH
+    const int kslice = (g.K + g.splitk - 1) / g.splitk;
+    if (g.splitk > 1 && kslice >= 8 * S_BK) {   // deep-K slices (dW = x^T dy over all rows): loads two k-tiles ahead
+        if (pieces == 1)
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1, false, 2>), grid, dim3(256), 0, st, g);
+        else if (pieces == 2)
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 2, false, 2>), grid, dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3, false, 2>), grid, dim3(256), 0, st, g);
+        return;
+    }
+#endif
     if (pieces == 1)
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1>), grid, dim3(256), 0, st, g);
     else if (pieces == 2)
