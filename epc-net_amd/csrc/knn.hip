@@ -168,8 +168,13 @@ extern "C" int epc_debug_knn_stats(unsigned long long* host_out, int reset) {
 // CONV1: the workgroup also produces conv1 (3 -> 64, models/epc-net.py:66-69) of its own KNN_THREADS points from the
 // cloud image it has just put in LDS -- 16 lanes x 4 channels per point, whole rows per store like conv1_kernel, ~1.5 %
 // more VALU work for this kernel instead of a separate 15-us launch that re-reads the cloud.
-template <int KSEL, bool CONV1>
-__global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const float* __restrict__ xyz, int n, int cap,
+// BATCH: candidates evaluated per group vote.  8 for grids of up to one workgroup per CU (fewest votes); 4 for larger grids
+// (EPC-Net-L at batch 256: 1024 workgroups): 48 instead of 68 registers, so that TWO 1024-thread workgroups share a CU
+// (8 waves per SIMD; their two 73-KB LDS images fit) and cover each other's LDS and branch latency -- the kernel issues a
+// vector instruction in under 40 % of the SIMD's cycles at 4 waves.  0.60 -> 0.51 ms per 256 clouds; at batch 64 (256
+// workgroups: nothing to share a CU with) the 8-wide form stays faster (0.19 vs 0.20 ms).  Same lists either way.
+template <int KSEL, bool CONV1, int BATCH>
+__global__ __launch_bounds__(KNN_THREADS, BATCH == 4 ? 8 : 1) void knn_topk_culled_kernel(const float* __restrict__ xyz, int n, int cap,
                                                                       int32_t* __restrict__ idx,
                                                                       int32_t* __restrict__ cnt,
                                                                       float* __restrict__ kth_out,
@@ -182,9 +187,11 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     const int npad = ntiles * KNN_CT;
     float4* bb = cand + npad;                  // [2*ntiles] boxes, then one float4 holding the margin
     float* s_margin = reinterpret_cast<float*>(bb + 2 * ntiles);
-    // per wave: one bit per (tile, 8-candidate batch) that produced a hit in pass 1 (KNN_CT / KNN_BATCH bits per tile)
-    constexpr int BPT = KNN_CT / KNN_BATCH;
-    unsigned int* hitmask = reinterpret_cast<unsigned int*>(s_margin + 4) + (threadIdx.x >> 6) * KNN_MASK_WORDS;
+    // per wave: one bit per (tile, 8-candidate batch) that produced a hit in pass 1 (KNN_CT / BATCH bits per tile)
+    constexpr int BPT = KNN_CT / BATCH;
+    constexpr int MASKW = KNN_LDS_MAX_N / BATCH / 32;   // hit-mask words per wave
+    static_assert(32 % BPT == 0, "a tile's batch bits must not straddle a mask word");
+    unsigned int* hitmask = reinterpret_cast<unsigned int*>(s_margin + 4) + (threadIdx.x >> 6) * MASKW;
     const int cloud = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pc = xyz + (size_t)cloud * n * 3;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
     }
     __syncthreads();
     const float margin = *s_margin;
-    for (int o = lane; o < KNN_MASK_WORDS; o += 64) hitmask[o] = 0u;  // wave-private: no barrier needed
+    for (int o = lane; o < MASKW; o += 64) hitmask[o] = 0u;  // wave-private: no barrier needed
 
     const int i = blockIdx.x * KNN_THREADS + tid;
     const bool valid = i < n;
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         const float dz = fmaxf(fmaxf(lo.z - zi, zi - hi.z), 0.f);
         return dx * dx + dy * dy + dz * dz - margin;
     };
-    // KNN_BATCH candidates at a time: the LDS reads are issued together, one wave vote decides whether any lane has
+    // BATCH candidates at a time: the LDS reads are issued together, one wave vote decides whether any lane has
     // anything to insert (almost never once the threshold has tightened).
     // d'_ij = (sq_i + -2*inner) + sq_j = -a_ij (negation is exact, so all comparisons are done on d').
     auto pos_sq_dist = [&](const float4& q) {
@@ -305,35 +312,40 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
         KSTAT(1);
         const float4* tp = cand + c * KNN_CT;
 #pragma unroll
-        for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
-            float4 q[KNN_BATCH];
+        for (int k0 = 0; k0 < KNN_CT; k0 += BATCH) {
+            float4 q[BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
-            float d[KNN_BATCH];
+            for (int u = 0; u < BATCH; ++u) q[u] = tp[k0 + u];
+            float d[BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) d[u] = pos_sq_dist(q[u]);
+            for (int u = 0; u < BATCH; ++u) d[u] = pos_sq_dist(q[u]);
             // one compare on the batch's smallest d' (v_min3_f32 in asm: four instructions for eight values, no canonicalising
             // v_max from fminf) instead of eight compares and eight mask ORs.  Non-strict: a batch without hits holds no
             // member of any lane's final set.  (Lanes past the cloud's end hold a list of -inf: nothing is ever <= it.)
-#if defined(KNN_BATCH_CMP_EACH) || KNN_BATCH != 8
-            bool hit = false;
+            bool hit;
+            if constexpr (BATCH == 8) {
+                float dmin;
+                asm("v_min3_f32 %0, %1, %2, %3\n\tv_min3_f32 %0, %0, %4, %5\n\tv_min3_f32 %0, %0, %6, %7\n\tv_min_f32 %0, %0, %8"
+                    : "=&v"(dmin)
+                    : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
+                hit = dmin <= thr;
+            } else if constexpr (BATCH == 4) {
+                float dmin;
+                asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, %0, %4" : "=&v"(dmin) : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+                hit = dmin <= thr;
+            } else {
+                hit = false;
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) hit |= d[u] <= thr;
-#else
-            float dmin;
-            asm("v_min3_f32 %0, %1, %2, %3\n\tv_min3_f32 %0, %0, %4, %5\n\tv_min3_f32 %0, %0, %6, %7\n\tv_min_f32 %0, %0, %8"
-                : "=&v"(dmin)
-                : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]));
-            const bool hit = dmin <= thr;
-#endif
+                for (int u = 0; u < BATCH; ++u) hit |= d[u] <= thr;
+            }
             if (wave_any(hit)) {
                 KSTAT(2);
                 if (lane == 0) {
-                    const int bit = c * BPT + k0 / KNN_BATCH;
+                    const int bit = c * BPT + k0 / BATCH;
                     hitmask[bit >> 5] |= 1u << (bit & 31);
                 }
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) {
+                for (int u = 0; u < BATCH; ++u) {
                     // wave-UNIFORM branch; every lane pushes its d': one that is not below the lane's threshold is >= all 20
                     // entries and falls straight through the network (min leaves each slot as it is), so no masking.
                     // (A per-lane `if` would make every slot a conditional update: +1 v_mov per slot to merge the paths.)
@@ -380,22 +392,22 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_topk_culled_kernel(const floa
             KSTAT(4);
             const float4* tp = cand + c * KNN_CT;
 #pragma unroll
-            for (int k0 = 0; k0 < KNN_CT; k0 += KNN_BATCH) {
-                if (!((bits >> (k0 / KNN_BATCH)) & 1u)) continue;
-                float4 q[KNN_BATCH];
+            for (int k0 = 0; k0 < KNN_CT; k0 += BATCH) {
+                if (!((bits >> (k0 / BATCH)) & 1u)) continue;
+                float4 q[BATCH];
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) q[u] = tp[k0 + u];
-                float d[KNN_BATCH];
+                for (int u = 0; u < BATCH; ++u) q[u] = tp[k0 + u];
+                float d[BATCH];
                 bool hit = false;
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) {
+                for (int u = 0; u < BATCH; ++u) {
                     d[u] = pos_sq_dist(q[u]);
                     hit |= d[u] <= dk;
                 }
                 if (wave_any(hit)) {
                     KSTAT(5);
 #pragma unroll
-                    for (int u = 0; u < KNN_BATCH; ++u)
+                    for (int u = 0; u < BATCH; ++u)
                         if (d[u] <= dk) {
                             if (valid && count < ucap) {
                                 char* slot = lists + (row + count * ESZ);
@@ -860,20 +872,39 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
     if (n <= KNN_LDS_MAX_N) {
         const int ntiles = (n + KNN_CT - 1) / KNN_CT;
         const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +
-                                 (size_t)KNN_WAVES * KNN_MASK_WORDS * sizeof(unsigned int);
-        const void* fn = conv1_pack ? reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT, true>)
-                                    : reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT, false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) {
-            epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
-            return EPC_EHIP;
+                                 (size_t)KNN_WAVES * (KNN_LDS_MAX_N / 4 / 32) * sizeof(unsigned int);   // (sized for the 4-wide form's masks)
+        // grids of more than one workgroup per CU run the 4-wide form, two workgroups to a CU (comment at the kernel)
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            num_cus = v;
         }
-        if (conv1_pack)
-            hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, true>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, conv1_pack, x32, (unsigned short*)x16, idx_u16, status);
-        else
-            hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, false>), grid, dim3(KNN_THREADS), lds_bytes,
-                               (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, status);
+#ifdef KNN_FORCE_BATCH
+        const bool wide_grid = KNN_FORCE_BATCH == 4;
+#else
+        const bool wide_grid = (long)grid.x * grid.y >= 2L * num_cus;
+#endif
+#define EPC_KNN_LAUNCH(C1, B)                                                                                                   \
+    do {                                                                                                                        \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_topk_culled_kernel<EPC_KNN_SELECT, C1, B>),       \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                        \
+        if (e_ != hipSuccess) {                                                                                                 \
+            epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_));                                           \
+            return EPC_EHIP;                                                                                                    \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((knn_topk_culled_kernel<EPC_KNN_SELECT, C1, B>), grid, dim3(KNN_THREADS), lds_bytes,                \
+                           (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, C1 ? conv1_pack : nullptr, C1 ? x32 : nullptr,     \
+                           C1 ? (unsigned short*)x16 : nullptr, C1 ? idx_u16 : 0, status);                                      \
+    } while (0)
+        if (conv1_pack) {
+            if (wide_grid) EPC_KNN_LAUNCH(true, 4);
+            else EPC_KNN_LAUNCH(true, 8);
+        } else {
+            if (wide_grid) EPC_KNN_LAUNCH(false, 4);
+            else EPC_KNN_LAUNCH(false, 8);
+        }
+#undef EPC_KNN_LAUNCH
     } else {
         hipLaunchKernelGGL(knn_topk_stream_kernel<EPC_KNN_SELECT>, grid, dim3(KNN_THREADS), 0, (hipStream_t)stream,
                            xyz, n, cap, idx, cnt, kth, status);

@@ -41,6 +41,46 @@ def test_knn_bit_exact(dev, kind, n, seed):
             assert np.array_equal(idx[b, i, :m], ref[:m])
 
 
+@pytest.mark.parametrize("kind,n", [("uniform", 192), ("dup", 128), ("lidar", 2048)])
+def test_knn_wide_grid_form_is_bit_exact(dev, kind, n):
+    """Grids of two or more workgroups per CU (here 640 / 520 clouds; EPC-Net-L's batch 256 x 4096 in production) run the kNN
+    kernel's 4-candidates-per-vote instantiation, two workgroups to a CU: thresholds, counts and lists must be those of the
+    oracle -- i.e. of the 8-wide form the small grids of the other tests run -- bit for bit, conv1 fused or not."""
+    L = H.pkg("lib")
+    lib = L.lib()
+    nc = 640 if n < 1024 else 260          # (260 clouds x 2 workgroups = 520 workgroups on 256 CUs)
+    pc = O.synthetic_clouds(nc, n, 11, kind)
+    xyz = torch.from_numpy(pc).to(dev)
+    idx = torch.zeros((nc, n, 32), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((nc, n), dtype=torch.int32, device=dev)
+    kth = torch.zeros((nc, n), device=dev)
+    L.check(lib.epc_knn_topk(xyz.data_ptr(), nc, n, 32, idx.data_ptr(), cnt.data_ptr(), kth.data_ptr(), L.current_stream()))
+    torch.cuda.synchronize()
+    kth_c, idx_c, cnt_c = kth.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    check = range(nc) if n < 1024 else (0, 1, nc // 2, nc - 1)
+    kth_ref, lists = O.knn_lists(pc[list(check)])
+    for bi, b in enumerate(check):
+        assert np.array_equal(kth_c[b], kth_ref[bi])
+        for i in range(n):
+            ref = lists[bi][i]
+            assert cnt_c[b, i] == len(ref)
+            m = min(len(ref), 32)
+            assert np.array_equal(idx_c[b, i, :m], ref[:m])
+    # the fused conv1 form with 2-byte lists on the same grid
+    eng, _ = H.make_engine("epc-net-l", O.seeded_weights("epc-net-l", 0), dev)
+    cfg = eng.cfg_for(n)
+    pk = eng.packed(cfg).data_ptr() + lib.epc_net_packed_offset(ctypes.byref(cfg), 0)
+    idx2 = torch.zeros((nc, n, 32), dtype=torch.int16, device=dev)
+    cnt2, kth2 = torch.zeros_like(cnt), torch.zeros_like(kth)
+    x1 = torch.zeros((nc * n, 64), device=dev)
+    status = torch.zeros((nc,), dtype=torch.int32, device=dev)
+    L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, idx2.data_ptr(), 1, cnt2.data_ptr(), kth2.data_ptr(), pk,
+                                   x1.data_ptr(), None, status.data_ptr(), L.current_stream()))
+    torch.cuda.synchronize()
+    m = torch.arange(32, device=dev)[None, None, :] < cnt.clamp(max=32)[..., None]
+    assert torch.equal(cnt, cnt2) and torch.equal(kth, kth2) and torch.equal(idx * m, idx2.int() * m)
+
+
 def _morton_sort(pc, dev):
     L = H.pkg("lib")
     t = torch.from_numpy(pc).to(dev)
