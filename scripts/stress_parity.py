@@ -10,6 +10,7 @@ from helpers import O
 dev = torch.device("cuda:0")
 tf_util = H.pkg("utils.tf_util"); ops = H.pkg("ops")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+precision = os.environ.get("PRECISION", "fast")   # EPC-Net arithmetic under test (EPC-Net-L has one)
 t0 = time.time()
 fails = cases = 0
 worst = {}
@@ -42,10 +43,10 @@ while time.time() - t0 < budget:
                 key = (arch, seed % 3)
                 if key not in engines:
                     w = O.seeded_weights(arch, seed % 3)
-                    engines[key] = (w, H.make_engine(arch, w, dev)[0])
+                    engines[key] = (w, H.make_engine(arch, w, dev, precision=precision)[0])
                 w, eng = engines[key]
                 # make_engine resets the default store: rebuild per use to stay independent
-                eng = H.make_engine(arch, w, dev)[0]
+                eng = H.make_engine(arch, w, dev, precision=precision)[0]
                 ref, _ = O.forward(s_np[:, None], w, arch=arch, formulation="lists", lists=lists)
                 out = eng.forward(x).cpu().numpy()
                 err = float(np.linalg.norm(out - ref.reshape(2, -1), axis=1).max())
@@ -55,7 +56,7 @@ while time.time() - t0 < budget:
                     fails += 1
                     print("DESCRIPTOR kind=%s n=%d seed=%d arch=%s err=%.3e" % (kind, n, seed, arch, err))
     seed += 1
-print("cases %d  failures %d  seeds %d" % (cases, fails, seed))
+print("precision %s: cases %d  failures %d  seeds %d" % (precision, cases, fails, seed))
 for k, v in sorted(worst.items()):
     print("  worst descriptor error %-10s %-8s %.3e" % (k[0], k[1], v))
 sys.exit(1 if fails else 0)
