@@ -36,8 +36,10 @@ def test_cfg_struct_layout_and_sizes():
         E.make_cfg("epc-net", 4096, dict(H.PARAMS, PRECISION="fp8"))
     f32 = E.make_cfg("epc-net", 4096, H.PARAMS, precision="f32")
     cfg = E.make_cfg("epc-net", 4096, H.PARAMS, precision="fast")
-    # the f32-equivalent path keeps f32 tensors between its stages: about twice the workspace of the fp16 path
-    assert L.lib().epc_net_workspace_bytes(ctypes.byref(f32), 64) > 1.8 * L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64)
+    # the f32-equivalent path keeps f32 tensors between its stages (and `feat` as 3-byte values against the fast path's fp16):
+    # 1.6 x the workspace of the fp16 path
+    ratio = L.lib().epc_net_workspace_bytes(ctypes.byref(f32), 64) / L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), 64)
+    assert 1.5 < ratio < 1.7
     assert L.lib().epc_net_packed_bytes(ctypes.byref(f32)) == L.lib().epc_net_packed_bytes(ctypes.byref(cfg))
     badp = E.make_cfg("epc-net", 4096, H.PARAMS)
     badp.precision = 7
