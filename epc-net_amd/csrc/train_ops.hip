@@ -1277,7 +1277,25 @@ __global__ __launch_bounds__(256) void neighbour_mean_kernel(const float* __rest
         }
     };
     if (c <= cap) {
-        for (int m = 0; m < c; ++m) visit(idx[(size_t)g * cap + m]);
+        int m = 0;
+        if (!BWD && c >= 20 && cap % 4 == 0) {
+            // the first 20 entries (every ordinary row has at least 20): five int4 index loads, then all 20 row loads in flight
+            // at once, added in ascending order -- the one-at-a-time loop below chains 20 dependent (index, row) round trips
+            const int4* il = reinterpret_cast<const int4*>(idx + (size_t)g * cap);
+            int nb[20];
+#pragma unroll
+            for (int m4 = 0; m4 < 5; ++m4) {
+                const int4 tq = il[m4];
+                nb[4 * m4] = tq.x, nb[4 * m4 + 1] = tq.y, nb[4 * m4 + 2] = tq.z, nb[4 * m4 + 3] = tq.w;
+            }
+            float4 v[20];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) v[u] = s4[(size_t)(cloud_base + nb[u]) * 16 + q];
+#pragma unroll
+            for (int u = 0; u < 20; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
+            m = 20;
+        }
+        for (; m < c; ++m) visit(idx[(size_t)g * cap + m]);
     } else {
         const float* pc = xyz + (size_t)cloud_base * 3;
         const int i = g - cloud_base;
@@ -1445,32 +1463,47 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
                                                                    float* __restrict__ dx) {
     // ddiff (optional): the gradient of diff = xm - x of the fused forward.  Then the rows gathered are dxm + ddiff and
     // the point's own -ddiff is added:  dx[j] = (sum_i (dxm[i] + ddiff[i])) / k - ddiff[j]
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // 16 lanes x float4 per point (four points per wave, like the forward gather): a quarter of the load instructions of the
+    // lane = channel form; eight list entries and their eight (sixteen) rows in flight per round, added in list order.
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int j = t >> 4, q = t & 15;
     if (j >= total_points) return;
     const int deg = rdeg[j];
     const int32_t* lst = rlist + roff[j];
-    float acc = 0.f;
-    for (int m0 = 0; m0 < deg; m0 += 64) {
-        const int mine = (m0 + lane < deg) ? lst[m0 + lane] : 0;
-        const int lim = min(64, deg - m0);
-        int m = 0;
-        for (; m + 4 <= lim; m += 4) {   // 4 independent row loads in flight
-            const int i0 = __shfl(mine, m), i1 = __shfl(mine, m + 1), i2 = __shfl(mine, m + 2), i3 = __shfl(mine, m + 3);
-            float v0 = dxm[(size_t)i0 * 64 + lane], v1 = dxm[(size_t)i1 * 64 + lane];
-            float v2 = dxm[(size_t)i2 * 64 + lane], v3 = dxm[(size_t)i3 * 64 + lane];
-            if (ddiff) {
-                v0 += ddiff[(size_t)i0 * 64 + lane], v1 += ddiff[(size_t)i1 * 64 + lane];
-                v2 += ddiff[(size_t)i2 * 64 + lane], v3 += ddiff[(size_t)i3 * 64 + lane];
-            }
-            acc += (v0 + v1) + (v2 + v3);
+    const float4* s4 = reinterpret_cast<const float4*>(dxm);
+    const float4* d4 = reinterpret_cast<const float4*>(ddiff);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int m = 0;
+    for (; m + 8 <= deg; m += 8) {
+        int ii[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ii[u] = lst[m + u];
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s4[(size_t)ii[u] * 16 + q];
+        if (ddiff) {
+            float4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = d4[(size_t)ii[u] * 16 + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u].x += w[u].x, v[u].y += w[u].y, v[u].z += w[u].z, v[u].w += w[u].w;
         }
-        for (; m < lim; ++m) {
-            const size_t o = (size_t)__shfl(mine, m) * 64 + lane;
-            acc += ddiff ? dxm[o] + ddiff[o] : dxm[o];
-        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
     }
-    const float own = ddiff ? ddiff[(size_t)j * 64 + lane] : 0.f;
-    dx[(size_t)j * 64 + lane] = acc / kdiv - own;
+    for (; m < deg; ++m) {
+        const size_t o = (size_t)lst[m] * 16 + q;
+        float4 v = s4[o];
+        if (ddiff) {
+            const float4 w = d4[o];
+            v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+        }
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ddiff) own = d4[(size_t)j * 16 + q];
+    reinterpret_cast<float4*>(dx)[(size_t)j * 16 + q] =
+        make_float4(acc.x / kdiv - own.x, acc.y / kdiv - own.y, acc.z / kdiv - own.z, acc.w / kdiv - own.w);
 }
 
 // scatter restricted to the rows the transposed graph does not list (cnt > cap)
@@ -1505,7 +1538,7 @@ extern "C" int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz,
     const long total = (long)num_clouds * n;
     const unsigned blocks = (unsigned)((total + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
+    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
                        (float)knn, (const float*)nullptr, dx);
     hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
                        (int)total, n, (float)knn, (const float*)nullptr, dx);
@@ -1523,7 +1556,7 @@ extern "C" int epc_neighbour_mean_diff_bwd_gather(const float* dxm, const float*
     const long total = (long)num_clouds * n;
     const unsigned blocks = (unsigned)((total + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3(blocks), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
+    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
                        (float)knn, ddiff, dx);
     hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
                        (int)total, n, (float)knn, ddiff, dx);
@@ -1555,6 +1588,44 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* pa = a + (size_t)row * C;
+    float* po = out + (size_t)row * C;
+    if (C == 1024) {
+        // conv5's rows (models/epc-net.py:148 on 1024 channels): the lane's 16 values as four float4 loads per operand, all in
+        // flight before the dot product, and kept for the second half -- one pass over the row instead of two, a quarter of
+        // the load / store instructions.  (Its own fixed summation order: float4 groups instead of strided scalars.)
+        const float4* a4 = reinterpret_cast<const float4*>(pa);
+        const float4* b4 = BWD ? reinterpret_cast<const float4*>(b + (size_t)row * C) : nullptr;
+        float4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = a4[lane + 64 * u];
+            if (BWD) vb[u] = b4[lane + 64 * u];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 o = BWD ? vb[u] : va[u];
+            s += va[u].x * o.x, s += va[u].y * o.y, s += va[u].z * o.z, s += va[u].w * o.w;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        float4* o4 = reinterpret_cast<float4*>(po);
+        if (!BWD) {
+            const float rn = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o4[lane + 64 * u] = make_float4(va[u].x * rn, va[u].y * rn, va[u].z * rn, va[u].w * rn);
+            if (lane == 0) rn_out[row] = rn;
+        } else {
+            const float rn = rn_in[row];
+            const bool clamped = rn >= 0.99e6f;  // sum x^2 <= 1e-12: y = x * 1e6, d/dx = 1e6 (no projection term)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                o4[lane + 64 * u] = clamped ? make_float4(va[u].x * rn, va[u].y * rn, va[u].z * rn, va[u].w * rn)
+                                            : make_float4(rn * (va[u].x - vb[u].x * s), rn * (va[u].y - vb[u].y * s),
+                                                          rn * (va[u].z - vb[u].z * s), rn * (va[u].w - vb[u].w * s));
+        }
+        return;
+    }
     float s = 0.f;
     if (!BWD) {
         for (int c = lane; c < C; c += 64) s += pa[c] * pa[c];
@@ -1564,7 +1635,6 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    float* po = out + (size_t)row * C;
     if (!BWD) {
         const float rn = 1.0f / sqrtf(fmaxf(s, 1e-12f));
         for (int c = lane; c < C; c += 64) po[c] = pa[c] * rn;
