@@ -579,6 +579,10 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(const float* __re
 
 extern "C" int epc_gemm_stats_tiles(int M) { return M >= 128 ? (M + 127) / 128 : (M + 63) / 64; }
 
+__global__ void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                      int rows, float* __restrict__ z, float* __restrict__ stats, unsigned int* __restrict__ counter,
+                                      float* __restrict__ mean, float* __restrict__ var);   // (below)
+
 extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
                                   float* var, void* stream) {
@@ -587,6 +591,19 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     const int tiles = epc_gemm_stats_tiles(M);
     EPC_CHECK_ARG(stats_floats >= (size_t)tiles * 2 * N, "statistics buffer too small (epc_gemm_stats_tiles(M) * 2 * N floats)");
     hipStream_t st = (hipStream_t)stream;
+#ifndef EPC_NO_THIN_FORWARD
+    if (N == 64 && K == 64 && sAm == 64 && sAk == 1 && sBk == 64 && sBn == 1 && ldc == 64 &&
+        ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(C)) & 15) == 0) {
+        // the thin layers: one pass, one partial per 256 rows (fewer than the tiles the caller sized `stats` for)
+        const int wgs = (M + 255) / 256;
+        hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, B, bias, M, C, stats, (unsigned int*)nullptr,
+                           (float*)nullptr, (float*)nullptr);
+        EPC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(256), 0, st, stats, wgs, 64, M, bias, mean, var);
+        EPC_CHECK_LAUNCH();
+        return EPC_OK;
+    }
+#endif
     GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, 0, 0, 0, 1, 0, stats, nullptr};
     const bool bigm = M >= 128, bign = N >= 128;
     if (bigm && bign) launch_gemm_split<2, 2>(g, 1, 3, st);
@@ -598,6 +615,148 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ---- the same for the thin layers (64 -> 64: conv*_a, conv*_b, conv2..4 of models/epc-net.py:66-132) ---------------------------
+// One pass over the rows, no k loop: W (16 KB) is split once per workgroup into B fragments in LDS, a wave takes 32 rows at a
+// time -- their 64 channels are the A fragments as loaded (lane = row, eight consecutive channels per k-step) -- and runs the
+// six products of the f32-accurate arithmetic; D = [row][out channel] puts a column on every lane, so the column sums of the
+// statistics are in-lane.  One partial per workgroup of 256 rows (the general kernel: one per 128-row tile, two barriers and
+// an LDS round trip per k-tile for a K of 64): 23.5 -> 13 us per layer at 73 728 rows, and half the partials to finalize.
+#define LS_TILES_PER_WAVE 2
+#define LS_ROWS_PER_WG (4 * 32 * LS_TILES_PER_WAVE)
+
+// `counter` (optional): a zero word of the caller's column-reduction workspace.  With it the workgroup that finishes LAST adds
+// the partials (ascending order, double precision: moments_finalize_kernel's arithmetic) and writes mean / var itself -- no
+// finalize launch; it leaves the word zero.  Partials cross workgroups through agent-scope stores / loads (colreduce_kernel).
+__global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, int rows,
+                                                             float* __restrict__ z, float* __restrict__ stats,
+                                                             unsigned int* __restrict__ counter, float* __restrict__ mean,
+                                                             float* __restrict__ var) {
+    __shared__ u32x4 Wf[2][4][3][64];                                  // [out tile][k-step][piece][lane]: 24 KB
+    __shared__ __attribute__((aligned(16))) float sred[3][2][64];      // column sums of waves 1..3: [wave][sum, sum of squares][column]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // B[k = in][n = out] = W[k][n]: lane (n = 32 nt + i, k group h) of k-step s holds W[16 s + 8 h .. + 7][n]
+    for (int f = tid; f < 2 * 4 * 64; f += 256) {
+        const int l = f & 63, s4 = (f >> 6) & 3, nt = f >> 8;
+        const float* src = W + (size_t)(16 * s4 + 8 * (l >> 5)) * 64 + 32 * nt + (l & 31);
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)q * 64];
+        bf16x8 p0, p1, p2;
+        split8x3(v, p0, p1, p2);
+        Wf[nt][s4][0][l] = __builtin_bit_cast(u32x4, p0);
+        Wf[nt][s4][1][l] = __builtin_bit_cast(u32x4, p1);
+        Wf[nt][s4][2][l] = __builtin_bit_cast(u32x4, p2);
+    }
+    __syncthreads();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const float b0 = bias ? bias[i] : 0.f, b1 = bias ? bias[32 + i] : 0.f;
+    for (int t = 0; t < LS_TILES_PER_WAVE; ++t) {
+        const int base = blockIdx.x * LS_ROWS_PER_WG + (wave * LS_TILES_PER_WAVE + t) * 32;   // wave-uniform
+        if (base >= rows) break;
+        const int row = base + i;
+        const bool ok = row < rows;
+        const size_t o = (size_t)(ok ? row : 0) * 64 + 8 * h;
+        bf16x8 a0[4], a1[4], a2[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float4 u0 = *reinterpret_cast<const float4*>(x + o + 16 * s4), u1 = *reinterpret_cast<const float4*>(x + o + 16 * s4 + 4);
+            if (!ok) u0 = u1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            split8x3(v, a0[s4], a1[s4], a2[s4]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, Wf[nt][s4][0][lane]), w1 = __builtin_bit_cast(bf16x8, Wf[nt][s4][1][lane]),
+                             w2 = __builtin_bit_cast(bf16x8, Wf[nt][s4][2][lane]);
+                acc = mfma_bf16(a2[s4], w0, acc);   // smallest terms first (gemm_split_kernel's order)
+                acc = mfma_bf16(a0[s4], w2, acc);
+                acc = mfma_bf16(a1[s4], w1, acc);
+                acc = mfma_bf16(a1[s4], w0, acc);
+                acc = mfma_bf16(a0[s4], w1, acc);
+                acc = mfma_bf16(a0[s4], w0, acc);
+            }
+            const float bv = nt ? b1 : b0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = base + mfma_row(r, h);
+                if (rr < rows) {
+                    const float v = acc[r];     // (statistics of the product WITHOUT the bias: moments_finalize_kernel adds it to the mean)
+                    s1[nt] += v;
+                    s2[nt] += v * v;
+                    z[(size_t)rr * 64 + 32 * nt + i] = v + bv;
+                }
+            }
+        }
+    }
+    // fixed order: registers (above), lane halves, waves 0..3
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+    }
+    if (wave > 0 && h == 0) {
+        sred[wave - 1][0][i] = s1[0], sred[wave - 1][0][32 + i] = s1[1];
+        sred[wave - 1][1][i] = s2[0], sred[wave - 1][1][32 + i] = s2[1];
+    }
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = 32 * nt + i;
+            __hip_atomic_store(&stats[((size_t)blockIdx.x * 2 + 0) * 64 + c], ((s1[nt] + sred[0][0][c]) + sred[1][0][c]) + sred[2][0][c],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stats[((size_t)blockIdx.x * 2 + 1) * 64 + c], ((s2[nt] + sred[0][1][c]) + sred[1][1][c]) + sred[2][1][c],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!counter) return;
+    __shared__ int s_last;
+    __shared__ double fin[2][4][64];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const int c = tid & 63, part = tid >> 6, nb = gridDim.x;
+        double t1 = 0.0, t2 = 0.0;
+        int b = part;
+        for (; b + 28 < nb; b += 32) {
+            float u1[8], u2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                u1[u] = __hip_atomic_load(&stats[((size_t)(b + 4 * u) * 2 + 0) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u2[u] = __hip_atomic_load(&stats[((size_t)(b + 4 * u) * 2 + 1) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t1 += (double)u1[u], t2 += (double)u2[u];
+        }
+        for (; b < nb; b += 4) {
+            t1 += (double)__hip_atomic_load(&stats[((size_t)b * 2 + 0) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += (double)__hip_atomic_load(&stats[((size_t)b * 2 + 1) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        fin[0][part][c] = t1, fin[1][part][c] = t2;
+        __syncthreads();
+        if (part == 0) {
+            t1 = (fin[0][0][c] + fin[0][1][c]) + (fin[0][2][c] + fin[0][3][c]);
+            t2 = (fin[1][0][c] + fin[1][1][c]) + (fin[1][2][c] + fin[1][3][c]);
+            const double m = t1 / rows;
+            mean[c] = (float)(m + (bias ? (double)bias[c] : 0.0));
+            var[c] = (float)fmax(t2 / rows - m * m, 0.0);
+        }
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 
 // ----------------------------------------------------------------------------------------------------------------
 // Column reductions over the rows of (rows, C) tensors, ONE launch each: every workgroup reduces a 256-row x 64-column
@@ -798,6 +957,22 @@ static int colreduce_check(const char* who, int rows, int C, const void* workspa
         epc_set_error(who);
         return EPC_ENOMEM;
     }
+    return EPC_OK;
+}
+
+// y = x W + b for a 64 -> 64 layer TOGETHER with the batch moments of y, one launch (linear_stats64_kernel with its in-kernel
+// finish).  `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64); zero counters, left zero).
+extern "C" int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(x && W && z && mean && var, "null pointer");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(z)) & 15) == 0, "x and z must be 16-byte aligned");
+    if (int rc = colreduce_check("epc_linear_stats64: workspace too small", rows, 64, workspace, workspace_bytes)) return rc;
+    unsigned int* counters = (unsigned int*)workspace;
+    float* part = (float*)(counters + CR_COUNTERS);
+    const int wgs = (rows + LS_ROWS_PER_WG - 1) / LS_ROWS_PER_WG;   // <= the 256-row panels the workspace is sized for
+    hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, W, bias, rows, z, part, counters,
+                       mean, var);
+    EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 

@@ -199,6 +199,11 @@ def _gemm_with_stats(x, W, b):
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     mean = torch.empty(cout, dtype=torch.float32, device=x.device)
     var = torch.empty(cout, dtype=torch.float32, device=x.device)
+    if cin == 64 and cout == 64 and x.is_contiguous() and W.is_contiguous():
+        ws, n = _ws(rows, 64, x.device)      # the thin layers: one launch, moments finished by the last workgroup
+        L.check(L.lib().epc_linear_stats64(x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, rows,
+                                           z.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
+        return z, mean, var
     tiles = L.lib().epc_gemm_stats_tiles(rows)
     stats = torch.empty(tiles * 2 * cout, dtype=torch.float32, device=x.device)
     L.check(L.lib().epc_gemm_f32_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,

@@ -300,6 +300,14 @@ int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, i
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
+/* y = x W + b for a 64 -> 64 layer (x, y: (rows, 64) row-major, 16-byte aligned; W: (64 in, 64 out)) TOGETHER with the batch
+ * moments of y (mean, population variance: tf.nn.moments) in ONE launch: one pass over the rows in the f32-accurate six-product
+ * arithmetic, per-workgroup column sums, and the workgroup that finishes last adds them in ascending order in double precision.
+ * `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64); zero counters, left zero).
+ * Replaces tf.nn.conv1d + bias_add + tf.nn.moments of utils/tf_util.py:94-99, 472 for the thin layers. */
+int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of a 64 -> 64 layer followed by a training-mode BatchNorm (+ReLU) (utils/tf_util.py:94-106 from the gradient side:
  * the thin layers conv*_a / conv*_b / conv2..4 of models/epc-net.py:66-132) in three launches instead of four GEMM-sized ones:
  * the BatchNorm column sums (dbeta, dgamma), ONE pass over the rows that forms dz in registers and produces dx = dz W^T
