@@ -428,8 +428,13 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 unsigned int w[12];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+#ifdef C5_FEAT_BITS11   // experiment: what 11 significant bits (a 2-byte format) would do to the descriptors
+                    const unsigned int a = (__float_as_uint(acc[4 * g]) + 0x1000u) & 0xffffe000u, b = (__float_as_uint(acc[4 * g + 1]) + 0x1000u) & 0xffffe000u;
+                    const unsigned int cc = (__float_as_uint(acc[4 * g + 2]) + 0x1000u) & 0xffffe000u, d = (__float_as_uint(acc[4 * g + 3]) + 0x1000u) & 0xffffe000u;
+#else
                     const unsigned int a = __float_as_uint(acc[4 * g]) + 0x80u, b = __float_as_uint(acc[4 * g + 1]) + 0x80u;
                     const unsigned int cc = __float_as_uint(acc[4 * g + 2]) + 0x80u, d = __float_as_uint(acc[4 * g + 3]) + 0x80u;
+#endif
                     w[3 * g] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
                     w[3 * g + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
                     w[3 * g + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
