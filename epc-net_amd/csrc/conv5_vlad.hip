@@ -1015,22 +1015,37 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         u32x4 bfr[2][2][2];    // [cluster tile][k-step][hi, lo]
         float rn;
     };
+    // A tile's 15 loads are inline asm and their completion a hand-counted s_waitcnt (the idiom of conv5's W5 stream): written
+    // as C++ loads, hipcc 7.2 either ends process(t) on `s_waitcnt vmcnt(0)` -- the conditional prefetch sat in exec-masked
+    // branches and its wait bookkeeping merges the paths -- or, with unconditional loads, sinks them below the other tile's
+    // processing to save registers.  Either way the ping-pong overlapped nothing and the kernel read at 4.7 TB/s.  Loads
+    // return in issue order, so with a tile's 15 loads issued after the previous tile's, `vmcnt(15)` is "the previous tile has
+    // landed"; the wait names the tile's registers as operands so that no use can be scheduled above it.
+    auto ld16 = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); };
+    auto ld16nt = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p)); };
     auto load = [&](Tile& t, int tt) {
-        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4;
-        const float* fb = assign_frag + (gt0 + tt) * 2048 + lane * 4;
+        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4);
+        const char* fb = reinterpret_cast<const char*>(assign_frag + (gt0 + tt) * 2048 + lane * 4);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 768 + q * 256));
-        t.rn = rnorm[(gt0 + tt) * 32 + j];
+            for (int q = 0; q < 3; ++q) ld16nt(t.raw[c][q], fa + (c * 768 + q * 256) * 4);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0 + tt) * 32 + j));
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int part = 0; part < 2; ++part)
-                    t.bfr[ct][ks][part] = *reinterpret_cast<const u32x4*>(fb + ((ct * 2 + ks) * 2 + part) * 256);
+                for (int part = 0; part < 2; ++part) ld16(t.bfr[ct][ks][part], fb + (((ct * 2 + ks) * 2 + part) * 256) * 4);
+    };
+    static_assert(AGG_FT == 2, "a tile is 6 + 1 + 8 = 15 vector-memory loads: the counted waits below say 15");
+    auto landed = [&](Tile& t) {   // every load issued before the LAST 15 has returned
+        asm volatile("s_waitcnt vmcnt(15)"
+                     : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[0][2]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.raw[1][2]),
+                       "+v"(t.rn), "+v"(t.bfr[0][0][0]), "+v"(t.bfr[0][0][1]), "+v"(t.bfr[0][1][0]), "+v"(t.bfr[0][1][1]),
+                       "+v"(t.bfr[1][0][0]), "+v"(t.bfr[1][0][1]), "+v"(t.bfr[1][1][0]), "+v"(t.bfr[1][1][1])
+                     :
+                     : "memory");
     };
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1082,12 +1097,18 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         }
     };
     Tile t0, t1;
-    if (per > 0) load(t0, 0);
-    for (int tt = 0; tt < per; tt += 2) {
-        if (tt + 1 < per) load(t1, tt + 1);
-        process(t0);
-        if (tt + 2 < per) load(t0, tt + 2);
-        if (tt + 1 < per) process(t1);
+    const int per_u = __builtin_amdgcn_readfirstlane(per);   // wave-uniform
+    if (per_u > 0) {
+        load(t0, 0);
+        for (int tt = 0; tt < per_u; tt += 2) {
+            load(t1, min(tt + 1, per_u - 1));     // (always 15 loads: past the end the last tile is requested again)
+            landed(t0);
+            process(t0);
+            load(t0, min(tt + 2, per_u - 1));
+            landed(t1);
+            if (tt + 1 < per_u) process(t1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's spare request
     }
 
     static_assert(AGG_FT == 2, "one chunk per half in the epilogue");
