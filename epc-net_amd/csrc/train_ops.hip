@@ -134,6 +134,33 @@ __device__ __forceinline__ void fetch_fragments(const float* __restrict__ P, lon
                                                 int tid) {
     const bool k_contig = s_k == 1;
     constexpr int ROWS = 32 * BLOCKS;
+    // Interior tiles (every row and all 32 k of the tile inside the matrix: all but the edge workgroups / the K tail) take a
+    // BRANCH-FREE fetch -- the test is workgroup-uniform, so it is one scalar branch.  The guarded form below puts every
+    // load in an exec-masked branch of its own, and hipcc then waits `vmcnt(0)` at each join before it merges the loaded
+    // values: the lane-fragments of a k-tile were fetched one memory round trip after the other (2.6 us per k-tile on the
+    // K = 73 728 products) instead of all at once.
+    const bool interior = outer0 + ROWS <= outer_lim && kt + S_BK <= k_lim;
+    if (interior && k_contig && ((reinterpret_cast<size_t>(P) | (size_t)(s_outer * 4)) & 15) == 0) {
+#pragma unroll
+        for (int u = 0; u < (ROWS * 4) / 256; ++u) {
+            const int f = tid + 256 * u;
+            const float* src = P + (size_t)(outer0 + (f >> 2)) * s_outer + (size_t)(kt + 8 * (f & 3));
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            v[u][0] = a.x, v[u][1] = a.y, v[u][2] = a.z, v[u][3] = a.w;
+            v[u][4] = b.x, v[u][5] = b.y, v[u][6] = b.z, v[u][7] = b.w;
+        }
+        return;
+    }
+    if (interior && !k_contig) {
+#pragma unroll
+        for (int u = 0; u < (ROWS * 4) / 256; ++u) {
+            const int f = tid + 256 * u;
+            const float* src = P + (size_t)(outer0 + f % ROWS) * s_outer + (size_t)(kt + 8 * (f / ROWS)) * s_k;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) v[u][jj] = src[(size_t)jj * s_k];
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < (ROWS * 4) / 256; ++u) {
         const int f = tid + 256 * u;  // ROWS x 4 lane-fragments (4 k-groups of 8)

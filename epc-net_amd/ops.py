@@ -98,12 +98,13 @@ def gemm(A, B, out=None, bias=None, trans_a=False, trans_b=False, splitk=1, accu
 
 
 def _splitk_for(M, N, K):
-    """Split-K factor of a deep-K product (dW = x^T dy over all rows): about three workgroups per CU.  The kernel's
+    """Split-K factor of a deep-K product (dW = x^T dy over all rows): about two workgroups per CU (three before the GEMM's
+    branch-free tile fetch: conv5's dW is 182 us at 32 slices, 227 at 48; the assignment's dWc 91 us at 64).  The kernel's
     tile is 128 wide on a side of at least 128, 64 otherwise (gemm_impl); measured on the training shapes
     (scripts/time_gemm.py): 256x1024x73728 16 -> 48 splits 550 -> 250 us; 64x64x73728 is best at 256."""
     tile = lambda d: 128 if d >= 128 else 64
     tiles = ((M + tile(M) - 1) // tile(M)) * ((N + tile(N) - 1) // tile(N))
-    return int(max(1, min(768 // max(tiles, 1), K // 128, 256)))
+    return int(max(1, min(512 // max(tiles, 1), K // 128, 256)))
 
 
 _ZEROS = {}
