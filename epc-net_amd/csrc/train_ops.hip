@@ -680,16 +680,28 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
     __syncthreads();
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     const float b0 = bias ? bias[i] : 0.f, b1 = bias ? bias[32 + i] : 0.f;
+    // every tile's rows are requested before the first is used (a wave is alone on its SIMD in these grids: 1152 waves on 1024
+    // SIMDs -- nothing else covers its memory latency)
+    float4 xr[LS_TILES_PER_WAVE][4][2];
+#pragma unroll
+    for (int t = 0; t < LS_TILES_PER_WAVE; ++t) {
+        const int row = min(blockIdx.x * LS_ROWS_PER_WG + (wave * LS_TILES_PER_WAVE + t) * 32 + i, rows - 1);
+        const size_t o = (size_t)row * 64 + 8 * h;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            xr[t][s4][0] = *reinterpret_cast<const float4*>(x + o + 16 * s4);
+            xr[t][s4][1] = *reinterpret_cast<const float4*>(x + o + 16 * s4 + 4);
+        }
+    }
+#pragma unroll
     for (int t = 0; t < LS_TILES_PER_WAVE; ++t) {
         const int base = blockIdx.x * LS_ROWS_PER_WG + (wave * LS_TILES_PER_WAVE + t) * 32;   // wave-uniform
         if (base >= rows) break;
-        const int row = base + i;
-        const bool ok = row < rows;
-        const size_t o = (size_t)(ok ? row : 0) * 64 + 8 * h;
+        const bool ok = base + i < rows;
         bf16x8 a0[4], a1[4], a2[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            float4 u0 = *reinterpret_cast<const float4*>(x + o + 16 * s4), u1 = *reinterpret_cast<const float4*>(x + o + 16 * s4 + 4);
+            float4 u0 = xr[t][s4][0], u1 = xr[t][s4][1];
             if (!ok) u0 = u1 = make_float4(0.f, 0.f, 0.f, 0.f);
             const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
             split8x3(v, a0[s4], a1[s4], a2[s4]);
@@ -1317,12 +1329,13 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                // (loads from clamped rows, zeroed afterwards: a guarded load is an exec-masked branch with a full wait at its
+                // join -- the 96 loads of this phase would go out one round trip at a time)
                 float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = base + 16 * s2 + 8 * h + q;
-                    v[q] = r < rows ? x[(size_t)r * 64 + 32 * mt + i] : 0.f;
-                }
+                for (int q = 0; q < 8; ++q) v[q] = x[(size_t)min(base + 16 * s2 + 8 * h + q, rows - 1) * 64 + 32 * mt + i];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (base + 16 * s2 + 8 * h + q < rows) ? v[q] : 0.f;
                 split8(v, xh[mt][s2], xl[mt][s2]);
             }
 #pragma unroll
@@ -1331,14 +1344,16 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
             const float cs = coef[0][c], ct = coef[1][c], mu = coef[2][c], k1 = coef[3][c], bb = coef[4][c], gg = coef[5][c];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                float v[8];
+                float v[8], gy[8], gz[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int r = base + 16 * s2 + 8 * h + q;
-                    const bool ok = r < rows;
-                    const size_t o = (size_t)(ok ? r : 0) * 64 + c;
-                    const float d = dz_of(dy[o], z[o], cs, ct, mu, k1, bb, gg);
-                    v[q] = ok ? d : 0.f;
+                    const size_t o = (size_t)min(base + 16 * s2 + 8 * h + q, rows - 1) * 64 + c;
+                    gy[q] = dy[o], gz[q] = z[o];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = dz_of(gy[q], gz[q], cs, ct, mu, k1, bb, gg);
+                    v[q] = (base + 16 * s2 + 8 * h + q < rows) ? d : 0.f;
                 }
                 bf16x8 dh, dl;
                 split8(v, dh, dl);
