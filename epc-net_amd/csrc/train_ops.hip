@@ -1463,6 +1463,91 @@ extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float*
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// conv1 of the training step (models/epc-net.py:66-69: 3 -> 64 on the coordinates): a K = 3 product is three FMAs per
+// output, not a matrix-pipe job -- the general kernel pads K to a 32-deep tile (45 us forward, 40 us for dW over
+// K = 73 728 rows with 256-way atomic split-K).  Forward: 16 lanes x 4 channels per row, one float4 store each.  dW (3, 64):
+// a workgroup walks 1024 rows, every thread keeps its channel quad's 3 x 4 sums, the 16 row groups meet in LDS in order,
+// one partial per workgroup, partial_sum_kernel adds the partials in ascending order (deterministic).  cin <= 4.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_smallk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, int rows, int cin, int cout,
+                                                                float* __restrict__ z) {
+    const int q4 = cout / 4;                       // channel quads per row
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t / q4;
+    const int c = (int)(t % q4) * 4;
+    if (row >= rows) return;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < cin; ++k) {
+        const float xv = x[row * cin + k];
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)k * cout + c);
+        acc.x = __builtin_fmaf(xv, w.x, acc.x), acc.y = __builtin_fmaf(xv, w.y, acc.y);
+        acc.z = __builtin_fmaf(xv, w.z, acc.z), acc.w = __builtin_fmaf(xv, w.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(z + row * cout + c) = acc;
+}
+
+#define SK_ROWS_PER_WG 1024
+__global__ __launch_bounds__(256) void linear_smallk_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               int rows, int cin, float* __restrict__ part) {
+    // cout == 64: thread = (row group rg of 16, channel quad l16 of 16)
+    __shared__ float red[16][4][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int r0 = blockIdx.x * SK_ROWS_PER_WG, r1 = min(rows, r0 + SK_ROWS_PER_WG);
+    float4 s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)r * 64 + 4 * l16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xv = k < cin ? x[(size_t)r * cin + k] : 0.f;
+            s[k].x = __builtin_fmaf(xv, g.x, s[k].x), s[k].y = __builtin_fmaf(xv, g.y, s[k].y);
+            s[k].z = __builtin_fmaf(xv, g.z, s[k].z), s[k].w = __builtin_fmaf(xv, g.w, s[k].w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(&red[rg][k][4 * l16]) = s[k];
+    __syncthreads();
+    // 256 threads = 4 k x 64 channels: ordered sum over the 16 row groups
+    const int k = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][k][c];
+    if (k < cin) part[(size_t)blockIdx.x * (cin * 64) + k * 64 + c] = t;
+}
+
+extern "C" int epc_linear_smallk_fwd(const float* x, const float* W, const float* bias, int rows, int cin, int cout, float* z,
+                                     void* stream) {
+    EPC_CHECK_ARG(x && W && z, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && cin >= 1 && cin <= 4 && cout > 0 && cout % 4 == 0, "rows > 0, 1 <= cin <= 4, cout a multiple of 4");
+    const long threads = (long)rows * (cout / 4);
+    hipLaunchKernelGGL(linear_smallk_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, W,
+                       bias, rows, cin, cout, z);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_linear_smallk_dw_partial_floats(int rows, int cin) {
+    return rows > 0 ? (size_t)((rows + SK_ROWS_PER_WG - 1) / SK_ROWS_PER_WG) * cin * 64 : 0;
+}
+
+extern "C" int epc_linear_smallk_dw(const float* x, const float* dy, int rows, int cin, int cout, float* dW, float* partials,
+                                    size_t partial_floats, void* stream) {
+    EPC_CHECK_ARG(x && dy && dW && partials, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && cin >= 1 && cin <= 4 && cout == 64, "rows > 0, 1 <= cin <= 4, cout == 64");
+    EPC_CHECK_ARG(partial_floats >= epc_linear_smallk_dw_partial_floats(rows, cin), "partial buffer too small");
+    const int wgs = (rows + SK_ROWS_PER_WG - 1) / SK_ROWS_PER_WG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_smallk_dw_kernel, dim3(wgs), dim3(256), 0, st, x, dy, rows, cin, partials);
+    const int E = cin * 64;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((E / 4 + 15) / 16), dim3(256), 0, st, partials, wgs, E, dW);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Neighbour mean over the kNN index lists (64 channels): forward gather, backward scatter (f32 atomics).
 // Rows with more than `cap` selected entries take the exact scan (same rule as the fused block kernel).
 // ----------------------------------------------------------------------------------------------------------------

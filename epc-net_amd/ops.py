@@ -133,6 +133,11 @@ class Linear(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.zero_bias_grad = bool(bias_before_batch_stats)
         rows, cin = x.shape
+        if cin <= 4 and W.shape[1] % 4 == 0 and W.is_contiguous():     # conv1 on the coordinates: three FMAs per output
+            z = torch.empty((rows, W.shape[1]), dtype=torch.float32, device=x.device)
+            L.check(L.lib().epc_linear_smallk_fwd(x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, rows, cin,
+                                                  W.shape[1], z.data_ptr(), _st()))
+            return z
         # few output tiles but a deep K (the 16384-wide hidden projection on a handful of rows): split K over workgroups
         tiles = ((rows + 63) // 64) * ((W.shape[1] + 63) // 64)
         splitk = int(max(1, min(256 // tiles, cin // 256, 64))) if tiles <= 32 else 1
@@ -145,7 +150,14 @@ class Linear(torch.autograd.Function):
         rows, cin = x.shape
         cout = W.shape[1]
         dx = gemm(dy, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
-        dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
+        if cin <= 4 and cout == 64:
+            dW = torch.empty_like(W)
+            pf = L.lib().epc_linear_smallk_dw_partial_floats(rows, cin)
+            part = _splitk_ws(pf, x.device)
+            L.check(L.lib().epc_linear_smallk_dw(x.data_ptr(), dy.data_ptr(), rows, cin, cout, dW.data_ptr(), part.data_ptr(),
+                                                 part.numel(), _st()))
+        else:
+            dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
         db = None      # exactly zero in front of a training-mode BatchNorm: left undefined (TrainStep reads it as zeros)
         if ctx.has_bias and not ctx.zero_bias_grad:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)

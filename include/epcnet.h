@@ -300,6 +300,14 @@ int epc_gemm_bf16(const float* A, const float* B, float* C, const float* bias, i
                  long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                  void* stream);
 
+/* Linear layers with 1 <= cin <= 4 (conv1 of the training step: 3 -> 64 on the coordinates, models/epc-net.py:66-69): the forward
+ * z = x W + b as three FMAs per output (cout a multiple of 4), and dW = x^T dy for cout == 64 as per-workgroup partials added in
+ * ascending order (`partials`: epc_linear_smallk_dw_partial_floats(rows, cin) floats of scratch) -- the same bits on every run. */
+int epc_linear_smallk_fwd(const float* x, const float* W, const float* bias, int rows, int cin, int cout, float* z, void* stream);
+size_t epc_linear_smallk_dw_partial_floats(int rows, int cin);
+int epc_linear_smallk_dw(const float* x, const float* dy, int rows, int cin, int cout, float* dW, float* partials,
+                         size_t partial_floats, void* stream);
+
 /* y = x W + b for a 64 -> 64 layer (x, y: (rows, 64) row-major, 16-byte aligned; W: (64 in, 64 out)) TOGETHER with the batch
  * moments of y (mean, population variance: tf.nn.moments) in ONE launch: one pass over the rows in the f32-accurate six-product
  * arithmetic, per-workgroup column sums, and the workgroup that finishes last adds them in ascending order in double precision.
