@@ -206,7 +206,68 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(const float* __restri
     int li = -1;
     int my_cand = -1;
     float my_approx = 0.f;
-    for (int r = 0; r < kc; ++r) {
+    // ---- fast selection: a bound, one filtering scan, a rank over <= 64 survivors (instead of kc full scans) ----------
+    // (1) every lane keeps the 4 smallest VALUES of its stride of the row (a 4-slot median network: 4 instructions per entry);
+    // (2) U = the kc-th smallest of those 256 values -- the kc-th smallest of a SUBSET of the row, hence an upper bound of the
+    //     row's kc-th smallest value;  (3) one more scan appends every finite (value, index) with value <= U to an LDS list:
+    //     it holds the row's kc smallest entries, usually kc of them or a few more;  (4) with at most 64 survivors a rank by
+    //     (value, index) puts the kc smallest on lanes 0 .. kc-1 in exactly the order the kc scans below would have found
+    //     them.  More than 64 survivors (masses of ties) or fewer than kc finite entries: the scans below take over.
+    bool fast_ok = false;
+    {
+        float* sv = srow + (rows_in_lds ? ((nd + 3) & ~3) : 0);          // [64] survivor values, [64] indices, [64] + [64] ranked
+        int* si = reinterpret_cast<int*>(sv + 64);
+        float* cv = sv + 128;
+        int* ci = reinterpret_cast<int*>(sv + 192);
+        float t0 = INFINITY, t1 = INFINITY, t2 = INFINITY, t3 = INFINITY;
+        for (int d = lane; d < nd; d += 64) {
+            const float v = row[d];
+            t3 = __builtin_amdgcn_fmed3f(t2, t3, v);
+            t2 = __builtin_amdgcn_fmed3f(t1, t2, v);
+            t1 = __builtin_amdgcn_fmed3f(t0, t1, v);
+            t0 = fminf(t0, v);
+        }
+        float U = INFINITY;
+        for (int r = 0; r < kc; ++r) {
+            float m = t0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+            U = m;
+            if (!(m < INFINITY)) break;                                   // fewer than kc finite values among the candidates
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(t0 == m);
+            if (lane == __builtin_ctzll(holders)) t0 = t1, t1 = t2, t2 = t3, t3 = INFINITY;   // pop ONE holder per round
+        }
+        int total = 0;
+        if (U < INFINITY) {
+            for (int d0 = 0; d0 < nd; d0 += 64) {
+                const int d = d0 + lane;
+                const float v = d < nd ? row[d] : INFINITY;
+                const bool hit = v <= U && v < INFINITY;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (mask) {
+                    const int pos = total + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                    if (hit && pos < 64) sv[pos] = v, si[pos] = d;
+                    total += __builtin_popcountll(mask);
+                }
+            }
+        }
+        if (total >= kc && total <= 64) {
+            __syncthreads();
+            const float v = lane < total ? sv[lane] : INFINITY;
+            const int d = lane < total ? si[lane] : 0x7fffffff;
+            int rank = 0;
+            for (int c = 0; c < total; ++c) {
+                const float ov = sv[c];
+                const int od = si[c];
+                if (ov < v || (ov == v && od < d)) ++rank;
+            }
+            if (lane < total) cv[rank] = v, ci[rank] = d;
+            __syncthreads();
+            if (lane < kc) my_cand = ci[lane], my_approx = cv[lane];
+            fast_ok = true;
+        }
+    }
+    for (int r = 0; r < (fast_ok ? 0 : kc); ++r) {
         float best = INFINITY;
         int bi = 0x7fffffff;
         for (int d = lane; d < nd; d += 64) {
@@ -324,8 +385,8 @@ extern "C" int epc_pairwise_topk_ws(const float* database, int num_db, const flo
     hipLaunchKernelGGL(rownorm2_kernel, dim3((num_db + 3) / 4), dim3(256), 0, st, database, num_db, dim, dn);
     hipLaunchKernelGGL(rownorm2_kernel, dim3((num_q + 3) / 4), dim3(256), 0, st, queries, num_q, dim, qn);
     EPC_CHECK_LAUNCH();
-    const int in_lds = (size_t)num_db * 4 <= 150 * 1024;
-    const size_t lds_bytes = in_lds ? (size_t)num_db * 4 : 0;
+    const int in_lds = (size_t)num_db * 4 <= 149 * 1024;
+    const size_t lds_bytes = (in_lds ? (((size_t)num_db + 3) & ~(size_t)3) * 4 : 0) + 4 * 64 * 4;   // the row (if it fits) + the selection's 4 x 64 words
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_rerank_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
     if (e != hipSuccess) {
