@@ -64,3 +64,34 @@ def test_hard_negative_selection_matches_kdtree():
     got = LP.get_random_hard_negatives(qv, negs, 10, lat, search=cpu_search)
     _, ind = KDTree(lat[negs]).query(np.array([qv]), k=10)                  # train.py:865-867
     assert got == np.squeeze(np.array(negs)[ind[0]]).tolist()
+
+
+def test_evaluate_runs_books_every_ordered_pair_like_the_reference():
+    """retrieval.evaluate_runs (evaluate.py:305-332) searches ONCE per database run -- the queries of all other runs in one call --
+    and must still book every ordered pair (m, n), m != n, in the reference's order with the reference's numbers: checked on the
+    CPU with an injected brute-force search against the oracle's pair-by-pair protocol (ragged run sizes, queries without a true
+    neighbour, a run pair whose queries all lack one is not generated here: the reference divides by zero there)."""
+    R = H.pkg("retrieval")
+    rng = np.random.RandomState(5)
+    sizes_db, sizes_q = [31, 47, 40, 25], [12, 9, 15, 11]
+    unit = lambda n: (lambda v: (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32))(rng.randn(n, 256))
+    dbs, qs = [unit(n) for n in sizes_db], [unit(n) for n in sizes_q]
+    truth = {(m, n): [sorted(rng.choice(sizes_db[m], size=rng.randint(0, 4), replace=False).tolist()) if i else [0]
+                      for i in range(sizes_q[n])] for m in range(4) for n in range(4)}
+    calls = []
+
+    def search(db, q, k):
+        calls.append((tuple(db.shape), tuple(q.shape)))
+        dist, idx = O.knn_bruteforce(db.numpy(), q.numpy(), min(k, db.shape[0]))
+        return torch.from_numpy(dist.astype(np.float32)), torch.from_numpy(idx.astype(np.int32))
+
+    res = R.evaluate_runs(dbs, qs, lambda m, n: truth[(m, n)], device=torch.device("cpu"), search=search)
+    assert len(calls) == 4 and all(c[1][0] == sum(sizes_q) - sizes_q[m] for m, c in enumerate(calls))
+    rec = np.zeros(25); opr = []; sim = []
+    for m in range(4):
+        for n in range(4):
+            if m != n:
+                r_, s_, o_ = O.get_recall(dbs[m], qs[n], truth[(m, n)])
+                rec += r_; opr.append(o_); sim.extend(s_)
+    assert np.allclose(res["ave_recall"], rec / 12) and np.isclose(res["ave_one_percent_recall"], np.mean(opr))
+    assert np.isclose(res["average_similarity"], np.mean(sim), atol=1e-6)
