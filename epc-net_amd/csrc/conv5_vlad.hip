@@ -416,6 +416,11 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             // bf16 hi + lo against hi + lo cluster weights (three products).
             const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
             auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
+#ifndef C5_NO_WC_PREFETCH
+            // the cluster-weight fragments of the first k-step are requested before the norm / pack / store work below (and the
+            // second k-step's before the first's MFMAs): read where they are used, each pair exposed its LDS latency
+            bf16x8 wq[2][2] = {{wfrag(0, 0, 0), wfrag(0, 0, 1)}, {wfrag(0, 1, 0), wfrag(0, 1, 1)}};
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
 #ifndef C5_ABL_NOSTORE
@@ -452,10 +457,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
                 bf16x8 fh, fl;
                 split8(v, fh, fl);
+#ifndef C5_NO_WC_PREFETCH
+                bf16x8 wn[2][2];
+                if (sp == 0) wn[0][0] = wfrag(1, 0, 0), wn[0][1] = wfrag(1, 0, 1), wn[1][0] = wfrag(1, 1, 0), wn[1][1] = wfrag(1, 1, 1);
+#endif
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #ifndef C5_ABL_NOASSIGN
+#ifndef C5_NO_WC_PREFETCH
+                    const bf16x8 wh = wq[t][0], wl = wq[t][1];
+#else
                     const bf16x8 wh = wfrag(sp, t, 0), wl = wfrag(sp, t, 1);
+#endif
                     P[t] = mfma_bf16(wl, fh, P[t]);
                     P[t] = mfma_bf16(wh, fl, P[t]);
                     P[t] = mfma_bf16(wh, fh, P[t]);
@@ -463,6 +476,9 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                     asm volatile("" :: "v"(fh), "v"(fl));
 #endif
                 }
+#ifndef C5_NO_WC_PREFETCH
+                if (sp == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
+#endif
             }
         } else if constexpr (kEpi && MODE == MODE_VLAD) {
             const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
