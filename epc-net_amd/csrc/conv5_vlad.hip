@@ -850,21 +850,31 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
         u32x4 bfr[2][2];       // [cluster tile][k-step]
         float rn;
     };
+    // The tile's 9 loads are inline asm with a hand-counted wait (see vlad_aggregate_f32_kernel: the C++ form ended every tile
+    // on `s_waitcnt vmcnt(0)`, so the ping-pong overlapped nothing).  feat is read exactly once: non-temporal, so the 0.54-GB
+    // stream does not evict the assignment fragments (read by the 16 waves that share a tile stream) from L2.
     auto load = [&](Tile& t, int tt) {
-        const float* fa = feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4;
-        const float* fb = assign_frag + (gt0 + tt) * 1024 + lane * 4;
+        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4);
+        const char* fb = reinterpret_cast<const char*>(assign_frag + (gt0 + tt) * 1024 + lane * 4);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                // read exactly once: non-temporal, so the 0.54-GB stream does not evict the assignment fragments (read
-                // by the 16 waves that share a tile stream) from L2
-                t.raw[c][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa + (size_t)c * 512 + q * 256));
-        t.rn = rnorm[(gt0 + tt) * 32 + j];
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(t.raw[c][q]) : "v"(fa + (c * 512 + q * 256) * 4));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0 + tt) * 32 + j));
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) t.bfr[ct][ks] = *reinterpret_cast<const u32x4*>(fb + (ct * 2 + ks) * 256);
+            for (int ks = 0; ks < 2; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t.bfr[ct][ks]) : "v"(fb + ((ct * 2 + ks) * 256) * 4));
+    };
+    static_assert(AGG_FT == 2, "a tile is 4 + 1 + 4 = 9 vector-memory loads: the counted wait below says 9");
+    auto landed = [&](Tile& t) {   // every load issued before the LAST 9 has returned
+        asm volatile("s_waitcnt vmcnt(9)"
+                     : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.rn), "+v"(t.bfr[0][0]),
+                       "+v"(t.bfr[0][1]), "+v"(t.bfr[1][0]), "+v"(t.bfr[1][1])
+                     :
+                     : "memory");
     };
     // Transposition lane = point -> lane = channel: every lane stores its 4-channel groups (8 bytes) into a
     // [point][channel] image and the A fragments (lane = channel, 8 consecutive points) come back through the hardware
@@ -903,12 +913,18 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
         }
     };
     Tile t0, t1;
-    if (per > 0) load(t0, 0);
-    for (int tt = 0; tt < per; tt += 2) {
-        if (tt + 1 < per) load(t1, tt + 1);
-        process(t0);
-        if (tt + 2 < per) load(t0, tt + 2);
-        if (tt + 1 < per) process(t1);
+    const int per_u = __builtin_amdgcn_readfirstlane(per);   // wave-uniform
+    if (per_u > 0) {
+        load(t0, 0);
+        for (int tt = 0; tt < per_u; tt += 2) {
+            load(t1, min(tt + 1, per_u - 1));     // (always 9 loads: past the end the last tile is requested again)
+            landed(t0);
+            process(t0);
+            load(t0, min(tt + 2, per_u - 1));
+            landed(t1);
+            if (tt + 1 < per_u) process(t1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's spare request
     }
 
     // ---- the two halves meet: V = (first + second) * 2^-14 - a_sum * centres, column sums of squares ----
