@@ -924,7 +924,14 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
             landed(t1);
             if (tt + 1 < per_u) process(t1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's spare request
+        // the tail's spare request is still in flight: the drain names both tiles' registers so that the compiler cannot hand them
+        // to the epilogue before the returning loads have written them
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(t0.raw[0][0]), "+v"(t0.raw[0][1]), "+v"(t0.raw[1][0]), "+v"(t0.raw[1][1]), "+v"(t0.rn), "+v"(t0.bfr[0][0]),
+                       "+v"(t0.bfr[0][1]), "+v"(t0.bfr[1][0]), "+v"(t0.bfr[1][1]), "+v"(t1.raw[0][0]), "+v"(t1.raw[0][1]), "+v"(t1.raw[1][0]),
+                       "+v"(t1.raw[1][1]), "+v"(t1.rn), "+v"(t1.bfr[0][0]), "+v"(t1.bfr[0][1]), "+v"(t1.bfr[1][0]), "+v"(t1.bfr[1][1])
+                     :
+                     : "memory");
     }
 
     // ---- the two halves meet: V = (first + second) * 2^-14 - a_sum * centres, column sums of squares ----
@@ -1017,8 +1024,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     const int fg = fgi * 4 + (wave & 3);
     const int sp = wave >> 2;
     const int tiles = n / 32, half = (tiles + 1) / 2;
-    const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
-    const size_t gt0 = (size_t)cloud * tiles + t_begin;
+    const int per = sp ? tiles - half : half;
 
     {
         const int t8 = (tiles + 7) / 8, ta = wave * t8, tb = min(tiles, ta + t8);
@@ -1042,40 +1048,42 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][0][r] = acc[t][1][r] = 0.f;
 
+    // A tile in a wave's registers is its `feat` bytes (HBM, read once).  The tile's ASSIGNMENT fragments (8 KB) are the same for
+    // the four waves of a half (same tiles, other features): each of the four brings a quarter of them into LDS by LDS-DMA and all
+    // four read them there -- as per-wave global loads they were 53 % of the kernel's load traffic (1.07 GB through L2 per launch
+    // beside the 0.8 GB of feat) and cost it 0.035 of its 0.19 ms (ablation: every wave re-reading one L1-hot fragment tile).
+    // Three LDS slots per half (aliasing the exchange buffer of the epilogue), one workgroup barrier per tile: a wave may run one
+    // tile ahead of the slowest, and the slot it fills (t + 2) is neither the one being read (t) nor the one landed (t + 1).
     struct Tile {
         u32x4 raw[AGG_FT][3];  // [chunk][piece]: the lane's 16 three-byte values of a chunk (value 4r + e = channel 8r + 4h + e of point j)
-        u32x4 bfr[2][2][2];    // [cluster tile][k-step][hi, lo]
         float rn;
     };
-    // A tile's 15 loads are inline asm and their completion a hand-counted s_waitcnt (the idiom of conv5's W5 stream): written
-    // as C++ loads, hipcc 7.2 either ends process(t) on `s_waitcnt vmcnt(0)` -- the conditional prefetch sat in exec-masked
-    // branches and its wait bookkeeping merges the paths -- or, with unconditional loads, sinks them below the other tile's
-    // processing to save registers.  Either way the ping-pong overlapped nothing and the kernel read at 4.7 TB/s.  Loads
-    // return in issue order, so with a tile's 15 loads issued after the previous tile's, `vmcnt(15)` is "the previous tile has
-    // landed"; the wait names the tile's registers as operands so that no use can be scheduled above it.
-    auto ld16 = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); };
-    auto ld16nt = [](u32x4& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p)); };
-    auto load = [&](Tile& t, int tt) {
-        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4);
-        const char* fb = reinterpret_cast<const char*>(assign_frag + (gt0 + tt) * 2048 + lane * 4);
+    const int sp_u = __builtin_amdgcn_readfirstlane(sp), w3_u = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int per_u = __builtin_amdgcn_readfirstlane(per);
+    const size_t gt0_u = (size_t)cloud * tiles + (sp_u ? half : 0);
+    float* stg = xch + sp_u * (3 * 2048);                       // [3 slots][2048 floats] of this half
+    const unsigned stg_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)stg;
+    // A tile's 9 vector-memory operations (6 feat loads, rnorm, 2 LDS-DMA pieces) are inline asm and their completion a
+    // hand-counted s_waitcnt: as C++ loads hipcc 7.2 ended every tile on `s_waitcnt vmcnt(0)` (its wait bookkeeping merges the
+    // exec-masked prefetch branches) and the ping-pong overlapped nothing.  Operations complete in issue order, so `vmcnt(9)`
+    // after the NEXT tile's 9 are issued is "this tile has landed".
+    auto load = [&](Tile& t, int tt, int slot) {
+        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0_u + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) ld16nt(t.raw[c][q], fa + (c * 768 + q * 256) * 4);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0 + tt) * 32 + j));
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int part = 0; part < 2; ++part) ld16(t.bfr[ct][ks][part], fb + (((ct * 2 + ks) * 2 + part) * 256) * 4);
+            for (int q = 0; q < 3; ++q)
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(t.raw[c][q]) : "v"(fa + (c * 768 + q * 256) * 4));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0_u + tt) * 32 + j));
+        const float* fb = assign_frag + (gt0_u + tt) * 2048 + (2 * w3_u) * 256;      // this wave's two 1-KB pieces of the tile
+        glds16(fb, lane * 16, stg_lds + 4u * (slot * 2048 + (2 * w3_u) * 256));
+        glds16(fb + 256, lane * 16, stg_lds + 4u * (slot * 2048 + (2 * w3_u + 1) * 256));
     };
-    static_assert(AGG_FT == 2, "a tile is 6 + 1 + 8 = 15 vector-memory loads: the counted waits below say 15");
-    auto landed = [&](Tile& t) {   // every load issued before the LAST 15 has returned
-        asm volatile("s_waitcnt vmcnt(15)"
+    static_assert(AGG_FT == 2, "a tile is 6 + 1 + 2 = 9 vector-memory operations: the counted wait below says 9");
+    auto landed = [&](Tile& t) {
+        asm volatile("s_waitcnt vmcnt(9)"
                      : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[0][2]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.raw[1][2]),
-                       "+v"(t.rn), "+v"(t.bfr[0][0][0]), "+v"(t.bfr[0][0][1]), "+v"(t.bfr[0][1][0]), "+v"(t.bfr[0][1][1]),
-                       "+v"(t.bfr[1][0][0]), "+v"(t.bfr[1][0][1]), "+v"(t.bfr[1][1][0]), "+v"(t.bfr[1][1][1])
+                       "+v"(t.rn)
                      :
                      : "memory");
     };
@@ -1092,7 +1100,16 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, both);
     };
-    auto process = [&](const Tile& t) {
+    auto process = [&](const Tile& t, int slot) {
+        const float* fbl = stg + slot * 2048 + lane * 4;
+        u32x4 bfr[2][2][2];    // [cluster tile][k-step][hi, lo]: this tile's assignment fragments, from the half's LDS slot
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    bfr[ct][ks][part] = *reinterpret_cast<const u32x4*>(fbl + ((ct * 2 + ks) * 2 + part) * 256);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c) {
 #pragma unroll
@@ -1120,7 +1137,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
                 const bf16x8 ah = tr_read(img_hi, ks), al = tr_read(img_lo, ks);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, t.bfr[ct][ks][0]), bl = __builtin_bit_cast(bf16x8, t.bfr[ct][ks][1]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bfr[ct][ks][0]), bl = __builtin_bit_cast(bf16x8, bfr[ct][ks][1]);
                     acc[c][ct] = mfma_bf16(al, bh, acc[c][ct]);
                     acc[c][ct] = mfma_bf16(ah, bl, acc[c][ct]);
                     acc[c][ct] = mfma_bf16(ah, bh, acc[c][ct]);
@@ -1129,18 +1146,34 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         }
     };
     Tile t0, t1;
-    const int per_u = __builtin_amdgcn_readfirstlane(per);   // wave-uniform
-    if (per_u > 0) {
-        load(t0, 0);
-        for (int tt = 0; tt < per_u; tt += 2) {
-            load(t1, min(tt + 1, per_u - 1));     // (always 15 loads: past the end the last tile is requested again)
+    {
+        // every wave of the workgroup walks `half` (the longer half's) tiles and meets the others at one barrier per tile; a wave
+        // whose own half is shorter requests its last tile again and skips the processing.  Loads are unconditional.
+        const int last = max(per_u - 1, 0);
+        const bool any = per_u > 0;                                 // (a one-tile cloud leaves the second half without work)
+        if (any) load(t0, 0, 0);
+        for (int tt = 0; tt < half; tt += 2) {
+            if (any) load(t1, min(tt + 1, last), (tt + 1) % 3);
             landed(t0);
-            process(t0);
-            load(t0, min(tt + 2, per_u - 1));
+            __builtin_amdgcn_s_barrier();                           // the four waves' DMA pieces of tile tt are in LDS
+            asm volatile("" ::: "memory");                          // (the raw barrier is no compiler fence: keep the LDS reads below it)
+            if (tt < per_u) process(t0, tt % 3);
+            if (any) load(t0, min(tt + 2, last), (tt + 2) % 3);
             landed(t1);
-            if (tt + 1 < per_u) process(t1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tt + 1 < per_u) process(t1, (tt + 1) % 3);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's spare request
+        // The tail's spare requests are still in flight: their destination registers are dead to the compiler -- it would hand
+        // them to the epilogue, and the returning loads would overwrite its values.  The drain names both tiles' registers, so they
+        // stay allocated until it has executed.  (The spare DMA pieces target LDS slots the epilogue's exchange buffer aliases.)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(t0.raw[0][0]), "+v"(t0.raw[0][1]), "+v"(t0.raw[0][2]), "+v"(t0.raw[1][0]), "+v"(t0.raw[1][1]), "+v"(t0.raw[1][2]),
+                       "+v"(t0.rn), "+v"(t1.raw[0][0]), "+v"(t1.raw[0][1]), "+v"(t1.raw[0][2]), "+v"(t1.raw[1][0]), "+v"(t1.raw[1][1]),
+                       "+v"(t1.raw[1][2]), "+v"(t1.rn)
+                     :
+                     : "memory");
+        __syncthreads();
     }
 
     static_assert(AGG_FT == 2, "one chunk per half in the epilogue");
