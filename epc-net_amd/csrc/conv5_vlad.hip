@@ -816,8 +816,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     const int fg = fgi * 4 + (wave & 3);         // group of AGG_FT chunks (32 features each): 64 features, 16 groups
     const int sp = wave >> 2;                    // which half of the cloud's tiles
     const int tiles = n / 32, half = (tiles + 1) / 2;
-    const int t_begin = sp ? half : 0, per = sp ? tiles - half : half;
-    const size_t gt0 = (size_t)cloud * tiles + t_begin;
+    const int per = sp ? tiles - half : half;
 
     // a_sum partials (loupe.py:276): wave w adds the per-tile sums of its eighth of the tiles, 8 loads in flight
     {
@@ -845,36 +844,33 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     // Ping-pong over the tiles: tile t+1's loads (4 KB of feat, 4 KB of assignment fragments per wave) are issued before
     // tile t is scaled, transposed and multiplied, so the wave always has a tile in flight (a pure streaming read reaches
     // 6.9 TB/s on this device with as little as 16 KB in flight per CU -- scripts/probe/read_bw.hip).
+    // A tile in a wave's registers is its `feat` bytes (HBM, read once, non-temporal).  The tile's assignment fragments (4 KB)
+    // are the same for the four waves of a half: each brings one 1-KB piece into LDS by LDS-DMA and all four read them there
+    // (three slots per half aliasing the epilogue's exchange buffer, one workgroup barrier per tile; vlad_aggregate_f32_kernel
+    // has the reasoning and the hazard analysis).  The 6 vector-memory operations of a tile are inline asm, their completion a
+    // hand-counted s_waitcnt.
     struct Tile {
         u32x4 raw[AGG_FT][2];  // [chunk][s']
-        u32x4 bfr[2][2];       // [cluster tile][k-step]
         float rn;
     };
-    // The tile's 9 loads are inline asm with a hand-counted wait (see vlad_aggregate_f32_kernel: the C++ form ended every tile
-    // on `s_waitcnt vmcnt(0)`, so the ping-pong overlapped nothing).  feat is read exactly once: non-temporal, so the 0.54-GB
-    // stream does not evict the assignment fragments (read by the 16 waves that share a tile stream) from L2.
-    auto load = [&](Tile& t, int tt) {
-        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0 + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4);
-        const char* fb = reinterpret_cast<const char*>(assign_frag + (gt0 + tt) * 1024 + lane * 4);
+    const int sp_u = __builtin_amdgcn_readfirstlane(sp), w3_u = __builtin_amdgcn_readfirstlane(wave & 3);
+    const int per_u = __builtin_amdgcn_readfirstlane(per);
+    const size_t gt0_u = (size_t)cloud * tiles + (sp_u ? half : 0);
+    float* stg = xch + sp_u * (3 * 1024);                       // [3 slots][1024 floats] of this half
+    const unsigned stg_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)stg;
+    auto load = [&](Tile& t, int tt, int slot) {
+        const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0_u + tt) * 32 + (size_t)fg * AGG_FT) * 512 + lane * 4);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(t.raw[c][q]) : "v"(fa + (c * 512 + q * 256) * 4));
-        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0 + tt) * 32 + j));
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t.bfr[ct][ks]) : "v"(fb + ((ct * 2 + ks) * 256) * 4));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0_u + tt) * 32 + j));
+        glds16(assign_frag + (gt0_u + tt) * 1024 + w3_u * 256, lane * 16, stg_lds + 4u * (slot * 1024 + w3_u * 256));
     };
-    static_assert(AGG_FT == 2, "a tile is 4 + 1 + 4 = 9 vector-memory loads: the counted wait below says 9");
-    auto landed = [&](Tile& t) {   // every load issued before the LAST 9 has returned
-        asm volatile("s_waitcnt vmcnt(9)"
-                     : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.rn), "+v"(t.bfr[0][0]),
-                       "+v"(t.bfr[0][1]), "+v"(t.bfr[1][0]), "+v"(t.bfr[1][1])
-                     :
-                     : "memory");
+    static_assert(AGG_FT == 2, "a tile is 4 + 1 + 1 = 6 vector-memory operations: the counted wait below says 6");
+    auto landed = [&](Tile& t) {   // every operation issued before the LAST 6 has completed
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.rn) : : "memory");
     };
     // Transposition lane = point -> lane = channel: every lane stores its 4-channel groups (8 bytes) into a
     // [point][channel] image and the A fragments (lane = channel, 8 consecutive points) come back through the hardware
@@ -885,7 +881,13 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
     const int li = lane & 15;
     // transposing-read address of this lane: block row q = li >> 2 (point), columns 16*((lane >> 4) & 1) + 4*(li & 3)
     const int tr_off = (8 * h + (li >> 2)) * AGG_ROW + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
-    auto process = [&](const Tile& t) {
+    auto process = [&](const Tile& t, int slot) {
+        const float* fbl = stg + slot * 1024 + lane * 4;
+        u32x4 bfr[2][2];       // [cluster tile][k-step]: this tile's assignment fragments, from the half's LDS slot
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[ct][ks] = *reinterpret_cast<const u32x4*>(fbl + (ct * 2 + ks) * 256);
 #pragma unroll
         for (int c = 0; c < AGG_FT; ++c) {
             // scale: element q of fragment s' is channel 16s' + 8(q>>2) + 4h + (q&3) of point j
@@ -908,30 +910,38 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_kernel(const float
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 const f16x8 af = __builtin_bit_cast(f16x8, both);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) acc[c][ct] = mfma_f16(af, __builtin_bit_cast(f16x8, t.bfr[ct][ks]), acc[c][ct]);
+                for (int ct = 0; ct < 2; ++ct) acc[c][ct] = mfma_f16(af, __builtin_bit_cast(f16x8, bfr[ct][ks]), acc[c][ct]);
             }
         }
     };
     Tile t0, t1;
-    const int per_u = __builtin_amdgcn_readfirstlane(per);   // wave-uniform
-    if (per_u > 0) {
-        load(t0, 0);
-        for (int tt = 0; tt < per_u; tt += 2) {
-            load(t1, min(tt + 1, per_u - 1));     // (always 9 loads: past the end the last tile is requested again)
+    {
+        // every wave of the workgroup walks `half` (the longer half's) tiles and meets the others at one barrier per tile; a wave
+        // whose own half is shorter requests its last tile again and skips the processing.  Loads are unconditional.
+        const int last = max(per_u - 1, 0);
+        const bool any = per_u > 0;                                 // (a one-tile cloud leaves the second half without work)
+        if (any) load(t0, 0, 0);
+        for (int tt = 0; tt < half; tt += 2) {
+            if (any) load(t1, min(tt + 1, last), (tt + 1) % 3);
             landed(t0);
-            process(t0);
-            load(t0, min(tt + 2, per_u - 1));
+            __builtin_amdgcn_s_barrier();                           // the four waves' DMA pieces of tile tt are in LDS
+            asm volatile("" ::: "memory");                          // (the raw barrier is no compiler fence: keep the LDS reads below it)
+            if (tt < per_u) process(t0, tt % 3);
+            if (any) load(t0, min(tt + 2, last), (tt + 2) % 3);
             landed(t1);
-            if (tt + 1 < per_u) process(t1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tt + 1 < per_u) process(t1, (tt + 1) % 3);
         }
-        // the tail's spare request is still in flight: the drain names both tiles' registers so that the compiler cannot hand them
-        // to the epilogue before the returning loads have written them
+        // the tail's spare requests are still in flight: the drain names both tiles' registers so that the compiler cannot hand
+        // them to the epilogue before the returning loads have written them (the spare DMA pieces target LDS slots the epilogue's
+        // exchange buffer aliases: hence the barrier)
         asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(t0.raw[0][0]), "+v"(t0.raw[0][1]), "+v"(t0.raw[1][0]), "+v"(t0.raw[1][1]), "+v"(t0.rn), "+v"(t0.bfr[0][0]),
-                       "+v"(t0.bfr[0][1]), "+v"(t0.bfr[1][0]), "+v"(t0.bfr[1][1]), "+v"(t1.raw[0][0]), "+v"(t1.raw[0][1]), "+v"(t1.raw[1][0]),
-                       "+v"(t1.raw[1][1]), "+v"(t1.rn), "+v"(t1.bfr[0][0]), "+v"(t1.bfr[0][1]), "+v"(t1.bfr[1][0]), "+v"(t1.bfr[1][1])
+                     : "+v"(t0.raw[0][0]), "+v"(t0.raw[0][1]), "+v"(t0.raw[1][0]), "+v"(t0.raw[1][1]), "+v"(t0.rn), "+v"(t1.raw[0][0]),
+                       "+v"(t1.raw[0][1]), "+v"(t1.raw[1][0]), "+v"(t1.raw[1][1]), "+v"(t1.rn)
                      :
                      : "memory");
+        __syncthreads();
     }
 
     // ---- the two halves meet: V = (first + second) * 2^-14 - a_sum * centres, column sums of squares ----
