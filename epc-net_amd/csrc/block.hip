@@ -233,16 +233,29 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int g = g0 + 4 * s + p;
+#ifdef BLK_ABL_NOIDX   // timing only
+        const int c = 20;
+#else
         const int c = cnt[g];
+#endif
         const bool ovf = c > cap;
         // every row holds >= 20 valid entries (cnt >= 20 by construction); ties beyond 20 are the rare tail
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ovf) {
             int nb[EPC_KNN_SELECT];
+#ifdef BLK_ABL_NOIDX
+#pragma unroll
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) nb[m] = 0;
+#else
             load_nb20(reinterpret_cast<const char*>(idx), (unsigned)(wg0 + 4 * s + p), cap, u16, nb);
+#endif
             float4 v[EPC_KNN_SELECT];
 #pragma unroll
+#ifdef BLK_ABL_NOGATHER   // timing only: every neighbour row = the point's own row (L1-resident after the first)
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(g - cloud_base + 0 * nb[m]);
+#else
             for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(nb[m]);
+#endif
 #pragma unroll
             for (int m = 0; m < EPC_KNN_SELECT; ++m) {  // ascending j, one rounding per add
                 acc.x += v[m].x;
@@ -294,10 +307,17 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     f16x8 bh[4], bl[4];
     f32x16 a1[2], a2[2];
     float inv_row = stage_to_bop(st, bh, bl, lane);
+#ifdef BLK_ABL_NOLAYERS   // timing only
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a2[t][r] = inv_row + (float)r;
+#else
     layer_s64(wa, ba, tia, bh, bl, inv_row, a1, lane);
     relu16(a1[0]);
     relu16(a1[1]);
     layer_acc64(wb, bb, tib, a1, a2, lane);
+#endif
     relu16(a2[0]);
     relu16(a2[1]);
 
