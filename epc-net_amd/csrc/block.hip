@@ -251,7 +251,9 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
 #endif
             float4 v[EPC_KNN_SELECT];
 #pragma unroll
-#ifdef BLK_ABL_NOGATHER   // timing only: every neighbour row = the point's own row (L1-resident after the first)
+#ifdef BLK_ABL_LDSGATHER   // timing only: every neighbour row read from LDS (the weight pack's bytes stand in for a row cache)
+            for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = ld4(lds + (((unsigned)nb[m] % 180u) * 64 + q * 4));
+#elif defined(BLK_ABL_NOGATHER)   // timing only: every neighbour row = the point's own row (L1-resident after the first)
             for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(g - cloud_base + 0 * nb[m]);
 #else
             for (int m = 0; m < EPC_KNN_SELECT; ++m) v[m] = row32(nb[m]);
