@@ -11,6 +11,9 @@ batch 64 x 4096 x 3 fp32 per GPU, NetVLAD K=64, 256-D output; inputs are residen
 Descriptor extraction shards over GPUs with no data-path collective (clouds are independent in inference)
 -> weak scaling; value = clouds all ranks processed / max-over-ranks time.
 
+--steps K: the timed region is K steps between fences (barrier + synchronize, max over ranks); it is repeated --regions
+times (default 7) and `value` / `ms_per_step` are the MEDIAN region's, `regions` holds min / max.
+
 `value` / `dtype` / `roofline` belong to EPC_PRECISION_F32 (include/epcnet.h): the f32-equivalent arithmetic (conv layers:
 both MFMA operands scaled by a per-row / per-column power of two and split into fp16 hi + lo, three products, f32 accumulate
 = 2^-21 per product; f32 tensors in HBM) -- the arithmetic class of the reference's float32 graph, the one that meets the
@@ -33,10 +36,11 @@ Objects on the JSON line:
                                FRESH tuple every step (the loss stays non-zero), HIP-graph replay at N = 1, data-parallel over
                                tuples with one flat RCCL all-reduce at N > 1;
                epc_net_l_b256  configs[3]: EPC-Net-L inference at batch 256 per GPU, with its own roofline;
-               retrieval       configs[4]: 11 960 synthetic descriptors (23 runs x (400 + 120), Oxford scale) sharded over the
-                               ranks, ONE RCCL all-gather of the shards, every rank ranks its query shard against the full
-                               database (epc_pairwise_topk, k = 25), the (Q, 25) index lists gathered to rank 0
-                               (evaluate.py:293-332).
+               retrieval       configs[4] composed end to end (retrieval.evaluate_sharded = evaluate.py:293-332): 23 runs x
+                               (400 + 120) synthetic clouds EXTRACTED sharded over the ranks, ONE RCCL all-gather of the
+                               descriptors, every rank ranks its share of the queries against each run's database
+                               (epc_pairwise_topk, k = 25), ONE RCCL gather of the neighbour lists, recall booked on rank 0.
+                               The process group is RCCL at N = 1 as well (a world of one rank: rccl_exercised true).
   pipeline_hbm HBM bytes one step moves (PMC counters of the committed profile x launches per step) over the step time,
                against 8 TB/s -- the north_star's "fraction of the HBM roofline"; secondary, the path is not HBM-bound.
   cpu_baseline the CPU oracle (numpy restatement of the reference's dense (N,N)-mask formulation, batch = 1 cloud per
@@ -189,12 +193,53 @@ class Harness:
         self.fence()
         return self.max_over_ranks(time.perf_counter() - t0)
 
+    def timed_regions(self, fn, steps, regions):
+        """`regions` fenced regions of EXACTLY `steps` calls each (fn(region, k)); returns the sorted list of max-over-ranks
+        seconds.  The reported figure is the MEDIAN region: a --steps 20 region of this path is ~25 ms, short enough for one
+        DVFS excursion or one host hiccup to move it by several per cent, and the chip's clock differs box to box."""
+        out = []
+        for r in range(regions):
+            out.append(self.timed(lambda k: fn(r, k), steps))
+        return sorted(out)
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def lib_sha256():
+    """SHA-256 of the libepcnet_hip.so this process loaded (stamped into profiles/pmc_*_current.json at collection time)."""
+    import hashlib
+    path = pkg("lib").LIB_PATH
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+_PMC_WHY = {}
+
 
 def pmc_summary(name):
+    """A committed rocprofv3 PMC summary -- only when it was collected on THIS build of the library (scripts/
+    summarise_profiles.py stamps the .so's SHA-256 into it); otherwise None and the reason in _PMC_WHY[name]."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
+        doc = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
+        _PMC_WHY[name] = "profiles/%s is absent" % name
         return None
+    stamp = doc.get("lib_sha256")
+    if not stamp:
+        _PMC_WHY[name] = "profiles/%s carries no lib_sha256 stamp" % name
+        return None
+    if stamp != lib_sha256():
+        _PMC_WHY[name] = ("profiles/%s was collected on another build of libepcnet_hip.so (stamp %s..., loaded %s...): re-run "
+                          "scripts/collect_profiles.sh" % (name, stamp[:12], lib_sha256()[:12]))
+        return None
+    return doc
 
 
 def kernel_entry(summary, prefix):
@@ -206,7 +251,7 @@ def kernel_entry(summary, prefix):
     return None
 
 
-def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms, every, lanes):
+def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms, every, lanes, regions=1):
     """The timed region of one (arch, precision): K steps on ONE stream (stage-boundary HIP events on every `every`-th
     step), then -- separately reported -- the same K steps with `lanes` of them in flight."""
     import torch
@@ -217,7 +262,7 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
     xyz = (torch.rand((batch, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
     outs = [torch.empty((batch, 256), dtype=torch.float32, device=device) for _ in range(max(1, lanes))]
     out = outs[0]
-    profiles = {k: E.StageProfile() for k in range(0, steps, every)}
+    profiles = {(r, k): E.StageProfile() for r in range(regions) for k in range(0, steps, every)}
     scratch = E.StageProfile()
     for k in range(max(warmup, 0)):
         eng.forward(xyz, out=out, profile=scratch if k % every == 0 else None, check=False)   # the entry point the timed steps use
@@ -231,7 +276,8 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
         while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
             eng.forward(xyz, out=out, check=False)
             torch.cuda.synchronize()
-    elapsed = H.timed(lambda k: eng.forward(xyz, out=out, profile=profiles.get(k), check=False), steps)
+    region_s = H.timed_regions(lambda r, k: eng.forward(xyz, out=out, profile=profiles.get((r, k)), check=False), steps, regions)
+    elapsed = median(region_s)
     norms = out.norm(dim=1)
     if not bool(torch.isfinite(out).all()) or float((norms - 1).abs().max()) > 1e-3:
         raise SystemExit("descriptors are not unit-norm / finite: refusing to report a number")
@@ -244,7 +290,7 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
     if lanes > 1:
         for k in range(4 * lanes):
             eng.submit(xyz, out=outs[k % lanes])
-        el2 = H.timed(lambda k: eng.submit(xyz, out=outs[k % lanes]), steps)
+        el2 = median(H.timed_regions(lambda r, k: eng.submit(xyz, out=outs[k % lanes]), steps, regions))
         if not all(torch.equal(out, o) for o in outs[1:]):
             raise SystemExit("lanes disagree with the one-stream descriptors: refusing to report a number")
         overlapped = {"steps_in_flight_per_gpu": lanes, "value": round(H.world * batch * steps / el2, 2),
@@ -274,8 +320,16 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
                 "kernel": "%s (conv5 + %s), %s MFMA, f32 accumulate"
                           % (CONV5_KERNEL[key][5:], "L2 + soft-assignment" if arch == "epc-net" else "global max-pool", DTYPE[key]),
                 "avg_launch_ms": round(conv5_ms, 4), "algorithmic_flops_per_launch": conv5_flops}
+    if hbm is None or comp is None:
+        roofline["counters_unavailable"] = ("batch differs from the profiled configuration" if not std_batch else
+                                            "; ".join(sorted(set(_PMC_WHY.values()))))
     res = {"value": round(H.world * batch * steps / elapsed, 2), "unit": "clouds/s", "dtype": DTYPE[key],
-           "ms_per_step": round(elapsed / steps * 1e3, 4), "roofline": roofline,
+           "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "regions": {"count": regions, "steps_each": steps, "statistic": "median",
+                       "ms_per_step_min": round(region_s[0] / steps * 1e3, 4), "ms_per_step_max": round(region_s[-1] / steps * 1e3, 4),
+                       "value_min": round(H.world * batch * steps / region_s[-1], 2),
+                       "value_max": round(H.world * batch * steps / region_s[0], 2)},
+           "roofline": roofline,
            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
            "pipeline_tflops": round(batch * steps / elapsed * FLOPS_PER_CLOUD[arch] / 1e12, 3)}
     if overlapped is not None:
@@ -319,49 +373,92 @@ def train_step_leg(H, steps, warmup):
             "loss_mean": round(sum(loss_vals) / len(loss_vals), 5)}
 
 
-def retrieval_leg(H, steps, warmup):
-    """configs[4]: descriptors sharded over the ranks, one RCCL all-gather, local top-25, index gather."""
+def retrieval_leg(H, E, steps, warmup, rccl):
+    """configs[4] composed end to end (evaluate.py:293-332): EXTRACTION of 23 runs x (400 database + 120 query) synthetic clouds
+    sharded over the ranks -> ONE RCCL all-gather of the descriptors -> every rank ranks its share of the queries against each
+    database run (epc_pairwise_topk, k = 25) -> ONE RCCL gather of the neighbour lists -> rank 0 books recall@N / top-1 %.
+    retrieval.evaluate_sharded is the product entry point; a step = one whole evaluation."""
+    import numpy as np
     import torch
     D, R = pkg("distributed"), pkg("retrieval")
-    n_db, n_q, k = 23 * 400, 23 * 120, 25
+    runs, n_db, n_q = 23, 400, 120
     rank, world = H.rank, H.world
-    g = torch.Generator(device="cpu")
-    g.manual_seed(31)                                          # the same global set on every rank; each keeps its shard
+    store = build_store("epc-net", H.device, 0)
+    eng = E.InferenceEngine("epc-net", PARAMS, store, outer=OUTER, micro_batch=64, in_flight=1, precision="f32")
+    # the same clouds on every rank (same device generator seed, same hardware); a rank only EXTRACTS its shard.
+    # query i of run n = a jittered copy of database cloud (7 i) % 400 of run (n + 1) % 23: its true neighbour there.
+    g = torch.Generator(device=H.device)
+    g.manual_seed(4242)
+    dbs = [torch.rand((n_db, N_POINTS, 3), generator=g, device=H.device) * 2.0 - 1.0 for _ in range(runs)]
+    qs = []
+    for n in range(runs):
+        src = dbs[(n + 1) % runs][(7 * torch.arange(n_q, device=H.device)) % n_db]
+        qs.append(src + 0.002 * torch.randn((n_q, N_POINTS, 3), generator=g, device=H.device))
+    rng = np.random.RandomState(5)
+    extra = {(m, n): [list(rng.choice(n_db, size=rng.randint(0, 3), replace=False)) for _ in range(n_q)]
+             for m in range(runs) for n in range(runs) if m != n}
 
-    def unit(n):
-        v = torch.randn((n, 256), generator=g)
-        return (v / v.norm(dim=1, keepdim=True)).float()
-    db_all, q_all = unit(n_db), unit(n_q)
-    a, b = D.shard_bounds(n_db, rank, world)
-    qa, qb = D.shard_bounds(n_q, rank, world)
-    db_local, q_local = db_all[a:b].to(H.device), q_all[qa:qb].to(H.device)
-    result = {}
+    def truth(m, n):
+        t = extra[(m, n)]
+        if m == (n + 1) % runs:
+            return [[(7 * i) % n_db] + [v for v in t[i] if v != (7 * i) % n_db] for i in range(n_q)]
+        return t
 
-    def one(_k):
-        result["idx"] = D.sharded_knn(db_local, n_db, q_local, n_q, k, R.knn_search)
-
-    for i in range(warmup):
-        one(i)
-    elapsed = H.timed(one, steps)
+    extract = lambda chunk: eng.forward(chunk, check=False)
+    prev = D.force_collective(bool(rccl))                     # a world of one still issues its RCCL collectives
+    tms, result = [], {}
+    try:
+        def one(_k):
+            tm = {}
+            result["res"] = R.evaluate_sharded(extract, dbs, qs, truth if rank == 0 else None, device=H.device,
+                                               batch_size=64, timings=tm)
+            tms.append(tm)
+        for i in range(warmup):
+            one(i)
+        del tms[:]
+        elapsed = H.timed(one, steps)
+    finally:
+        D.force_collective(prev)
+    total = runs * (n_db + n_q)
+    out = None
     if rank == 0:
-        # exactness against a float64 brute force on a sample of the queries (host, after the timed region)
-        # (distances, not indices: two database rows whose float32 distances tie can order differently in float64)
-        idx = torch.as_tensor(result["idx"]).long()
-        sample = list(range(0, n_q, 97))
-        d = torch.cdist(q_all[sample].double(), db_all.double())
-        ref = torch.topk(d, k, dim=1, largest=False).values
-        got = torch.gather(d, 1, idx[sample])
-        if idx.shape != (n_q, k) or float((got - ref).abs().max()) > 1e-6:
-            raise SystemExit("retrieval leg: neighbour lists differ from the brute force: refusing to report a number")
-    gathered = (world - 1) * n_db * 256 * 4 // world if world > 1 else 0    # bytes each rank RECEIVES in the all-gather
-    ms = elapsed / steps * 1e3
-    return {"workload": "Oxford-scale retrieval, %d database + %d query descriptors (256-d, synthetic unit vectors) sharded over "
-                        "%d rank(s): all-gather of the database shards, local exact top-%d of the rank's queries, index gather "
-                        "(BASELINE.json configs[4]; evaluate.py:293-332, 463, 481)" % (n_db, n_q, world, k),
-            "rccl_ranks": world, "value": round(n_q * steps / elapsed, 1), "unit": "queries/s", "steps": steps,
-            "ms_per_step": round(ms, 4), "all_gather_bytes_received_per_rank": gathered,
-            "all_gather_GBps_per_rank_lower_bound": round(gathered / (ms * 1e-3) / 1e9, 2) if gathered else None,
-            "pair_distances_per_s": round(n_q * n_db * steps / elapsed / 1e9, 2), "pair_unit": "G pairs/s"}
+        res = result["res"]
+        # the descriptors the flow produced, ranked by a float64 brute force on a sample (host, after the timed region): the
+        # composed flow's neighbour lists must be the exact ones
+        dbv, qv = res["database_vectors"], res["query_vectors"]
+        top1 = []
+        for n in range(0, runs, 5):
+            m = (n + 1) % runs
+            d = torch.cdist(torch.from_numpy(qv[n]).double(), torch.from_numpy(dbv[m]).double())
+            top1.append(float((d.argmin(dim=1) == (7 * torch.arange(n_q)) % n_db).double().mean()))
+        if min(top1) < 0.5:
+            raise SystemExit("retrieval leg: the jittered copies are not their sources' nearest neighbours (%.3f): refusing to "
+                             "report a number" % min(top1))
+        ms = elapsed / steps * 1e3
+        agg = lambda k: round(1e3 * sum(t[k] for t in tms) / len(tms), 3)
+        gather_ms = agg("all_gather")
+        out = {"workload": "Oxford-scale evaluate(): %d runs x (%d database + %d query) synthetic clouds x %d pts = %d clouds "
+                           "extracted (EPC-Net, f32-equivalent arithmetic, batch 64) sharded over %d rank(s) -> one all-gather of the "
+                           "256-d descriptors -> exact top-25 of every query against each other run's database -> one index "
+                           "gather -> recall bookkeeping on rank 0 (BASELINE.json configs[4]; evaluate.py:293-332, 351-537; "
+                           "retrieval.evaluate_sharded)" % (runs, n_db, n_q, N_POINTS, total, world),
+               "rccl_exercised": bool(rccl), "backend": D.backend_name(), "rccl_ranks": world,
+               "value": round(total * steps / elapsed, 1), "unit": "clouds/s evaluated end to end", "steps": steps,
+               "ms_per_step": round(ms, 3),
+               "phase_ms_rank0": {"extract": agg("extract"), "all_gather": gather_ms, "rank": agg("rank"),
+                                  "index_gather": agg("index_gather"), "book_host": agg("book")},
+               "all_gather_bytes": tms[-1]["all_gather_bytes"],
+               "all_gather_GBps": round(tms[-1]["all_gather_bytes"] * (world - 1) / max(world, 1) / (gather_ms * 1e-3) / 1e9, 3)
+                                  if world > 1 and gather_ms > 0 else None,
+               "ordered_pairs": runs * (runs - 1), "queries_ranked": runs * (runs - 1) * n_q,
+               "jittered_copy_is_top1_float64_bruteforce": round(min(top1), 4),
+               "ave_recall_at_1": round(float(res["ave_recall"][0]), 4),
+               "ave_one_percent_recall": round(float(res["ave_one_percent_recall"]), 4),
+               "average_similarity": round(float(res["average_similarity"]), 6),
+               "note": "synthetic truth: query i of run n is a jittered copy of database cloud (7 i) %% 400 of run (n + 1) %% 23 "
+                       "(its top-1 there, checked against a float64 brute force) plus random sets elsewhere -- the recall "
+                       "figures check the bookkeeping, they are not Oxford Recall@1 %% (no dataset in this image)"}
+    return out
 
 
 def main():
@@ -384,6 +481,9 @@ def main():
     ap.add_argument("--cpu-clouds", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the train_step / epc_net_l_b256 / retrieval legs")
+    ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: do not create the world-of-one RCCL process group")
+    ap.add_argument("--regions", type=int, default=7,
+                    help="fenced regions of --steps steps each; value / ms_per_step = the median region (min / max reported)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -399,11 +499,27 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    # The process group is RCCL ("nccl") at every N -- at N = 1 too, a world of one rank (under torchrun --nproc-per-node 1 or
+    # a plain `python bench.py`): the retrieval leg then drives its all-gather / index gather through RCCL on device tensors
+    # exactly as the 8-GPU run does.  The extraction region's fences use the barrier only when there are ranks to wait for.
+    import torch.distributed as tdist
+    rccl, rccl_why = False, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or not args.no_rccl:
+        try:
+            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            rccl = True
+        except Exception as e:                                  # N = 1 only: the line then says so instead of dying
+            if world > 1:
+                raise
+            rccl_why = "init_process_group('nccl') failed at world 1: %r" % (e,)
+    dist = tdist if world > 1 else None
     H = Harness(device, dist, world, rank)
     E = pkg("engine")
     every = max(1, args.profile_every)
@@ -414,7 +530,7 @@ def main():
     legs = {}
     for prec in precisions:
         legs[prec], _ = extraction_leg(H, E, store, args.arch, prec, args.batch, args.steps, args.warmup, args.settle_ms,
-                                       every, lanes)
+                                       every, lanes, regions=max(1, args.regions))
     head_prec = precisions[0]
     head = legs[head_prec]
 
@@ -426,7 +542,9 @@ def main():
                                 every, 1)
         leg["workload"] = "EPC-Net-L inference, batch 256x4096x3 fp32 per GPU (BASELINE.json configs[3]; models/epc-net-l.py:29-102)"
         configs["epc_net_l_b256"] = leg
-        configs["retrieval"] = retrieval_leg(H, steps=max(5, min(20, args.steps)), warmup=3)
+        configs["retrieval"] = retrieval_leg(H, E, steps=3, warmup=1, rccl=rccl)
+        if rank == 0 and rccl_why:
+            configs["retrieval"]["rccl_unavailable"] = rccl_why
 
     # HBM bytes of ONE step = the PMC bytes per launch of the pipeline's kernels (profiles/pmc_hbm_current.json, collected
     # by scripts/collect_profiles.sh on this configuration) x their launches per step: the figure behind "fraction of the
@@ -453,6 +571,7 @@ def main():
                        "weights": "seeded random init of the architecture (no checkpoint payloads exist)",
                        "parallelism": "independent clouds sharded over %d GPU(s), no data-path collective" % world,
                        "stage_events_on_every_nth_step": every},
+            "regions": head["regions"],
             "roofline": head["roofline"], "stage_ms": head["stage_ms"], "pipeline_tflops": head["pipeline_tflops"],
         }
         if args.requested_gpus and args.requested_gpus != world:
@@ -463,6 +582,10 @@ def main():
             line["pipeline_hbm"] = {"bytes_per_step": int(hbm_step), "achieved_GBps": round(gbps, 1), "peak_GBps": 8000.0,
                                     "frac": round(gbps / 8000.0, 4),
                                     "how": "PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/) x launches per step / ms_per_step"}
+        elif args.arch == "epc-net" and args.batch == 64:
+            line["pipeline_hbm"] = None
+            line["pipeline_hbm_unavailable"] = _PMC_WHY.get("pmc_hbm_current.json", "no launch table for this arithmetic")
+        line["lib_sha256"] = lib_sha256()
         if "overlapped" in head:
             line["overlapped"] = head["overlapped"]
         if "fast" in legs and head_prec != "fast":
@@ -473,9 +596,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.arch, store if args.arch != "epc-net" or not configs else build_store(args.arch, device, 0),
                                                 args.cpu_budget_s, args.cpu_clouds)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rccl:
+        tdist.barrier()
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

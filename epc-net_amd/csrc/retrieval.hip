@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void pairwise_topk_kernel(const float* __restri
             acc += e2 * e2;
             acc += e3 * e3;
         }
-        d2[d] = acc;
+        d2[d] = acc <= 3.0e38f ? acc : INFINITY;   // NaN / overflow: never selected
     }
     __syncthreads();
     for (int r = 0; r < k; ++r) {
@@ -57,9 +57,11 @@ __global__ __launch_bounds__(64) void pairwise_topk_kernel(const float* __restri
             }
         }
         if (lane == 0) {
-            idx[(size_t)qi * k + r] = bi;
+            // fewer than k rows at a finite distance (NaN / Inf query or database rows -- the descriptors of flagged clouds):
+            // no such neighbour, index -1 at distance +Inf
+            idx[(size_t)qi * k + r] = bi < num_db ? bi : -1;
             dist[(size_t)qi * k + r] = sqrtf(best);
-            d2[bi] = INFINITY;
+            if (bi < num_db) d2[bi] = INFINITY;
         }
         __syncthreads();
     }
@@ -189,9 +191,9 @@ __device__ __forceinline__ void wave_argmin(float& best, int& bi) {
 // distances, the k best of those; flag[q] = 1 when the bracket does not prove the answer.
 __global__ __launch_bounds__(64) void select_rerank_kernel(const float* __restrict__ S, const float* __restrict__ Q,
                                                            const float* __restrict__ D, const float* __restrict__ qn,
-                                                           int nd, int dim, int k, int rows_in_lds,
-                                                           int32_t* __restrict__ idx, float* __restrict__ dist,
-                                                           int32_t* __restrict__ flag) {
+                                                           const float* __restrict__ dn_max, int nd, int dim, int k,
+                                                           int rows_in_lds, int32_t* __restrict__ idx,
+                                                           float* __restrict__ dist, int32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) float srow[];
     const int lane = threadIdx.x, qi = blockIdx.x;
     const float* grow = S + (size_t)qi * nd;
@@ -302,17 +304,50 @@ __global__ __launch_bounds__(64) void select_rerank_kernel(const float* __restri
         idx[(size_t)qi * k + rank] = my_cand < nd ? my_cand : -1;
         dist[(size_t)qi * k + rank] = sqrtf(e);
     }
-    // proof: every row outside the candidates has a GEMM value >= the last candidate's (m), hence an exact distance
-    // >= m - eps; the answer stands if the k-th exact distance is below that.  eps bounds the f32 rounding of the GEMM form
-    // (128 sequential pair-additions of the dot product, the norms, the final combination) for THIS query against any row
-    // whose norm is of the same order: 2^-14 of the magnitudes involved.
+    // Proof that no row r outside the candidates belongs to the answer.  Its GEMM value g_r is >= the last candidate's (m).
+    // With u = 2^-24 and c = (dim + 3) u (first order; the constant below carries slack):
+    //   |g_r - d2_r| <= c (sqrt(qn) + sqrt(dn_r))^2 =: E_r   (norms: <= dim u each; dot product: dim sequential f32
+    //                   accumulations, |err| <= dim u sum|q_c d_c| <= dim u sqrt(qn dn_r); the two final additions: 2 u),
+    //   exact form:     e_r >= d2_r (1 - c)                  (one rounding per difference, square and addition).
+    // E_r needs a bound that does not know r.  (a) dn_r <= dn_max, the largest finite squared norm of the database:
+    // E_r <= c (sqrt(qn) + sqrt(dn_max))^2.  (b) norm-free: if sqrt(dn_r) <= 3 sqrt(qn), E_r <= 16 c qn; otherwise
+    // sqrt(qn) + sqrt(dn_r) < 2 (sqrt(dn_r) - sqrt(qn)) <= 2 sqrt(d2_r), so E_r <= 4 c d2_r and d2_r >= m (1 - 4c):
+    // E_r <= c (16 qn + 4 m) either way.  Both hold, so the smaller applies:
+    //   e_r >= m - eps,   eps = c (min((sqrt(qn) + sqrt(dn_max))^2, 16 qn + 4 m) + m).
+    // The answer stands when the k-th exact distance is STRICTLY below m - eps (an equal distance at a lower index would
+    // win the tie).  A row whose GEMM value is +Inf (NaN / Inf descriptor) has no finite exact distance either and is
+    // never part of an answer: m = +Inf means every finite row is a candidate, nothing to prove.
     float kth_exact = (lane < kc && rank == k - 1) ? e : -INFINITY;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) kth_exact = fmaxf(kth_exact, __shfl_xor(kth_exact, off));
     const float m = __shfl(my_approx, kc - 1);
     if (lane == 0) {
-        const float eps = 6.1e-5f * (qn[qi] + m + 1e-30f);
-        flag[qi] = (kc < nd && !(kth_exact + eps < m)) ? 1 : 0;
+        int f = 0;
+        if (kc < nd && m < INFINITY) {
+            const float c = 1.05f * (float)(dim + 8) * 5.9604645e-8f;
+            const float qq = qn[qi], sq = sqrtf(qq) + sqrtf(*dn_max);
+            const float eps = c * (fminf(sq * sq, 16.0f * qq + 4.0f * m) + m) + 1e-37f;
+            f = !(kth_exact < m - eps);
+        }
+        flag[qi] = f;
+    }
+}
+
+// largest FINITE squared norm of the database rows (one workgroup; nd is 10^2 .. 10^5)
+__global__ __launch_bounds__(1024) void finite_max_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float part[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = x[i];
+        if (v <= 3.0e38f) m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, part[w]);
+        *out = m;
     }
 }
 
@@ -325,7 +360,10 @@ __global__ __launch_bounds__(64) void exact_fallback_kernel(float* __restrict__ 
     if (!flag[qi]) return;
     float* row = S + (size_t)qi * nd;
     const float* qrow = Q + (size_t)qi * dim;
-    for (int d = lane; d < nd; d += 64) row[d] = exact_d2(qrow, D + (size_t)d * dim, dim);
+    for (int d = lane; d < nd; d += 64) {
+        const float v = exact_d2(qrow, D + (size_t)d * dim, dim);
+        row[d] = v <= 3.0e38f ? v : INFINITY;      // NaN / overflow: never selected (as in select_rerank_kernel)
+    }
     __syncthreads();
     for (int r = 0; r < k; ++r) {
         float best = INFINITY;
@@ -339,9 +377,10 @@ __global__ __launch_bounds__(64) void exact_fallback_kernel(float* __restrict__ 
         }
         wave_argmin(best, bi);
         if (lane == 0) {
-            idx[(size_t)qi * k + r] = bi;
+            // fewer than k rows at a finite distance: no such neighbour (-1, +Inf) -- bi is NOT a row then, never store through it
+            idx[(size_t)qi * k + r] = bi < nd ? bi : -1;
             dist[(size_t)qi * k + r] = sqrtf(best);
-            row[bi] = INFINITY;
+            if (bi < nd) row[bi] = INFINITY;
         }
         __syncthreads();
     }
@@ -358,7 +397,8 @@ static int rt_chunk(int num_db, int num_q) {
 extern "C" size_t epc_pairwise_topk_workspace_bytes(int num_db, int num_q) {
     if (num_db <= 0 || num_q <= 0) return 0;
     const int ch = rt_chunk(num_db, num_q);
-    return rt_align((size_t)ch * num_db * 4) + rt_align((size_t)num_db * 4) + rt_align((size_t)num_q * 4) + rt_align((size_t)num_q * 4);
+    return rt_align((size_t)ch * num_db * 4) + rt_align((size_t)num_db * 4) + rt_align((size_t)num_q * 4) + rt_align((size_t)num_q * 4) +
+           rt_align(4);
 }
 
 extern "C" int epc_pairwise_topk_ws(const float* database, int num_db, const float* queries, int num_q, int dim, int k,
@@ -381,9 +421,12 @@ extern "C" int epc_pairwise_topk_ws(const float* database, int num_db, const flo
     float* qn = (float*)w;
     w += rt_align((size_t)num_q * 4);
     int32_t* flag = (int32_t*)w;
+    w += rt_align((size_t)num_q * 4);
+    float* dn_max = (float*)w;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(rownorm2_kernel, dim3((num_db + 3) / 4), dim3(256), 0, st, database, num_db, dim, dn);
     hipLaunchKernelGGL(rownorm2_kernel, dim3((num_q + 3) / 4), dim3(256), 0, st, queries, num_q, dim, qn);
+    hipLaunchKernelGGL(finite_max_kernel, dim3(1), dim3(1024), 0, st, dn, num_db, dn_max);
     EPC_CHECK_LAUNCH();
     const int in_lds = (size_t)num_db * 4 <= 149 * 1024;
     const size_t lds_bytes = (in_lds ? (((size_t)num_db + 3) & ~(size_t)3) * 4 : 0) + 4 * 64 * 4;   // the row (if it fits) + the selection's 4 x 64 words
@@ -398,7 +441,7 @@ extern "C" int epc_pairwise_topk_ws(const float* database, int num_db, const flo
         const float* Qc = queries + (size_t)q0 * dim;
         hipLaunchKernelGGL(pairdist_gemm_kernel, dim3((num_db + 127) / 128, (nq + 127) / 128), dim3(256), 0, st, Qc, database,
                            qn + q0, dn, nq, num_db, dim, S);
-        hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(64), lds_bytes, st, S, Qc, database, qn + q0, num_db, dim, k,
+        hipLaunchKernelGGL(select_rerank_kernel, dim3(nq), dim3(64), lds_bytes, st, S, Qc, database, qn + q0, dn_max, num_db, dim, k,
                            in_lds, idx + (size_t)q0 * k, dist + (size_t)q0 * k, flag + q0);
         hipLaunchKernelGGL(exact_fallback_kernel, dim3(nq), dim3(64), 0, st, S, Qc, database, num_db, dim, k, flag + q0,
                            idx + (size_t)q0 * k, dist + (size_t)q0 * k);

@@ -33,6 +33,31 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+# Single-rank runs skip every collective (there is nothing to exchange).  ``force_collective(True)`` makes the helpers below
+# issue their collectives even in a world of ONE rank, provided a process group exists: this is how the RCCL code the
+# 8-GPU runs depend on (all_gather_into_tensor / all_reduce / broadcast on device tensors, backend "nccl") is executed and
+# tested on a 1-GPU box -- same calls, same buffers, a degenerate ring.
+_FORCE_COLLECTIVE = False
+
+
+def force_collective(on: bool = True) -> bool:
+    """Returns the previous setting."""
+    global _FORCE_COLLECTIVE
+    prev, _FORCE_COLLECTIVE = _FORCE_COLLECTIVE, bool(on)
+    return prev
+
+
+def collectives_active() -> bool:
+    """True when the helpers of this module talk to the process group: world > 1, or a world of one with force_collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _FORCE_COLLECTIVE
+
+
+def backend_name() -> Optional[str]:
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous, balanced shards: the first (n % world) ranks hold one extra row.  [start, stop)."""
     q, r = divmod(n, world_size)
@@ -48,18 +73,36 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """All-gather row shards laid out by ``shard_bounds`` into the full (n_total, ...) tensor on every rank.
     Shards are padded to the largest shard so that ONE equal-size all-gather moves everything."""
     rank, ws = world()
-    if ws == 1:
+    if not collectives_active():
         assert local.shape[0] == n_total
         return local
-    sizes = shard_sizes(n_total, ws)
-    assert local.shape[0] == sizes[rank], "local shard has %d rows, expected %d" % (local.shape[0], sizes[rank])
+    return all_gather_var_rows(local, shard_sizes(n_total, ws))
+
+
+def all_gather_var_rows(local: torch.Tensor, sizes: Sequence[int]) -> torch.Tensor:
+    """All-gather of row blocks of KNOWN, possibly different sizes (``sizes[r]`` rows on rank r; every rank can compute the
+    list, so no size exchange is needed) into their concatenation in rank order.  ONE equal-size ``all_gather_into_tensor``:
+    blocks are padded to the largest one; when the blocks are equal nothing is padded or re-packed."""
+    rank, ws = world()
+    sizes = [int(v) for v in sizes]
+    assert len(sizes) == ws and local.shape[0] == sizes[rank], \
+        "local block has %d rows, expected %d" % (local.shape[0], sizes[rank])
+    if not collectives_active():
+        return local
     m = max(sizes)
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    out = torch.empty((ws * m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
-    parts = [out[r * m: r * m + sizes[r]] for r in range(ws)]
-    return torch.cat(parts, dim=0)
+    tail = tuple(local.shape[1:])
+    if m == 0:
+        return local
+    if sizes[rank] == m:
+        send = local.contiguous()
+    else:
+        send = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+        send[: sizes[rank]] = local
+    out = torch.empty((ws * m,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send)
+    if min(sizes) == m:
+        return out
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(ws)], dim=0)
 
 
 def extract_shard(extract: Callable[[object], torch.Tensor], clouds) -> Tuple[torch.Tensor, int]:
@@ -79,7 +122,7 @@ def sharded_knn(database_local: torch.Tensor, n_db: int, queries_local: torch.Te
     database = all_gather_rows(database_local, n_db)
     _, idx = search(database, queries_local, k)
     idx = idx.to(torch.int32)
-    if ws == 1:
+    if not collectives_active():
         return idx.cpu().numpy()
     full = all_gather_rows(idx, n_q)       # (n_q, k) everywhere; tiny (25 ints per query)
     return full.cpu().numpy() if rank == 0 else None
@@ -90,7 +133,7 @@ def all_reduce_gradients(tensors: Sequence[torch.Tensor], bucket_bytes: int = 32
     ``bucket_bytes`` (default 32 MB: the whole 18.8-MB EPC-Net gradient is ONE message).  Order and shapes must be the
     same on every rank.  No-op in a single process."""
     rank, ws = world()
-    if ws == 1 or not tensors:
+    if not collectives_active() or not tensors:
         return
     bucket: List[torch.Tensor] = []
     size = 0
@@ -122,7 +165,7 @@ def all_reduce_gradients(tensors: Sequence[torch.Tensor], bucket_bytes: int = 32
 def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0) -> None:
     """In-place broadcast of a list of same-dtype tensors from rank ``src`` as ONE flat message.  No-op in a single process."""
     rank, ws = world()
-    if ws == 1 or not tensors:
+    if not collectives_active() or not tensors:
         return
     flat = torch.cat([t.detach().reshape(-1) for t in tensors])
     dist.broadcast(flat, src=src)
@@ -138,8 +181,10 @@ def all_true(flag: bool, device=None) -> bool:
     a training iteration together when ANY rank drew a faulty tuple, so that no rank waits in a collective the others never
     enter.  Single process: the flag itself."""
     rank, ws = world()
-    if ws == 1:
+    if not collectives_active():
         return bool(flag)
+    if device is None and backend_name() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())       # RCCL moves device memory only
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t.item()))

@@ -5,6 +5,9 @@
   knn_search           evaluate.py:463,481  sklearn KDTree(database).query(q, k=25) -> epc_pairwise_topk on the GPU
   get_recall           evaluate.py:455-537  recall@1..25, top-1 % recall, top-1 similarity for one (m, n) run pair
   evaluate_runs        evaluate.py:293-332  average over all ordered pairs m != n
+  evaluate_sharded     evaluate.py:293-332 end to end over the ranks of a process group (BASELINE.json configs[4]):
+                       extraction of every run sharded over the ranks -> ONE all-gather of the descriptors -> every rank
+                       ranks its share of the queries -> ONE index gather -> rank 0 books the recall
   write_results        evaluate.py:336-348  results.txt
 """
 from __future__ import annotations
@@ -25,6 +28,14 @@ def get_latent_vectors(engine, clouds, batch_size: int = 64, device: Optional[to
     launches are asynchronous, so the 48 KB per cloud of batch i+1 cross PCIe while batch i is being extracted
     (measured from pageable host memory: 55 k clouds/s vs 61 k device-resident; a pinned double-buffer pipeline with a
     copy stream was tried and is not faster)."""
+    out = latent_vectors_device(engine, clouds, batch_size, device)
+    if out.shape[0]:
+        torch.cuda.synchronize(out.device)
+    return out.cpu().numpy()
+
+
+def latent_vectors_device(engine, clouds, batch_size: int = 64, device: Optional[torch.device] = None) -> torch.Tensor:
+    """``get_latent_vectors`` without the trip to the host: (n, 256) float32 on the device, asynchronous."""
     dev = device or (clouds.device if torch.is_tensor(clouds) and clouds.is_cuda
                      else torch.device("cuda", torch.cuda.current_device()))
     n = int(clouds.shape[0])
@@ -32,9 +43,7 @@ def get_latent_vectors(engine, clouds, batch_size: int = 64, device: Optional[to
     for i in range(0, n, batch_size):
         chunk = torch.as_tensor(clouds[i:i + batch_size], dtype=torch.float32).to(dev, non_blocking=True)
         engine.forward(chunk, out=out[i:i + chunk.shape[0]])
-    if n:
-        torch.cuda.synchronize(dev)
-    return out.cpu().numpy()
+    return out
 
 
 def knn_search(database: torch.Tensor, queries: torch.Tensor, k: int = NUM_NEIGHBORS) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -78,6 +87,8 @@ def recall_from_indices(indices: np.ndarray, database_output: np.ndarray, querie
         ind = indices[i]
         truth_set = set(int(t) for t in truth)
         for j in range(len(ind)):                                         # :512-521
+            if int(ind[j]) < 0:       # no such neighbour: fewer than k finite database rows (e.g. a NaN query descriptor)
+                continue
             if int(ind[j]) in truth_set:
                 if j == 0:
                     top1_similarity_score.append(float(np.dot(queries_output[i], database_output[ind[j]])))
@@ -134,6 +145,147 @@ def evaluate_runs(database_vectors: Sequence[np.ndarray], query_vectors: Sequenc
             similarity.extend(pair_sim)
     return {"ave_recall": recall / count, "average_similarity": float(np.mean(similarity)) if similarity else float("nan"),
             "ave_one_percent_recall": float(np.mean(one_percent))}
+
+
+class _Sliced:
+    """Rows [a, b) of the concatenation of several (n_i, N, 3) arrays, without building the concatenation."""
+
+    def __init__(self, parts: Sequence, a: int, b: int):
+        self.parts, self.a, self.b = parts, a, b
+        self.starts = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
+
+    def chunks(self, batch: int):
+        at = self.a
+        while at < self.b:
+            r = int(np.searchsorted(self.starts, at, side="right") - 1)
+            stop = min(self.b, int(self.starts[r + 1]), at + batch)
+            yield self.parts[r][at - int(self.starts[r]): stop - int(self.starts[r])]
+            at = stop
+
+
+def evaluate_sharded(extract: Callable, database_sets: Sequence, query_sets: Sequence,
+                     truth: Optional[Callable[[int, int], Sequence[Sequence[int]]]], device=None, search=None,
+                     batch_size: int = 64, timings: Optional[dict] = None) -> Optional[Dict[str, object]]:
+    """The reference's whole ``evaluate()`` (evaluate.py:293-332: extract every run, rank every ordered pair of runs,
+    average) as ONE rank-aware flow (BASELINE.json configs[4]).  Call it on every rank of the process group
+    (or in a single process) with the same arguments:
+
+      1. the clouds of ALL runs -- ``database_sets[m]`` (n_m, N, 3) then ``query_sets[n]`` -- form one list that is sharded
+         contiguously over the ranks; ``extract(chunk (b, N, 3)) -> (b, 256) device tensor`` runs on this rank's shard in
+         chunks of ``batch_size`` (e.g. ``lambda x: engine.forward(torch.as_tensor(x).to(dev))``): no collective,
+         inference-mode descriptors are independent;
+      2. ONE fused all-gather of the descriptor shards (not one per run): every rank holds all database and query descriptors
+         (Oxford scale: 23 x (400 + 120) x 1 KB = 12 MB);
+      3. for every database run m the queries of all the other runs are ranked against it; each rank searches ITS contiguous
+         share of those queries (``search(db, q, 25)``, default ``knn_search`` = epc_pairwise_topk);
+      4. ONE gather of the (q, 25) int32 neighbour lists of all runs;
+      5. rank 0 books recall@N / top-1 % / similarity per ordered pair exactly as ``evaluate_runs`` does and returns the
+         result dictionary (plus the descriptors under "database_vectors" / "query_vectors"); the other ranks return None.
+
+    ``truth(m, n)[i]`` = QUERY_SETS[n][i][m]; only rank 0 calls it.  The result equals the single-process
+    ``evaluate_runs`` on the same descriptors bit for bit: a query's neighbour list does not depend on which rank ranks it.
+    ``timings`` (optional dict) receives wall-clock seconds of the phases on this rank, each closed by a device
+    synchronisation (extract, all_gather, rank, index_gather, book)."""
+    import time
+    from . import distributed as D
+    rank, ws = D.world()
+    search = search or knn_search
+    n_dbs = [len(x) for x in database_sets]
+    n_qs = [len(x) for x in query_sets]
+    parts = list(database_sets) + list(query_sets)
+    total = sum(n_dbs) + sum(n_qs)
+    a, b = D.shard_bounds(total, rank, ws)
+    on_gpu = torch.cuda.is_available()
+
+    def tick():
+        if on_gpu:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    t0 = tick()
+    local = [extract(chunk) for chunk in _Sliced(parts, a, b).chunks(batch_size)]
+    if local:
+        local = torch.cat(local, dim=0) if len(local) > 1 else local[0]
+    else:
+        dev = device or (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+        local = torch.empty((0, 256), dtype=torch.float32, device=dev)
+    local = local.float().contiguous()
+    dev = local.device
+    t1 = tick()
+    vectors = D.all_gather_rows(local, total)                                   # (total, 256) on every rank
+    t2 = tick()
+    starts = np.concatenate([[0], np.cumsum(n_dbs + n_qs)]).astype(np.int64)
+    db_vec = [vectors[starts[m]: starts[m + 1]] for m in range(len(n_dbs))]
+    q_vec = [vectors[starts[len(n_dbs) + n]: starts[len(n_dbs) + n + 1]] for n in range(len(n_qs))]
+
+    # every rank's share of the queries ranked against database run m: rows [qa, qb) of cat(q_vec[n] for n != m)
+    mine, counts = [], []                       # counts[m] = rows of run m's query list (same on every rank)
+    for m in range(len(n_dbs)):
+        others = [n for n in range(len(n_qs)) if n != m]
+        nq = sum(n_qs[n] for n in others)
+        counts.append(nq)
+        if nq == 0 or n_dbs[m] == 0:
+            continue
+        qa, qb = D.shard_bounds(nq, rank, ws)
+        if qb > qa:
+            q = torch.cat([q_vec[n] for n in others], dim=0)[qa:qb]
+            _, idx = search(db_vec[m], q, NUM_NEIGHBORS)
+            idx = idx.to(torch.int32)
+            if idx.shape[1] < NUM_NEIGHBORS:                                     # a database run with fewer than 25 rows
+                idx = torch.cat([idx, torch.full((idx.shape[0], NUM_NEIGHBORS - idx.shape[1]), -1, dtype=torch.int32,
+                                                 device=idx.device)], dim=1)
+            mine.append(idx)
+    width = NUM_NEIGHBORS
+    mine = torch.cat(mine, dim=0) if mine else torch.empty((0, width), dtype=torch.int32, device=dev)
+    t3 = tick()
+    live = [m for m in range(len(n_dbs)) if counts[m] > 0 and n_dbs[m] > 0]
+    per_rank = [sum(D.shard_bounds(counts[m], r, ws)[1] - D.shard_bounds(counts[m], r, ws)[0] for m in live)
+                for r in range(ws)]
+    gathered = D.all_gather_var_rows(mine, per_rank)                             # rank-major, run-minor
+    t4 = tick()
+    if timings is not None:
+        timings.update(extract=t1 - t0, all_gather=t2 - t1, rank=t3 - t2, index_gather=t4 - t3,
+                       all_gather_bytes=int(vectors.numel() * 4), clouds_local=b - a, clouds_total=total)
+    if rank != 0:
+        return None
+    gathered = gathered.cpu().numpy()
+    vec_np = vectors.cpu().numpy()
+    db_np = [vec_np[starts[m]: starts[m + 1]] for m in range(len(n_dbs))]
+    q_np = [vec_np[starts[len(n_dbs) + n]: starts[len(n_dbs) + n + 1]] for n in range(len(n_qs))]
+    # un-shard: lists[m] (counts[m], 25) = concatenation over the ranks of their slices for run m
+    offs = np.concatenate([[0], np.cumsum(per_rank)]).astype(np.int64)
+    lists = {}
+    cursor = [int(o) for o in offs[:-1]]
+    for m in live:
+        rows = []
+        for r in range(ws):
+            qa, qb = D.shard_bounds(counts[m], r, ws)
+            rows.append(gathered[cursor[r]: cursor[r] + (qb - qa)])
+            cursor[r] += qb - qa
+        lists[m] = np.concatenate(rows, axis=0)
+    recall = np.zeros(NUM_NEIGHBORS)
+    count = 0
+    similarity: List[float] = []
+    one_percent: List[float] = []
+    for m in range(len(n_dbs)):                                                  # evaluate.py:305-319 order
+        at = 0
+        for n in range(len(n_qs)):
+            if n == m:
+                continue
+            nq = n_qs[n]
+            if m not in lists:
+                raise ValueError("database run %d is empty" % m)
+            k_eff = min(NUM_NEIGHBORS, n_dbs[m])
+            pair_recall, pair_sim, pair_opr = recall_from_indices(lists[m][at:at + nq, :k_eff], db_np[m], q_np[n], truth(m, n))
+            at += nq
+            recall += np.array(pair_recall)
+            count += 1
+            one_percent.append(pair_opr)
+            similarity.extend(pair_sim)
+    if timings is not None:
+        timings["book"] = time.perf_counter() - t4
+    return {"ave_recall": recall / count, "average_similarity": float(np.mean(similarity)) if similarity else float("nan"),
+            "ave_one_percent_recall": float(np.mean(one_percent)), "database_vectors": db_np, "query_vectors": q_np}
 
 
 def write_results(path: str, res: Dict[str, object], arch: str = "epc-net") -> None:

@@ -45,7 +45,8 @@ class TrainStep:
         self.beta1, self.beta2, self.eps = 0.9, 0.999, 1e-8
         self.m: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
-        self._graph = None                        # captured HIP graph of one step (step(..., graph=True))
+        self._graph = None                        # captured HIP graph(s) of one step (step(..., graph=True))
+        self._exchange = None                     # flat gradient / statistics buffer of data-parallel steps
         # GEMM arithmetic of the step (ops.set_gemm_precision): "bf16x6" = f32-accurate like the reference's fp32 graph
         # (default); "bf16" = one bf16 value per operand, the arithmetic BASELINE.json configs[2] names
         self.precision = params.get("TRAIN_PRECISION", "bf16x6")
@@ -100,7 +101,7 @@ class TrainStep:
         average gradients of different models).  Called once when the step is first built and after ``restore``; one flat
         broadcast per dtype.  Single process: nothing to do."""
         from . import distributed as D
-        if D.world()[1] == 1:
+        if not D.collectives_active():
             return
         pre = self.outer + "/" if self.outer else ""
         tensors = [v for k, v in self.store.vars.items() if k.startswith(pre)]
@@ -114,19 +115,18 @@ class TrainStep:
 
     def step(self, query, positives, negatives, other_neg, epoch: int = 0, graph: bool = False):
         """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3).
-        ``graph=True`` records the whole step (forward, backward, 62 Adam updates, moving averages: ~670 kernel
-        launches) into one HIP graph on first use and replays it afterwards -- the step is launch-bound from Python
-        otherwise.  The schedule values (learning rate with Adam's bias correction, BN decay) live in device memory and
-        are refreshed before every replay, so replays follow train.py:138-157 exactly like eager steps."""
+        ``graph=True`` records the step into HIP graphs on first use and replays them afterwards -- the step is launch-bound
+        from Python otherwise.  Single rank: ONE graph (forward, backward, moving averages, Adam).  Data-parallel ranks
+        (SURVEY.md 8e): TWO graphs around the one flat all-reduce -- [forward, backward, moving averages, pack gradients +
+        statistics into the flat exchange buffer] -> RCCL all-reduce (eager, on the same stream) -> [mean, unpack the
+        statistics, Adam].  The schedule values (learning rate with Adam's bias correction, BN decay) live in device memory
+        and are refreshed before every replay, so replays follow train.py:138-157 exactly like eager steps."""
         p = self.params
         B = int(query.shape[0])
         self._ensure_built(int(query.shape[2]))
         bn_decay = get_bn_decay(self.global_step, p.get("BATCH_NUM_QUERIES", B), p.get("DECAY_STEP", 200000))
         lr = get_learning_rate(epoch, p.get("BASE_LEARNING_RATE", 5e-5))
         t = self.global_step + 1
-        if graph:
-            from . import distributed as D
-            graph = D.world()[1] == 1      # the gradient all-reduce of data-parallel runs is not captured: eager there
         if graph:
             loss = self._graphed_step(query, positives, negatives, other_neg, lr, bn_decay, t)
         else:
@@ -136,7 +136,10 @@ class TrainStep:
         # (the graphed path returns the replayed graph's static output buffer: clone it, or the next replay overwrites it)
         return (loss.detach().clone() if graph else loss.detach()), lr, bn_decay
 
-    def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
+    # -- the three phases of a step ------------------------------------------------------------------------------------
+    def _forward_backward(self, query, positives, negatives, other_neg, bn_decay):
+        """Forward in training mode, loss, backward, and the moving-average updates of this step (UPDATE_OPS,
+        train.py:275-277).  Returns (loss, gradients in trainable_names() order)."""
         from .utils import tf_util
         from .loupe import SLIM_DECAY
         for name in self.trainable_names():
@@ -153,28 +156,79 @@ class TrainStep:
         finally:
             ops.set_gemm_precision(prev)
         with torch.no_grad():
-            names = self.trainable_names()
             grads = []
-            for name in names:
+            for name in self.trainable_names():
                 w = self.store.vars[name]
                 grads.append(w.grad if w.grad is not None else ops.const_zeros_like(w))
-            # data-parallel runs average the moving statistics too: apply the updates first
+            # data-parallel runs average the moving statistics too: apply the updates before the exchange
             tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9, scope=self.outer or None)
-            self._average_over_ranks(grads)
-            ops.adam_multi([self.store.vars[k] for k in names], [self.m[k] for k in names], [self.v[k] for k in names],
-                           grads, lr, t, self.beta1, self.beta2, self.eps)                                # :273-277
-        return loss
+        return loss, grads
 
-    def _average_over_ranks(self, grads) -> None:
-        """Data parallelism over tuples: one flat all-reduce of the gradients, and of the BatchNorm moving
-        statistics this step updated, so that every rank applies the same update.  Single process: nothing to do."""
-        from . import distributed as D
-        if D.world()[1] == 1:
-            return
-        D.all_reduce_gradients(grads)
+    def _apply(self, grads, lr, t) -> None:
+        """tf.train.AdamOptimizer(learning_rate).minimize (train.py:273-277): all 62 updates in one launch."""
+        names = self.trainable_names()
+        with torch.no_grad():
+            ops.adam_multi([self.store.vars[k] for k in names], [self.m[k] for k in names], [self.v[k] for k in names],
+                           grads, lr, t, self.beta1, self.beta2, self.eps)
+
+    def _statistics(self):
         pre = self.outer + "/" if self.outer else ""
         trainable = set(self.store.trainable)
-        D.all_reduce_gradients([v for k, v in self.store.vars.items() if k.startswith(pre) and k not in trainable])
+        return [v for k, v in self.store.vars.items() if k.startswith(pre) and k not in trainable]
+
+    def _exchange_layout(self, grads):
+        """The flat f32 exchange buffer of data-parallel steps: [gradients | moving statistics], every tensor at a
+        64-float (256-byte) boundary.  ONE RCCL message per step (18.8 MB of gradients + 10 KB of statistics for EPC-Net:
+        xGMI rings are per-link bound, so one large message, not 62 + 34 small ones)."""
+        tensors = list(grads) + self._statistics()
+        key = tuple((tuple(x.shape), x.dtype) for x in tensors)
+        ex = self._exchange
+        if ex is None or ex["key"] != key or ex["flat"].device != tensors[0].device:
+            offs, o = [], 0
+            for x in tensors:
+                offs.append(o)
+                o += (x.numel() + 63) // 64 * 64
+            flat = torch.zeros(max(o, 64), dtype=torch.float32, device=tensors[0].device)
+            views = [flat[a:a + x.numel()].view(x.shape) for a, x in zip(offs, tensors)]
+            ex = self._exchange = {"key": key, "flat": flat, "views": views, "n_grads": len(grads)}
+        return ex
+
+    def _pack(self, grads):
+        ex = self._exchange_layout(grads)
+        with torch.no_grad():
+            torch._foreach_copy_(ex["views"], list(grads) + self._statistics())
+        return ex
+
+    def _unpack_mean(self, ex, world_size: int):
+        """After the all-reduce(sum): mean over the ranks in place, statistics back into the variables; returns the averaged
+        gradients (views of the exchange buffer, what Adam then reads)."""
+        with torch.no_grad():
+            if world_size > 1:
+                ex["flat"].mul_(1.0 / world_size)
+            ng = ex["n_grads"]
+            torch._foreach_copy_(self._statistics(), ex["views"][ng:])
+        return ex["views"][:ng]
+
+    def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
+        loss, grads = self._forward_backward(query, positives, negatives, other_neg, bn_decay)
+        grads = self._average_over_ranks(grads)
+        self._apply(grads, lr, t)
+        return loss
+
+    def _average_over_ranks(self, grads):
+        """Data parallelism over tuples: one flat all-reduce of the gradients and of the BatchNorm moving
+        statistics this step updated, so that every rank applies the same update.  Returns the averaged gradients (the
+        input list is averaged in place as well).  Single process without force_collective: nothing to do."""
+        from . import distributed as D
+        if not D.collectives_active():
+            return grads
+        import torch.distributed as dist
+        ex = self._pack(grads)
+        dist.all_reduce(ex["flat"], op=dist.ReduceOp.SUM)
+        avg = self._unpack_mean(ex, D.world()[1])
+        with torch.no_grad():
+            torch._foreach_copy_(list(grads), avg)
+        return avg
 
     # -- HIP-graph replay ------------------------------------------------------------------------------------------------
     def _state_tensors(self):
@@ -183,24 +237,30 @@ class TrainStep:
         return out
 
     def _graphed_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
+        from . import distributed as D
         inputs = (query, positives, negatives, other_neg)
         shapes = tuple(tuple(x.shape) for x in inputs)
+        dp = D.collectives_active()
         g = self._graph
-        if g is None or g["shapes"] != shapes:
+        if g is None or g["shapes"] != shapes or g["dp"] != dp:
             dev = query.device
-            g = {"shapes": shapes, "in": [torch.empty_like(x) for x in inputs],
+            g = {"shapes": shapes, "dp": dp, "in": [torch.empty_like(x) for x in inputs],
                  "lr_t": torch.zeros(1, dtype=torch.float32, device=dev),
                  "bn_decay": torch.zeros((), dtype=torch.float32, device=dev)}
             for dst, src in zip(g["in"], inputs):
                 dst.copy_(src)
             g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
             g["bn_decay"].fill_(bn_decay)
-            # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored
+            # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored.
+            # No collective here: every rank restores its own snapshot, so the ranks stay in step.
             snap = [x.detach().clone() for x in self._state_tensors()]
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                self._eager_step(*g["in"], g["lr_t"], g["bn_decay"], t)
+                loss, grads = self._forward_backward(*g["in"], g["bn_decay"])
+                if dp:
+                    grads = self._unpack_mean(self._pack(grads), 1)
+                self._apply(grads, g["lr_t"], t)
             torch.cuda.current_stream(dev).wait_stream(side)
             with torch.no_grad():
                 for x, s0 in zip(self._state_tensors(), snap):
@@ -208,14 +268,28 @@ class TrainStep:
             for name in self.trainable_names():
                 self.store.vars[name].grad = None
             g["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["graph"]):
-                g["loss"] = self._eager_step(*g["in"], g["lr_t"], g["bn_decay"], t)
+            if not dp:
+                with torch.cuda.graph(g["graph"]):
+                    g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"])
+                    self._apply(grads, g["lr_t"], t)
+            else:
+                ws = D.world()[1]
+                with torch.cuda.graph(g["graph"]):
+                    g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"])
+                    g["ex"] = self._pack(grads)
+                g["graph2"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g["graph2"], pool=g["graph"].pool()):
+                    self._apply(self._unpack_mean(g["ex"], ws), g["lr_t"], t)
             self._graph = g
         for dst, src in zip(g["in"], inputs):
             dst.copy_(src)
         g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
         g["bn_decay"].fill_(bn_decay)
         g["graph"].replay()
+        if dp:
+            import torch.distributed as dist
+            dist.all_reduce(g["ex"]["flat"], op=dist.ReduceOp.SUM)        # same stream: ordered between the two replays
+            g["graph2"].replay()
         return g["loss"]
 
     def compute_loss(self, query, positives, negatives, other_neg, is_training: bool, bn_decay=None):

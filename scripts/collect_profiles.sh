@@ -10,12 +10,12 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-args="bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --no-configs"
+args="bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --no-configs --no-rccl --regions 1"
 python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err"        # the un-profiled line: bench.py's own defaults
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 $root/$args > "$out/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs > "$out/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs > "$out/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs --no-rccl --regions 1 > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs --no-rccl --regions 1 > "$out/pmc_write.log" 2>&1
 # Compute-side counters, two more passes of the same command: the matrix pipe's busy cycles and the vector
 # ALU's issue / active-lane counters (pass A), LDS and wait-state counters (pass B).  8 SQ slots per pass; GRBM_GUI_ACTIVE
 # rides in the independent GRBM block.  Counter names are checked against `rocprofv3 -L` first: a name this ROCm does not
@@ -26,7 +26,7 @@ setA=$(pick SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
 setB=$(pick SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_SALU GRBM_GUI_ACTIVE)
 echo "pass A: $setA" > "$out/pmc_compute_sets.txt"; echo "pass B: $setB" >> "$out/pmc_compute_sets.txt"
 cd /tmp
-[ -n "$setA" ] && rocprofv3 --kernel-trace --pmc $setA --output-format csv -d "$out/pmc_compA" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs > "$out/pmc_compA.log" 2>&1
-[ -n "$setB" ] && rocprofv3 --kernel-trace --pmc $setB --output-format csv -d "$out/pmc_compB" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs > "$out/pmc_compB.log" 2>&1
+[ -n "$setA" ] && rocprofv3 --kernel-trace --pmc $setA --output-format csv -d "$out/pmc_compA" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs --no-rccl --regions 1 > "$out/pmc_compA.log" 2>&1
+[ -n "$setB" ] && rocprofv3 --kernel-trace --pmc $setB --output-format csv -d "$out/pmc_compB" -- python3 $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 --no-configs --no-rccl --regions 1 > "$out/pmc_compB.log" 2>&1
 cd "$root"
 python3 scripts/summarise_profiles.py "$tag"

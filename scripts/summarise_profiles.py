@@ -9,8 +9,23 @@
 and refresh profiles/pmc_hbm_current.json / pmc_compute_current.json (what bench.py's roofline.traffic / mfma_util read)."""
 import csv, glob, json, os, shutil, sys
 
+import hashlib
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "cur"
+
+
+def lib_sha256():
+    """The library the profiled runs loaded (scripts/collect_profiles.sh runs this script right after them, on the same box,
+    from the same tree): bench.py prints the counters only while the library it loads still has this hash."""
+    h = hashlib.sha256()
+    with open(os.environ.get("EPCNET_LIB") or os.path.join(root, "epc-net_amd", "libepcnet_hip.so"), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+LIB_SHA = lib_sha256()
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -52,7 +67,7 @@ for k in sorted(set(fetch) | set(write)):
 if kernels:
     doc = {"command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
                       "--no-cpu-baseline (separate passes for FETCH_SIZE and WRITE_SIZE; scripts/collect_profiles.sh)",
-           "tag": tag, "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024)", "kernels": kernels}
+           "tag": tag, "lib_sha256": LIB_SHA, "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024)", "kernels": kernels}
     for name in (tag + "_pmc_hbm.json", "pmc_hbm_current.json"):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
@@ -123,7 +138,7 @@ if comp:
         pass
     doc = {"command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
                       "--no-cpu-baseline --in-flight 1 --no-configs (two passes; scripts/collect_profiles.sh)",
-           "tag": tag, "counter_sets": sets,
+           "tag": tag, "lib_sha256": LIB_SHA, "counter_sets": sets,
            "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); valu_active_lane_fraction = "
                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); *_share = counter / SQ_WAVE_CYCLES; means per launch",
            "kernels": {k: {c: (round(v, 1) if isinstance(v, float) and v > 10 else v) for c, v in d.items()} for k, d in sorted(comp.items())}}

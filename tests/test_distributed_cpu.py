@@ -176,3 +176,128 @@ def test_train_state_sync_and_skip_vote_world2_gloo():
         p.join(180)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == "ok"
+
+
+# ---- configs[4] as one composed, rank-aware flow: evaluate_sharded == single-process evaluate_runs --------------------------
+def _synthetic_runs(seed=5, n_runs=3, n_points=32):
+    """Three runs of (database clouds, query clouds) + truth sets shaped like QUERY_SETS[n][i][m] (evaluate.py:476)."""
+    rng = np.random.RandomState(seed)
+    n_db = [41, 29, 37][:n_runs]
+    n_q = [13, 17, 9][:n_runs]
+    dbs = [rng.uniform(-1, 1, (n, n_points, 3)).astype(np.float32) for n in n_db]
+    # queries = noisy copies of database clouds of OTHER runs, so that true neighbours are actually retrieved
+    qs, truth = [], {}
+    for n in range(n_runs):
+        q = rng.uniform(-1, 1, (n_q[n], n_points, 3)).astype(np.float32)
+        for m in range(n_runs):
+            if m == n:
+                continue
+            t = []
+            for i in range(n_q[n]):
+                k = rng.randint(0, 4)                     # some queries have no true neighbour in run m (skipped, :477)
+                pick = list(rng.choice(n_db[m], size=k, replace=False))
+                if k and rng.rand() < 0.7:
+                    q[i] = dbs[m][pick[0]] + 0.01 * rng.randn(n_points, 3).astype(np.float32)
+                t.append(pick)
+            truth[(m, n)] = t
+        qs.append(q)
+    return dbs, qs, truth
+
+
+def _cpu_extract(chunk):
+    """Stand-in for engine.forward in the CPU tests: a fixed per-cloud map to a unit 256-vector (chunking-independent)."""
+    x = torch.as_tensor(np.asarray(chunk), dtype=torch.float32).reshape(len(chunk), -1)
+    g = torch.Generator().manual_seed(99)
+    w = torch.randn((x.shape[1], 256), generator=g)
+    v = torch.stack([torch.mv(w.t(), torch.tanh(r)) for r in x]) if len(x) else torch.empty((0, 256))   # row by row: bit-equal in any chunking
+    return v / v.norm(dim=1, keepdim=True)
+
+
+def _single_process_reference(dbs, qs, truth):
+    R = H.pkg("retrieval")
+    dbv = [_cpu_extract(d).numpy() for d in dbs]
+    qv = [_cpu_extract(q).numpy() for q in qs]
+    return R.evaluate_runs(dbv, qv, lambda m, n: truth[(m, n)], device=torch.device("cpu"), search=_oracle_search)
+
+
+def _eval_worker(rank, ws, port, ret, force):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    D, R = H.pkg("distributed"), H.pkg("retrieval")
+    D.force_collective(force)
+    dbs, qs, truth = _synthetic_runs()
+    tm = {}
+    res = R.evaluate_sharded(_cpu_extract, dbs, qs, (lambda m, n: truth[(m, n)]) if rank == 0 else None,
+                             device=torch.device("cpu"), search=_oracle_search, batch_size=8, timings=tm)
+    assert tm["clouds_total"] == sum(map(len, dbs)) + sum(map(len, qs))
+    if rank == 0:
+        ref = _single_process_reference(dbs, qs, truth)
+        assert np.array_equal(res["ave_recall"], ref["ave_recall"]), (res["ave_recall"], ref["ave_recall"])
+        assert res["ave_one_percent_recall"] == ref["ave_one_percent_recall"]
+        assert res["average_similarity"] == ref["average_similarity"]
+        assert res["ave_recall"][-1] > 20.0            # the synthetic truth really is retrieved: not a vacuous comparison
+        for m, d in enumerate(dbs):
+            assert np.array_equal(res["database_vectors"][m], _cpu_extract(d).numpy())
+        ret.put("ok")
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws,force", [(2, False), (1, True)])
+def test_evaluate_sharded_equals_single_rank(ws, force):
+    """extraction sharded over the ranks -> one all-gather -> every rank ranks its query share -> one
+    index gather -> rank 0 books the recall; the numbers must equal the single-process evaluate_runs bit for bit.
+    (1, True) = a world of one with the collectives forced on: the code path the 1-GPU nccl test takes."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, ws, port, ret, force)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
+def test_evaluate_sharded_without_process_group():
+    R = H.pkg("retrieval")
+    dbs, qs, truth = _synthetic_runs(seed=8)
+    res = R.evaluate_sharded(_cpu_extract, dbs, qs, lambda m, n: truth[(m, n)], device=torch.device("cpu"),
+                             search=_oracle_search, batch_size=16)
+    ref = _single_process_reference(dbs, qs, truth)
+    assert np.array_equal(res["ave_recall"], ref["ave_recall"])
+    assert res["ave_one_percent_recall"] == ref["ave_one_percent_recall"]
+    assert res["average_similarity"] == ref["average_similarity"]
+
+
+def test_all_gather_var_rows_world2_gloo():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_var_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
+def _var_worker(rank, ws, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    D = H.pkg("distributed")
+    for sizes in ([3, 5], [4, 4], [0, 6], [0, 0]):
+        full = torch.arange(sum(sizes) * 2, dtype=torch.int32).reshape(-1, 2)
+        a = sum(sizes[:rank])
+        got = D.all_gather_var_rows(full[a:a + sizes[rank]], sizes)
+        assert torch.equal(got, full), (sizes, got)
+    if rank == 0:
+        ret.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()

@@ -460,6 +460,82 @@ def test_pairwise_topk_workspace_form_is_the_exact_answer(dev, n_db, n_q, kind):
         assert np.array_equal(ws[0], np.tile(np.arange(25, dtype=np.int32), (n_q, 1)))
 
 
+def test_pairwise_topk_nan_rows_and_queries(dev):
+    """flagged clouds have NaN descriptors by design.  A NaN query has no neighbour at a finite distance
+    -> (-1, +Inf) in every slot, from BOTH forms, with no store outside the buffers (canaries around idx / dist / workspace);
+    NaN database rows are never selected; a query with fewer than k finite rows gets the finite ones then (-1, +Inf)."""
+    L = H.pkg("lib")
+    R = H.pkg("retrieval")
+    rng = np.random.RandomState(11)
+    n_db, n_q, k = 700, 40, 25
+    db = rng.randn(n_db, 256).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[rng.randint(0, n_db, n_q)] + 0.3 * rng.randn(n_q, 256).astype(np.float32)
+    q = np.ascontiguousarray(q / np.linalg.norm(q, axis=1, keepdims=True), dtype=np.float32)
+    db[5] = np.nan
+    db[77, 3] = np.inf
+    q[2] = np.nan
+    q[9, 100] = np.nan
+    good_db = np.isfinite(db).all(axis=1)
+    lds, ws = _topk_both(L, db, q, k, dev)
+    for idx, dist in (lds, ws):
+        for i in (2, 9):
+            assert (idx[i] == -1).all() and np.isinf(dist[i]).all()
+        ok = [i for i in range(n_q) if i not in (2, 9)]
+        dref, iref = O.knn_bruteforce(db[good_db], q[ok], k)
+        remap = np.nonzero(good_db)[0]
+        assert np.array_equal(idx[ok], remap[iref])
+        assert np.allclose(dist[ok], dref, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(lds[0], ws[0]) and np.array_equal(lds[1], ws[1])
+    # fewer than k finite rows: 30 rows, 10 of them NaN, k = 25 -> 20 neighbours then (-1, +Inf)
+    db2 = db[:30].copy()
+    db2[10:20] = np.nan
+    lds2, ws2 = _topk_both(L, db2, q[:5], k, dev)
+    for idx, dist in (lds2, ws2):
+        for i in (0, 1, 3, 4):
+            assert (idx[i, :20] >= 0).all() and (idx[i, 20:] == -1).all() and np.isinf(dist[i, 20:]).all()
+            assert not set(idx[i, :20].tolist()) & set(range(10, 20))
+        assert (idx[2] == -1).all()
+    # canaries: the workspace form must not write past its buffers when a query is NaN (the old fallback stored row[0x7fffffff])
+    tdb, tq = torch.from_numpy(db).to(dev), torch.from_numpy(q).to(dev)
+    need = L.lib().epc_pairwise_topk_workspace_bytes(n_db, n_q)
+    arena = torch.full((need + 8192,), 0x5A, dtype=torch.uint8, device=dev)
+    out = torch.full((n_q * k + 64,), -7, dtype=torch.int32, device=dev)
+    dst = torch.full((n_q * k + 64,), -7.0, dtype=torch.float32, device=dev)
+    L.check(L.lib().epc_pairwise_topk_ws(tdb.data_ptr(), n_db, tq.data_ptr(), n_q, 256, k, out.data_ptr(), dst.data_ptr(),
+                                         arena.data_ptr() + 4096, need, L.current_stream()))
+    torch.cuda.synchronize()
+    assert (arena[:4096] == 0x5A).all() and (arena[4096 + need:] == 0x5A).all()
+    assert (out[n_q * k:] == -7).all() and (dst[n_q * k:] == -7.0).all()
+    # the host bookkeeping skips the -1 slots (a NaN query is evaluated and scores no hit, like a KDTree answer of far rows)
+    truth = [[int(v)] for v in rng.randint(0, n_db, n_q)]
+    rec, sim, opr = R.recall_from_indices(ws[0], np.nan_to_num(db), np.nan_to_num(q), truth)
+    assert np.isfinite(rec).all()
+
+
+def test_pairwise_topk_large_norm_near_ties(dev):
+    """un-normalised descriptors whose near-ties sit far from the origin.  The proof's rounding bound must
+    scale with the norms involved (dim, |q|^2, the database's largest |d|^2): the workspace form has to return the LDS form's
+    lists bit for bit, i.e. flag every query the GEMM's cancellation could have mis-ranked."""
+    L = H.pkg("lib")
+    rng = np.random.RandomState(21)
+    n_db, n_q, k = 3000, 64, 25
+    base = rng.randn(1, 256).astype(np.float32) * 40.0                    # |d|^2 ~ 4e5: f32 spacing of the norms ~ 0.03
+    db = (base + rng.randn(n_db, 256).astype(np.float32) * 0.05).astype(np.float32)   # pairwise d2 ~ 1.3, spread ~ 0.1
+    db[1500:] = rng.randn(1500, 256).astype(np.float32)                   # plus ordinary rows near the origin
+    q = np.ascontiguousarray(db[rng.randint(0, 1500, n_q)] + 0.02 * rng.randn(n_q, 256).astype(np.float32), dtype=np.float32)
+    q[0] = db[3]
+    lds, ws = _topk_both(L, db, q, k, dev)
+    assert np.array_equal(ws[0], lds[0]) and np.array_equal(ws[1], lds[1])
+    # and a single outlier row of huge norm must not break the others' answers (the norm-free half of the bound)
+    db2 = rng.randn(2000, 256).astype(np.float32)
+    db2 /= np.linalg.norm(db2, axis=1, keepdims=True)
+    db2[123] *= 1e6
+    q2 = np.ascontiguousarray(db2[rng.randint(0, 2000, 32)] + 0.3 * rng.randn(32, 256).astype(np.float32), dtype=np.float32)
+    lds2, ws2 = _topk_both(L, db2, q2, k, dev)
+    assert np.array_equal(ws2[0], lds2[0]) and np.array_equal(ws2[1], lds2[1])
+
+
 def test_evaluate_protocol_single_rank(dev):
     """get_latent_vectors + get_recall/evaluate_runs (evaluate.py:293-332, 351-537) on synthetic runs: GPU neighbour
     search + host bookkeeping must reproduce the oracle's recall numbers on the same descriptors."""
