@@ -73,7 +73,41 @@ def knn_search(database: torch.Tensor, queries: torch.Tensor, k: int = NUM_NEIGH
 
 def recall_from_indices(indices: np.ndarray, database_output: np.ndarray, queries_output: np.ndarray,
                         true_neighbors: Sequence[Sequence[int]], num_neighbors: int = NUM_NEIGHBORS):
-    """The bookkeeping of evaluate.py:467-537 given each query's sorted neighbour indices."""
+    """The bookkeeping of evaluate.py:467-537 given each query's sorted neighbour indices -- the reference's per-query Python
+    loop (set membership per neighbour, :512-527) as array operations with the same results: at Oxford scale the loop form
+    costs as much host time as extracting the descriptors costs the GPU.  ``recall_from_indices_loop`` keeps the
+    reference-shaped loop; the tests hold the two to each other and to the oracle.  An index < 0 = "no such neighbour"
+    (fewer than k finite database rows, e.g. a NaN query descriptor): never a hit."""
+    import itertools
+    nq, nd = len(queries_output), len(database_output)
+    threshold = max(int(round(nd / 100.0)), 1)                            # :470 (Python banker's rounding)
+    lens = np.fromiter((len(t) for t in true_neighbors[:nq]), dtype=np.int64, count=nq)
+    evaluated = lens > 0                                                  # :477-478
+    num_evaluated = int(evaluated.sum())
+    if num_evaluated == 0:
+        raise ZeroDivisionError("no query of this pair has a true neighbour (evaluate.py:529 divides by zero too)")
+    ind = np.asarray(indices)[:nq, :num_neighbors].astype(np.int64)
+    is_true = np.zeros((nq, nd + 1), dtype=bool)                          # column nd: where the invalid indices point
+    cols = np.fromiter(itertools.chain.from_iterable(true_neighbors[:nq]), dtype=np.int64, count=int(lens.sum()))
+    rows = np.repeat(np.arange(nq), lens)
+    ok = (cols >= 0) & (cols < nd)
+    is_true[rows[ok], cols[ok]] = True
+    hits = is_true[np.arange(nq)[:, None], np.where((ind < 0) | (ind >= nd), nd, ind)]      # (nq, k)
+    hits &= evaluated[:, None]
+    any_hit = hits.any(axis=1)
+    first = hits.argmax(axis=1)                                           # :512-521: the FIRST true neighbour in the list
+    recall = np.bincount(first[any_hit], minlength=num_neighbors)[:num_neighbors]
+    top1_similarity_score = [float(np.dot(queries_output[i], database_output[ind[i, 0]]))  # :515-517, in query order
+                             for i in np.nonzero(any_hit & (first == 0))[0]]
+    one_percent_retrieved = int(hits[:, :threshold].any(axis=1).sum())    # :526-527
+    one_percent_recall = (one_percent_retrieved / float(num_evaluated)) * 100
+    recall_pct = (np.cumsum(recall) / float(num_evaluated)) * 100
+    return recall_pct, top1_similarity_score, one_percent_recall
+
+
+def recall_from_indices_loop(indices: np.ndarray, database_output: np.ndarray, queries_output: np.ndarray,
+                             true_neighbors: Sequence[Sequence[int]], num_neighbors: int = NUM_NEIGHBORS):
+    """evaluate.py:467-537 in the reference's own loop shape (what ``recall_from_indices`` must reproduce)."""
     recall = [0] * num_neighbors
     top1_similarity_score: List[float] = []
     one_percent_retrieved = 0

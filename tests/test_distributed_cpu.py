@@ -88,6 +88,20 @@ def test_recall_bookkeeping_matches_oracle():
     a = R.recall_from_indices(ind, db, q, truth)
     b = O.get_recall(db, q, truth)
     assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.allclose(a[1], b[1])
+    # the array form against the reference-shaped loop: identical, also with invalid (-1) slots, short lists, a 1 % threshold
+    # above 1 and truth entries outside the database
+    for trial in range(6):
+        nd, nq, k = [250, 1000, 30, 400, 26, 333][trial], 40 + trial, [25, 25, 25, 7, 25, 25][trial]
+        db2 = rng.randn(nd, 256).astype(np.float32)
+        q2 = rng.randn(nq, 256).astype(np.float32)
+        _, ind2 = O.knn_bruteforce(db2, q2, min(k, nd))
+        ind2 = ind2.astype(np.int32)
+        ind2[rng.rand(*ind2.shape) < 0.05] = -1
+        truth2 = [list(rng.choice(nd + 5, size=rng.randint(0, 5), replace=False)) for _ in range(nq)]
+        truth2[0] = [int(ind2[0, 0])] if ind2[0, 0] >= 0 else [int(ind2[0][ind2[0] >= 0][0])]
+        va = R.recall_from_indices(ind2, db2, q2, truth2)
+        vb = R.recall_from_indices_loop(ind2, db2, q2, truth2)
+        assert np.array_equal(va[0], vb[0]) and va[1] == vb[1] and va[2] == vb[2], trial
 
 
 def _grad_worker(rank, ws, port, ret):
