@@ -27,8 +27,6 @@
 #define BLK_PACK_S EPC_BLOCK_PACK_FLOATS_S   // f32 kernel: the three layers' inverse column scales follow the layer packs
 #define BLK_LDS_FLOATS (BLK_PACK_S + BLK_WAVES * 32 * ST_STRIDE)
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __device__ __forceinline__ void acc_init_bias(f32x16& acc, const float* bias32, int h) {
 #pragma unroll
@@ -54,9 +52,6 @@ __device__ __forceinline__ void relu16(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
 }
 
-__device__ __forceinline__ bf16x8 ldfrag(const float* p) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-}
 
 // The three 64x64 layers of the f32 kernel run on the fp16 MFMA in SCALED split-fp16 arithmetic (common.h: every point's
 // 64-channel row and every output channel's weight column scaled by a power of two into [2^14, 2^15), hi + lo fp16 parts,
@@ -356,9 +351,6 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
 // Lane mapping of the row phases: 8 lanes x 8 channels (16 B of fp16) per point, 8 points per wave-instruction.
 #define ST16 72  // halfs per staged row: 64 + 8 pad (144 B: conflict-free b128 / b64 accesses in both layouts)
 
-__device__ __forceinline__ f16x8 ldfrag16(const float* p) {
-    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
-}
 
 // 64->64 layer on fp16 fragments: bop[s] = the lane's B fragment of k-step s (order fixed by the pack mode)
 __device__ __forceinline__ void layer_f16(const float* lw, const float* lbias, const f16x8 (&bop)[4], f32x16 (&acc)[2],

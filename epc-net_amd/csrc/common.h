@@ -44,6 +44,26 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ bf16x8 ldfrag(const float* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+}
+__device__ __forceinline__ f16x8 ldfrag16(const float* p) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
+}
+// 16 bytes per lane, global -> LDS without a VGPR destination (LDS-DMA): lane l reads uniform_base + lane_byte_off and lands at LDS byte
+// address lds_dst + 16*l (uniform_base and lds_dst wave-uniform, in SGPRs).  Written as inline asm on purpose: with the builtin hipcc (ROCm 7.2) drains
+// vmcnt(0) before the next ds_read of the same __shared__ array, which would serialise the prefetch; the asm form is
+// invisible to its wait bookkeeping, so completion is tracked by the hand-placed counted s_waitcnt in the chunk loop.
+__device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst)
+                 : "memory");
+}
+
 // conv5 / assignment weights are packed as fp16 hi + lo fragments of W * W5_SCALE (2^8 keeps the lo parts of ordinary
 // weights in fp16's normal range; biases are packed with the same factor and the kernel multiplies the result by
 // 2^-8).  With ONE fp16 value per activation the product is x16*W_hi + x16*W_lo, f32 accumulate: two MFMAs per f32 product.

@@ -1,0 +1,484 @@
+// conv5 (+BN+ReLU) in the f32-equivalent arithmetic (EPC_PRECISION_F32; EPC-Net-L always), fused with what consumes it, on
+// v_mfma_f32_16x16x32_f16 / _bf16.
+//
+//   MODE_VLAD (EPC-Net: models/epc-net.py:134-148 + loupe.py:249-272): conv5 256 -> 1024, per-point L2 norm, the soft
+//             assignment (feat @ cluster_weights, cluster_bn, softmax over 64); outputs feat (3-byte values), rnorm, the
+//             assignment as bf16 hi + lo B fragments of the aggregate GEMM, per-tile a_sum partials.
+//   MODE_MAX  (EPC-Net-L: models/epc-net-l.py:84-92): conv5 128 -> 1024 and the global max over the cloud's points.
+//
+// Arithmetic: the scaled split-fp16 form of common.h (row / column power-of-two scales, hi + lo fp16 parts, three products
+// lo*hi + hi*lo + hi*hi, f32 accumulate): 2^-21 per product.  The assignment GEMM takes feat split into bf16 hi + lo against
+// bf16 hi + lo cluster weights (three products).
+//
+// Why the 16x16x32 shape: the kernel is bound by the matrix pipe at the clock the chip holds under matrix load, and that clock
+// depends on the MFMA shape (MI355X_MICROARCH.md, DVFS give-back item 7).  scripts/probe/mfma_shape_probe.hip runs this
+// kernel's chunk loop bare (2 waves per SIMD, A fragments re-read from LDS, 3 products): 32x32x16 1.22 PFLOP/s, 16x16x32
+// 1.49 PFLOP/s of executed products on random data -- the same FLOP per cycle, 1.22x the wall-clock rate.
+//
+// Geometry (unchanged from the 32x32 form): 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block
+// (32 points x CIN) lives in registers as fragments for all 32 output chunks (CIN = 256: 128 VGPRs); W5 (hi + lo, 1 MB at
+// CIN = 256) streams through a double-buffered LDS chunk (32 output channels, 128*CIN bytes) shared by the 8 waves: LDS-DMA,
+// one barrier per chunk, the next chunk's pieces in flight under this chunk's MFMAs.
+//
+// Tile algebra.  A 32-channel x 32-point chunk tile is 2 x 2 tiles of 16 x 16, a k-step is 32 input channels.
+//   fragment of lane l (q = l >> 4, li = l & 15) for k-step s:  8 consecutive k = 32 s + 8 q + 0..7 of row / column li
+//   VLAD: D[channel][point] = W^T x^T:  A = weights (row = channel 16 g + li), B = inputs (column = point 16 p + li);
+//         lane holds D[channel 16 g + 4 q + r][point 16 p + li], r = 0..3  -> acc[g][p][r]
+//   MAX : D[point][channel] = x W (operands swapped: the max over points is register- and lane-group-wise);
+//         lane holds D[point 16 p + 4 q + r][channel 16 g + li]             -> acc[g][p][r]
+// The same register image serves as A or B operand, so both modes read the same packed weights (pack.hip
+// fold_pack_conv5_kernel, f16 = 0):  W5p[chunk c][k-step s][g][part (hi, lo)][lane][8 fp16].
+//
+// feat (VLAD) leaves as 3-byte values in accumulator order: the lane's 16 values of a chunk, value 4 t + r with t = 2 g + p,
+// = feat[point 16 p + li][channel 32 c + 16 g + 4 q + r], packed into 12 dwords = three 16-byte pieces:
+// [tile][chunk][piece][lane][16 B] (1 KB per wave-instruction).  The assignment GEMM reads the same accumulators as its B
+// operand: for point group p, k index 8 q + e of the chunk's 32 channels <-> channel 16 (e >> 2) + 4 q + (e & 3); the
+// cluster weights are packed in that k order (pack.hip pack_wc_bf16x2_kernel).
+#include <type_traits>
+#include "common.h"
+
+#define C5_THREADS 512
+#define C5_WAVES 8
+enum { MODE_VLAD = 0, MODE_MAX = 1 };
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma16_f16(f16x8 a, f16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int CIN, int MODE>
+struct C5fLds {  // offsets in floats (4 B)
+    static constexpr int W5_CHUNK = 32 * CIN;              // hi + lo fragments of 32 output channels: 128 * CIN bytes
+    static constexpr int WC_CHUNK = 2048;                  // cluster weights of the chunk's 32 channels: 4 groups x (hi, lo) x 1 KB
+    static constexpr int OFF_W5 = 0;
+    static constexpr int OFF_WC = 2 * W5_CHUNK;
+    static constexpr int OFF_B5 = OFF_WC + (MODE == MODE_VLAD ? 2 * WC_CHUNK : 0);
+    static constexpr int OFF_TI = OFF_B5 + 1024;           // the 1024 inverse column scales
+    static constexpr int OFF_CBN = OFF_TI + 1024;          // VLAD: cluster_bn scale[64], shift[64]
+    // per-wave 32 x 32 f32 transpose tile (row stride 36) of the VLAD final epilogue: aliases the W5 stream buffers, dead by then
+    static constexpr int OFF_T = OFF_W5;
+    static constexpr int T_WAVE = 33 * 36;
+    static constexpr int OFF_MAX = OFF_CBN + 128;          // MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
+    static constexpr int OFF_IS = OFF_MAX + 1536;          // MAX: per wave the 32 inverse row scales of its tile
+    static constexpr int TOTAL = OFF_IS + 256;
+};
+
+// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64][tinv 1024]   (VLAD)
+//                                    [W5p CIN*1024][b5f 1024][tinv 1024]                                     (MAX)
+template <int CIN, int MODE>
+__global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __restrict__ cat, const float* __restrict__ pack,
+                                                               int total_points, int n, float* __restrict__ feat,
+                                                               float* __restrict__ rnorm, float* __restrict__ assign,
+                                                               float* __restrict__ assign_frag, float* __restrict__ apart,
+                                                               float* __restrict__ pooled) {
+    using L = C5fLds<CIN, MODE>;
+    constexpr int STEPS = CIN / 32;
+    static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const float* gw5 = pack;
+    const float* gb5 = pack + (size_t)CIN * 1024;
+    const float* gwc = gb5 + 1024;
+    const float* gcbn = gwc + 1024 * 64;
+    const float* gti = MODE == MODE_VLAD ? gcbn + 128 : gb5 + 1024;
+
+    // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction lands 1 KB at a wave-uniform LDS
+    // base + lane * 16 = the packed fragment order).  Completion: a counted vmcnt in the chunk loop, then a raw s_barrier.
+    constexpr int W5_PIECES = L::W5_CHUNK / (C5_WAVES * 256);  // 1-KB pieces per wave per chunk
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
+    const unsigned lane_off = lane * 16;
+    auto stage_chunk = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int u = 0; u < W5_PIECES; ++u) {
+            const int piece = u * C5_WAVES + wave_u;
+            glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
+                   lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
+        }
+        if constexpr (MODE == MODE_VLAD)   // 8 KB per chunk: one 1-KB piece from each wave
+            glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
+                   lds_base + 4u * (L::OFF_WC + (c & 1) * L::WC_CHUNK + wave_u * 256));
+    };
+
+    stage_chunk(0, std::integral_constant<int, 0>{});
+    for (int o = tid; o < 1024; o += C5_THREADS) {
+        lds[L::OFF_B5 + o] = gb5[o];
+        lds[L::OFF_TI + o] = gti[o];
+    }
+    if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
+
+    const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
+    const bool active = g0 < total_points;
+    const bool wg_one_cloud = MODE == MODE_MAX && n % (C5_WAVES * 32) == 0;  // the workgroup's 8 tiles share a cloud
+
+    // ---- the wave's 32 x CIN input block as fragments: lane (li, q) holds, for point group p and k-step s, channels
+    // 32 s + 8 q .. + 7 of point 16 p + li.  ONE pass: the lane's 2 * STEPS quarter-row pieces are loaded (32 B each, the four q
+    // lanes of a point cover 128 contiguous bytes), the row's largest magnitude meets over the four q lanes, and every eight raw
+    // values are split IN PLACE into their hi and lo fragment registers -- the raw row and the fragments never coexist.
+    f16x8 xh[2][STEPS], xl[2][STEPS];
+    float inv_row[2];
+    {
+        float raw[2][STEPS][8];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float* row = cat + (size_t)(active ? g0 + 16 * p + li : 0) * CIN + 8 * q;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const float4 a = active ? ld4(row + 32 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b = active ? ld4(row + 32 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                raw[p][s][0] = a.x, raw[p][s][1] = a.y, raw[p][s][2] = a.z, raw[p][s][3] = a.w;
+                raw[p][s][4] = b.x, raw[p][s][5] = b.y, raw[p][s][6] = b.z, raw[p][s][7] = b.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float m = 0.f;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) m = fmaxf(fmaxf(m, fabsf(raw[p][s][e])), fabsf(raw[p][s][e + 1]));
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float row_s;
+            row_scale_pow2(m, row_s, inv_row[p]);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) split8_f16s(raw[p][s], row_s, xh[p][s], xl[p][s]);
+        }
+    }
+    // MAX: register r of acc[g][p] belongs to point 16 p + 4 q + r, whose inverse row scale lives in the lane that loaded it:
+    // through a wave-private LDS row, read back once (the tile's 8 scales of this lane's q)
+    float isr[2][4];
+    if constexpr (MODE == MODE_MAX) {
+        if (q == 0) {
+            lds[L::OFF_IS + wave * 32 + li] = inv_row[0];
+            lds[L::OFF_IS + wave * 32 + 16 + li] = inv_row[1];
+        }
+    }
+
+    f32x4v P[4][2];   // VLAD: logits^T, P[cg][p][r] = cluster 16 cg + 4 q + r, point 16 p + li
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) P[cg][0] = P[cg][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float ss[2] = {0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (MODE == MODE_MAX) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float4 v = ld4(lds + L::OFF_IS + wave * 32 + 16 * p + 4 * q);
+            isr[p][0] = v.x, isr[p][1] = v.y, isr[p][2] = v.z, isr[p][3] = v.w;
+        }
+    }
+
+    // max-pool mode: fold the 8 per-wave maxima of chunk c (written before the barrier that ended it) into the workgroup's
+    auto fold_chunk_max = [&](int c) {
+        if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
+            const float* red = lds + L::OFF_MAX + (c & 1) * 256 + tid;
+            float m = red[0];
+#pragma unroll
+            for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
+            lds[L::OFF_MAX + 512 + 32 * c + tid] = m;
+        }
+    };
+
+    auto do_chunk = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (c > 0) fold_chunk_max(c - 1);
+        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+        const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
+        // ---- the chunk's MFMA chain: 2 x 2 accumulator tiles, STEPS k-steps, three products: 12 * STEPS MFMAs ----
+        f32x4v acc[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[g][0] = acc[g][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        // fragment reads run one (k-step, channel group) ahead of the MFMAs that consume them
+        constexpr int NF = 2 * STEPS;
+        f16x8 fa[2][2];   // [ring slot][hi, lo]
+        fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
+        fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int s = f >> 1, g = f & 1;
+            if (f + 1 < NF) {
+                fa[(f + 1) & 1][0] = ldfrag16(w5 + (((f + 1) * 2 + 0) * 64 + lane) * 4);
+                fa[(f + 1) & 1][1] = ldfrag16(w5 + (((f + 1) * 2 + 1) * 64 + lane) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
+            const f16x8 wh = fa[f & 1][0], wl = fa[f & 1][1];
+            if constexpr (MODE == MODE_VLAD) {
+                acc[g][0] = mfma16_f16(wl, xh[0][s], acc[g][0]);
+                acc[g][1] = mfma16_f16(wl, xh[1][s], acc[g][1]);
+                acc[g][0] = mfma16_f16(wh, xl[0][s], acc[g][0]);
+                acc[g][1] = mfma16_f16(wh, xl[1][s], acc[g][1]);
+                acc[g][0] = mfma16_f16(wh, xh[0][s], acc[g][0]);
+                acc[g][1] = mfma16_f16(wh, xh[1][s], acc[g][1]);
+            } else {   // operands swapped: D[point][channel]
+                acc[g][0] = mfma16_f16(xh[0][s], wl, acc[g][0]);
+                acc[g][1] = mfma16_f16(xh[1][s], wl, acc[g][1]);
+                acc[g][0] = mfma16_f16(xl[0][s], wh, acc[g][0]);
+                acc[g][1] = mfma16_f16(xl[1][s], wh, acc[g][1]);
+                acc[g][0] = mfma16_f16(xh[0][s], wh, acc[g][0]);
+                acc[g][1] = mfma16_f16(xh[1][s], wh, acc[g][1]);
+            }
+        }
+        // ---- epilogue: out = relu(acc * (inverse row scale * inverse column scale) + bias) ----
+        if constexpr (MODE == MODE_VLAD) {
+            const float* wc = lds + L::OFF_WC + (c & 1) * L::WC_CHUNK;
+            auto wfrag = [&](int cg, int part) { return ldfrag(wc + ((cg * 2 + part) * 64 + lane) * 4); };
+            // the cluster-weight fragments of the first two cluster groups are requested before the VALU work below
+            bf16x8 wq[2][2] = {{wfrag(0, 0), wfrag(0, 1)}, {wfrag(1, 0), wfrag(1, 1)}};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 bv = ld4(lds + L::OFF_B5 + 32 * c + 16 * g + 4 * q), tv = ld4(lds + L::OFF_TI + 32 * c + 16 * g + 4 * q);
+                const float b4[4] = {bv.x, bv.y, bv.z, bv.w}, t4[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = __builtin_fmaf(acc[g][p][r], inv_row[p] * t4[r], b4[r]);
+                        const int vb = __float_as_int(a);
+                        const float y = __int_as_float(vb > 0 ? vb : 0);      // ReLU on the bit pattern (NaN stays NaN)
+                        acc[g][p][r] = y;
+                        ss[p] += y * y;
+                    }
+            }
+            // feat leaves as 3-BYTE values (the upper 24 bits of the float, rounded: 16 significant bits -- its only reader, the
+            // aggregate, multiplies by rnorm and splits the product into bf16 hi + lo, 16 significant bits as well): the lane's 16
+            // values in order 4 t + r, t = 2 g + p, are 12 dwords = three 16-B stores, 1 KB per wave-instruction.
+            if (active) {
+                unsigned int w[12];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4v& v = acc[t >> 1][t & 1];
+                    const unsigned int a = __float_as_uint(v[0]) + 0x80u, b = __float_as_uint(v[1]) + 0x80u;
+                    const unsigned int cc = __float_as_uint(v[2]) + 0x80u, d = __float_as_uint(v[3]) + 0x80u;
+                    w[3 * t] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
+                    w[3 * t + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
+                    w[3 * t + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
+                }
+                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 768 + lane * 4;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    *reinterpret_cast<u32x4*>(fdst + pc * 256) = u32x4{w[4 * pc], w[4 * pc + 1], w[4 * pc + 2], w[4 * pc + 3]};
+            }
+            // assignment GEMM share of this chunk: P^T (64 clusters x 32 points) += Wc^T (64 x 32 ch) feat^T (32 ch x 32 points);
+            // (feat * rn) @ Wc == (feat @ Wc) * rn, so it runs while the norm is still accumulating.  B operand of point group p:
+            // k index 8 q + e <-> channel 16 (e >> 2) + 4 q + (e & 3) = the lane's own accumulators acc[e >> 2][p][e & 3].
+            bf16x8 fh[2], fl[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3],
+                                    acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
+                split8(v, fh[p], fl[p]);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 wn[2][2];
+                if (half == 0) wn[0][0] = wfrag(2, 0), wn[0][1] = wfrag(2, 1), wn[1][0] = wfrag(3, 0), wn[1][1] = wfrag(3, 1);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int cg = 2 * half + k2;
+                    const bf16x8 wh = wq[k2][0], wl = wq[k2][1];
+                    P[cg][0] = mfma16_bf16(wl, fh[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wl, fh[1], P[cg][1]);
+                    P[cg][0] = mfma16_bf16(wh, fl[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wh, fl[1], P[cg][1]);
+                    P[cg][0] = mfma16_bf16(wh, fh[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wh, fh[1], P[cg][1]);
+                }
+                if (half == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
+            }
+        } else {
+            // channel = 16 g + li, the 4 registers are points 16 p + 4 q + r.  Max over the tile's 32 points: registers, the two
+            // point groups, then the four q lanes.  When the workgroup's 8 tiles lie in one cloud the per-wave maxima meet in LDS
+            // (red: two chunk-parity slabs of 8 waves x 32 channels) and the workgroup's 1024 maxima leave as 256-B atomic
+            // wave-instructions at the very end; otherwise each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
+            // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
+            float* red = lds + L::OFF_MAX + (c & 1) * 256 + wave * 32;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float ti = lds[L::OFF_TI + 32 * c + 16 * g + li], bv = lds[L::OFF_B5 + 32 * c + 16 * g + li];
+                float m = 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = __builtin_fmaf(acc[g][p][r], isr[p][r] * ti, bv);
+                        const int vb = __float_as_int(a);
+                        m = fmaxf(m, __int_as_float(vb > 0 ? vb : 0));
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                if (!active) m = 0.f;
+                if (wg_one_cloud) {
+                    if (q == 0) red[16 * g + li] = m;
+                } else if (active && q == 0) {
+                    atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + 16 * g + li), __float_as_uint(m));
+                }
+            }
+        }
+        // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 3 feat stores
+        // issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores drain everything.
+        if (MODE == MODE_VLAD && active)
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int c = 0; c < 32; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{});
+        do_chunk(c + 1, std::integral_constant<int, 1>{});
+    }
+
+    if (MODE == MODE_MAX && wg_one_cloud) {
+        fold_chunk_max(31);
+        __syncthreads();
+        unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
+        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 512 + o]));
+    }
+
+    if (MODE == MODE_VLAD && active) {
+        // per-point inverse norm (models/epc-net.py:148): the point's 1024 squares sit in its four q lanes
+        float rn[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float s_ = ss[p];
+            s_ += __shfl_xor(s_, 16);
+            s_ += __shfl_xor(s_, 32);
+            rn[p] = 1.0f / sqrtf(fmaxf(s_, 1e-12f));
+        }
+        // cluster_bn (folded: logit * s + t) then softmax over the 64 clusters (16 here, 48 in the other three q lanes)
+        const float* cs = lds + L::OFF_CBN;
+        const float* ct = cs + 64;
+        float inv_sum[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 16 * cg + 4 * q + r;
+                    const float v = (P[cg][p][r] * rn[p]) * cs[k] + ct[k];
+                    P[cg][p][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = expf(P[cg][p][r] - mx);
+                    P[cg][p][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            inv_sum[p] = sum;
+        }
+        if (assign) {  // the f32 point-major copy is for op-level callers; the fused pipeline passes NULL (67 MB less HBM)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float* arow = assign + (size_t)(g0 + 16 * p + li) * 64 + 4 * q;
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+                    st4(arow + 16 * cg, make_float4(P[cg][p][0] / inv_sum[p], P[cg][p][1] / inv_sum[p], P[cg][p][2] / inv_sum[p],
+                                                    P[cg][p][3] / inv_sum[p]));
+            }
+        }
+        if (q == 0) {
+            rnorm[g0 + li] = rn[0];
+            rnorm[g0 + 16 + li] = rn[1];
+        }
+        // the assignments as bf16 hi + lo B fragments of the aggregate GEMM (cluster -> lane, 8 consecutive points -> fragment:
+        // [tile][cluster tile t][k-step][part][lane][8], a[32 g + 16 ks + 8 (l >> 5) + e][32 t + (l & 31)]) and the tile's partial
+        // a_sum (loupe.py:276), through a per-wave [cluster][point] LDS tile.  rnorm is applied on the feature side there.
+        float* T = lds + L::OFF_T + wave * L::T_WAVE;
+        float* fdst = assign_frag + (size_t)(g0 >> 5) * 2048 + lane * 4;
+        const int j = lane & 31, h = lane >> 5;
+        float asum[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(16 * k2 + 4 * q + r) * 36 + 16 * p + li] = P[2 * t + k2][p][r] / inv_sum[p];
+            float s_ = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+                const float4 a0 = ld4(T + j * 36 + 16 * ks + 8 * h), a1 = ld4(T + j * 36 + 16 * ks + 8 * h + 4);
+                v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_ += v[e];
+                bf16x8 ah, al;
+                split8(v, ah, al);
+                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 0) * 256) = __builtin_bit_cast(u32x4, ah);
+                *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 1) * 256) = __builtin_bit_cast(u32x4, al);
+            }
+            asum[t] = s_ + __shfl_xor(s_, 32);
+        }
+        if (h == 0) {
+            apart[(size_t)(g0 >> 5) * 64 + j] = asum[0];
+            apart[(size_t)(g0 >> 5) * 64 + 32 + j] = asum[1];
+        }
+    }
+}
+
+template <int CIN, int MODE>
+static int launch_conv5_f32(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm, float* assign,
+                            float* assign_frag, float* apart, float* pooled, hipStream_t stream, const char* who) {
+    const size_t lds_bytes = C5fLds<CIN, MODE>::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f32_kernel<CIN, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) {
+        epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
+    hipLaunchKernelGGL((conv5_f32_kernel<CIN, MODE>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack, (int)total, n,
+                       feat, rnorm, assign, assign_frag, apart, pooled);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
+        return EPC_EHIP;
+    }
+    return EPC_OK;
+}
+
+extern "C" int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
+                                        void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
+                                        void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
+    EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
+    EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
+    if (num_points_total == 0) return EPC_OK;
+    return launch_conv5_f32<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 32, (float*)feat_frag, rnorm,
+                                            assign, (float*)assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
+}
+
+extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
+                                     float* pooled, void* stream) {
+    EPC_CHECK_ARG(cat && packed_conv5 && pooled, "null pointer");
+    EPC_CHECK_ARG(cin == 128, "EPC-Net-L conv5 takes the 128-channel concat (models/epc-net-l.py:84)");
+    EPC_CHECK_ARG(n > 0 && n % 32 == 0 && num_clouds >= 0, "num_points must be a multiple of 32");
+    if (num_clouds == 0) return EPC_OK;
+    const long total = (long)num_clouds * n;
+    hipError_t e = hipMemsetAsync(pooled, 0, (size_t)num_clouds * 1024 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    return launch_conv5_f32<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                           pooled, (hipStream_t)stream, __func__);
+}

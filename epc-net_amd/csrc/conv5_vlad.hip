@@ -18,29 +18,12 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef C5_DMA_INTERLEAVE
+#define C5_DMA_INTERLEAVE 0
+#endif
 #define C5_THREADS 512
 #define C5_WAVES 8
 enum { MODE_VLAD = 0, MODE_MAX = 1 };
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ bf16x8 ldfrag(const float* p) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
-}
-__device__ __forceinline__ f16x8 ldfrag16(const float* p) {
-    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(p));
-}
-// 16 bytes per lane, global -> LDS without a VGPR destination (LDS-DMA): lane l reads uniform_base + lane_byte_off and lands at LDS byte
-// address lds_dst + 16*l (uniform_base and lds_dst wave-uniform, in SGPRs).  Written as inline asm on purpose: with the builtin hipcc (ROCm 7.2) drains
-// vmcnt(0) before the next ds_read of the same __shared__ array, which would serialise the prefetch; the asm form is
-// invisible to its wait bookkeeping, so completion is tracked by the hand-placed counted s_waitcnt in the chunk loop.
-__device__ __forceinline__ void glds16(const float* uniform_base, unsigned lane_byte_off, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst)
-                 : "memory");
-}
 
 // F8LO (EPC-Net): per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][MX fp6 lo fragments:
 // CIN/64 k-steps x (1 KB + 512 B), then 256 B of block scales; pack.hip pack_conv5_lo6_kernel] inside 96*CIN bytes;
@@ -119,6 +102,20 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256)   // 4 (8) KB per chunk: one 1-KB piece from each of four (eight) waves
             glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
                    lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
+    };
+
+    // the same pieces one at a time (u < W5_PIECES: the wave's u-th W5 piece; u == W5_PIECES: its cluster-weight piece), so
+    // that the chunk loop can issue them BETWEEN the k-steps of the running chunk's MFMA chain (C5_DMA_INTERLEAVE)
+    auto stage_piece = [&](int c, auto bufc, int u) {
+        constexpr int buf = decltype(bufc)::value;
+        if (u < W5_PIECES) {
+            const int piece = u * C5_WAVES + wave_u;
+            glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
+                   lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
+        } else if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256) {
+            glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
+                   lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
+        }
     };
 
     stage_chunk(0, std::integral_constant<int, 0>{});
@@ -355,6 +352,20 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
+#if C5_DMA_INTERLEAVE
+                // the next chunk's LDS-DMA pieces, one per few k-steps: a piece costs its wave ~60+ issue cycles, which at the
+                // head of the chunk nothing covers (all eight waves issue theirs together, the matrix pipe idles); here the
+                // wave's own previous MFMA and its SIMD partner's are executing meanwhile.  Waves 4-7 (the partners) issue one
+                // k-step later than waves 0-3.
+                if constexpr (!kF16) {
+                    constexpr int NP = W5_PIECES + (MODE == MODE_VLAD ? 1 : 0);
+                    constexpr int STRIDE = (STEPS - 2) / NP > 0 ? (STEPS - 2) / NP : 1;
+                    if (c + 1 < 32 && s >= 1 && (s - 1) % STRIDE <= 1 && (s - 1) / STRIDE < NP) {
+                        const bool mine = ((s - 1) % STRIDE) == (wave_u >> 2);
+                        if (mine) stage_piece(c + 1, std::integral_constant<int, buf ^ 1>{}, (s - 1) / STRIDE);
+                    }
+                }
+#endif
                 if constexpr (kF16) {
                     acc = mfma_f16(fa[s % RING][0], xf[s], acc);
                 } else if constexpr (MODE == MODE_MAX) {   // operands swapped: D[point][channel]
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         constexpr int buf = decltype(bufc)::value;
         if (c > 0) fold_chunk_max(c - 1);
 #ifndef C5_ABL_NODMA
-        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+        if (c + 1 < 32 && !(C5_DMA_INTERLEAVE && !kF16)) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
 #endif
         chunk_mfma(c, bufc);
         chunk_epi(c);
@@ -747,34 +758,6 @@ extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, cons
     return launch_conv5<256, MODE_VLAD, false, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n,
                                                      (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
                                                      status, (hipStream_t)stream, __func__);
-}
-
-extern "C" int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* packed_conv5, int num_points_total,
-                                        void* feat_frag, float* rnorm, float* assign, void* assign_frag, float* apart,
-                                        void* stream) {
-    EPC_CHECK_ARG(cat && packed_conv5 && feat_frag && rnorm && assign_frag && apart, "null pointer");
-    EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
-    EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
-    if (num_points_total == 0) return EPC_OK;
-    return launch_conv5<256, MODE_VLAD, false, false>(cat, (const float*)packed_conv5, num_points_total, 32, (float*)feat_frag,
-                                                      rnorm, assign, (float*)assign_frag, apart, nullptr, nullptr,
-                                                      (hipStream_t)stream, __func__);
-}
-
-extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
-                                     float* pooled, void* stream) {
-    EPC_CHECK_ARG(cat && packed_conv5 && pooled, "null pointer");
-    EPC_CHECK_ARG(cin == 128, "EPC-Net-L conv5 takes the 128-channel concat (models/epc-net-l.py:84)");
-    EPC_CHECK_ARG(n > 0 && n % 32 == 0 && num_clouds >= 0, "num_points must be a multiple of 32");
-    if (num_clouds == 0) return EPC_OK;
-    const long total = (long)num_clouds * n;
-    hipError_t e = hipMemsetAsync(pooled, 0, (size_t)num_clouds * 1024 * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) {
-        epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
-        return EPC_EHIP;
-    }
-    return launch_conv5<128, MODE_MAX, false, false>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr,
-                                                     nullptr, nullptr, pooled, nullptr, (hipStream_t)stream, __func__);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1028,6 +1011,7 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     unsigned short* xt = reinterpret_cast<unsigned short*>(s_asum + 8 * 64);   // [8 waves][hi, lo][32 points][AGG_ROW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
+    const int li = lane & 15, q4 = lane >> 4;            // conv5_f32.hip's lane roles: point-in-group, channel quad
     const int wg = blockIdx.x, fgi = (wg >> 3) & 3;      // XCD-aware (cloud, feature group) mapping: see vlad_aggregate_kernel
     const int cloud = (wg >> 5) * 8 + (wg & 7);
     if (cloud >= num_clouds) return;
@@ -1065,18 +1049,20 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     // Three LDS slots per half (aliasing the exchange buffer of the epilogue), one workgroup barrier per tile: a wave may run one
     // tile ahead of the slowest, and the slot it fills (t + 2) is neither the one being read (t) nor the one landed (t + 1).
     struct Tile {
-        u32x4 raw[AGG_FT][3];  // [chunk][piece]: the lane's 16 three-byte values of a chunk (value 4r + e = channel 8r + 4h + e of point j)
-        float rn;
+        // [chunk][piece]: the lane's 16 three-byte values of a chunk in conv5_f32.hip's accumulator order: with li = lane & 15,
+        // q = lane >> 4, value 4 t + r (t = 2 g + p) = channel 16 g + 4 q + r of point 16 p + li
+        u32x4 raw[AGG_FT][3];
+        float rn[2];           // rnorm of points li and 16 + li
     };
     const int sp_u = __builtin_amdgcn_readfirstlane(sp), w3_u = __builtin_amdgcn_readfirstlane(wave & 3);
     const int per_u = __builtin_amdgcn_readfirstlane(per);
     const size_t gt0_u = (size_t)cloud * tiles + (sp_u ? half : 0);
     float* stg = xch + sp_u * (3 * 2048);                       // [3 slots][2048 floats] of this half
     const unsigned stg_lds = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)stg;
-    // A tile's 9 vector-memory operations (6 feat loads, rnorm, 2 LDS-DMA pieces) are inline asm and their completion a
+    // A tile's 10 vector-memory operations (6 feat loads, 2 rnorm, 2 LDS-DMA pieces) are inline asm and their completion a
     // hand-counted s_waitcnt: as C++ loads hipcc 7.2 ended every tile on `s_waitcnt vmcnt(0)` (its wait bookkeeping merges the
-    // exec-masked prefetch branches) and the ping-pong overlapped nothing.  Operations complete in issue order, so `vmcnt(9)`
-    // after the NEXT tile's 9 are issued is "this tile has landed".
+    // exec-masked prefetch branches) and the ping-pong overlapped nothing.  Operations complete in issue order, so `vmcnt(10)`
+    // after the NEXT tile's 10 are issued is "this tile has landed".
     auto load = [&](Tile& t, int tt, int slot) {
         const char* fa = reinterpret_cast<const char*>(feat_frag + ((gt0_u + tt) * 32 + (size_t)fg * AGG_FT) * 768 + lane * 4);
 #pragma unroll
@@ -1084,16 +1070,17 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(t.raw[c][q]) : "v"(fa + (c * 768 + q * 256) * 4));
-        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn) : "v"(rnorm + (gt0_u + tt) * 32 + j));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn[0]) : "v"(rnorm + (gt0_u + tt) * 32 + li));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(t.rn[1]) : "v"(rnorm + (gt0_u + tt) * 32 + 16 + li));
         const float* fb = assign_frag + (gt0_u + tt) * 2048 + (2 * w3_u) * 256;      // this wave's two 1-KB pieces of the tile
         glds16(fb, lane * 16, stg_lds + 4u * (slot * 2048 + (2 * w3_u) * 256));
         glds16(fb + 256, lane * 16, stg_lds + 4u * (slot * 2048 + (2 * w3_u + 1) * 256));
     };
-    static_assert(AGG_FT == 2, "a tile is 6 + 1 + 2 = 9 vector-memory operations: the counted wait below says 9");
+    static_assert(AGG_FT == 2, "a tile is 6 + 2 + 2 = 10 vector-memory operations: the counted wait below says 10");
     auto landed = [&](Tile& t) {
-        asm volatile("s_waitcnt vmcnt(9)"
+        asm volatile("s_waitcnt vmcnt(10)"
                      : "+v"(t.raw[0][0]), "+v"(t.raw[0][1]), "+v"(t.raw[0][2]), "+v"(t.raw[1][0]), "+v"(t.raw[1][1]), "+v"(t.raw[1][2]),
-                       "+v"(t.rn)
+                       "+v"(t.rn[0]), "+v"(t.rn[1])
                      :
                      : "memory");
     };
@@ -1102,7 +1089,6 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     unsigned short* img_hi = xt + (wave * 2 + 0) * 32 * AGG_ROW;
     unsigned short* img_lo = xt + (wave * 2 + 1) * 32 * AGG_ROW;
-    const int li = lane & 15;
     const int tr_off = (8 * h + (li >> 2)) * AGG_ROW + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
     auto tr_read = [&](const unsigned short* img, int ks) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + tr_off + (16 * ks) * AGG_ROW));
@@ -1132,13 +1118,13 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
                                             __builtin_amdgcn_perm(w2, w1, 0x0403020cu), w2 & 0xffffff00u};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = __uint_as_float(fv[e]) * t.rn;
+                    const float y = __uint_as_float(fv[e]) * t.rn[r4 & 1];
                     const __bf16 yh = (__bf16)y;
                     const __bf16 yl = (__bf16)(y - (float)yh);
                     hb[e] = __builtin_bit_cast(unsigned short, yh);
                     lb[e] = __builtin_bit_cast(unsigned short, yl);
                 }
-                const int off = j * AGG_ROW + 8 * r4 + 4 * h;   // channels 8r + 4h + 0..3 of point j
+                const int off = (16 * (r4 & 1) + li) * AGG_ROW + 16 * (r4 >> 1) + 4 * q4;   // t = r4 = 2 g + p: channels 16 g + 4 q + 0..3 of point 16 p + li
                 *reinterpret_cast<uint2*>(img_hi + off) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
                 *reinterpret_cast<uint2*>(img_lo + off) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
             }
@@ -1179,8 +1165,8 @@ __global__ __launch_bounds__(AGG_THREADS) void vlad_aggregate_f32_kernel(const f
         // stay allocated until it has executed.  (The spare DMA pieces target LDS slots the epilogue's exchange buffer aliases.)
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(t0.raw[0][0]), "+v"(t0.raw[0][1]), "+v"(t0.raw[0][2]), "+v"(t0.raw[1][0]), "+v"(t0.raw[1][1]), "+v"(t0.raw[1][2]),
-                       "+v"(t0.rn), "+v"(t1.raw[0][0]), "+v"(t1.raw[0][1]), "+v"(t1.raw[0][2]), "+v"(t1.raw[1][0]), "+v"(t1.raw[1][1]),
-                       "+v"(t1.raw[1][2]), "+v"(t1.rn)
+                       "+v"(t0.rn[0]), "+v"(t0.rn[1]), "+v"(t1.raw[0][0]), "+v"(t1.raw[0][1]), "+v"(t1.raw[0][2]), "+v"(t1.raw[1][0]),
+                       "+v"(t1.raw[1][1]), "+v"(t1.raw[1][2]), "+v"(t1.rn[0]), "+v"(t1.rn[1])
                      :
                      : "memory");
         __syncthreads();

@@ -109,31 +109,38 @@ __global__ void colscale_kernel(const float* __restrict__ W, const float* __rest
 // conv5 weights as fragments (layout + arithmetic: common.h, conv5_vlad.hip C5Lds).  One thread per (chunk, k, channel).
 // f16 = 1 (EPC-Net: conv5 feeds the VLAD aggregation): per chunk [fp16 hi of W * W5_SCALE: k-step s (16 k), lane, 8]
 //         then the MX fp6 lo fragments written by pack_conv5_lo6_kernel; bias scaled by W5_SCALE.
-// f16 = 0 (f32-equivalent arithmetic): fp16 hi and lo fragments of W' / tinv[col] interleaved per k-step (scaled
-//         split-fp16 form, common.h); bias un-scaled.
+// f16 = 0 (f32-equivalent arithmetic, conv5_f32.hip): fp16 hi and lo fragments of W' / tinv[col] for the 16x16x32 MFMA
+//         (scaled split-fp16 form, common.h); bias un-scaled.
 __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ mean, const float* __restrict__ var, int cin, int f16,
                                        unsigned short* __restrict__ dstW, float* __restrict__ dstB,
                                        unsigned int* __restrict__ guard, const float* __restrict__ tinv) {
     const int o = blockIdx.x * 256 + threadIdx.x;
-    const int steps = cin / 16;
     const float scale = f16 ? W5_SCALE : 1.0f;
     if (o < cin * 1024) {
         const int j = o & 7, lane = (o >> 3) & 63, rest = o >> 9;
-        const int s = rest % steps, c = rest / steps;
-        const int k = 16 * s + 8 * (lane >> 5) + j, col = 32 * c + (lane & 31);
-        const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col) * scale;
         if (f16) {
+            // 32x32x16 fragments: k-step s = 16 input channels, lane l = (column l & 31, k-octet l >> 5)
+            const int steps = cin / 16;
+            const int s = rest % steps, c = rest / steps;
+            const int k = 16 * s + 8 * (lane >> 5) + j, col = 32 * c + (lane & 31);
+            const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col) * scale;
             const _Float16 h = (_Float16)w;
             guard_track(guard, w);
             const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
             dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
         } else {
+            // 16x16x32 fragments (conv5_f32.hip): [chunk c][k-step s (32 input channels)][channel group g (16)][part][lane][8],
+            // lane l = (column l & 15, k-octet l >> 4)
+            const int steps = cin / 32;
+            const int g = rest & 1, s = (rest >> 1) % steps, c = (rest >> 1) / steps;
+            const int k = 32 * s + 8 * (lane >> 4) + j, col = 32 * c + 16 * g + (lane & 15);
+            const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col);
             const float ws = w * (1.0f / tinv[col]);   // exact: a power of two
             const _Float16 hh = (_Float16)ws;
             const _Float16 ll = (_Float16)(ws - (float)hh);
-            const size_t base = ((size_t)(c * steps + s) * 2) * 512 + lane * 8 + j;
+            const size_t base = ((size_t)((c * steps + s) * 2 + g) * 2) * 512 + lane * 8 + j;
             dstW[base] = __builtin_bit_cast(unsigned short, hh);
             dstW[base + 512] = __builtin_bit_cast(unsigned short, ll);
         }
@@ -237,17 +244,19 @@ __global__ void pack_wc_f16_kernel(const float* __restrict__ Wc, unsigned short*
     dst[o] = __builtin_bit_cast(unsigned short, h);
 }
 
-// EPC_PRECISION_F32: the same fragments as bf16 hi + lo, un-scaled:
-// [chunk c][k-step sp][cluster tile t][part (hi, lo)][lane][8]
+// EPC_PRECISION_F32: bf16 hi + lo, un-scaled, as A fragments of v_mfma_f32_16x16x32_bf16 (conv5_f32.hip):
+// [chunk c][cluster group cg (4 x 16)][part (hi, lo)][lane][8]: element j of lane l (q = l >> 4) =
+// Wc[32c + 16(j >> 2) + 4q + (j & 3)][16 cg + (l & 15)] -- the k order in which a lane's conv5 accumulators
+// (acc[g = j >> 2][.][r = j & 3] = channel 16 g + 4 q + r) form the B operand.
 __global__ void pack_wc_bf16x2_kernel(const float* __restrict__ Wc, unsigned short* __restrict__ dst) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= 1024 * 64) return;
-    const int j = o & 7, lane = (o >> 3) & 63, t = (o >> 9) & 1, sp = (o >> 10) & 1, c = o >> 11;
-    const int ch = 32 * c + 16 * sp + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
-    const float w = Wc[(size_t)ch * 64 + 32 * t + (lane & 31)];
+    const int j = o & 7, lane = (o >> 3) & 63, cg = (o >> 9) & 3, c = o >> 11;
+    const int ch = 32 * c + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    const float w = Wc[(size_t)ch * 64 + 16 * cg + (lane & 15)];
     const unsigned short hi = bf16_bits_rne(w);
     const unsigned short lo = bf16_bits_rne(w - bf16_bits_to_float(hi));
-    const size_t base = ((size_t)((c * 2 + sp) * 2 + t) * 2) * 512 + lane * 8 + j;
+    const size_t base = ((size_t)(c * 4 + cg) * 2) * 512 + lane * 8 + j;
     dst[base] = hi;
     dst[base + 512] = lo;
 }

@@ -110,11 +110,12 @@ def run_stages(eng, xyz):
             L.check(lib.epc_vlad_aggregate_f32_fwd(featf.data_ptr(), assignf.data_ptr(), rnorm.data_ptr(),
                                                    apart.data_ptr(), off(6), nc, n, vlad.data_ptr(), colss.data_ptr(), st))
             # 3-byte values (include/epcnet.h): the 48 bytes of lane l of (tile g, chunk c) -- its three 16-byte pieces
-            # concatenated -- are 16 little-endian values, value 4r + e -> feat[32g + (l&31)][32c + 8r + 4(l>>5) + e]
+            # concatenated -- are 16 little-endian values; with li = l & 15, q = l >> 4, value 4t + r (t = 2g2 + p) ->
+            # feat[32g + 16p + li][32c + 16g2 + 4q + r]   (conv5_f32.hip's 16x16x32 accumulator order)
             by = featf.permute(0, 1, 3, 2, 4).reshape(M // 32, 32, 64, 16, 3).to(torch.int32)       # (g, c, l, value, byte)
             bits = (by[..., 0] << 8) | (by[..., 1] << 16) | (by[..., 2] << 24)
-            ff = bits.view(torch.float32).reshape(M // 32, 32, 2, 32, 4, 4)                           # (g, c, h, j, r, e)
-            feat = ff.permute(0, 3, 1, 4, 2, 5).reshape(nc, n, 1024)                                  # (g, j, c, r, h, e)
+            ff = bits.view(torch.float32).reshape(M // 32, 32, 4, 16, 2, 2, 4)                       # (g, c, q, li, g2, p, r)
+            feat = ff.permute(0, 5, 3, 1, 4, 2, 6).reshape(nc, n, 1024)                              # (g, p, li, c, g2, q, r)
             # [tile g][t][s][part][lane l][q] -> a[32g + 16s + 8(l>>5) + q][32t + (l&31)], hi + lo
             af = assignf.float().sum(3).reshape(M // 32, 2, 2, 2, 32, 8)   # (g, t, s, h, j, q)
             aprime = af.permute(0, 2, 3, 5, 1, 4).reshape(nc, n, 64) * rnorm.reshape(nc, n, 1)

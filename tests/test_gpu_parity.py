@@ -487,14 +487,16 @@ def test_pairwise_topk_nan_rows_and_queries(dev):
         assert np.array_equal(idx[ok], remap[iref])
         assert np.allclose(dist[ok], dref, rtol=1e-5, atol=1e-5)
     assert np.array_equal(lds[0], ws[0]) and np.array_equal(lds[1], ws[1])
-    # fewer than k finite rows: 30 rows, 10 of them NaN, k = 25 -> 20 neighbours then (-1, +Inf)
+    # fewer than k finite rows: 30 rows, 11 of them NaN (row 5 from above), k = 25 -> 19 neighbours then (-1, +Inf)
     db2 = db[:30].copy()
     db2[10:20] = np.nan
+    nf = int(np.isfinite(db2).all(axis=1).sum())
+    assert nf == 19
     lds2, ws2 = _topk_both(L, db2, q[:5], k, dev)
     for idx, dist in (lds2, ws2):
         for i in (0, 1, 3, 4):
-            assert (idx[i, :20] >= 0).all() and (idx[i, 20:] == -1).all() and np.isinf(dist[i, 20:]).all()
-            assert not set(idx[i, :20].tolist()) & set(range(10, 20))
+            assert (idx[i, :nf] >= 0).all() and (idx[i, nf:] == -1).all() and np.isinf(dist[i, nf:]).all()
+            assert not set(idx[i, :nf].tolist()) & (set(range(10, 20)) | {5})
         assert (idx[2] == -1).all()
     # canaries: the workspace form must not write past its buffers when a query is NaN (the old fallback stored row[0x7fffffff])
     tdb, tq = torch.from_numpy(db).to(dev), torch.from_numpy(q).to(dev)
