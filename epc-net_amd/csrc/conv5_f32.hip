@@ -15,10 +15,24 @@
 // kernel's chunk loop bare (2 waves per SIMD, A fragments re-read from LDS, 3 products): 32x32x16 1.22 PFLOP/s, 16x16x32
 // 1.49 PFLOP/s of executed products on random data -- the same FLOP per cycle, 1.22x the wall-clock rate.
 //
-// Geometry (unchanged from the 32x32 form): 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block
-// (32 points x CIN) lives in registers as fragments for all 32 output chunks (CIN = 256: 128 VGPRs); W5 (hi + lo, 1 MB at
-// CIN = 256) streams through a double-buffered LDS chunk (32 output channels, 128*CIN bytes) shared by the 8 waves: LDS-DMA,
-// one barrier per chunk, the next chunk's pieces in flight under this chunk's MFMAs.
+// Geometry: 512 threads = 8 waves (two per SIMD), one 32-point tile per wave; the wave's input row block (32 points x CIN)
+// lives in registers as fragments for all 32 output chunks (CIN = 256: 128 VGPRs); W5 (hi + lo, 1 MB at CIN = 256) streams
+// through a double-buffered LDS chunk (32 output channels, 128*CIN bytes) shared by the 8 waves: LDS-DMA, ONE barrier per
+// chunk, the next chunk's pieces in flight under this chunk's MFMAs.
+//
+// Schedule.  In-kernel stamps (-DC5_STAMPS, scripts/c5_stamps.py) of the lock-step form -- every wave: chain(c), epilogue(c),
+// barrier -- showed the two waves of a SIMD serialising: the older wave wins the matrix pipe and runs its 96-MFMA chain, the
+// younger one runs its chain afterwards (beside the older one's epilogue), then its own epilogue beside NOTHING while the older
+// wave idles at the barrier (per wave: barrier wait 11 %, the un-overlapped epilogue 23 % of the cycles; matrix pipe busy 59 %
+// of the chunk loop).  So the two waves of a SIMD run the chunk in different orders around the same single barrier:
+//     waves 0-3:  [DMA c+1]  chain(c)      epilogue(c)  | barrier c
+//     waves 4-7:  [DMA c+1]  epilogue(c-1) chain(c)     | barrier c
+// -- each SIMD always has one wave on the matrix pipe and one in the VALU / store epilogue, and both reach the barrier
+// together.  Hazards: a W5 buffer is overwritten only after the barrier that follows every wave's chain on it (as before);
+// waves 4-7 read chunk c's cluster weights one interval late, so those sit in FOUR LDS slots (chunk c + 4's piece is issued
+// after barrier c + 2); the max-pool form's per-wave maxima sit in four slabs for the same reason and are folded two
+// intervals late.  (A 256-thread, two-workgroups-per-CU form with the SIMD partners in different workgroups was also built
+// and measured: no barrier ties the partners, but each wave issues twice the LDS-DMA and the phases drift: 0.458 vs 0.449 ms.)
 //
 // Tile algebra.  A 32-channel x 32-point chunk tile is 2 x 2 tiles of 16 x 16, a k-step is 32 input channels.
 //   fragment of lane l (q = l >> 4, li = l & 15) for k-step s:  8 consecutive k = 32 s + 8 q + 0..7 of row / column li
@@ -50,20 +64,42 @@ __device__ __forceinline__ f32x4v mfma16_bf16(bf16x8 a, bf16x8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifdef C5_STAMPS
+// Diagnostic build only (scripts/c5_stamps.py): per wave the shader cycles spent in each phase of the kernel, summed over the
+// 32 chunks -- [prologue, DMA issue, MFMA chain, epilogue VALU + stores, vmcnt / lgkmcnt wait, barrier, final epilogue, total].
+// The values go to a buffer of their own that nothing else reads; the product build contains no stamp.
+__device__ unsigned int c5_stamp_buf[16384][8];
+extern "C" int epc_debug_c5_stamps(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(c5_stamp_buf), bytes < sizeof(c5_stamp_buf) ? bytes : sizeof(c5_stamp_buf)) == hipSuccess ? 0 : -3;
+}
+#define C5_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define C5_ADD(dst, a, b) dst += (unsigned)((b) - (a))
+#else
+#define C5_T(var)
+#define C5_ADD(dst, a, b)
+#endif
+#ifndef C5_START_STAGGER
+#define C5_START_STAGGER 0   // shader cycles between the start phases of first-round workgroups (0 = none)
+#endif
+#ifndef C5_ASYM
+#define C5_ASYM 1   // 0: the lock-step schedule (every wave chain, epilogue, barrier), kept for the A/B measurement
+#endif
+
 template <int CIN, int MODE>
 struct C5fLds {  // offsets in floats (4 B)
     static constexpr int W5_CHUNK = 32 * CIN;              // hi + lo fragments of 32 output channels: 128 * CIN bytes
     static constexpr int WC_CHUNK = 2048;                  // cluster weights of the chunk's 32 channels: 4 groups x (hi, lo) x 1 KB
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
-    static constexpr int OFF_B5 = OFF_WC + (MODE == MODE_VLAD ? 2 * WC_CHUNK : 0);
+    static constexpr int WC_SLOTS = 4;                     // waves 4-7 read a chunk's cluster weights one interval late
+    static constexpr int OFF_B5 = OFF_WC + (MODE == MODE_VLAD ? WC_SLOTS * WC_CHUNK : 0);
     static constexpr int OFF_TI = OFF_B5 + 1024;           // the 1024 inverse column scales
     static constexpr int OFF_CBN = OFF_TI + 1024;          // VLAD: cluster_bn scale[64], shift[64]
     // per-wave 32 x 32 f32 transpose tile (row stride 36) of the VLAD final epilogue: aliases the W5 stream buffers, dead by then
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
-    static constexpr int OFF_MAX = OFF_CBN + 128;          // MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
-    static constexpr int OFF_IS = OFF_MAX + 1536;          // MAX: per wave the 32 inverse row scales of its tile
+    static constexpr int OFF_MAX = OFF_CBN + 128;          // MAX: 4 slabs x 256 per-wave maxima + 1024 workgroup maxima
+    static constexpr int OFF_IS = OFF_MAX + 2048;          // MAX: per wave the 32 inverse row scales of its tile
     static constexpr int TOTAL = OFF_IS + 256;
 };
 
@@ -77,6 +113,10 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
                                                                float* __restrict__ pooled) {
     using L = C5fLds<CIN, MODE>;
     constexpr int STEPS = CIN / 32;
+#ifdef C5_STAMPS
+    unsigned int st_dma = 0, st_mfma = 0, st_epi = 0, st_wait = 0, st_bar = 0;
+#endif
+    C5_T(t_begin);
     static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,9 +143,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
         }
         if constexpr (MODE == MODE_VLAD)   // 8 KB per chunk: one 1-KB piece from each wave
             glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
-                   lds_base + 4u * (L::OFF_WC + (c & 1) * L::WC_CHUNK + wave_u * 256));
+                   lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
     };
 
+#if C5_START_STAGGER
+    // First-round workgroups start a quarter-phase apart: every workgroup's prologue is a 256-KB burst from HBM, all tiles take
+    // the same time, so without this the 256 CUs load together (4.5 TB/s bursts with the matrix pipes idle) and then compute
+    // together; a CU's later workgroups inherit its phase.
+    if (blockIdx.x < 256 && (blockIdx.x & 3)) {
+        const unsigned long long t0s = __builtin_amdgcn_s_memtime();
+        const unsigned long long d = (unsigned long long)(blockIdx.x & 3) * C5_START_STAGGER;
+        while (__builtin_amdgcn_s_memtime() - t0s < d) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     stage_chunk(0, std::integral_constant<int, 0>{});
     for (int o = tid; o < 1024; o += C5_THREADS) {
         lds[L::OFF_B5 + o] = gb5[o];
@@ -167,6 +217,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
     float ss[2] = {0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    C5_T(t_pro);
     if constexpr (MODE == MODE_MAX) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -175,24 +226,23 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
         }
     }
 
-    // max-pool mode: fold the 8 per-wave maxima of chunk c (written before the barrier that ended it) into the workgroup's
+    // max-pool mode: fold the 8 per-wave maxima of chunk c (slab c & 3; every wave has written them once barrier c + 1 has
+    // passed: waves 4-7 run epilogue(c) in interval c + 1) into the workgroup's maxima
     auto fold_chunk_max = [&](int c) {
         if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
-            const float* red = lds + L::OFF_MAX + (c & 1) * 256 + tid;
+            const float* red = lds + L::OFF_MAX + (c & 3) * 256 + tid;
             float m = red[0];
 #pragma unroll
             for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
-            lds[L::OFF_MAX + 512 + 32 * c + tid] = m;
+            lds[L::OFF_MAX + 1024 + 32 * c + tid] = m;
         }
     };
 
-    auto do_chunk = [&](int c, auto bufc) {
+    f32x4v acc[2][2];
+    // ---- the chunk's MFMA chain: 2 x 2 accumulator tiles, STEPS k-steps, three products: 12 * STEPS MFMAs ----
+    auto chain = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (c > 0) fold_chunk_max(c - 1);
-        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
-        // ---- the chunk's MFMA chain: 2 x 2 accumulator tiles, STEPS k-steps, three products: 12 * STEPS MFMAs ----
-        f32x4v acc[2][2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc[g][0] = acc[g][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
         // fragment reads run one (k-step, channel group) ahead of the MFMAs that consume them
@@ -226,12 +276,13 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
                 acc[g][1] = mfma16_f16(xh[1][s], wh, acc[g][1]);
             }
         }
+    };
+    // The epilogue of a chunk in two parts: epi_valu = VALU + stores (un-scale, ReLU, |feat|^2, feat stores, the bf16 split of
+    // the accumulators into fh / fl); assign_mfma = the chunk's 24 assignment MFMAs.
+    bf16x8 fh[2], fl[2];
+    auto epi_valu = [&](int c) {
         // ---- epilogue: out = relu(acc * (inverse row scale * inverse column scale) + bias) ----
         if constexpr (MODE == MODE_VLAD) {
-            const float* wc = lds + L::OFF_WC + (c & 1) * L::WC_CHUNK;
-            auto wfrag = [&](int cg, int part) { return ldfrag(wc + ((cg * 2 + part) * 64 + lane) * 4); };
-            // the cluster-weight fragments of the first two cluster groups are requested before the VALU work below
-            bf16x8 wq[2][2] = {{wfrag(0, 0), wfrag(0, 1)}, {wfrag(1, 0), wfrag(1, 1)}};
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float4 bv = ld4(lds + L::OFF_B5 + 32 * c + 16 * g + 4 * q), tv = ld4(lds + L::OFF_TI + 32 * c + 16 * g + 4 * q);
@@ -269,37 +320,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
             // assignment GEMM share of this chunk: P^T (64 clusters x 32 points) += Wc^T (64 x 32 ch) feat^T (32 ch x 32 points);
             // (feat * rn) @ Wc == (feat @ Wc) * rn, so it runs while the norm is still accumulating.  B operand of point group p:
             // k index 8 q + e <-> channel 16 (e >> 2) + 4 q + (e & 3) = the lane's own accumulators acc[e >> 2][p][e & 3].
-            bf16x8 fh[2], fl[2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3],
                                     acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
                 split8(v, fh[p], fl[p]);
             }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                bf16x8 wn[2][2];
-                if (half == 0) wn[0][0] = wfrag(2, 0), wn[0][1] = wfrag(2, 1), wn[1][0] = wfrag(3, 0), wn[1][1] = wfrag(3, 1);
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int cg = 2 * half + k2;
-                    const bf16x8 wh = wq[k2][0], wl = wq[k2][1];
-                    P[cg][0] = mfma16_bf16(wl, fh[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wl, fh[1], P[cg][1]);
-                    P[cg][0] = mfma16_bf16(wh, fl[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wh, fl[1], P[cg][1]);
-                    P[cg][0] = mfma16_bf16(wh, fh[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wh, fh[1], P[cg][1]);
-                }
-                if (half == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
-            }
         } else {
             // channel = 16 g + li, the 4 registers are points 16 p + 4 q + r.  Max over the tile's 32 points: registers, the two
             // point groups, then the four q lanes.  When the workgroup's 8 tiles lie in one cloud the per-wave maxima meet in LDS
-            // (red: two chunk-parity slabs of 8 waves x 32 channels) and the workgroup's 1024 maxima leave as 256-B atomic
+            // (red: four slabs of 8 waves x 32 channels, chunk c in slab c & 3) and the workgroup's 1024 maxima leave as 256-B atomic
             // wave-instructions at the very end; otherwise each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
             // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
-            float* red = lds + L::OFF_MAX + (c & 1) * 256 + wave * 32;
+            float* red = lds + L::OFF_MAX + (c & 3) * 256 + wave * 32;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float ti = lds[L::OFF_TI + 32 * c + 16 * g + li], bv = lds[L::OFF_B5 + 32 * c + 16 * g + li];
@@ -322,25 +355,84 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
                 }
             }
         }
+    };
+    auto assign_mfma = [&](int c) {
+        if constexpr (MODE == MODE_VLAD) {
+            const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
+            auto wfrag = [&](int cg, int part) { return ldfrag(wc + ((cg * 2 + part) * 64 + lane) * 4); };
+            bf16x8 wq[2][2] = {{wfrag(0, 0), wfrag(0, 1)}, {wfrag(1, 0), wfrag(1, 1)}};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                bf16x8 wn[2][2];
+                if (half == 0) wn[0][0] = wfrag(2, 0), wn[0][1] = wfrag(2, 1), wn[1][0] = wfrag(3, 0), wn[1][1] = wfrag(3, 1);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int cg = 2 * half + k2;
+                    const bf16x8 wh = wq[k2][0], wl = wq[k2][1];
+                    P[cg][0] = mfma16_bf16(wl, fh[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wl, fh[1], P[cg][1]);
+                    P[cg][0] = mfma16_bf16(wh, fl[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wh, fl[1], P[cg][1]);
+                    P[cg][0] = mfma16_bf16(wh, fh[0], P[cg][0]);
+                    P[cg][1] = mfma16_bf16(wh, fh[1], P[cg][1]);
+                }
+                if (half == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
+            }
+        }
+    };
+    // (measured: the assignment MFMAs deferred to the head of the wave's next chain, so that each phase is pure VALU or pure
+    // MFMA: 0.456-0.468 vs 0.441-0.453 ms with the epilogue in one piece -- the pure-VALU part still takes 1 400 cycles per
+    // chunk beside the partner's chain, and the longer chain phase of the late waves lengthens the interval)
+    auto epilogue = [&](int c) {
+        epi_valu(c);
+        assign_mfma(c);
+    };
+    // One interval = everything between two chunk barriers.  `late` waves (4-7) run the epilogue of the PREVIOUS chunk before this
+    // chunk's chain (see Schedule at the top of the file).
+    const bool late = C5_ASYM && wave_u >= 4;
+    auto interval = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        C5_T(t0);
+        if (c >= 2) fold_chunk_max(c - 2);
+        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+        C5_T(t1);
+        if (late && c > 0) epilogue(c - 1);
+        C5_T(t2);
+        chain(bufc);
+        C5_T(t3);
+        if (!late) epilogue(c);
+        C5_T(t4);
         // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 3 feat stores
         // issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores drain everything.
-        if (MODE == MODE_VLAD && active)
+        if (MODE == MODE_VLAD && active && (!late || c > 0))
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        C5_T(t5);
         __builtin_amdgcn_s_barrier();
+        C5_T(t6);
+        C5_ADD(st_dma, t0, t1);
+        C5_ADD(st_epi, t1, t2);
+        C5_ADD(st_mfma, t2, t3);
+        C5_ADD(st_epi, t3, t4);
+        C5_ADD(st_wait, t4, t5);
+        C5_ADD(st_bar, t5, t6);
     };
     for (int c = 0; c < 32; c += 2) {
-        do_chunk(c, std::integral_constant<int, 0>{});
-        do_chunk(c + 1, std::integral_constant<int, 1>{});
+        interval(c, std::integral_constant<int, 0>{});
+        interval(c + 1, std::integral_constant<int, 1>{});
     }
+    if (late) epilogue(31);
+    C5_T(t_loop);
 
     if (MODE == MODE_MAX && wg_one_cloud) {
+        __syncthreads();                 // every wave's epilogue(31) has written its maxima
+        fold_chunk_max(30);
         fold_chunk_max(31);
         __syncthreads();
         unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
-        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 512 + o]));
+        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 1024 + o]));
     }
 
     if (MODE == MODE_VLAD && active) {
@@ -433,6 +525,18 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
             apart[(size_t)(g0 >> 5) * 64 + 32 + j] = asum[1];
         }
     }
+#ifdef C5_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C5_T(t_end);
+        const unsigned wv = blockIdx.x * C5_WAVES + wave;
+        if (lane == 0 && wv < 16384) {
+            unsigned int* o = c5_stamp_buf[wv];
+            o[0] = (unsigned)(t_pro - t_begin), o[1] = st_dma, o[2] = st_mfma, o[3] = st_epi, o[4] = st_wait, o[5] = st_bar;
+            o[6] = (unsigned)(t_end - t_loop), o[7] = (unsigned)(t_end - t_begin);
+        }
+    }
+#endif
 }
 
 template <int CIN, int MODE>
