@@ -507,6 +507,10 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     if (partial) {
         EPC_CHECK_ARG(partial_floats >= (size_t)batch * splitk * M * N, "split-K workspace too small (batch * splitk * M * N floats)");
         EPC_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && bC % 4 == 0, "deterministic split-K needs N, ldc and the batch stride of C in multiples of 4");
+        // splitk_reduce_kernel moves float4s of the partials, of C and of the bias
+        EPC_CHECK_ARG((reinterpret_cast<size_t>(C) & 15) == 0 && (reinterpret_cast<size_t>(partial) & 15) == 0 &&
+                          (!bias || (reinterpret_cast<size_t>(bias) & 15) == 0),
+                      "deterministic split-K needs 16-byte aligned C, bias and workspace");
     }
     if (splitk > 1 && !accumulate && !partial) {  // split-K partial sums are added atomically into a zeroed C
         if (ldc == N && (batch == 1 || bC == (long)M * N)) {

@@ -159,6 +159,7 @@ class InferenceEngine:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
             aux = [ln[0] for ln in self._get_lanes(xyz.device)[:lanes - 1]]
             arr = (ctypes.c_void_p * max(len(aux), 1))(*[a.cuda_stream for a in aux])
+            self._last_cfg = None            # several lanes, several workspace slices: last_status() has no single answer
             L.check(L.lib().epc_net_forward_overlapped(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                        self._ws.data_ptr(), self._ws.numel(), L.current_stream(), arr,
                                                        len(aux)))
@@ -174,10 +175,18 @@ class InferenceEngine:
     def last_status(self, xyz_or_count) -> "list[int]":
         """Per-cloud EPC_STATUS_* words of the last pass of the most recent ``forward`` call on this engine's own
         workspace (include/epcnet.h: epc_net_last_status; synchronises the stream).  A non-zero word = that cloud's
-        descriptor is NaN: bit 0 a NaN / Inf coordinate, bit 1 (fast precision) an activation outside fp16's range."""
+        descriptor is NaN: bit 0 a NaN / Inf coordinate, bit 1 (fast precision) an activation outside fp16's range.
+        Raises after a call that was dealt over several lanes (see below) -- never returns another call's words."""
         nc = int(xyz_or_count.shape[0]) if torch.is_tensor(xyz_or_count) else int(xyz_or_count)
-        if self._ws is None or self._last_cfg is None or nc <= 0:
+        if nc <= 0:
             return []
+        if self._ws is None or self._last_cfg is None:
+            # nothing ran yet, or the last call was dealt over the engine's lanes (num_clouds > micro_batch with in_flight > 1:
+            # epc_net_forward_overlapped keeps one workspace slice per lane, so "the last pass's status words" do not exist in
+            # one place): say so instead of returning stale words (ADVICE r2).  The NaN descriptor marks a flagged cloud in
+            # every mode; for status words run the engine with in_flight=1.
+            raise L.EpcNetError(-1, "last_status(): no single-workspace forward to report on (call forward() with "
+                                    "num_clouds <= micro_batch or an engine built with in_flight=1)")
         mb = L.micro_batch_of(self._last_cfg, nc)
         last = nc % mb or mb
         arr = (ctypes.c_int32 * last)()

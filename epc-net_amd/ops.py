@@ -151,7 +151,7 @@ class Linear(torch.autograd.Function):
         cout = W.shape[1]
         dx = gemm(dy, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         if cin <= 4 and cout == 64:
-            dW = torch.empty_like(W)
+            dW = torch.empty(W.shape, dtype=torch.float32, device=W.device)   # dense [cin][64] (the kernel's layout), whatever W's strides
             pf = L.lib().epc_linear_smallk_dw_partial_floats(rows, cin)
             part = _splitk_ws(pf, x.device)
             L.check(L.lib().epc_linear_smallk_dw(x.data_ptr(), dy.data_ptr(), rows, cin, cout, dW.data_ptr(), part.data_ptr(),

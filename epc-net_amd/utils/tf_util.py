@@ -180,7 +180,25 @@ def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=Fal
     return y
 
 
+# Test hook (tests/test_gpu_train_step.py, mask-pinned gradient parity): when a dict, every ReLU'd layer records the boolean
+# mask `output > 0` of its (rows, C) activations under its full variable scope.  Never set by product code; eager steps only.
+RELU_MASK_TAPS = None
+
+
+def _tap_relu_mask(y) -> None:
+    if RELU_MASK_TAPS is not None:
+        from ..variables import current_scope
+        RELU_MASK_TAPS[current_scope()] = (y.detach() > 0)
+
+
 def _dense(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training):
+    y = _dense_impl(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training)
+    if activation_fn is not None:
+        _tap_relu_mask(y)
+    return y
+
+
+def _dense_impl(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_training):
     from .. import ops
     want_relu = activation_fn is not None
     if activation_fn not in (None, relu):
@@ -223,13 +241,16 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     with variable_scope(scope):
         x2 = inputs.reshape(-1, cin)
         if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
-            return _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True)
+            f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True)
+            _tap_relu_mask(f)          # (the row norm is a positive factor: f > 0 exactly where the ReLU's output is)
+            return f
         z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)
         beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
         f, mean, var = ops.BatchNormReluRowNorm.apply(z, gamma, beta, 1e-3)
         decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
         _ema_update(ema_mean, mean, decay)
         _ema_update(ema_var, var, decay)
+        _tap_relu_mask(f)
     return f
 
 

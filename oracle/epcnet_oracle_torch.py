@@ -50,6 +50,20 @@ class TorchOracle:
             self.w[k] = t
         self.trainable = [k for k, (_, kind) in table.items() if kind in ("weight", "bias", "gamma", "beta")]
         self.new_stats: Dict[str, torch.Tensor] = {}
+        # Mask pinning (tests/test_gpu_train_step.py): {scope: bool array of the layer's output shape}.  A ReLU'd layer named
+        # here computes y * mask instead of relu(y) -- the same piecewise-linear function as the implementation whose forward
+        # produced the masks, so that the two gradients differ by arithmetic only, not by which side of zero a pre-activation
+        # within float32 rounding of zero fell on.  ``relu_mask_disagreement`` counts the elements where relu(y) would have
+        # chosen otherwise.
+        self.relu_masks: Optional[Dict[str, np.ndarray]] = None
+        self.relu_mask_disagreement: Dict[str, int] = {}
+
+    def _relu(self, y, scope):
+        if self.relu_masks is None or scope not in self.relu_masks:
+            return torch.relu(y)
+        m = torch.as_tensor(np.asarray(self.relu_masks[scope]).reshape(tuple(y.shape)), dtype=torch.bool)
+        self.relu_mask_disagreement[scope] = int(((y.detach() > 0) != m).sum())
+        return y * m.to(y.dtype)
 
     # ---- layers ----------------------------------------------------------------------------------------------
     def _tfutil_bn(self, z, scope, axes, training, bn_decay):
@@ -67,7 +81,7 @@ class TorchOracle:
     def conv1d(self, x, scope, training, bn_decay):
         W = self.w[scope + "/weights"]
         z = x @ W.reshape(W.shape[-2], W.shape[-1]) + self.w[scope + "/biases"]
-        return torch.relu(self._tfutil_bn(z, scope, (0, 1), training, bn_decay))
+        return self._relu(self._tfutil_bn(z, scope, (0, 1), training, bn_decay), scope)
 
     def _slim_bn(self, x, scope, training, fused):
         g, b = self.w[scope + "/gamma"], self.w[scope + "/beta"]
@@ -121,7 +135,7 @@ class TorchOracle:
         else:
             net = x.max(dim=1).values
             z = net @ self.w["VLAD/fc1/weights"] + self.w["VLAD/fc1/biases"]
-            out = torch.relu(self._tfutil_bn(z, "VLAD/fc1", (0,), tr, bd))
+            out = self._relu(self._tfutil_bn(z, "VLAD/fc1", (0,), tr, bd), "VLAD/fc1")
         return _l2n(out, 1).reshape(B, P, self.p["FEATURE_OUTPUT_DIM"])
 
 
@@ -135,12 +149,14 @@ def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
 
 def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, other_neg, step: int, epoch: int,
                adam_m: Optional[Dict[str, np.ndarray]] = None, adam_v: Optional[Dict[str, np.ndarray]] = None,
-               arch="epc-net", params=None, m1=0.5, m2=0.2, base_lr=5e-5, batch_num_queries=1, dtype=torch.float64):
+               arch="epc-net", params=None, m1=0.5, m2=0.2, base_lr=5e-5, batch_num_queries=1, dtype=torch.float64,
+               relu_masks: Optional[Dict[str, np.ndarray]] = None):
     """One reference training step (train.py:251-277, 484-495): returns dict(loss, grads, new_weights, adam_m, adam_v).
 
     ``step`` = value of the global-step variable BEFORE the step (``batch``, train.py:246): bn_decay is evaluated with
     it; Adam's bias correction uses t = step + 1 (TensorFlow's beta*_power are multiplied after each apply)."""
     orc = TorchOracle(weights, arch, params, dtype)
+    orc.relu_masks = relu_masks        # None = the reference's relu; a dict pins the masks (see TorchOracle.__init__)
     vecs = np.concatenate([query, positives, negatives, other_neg], axis=1)          # train.py:252
     bn_decay = O.get_bn_decay(step, batch_num_queries)
     out = orc.forward(vecs, True, bn_decay)
@@ -165,4 +181,5 @@ def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, othe
     for k, v in orc.new_stats.items():
         new_w[k] = v.numpy().copy()
     return {"loss": float(loss.detach()), "grads": g_out, "new_weights": new_w, "adam_m": am, "adam_v": av,
-            "lr": lr, "bn_decay": bn_decay, "descriptors": out.detach().numpy()}
+            "lr": lr, "bn_decay": bn_decay, "descriptors": out.detach().numpy(),
+            "relu_mask_disagreement": dict(orc.relu_mask_disagreement)}

@@ -566,6 +566,23 @@ def test_evaluate_protocol_single_rank(dev):
     assert np.array_equal(idx, O.knn_bruteforce(vecs[0], vecs[1], 25)[1])
 
 
+def test_last_status_refuses_after_a_multi_lane_call(dev):
+    """a forward dealt over the engine's lanes (num_clouds > micro_batch, in_flight > 1) keeps one workspace slice per
+    lane, so there are no "status words of the last pass" to report: last_status must raise, not return another call's words."""
+    L = H.pkg("lib")
+    w = O.seeded_weights("epc-net-l", 0)
+    eng, _ = H.make_engine("epc-net-l", w, dev, micro_batch=4)
+    pc = torch.from_numpy(O.synthetic_clouds(12, 256, 3)).to(dev)
+    one = eng.forward(pc[:4])
+    assert eng.last_status(4) == [0, 0, 0, 0]
+    many = eng.forward(pc)                                   # 3 passes over 2 lanes
+    assert torch.equal(many[:4], one)
+    with pytest.raises(L.EpcNetError):
+        eng.last_status(12)
+    eng.forward(pc[4:8])
+    assert eng.last_status(4) == [0, 0, 0, 0]
+
+
 def test_errors_are_loud(dev):
     L = H.pkg("lib")
     w = O.seeded_weights("epc-net", 0)

@@ -54,13 +54,18 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
 
     H.pkg("ops").adam_multi = spy
     TR.ops.adam_multi = spy
+    TFU = H.pkg("utils.tf_util")
+    TFU.RELU_MASK_TAPS = {}                                  # the ReLU masks of THIS forward, for the mask-pinned comparison below
     try:
         to = lambda a: torch.from_numpy(a).to(dev)
         loss, lr, bn_decay = ts.step(to(q), to(pos), to(neg), to(oth), epoch=epoch)
     finally:
         H.pkg("ops").adam_multi = orig
         TR.ops.adam_multi = orig
+        masks, TFU.RELU_MASK_TAPS = TFU.RELU_MASK_TAPS, None
     torch.cuda.synchronize()
+    masks = {k[len(H.OUTER) + 1:]: v.cpu().numpy() for k, v in masks.items()}
+    assert len(masks) == (13 if arch == "epc-net" else 8), sorted(masks)     # 12 + conv5 / 6 + conv5 + fc1 ReLU'd layers
 
     assert lr == pytest.approx(ref["lr"]) and bn_decay == pytest.approx(ref["bn_decay"])
     assert float(loss) == pytest.approx(ref["loss"], rel=2e-5, abs=1e-6)
@@ -99,6 +104,30 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
             k, np.abs(g - g_ref).max(), gmax)
         assert np.linalg.norm(g - g_ref) <= bar_l2 * np.linalg.norm(g_ref) + floor * np.sqrt(g.size), \
             "gradient of %s: relative L2 error %.3e (float32 torch: %.3e)" % (k, rel_l2, noise.get(k, (0, 0))[1])
+    # ---- the same comparison with the ReLU masks PINNED ---------------------------------------------------
+    # The bars above have to leave room for mask flips: a pre-activation within float32 rounding of zero falls on the other
+    # side in the other arithmetic and moves a few gradient elements by per cents of the tensor's maximum.  Given the masks
+    # of the HIP forward, the oracle differentiates the SAME piecewise-linear function, what remains is arithmetic, and every
+    # one of the 62 (30) gradients is held to a relative L2 error of 1e-3 -- a 1 % gradient bug cannot hide behind the flips.
+    # (the training forward Morton-sorts every cloud's points -- the network is permutation-invariant -- so the masks' rows are in
+    # that order: the pinned oracle run gets the same sorted clouds; its gradients do not depend on the order)
+    srt = H.pkg("ops").morton_sort(torch.from_numpy(np.concatenate([q, pos, neg, oth], axis=1)[0]).to(dev)).cpu().numpy()[None]
+    assert np.array_equal(np.sort(srt.reshape(ncl, n * 3), axis=1), np.sort(pcs.reshape(ncl, n * 3), axis=1))
+    pin = T.train_step(w0, srt[:, :1], srt[:, 1:3], srt[:, 3:3 + nneg], srt[:, 3 + nneg:], step=step0, epoch=epoch, arch=arch,
+                       relu_masks=masks)
+    flips = sum(pin["relu_mask_disagreement"].values())
+    total = sum(int(np.prod(m.shape)) for m in masks.values())
+    assert flips <= 2e-5 * total, "the HIP forward's ReLU masks differ from the float64 forward's in %d of %d elements" % (flips, total)
+    worst_pin = (0.0, "")
+    for k, g_ref in pin["grads"].items():
+        g = grads[H.OUTER + "/" + k].reshape(g_ref.shape)
+        if k.endswith("/biases") or np.linalg.norm(g_ref) <= 1e-12:
+            continue                                        # exactly-zero true gradients: held by the absolute floor above
+        rel_l2 = np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref)
+        worst_pin = max(worst_pin, (rel_l2, k))
+        assert rel_l2 <= 1e-3, "mask-pinned gradient of %s: relative L2 error %.3e" % (k, rel_l2)
+    print("train step %s %dx%d, ReLU masks pinned (%d of %d elements differ from the float64 forward's): worst gradient "
+          "relative L2 error %.2e (%s)" % (arch, ncl, n, flips, total, worst_pin[0], worst_pin[1]))
     print("train step %s %dx%d: worst gradient relative L2 error %.2e (%s)%s" % (
         arch, ncl, n, worst[0], worst[1],
         "; float32 torch on the same tensor: %.2e" % noise[worst[1]][1] if noise else ""))
