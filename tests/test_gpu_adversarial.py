@@ -97,7 +97,11 @@ def test_f32_equivalent_arithmetic_everywhere(dev, arch, level):
     e32, e64, gap = errors(out, ref, ref64)
     report("adversarial %s/f32 %s:" % (arch, level), e32, e64, gap)
     assert np.isfinite(out).all() and np.allclose(np.linalg.norm(out, axis=1), 1, atol=1e-5)
-    assert all(within_bar(*t) for t in zip(e32, e64, gap))
+    # BOTH criteria on every cloud of the committed seeds: within 1e-4 of the float32 oracle -- no waiver for
+    # the ill-conditioned clouds, whose float32 oracle itself sits up to 1.5e-4 from the float64 result -- and within
+    # max(1e-4, 4 x that gap) of the float64 oracle.
+    assert (e32 <= DESC_TOL).all(), e32
+    assert all(b <= max(DESC_TOL, 4 * g) for b, g in zip(e64, gap)), (e64, gap)
     assert eng.last_status(len(pc)) == [0] * len(pc)
 
 
