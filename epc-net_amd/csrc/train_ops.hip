@@ -1745,6 +1745,34 @@ __global__ __launch_bounds__(256) void transpose_fill_kernel(const int32_t* __re
     }
 }
 
+// The fill's positions come from an atomic counter, so the ORDER of a list's entries varies from run to run -- and with it the
+// order in which neighbour_gather_bwd_kernel adds the rows, i.e. the last bits of every gradient upstream.  Each list is
+// therefore sorted ascending afterwards (entries are distinct rows): one wave per list, an entry per lane, rank = the number
+// of smaller entries (64 readlanes); lists longer than 64 (hubs of clumped clouds) are insertion-sorted by one lane.
+__global__ __launch_bounds__(256) void transpose_sort_kernel(const int32_t* __restrict__ rdeg, const int32_t* __restrict__ roff,
+                                                             int total_points, int32_t* __restrict__ rlist) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= total_points) return;
+    const int deg = rdeg[j];
+    int32_t* lst = rlist + roff[j];
+    if (deg <= 64) {
+        const int mine = lane < deg ? lst[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int u = 0; u < deg; ++u) rank += __builtin_amdgcn_readlane(mine, u) < mine ? 1 : 0;
+        if (lane < deg) lst[rank] = mine;     // (every lane has read its entry before any lane writes: one wave, in order)
+    } else if (lane == 0) {
+        for (int a = 1; a < deg; ++a) {
+            const int v = lst[a];
+            int b = a - 1;
+            while (b >= 0 && lst[b] > v) {
+                lst[b + 1] = lst[b];
+                --b;
+            }
+            lst[b + 1] = v;
+        }
+    }
+}
+
 extern "C" int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap, int num_clouds, int n, int32_t* rdeg,
                                  int32_t* roff, int32_t* cursor, int32_t* rlist, void* stream) {
     EPC_CHECK_ARG(idx && cnt && rdeg && roff && cursor && rlist, "null pointer");
@@ -1760,6 +1788,7 @@ extern "C" int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap
     hipLaunchKernelGGL(transpose_count_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, rdeg);
     hipLaunchKernelGGL(transpose_scan_kernel, dim3(num_clouds), dim3(1024), 0, st, rdeg, n, cap, roff, cursor);
     hipLaunchKernelGGL(transpose_fill_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, roff, cursor, rlist);
+    hipLaunchKernelGGL(transpose_sort_kernel, dim3(blocks), dim3(256), 0, st, rdeg, roff, (int)total, rlist);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -157,7 +157,7 @@ class Linear(torch.autograd.Function):
             L.check(L.lib().epc_linear_smallk_dw(x.data_ptr(), dy.data_ptr(), rows, cin, cout, dW.data_ptr(), part.data_ptr(),
                                                  part.numel(), _st()))
         else:
-            dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True)
+            dW = gemm(x, dy, trans_a=True, splitk=_splitk_for(cin, cout, rows), fast=True, deterministic=True)
         db = None      # exactly zero in front of a training-mode BatchNorm: left undefined (TrainStep reads it as zeros)
         if ctx.has_bias and not ctx.zero_bias_grad:
             db = torch.empty(cout, dtype=torch.float32, device=x.device)
@@ -292,7 +292,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
                                          beta.data_ptr(), ctx.eps, 1 if ctx.rownorm else ctx.relu, rows, C, dz.data_ptr(),
                                          dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, _st()))
         dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
-        dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True)
+        dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
         return dx, dW, None, dgamma, dbeta, None, None, None
 
 
@@ -612,7 +612,7 @@ class VladAssignAggregate(torch.autograd.Function):
         L.check(L.lib().epc_bn_apply_bwd(dpre.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                          beta.data_ptr(), ctx.eps, 0, rows, 64, dz.data_ptr(), dgamma.data_ptr(),
                                          dbeta.data_ptr(), ws.data_ptr(), n, _st()))
-        dWc = gemm(f, dz, trans_a=True, splitk=_splitk_for(F, 64, rows), fast=True)
+        dWc = gemm(f, dz, trans_a=True, splitk=_splitk_for(F, 64, rows), fast=True, deterministic=True)
         df = None
         if ctx.needs_input_grad[0]:
             lhs = torch.cat((a, dz), dim=1).view(B, N, 128)                                    # [a | dz]

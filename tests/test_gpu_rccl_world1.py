@@ -126,9 +126,7 @@ def test_data_parallel_train_step_through_rccl(rccl, graph):
         losses.append(ls)
     D.force_collective(True)
     assert torch.isfinite(states[0]).all()
-    # step 0 sees identical weights; later losses inherit the run-to-run noise of the previous updates (below)
-    assert losses[0][0] == losses[1][0] and np.allclose(losses[0], losses[1], rtol=1e-4), losses
-    # gradients of the backward's atomically-met dW products repeat to ~1e-5, not bit for bit, between two runs of the same
-    # step; the exchange itself adds nothing on top (mean over one rank, copies)
-    num = (states[0] - states[1]).norm() / states[0].norm()
-    assert float(num) < 1e-6, float(num)
+    # the step is bit-reproducible (ordered split-K, sorted transposed lists) and the exchange adds nothing on top of it (a sum
+    # over one rank, a multiplication by 1.0, copies): identical losses and identical state
+    assert losses[0] == losses[1], losses
+    assert torch.equal(states[0], states[1])

@@ -152,10 +152,10 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
     state = ts.optimizer_state()
     assert int(state["Variable"]) == step0 + 1 and len([k for k in state if k.endswith("/Adam")]) == len(ref["grads"])
     if n == 4096:
-        # repeatability: the FORWARD of the same step from the same state is bit-identical (its split-K products add their slices
-        # in a fixed order, epc_gemm_splitk_det; column reductions are ordered too), so the loss, the descriptors and every ReLU
-        # mask repeat exactly; the backward's dW products (K = all rows) still meet in f32 atomics, whose order varies from run
-        # to run: gradients repeat to float32 rounding, not bit for bit
+        # repeatability: the same step from the same state is bit-identical -- forward AND gradients.  Split-K products add their
+        # slices in a fixed order (epc_gemm_splitk_det: the forward since round 2, the backward's dW products since round 3),
+        # column reductions are ordered, and the transposed neighbour lists the backward gathers over are sorted
+        # (transpose_sort_kernel) instead of standing in the arrival order of an atomic counter.
         first = {k: v.copy() for k, v in grads.items()}
         d_first = ts.last_aux["q_vec"].clone()
         st2 = H.make_store(arch, w0, dev)
@@ -173,9 +173,9 @@ def test_train_step_matches_gradient_oracle(dev, arch, nneg, n):
         torch.cuda.synchronize()
         assert float(loss2) == float(loss)
         assert torch.equal(ts2.last_aux["q_vec"], d_first)
-        for k in ("fastdgcnn/conv1/weights", "fastdgcnn/conv5/weights", "VLAD/hidden1_weights"):
-            a, b = first[H.OUTER + "/" + k], grads[H.OUTER + "/" + k]
-            assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-30), k
+        assert set(first) == set(grads)
+        for k in first:
+            assert np.array_equal(first[k], grads[k]), "gradient of %s differs between two runs of the same step" % k
 
 
 @pytest.mark.parametrize("arch", ["epc-net", "epc-net-l"])
