@@ -75,8 +75,8 @@ SPLIT_PRODUCTS = {("epc-net", "f32"): 3.0, ("epc-net", "fast"): 1.2, ("epc-net-l
 FLOPS_PER_CLOUD = {"epc-net": 3.747e9, "epc-net-l": 1.355e9}
 # arithmetic of the dominant kernel (not a precision claim: tests/test_gpu_parity.py, tests/test_gpu_adversarial.py)
 DTYPE = {("epc-net", "f32"): "f16x3", ("epc-net", "fast"): "f16+f6", ("epc-net-l", "f32"): "f16x3"}
-CONV5_KERNEL = {("epc-net", "f32"): "void conv5_kernel<256, 0, false, false>", ("epc-net", "fast"): "void conv5_kernel<256, 0, true, true>",
-                ("epc-net-l", "f32"): "void conv5_kernel<128, 1, false, false>"}
+CONV5_KERNEL = {("epc-net", "f32"): "void conv5_vlad_f32_kernel<256>", ("epc-net", "fast"): "void conv5_kernel<256, 0, true, true>",
+                ("epc-net-l", "f32"): "void conv5_max_f32_kernel<128>"}
 
 
 def pkg(name=""):

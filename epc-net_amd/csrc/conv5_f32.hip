@@ -1,10 +1,10 @@
 // conv5 (+BN+ReLU) in the f32-equivalent arithmetic (EPC_PRECISION_F32; EPC-Net-L always), fused with what consumes it, on
 // v_mfma_f32_16x16x32_f16 / _bf16.
 //
-//   MODE_VLAD (EPC-Net: models/epc-net.py:134-148 + loupe.py:249-272): conv5 256 -> 1024, per-point L2 norm, the soft
-//             assignment (feat @ cluster_weights, cluster_bn, softmax over 64); outputs feat (3-byte values), rnorm, the
+//   conv5_vlad_f32_kernel (EPC-Net: models/epc-net.py:134-148 + loupe.py:249-272): conv5 256 -> 1024, per-point L2 norm, the
+//             soft assignment (feat @ cluster_weights, cluster_bn, softmax over 64); outputs feat (3-byte values), rnorm, the
 //             assignment as bf16 hi + lo B fragments of the aggregate GEMM, per-tile a_sum partials.
-//   MODE_MAX  (EPC-Net-L: models/epc-net-l.py:84-92): conv5 128 -> 1024 and the global max over the cloud's points.
+//   conv5_max_f32_kernel  (EPC-Net-L: models/epc-net-l.py:84-92): conv5 128 -> 1024 and the global max over the cloud's points.
 //
 // Arithmetic: the scaled split-fp16 form of common.h (row / column power-of-two scales, hi + lo fp16 parts, three products
 // lo*hi + hi*lo + hi*hi, f32 accumulate): 2^-21 per product.  The assignment GEMM takes feat split into bf16 hi + lo against
@@ -40,8 +40,9 @@
 //         lane holds D[channel 16 g + 4 q + r][point 16 p + li], r = 0..3  -> acc[g][p][r]
 //   MAX : D[point][channel] = x W (operands swapped: the max over points is register- and lane-group-wise);
 //         lane holds D[point 16 p + 4 q + r][channel 16 g + li]             -> acc[g][p][r]
-// The same register image serves as A or B operand, so both modes read the same packed weights (pack.hip
-// fold_pack_conv5_kernel, f16 = 0):  W5p[chunk c][k-step s][g][part (hi, lo)][lane][8 fp16].
+// The same register image serves as A or B operand, so both kernels read the same packed weights (pack.hip
+// fold_pack_conv5_kernel, f16 = 0):  W5p[chunk c][g][k-step s][part (hi, lo)][lane][8 fp16] -- a (chunk, channel group)
+// is contiguous: it is one LDS stage of the max-pool kernel, half a chunk buffer of the VLAD kernel.
 //
 // feat (VLAD) leaves as 3-byte values in accumulator order: the lane's 16 values of a chunk, value 4 t + r with t = 2 g + p,
 // = feat[point 16 p + li][channel 32 c + 16 g + 4 q + r], packed into 12 dwords = three 16-byte pieces:
@@ -53,7 +54,6 @@
 
 #define C5_THREADS 512
 #define C5_WAVES 8
-enum { MODE_VLAD = 0, MODE_MAX = 1 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -85,39 +85,67 @@ extern "C" int epc_debug_c5_stamps(void* host, size_t bytes) {
 #define C5_ASYM 1   // 0: the lock-step schedule (every wave chain, epilogue, barrier), kept for the A/B measurement
 #endif
 
-template <int CIN, int MODE>
-struct C5fLds {  // offsets in floats (4 B)
+template <int CIN>
+struct C5fLds {  // VLAD kernel; offsets in floats (4 B)
     static constexpr int W5_CHUNK = 32 * CIN;              // hi + lo fragments of 32 output channels: 128 * CIN bytes
     static constexpr int WC_CHUNK = 2048;                  // cluster weights of the chunk's 32 channels: 4 groups x (hi, lo) x 1 KB
     static constexpr int OFF_W5 = 0;
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int WC_SLOTS = 4;                     // waves 4-7 read a chunk's cluster weights one interval late
-    static constexpr int OFF_B5 = OFF_WC + (MODE == MODE_VLAD ? WC_SLOTS * WC_CHUNK : 0);
+    static constexpr int OFF_B5 = OFF_WC + WC_SLOTS * WC_CHUNK;
     static constexpr int OFF_TI = OFF_B5 + 1024;           // the 1024 inverse column scales
-    static constexpr int OFF_CBN = OFF_TI + 1024;          // VLAD: cluster_bn scale[64], shift[64]
-    // per-wave 32 x 32 f32 transpose tile (row stride 36) of the VLAD final epilogue: aliases the W5 stream buffers, dead by then
+    static constexpr int OFF_CBN = OFF_TI + 1024;          // cluster_bn scale[64], shift[64]
+    // per-wave 32 x 32 f32 transpose tile (row stride 36) of the final epilogue: aliases the W5 stream buffers, dead by then
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
-    static constexpr int OFF_MAX = OFF_CBN + 128;          // MAX: 4 slabs x 256 per-wave maxima + 1024 workgroup maxima
-    static constexpr int OFF_IS = OFF_MAX + 2048;          // MAX: per wave the 32 inverse row scales of its tile
-    static constexpr int TOTAL = OFF_IS + 256;
+    static constexpr int TOTAL = OFF_CBN + 128;
 };
 
-// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64][tinv 1024]   (VLAD)
-//                                    [W5p CIN*1024][b5f 1024][tinv 1024]                                     (MAX)
-template <int CIN, int MODE>
-__global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __restrict__ cat, const float* __restrict__ pack,
-                                                               int total_points, int n, float* __restrict__ feat,
-                                                               float* __restrict__ rnorm, float* __restrict__ assign,
-                                                               float* __restrict__ assign_frag, float* __restrict__ apart,
-                                                               float* __restrict__ pooled) {
-    using L = C5fLds<CIN, MODE>;
+// The wave's 32 x CIN input block as scaled split-fp16 fragments (common.h): lane (li, q) holds, for point group p and k-step s,
+// channels 32 s + 8 q .. + 7 of point 16 p + li.  ONE pass: the lane's 2 * STEPS quarter-row pieces are loaded (32 B each, the
+// four q lanes of a point cover 128 contiguous bytes), the row's largest magnitude meets over the four q lanes, and every eight
+// raw values are split IN PLACE into their hi and lo fragment registers -- the raw row and the fragments never coexist.
+// A macro on purpose: as a function taking xh / xl by reference hipcc 7.2 keeps the raw rows and the fragments in separate
+// registers (256 VGPRs + 39 spilled instead of 242).  Declares xh, xl, inv_row in the caller's scope.
+#define C5_LOAD_ROWS_SPLIT(CIN_, cat_, g0_, active_, li_, q_)                                                                    \
+    f16x8 xh[2][(CIN_) / 32], xl[2][(CIN_) / 32];                                                                                \
+    float inv_row[2];                                                                                                            \
+    {                                                                                                                            \
+        float raw[2][(CIN_) / 32][8];                                                                                            \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                          \
+            const float* row = (cat_) + (size_t)((active_) ? (g0_) + 16 * p + (li_) : 0) * (CIN_) + 8 * (q_);                    \
+            _Pragma("unroll") for (int s = 0; s < (CIN_) / 32; ++s) {                                                            \
+                const float4 a = (active_) ? ld4(row + 32 * s) : make_float4(0.f, 0.f, 0.f, 0.f);                                \
+                const float4 b = (active_) ? ld4(row + 32 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);                            \
+                raw[p][s][0] = a.x, raw[p][s][1] = a.y, raw[p][s][2] = a.z, raw[p][s][3] = a.w;                                  \
+                raw[p][s][4] = b.x, raw[p][s][5] = b.y, raw[p][s][6] = b.z, raw[p][s][7] = b.w;                                  \
+            }                                                                                                                    \
+        }                                                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                          \
+            float m = 0.f;                                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < (CIN_) / 32; ++s)                                                              \
+                _Pragma("unroll") for (int e = 0; e < 8; e += 2) m = fmaxf(fmaxf(m, fabsf(raw[p][s][e])), fabsf(raw[p][s][e + 1])); \
+            m = fmaxf(m, __shfl_xor(m, 16));                                                                                     \
+            m = fmaxf(m, __shfl_xor(m, 32));                                                                                     \
+            float row_s;                                                                                                         \
+            row_scale_pow2(m, row_s, inv_row[p]);                                                                                \
+            _Pragma("unroll") for (int s = 0; s < (CIN_) / 32; ++s) split8_f16s(raw[p][s], row_s, xh[p][s], xl[p][s]);           \
+        }                                                                                                                        \
+    }
+
+// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64][tinv 1024]
+template <int CIN>
+__global__ __launch_bounds__(C5_THREADS) void conv5_vlad_f32_kernel(const float* __restrict__ cat, const float* __restrict__ pack,
+                                                                    int total_points, float* __restrict__ feat,
+                                                                    float* __restrict__ rnorm, float* __restrict__ assign,
+                                                                    float* __restrict__ assign_frag, float* __restrict__ apart) {
+    using L = C5fLds<CIN>;
     constexpr int STEPS = CIN / 32;
 #ifdef C5_STAMPS
     unsigned int st_dma = 0, st_mfma = 0, st_epi = 0, st_wait = 0, st_bar = 0;
 #endif
     C5_T(t_begin);
-    static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
+    static_assert(C5_WAVES * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, q = lane >> 4;
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
     const float* gb5 = pack + (size_t)CIN * 1024;
     const float* gwc = gb5 + 1024;
     const float* gcbn = gwc + 1024 * 64;
-    const float* gti = MODE == MODE_VLAD ? gcbn + 128 : gb5 + 1024;
+    const float* gti = gcbn + 128;
 
     // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction lands 1 KB at a wave-uniform LDS
     // base + lane * 16 = the packed fragment order).  Completion: a counted vmcnt in the chunk loop, then a raw s_barrier.
@@ -141,8 +169,8 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
             glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
                    lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
         }
-        if constexpr (MODE == MODE_VLAD)   // 8 KB per chunk: one 1-KB piece from each wave
-            glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
+        glds16(   // the chunk's cluster weights, 8 KB: one 1-KB piece from each wave
+            gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
                    lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
     };
 
@@ -161,82 +189,20 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
         lds[L::OFF_B5 + o] = gb5[o];
         lds[L::OFF_TI + o] = gti[o];
     }
-    if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
+    if (tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
 
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
-    const bool wg_one_cloud = MODE == MODE_MAX && n % (C5_WAVES * 32) == 0;  // the workgroup's 8 tiles share a cloud
 
-    // ---- the wave's 32 x CIN input block as fragments: lane (li, q) holds, for point group p and k-step s, channels
-    // 32 s + 8 q .. + 7 of point 16 p + li.  ONE pass: the lane's 2 * STEPS quarter-row pieces are loaded (32 B each, the four q
-    // lanes of a point cover 128 contiguous bytes), the row's largest magnitude meets over the four q lanes, and every eight raw
-    // values are split IN PLACE into their hi and lo fragment registers -- the raw row and the fragments never coexist.
-    f16x8 xh[2][STEPS], xl[2][STEPS];
-    float inv_row[2];
-    {
-        float raw[2][STEPS][8];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float* row = cat + (size_t)(active ? g0 + 16 * p + li : 0) * CIN + 8 * q;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const float4 a = active ? ld4(row + 32 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 b = active ? ld4(row + 32 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                raw[p][s][0] = a.x, raw[p][s][1] = a.y, raw[p][s][2] = a.z, raw[p][s][3] = a.w;
-                raw[p][s][4] = b.x, raw[p][s][5] = b.y, raw[p][s][6] = b.z, raw[p][s][7] = b.w;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float m = 0.f;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) m = fmaxf(fmaxf(m, fabsf(raw[p][s][e])), fabsf(raw[p][s][e + 1]));
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float row_s;
-            row_scale_pow2(m, row_s, inv_row[p]);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) split8_f16s(raw[p][s], row_s, xh[p][s], xl[p][s]);
-        }
-    }
-    // MAX: register r of acc[g][p] belongs to point 16 p + 4 q + r, whose inverse row scale lives in the lane that loaded it:
-    // through a wave-private LDS row, read back once (the tile's 8 scales of this lane's q)
-    float isr[2][4];
-    if constexpr (MODE == MODE_MAX) {
-        if (q == 0) {
-            lds[L::OFF_IS + wave * 32 + li] = inv_row[0];
-            lds[L::OFF_IS + wave * 32 + 16 + li] = inv_row[1];
-        }
-    }
+    C5_LOAD_ROWS_SPLIT(CIN, cat, g0, active, li, q)
 
-    f32x4v P[4][2];   // VLAD: logits^T, P[cg][p][r] = cluster 16 cg + 4 q + r, point 16 p + li
+    f32x4v P[4][2];   // logits^T, P[cg][p][r] = cluster 16 cg + 4 q + r, point 16 p + li
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) P[cg][0] = P[cg][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
     float ss[2] = {0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     C5_T(t_pro);
-    if constexpr (MODE == MODE_MAX) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float4 v = ld4(lds + L::OFF_IS + wave * 32 + 16 * p + 4 * q);
-            isr[p][0] = v.x, isr[p][1] = v.y, isr[p][2] = v.z, isr[p][3] = v.w;
-        }
-    }
-
-    // max-pool mode: fold the 8 per-wave maxima of chunk c (slab c & 3; every wave has written them once barrier c + 1 has
-    // passed: waves 4-7 run epilogue(c) in interval c + 1) into the workgroup's maxima
-    auto fold_chunk_max = [&](int c) {
-        if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
-            const float* red = lds + L::OFF_MAX + (c & 3) * 256 + tid;
-            float m = red[0];
-#pragma unroll
-            for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
-            lds[L::OFF_MAX + 1024 + 32 * c + tid] = m;
-        }
-    };
 
     f32x4v acc[2][2];
     // ---- the chunk's MFMA chain: 2 x 2 accumulator tiles, STEPS k-steps, three products: 12 * STEPS MFMAs ----
@@ -245,36 +211,29 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc[g][0] = acc[g][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        // fragment reads run one (k-step, channel group) ahead of the MFMAs that consume them
+        // fragment reads run one (k-step, channel group) ahead of the MFMAs that consume them; the pack holds group g's k-steps
+        // contiguously: fragment (s, g) is the (g * STEPS + s)-th hi / lo pair of the chunk
         constexpr int NF = 2 * STEPS;
+        auto frag = [&](int f, int part) { return ldfrag16(w5 + ((((f & 1) * STEPS + (f >> 1)) * 2 + part) * 64 + lane) * 4); };
         f16x8 fa[2][2];   // [ring slot][hi, lo]
-        fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
-        fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
+        fa[0][0] = frag(0, 0);
+        fa[0][1] = frag(0, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const int s = f >> 1, g = f & 1;
             if (f + 1 < NF) {
-                fa[(f + 1) & 1][0] = ldfrag16(w5 + (((f + 1) * 2 + 0) * 64 + lane) * 4);
-                fa[(f + 1) & 1][1] = ldfrag16(w5 + (((f + 1) * 2 + 1) * 64 + lane) * 4);
+                fa[(f + 1) & 1][0] = frag(f + 1, 0);
+                fa[(f + 1) & 1][1] = frag(f + 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
             const f16x8 wh = fa[f & 1][0], wl = fa[f & 1][1];
-            if constexpr (MODE == MODE_VLAD) {
-                acc[g][0] = mfma16_f16(wl, xh[0][s], acc[g][0]);
-                acc[g][1] = mfma16_f16(wl, xh[1][s], acc[g][1]);
-                acc[g][0] = mfma16_f16(wh, xl[0][s], acc[g][0]);
-                acc[g][1] = mfma16_f16(wh, xl[1][s], acc[g][1]);
-                acc[g][0] = mfma16_f16(wh, xh[0][s], acc[g][0]);
-                acc[g][1] = mfma16_f16(wh, xh[1][s], acc[g][1]);
-            } else {   // operands swapped: D[point][channel]
-                acc[g][0] = mfma16_f16(xh[0][s], wl, acc[g][0]);
-                acc[g][1] = mfma16_f16(xh[1][s], wl, acc[g][1]);
-                acc[g][0] = mfma16_f16(xl[0][s], wh, acc[g][0]);
-                acc[g][1] = mfma16_f16(xl[1][s], wh, acc[g][1]);
-                acc[g][0] = mfma16_f16(xh[0][s], wh, acc[g][0]);
-                acc[g][1] = mfma16_f16(xh[1][s], wh, acc[g][1]);
-            }
+            acc[g][0] = mfma16_f16(wl, xh[0][s], acc[g][0]);
+            acc[g][1] = mfma16_f16(wl, xh[1][s], acc[g][1]);
+            acc[g][0] = mfma16_f16(wh, xl[0][s], acc[g][0]);
+            acc[g][1] = mfma16_f16(wh, xl[1][s], acc[g][1]);
+            acc[g][0] = mfma16_f16(wh, xh[0][s], acc[g][0]);
+            acc[g][1] = mfma16_f16(wh, xh[1][s], acc[g][1]);
         }
     };
     // The epilogue of a chunk in two parts: epi_valu = VALU + stores (un-scale, ReLU, |feat|^2, feat stores, the bf16 split of
@@ -282,102 +241,70 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
     bf16x8 fh[2], fl[2];
     auto epi_valu = [&](int c) {
         // ---- epilogue: out = relu(acc * (inverse row scale * inverse column scale) + bias) ----
-        if constexpr (MODE == MODE_VLAD) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float4 bv = ld4(lds + L::OFF_B5 + 32 * c + 16 * g + 4 * q), tv = ld4(lds + L::OFF_TI + 32 * c + 16 * g + 4 * q);
-                const float b4[4] = {bv.x, bv.y, bv.z, bv.w}, t4[4] = {tv.x, tv.y, tv.z, tv.w};
+        for (int g = 0; g < 2; ++g) {
+            const float4 bv = ld4(lds + L::OFF_B5 + 32 * c + 16 * g + 4 * q), tv = ld4(lds + L::OFF_TI + 32 * c + 16 * g + 4 * q);
+            const float b4[4] = {bv.x, bv.y, bv.z, bv.w}, t4[4] = {tv.x, tv.y, tv.z, tv.w};
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a = __builtin_fmaf(acc[g][p][r], inv_row[p] * t4[r], b4[r]);
-                        const int vb = __float_as_int(a);
-                        const float y = __int_as_float(vb > 0 ? vb : 0);      // ReLU on the bit pattern (NaN stays NaN)
-                        acc[g][p][r] = y;
-                        ss[p] += y * y;
-                    }
-            }
-            // feat leaves as 3-BYTE values (the upper 24 bits of the float, rounded: 16 significant bits -- its only reader, the
-            // aggregate, multiplies by rnorm and splits the product into bf16 hi + lo, 16 significant bits as well): the lane's 16
-            // values in order 4 t + r, t = 2 g + p, are 12 dwords = three 16-B stores, 1 KB per wave-instruction.
-            if (active) {
-                unsigned int w[12];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const f32x4v& v = acc[t >> 1][t & 1];
-                    const unsigned int a = __float_as_uint(v[0]) + 0x80u, b = __float_as_uint(v[1]) + 0x80u;
-                    const unsigned int cc = __float_as_uint(v[2]) + 0x80u, d = __float_as_uint(v[3]) + 0x80u;
-                    w[3 * t] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
-                    w[3 * t + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
-                    w[3 * t + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
+                for (int r = 0; r < 4; ++r) {
+                    const float a = __builtin_fmaf(acc[g][p][r], inv_row[p] * t4[r], b4[r]);
+                    const int vb = __float_as_int(a);
+                    const float y = __int_as_float(vb > 0 ? vb : 0);      // ReLU on the bit pattern (NaN stays NaN)
+                    acc[g][p][r] = y;
+                    ss[p] += y * y;
                 }
-                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 768 + lane * 4;
+        }
+        // feat leaves as 3-BYTE values (the upper 24 bits of the float, rounded: 16 significant bits -- its only reader, the
+        // aggregate, multiplies by rnorm and splits the product into bf16 hi + lo, 16 significant bits as well): the lane's 16
+        // values in order 4 t + r, t = 2 g + p, are 12 dwords = three 16-B stores, 1 KB per wave-instruction.
+        if (active) {
+            unsigned int w[12];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    *reinterpret_cast<u32x4*>(fdst + pc * 256) = u32x4{w[4 * pc], w[4 * pc + 1], w[4 * pc + 2], w[4 * pc + 3]};
+            for (int t = 0; t < 4; ++t) {
+                const f32x4v& v = acc[t >> 1][t & 1];
+                const unsigned int a = __float_as_uint(v[0]) + 0x80u, b = __float_as_uint(v[1]) + 0x80u;
+                const unsigned int cc = __float_as_uint(v[2]) + 0x80u, d = __float_as_uint(v[3]) + 0x80u;
+                w[3 * t] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
+                w[3 * t + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
+                w[3 * t + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
             }
-            // assignment GEMM share of this chunk: P^T (64 clusters x 32 points) += Wc^T (64 x 32 ch) feat^T (32 ch x 32 points);
-            // (feat * rn) @ Wc == (feat @ Wc) * rn, so it runs while the norm is still accumulating.  B operand of point group p:
-            // k index 8 q + e <-> channel 16 (e >> 2) + 4 q + (e & 3) = the lane's own accumulators acc[e >> 2][p][e & 3].
+            float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 768 + lane * 4;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3],
-                                    acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
-                split8(v, fh[p], fl[p]);
-            }
-        } else {
-            // channel = 16 g + li, the 4 registers are points 16 p + 4 q + r.  Max over the tile's 32 points: registers, the two
-            // point groups, then the four q lanes.  When the workgroup's 8 tiles lie in one cloud the per-wave maxima meet in LDS
-            // (red: four slabs of 8 waves x 32 channels, chunk c in slab c & 3) and the workgroup's 1024 maxima leave as 256-B atomic
-            // wave-instructions at the very end; otherwise each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
-            // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
-            float* red = lds + L::OFF_MAX + (c & 3) * 256 + wave * 32;
+            for (int pc = 0; pc < 3; ++pc)
+                *reinterpret_cast<u32x4*>(fdst + pc * 256) = u32x4{w[4 * pc], w[4 * pc + 1], w[4 * pc + 2], w[4 * pc + 3]};
+        }
+        // assignment GEMM share of this chunk: P^T (64 clusters x 32 points) += Wc^T (64 x 32 ch) feat^T (32 ch x 32 points);
+        // (feat * rn) @ Wc == (feat @ Wc) * rn, so it runs while the norm is still accumulating.  B operand of point group p:
+        // k index 8 q + e <-> channel 16 (e >> 2) + 4 q + (e & 3) = the lane's own accumulators acc[e >> 2][p][e & 3].
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float ti = lds[L::OFF_TI + 32 * c + 16 * g + li], bv = lds[L::OFF_B5 + 32 * c + 16 * g + li];
-                float m = 0.f;
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a = __builtin_fmaf(acc[g][p][r], isr[p][r] * ti, bv);
-                        const int vb = __float_as_int(a);
-                        m = fmaxf(m, __int_as_float(vb > 0 ? vb : 0));
-                    }
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
-                if (!active) m = 0.f;
-                if (wg_one_cloud) {
-                    if (q == 0) red[16 * g + li] = m;
-                } else if (active && q == 0) {
-                    atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + 16 * g + li), __float_as_uint(m));
-                }
-            }
+        for (int p = 0; p < 2; ++p) {
+            const float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3],
+                                acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
+            split8(v, fh[p], fl[p]);
         }
     };
     auto assign_mfma = [&](int c) {
-        if constexpr (MODE == MODE_VLAD) {
-            const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
-            auto wfrag = [&](int cg, int part) { return ldfrag(wc + ((cg * 2 + part) * 64 + lane) * 4); };
-            bf16x8 wq[2][2] = {{wfrag(0, 0), wfrag(0, 1)}, {wfrag(1, 0), wfrag(1, 1)}};
+        const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
+        auto wfrag = [&](int cg, int part) { return ldfrag(wc + ((cg * 2 + part) * 64 + lane) * 4); };
+        bf16x8 wq[2][2] = {{wfrag(0, 0), wfrag(0, 1)}, {wfrag(1, 0), wfrag(1, 1)}};
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                bf16x8 wn[2][2];
-                if (half == 0) wn[0][0] = wfrag(2, 0), wn[0][1] = wfrag(2, 1), wn[1][0] = wfrag(3, 0), wn[1][1] = wfrag(3, 1);
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 wn[2][2];
+            if (half == 0) wn[0][0] = wfrag(2, 0), wn[0][1] = wfrag(2, 1), wn[1][0] = wfrag(3, 0), wn[1][1] = wfrag(3, 1);
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int cg = 2 * half + k2;
-                    const bf16x8 wh = wq[k2][0], wl = wq[k2][1];
-                    P[cg][0] = mfma16_bf16(wl, fh[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wl, fh[1], P[cg][1]);
-                    P[cg][0] = mfma16_bf16(wh, fl[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wh, fl[1], P[cg][1]);
-                    P[cg][0] = mfma16_bf16(wh, fh[0], P[cg][0]);
-                    P[cg][1] = mfma16_bf16(wh, fh[1], P[cg][1]);
-                }
-                if (half == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int cg = 2 * half + k2;
+                const bf16x8 wh = wq[k2][0], wl = wq[k2][1];
+                P[cg][0] = mfma16_bf16(wl, fh[0], P[cg][0]);
+                P[cg][1] = mfma16_bf16(wl, fh[1], P[cg][1]);
+                P[cg][0] = mfma16_bf16(wh, fl[0], P[cg][0]);
+                P[cg][1] = mfma16_bf16(wh, fl[1], P[cg][1]);
+                P[cg][0] = mfma16_bf16(wh, fh[0], P[cg][0]);
+                P[cg][1] = mfma16_bf16(wh, fh[1], P[cg][1]);
             }
+            if (half == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
         }
     };
     // (measured: the assignment MFMAs deferred to the head of the wave's next chain, so that each phase is pure VALU or pure
@@ -393,7 +320,6 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
     auto interval = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         C5_T(t0);
-        if (c >= 2) fold_chunk_max(c - 2);
         if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
         C5_T(t1);
         if (late && c > 0) epilogue(c - 1);
@@ -404,7 +330,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
         C5_T(t4);
         // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 3 feat stores
         // issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores drain everything.
-        if (MODE == MODE_VLAD && active && (!late || c > 0))
+        if (active && (!late || c > 0))
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -426,16 +352,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
     if (late) epilogue(31);
     C5_T(t_loop);
 
-    if (MODE == MODE_MAX && wg_one_cloud) {
-        __syncthreads();                 // every wave's epilogue(31) has written its maxima
-        fold_chunk_max(30);
-        fold_chunk_max(31);
-        __syncthreads();
-        unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
-        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 1024 + o]));
-    }
-
-    if (MODE == MODE_VLAD && active) {
+    if (active) {
         // per-point inverse norm (models/epc-net.py:148): the point's 1024 squares sit in its four q lanes
         float rn[2];
 #pragma unroll
@@ -539,22 +456,161 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_f32_kernel(const float* __re
 #endif
 }
 
-template <int CIN, int MODE>
-static int launch_conv5_f32(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm, float* assign,
-                            float* assign_frag, float* apart, float* pooled, hipStream_t stream, const char* who) {
-    const size_t lds_bytes = C5fLds<CIN, MODE>::TOTAL * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_f32_kernel<CIN, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+// ---------------------------------------------------------------------------------------------------------------------------
+// conv5 + global max-pool (EPC-Net-L).  Operands swapped (D[point][channel]: lane holds points 16 p + 4 q + r of channel
+// 16 g + li), so the max over a tile's points is over registers, the two point groups and the four q lanes.
+//
+// Geometry: 256 threads = 4 waves, ONE wave per SIMD, one 32-point tile per wave; at CIN = 128 the kernel needs ~122 VGPRs
+// and 30 KB of LDS, so FOUR workgroups share a CU and a SIMD's four waves belong to four different workgroups: no barrier
+// ties them, and one's prologue, epilogue or barrier wait runs beside another's MFMA chain (measured at batch 256: 0.604 ms
+// against 0.69 ms for the 8-wave form above with this epilogue).  W5 streams in stages of ONE channel group (16 output
+// channels, 64 * CIN bytes, contiguous in the pack), double-buffered, one barrier per stage.  When the workgroup's four tiles
+// lie in one cloud the per-wave maxima meet in LDS (one slab per stage parity) and the workgroup's 1024 maxima leave as
+// 256-B atomic wave-instructions at the very end; otherwise each wave issues its own atomics.  Values are >= 0 (ReLU) and
+// pooled starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define C5M_THREADS 256
+#define C5M_WAVES 4
+template <int CIN>
+struct C5mLds {  // offsets in floats
+    static constexpr int W5_STAGE = 16 * CIN;
+    static constexpr int OFF_W5 = 0;                                   // two stage buffers: buffer g holds channel group g
+    static constexpr int OFF_B5 = 2 * W5_STAGE;
+    static constexpr int OFF_TI = OFF_B5 + 1024;
+    static constexpr int OFF_MAX = OFF_TI + 1024;                      // 2 x (4 waves x 16) per-wave maxima + 1024 workgroup maxima
+    static constexpr int OFF_IS = OFF_MAX + 2 * C5M_WAVES * 16 + 1024; // per wave the 32 inverse row scales of its tile
+    static constexpr int TOTAL = OFF_IS + C5M_WAVES * 32;
+};
+
+// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][tinv 1024]
+template <int CIN>
+__global__ __launch_bounds__(C5M_THREADS, 4) void conv5_max_f32_kernel(const float* __restrict__ cat, const float* __restrict__ pack,
+                                                                       int total_points, int n, float* __restrict__ pooled) {
+    using L = C5mLds<CIN>;
+    constexpr int STEPS = CIN / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, q = lane >> 4;
+    const float* gw5 = pack;
+    const float* gb5 = pack + (size_t)CIN * 1024;
+    const float* gti = gb5 + 1024;
+    constexpr int W5_PIECES = L::W5_STAGE / (C5M_WAVES * 256);         // 1-KB LDS-DMA pieces per wave per stage
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
+    const unsigned lane_off = lane * 16;
+    auto stage_w5 = [&](int c, auto gc) {      // channel group g of chunk c -> stage buffer g
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int u = 0; u < W5_PIECES; ++u) {
+            const int piece = u * C5M_WAVES + wave_u;
+            glds16(gw5 + (size_t)c * (2 * L::W5_STAGE) + g * L::W5_STAGE + piece * 256, lane_off,
+                   lds_base + 4u * (L::OFF_W5 + g * L::W5_STAGE + piece * 256));
+        }
+    };
+    stage_w5(0, std::integral_constant<int, 0>{});
+    for (int o = tid; o < 1024; o += C5M_THREADS) {
+        lds[L::OFF_B5 + o] = gb5[o];
+        lds[L::OFF_TI + o] = gti[o];
+    }
+    const int g0 = (blockIdx.x * C5M_WAVES + wave) * 32;
+    const bool active = g0 < total_points;
+    const bool wg_one_cloud = n % (C5M_WAVES * 32) == 0;               // the workgroup's four tiles share a cloud
+    C5_LOAD_ROWS_SPLIT(CIN, cat, g0, active, li, q)
+    // register r of acc[p] belongs to point 16 p + 4 q + r, whose inverse row scale lives in the lane that loaded that point:
+    // through a wave-private LDS row, read back once
+    if (q == 0) {
+        lds[L::OFF_IS + wave * 32 + li] = inv_row[0];
+        lds[L::OFF_IS + wave * 32 + 16 + li] = inv_row[1];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float isr[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float4 v = ld4(lds + L::OFF_IS + wave * 32 + 16 * p + 4 * q);
+        isr[p][0] = v.x, isr[p][1] = v.y, isr[p][2] = v.z, isr[p][3] = v.w;
+    }
+    // fold the per-wave maxima of stage (c, g) (written before the barrier that ended it) into the workgroup's
+    auto fold_stage_max = [&](int c, int g) {
+        if (wg_one_cloud && tid < 16) {
+            const float* red = lds + L::OFF_MAX + g * (C5M_WAVES * 16) + tid;
+            float m = red[0];
+#pragma unroll
+            for (int w = 1; w < C5M_WAVES; ++w) m = fmaxf(m, red[16 * w]);
+            lds[L::OFF_MAX + 2 * C5M_WAVES * 16 + 32 * c + 16 * g + tid] = m;
+        }
+    };
+    // One stage = channel group g of chunk c: 6 * STEPS MFMAs from stage buffer g while the NEXT stage's pieces land in the other
+    // buffer (last read one stage ago; the barrier that ended that stage orders it), then the stage's maxima.
+    auto do_stage = [&](int c, auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g == 0) {
+            if (c > 0) fold_stage_max(c - 1, 1);
+            stage_w5(c, std::integral_constant<int, 1>{});
+        } else {
+            fold_stage_max(c, 0);
+            if (c + 1 < 32) stage_w5(c + 1, std::integral_constant<int, 0>{});
+        }
+        const float* w5 = lds + L::OFF_W5 + g * L::W5_STAGE;
+        f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+        f16x8 fa[2][2];   // fragment reads run one k-step ahead of their MFMAs: [ring slot][hi, lo]
+        fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
+        fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + 1 < STEPS) {
+                fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
+                fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
+            const f16x8 wh = fa[s & 1][0], wl = fa[s & 1][1];
+            acc[0] = mfma16_f16(xh[0][s], wl, acc[0]);
+            acc[1] = mfma16_f16(xh[1][s], wl, acc[1]);
+            acc[0] = mfma16_f16(xl[0][s], wh, acc[0]);
+            acc[1] = mfma16_f16(xl[1][s], wh, acc[1]);
+            acc[0] = mfma16_f16(xh[0][s], wh, acc[0]);
+            acc[1] = mfma16_f16(xh[1][s], wh, acc[1]);
+        }
+        // out = relu(acc * (inverse row scale * inverse column scale) + bias), then the maximum over the tile's points
+        const float ti = lds[L::OFF_TI + 32 * c + 16 * g + li], bv = lds[L::OFF_B5 + 32 * c + 16 * g + li];
+        float m = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = __builtin_fmaf(acc[p][r], isr[p][r] * ti, bv);
+                const int vb = __float_as_int(a);
+                m = fmaxf(m, __int_as_float(vb > 0 ? vb : 0));      // ReLU on the bit pattern
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (!active) m = 0.f;
+        if (wg_one_cloud) {
+            if (q == 0) lds[L::OFF_MAX + g * (C5M_WAVES * 16) + wave * 16 + li] = m;
+        } else if (active && q == 0) {
+            atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + 16 * g + li), __float_as_uint(m));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage's pieces have landed (and this wave's atomics have left)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int c = 0; c < 32; ++c) {
+        do_stage(c, std::integral_constant<int, 0>{});
+        do_stage(c, std::integral_constant<int, 1>{});
+    }
+    if (wg_one_cloud) {
+        fold_stage_max(31, 1);
+        __syncthreads();
+        unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5M_WAVES * 32) / n) * 1024);
+        for (int o = tid; o < 1024; o += C5M_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 2 * C5M_WAVES * 16 + o]));
+    }
+}
+
+static int c5_set_lds(const void* fn, size_t lds_bytes, const char* who) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
-        return EPC_EHIP;
-    }
-    const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
-    hipLaunchKernelGGL((conv5_f32_kernel<CIN, MODE>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack, (int)total, n,
-                       feat, rnorm, assign, assign_frag, apart, pooled);
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-        epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
         return EPC_EHIP;
     }
     return EPC_OK;
@@ -567,8 +623,13 @@ extern "C" int epc_conv5_assign_f32_fwd(const float* cat, int cin, const void* p
     EPC_CHECK_ARG(cin == 256, "EPC-Net conv5 takes the 256-channel concat (models/epc-net.py:134)");
     EPC_CHECK_ARG(num_points_total >= 0 && num_points_total % 32 == 0, "point count must be a multiple of 32");
     if (num_points_total == 0) return EPC_OK;
-    return launch_conv5_f32<256, MODE_VLAD>(cat, (const float*)packed_conv5, num_points_total, 32, (float*)feat_frag, rnorm,
-                                            assign, (float*)assign_frag, apart, nullptr, (hipStream_t)stream, __func__);
+    const size_t lds_bytes = C5fLds<256>::TOTAL * sizeof(float);
+    if (int rc = c5_set_lds(reinterpret_cast<const void*>(conv5_vlad_f32_kernel<256>), lds_bytes, __func__)) return rc;
+    const unsigned blocks = (unsigned)((num_points_total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
+    hipLaunchKernelGGL((conv5_vlad_f32_kernel<256>), dim3(blocks), dim3(C5_THREADS), lds_bytes, (hipStream_t)stream, cat,
+                       (const float*)packed_conv5, num_points_total, (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
 }
 
 extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* packed_conv5, int num_clouds, int n,
@@ -583,6 +644,11 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
         epc_set_error("epc_conv5_maxpool_fwd: hipMemsetAsync: %s", hipGetErrorString(e));
         return EPC_EHIP;
     }
-    return launch_conv5_f32<128, MODE_MAX>(cat, (const float*)packed_conv5, total, n, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                           pooled, (hipStream_t)stream, __func__);
+    const size_t lds_bytes = C5mLds<128>::TOTAL * sizeof(float);
+    if (int rc = c5_set_lds(reinterpret_cast<const void*>(conv5_max_f32_kernel<128>), lds_bytes, __func__)) return rc;
+    const unsigned blocks = (unsigned)((total + C5M_WAVES * 32 - 1) / (C5M_WAVES * 32));
+    hipLaunchKernelGGL((conv5_max_f32_kernel<128>), dim3(blocks), dim3(C5M_THREADS), lds_bytes, (hipStream_t)stream, cat,
+                       (const float*)packed_conv5, (int)total, n, pooled);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
 }

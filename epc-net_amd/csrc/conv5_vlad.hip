@@ -1,65 +1,48 @@
-// conv5 (+BN+ReLU) fused with what consumes it, on the half-precision MFMA in split arithmetic (common.h).
+// EPC_PRECISION_FAST form of conv5 (+BN+ReLU) + per-point L2 norm + soft assignment (EPC-Net: models/epc-net.py:136-139,
+// 147-148 + loupe.py:249-272), and the two VLAD aggregate kernels (fast and f32-equivalent).  The f32-equivalent conv5 kernels
+// (EPC-Net and EPC-Net-L) live in conv5_f32.hip.
 //
-// MODE_VLAD  (EPC-Net: models/epc-net.py:136-139,147-148 + loupe.py:249-272) -- "f16x2": one fp16 value per activation,
-//   weights as fp16 hi + lo of W * 2^8: two v_mfma_f32_32x32x16_f16 per product, f32 accumulation.
+// Arithmetic ("f16 + f6"): ONE fp16 value per activation; weights as fp16 hi + MX-fp6 lo of W * 2^8: per 32-channel chunk 16
+// v_mfma_f32_32x32x16_f16 (hi) + 4 v_mfma_scale_f32_32x32x64_f8f6f4 (lo), f32 accumulation.
 //   feat^T chunk (32 ch x 32 pts) = W5f^T X^T; epilogue per chunk: ReLU, 2^-8, |feat|^2 partial, rounding to fp16: that
 //   fragment is stored (feat, accumulator-fragment order) AND is the B operand of P^T (64 clusters x 32 pts) += Wc^T feat^T
 //   ((feat*rn) @ Wc == (feat @ Wc) * rn, so the assignment GEMM runs while the norm is still being accumulated).
 //   Final: rn = rsqrt(max(|feat|^2,1e-12)), cluster_bn (folded), softmax over 64; assign (f32) + fp16 fragments.
-// MODE_MAX   (EPC-Net-L: models/epc-net-l.py:84-92) -- "bf16x3": hi = bf16(x), lo = bf16(x - hi), products
-//   lo*hi + hi*lo + hi*hi (a max-pool keeps single points: no averaging of an activation rounding), operands swapped so
-//   that D = [point][channel]: max over the tile's points is register-wise; per-workgroup maxima leave as 256-B
-//   atomic-max instructions (values are >= 0 after ReLU, so the uint ordering equals the float ordering and
-//   0-initialisation is the identity).
 //
-// Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x CIN) lives in
-// registers as B fragments for all 32 output chunks; W5 (hi+lo: 4 B per weight, 1 MB) streams through a
+// Geometry: 512 threads = 8 waves, one 32-point tile per wave; the wave's input row block (32 pts x 256) lives in
+// registers as B fragments for all 32 output chunks; W5 (hi + lo: 3 B per weight, 768 KB) streams through a
 // double-buffered LDS chunk shared by the 8 waves (LDS-DMA, one barrier per chunk).
 #include <type_traits>
 #include "common.h"
 
-#ifndef C5_DMA_INTERLEAVE
-#define C5_DMA_INTERLEAVE 0
-#endif
 #define C5_THREADS 512
 #define C5_WAVES 8
-enum { MODE_VLAD = 0, MODE_MAX = 1 };
 
-// F8LO (EPC-Net): per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][MX fp6 lo fragments:
-// CIN/64 k-steps x (1 KB + 512 B), then 256 B of block scales; pack.hip pack_conv5_lo6_kernel] inside 96*CIN bytes;
-// otherwise (EPC-Net-L) bf16 hi and lo fragments interleaved per k-step: 128*CIN bytes.
-template <int CIN, bool F8LO>
+// Per 32-channel chunk the weights are [fp16 hi fragments: CIN/16 k-steps x 1 KB][MX fp6 lo fragments: CIN/64 k-steps x
+// (1 KB + 512 B), then 256 B of block scales; pack.hip pack_conv5_lo6_kernel] inside 96*CIN bytes.
+template <int CIN>
 struct C5Lds {  // offsets in floats (4 B)
-    static constexpr int W5_CHUNK = F8LO ? 24 * CIN : 32 * CIN;
-    static constexpr int FEAT_STORES = F8LO ? 2 : 3;   // 16-B feat stores per lane per chunk (VLAD mode): fp16 / 3-byte values
-    static constexpr int W5_LO8 = 16 * CIN;    // F8LO: float offset of the fp6 lo fragments inside a chunk
+    static constexpr int W5_CHUNK = 24 * CIN;
+    static constexpr int W5_LO8 = 16 * CIN;    // float offset of the fp6 lo fragments inside a chunk
     static constexpr int LO6_KS = 384;         // floats per k-step of lo fragments (1 KB of 16-B pieces + 512 B of 8-B pieces)
     static constexpr int W5_LOSC = W5_LO8 + (CIN / 64) * LO6_KS;   // the block-scale dwords (one per lane)
-    // cluster-weight chunk: 32 ch x 64 clusters x 2 B (FAST: ONE fp16 per cluster weight, see the epilogue) or bf16 hi + lo
-    static constexpr int WC_CHUNK = F8LO ? 1024 : 2048;
+    static constexpr int WC_CHUNK = 1024;      // cluster-weight chunk: 32 ch x 64 clusters x 2 B (ONE fp16 per cluster weight, see the epilogue)
     static constexpr int OFF_W5 = 0;
-    // cluster-weight slots: 2 (chunk parity) in the fast form; 4 in the f32-equivalent form, whose second wave group runs its
-    // epilogue half a chunk interval late (C5_STAGGER) and still reads chunk c's slot while chunk c + 2 is landing
-    static constexpr int WC_SLOTS = F8LO ? 2 : 4;
+    static constexpr int WC_SLOTS = 2;         // chunk parity
     static constexpr int OFF_WC = 2 * W5_CHUNK;
     static constexpr int OFF_B5 = OFF_WC + WC_SLOTS * WC_CHUNK;
     static constexpr int OFF_CBN = OFF_B5 + 1024;
     // per-wave 32 x 32 f32 transpose tile (row stride 36) of the FINAL epilogue: it aliases the W5 stream buffers, which
     // are dead by then (a barrier separates the last chunk from the first tile write) -- 38 KB less LDS, so that a
-    // kNN workgroup (65 KB) of another stream can share the CU.  MODE_MAX keeps its per-wave / per-workgroup maxima in
-    // a small area of its own.
+    // kNN workgroup (65 KB) of another stream can share the CU.
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
-    static constexpr int OFF_TI = OFF_CBN + 128;           // scaled split-fp16 form: the 1024 inverse column scales
-    static constexpr int OFF_MAX = OFF_TI + 1024;          // MODE_MAX: 2 x 256 per-wave maxima + 1024 workgroup maxima
-    static constexpr int OFF_IS = OFF_MAX + 1536;          // MODE_MAX: per wave the 32 inverse row scales of its tile
-    static constexpr int TOTAL = OFF_IS + 256;
+    static constexpr int TOTAL = OFF_CBN + 128;
 };
 
-// packed conv5 stage (4-byte units): [W5p CIN*1024][b5f 1024][Wcp 1024*64][cbn_s 64][cbn_t 64]   (VLAD)
-//                                    [W5p CIN*1024][b5f 1024]                                     (MAX)
-// FAST (MODE_VLAD only): the f16 + f6 arithmetic of EPC_PRECISION_FAST; otherwise split-bf16 x3 (f32-equivalent).
-template <int CIN, int MODE, bool CAT16, bool FAST>
+// packed conv5 stage (4-byte units): [W5p: 24*CIN*32 floats][b5f 1024][Wcp 1024*32 (fp16)][cbn_s 64][cbn_t 64]
+// CAT16: the input rows are fp16 (the fast block chain's out16) instead of f32.
+template <int CIN, bool CAT16>
 __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restrict__ cat,
                                                            const float* __restrict__ pack, int total_points,
                                                            int n, float* __restrict__ feat,
@@ -67,26 +50,22 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                                                            float* __restrict__ assign,
                                                            float* __restrict__ assign_frag,
                                                            float* __restrict__ apart,
-                                                           float* __restrict__ pooled,
                                                            int32_t* __restrict__ status) {
-    static_assert(!FAST || MODE == MODE_VLAD, "the fast arithmetic exists for the VLAD form only");
-    using L = C5Lds<CIN, FAST>;
+    using L = C5Lds<CIN>;
     constexpr int STEPS = CIN / 16;
-    static_assert(MODE != MODE_VLAD || 8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
+    static_assert(8 * L::T_WAVE <= 2 * L::W5_CHUNK, "the transpose tiles must fit in the W5 buffers");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const float* gw5 = pack;
     const float* gb5 = pack + (size_t)CIN * 1024;
     const float* gwc = gb5 + 1024;
-    const float* gcbn = gwc + (FAST ? 1024 * 32 : 1024 * 64);   // past 1024 x 64 fp16 / bf16 hi + lo
-    // inverse column scales of the scaled split-fp16 form (pack.hip colscale_kernel): the last 1024 floats of the stage
-    const float* gti = MODE == MODE_VLAD ? gcbn + 128 : gb5 + 1024;
+    const float* gcbn = gwc + 1024 * 32;   // past 1024 x 64 fp16
 
     // Weight chunks go global -> LDS directly (global_load_lds_dwordx4: each wave-instruction writes 1 KB at a
     // wave-uniform LDS base + lane*16, which is exactly the packed fragment order), so no VGPRs are spent on staging
     // and the loads of chunk c+1 stay in flight under chunk c's MFMAs.  Completion is a counted vmcnt (the chunk's
-    // 4 feat stores are younger and may stay in flight) followed by a raw s_barrier.
+    // 2 feat stores are younger and may stay in flight) followed by a raw s_barrier.
     constexpr int W5_PIECES = L::W5_CHUNK / (C5_WAVES * 256);  // 1-KB pieces per wave per chunk (256 floats each)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
@@ -99,46 +78,26 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
             glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
                    lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
         }
-        if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256)   // 4 (8) KB per chunk: one 1-KB piece from each of four (eight) waves
+        if (wave_u < L::WC_CHUNK / 256)   // 4 KB per chunk: one 1-KB piece from each of four waves
             glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
                    lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
-    };
-
-    // the same pieces one at a time (u < W5_PIECES: the wave's u-th W5 piece; u == W5_PIECES: its cluster-weight piece), so
-    // that the chunk loop can issue them BETWEEN the k-steps of the running chunk's MFMA chain (C5_DMA_INTERLEAVE)
-    auto stage_piece = [&](int c, auto bufc, int u) {
-        constexpr int buf = decltype(bufc)::value;
-        if (u < W5_PIECES) {
-            const int piece = u * C5_WAVES + wave_u;
-            glds16(gw5 + (size_t)c * L::W5_CHUNK + piece * 256, lane_off,
-                   lds_base + 4u * (L::OFF_W5 + buf * L::W5_CHUNK + piece * 256));
-        } else if (MODE == MODE_VLAD && wave_u < L::WC_CHUNK / 256) {
-            glds16(gwc + (size_t)c * L::WC_CHUNK + wave_u * 256, lane_off,
-                   lds_base + 4u * (L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK + wave_u * 256));
-        }
     };
 
     stage_chunk(0, std::integral_constant<int, 0>{});
     for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_B5 + o] = gb5[o];
-    if (MODE == MODE_VLAD && tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
-    if constexpr (!FAST)
-        for (int o = tid; o < 1024; o += C5_THREADS) lds[L::OFF_TI + o] = gti[o];
+    if (tid < 128) lds[L::OFF_CBN + tid] = gcbn[tid];
 
     const int g0 = (blockIdx.x * C5_WAVES + wave) * 32;
     const bool active = g0 < total_points;
-    const bool wg_one_cloud = MODE == MODE_MAX && n % (C5_WAVES * 32) == 0;  // the workgroup's 8 tiles share a cloud
 
-    // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7.
-    // FAST: ONE fp16 value per input, the weights carry the hi+lo split (two MFMAs per product; W5_SCALE comment in
-    // common.h) -- the input rounding averages out over the cloud's points in the aggregation.  Otherwise (f32-equivalent
-    // arithmetic; the max-pool form always: it keeps one point's value per channel, nothing averages) the scaled
-    // split-fp16 form of common.h: the point's row scaled by a power of two, hi + lo parts, three MFMAs.
-    constexpr bool kF16 = FAST;
-    constexpr float kDescale = kF16 ? 1.0f / W5_SCALE : 1.0f;
-    f16x8 xf[kF16 ? STEPS : 1];
+    // this lane's B fragments: point j, k-step s covers input channels 16s + 8h .. +7.  ONE fp16 value per input, the weights
+    // carry the hi + lo split (W5_SCALE comment in common.h) -- the input rounding averages out over the cloud's points in the
+    // aggregation.
+    constexpr float kDescale = 1.0f / W5_SCALE;
+    f16x8 xf[STEPS];
     // the same inputs as MX fp6 (B operand of the lo-term MFMA): per 64-wide k-step the lane's 32 consecutive channels
     // 64ks + 32h .. +31 in six dwords, their block scale in byte ks of xsc
-    i32x6 x6[kF16 ? CIN / 64 : 1];
+    i32x6 x6[CIN / 64];
     int xsc = 0;
     auto to_fp6 = [&](f16x32 v, int ks) {
         typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -155,109 +114,49 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         x6[ks] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v * down, 1.0f);
         xsc |= (127 + e) << (8 * ks);
     };
-    f16x8 xh[kF16 ? 1 : STEPS], xl[kF16 ? 1 : STEPS];
-    float inv_row = 1.0f;   // inverse of the row's power-of-two scale (scaled split-fp16 form)
     if constexpr (CAT16) {  // fp16 rows (the blocks' out16): the 16 B a lane reads ARE its fragment
-        static_assert(!CAT16 || FAST, "fp16 input only feeds the fp16 arithmetic");
         const unsigned short* row = reinterpret_cast<const unsigned short*>(cat) + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             u32x4 w = *reinterpret_cast<const u32x4*>(row + 16 * s);
             if (!active) w = u32x4{0u, 0u, 0u, 0u};
-            xf[kF16 ? s : 0] = __builtin_bit_cast(f16x8, w);
+            xf[s] = __builtin_bit_cast(f16x8, w);
         }
-        if constexpr (kF16) {
 #pragma unroll
-            for (int ks = 0; ks < CIN / 64; ++ks) {   // channels 64ks + 32h .. +31 of the lane's point
-                typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
-                u32x16 w16;
+        for (int ks = 0; ks < CIN / 64; ++ks) {   // channels 64ks + 32h .. +31 of the lane's point
+            typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+            u32x16 w16;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    u32x4 w = *reinterpret_cast<const u32x4*>(row + 64 * ks + 24 * h + 8 * q4);   // row already holds +8h
-                    if (!active) w = u32x4{0u, 0u, 0u, 0u};
-                    w16[4 * q4] = w[0], w16[4 * q4 + 1] = w[1], w16[4 * q4 + 2] = w[2], w16[4 * q4 + 3] = w[3];
-                }
-                to_fp6(__builtin_bit_cast(f16x32, w16), ks);
+            for (int q4 = 0; q4 < 4; ++q4) {
+                u32x4 w = *reinterpret_cast<const u32x4*>(row + 64 * ks + 24 * h + 8 * q4);   // row already holds +8h
+                if (!active) w = u32x4{0u, 0u, 0u, 0u};
+                w16[4 * q4] = w[0], w16[4 * q4 + 1] = w[1], w16[4 * q4 + 2] = w[2], w16[4 * q4 + 3] = w[3];
             }
+            to_fp6(__builtin_bit_cast(f16x32, w16), ks);
         }
     } else {
         const float* row = cat + (size_t)(active ? g0 + j : 0) * CIN + 8 * h;
-        if constexpr (!kF16) {
-            // ONE pass over the lane's half of the row: all of it is loaded (32 independent 16-B loads in flight), the largest
-            // magnitude taken (the other half sits in lane ^ 32), and every eight raw values are then split IN PLACE into the
-            // four + four registers of their hi and lo fragments -- the raw row and the fragments never coexist, so the 128
-            // registers are the fragments' own.  (The first form read the row twice: 217 MB more traffic per launch and a second
-            // round of load latency in a prologue nothing overlaps.)
-#ifndef C5_ROW_TWO_PASS
-            float raw[STEPS][8];
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                raw[s][0] = a.x, raw[s][1] = a.y, raw[s][2] = a.z, raw[s][3] = a.w;
-                raw[s][4] = b.x, raw[s][5] = b.y, raw[s][6] = b.z, raw[s][7] = b.w;
-            }
-            float m = 0.f;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-                for (int q = 0; q < 8; q += 2) m = fmaxf(fmaxf(m, fabsf(raw[s][q])), fabsf(raw[s][q + 1]));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float row_s = 1.0f;
-            row_scale_pow2(m, row_s, inv_row);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) split8_f16s(raw[s], row_s, xh[s], xl[s]);
-#else
-            float row_s = 1.0f;
-            float m = 0.f;
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                m = fmaxf(fmaxf(fmaxf(m, fabsf(a.x)), fmaxf(fabsf(a.y), fabsf(a.z))), fmaxf(fmaxf(fabsf(a.w), fabsf(b.x)), fmaxf(fabsf(b.y), fmaxf(fabsf(b.z), fabsf(b.w)))));
-            }
-            m = fmaxf(m, __shfl_xor(m, 32));
-            row_scale_pow2(m, row_s, inv_row);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                float v[8];
-                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
-                split8_f16s(v, row_s, xh[s], xl[s]);
-            }
-#endif
-        } else {
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                xf[s][0] = (_Float16)a.x, xf[s][1] = (_Float16)a.y, xf[s][2] = (_Float16)a.z, xf[s][3] = (_Float16)a.w;
-                xf[s][4] = (_Float16)b.x, xf[s][5] = (_Float16)b.y, xf[s][6] = (_Float16)b.z, xf[s][7] = (_Float16)b.w;
-            }
+        for (int s = 0; s < STEPS; ++s) {
+            const float4 a = active ? ld4(row + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = active ? ld4(row + 16 * s + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xf[s][0] = (_Float16)a.x, xf[s][1] = (_Float16)a.y, xf[s][2] = (_Float16)a.z, xf[s][3] = (_Float16)a.w;
+            xf[s][4] = (_Float16)b.x, xf[s][5] = (_Float16)b.y, xf[s][6] = (_Float16)b.z, xf[s][7] = (_Float16)b.w;
         }
-        if constexpr (kF16) {
-            const float* row0 = row - 8 * h;   // channel 0 of the lane's point
+        const float* row0 = row - 8 * h;   // channel 0 of the lane's point
 #pragma unroll
-            for (int ks = 0; ks < CIN / 64; ++ks) {
-                f16x32 v;
+        for (int ks = 0; ks < CIN / 64; ++ks) {
+            f16x32 v;
 #pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) {
-                    const float4 a = active ? ld4(row0 + 64 * ks + 32 * h + 4 * w8) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    // (through fp16: the fp6 copy must describe the same input the hi term sees)
-                    v[4 * w8] = (_Float16)a.x, v[4 * w8 + 1] = (_Float16)a.y, v[4 * w8 + 2] = (_Float16)a.z, v[4 * w8 + 3] = (_Float16)a.w;
-                }
-                to_fp6(v, ks);
+            for (int w8 = 0; w8 < 8; ++w8) {
+                const float4 a = active ? ld4(row0 + 64 * ks + 32 * h + 4 * w8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                // (through fp16: the fp6 copy must describe the same input the hi term sees)
+                v[4 * w8] = (_Float16)a.x, v[4 * w8 + 1] = (_Float16)a.y, v[4 * w8 + 2] = (_Float16)a.z, v[4 * w8 + 3] = (_Float16)a.w;
             }
+            to_fp6(v, ks);
         }
     }
 
-    // max-pool form (operands swapped): register r of this lane belongs to point mfma_row(r, h) of the tile -- its inverse
-    // row scale lives in the lane of that point
-    // (kept in a wave-private LDS row and re-read per chunk: 16 more live registers would cost this kernel a wave per SIMD)
-    if constexpr (MODE == MODE_MAX) {
-        if (h == 0) lds[L::OFF_IS + wave * 32 + j] = inv_row;
-    }
     f32x16 P[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) P[0][r] = P[1][r] = 0.f;
@@ -265,150 +164,66 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // one chunk; the LDS buffer index is a compile-time constant so that the compiler can see that the DMA destination
-    // (the other buffer) never aliases the fragments being read (otherwise it drains vmcnt before every ds_read)
-    // max-pool mode: fold the 8 per-wave maxima of chunk c (written before the barrier that ended it) into wgmax
-    auto fold_chunk_max = [&](int c) {
-        if (MODE == MODE_MAX && wg_one_cloud && tid < 32) {
-            const float* red = lds + L::OFF_MAX + (c & 1) * 256 + tid;
-            float m = red[0];
-#pragma unroll
-            for (int w = 1; w < C5_WAVES; ++w) m = fmaxf(m, red[32 * w]);
-            lds[L::OFF_MAX + 512 + 32 * c + tid] = m;
-        }
-    };
-    // A chunk is three pieces: its MFMA chain (chunk_mfma: fragments from the LDS buffer, accumulator left in `acc`), its
-    // epilogue (chunk_epi: un-scaling, bias, ReLU, |feat|^2, feat stores, the assignment GEMM's share) and the wait that lets
-    // the next chunk's weights land (chunk_wait).  do_chunk runs them back to back; the staggered schedule below runs the
-    // epilogue of one wave group beside the MFMA chain of the other.
+    // A chunk is three pieces: its MFMA chain (chunk_mfma: fragments from the LDS buffer -- the buffer index is a compile-time
+    // constant so that the compiler can see that the DMA destination, the other buffer, never aliases the fragments being read;
+    // otherwise it drains vmcnt before every ds_read -- accumulator left in `acc`), its epilogue (chunk_epi: ReLU, |feat|^2, feat
+    // stores, the assignment GEMM's share) and the wait that lets the next chunk's weights land (chunk_wait).
     f32x16 acc;
     auto chunk_mfma = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         const float* w5 = lds + L::OFF_W5 + buf * L::W5_CHUNK;
-        if constexpr (!kF16) {
-            // scaled split-fp16 form: the accumulator holds the product of the SCALED operands; bias and un-scaling follow
+        const float* b = lds + L::OFF_B5 + 32 * c;      // the (scaled) bias initialises the accumulator
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        } else {
-            const float* b = lds + L::OFF_B5 + 32 * c;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bv = ld4(b + 8 * g + 4 * h);
-                acc[4 * g] = bv.x;
-                acc[4 * g + 1] = bv.y;
-                acc[4 * g + 2] = bv.z;
-                acc[4 * g + 3] = bv.w;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = ld4(b + 8 * g + 4 * h);
+            acc[4 * g] = bv.x;
+            acc[4 * g + 1] = bv.y;
+            acc[4 * g + 2] = bv.z;
+            acc[4 * g + 3] = bv.w;
         }
-        {
-            if constexpr (kF16) {
-                // lo term first (small): W_lo and the inputs as MX fp6, K = 64 per instruction in 8 passes (the fp16 K = 16
-                // instruction takes 8 as well) -- the lo term is a 2^-11 correction, so 4 significant bits on each side keep it
-                // to 2^-15 of the product.  Block scales: byte ks of the lanes' scale dwords (op_sel).
-                const float* wl = w5 + L::W5_LO8;
+        // lo term first (small): W_lo and the inputs as MX fp6, K = 64 per instruction in 8 passes (the fp16 K = 16
+        // instruction takes 8 as well) -- the lo term is a 2^-11 correction, so 4 significant bits on each side keep it
+        // to 2^-15 of the product.  Block scales: byte ks of the lanes' scale dwords (op_sel).
+        const float* wl = w5 + L::W5_LO8;
 #ifndef CONV5_ABL_NO_LO
-                const int wsc = __float_as_int(w5[L::W5_LOSC + lane]);
-                auto lo_step = [&](auto ksc) {
-                    constexpr int ks = decltype(ksc)::value;
-                    if constexpr (ks < CIN / 64) {
-                        const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + ks * L::LO6_KS + lane * 4);
-                        const uint2 l1 = *reinterpret_cast<const uint2*>(wl + ks * L::LO6_KS + 256 + lane * 2);
-                        const i32x8 a = {(int)l0[0], (int)l0[1], (int)l0[2], (int)l0[3], (int)l1.x, (int)l1.y, 0, 0};
-                        const i32x8 b = {x6[ks][0], x6[ks][1], x6[ks][2], x6[ks][3], x6[ks][4], x6[ks][5], 0, 0};
-                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 2, 2, ks, wsc, ks, xsc);
-                    }
-                };
-                lo_step(std::integral_constant<int, 0>{});
-                lo_step(std::integral_constant<int, 1>{});
-                lo_step(std::integral_constant<int, 2>{});
-                lo_step(std::integral_constant<int, 3>{});
-                static_assert(CIN / 64 <= 4, "one scale dword holds four block scales");
-#endif
+        const int wsc = __float_as_int(w5[L::W5_LOSC + lane]);
+        auto lo_step = [&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if constexpr (ks < CIN / 64) {
+                const u32x4 l0 = *reinterpret_cast<const u32x4*>(wl + ks * L::LO6_KS + lane * 4);
+                const uint2 l1 = *reinterpret_cast<const uint2*>(wl + ks * L::LO6_KS + 256 + lane * 2);
+                const i32x8 a = {(int)l0[0], (int)l0[1], (int)l0[2], (int)l0[3], (int)l1.x, (int)l1.y, 0, 0};
+                const i32x8 b6 = {x6[ks][0], x6[ks][1], x6[ks][2], x6[ks][3], x6[ks][4], x6[ks][5], 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b6, acc, 2, 2, ks, wsc, ks, xsc);
             }
-            // fragment reads run C5_PF k-steps ahead of the MFMAs that consume them: eight waves share the LDS port, so a
-            // read returns after ~8 other 1-KB reads (64+ cycles) while a k-step's MFMA takes 32 -- with one read in flight
-            // per wave the port idles
+        };
+        lo_step(std::integral_constant<int, 0>{});
+        lo_step(std::integral_constant<int, 1>{});
+        lo_step(std::integral_constant<int, 2>{});
+        lo_step(std::integral_constant<int, 3>{});
+        static_assert(CIN / 64 <= 4, "one scale dword holds four block scales");
+#endif
+        // fragment reads run C5_PF k-steps ahead of the MFMAs that consume them: eight waves share the LDS port, so a
+        // read returns after ~8 other 1-KB reads (64+ cycles) while a k-step's MFMA takes 32 -- with one read in flight
+        // per wave the port idles
 #ifndef C5_PF
 #define C5_PF 1   // measured 1, 2, 3, 4, 6: 0.258-0.260 ms alike, so the shallowest (fewest registers) stays
 #endif
-            constexpr int PF = C5_PF < STEPS ? C5_PF : STEPS - 1;
-            constexpr int RING = PF + 1;
-            f16x8 fa[RING][2];
-            constexpr int FS = kF16 ? 1 : 2;   // fragments per k-step in LDS (fp16 hi only / bf16 hi + lo)
+        constexpr int PF = C5_PF < STEPS ? C5_PF : STEPS - 1;
+        constexpr int RING = PF + 1;
+        f16x8 fa[RING];
 #pragma unroll
-            for (int s = 0; s < PF; ++s) {
-                fa[s][0] = ldfrag16(w5 + ((s * FS + 0) * 64 + lane) * 4);
-                if (!kF16) fa[s][1] = ldfrag16(w5 + ((s * FS + 1) * 64 + lane) * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < PF; ++s) fa[s] = ldfrag16(w5 + (s * 64 + lane) * 4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-#ifdef C5_ABL_NOLDSREAD
-                if (s + PF < STEPS) fa[(s + PF) % RING][0] = fa[s % RING][0], fa[(s + PF) % RING][1] = fa[s % RING][1];
-#else
-                if (s + PF < STEPS) {
-                    fa[(s + PF) % RING][0] = ldfrag16(w5 + (((s + PF) * FS + 0) * 64 + lane) * 4);
-                    if (!kF16) fa[(s + PF) % RING][1] = ldfrag16(w5 + (((s + PF) * FS + 1) * 64 + lane) * 4);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
-#if C5_DMA_INTERLEAVE
-                // the next chunk's LDS-DMA pieces, one per few k-steps: a piece costs its wave ~60+ issue cycles, which at the
-                // head of the chunk nothing covers (all eight waves issue theirs together, the matrix pipe idles); here the
-                // wave's own previous MFMA and its SIMD partner's are executing meanwhile.  Waves 4-7 (the partners) issue one
-                // k-step later than waves 0-3.
-                if constexpr (!kF16) {
-                    constexpr int NP = W5_PIECES + (MODE == MODE_VLAD ? 1 : 0);
-                    constexpr int STRIDE = (STEPS - 2) / NP > 0 ? (STEPS - 2) / NP : 1;
-                    if (c + 1 < 32 && s >= 1 && (s - 1) % STRIDE <= 1 && (s - 1) / STRIDE < NP) {
-                        const bool mine = ((s - 1) % STRIDE) == (wave_u >> 2);
-                        if (mine) stage_piece(c + 1, std::integral_constant<int, buf ^ 1>{}, (s - 1) / STRIDE);
-                    }
-                }
-#endif
-                if constexpr (kF16) {
-                    acc = mfma_f16(fa[s % RING][0], xf[s], acc);
-                } else if constexpr (MODE == MODE_MAX) {   // operands swapped: D[point][channel]
-                    acc = mfma_f16(xh[s], fa[s % RING][1], acc);
-                    acc = mfma_f16(xl[s], fa[s % RING][0], acc);
-                    acc = mfma_f16(xh[s], fa[s % RING][0], acc);
-                } else {                                   // D[channel][point], scaled split-fp16 x3
-                    acc = mfma_f16(fa[s % RING][1], xh[s], acc);
-                    acc = mfma_f16(fa[s % RING][0], xl[s], acc);
-                    acc = mfma_f16(fa[s % RING][0], xh[s], acc);
-                }
-            }
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + PF < STEPS) fa[(s + PF) % RING] = ldfrag16(w5 + ((s + PF) * 64 + lane) * 4);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this step's MFMAs (hipcc sinks them otherwise)
+            acc = mfma_f16(fa[s % RING], xf[s], acc);
         }
     };
     auto chunk_epi = [&](int c) {
-        if constexpr (!kF16) {
-            // out = acc * (inverse row scale * inverse column scale) + bias
-            if constexpr (MODE == MODE_MAX) {
-                // transposed product: channel = lane & 31, the 16 registers are 16 of the tile's points
-                const float ti = lds[L::OFF_TI + 32 * c + j], bv = lds[L::OFF_B5 + 32 * c + j];
-                const float* isr = lds + L::OFF_IS + wave * 32 + 4 * h;   // rows mfma_row(4g + e, h) = 8g + 4h + e
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 iv = ld4(isr + 8 * g);
-                    acc[4 * g] = __builtin_fmaf(acc[4 * g], iv.x * ti, bv);
-                    acc[4 * g + 1] = __builtin_fmaf(acc[4 * g + 1], iv.y * ti, bv);
-                    acc[4 * g + 2] = __builtin_fmaf(acc[4 * g + 2], iv.z * ti, bv);
-                    acc[4 * g + 3] = __builtin_fmaf(acc[4 * g + 3], iv.w * ti, bv);
-                }
-            } else {
-                const float* b = lds + L::OFF_B5 + 32 * c;
-                const float* ti = lds + L::OFF_TI + 32 * c;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = ld4(b + 8 * g + 4 * h), tv = ld4(ti + 8 * g + 4 * h);
-                    acc[4 * g] = __builtin_fmaf(acc[4 * g], inv_row * tv.x, bv.x);
-                    acc[4 * g + 1] = __builtin_fmaf(acc[4 * g + 1], inv_row * tv.y, bv.y);
-                    acc[4 * g + 2] = __builtin_fmaf(acc[4 * g + 2], inv_row * tv.z, bv.z);
-                    acc[4 * g + 3] = __builtin_fmaf(acc[4 * g + 3], inv_row * tv.w, bv.w);
-                }
-            }
-        }
-        // ReLU and (VLAD mode) the 2^-8 that removes W5_SCALE (bias and weights are packed scaled): max on the bit pattern
+        // ReLU and the 2^-8 that removes W5_SCALE (bias and weights are packed scaled): max on the bit pattern
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float a = acc[r];  // (a scalar copy: __builtin_bit_cast on a vector ELEMENT reads element 0 with hipcc 7.2)
@@ -421,77 +236,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #else
         constexpr bool kEpi = true;
 #endif
-        if constexpr (kEpi && MODE == MODE_VLAD && !FAST) {
-            // f32-equivalent form: feat leaves as f32 in accumulator order ([quad r][lane][4]: 1 KB per wave-instruction;
-            // element e of quad r = channel 32c + 8r + 4h + e), and the assignment GEMM takes the accumulators split into
-            // bf16 hi + lo against hi + lo cluster weights (three products).
-            const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
-            auto wfrag = [&](int sp, int t, int part) { return ldfrag(wc + (((sp * 2 + t) * 2 + part) * 64 + lane) * 4); };
-#ifndef C5_NO_WC_PREFETCH
-            // the cluster-weight fragments of the first k-step are requested before the norm / pack / store work below (and the
-            // second k-step's before the first's MFMAs): read where they are used, each pair exposed its LDS latency
-            bf16x8 wq[2][2] = {{wfrag(0, 0, 0), wfrag(0, 0, 1)}, {wfrag(0, 1, 0), wfrag(0, 1, 1)}};
-#endif
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ss += acc[r] * acc[r];
-#ifndef C5_ABL_NOSTORE
-            // feat leaves as 3-BYTE values (the upper 24 bits of the float, rounded: sign, exponent, 15 fraction bits = 16
-            // significant bits).  Its only reader, the aggregate, multiplies by rnorm and splits the product into bf16 hi + lo
-            // -- 16 significant bits as well -- so a fourth byte would be dropped there anyway; without it the round trip that
-            // dominates the step's HBM traffic (conv5 writes, the aggregate reads) is 25 % shorter.  The lane's 16 values
-            // (accumulator order) are 12 dwords = three 16-B stores, 1 KB per wave-instruction: [tile][chunk][piece][lane][16 B].
-            if (active) {
-                unsigned int w[12];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#ifdef C5_FEAT_BITS11   // experiment: what 11 significant bits (a 2-byte format) would do to the descriptors
-                    const unsigned int a = (__float_as_uint(acc[4 * g]) + 0x1000u) & 0xffffe000u, b = (__float_as_uint(acc[4 * g + 1]) + 0x1000u) & 0xffffe000u;
-                    const unsigned int cc = (__float_as_uint(acc[4 * g + 2]) + 0x1000u) & 0xffffe000u, d = (__float_as_uint(acc[4 * g + 3]) + 0x1000u) & 0xffffe000u;
-#else
-                    const unsigned int a = __float_as_uint(acc[4 * g]) + 0x80u, b = __float_as_uint(acc[4 * g + 1]) + 0x80u;
-                    const unsigned int cc = __float_as_uint(acc[4 * g + 2]) + 0x80u, d = __float_as_uint(acc[4 * g + 3]) + 0x80u;
-#endif
-                    w[3 * g] = __builtin_amdgcn_perm(b, a, 0x05030201u);        // a.b1 a.b2 a.b3 b.b1
-                    w[3 * g + 1] = __builtin_amdgcn_perm(cc, b, 0x06050302u);   // b.b2 b.b3 c.b1 c.b2
-                    w[3 * g + 2] = __builtin_amdgcn_perm(d, cc, 0x07060503u);   // c.b3 d.b1 d.b2 d.b3
-                }
-                float* fdst = feat + ((size_t)(g0 >> 5) * 32 + c) * 768 + lane * 4;
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<u32x4*>(fdst + p * 256) = u32x4{w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]};
-            }
-#endif
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = acc[8 * sp + q];
-                bf16x8 fh, fl;
-                split8(v, fh, fl);
-#ifndef C5_NO_WC_PREFETCH
-                bf16x8 wn[2][2];
-                if (sp == 0) wn[0][0] = wfrag(1, 0, 0), wn[0][1] = wfrag(1, 0, 1), wn[1][0] = wfrag(1, 1, 0), wn[1][1] = wfrag(1, 1, 1);
-#endif
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#ifndef C5_ABL_NOASSIGN
-#ifndef C5_NO_WC_PREFETCH
-                    const bf16x8 wh = wq[t][0], wl = wq[t][1];
-#else
-                    const bf16x8 wh = wfrag(sp, t, 0), wl = wfrag(sp, t, 1);
-#endif
-                    P[t] = mfma_bf16(wl, fh, P[t]);
-                    P[t] = mfma_bf16(wh, fl, P[t]);
-                    P[t] = mfma_bf16(wh, fh, P[t]);
-#else
-                    asm volatile("" :: "v"(fh), "v"(fl));
-#endif
-                }
-#ifndef C5_NO_WC_PREFETCH
-                if (sp == 0) wq[0][0] = wn[0][0], wq[0][1] = wn[0][1], wq[1][0] = wn[1][0], wq[1][1] = wn[1][1];
-#endif
-            }
-        } else if constexpr (kEpi && MODE == MODE_VLAD) {
+        if constexpr (kEpi) {
             const float* wc = lds + L::OFF_WC + (c & (L::WC_SLOTS - 1)) * L::WC_CHUNK;
             // The cluster weights are ONE fp16 value each (x 2^8): the soft assignment only enters through a softmax whose
             // logits tolerate a 2^-12 weight rounding -- emulated descriptor effect 5e-9 on top of the 9.4e-7 of the
@@ -531,115 +276,45 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
 #endif
                 if (sp == 0) wf[0] = wn[0], wf[1] = wn[1];
             }
-        } else if constexpr (kEpi) {
-            // max over the tile's 32 points (registers, then the two lane halves).  When the workgroup's 8 tiles lie in one cloud the
-            // per-wave maxima meet in LDS (red: two chunk-parity slabs of 8 waves x 32 channels, in the unused transpose
-            // area) and the workgroup's 1024 maxima leave as sixteen 256-B atomic wave-instructions at the very end;
-            // otherwise (n not a multiple of 256) each wave issues its own atomics.  Values are >= 0 (ReLU) and pooled
-            // starts at 0, so unsigned-integer max on the bit patterns is the float max and 0 is the neutral element.
-            float* red = lds + L::OFF_MAX + (c & 1) * 256 + wave * 32;
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            m = fmaxf(m, __shfl_xor(m, 32));  // the other 16 points of the tile
-            if (!active) m = 0.f;
-            if (wg_one_cloud) {
-                if (h == 0) red[j] = m;
-            } else if (active && h == 0) {
-                atomicMax(reinterpret_cast<unsigned int*>(pooled + (size_t)(g0 / n) * 1024 + 32 * c + j), __float_as_uint(m));
-            }
         }
-
     };
-    // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 2 (4) feat
-    // stores issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of
-    // the grid) and the atomic-max variant drain everything.
-    auto chunk_wait = [&](bool stores_younger_than_dma) {
+    // the next chunk's LDS-DMA pieces are the OLDEST outstanding vector-memory operations of this wave; the 2 feat stores
+    // issued after them may stay in flight (vmcnt counts in issue order).  Waves without stores (tail of the grid) drain
+    // everything.
+    auto chunk_wait = [&]() {
 #ifdef C5_ABL_NOSTORE
         if (false)
 #else
-        if (MODE == MODE_VLAD && active && stores_younger_than_dma)
+        if (active)
 #endif
-        {
-            if constexpr (L::FEAT_STORES == 2)
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
+    // (measured on this kernel and not adopted: the second wave of each SIMD deferring its epilogue across the chunk barrier,
+    // 0.32 vs 0.31 ms; a one-wave-per-SIMD, two-tiles-per-wave form with a software-pipelined epilogue, 0.50-0.52 vs 0.48 ms)
     auto do_chunk = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (c > 0) fold_chunk_max(c - 1);
 #ifndef C5_ABL_NODMA
-        if (c + 1 < 32 && !(C5_DMA_INTERLEAVE && !kF16)) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
+        if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
 #endif
         chunk_mfma(c, bufc);
         chunk_epi(c);
-        chunk_wait(true);
+        chunk_wait();
 #ifndef C5_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
 #endif
     };
-#ifndef C5_STAGGER
-#define C5_STAGGER 0   // measured (round 2): 0.542 vs 0.511 ms in lock step -- the pairing costs more than it hides; see DESIGN.md
-#endif
-    constexpr bool kStagger = C5_STAGGER && MODE == MODE_VLAD && !FAST;
-    if constexpr (!kStagger) {
-        for (int c = 0; c < 32; c += 2) {
-            do_chunk(c, std::integral_constant<int, 0>{});
-            do_chunk(c + 1, std::integral_constant<int, 1>{});
-        }
-    } else {
-        // Staggered schedule (f32-equivalent VLAD form).  The eight waves are two groups, one wave of each per SIMD (waves w and
-        // w + 4 share a SIMD); a chunk interval is two half intervals separated by barriers:
-        //     half 1:  group A runs the MFMA chain of chunk c   |  group B runs the EPILOGUE of chunk c - 1
-        //     half 2:  group A runs the epilogue of chunk c     |  group B runs the MFMA chain of chunk c
-        // so each SIMD always pairs one wave on the matrix pipe with one on the VALU / store side (in lock step both waves
-        // of a SIMD fight for the matrix pipe and then leave it idle together: MFMA busy 0.47).  Chunk c's weight buffer is
-        // read in both halves of interval c and chunk c + 1 lands in the other buffer meanwhile, exactly as before; group
-        // B's late epilogue is why the cluster weights sit in four slots.  Every wave issues its DMA pieces of chunk c + 1 at
-        // the start of interval c -- before its feat stores of that interval, so the counted vmcnt still proves them landed.
-        auto interval = [&](int c, auto bufc) {
-            constexpr int buf = decltype(bufc)::value;
-#ifndef C5_ABL_NODMA
-            if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
-#endif
-            if (wave_u < 4) {
-                chunk_mfma(c, bufc);
-                __builtin_amdgcn_s_barrier();
-                chunk_epi(c);
-                chunk_wait(true);
-                __builtin_amdgcn_s_barrier();
-            } else {
-                if (c > 0) chunk_epi(c - 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                chunk_mfma(c, bufc);
-                chunk_wait(c > 0);
-                __builtin_amdgcn_s_barrier();
-            }
-        };
-        for (int c = 0; c < 32; c += 2) {
-            interval(c, std::integral_constant<int, 0>{});
-            interval(c + 1, std::integral_constant<int, 1>{});
-        }
-        if (wave_u >= 4) chunk_epi(31);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // group B's last epilogue reads the cluster weights; the transpose tiles below alias W5 only, but keep the groups together
-    }
-    if (MODE == MODE_MAX && wg_one_cloud) {
-        fold_chunk_max(31);
-        __syncthreads();
-        unsigned int* dst = reinterpret_cast<unsigned int*>(pooled + (size_t)((blockIdx.x * C5_WAVES * 32) / n) * 1024);
-        for (int o = tid; o < 1024; o += C5_THREADS) atomicMax(dst + o, __float_as_uint(lds[L::OFF_MAX + 512 + o]));
+    for (int c = 0; c < 32; c += 2) {
+        do_chunk(c, std::integral_constant<int, 0>{});
+        do_chunk(c + 1, std::integral_constant<int, 1>{});
     }
 
-    if (MODE == MODE_VLAD && active) {
+    if (active) {
         // per-point inverse norm (models/epc-net.py:148)
         ss += __shfl_xor(ss, 32);
-        if constexpr (FAST) {
+        {
             // fp16 range guard: no element of the row exceeds 65504 unless |feat|^2 does (NaN / Inf rows fail the compare too)
             const bool over = !(ss <= 65504.0f * 65504.0f);
             if (status && __builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(status + g0 / n, EPC_STATUS_FP16_RANGE);
@@ -649,7 +324,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         const float* cs = lds + L::OFF_CBN;
         const float* ct = cs + 64;
         float mx = -INFINITY;
-        const float rn_w = FAST ? rn * (1.0f / W5_SCALE) : rn;  // (fast form: the cluster weights are packed scaled as well)
+        const float rn_w = rn * (1.0f / W5_SCALE);  // (the cluster weights are packed scaled as well)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -684,7 +359,7 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
         // tile's partial a_sum (loupe.py:276).  The 2^14 keeps small assignments in fp16's normal range; it is exact
         // and the aggregate kernel removes it.  rnorm is applied on the feature side there.
         float* T = lds + L::OFF_T + wave * L::T_WAVE;
-        float* fdst = assign_frag + (size_t)(g0 >> 5) * (FAST ? 1024 : 2048) + lane * 4;
+        float* fdst = assign_frag + (size_t)(g0 >> 5) * 1024 + lane * 4;
         float asum[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -698,17 +373,10 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
                 v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) s_ += v[q];
-                if constexpr (FAST) {
-                    f16x8 th;
+                f16x8 th;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) th[q] = (_Float16)(v[q] * AGG_ASSIGN_SCALE);
-                    *reinterpret_cast<u32x4*>(fdst + (t * 2 + ks) * 256) = __builtin_bit_cast(u32x4, th);
-                } else {   // bf16 hi + lo fragments (no scale: bf16 has f32's range)
-                    bf16x8 ah, al;
-                    split8(v, ah, al);
-                    *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 0) * 256) = __builtin_bit_cast(u32x4, ah);
-                    *reinterpret_cast<u32x4*>(fdst + ((t * 2 + ks) * 2 + 1) * 256) = __builtin_bit_cast(u32x4, al);
-                }
+                for (int q = 0; q < 8; ++q) th[q] = (_Float16)(v[q] * AGG_ASSIGN_SCALE);
+                *reinterpret_cast<u32x4*>(fdst + (t * 2 + ks) * 256) = __builtin_bit_cast(u32x4, th);
             }
             asum[t] = s_ + __shfl_xor(s_, 32);
         }
@@ -719,20 +387,19 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_kernel(const float* __restri
     }
 }
 
-template <int CIN, int MODE, bool CAT16, bool FAST>
+template <int CIN, bool CAT16>
 static int launch_conv5(const float* cat, const float* pack, long total, int n, float* feat, float* rnorm,
-                        float* assign, float* assign_frag, float* apart, float* pooled, int32_t* status,
-                        hipStream_t stream, const char* who) {
-    const size_t lds_bytes = C5Lds<CIN, FAST>::TOTAL * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, MODE, CAT16, FAST>),
+                        float* assign, float* assign_frag, float* apart, int32_t* status, hipStream_t stream, const char* who) {
+    const size_t lds_bytes = C5Lds<CIN>::TOTAL * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv5_kernel<CIN, CAT16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
         epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
         return EPC_EHIP;
     }
     const unsigned blocks = (unsigned)((total + C5_WAVES * 32 - 1) / (C5_WAVES * 32));
-    hipLaunchKernelGGL((conv5_kernel<CIN, MODE, CAT16, FAST>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack,
-                       (int)total, n, feat, rnorm, assign, assign_frag, apart, pooled, status);
+    hipLaunchKernelGGL((conv5_kernel<CIN, CAT16>), dim3(blocks), dim3(C5_THREADS), lds_bytes, stream, cat, pack, (int)total, n, feat,
+                       rnorm, assign, assign_frag, apart, status);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
         epc_set_error("%s: launch failed: %s", who, hipGetErrorString(le));
@@ -752,12 +419,10 @@ extern "C" int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, cons
     if (num_points_total == 0) return EPC_OK;
     if (!status) n = 32;   // (only used to find a tile's status word)
     if (cat_fp16)
-        return launch_conv5<256, MODE_VLAD, true, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n,
-                                                        (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart,
-                                                        nullptr, status, (hipStream_t)stream, __func__);
-    return launch_conv5<256, MODE_VLAD, false, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n,
-                                                     (float*)feat_frag, rnorm, assign, (float*)assign_frag, apart, nullptr,
-                                                     status, (hipStream_t)stream, __func__);
+        return launch_conv5<256, true>((const float*)cat, (const float*)packed_conv5, num_points_total, n, (float*)feat_frag, rnorm,
+                                       assign, (float*)assign_frag, apart, status, (hipStream_t)stream, __func__);
+    return launch_conv5<256, false>((const float*)cat, (const float*)packed_conv5, num_points_total, n, (float*)feat_frag, rnorm,
+                                    assign, (float*)assign_frag, apart, status, (hipStream_t)stream, __func__);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -131,16 +131,16 @@ __global__ void fold_pack_conv5_kernel(const float* __restrict__ W, const float*
             const size_t chunk_halfs = (size_t)48 * cin;                       // 96*cin bytes per chunk
             dstW[(size_t)c * chunk_halfs + (size_t)s * 512 + lane * 8 + j] = __builtin_bit_cast(unsigned short, h);
         } else {
-            // 16x16x32 fragments (conv5_f32.hip): [chunk c][k-step s (32 input channels)][channel group g (16)][part][lane][8],
-            // lane l = (column l & 15, k-octet l >> 4)
+            // 16x16x32 fragments (conv5_f32.hip): [chunk c][channel group g (16)][k-step s (32 input channels)][part][lane][8],
+            // lane l = (column l & 15, k-octet l >> 4); a (chunk, group) is contiguous: one LDS stage of the max-pool kernel
             const int steps = cin / 32;
-            const int g = rest & 1, s = (rest >> 1) % steps, c = (rest >> 1) / steps;
+            const int s = rest % steps, g = (rest / steps) & 1, c = rest / (2 * steps);
             const int k = 32 * s + 8 * (lane >> 4) + j, col = 32 * c + 16 * g + (lane & 15);
             const float w = W[(size_t)k * 1024 + col] * bn_inv(gamma, var, col);
             const float ws = w * (1.0f / tinv[col]);   // exact: a power of two
             const _Float16 hh = (_Float16)ws;
             const _Float16 ll = (_Float16)(ws - (float)hh);
-            const size_t base = ((size_t)((c * steps + s) * 2 + g) * 2) * 512 + lane * 8 + j;
+            const size_t base = ((size_t)((c * 2 + g) * steps + s) * 2) * 512 + lane * 8 + j;
             dstW[base] = __builtin_bit_cast(unsigned short, hh);
             dstW[base + 512] = __builtin_bit_cast(unsigned short, ll);
         }

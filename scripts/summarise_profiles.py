@@ -74,7 +74,7 @@ if kernels:
 # ---- compute-side counters -------------------------------------------------------------------------------------------
 # the launches of one bench step, per arithmetic (bench.py's pipeline_hbm sums bytes over them)
 LAUNCHES = {"f32": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel<20, true, 8>": 1, "proxyconv_block_kernel": 4,
-                    "void conv5_kernel<256, 0, false, false>": 1, "vlad_aggregate_f32_kernel": 1, "void vlad_fold_kernel": 1,
+                    "void conv5_vlad_f32_kernel<256>": 1, "vlad_aggregate_f32_kernel": 1, "void vlad_fold_kernel": 1,
                     "hidden_gemm_kernel": 1, "head_finish_kernel": 1},
             "fast": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel<20, true, 8>": 1, "proxyconv_block_f16_kernel": 4,
                      "void conv5_kernel<256, 0, true, true>": 1, "vlad_aggregate_kernel": 1, "void vlad_fold_kernel": 1,
