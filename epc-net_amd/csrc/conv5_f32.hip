@@ -31,8 +31,23 @@
 // together.  Hazards: a W5 buffer is overwritten only after the barrier that follows every wave's chain on it (as before);
 // waves 4-7 read chunk c's cluster weights one interval late, so those sit in FOUR LDS slots (chunk c + 4's piece is issued
 // after barrier c + 2); the max-pool form's per-wave maxima sit in four slabs for the same reason and are folded two
-// intervals late.  (A 256-thread, two-workgroups-per-CU form with the SIMD partners in different workgroups was also built
-// and measured: no barrier ties the partners, but each wave issues twice the LDS-DMA and the phases drift: 0.458 vs 0.449 ms.)
+// intervals late.  Also built, measured and dropped (round 3):
+//  * 256-thread workgroups, two per CU, the SIMD partners in different workgroups: no barrier ties them, but each wave issues
+//    twice the LDS-DMA and the phases drift: 0.458 vs 0.449 ms (kept for the max-pool kernel below, where it wins);
+//  * the chunk's 24 assignment MFMAs deferred to the head of the wave's next chain (pure VALU / pure MFMA phases): 0.456-0.468
+//    vs 0.441-0.453 ms;
+//  * first-round workgroups started a quarter phase apart (so that the CUs' 256-KB prologue bursts do not coincide): 0.430 vs
+//    0.435 ms -- the prologue is bound by the CU's own miss queue at HBM latency (~9 B/clk/CU), not by the shared HBM rate;
+//  * a PERSISTENT workgroup (one per CU, the W5 stream never stops, a wave starts its tile at whatever chunk the stream is at
+//    and spreads the previous tile's final epilogue and the next tile's row loads over nine intervals while its SIMD partner,
+//    eleven intervals out of phase, computes): bit-exact feat, but 0.492 ms as first built (the boundary intervals are
+//    barrier-coupled: everyone waits for the loading wave's HBM latency and for the 9k-cycle final epilogue) and, decisive, a
+//    tile that starts at chunk c0 adds |feat|^2 and the assignment logits in the ROTATED chunk order c0 .. c0 - 1, so a cloud's
+//    descriptor would depend on its position in the batch in the last bits (tests/test_gpu_parity.py::
+//    test_full_size_properties, and retrieval.evaluate_sharded == evaluate_runs bit for bit, rely on it not doing so); starts
+//    aligned to chunk 0 need a 64-interval period, i.e. ONE computing wave per SIMD at a time: at best -6 %.
+//  What the stamps leave (per wave, 212k cycles per tile): prologue 18 %, chain 27 %, epilogue 31 % (1 900 cycles per chunk
+//  beside the partner's chain: a 16x16x32 MFMA blocks the SIMD's vector issue for 8 of its 16 cycles), barrier 12 %.
 //
 // Tile algebra.  A 32-channel x 32-point chunk tile is 2 x 2 tiles of 16 x 16, a k-step is 32 input channels.
 //   fragment of lane l (q = l >> 4, li = l & 15) for k-step s:  8 consecutive k = 32 s + 8 q + 0..7 of row / column li

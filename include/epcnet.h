@@ -219,9 +219,9 @@ int epc_conv5_assign_fwd(const void* cat, int cat_fp16, int cin, const void* pac
 /* The same stage in EPC_PRECISION_F32 (weights packed for that precision): cat (M, 256) f32 ->
  *   feat_frag   (M/32, 32 chunks, 3 pieces, 64 lanes, 16 bytes): the un-normalised conv5 output as 3-BYTE values -- the upper
  *               24 bits of the float32 (sign, exponent, 15 fraction bits), rounded to nearest: the 16 significant bits the
- *               aggregate's bf16 hi + lo split keeps.  Accumulator order: the 48 bytes of lane l of (tile g, chunk c), pieces
- *               concatenated, are 16 values, little-endian, value 4r + e = point 32g + (l&31), channel 32c + 8r + 4(l>>5) + e.
- *               3 KB per point (M * 3072 bytes);
+ *               aggregate's bf16 hi + lo split keeps.  Accumulator order of the 16x16x32 MFMA (csrc/conv5_f32.hip): the 48 bytes
+ *               of lane l of (tile g, chunk c), pieces concatenated, are 16 values, little-endian; with li = l & 15, q = l >> 4,
+ *               value 4t + r (t = 2 g2 + p) = point 32g + 16p + li, channel 32c + 16 g2 + 4q + r.  3 KB per point (M * 3072 bytes);
  *   rnorm, assign, apart as above;
  *   assign_frag (M/32, 2 cluster tiles t, 2 k-steps s, 2 parts (hi, lo), 64 lanes, 8 bf16): assign split as
  *               hi = bf16(a), lo = bf16(a - hi), B fragments (lane l: cluster 32t + (l&31), points 32g + 16s + 8(l>>5) + 0..7). */
