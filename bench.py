@@ -489,6 +489,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])                        # does not return
 
+    # stdout carries ONE JSON line and nothing else.  Libraries write there behind Python's back (RCCL prints a five-line
+    # version banner to the C stdout of every rank that creates a communicator), so file descriptor 1 is pointed at stderr for
+    # the whole run and the line goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -595,7 +602,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, store if args.arch != "epc-net" or not configs else build_store(args.arch, device, 0),
                                                 args.cpu_budget_s, args.cpu_clouds)
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if rccl:
         tdist.barrier()
         tdist.destroy_process_group()
