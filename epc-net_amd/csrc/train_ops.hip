@@ -290,21 +290,31 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
         if constexpr (G_PF > 1)
             if (kt + S_BK < k1) k_tile(kt + S_BK, std::integral_constant<int, 1>{});
     }
-    // Column statistics of the product for a training-mode BatchNorm that follows (epc_gemm_f32_stats): per row tile the sums
-    // of acc and acc^2 over the tile's valid rows -- of the product WITHOUT the bias, i.e. already shifted by the column's
-    // bias, which keeps the second moment away from cancellation.  Fixed order: registers, lane halves, the two row-waves.
+    // Column statistics of the product for a training-mode BatchNorm that follows (epc_gemm_f32_stats): per row tile and column
+    // the PIVOT p = the product's value in the tile's first row, and the sums of (v - p) and (v - p)^2 over the tile's valid rows
+    // (of the product without the bias).  Shifted by a value of the column itself the sums stay at the scale of the column's
+    // spread, so a channel with |mean| >> std loses nothing to cancellation (the sums were shifted by the bias only);
+    // moments_finalize_kernel merges the tiles' (n, mean, M2) in double precision.  Fixed order: registers, lane halves, the
+    // two row-waves.
     if (g.stats) {
         __shared__ float sstat[2][2][32 * WN];   // [column wave][sum, sum of squares][column]
-        float s1[WN], s2[WN];
+        __shared__ float spiv[2][32 * WN];       // [column wave][column]: the tile's first row (held by row-wave 0)
+        float s1[WN], s2[WN], piv[WN];
+        if (wm == 0 && h == 0) {
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb) spiv[wn][32 * cb + i] = acc[0][cb][0];   // mfma_row(0, 0) = row m0 of the tile
+        }
+        __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < WN; ++cb) {
+            piv[cb] = spiv[wn][32 * cb + i];
             s1[cb] = s2[cb] = 0.f;
 #pragma unroll
             for (int rb = 0; rb < WM; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + 32 * WM * wm + 32 * rb + mfma_row(r, h);
-                    const float v = row < g.M ? acc[rb][cb][r] : 0.f;
+                    const float v = row < g.M ? acc[rb][cb][r] - piv[cb] : 0.f;
                     s1[cb] += v;
                     s2[cb] += v * v;
                 }
@@ -321,8 +331,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
             for (int cb = 0; cb < WN; ++cb) {
                 const int col = n0 + 32 * WN * wn + 32 * cb + i;
                 if (col < g.N) {
-                    g.stats[((size_t)blockIdx.y * 2 + 0) * g.N + col] = s1[cb] + sstat[wn][0][32 * cb + i];
-                    g.stats[((size_t)blockIdx.y * 2 + 1) * g.N + col] = s2[cb] + sstat[wn][1][32 * cb + i];
+                    g.stats[((size_t)blockIdx.y * 3 + 0) * g.N + col] = s1[cb] + sstat[wn][0][32 * cb + i];
+                    g.stats[((size_t)blockIdx.y * 3 + 1) * g.N + col] = s2[cb] + sstat[wn][1][32 * cb + i];
+                    g.stats[((size_t)blockIdx.y * 3 + 2) * g.N + col] = piv[cb];
                 }
             }
         }
@@ -564,47 +575,62 @@ extern "C" int epc_gemm_splitk_det(const float* A, const float* B, float* C, con
 }
 
 // ---- y = x W + b together with the batch statistics a training-mode BatchNorm on y needs -------------------------------
-// The GEMM's epilogue leaves, per 128-row (64-row below 128 rows) tile, the column sums of the product and of its square;
-// moments_finalize_kernel adds them in tile order in double precision: mean = b + S1 / rows, var = S2 / rows - (S1 / rows)^2
-// (population variance, tf.nn.moments).  This replaces a pass of epc_col_moments over y (0.35 ms of the 5.3-ms step).
+// The GEMM's epilogue leaves, per row tile of `tile_rows` rows (the last one shorter) and column, (S1, S2, p): the sums of
+// (v - p) and (v - p)^2 with p the tile's first-row value.  A tile's own moments are mean_t = p + S1 / n_t and
+// M2_t = S2 - S1^2 / n_t; tiles are merged pairwise (Chan et al.): mean += d n_t / (n + n_t), M2 += M2_t + d^2 n n_t / (n + n_t),
+// d = mean_t - mean -- all in double precision, in a fixed order (population variance = M2 / rows, tf.nn.moments).
+struct Moments {
+    double n, mean, m2;
+};
+__device__ __forceinline__ void moments_merge(Moments& a, double nt, double mean_t, double m2_t) {
+    if (nt <= 0.0) return;
+    const double tot = a.n + nt, d = mean_t - a.mean;
+    a.mean += d * (nt / tot);
+    a.m2 += m2_t + d * d * (a.n * nt / tot);
+    a.n = tot;
+}
+__device__ __forceinline__ void moments_add_tile(Moments& a, float S1, float S2, float p, double nt) {
+    if (nt <= 0.0) return;
+    const double s1 = (double)S1, s2 = (double)S2;
+    moments_merge(a, nt, (double)p + s1 / nt, fmax(s2 - s1 * s1 / nt, 0.0));
+}
+
 __global__ __launch_bounds__(256) void moments_finalize_kernel(const float* __restrict__ stats, int tiles, int N, int rows,
-                                                               const float* __restrict__ bias, float* __restrict__ mean,
-                                                               float* __restrict__ var) {
-    // 64 columns per workgroup; thread (column, part) adds tiles part, part + 4, ... (8 independent loads in flight), the four
+                                                               int tile_rows, const float* __restrict__ bias,
+                                                               float* __restrict__ mean, float* __restrict__ var) {
+    // 64 columns per workgroup; thread (column, part) merges tiles part, part + 4, ... (8 independent loads in flight), the four
     // parts meet in LDS in a fixed order: deterministic, and the serial chain is tiles / 4 long instead of tiles
-    __shared__ double p1[4][64], p2[4][64];
+    __shared__ Moments pm[4][64];
     const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    double s1 = 0.0, s2 = 0.0;
+    Moments acc{0.0, 0.0, 0.0};
+    auto n_of = [&](int t) { return (double)min(tile_rows, rows - t * tile_rows); };
     if (c < N) {
         int t = part;
         for (; t + 28 < tiles; t += 32) {
-            float a[8], b[8];
+            float a[8], b[8], p[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                a[u] = stats[((size_t)(t + 4 * u) * 2 + 0) * N + c];
-                b[u] = stats[((size_t)(t + 4 * u) * 2 + 1) * N + c];
+                a[u] = stats[((size_t)(t + 4 * u) * 3 + 0) * N + c];
+                b[u] = stats[((size_t)(t + 4 * u) * 3 + 1) * N + c];
+                p[u] = stats[((size_t)(t + 4 * u) * 3 + 2) * N + c];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s1 += (double)a[u];
-                s2 += (double)b[u];
-            }
+            for (int u = 0; u < 8; ++u) moments_add_tile(acc, a[u], b[u], p[u], n_of(t + 4 * u));
         }
-        for (; t < tiles; t += 4) {
-            s1 += (double)stats[((size_t)t * 2 + 0) * N + c];
-            s2 += (double)stats[((size_t)t * 2 + 1) * N + c];
-        }
+        for (; t < tiles; t += 4)
+            moments_add_tile(acc, stats[((size_t)t * 3 + 0) * N + c], stats[((size_t)t * 3 + 1) * N + c],
+                             stats[((size_t)t * 3 + 2) * N + c], n_of(t));
     }
-    p1[part][cl] = s1;
-    p2[part][cl] = s2;
+    pm[part][cl] = acc;
     __syncthreads();
     if (part == 0 && c < N) {
-        s1 = (p1[0][cl] + p1[1][cl]) + (p1[2][cl] + p1[3][cl]);
-        s2 = (p2[0][cl] + p2[1][cl]) + (p2[2][cl] + p2[3][cl]);
-        const double m = s1 / rows;
-        mean[c] = (float)(m + (bias ? (double)bias[c] : 0.0));
-        var[c] = (float)fmax(s2 / rows - m * m, 0.0);
+        Moments m = pm[0][cl];
+        moments_merge(m, pm[1][cl].n, pm[1][cl].mean, pm[1][cl].m2);
+        moments_merge(m, pm[2][cl].n, pm[2][cl].mean, pm[2][cl].m2);
+        moments_merge(m, pm[3][cl].n, pm[3][cl].mean, pm[3][cl].m2);
+        mean[c] = (float)(m.mean + (bias ? (double)bias[c] : 0.0));
+        var[c] = (float)fmax(m.m2 / rows, 0.0);
     }
 }
 
@@ -620,7 +646,7 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     EPC_CHECK_ARG(A && B && C && stats && mean && var, "null pointer");
     EPC_CHECK_ARG(M >= 64 && N >= 64 && K >= 32 && ldc >= N, "the statistics epilogue exists in the split-bf16 kernel: M, N >= 64, K >= 32");
     const int tiles = epc_gemm_stats_tiles(M);
-    EPC_CHECK_ARG(stats_floats >= (size_t)tiles * 2 * N, "statistics buffer too small (epc_gemm_stats_tiles(M) * 2 * N floats)");
+    EPC_CHECK_ARG(stats_floats >= (size_t)tiles * 3 * N, "statistics buffer too small (epc_gemm_stats_tiles(M) * 3 * N floats)");
     hipStream_t st = (hipStream_t)stream;
 #ifndef EPC_NO_THIN_FORWARD
     if (N == 64 && K == 64 && sAm == 64 && sAk == 1 && sBk == 64 && sBn == 1 && ldc == 64 &&
@@ -630,7 +656,7 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
         hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, B, bias, M, C, stats, (unsigned int*)nullptr,
                            (float*)nullptr, (float*)nullptr);
         EPC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(256), 0, st, stats, wgs, 64, M, bias, mean, var);
+        hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(256), 0, st, stats, wgs, 64, M, 256 /* LS_ROWS_PER_WG */, bias, mean, var);
         EPC_CHECK_LAUNCH();
         return EPC_OK;
     }
@@ -642,7 +668,8 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     else if (bign) launch_gemm_split<1, 2>(g, 1, 3, st);
     else launch_gemm_split<1, 1>(g, 1, 3, st);
     EPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, st, stats, tiles, N, M, bias, mean, var);
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, st, stats, tiles, N, M, M >= 128 ? 128 : 64, bias,
+                       mean, var);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -655,6 +682,7 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
 // an LDS round trip per k-tile for a K of 64): 23.5 -> 13 us per layer at 73 728 rows, and half the partials to finalize.
 #define LS_TILES_PER_WAVE 2
 #define LS_ROWS_PER_WG (4 * 32 * LS_TILES_PER_WAVE)
+static_assert(LS_ROWS_PER_WG == 256, "epc_gemm_f32_stats passes 256 to moments_finalize_kernel");
 
 // `counter` (optional): a zero word of the caller's column-reduction workspace.  With it the workgroup that finishes LAST adds
 // the partials (ascending order, double precision: moments_finalize_kernel's arithmetic) and writes mean / var itself -- no
@@ -665,7 +693,7 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
                                                              unsigned int* __restrict__ counter, float* __restrict__ mean,
                                                              float* __restrict__ var) {
     __shared__ u32x4 Wf[2][4][3][64];                                  // [out tile][k-step][piece][lane]: 24 KB
-    __shared__ __attribute__((aligned(16))) float sred[3][2][64];      // column sums of waves 1..3: [wave][sum, sum of squares][column]
+    __shared__ __attribute__((aligned(16))) float sred[3][3][64];      // waves 1..3: [wave][sum, sum of squares, pivot][column]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     // B[k = in][n = out] = W[k][n]: lane (n = 32 nt + i, k group h) of k-step s holds W[16 s + 8 h .. + 7][n]
@@ -682,7 +710,9 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
         Wf[nt][s4][2][l] = __builtin_bit_cast(u32x4, p2);
     }
     __syncthreads();
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // column statistics shifted by a PIVOT (the wave's first row of that column): sums of (v - p), (v - p)^2 stay at the scale of
+    // the column's spread whatever its mean; waves are rebased onto wave 0's pivot when they meet
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, piv[2] = {0.f, 0.f};
     const float b0 = bias ? bias[i] : 0.f, b1 = bias ? bias[32 + i] : 0.f;
     // every tile's rows are requested before the first is used (a wave is alone on its SIMD in these grids: 1152 waves on 1024
     // SIMDs -- nothing else covers its memory latency)
@@ -727,19 +757,22 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
                 acc = mfma_bf16(a0[s4], w0, acc);
             }
             const float bv = nt ? b1 : b0;
+            if (t == 0) piv[nt] = __shfl(acc[0], i);   // row `base` of the wave's first tile (mfma_row(0, 0) = 0: lanes h = 0), always < rows
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = base + mfma_row(r, h);
                 if (rr < rows) {
-                    const float v = acc[r];     // (statistics of the product WITHOUT the bias: moments_finalize_kernel adds it to the mean)
-                    s1[nt] += v;
-                    s2[nt] += v * v;
+                    const float v = acc[r];     // (statistics of the product WITHOUT the bias: the finish adds it to the mean)
+                    const float d = v - piv[nt];
+                    s1[nt] += d;
+                    s2[nt] += d * d;
                     z[(size_t)rr * 64 + 32 * nt + i] = v + bv;
                 }
             }
         }
     }
-    // fixed order: registers (above), lane halves, waves 0..3
+    // fixed order: registers (above), lane halves, waves 0..3 (each rebased onto wave 0's pivot:
+    // sum (v - p0) = sum (v - pw) + n (pw - p0),  sum (v - p0)^2 = sum (v - pw)^2 + 2 (pw - p0) sum (v - pw) + n (pw - p0)^2)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         s1[nt] += __shfl_xor(s1[nt], 32);
@@ -748,21 +781,29 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
     if (wave > 0 && h == 0) {
         sred[wave - 1][0][i] = s1[0], sred[wave - 1][0][32 + i] = s1[1];
         sred[wave - 1][1][i] = s2[0], sred[wave - 1][1][32 + i] = s2[1];
+        sred[wave - 1][2][i] = piv[0], sred[wave - 1][2][32 + i] = piv[1];
     }
     __syncthreads();
     if (wave == 0 && h == 0) {
+        const int wg_rows = min(LS_ROWS_PER_WG, rows - (int)blockIdx.x * LS_ROWS_PER_WG);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = 32 * nt + i;
-            __hip_atomic_store(&stats[((size_t)blockIdx.x * 2 + 0) * 64 + c], ((s1[nt] + sred[0][0][c]) + sred[1][0][c]) + sred[2][0][c],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&stats[((size_t)blockIdx.x * 2 + 1) * 64 + c], ((s2[nt] + sred[0][1][c]) + sred[1][1][c]) + sred[2][1][c],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float t1 = s1[nt], t2 = s2[nt];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float nw = (float)max(0, min(32 * LS_TILES_PER_WAVE, wg_rows - w * 32 * LS_TILES_PER_WAVE));   // the wave's valid rows
+                const float dp = nw > 0.f ? sred[w - 1][2][c] - piv[nt] : 0.f;
+                t1 += sred[w - 1][0][c] + nw * dp;
+                t2 += sred[w - 1][1][c] + (2.0f * dp) * sred[w - 1][0][c] + nw * dp * dp;
+            }
+            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 0) * 64 + c], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 1) * 64 + c], t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 2) * 64 + c], piv[nt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (!counter) return;
     __shared__ int s_last;
-    __shared__ double fin[2][4][64];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
@@ -770,31 +811,33 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
     __syncthreads();
     if (!s_last) return;
     {
+        // the workgroup that arrives last merges the partials (ascending order within a part, parts in order: double precision,
+        // moments_finalize_kernel's arithmetic)
         const int c = tid & 63, part = tid >> 6, nb = gridDim.x;
-        double t1 = 0.0, t2 = 0.0;
-        int b = part;
-        for (; b + 28 < nb; b += 32) {
-            float u1[8], u2[8];
+        Moments acc{0.0, 0.0, 0.0};
+        auto n_of = [&](int b_) { return (double)min(LS_ROWS_PER_WG, rows - b_ * LS_ROWS_PER_WG); };
+        auto ld = [&](int b_, int k_) {
+            return __hip_atomic_load(&stats[((size_t)b_ * 3 + k_) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        int b_ = part;
+        for (; b_ + 28 < nb; b_ += 32) {
+            float u1[8], u2[8], u3[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                u1[u] = __hip_atomic_load(&stats[((size_t)(b + 4 * u) * 2 + 0) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u2[u] = __hip_atomic_load(&stats[((size_t)(b + 4 * u) * 2 + 1) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int u = 0; u < 8; ++u) u1[u] = ld(b_ + 4 * u, 0), u2[u] = ld(b_ + 4 * u, 1), u3[u] = ld(b_ + 4 * u, 2);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t1 += (double)u1[u], t2 += (double)u2[u];
+            for (int u = 0; u < 8; ++u) moments_add_tile(acc, u1[u], u2[u], u3[u], n_of(b_ + 4 * u));
         }
-        for (; b < nb; b += 4) {
-            t1 += (double)__hip_atomic_load(&stats[((size_t)b * 2 + 0) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t2 += (double)__hip_atomic_load(&stats[((size_t)b * 2 + 1) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        fin[0][part][c] = t1, fin[1][part][c] = t2;
+        for (; b_ < nb; b_ += 4) moments_add_tile(acc, ld(b_, 0), ld(b_, 1), ld(b_, 2), n_of(b_));
+        __shared__ Moments fin[4][64];
+        fin[part][c] = acc;
         __syncthreads();
         if (part == 0) {
-            t1 = (fin[0][0][c] + fin[0][1][c]) + (fin[0][2][c] + fin[0][3][c]);
-            t2 = (fin[1][0][c] + fin[1][1][c]) + (fin[1][2][c] + fin[1][3][c]);
-            const double m = t1 / rows;
-            mean[c] = (float)(m + (bias ? (double)bias[c] : 0.0));
-            var[c] = (float)fmax(t2 / rows - m * m, 0.0);
+            Moments m = fin[0][c];
+            moments_merge(m, fin[1][c].n, fin[1][c].mean, fin[1][c].m2);
+            moments_merge(m, fin[2][c].n, fin[2][c].mean, fin[2][c].m2);
+            moments_merge(m, fin[3][c].n, fin[3][c].mean, fin[3][c].m2);
+            mean[c] = (float)(m.mean + (bias ? (double)bias[c] : 0.0));
+            var[c] = (float)fmax(m.m2 / rows, 0.0);
         }
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -994,7 +1037,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 
 extern "C" size_t epc_colreduce_workspace_bytes(int rows, int C) {
     const size_t nb = (rows + CR_ROWS - 1) / CR_ROWS;
-    return CR_COUNTERS * sizeof(unsigned int) + 2 * nb * (size_t)C * sizeof(float);
+    return CR_COUNTERS * sizeof(unsigned int) + 3 * nb * (size_t)C * sizeof(float);   // (linear_stats64: sum, sum of squares, pivot)
 }
 
 static int colreduce_check(const char* who, int rows, int C, const void* workspace, size_t workspace_bytes) {

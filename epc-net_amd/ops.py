@@ -218,7 +218,7 @@ def _gemm_with_stats(x, W, b):
                                            z.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
         return z, mean, var
     tiles = L.lib().epc_gemm_stats_tiles(rows)
-    stats = torch.empty(tiles * 2 * cout, dtype=torch.float32, device=x.device)
+    stats = torch.empty(tiles * 3 * cout, dtype=torch.float32, device=x.device)   # per row tile: sum, sum of squares, pivot
     L.check(L.lib().epc_gemm_f32_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
                                        rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
                                        stats.data_ptr(), stats.numel(), mean.data_ptr(), var.data_ptr(), _st()))

@@ -287,9 +287,10 @@ int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bia
 
 /* y = x W + b (the f32-accurate three-piece arithmetic of epc_gemm_f32, one problem, no split-K) TOGETHER with the batch
  * statistics a training-mode BatchNorm on y needs (utils/tf_util.py:472 tf.nn.moments over the rows): mean[N] and POPULATION
- * var[N].  The GEMM's epilogue leaves per row tile the column sums of the product and of its square in `stats`
- * (epc_gemm_stats_tiles(M) * 2 * N floats), a second tiny launch adds them in tile order in double precision -- no pass of
- * epc_col_moments over y.  M, N >= 64, K >= 32. */
+ * var[N].  The GEMM's epilogue leaves per row tile and column a pivot p (the product's value in the tile's first row) and the
+ * sums of (y - p) and (y - p)^2 in `stats` (epc_gemm_stats_tiles(M) * 3 * N floats); a second tiny launch merges the tiles'
+ * (count, mean, M2) in tile order in double precision (Chan's pairwise update) -- no pass of epc_col_moments over y, and no
+ * cancellation for columns whose |mean| is far above their spread.  M, N >= 64, K >= 32. */
 int epc_gemm_stats_tiles(int M);
 int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                        long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, void* stream);
@@ -310,7 +311,8 @@ int epc_linear_smallk_dw(const float* x, const float* dy, int rows, int cin, int
 
 /* y = x W + b for a 64 -> 64 layer (x, y: (rows, 64) row-major, 16-byte aligned; W: (64 in, 64 out)) TOGETHER with the batch
  * moments of y (mean, population variance: tf.nn.moments) in ONE launch: one pass over the rows in the f32-accurate six-product
- * arithmetic, per-workgroup column sums, and the workgroup that finishes last adds them in ascending order in double precision.
+ * arithmetic, per-workgroup pivot-shifted column sums (as epc_gemm_f32_stats), and the workgroup that finishes last merges
+ * them in ascending order in double precision.
  * `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64); zero counters, left zero).
  * Replaces tf.nn.conv1d + bias_add + tf.nn.moments of utils/tf_util.py:94-99, 472 for the thin layers. */
 int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,

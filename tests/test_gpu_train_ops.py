@@ -91,6 +91,27 @@ def test_linear_batch_norm_train_node(dev, rows, cin, cout, relu, need_dx):
             assert (a is None and bb is None) or torch.equal(a, bb)
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(5000, 64, 64), (300, 64, 64), (4096, 256, 1024), (777, 64, 128)])
+def test_fused_batch_statistics_with_mean_far_above_spread(dev, rows, cin, cout):
+    """the statistics epilogues (epc_linear_stats64 for the thin layers, epc_gemm_f32_stats for the others)
+    must not lose the variance of a channel whose |mean| is ~10^3 standard deviations (post-ReLU inputs, trained checkpoints):
+    the per-tile sums are shifted by a pivot row of the column itself and merged Chan-style.  x = a constant large offset along
+    one input direction + unit noise; the bias adds another 10^3.  Variance against float64 at 1e-4 (plain sum / sum-of-squares
+    in float32 is off by tens of per cent here, or negative)."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(rows)
+    W = torch.randn(cin, cout, dtype=torch.float64, generator=g) / np.sqrt(cin)
+    x = torch.randn(rows, cin, dtype=torch.float64, generator=g) + 300.0        # every output channel: mean ~ 300 * sum_k W[k][c]
+    b = torch.full((cout,), 1000.0, dtype=torch.float64)
+    z = x.float().double() @ W.float().double() + b.float().double()
+    mean_ref, var_ref = z.mean(0), z.var(0, unbiased=False)
+    assert float((mean_ref.abs() / var_ref.sqrt()).median()) > 300.0               # the regime the test is about
+    zz, mean, var = ops._gemm_with_stats(x.float().to(dev).contiguous(), W.float().to(dev).contiguous(), b.float().to(dev))
+    assert rel(zz, z) <= 2e-6
+    assert float(((mean.double().cpu() - mean_ref).abs() / mean_ref.abs()).max()) <= 1e-6
+    assert float(((var.double().cpu() - var_ref).abs() / var_ref).max()) <= 1e-4, ((var.double().cpu() - var_ref).abs() / var_ref).max()
+
+
 @pytest.mark.parametrize("rows,C,relu", [(8192, 64, 1), (5000, 1024, 1), (72, 256, 0), (18, 256, 0), (4096, 64, 0)])
 def test_batch_norm_train(dev, rows, C, relu):
     ops = H.pkg("ops")
