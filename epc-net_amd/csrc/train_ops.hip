@@ -2047,11 +2047,14 @@ extern "C" int epc_rownorm_bwd(const float* dy, const float* y, const float* rn,
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// Softmax over 64 columns, one wave per row.  bwd: dx = y * (dy - sum(dy*y)).
+// Softmax over 64 columns, one wave per row.  bwd: dx = y * (dy - sum(dy*y)); with BCAST the incoming gradient is
+// dy + dsum[row / n_points] -- the gradient of a_sum = sum over the cloud's points (loupe.py:276) reaches every point
+// of the cloud unchanged, so it is added here instead of being expanded to (rows, 64) in memory.
 // ----------------------------------------------------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, bool BCAST>
 __global__ __launch_bounds__(256) void softmax64_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        int rows, float* __restrict__ out) {
+                                                        const float* __restrict__ dsum, int n_points, int rows,
+                                                        float* __restrict__ out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const size_t o = (size_t)row * 64 + lane;
@@ -2066,7 +2069,9 @@ __global__ __launch_bounds__(256) void softmax64_kernel(const float* __restrict_
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
         out[o] = e / s;
     } else {
-        const float dy = a[o], y = b[o];
+        float dy = a[o];
+        if (BCAST) dy += dsum[(size_t)(row / n_points) * 64 + lane];
+        const float y = b[o];
         float s = dy * y;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
@@ -2076,14 +2081,110 @@ __global__ __launch_bounds__(256) void softmax64_kernel(const float* __restrict_
 
 extern "C" int epc_softmax64_fwd(const float* x, int rows, float* y, void* stream) {
     EPC_CHECK_ARG(x && y && rows > 0, "bad argument");
-    hipLaunchKernelGGL(softmax64_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, nullptr, rows, y);
+    hipLaunchKernelGGL((softmax64_kernel<false, false>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                       nullptr, 1, rows, y);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
 
 extern "C" int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void* stream) {
     EPC_CHECK_ARG(dy && y && dx && rows > 0, "bad argument");
-    hipLaunchKernelGGL(softmax64_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, rows, dx);
+    hipLaunchKernelGGL((softmax64_kernel<true, false>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, nullptr,
+                       1, rows, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n_points, const float* y, int rows, float* dx,
+                                       void* stream) {
+    EPC_CHECK_ARG(dy && dsum && y && dx && rows > 0 && n_points > 0 && rows % n_points == 0, "bad argument");
+    hipLaunchKernelGGL((softmax64_kernel<true, true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, dsum,
+                       n_points, rows, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// a_sum[b][c] = sum over the cloud's points of a[b][n][c] (loupe.py:276), 64 columns.  CS_SEG segments per cloud, each one
+// workgroup: thread (column, quarter) adds its rows in order, the four quarters are added in order, and the second kernel
+// adds the CS_SEG partial sums in order -- the same bits every run.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int CS_SEG = 16;
+
+__global__ __launch_bounds__(256) void cloud_colsum64_partial_kernel(const float* __restrict__ a, int n_points,
+                                                                     float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int seg = blockIdx.x, b = blockIdx.y, col = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int len = (n_points + CS_SEG - 1) / CS_SEG;
+    const int r0 = seg * len, r1 = min(n_points, r0 + len);
+    const float* src = a + (size_t)b * n_points * 64 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0 + q;
+    for (; r + 12 < r1; r += 16) {
+        s0 += src[(size_t)r * 64];
+        s1 += src[(size_t)(r + 4) * 64];
+        s2 += src[(size_t)(r + 8) * 64];
+        s3 += src[(size_t)(r + 12) * 64];
+    }
+    for (; r < r1; r += 4) s0 += src[(size_t)r * 64];
+    red[q][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0) part[((size_t)b * CS_SEG + seg) * 64 + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+__global__ void cloud_colsum64_finish_kernel(const float* __restrict__ part, int total, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* p = part + (size_t)(i >> 6) * CS_SEG * 64 + (i & 63);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_SEG; ++k) s += p[k * 64];
+    out[i] = s;
+}
+
+extern "C" size_t epc_cloud_colsum64_partial_floats(int num_clouds) { return (size_t)max(num_clouds, 0) * CS_SEG * 64; }
+
+extern "C" int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out, float* partials,
+                                  size_t partial_floats, void* stream) {
+    EPC_CHECK_ARG(a && out && partials && num_clouds > 0 && n_points > 0, "bad argument");
+    EPC_CHECK_ARG(partial_floats >= epc_cloud_colsum64_partial_floats(num_clouds), "partials buffer too small");
+    hipLaunchKernelGGL(cloud_colsum64_partial_kernel, dim3(CS_SEG, num_clouds), dim3(256), 0, (hipStream_t)stream, a, n_points,
+                       partials);
+    const int total = num_clouds * 64;
+    hipLaunchKernelGGL(cloud_colsum64_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
+                       total, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout*s, dg = dout*y*s*(1-s).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void gate_fwd_kernel(const float* __restrict__ y, const float* __restrict__ g, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = y[i] * (1.f / (1.f + expf(-g[i])));
+}
+
+__global__ void gate_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ g,
+                                long n, float* __restrict__ dy, float* __restrict__ dg) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.f / (1.f + expf(-g[i])), d = dout[i];
+    dy[i] = d * s;
+    dg[i] = d * y[i] * (s * (1.f - s));
+}
+
+extern "C" int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream) {
+    EPC_CHECK_ARG(y && g && out && n > 0, "bad argument");
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, g, n, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, float* dy, float* dg, void* stream) {
+    EPC_CHECK_ARG(dout && y && g && dy && dg && n > 0, "bad argument");
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, y, g, n,
+                       dy, dg);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

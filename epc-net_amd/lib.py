@@ -46,7 +46,8 @@ EXPORTS = [
     "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_stats64", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
-    "epc_softmax64_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
+    "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64", "epc_gate_fwd",
+    "epc_gate_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -145,6 +146,12 @@ _lib.epc_rownorm_fwd.argtypes = [_P, c_int, c_int, _P, _P, _P]
 _lib.epc_rownorm_bwd.argtypes = [_P, _P, _P, c_int, c_int, _P, _P]
 _lib.epc_softmax64_fwd.argtypes = [_P, c_int, _P, _P]
 _lib.epc_softmax64_bwd.argtypes = [_P, _P, c_int, _P, _P]
+_lib.epc_softmax64_bwd_bcast.argtypes = [_P, _P, c_int, _P, c_int, _P, _P]
+_lib.epc_cloud_colsum64_partial_floats.argtypes = [c_int]
+_lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
+_lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
+_lib.epc_gate_fwd.argtypes = [_P, _P, ctypes.c_long, _P, _P]
+_lib.epc_gate_bwd.argtypes = [_P, _P, _P, ctypes.c_long, _P, _P, _P]
 _lib.epc_adam_step.argtypes = [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]
 _lib.epc_adam_step_dev.argtypes = [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, _P]
 _lib.epc_ema_update.argtypes = [_P, _P, c_long, c_float, _P, _P]

@@ -89,7 +89,7 @@ class PoolingBaseModel(object):
         w = default_store().vars[scoped("gating_weights")]
         gates = ops.Linear.apply(input_layer, w, None)
         gates = _slim_batch_norm(gates, "gating_bn", self.is_training, fused=True)
-        return input_layer * torch.sigmoid(gates)
+        return ops.GateMul.apply(input_layer, gates)
 
 
 class _VladBase(PoolingBaseModel):
@@ -122,10 +122,9 @@ class _VladBase(PoolingBaseModel):
             # :255-263, :272-274, :286-291 as one autograd node (the two gradients of x are one product: ops.VladAssignAggregate)
             from .utils.tf_util import _ema_update
             beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)
-            vlad, activation, mean, var = ops.VladAssignAggregate.apply(x, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N)
+            vlad, a_sum, mean, var = ops.VladAssignAggregate.apply(x, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N)   # a_sum: :276
             _ema_update(mm, mean, SLIM_DECAY, scheduled=False)
             _ema_update(mv, var, SLIM_DECAY, scheduled=False)          # (the unfused slim op: population variance)
-            a_sum = activation.sum(dim=-2, keepdim=True)                                         # :276
         else:
             if self.add_batch_norm:
                 activation = ops.Linear.apply(x, st[scoped("cluster_weights")], None)                    # :255

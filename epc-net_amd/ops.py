@@ -552,7 +552,9 @@ class VladAggregate(torch.autograd.Function):
 class VladAssignAggregate(torch.autograd.Function):
     """The soft assignment and the aggregation of loupe.py:255-291 in training mode as ONE node:
         z = f @ cluster_weights; a = softmax(batch_norm(z)) (slim.batch_norm, batch statistics); vlad[b] = f[b]^T @ a[b]
-    -> (vlad (B, F, 64), a (B, N, 64), mean, var).  What the single node buys is the backward: the two gradients of the shared
+    -> (vlad (B, F, 64), a_sum (B, 1, 64) = sum of a over the cloud's points (:276), mean, var).  The assignment a itself stays
+    inside the node: its only other consumer is a_sum, whose gradient (one row per cloud) is added to every point's row inside the
+    softmax backward (epc_softmax64_bwd_bcast) instead of as an expanded (B, N, 64) tensor.  What the single node buys is the backward: the two gradients of the shared
     input f -- a dvlad^T from the aggregation, dz Wc^T from the assignment -- are ONE product, [a | dz] (rows, 128) times the
     per-cloud [dvlad^T ; Wc^T] (128, F): the (rows, 1024) gradient is written once instead of twice and never re-read for an
     addition (three passes over a 302-MB tensor less per step).  Forward products in the f32-accurate arithmetic (the
@@ -579,14 +581,18 @@ class VladAssignAggregate(torch.autograd.Function):
         B = rows // n_points
         f3, a3 = f.view(B, n_points, F), a.view(B, n_points, 64)
         vlad = gemm(f3, a3, trans_a=True, splitk=max(1, min(8, n_points // 256)), deterministic=True)
+        a_sum = torch.empty((B, 1, 64), dtype=torch.float32, device=f.device)
+        nparts = L.lib().epc_cloud_colsum64_partial_floats(B)
+        parts = torch.empty(nparts, dtype=torch.float32, device=f.device)
+        L.check(L.lib().epc_cloud_colsum64(a.data_ptr(), B, n_points, a_sum.data_ptr(), parts.data_ptr(), nparts, _st()))
         ctx.save_for_backward(f, Wc, z, mean, var, gamma, beta, a)
         ctx.eps, ctx.n_points = float(eps), int(n_points)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)
-        return vlad, a3, mean, var
+        return vlad, a_sum, mean, var
 
     @staticmethod
-    def backward(ctx, dvlad, da_ext, _dm, _dv):
+    def backward(ctx, dvlad, dasum, _dm, _dv):
         f, Wc, z, mean, var, gamma, beta, a = ctx.saved_tensors
         rows, F = f.shape
         N = ctx.n_points
@@ -595,16 +601,15 @@ class VladAssignAggregate(torch.autograd.Function):
         if dvlad is None:
             dvlad = torch.zeros((B, F, 64), dtype=torch.float32, device=f.device)
         dvlad = dvlad.contiguous()
-        # da = f dvlad (+ the gradient that reaches a directly: a_sum of loupe.py:276 -- an expanded view, materialised here)
-        if da_ext is not None:
-            da = da_ext.contiguous()
-            if da.data_ptr() == da_ext.data_ptr():
-                da = da.clone()
-            gemm(f3, dvlad, out=da.view(B, N, 64), accumulate=True, fast=True)
-        else:
-            da = gemm(f3, dvlad, fast=True)
+        # da = f dvlad + (for every point of the cloud) the gradient of a_sum, the latter added inside the softmax backward
+        da = gemm(f3, dvlad, fast=True)
         dpre = torch.empty_like(z)
-        L.check(L.lib().epc_softmax64_bwd(da.data_ptr(), a.data_ptr(), rows, dpre.data_ptr(), _st()))
+        if dasum is not None:
+            dasum = dasum.contiguous()
+            L.check(L.lib().epc_softmax64_bwd_bcast(da.data_ptr(), dasum.data_ptr(), N, a.data_ptr(), rows, dpre.data_ptr(),
+                                                    _st()))
+        else:
+            L.check(L.lib().epc_softmax64_bwd(da.data_ptr(), a.data_ptr(), rows, dpre.data_ptr(), _st()))
         dz = torch.empty_like(z)
         dgamma = torch.empty(64, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(64, dtype=torch.float32, device=z.device)
@@ -619,6 +624,28 @@ class VladAssignAggregate(torch.autograd.Function):
             rhs = torch.cat((dvlad.transpose(1, 2), Wc.t().unsqueeze(0).expand(B, 64, F)), dim=1)   # [dvlad^T ; Wc^T]  (B, 128, F)
             df = gemm(lhs, rhs, fast=True).view(rows, F)
         return df, dWc, dgamma, dbeta, None, None
+
+
+class GateMul(torch.autograd.Function):
+    """Context gating's product, y * sigmoid(g) (loupe.py:99-100), forward and backward one kernel each."""
+
+    @staticmethod
+    def forward(ctx, y, g):
+        y, g = y.contiguous(), g.contiguous()
+        assert y.shape == g.shape
+        out = torch.empty_like(y)
+        L.check(L.lib().epc_gate_fwd(y.data_ptr(), g.data_ptr(), y.numel(), out.data_ptr(), _st()))
+        ctx.save_for_backward(y, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, g = ctx.saved_tensors
+        dout = dout.contiguous()
+        dy, dg = torch.empty_like(y), torch.empty_like(g)
+        L.check(L.lib().epc_gate_bwd(dout.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), dy.data_ptr(), dg.data_ptr(),
+                                     _st()))
+        return dy, dg
 
 
 def morton_sort(xyz):

@@ -32,6 +32,23 @@ def get_learning_rate(epoch: int, base_learning_rate: float) -> float:
     return max(base_learning_rate * (0.9 ** (epoch // 5)), 0.00001)
 
 
+def _joined_along_dim1(parts):
+    """The tensor of which ``parts`` are the consecutive dim-1 slices (torch.split views of one contiguous buffer), or None."""
+    base = parts[0]._base
+    if base is None or not base.is_contiguous() or any(p._base is not base for p in parts):
+        return None
+    if base.dim() != parts[0].dim() or base.shape[1] != sum(int(p.shape[1]) for p in parts):
+        return None
+    at = 0
+    for p in parts:
+        if p.dim() != base.dim() or p.stride() != base.stride() or p.shape[0] != base.shape[0] or p.shape[2:] != base.shape[2:]:
+            return None
+        if p.storage_offset() != base.storage_offset() + at * base.stride(1):
+            return None
+        at += int(p.shape[1])
+    return base
+
+
 class TrainStep:
     def __init__(self, params: dict, store: Optional[VariableStore] = None, outer: str = "query_triplets",
                  arch: Optional[str] = None):
@@ -244,7 +261,10 @@ class TrainStep:
         g = self._graph
         if g is None or g["shapes"] != shapes or g["dp"] != dp:
             dev = query.device
-            g = {"shapes": shapes, "dp": dp, "in": [torch.empty_like(x) for x in inputs],
+            # the four inputs are slices of ONE buffer in train.py:252's order, so that its concat is the buffer itself
+            joined = torch.empty((query.shape[0], sum(s[1] for s in shapes)) + tuple(query.shape[2:]), dtype=query.dtype,
+                                 device=dev)
+            g = {"shapes": shapes, "dp": dp, "in": list(torch.split(joined, [s[1] for s in shapes], 1)),
                  "lr_t": torch.zeros(1, dtype=torch.float32, device=dev),
                  "bn_decay": torch.zeros((), dtype=torch.float32, device=dev)}
             for dst, src in zip(g["in"], inputs):
@@ -297,7 +317,9 @@ class TrainStep:
         evaluation loss of train.py:568-576 (stored statistics, no moving-average update)."""
         p = self.params
         with variable_scope(self.outer):
-            vecs = torch.cat([query, positives, negatives, other_neg], 1)                               # train.py:252
+            vecs = _joined_along_dim1((query, positives, negatives, other_neg))                         # train.py:252
+            if vecs is None:
+                vecs = torch.cat([query, positives, negatives, other_neg], 1)
             out_vecs = self.model.forward(vecs, is_training, bn_decay=bn_decay, params=p)                # :254
             q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
                 out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)                  # :255

@@ -419,6 +419,20 @@ int epc_rownorm_bwd(const float* dy, const float* y, const float* rn, int rows, 
 /* tf.nn.softmax over 64 clusters (loupe.py:272). */
 int epc_softmax64_fwd(const float* x, int rows, float* y, void* stream);
 int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void* stream);
+/* The same with the incoming gradient dy[row] + dsum[row / n_points] (dsum (rows/n_points, 64)): the gradient of
+ * a_sum = reduce_sum(activation, -2) (loupe.py:276) reaches every point of its cloud, added here without being expanded. */
+int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n_points, const float* y, int rows, float* dx,
+                            void* stream);
+
+/* a_sum of loupe.py:276: out (num_clouds, 64) = sum over the n_points rows of each cloud of a (num_clouds, n_points, 64), added
+ * in a fixed order (bit-reproducible).  partials: caller-owned scratch of epc_cloud_colsum64_partial_floats(num_clouds). */
+size_t epc_cloud_colsum64_partial_floats(int num_clouds);
+int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out, float* partials, size_t partial_floats,
+                       void* stream);
+
+/* Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout * s, dg = dout * y * s * (1 - s). */
+int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
+int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, float* dy, float* dg, void* stream);
 
 /* tf.train.AdamOptimizer.apply (train.py:273): t = 1-based step count for the bias correction. */
 int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2, float eps,

@@ -174,6 +174,51 @@ def test_rownorm_and_softmax(dev):
     run_pair(lambda a: ops.Softmax64.apply(a), lambda a: torch.softmax(a, 1), [a], dev)
 
 
+def test_context_gating_product(dev):
+    """loupe.py:99-100: y * sigmoid(g) and both gradients, including saturated gates."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(18, 256, dtype=torch.float64, generator=g)
+    gt = torch.randn(18, 256, dtype=torch.float64, generator=g) * 4
+    gt[0, :4] = torch.tensor([-60.0, 60.0, 0.0, -20.0], dtype=torch.float64)
+    run_pair(lambda y, gt: ops.GateMul.apply(y, gt), lambda y, gt: y * torch.sigmoid(gt), [y, gt], dev)
+
+
+@pytest.mark.parametrize("B,N", [(3, 512), (2, 1000), (18, 4096)])
+def test_assign_aggregate_node_with_cloud_sums(dev, B, N):
+    """ops.VladAssignAggregate: vlad and a_sum (loupe.py:276) against float64, the gradients with BOTH outputs in the loss
+    (a_sum's gradient is the per-cloud row the softmax backward adds to every point), and a_sum bit-equal across runs."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(12)
+    f = torch.rand(B * N, 1024, dtype=torch.float64, generator=g)
+    f = f / f.norm(dim=1, keepdim=True)
+    Wc = torch.randn(1024, 64, dtype=torch.float64, generator=g) / 32
+    gamma = 1 + 0.1 * torch.randn(64, dtype=torch.float64, generator=g)
+    beta = 0.1 * torch.randn(64, dtype=torch.float64, generator=g)
+    up_v = torch.randn(B, 1024, 64, dtype=torch.float64, generator=g)
+    up_s = torch.randn(B, 1, 64, dtype=torch.float64, generator=g)
+
+    def ref(f, Wc, gamma, beta):
+        z = f @ Wc
+        m, v = z.mean(0), z.var(0, unbiased=False)
+        a = torch.softmax((z - m) * torch.rsqrt(v + 1e-3) * gamma + beta, 1).reshape(B, N, 64)
+        return torch.matmul(f.reshape(B, N, 1024).transpose(1, 2), a), a.sum(dim=1, keepdim=True)
+
+    ins = [f, Wc, gamma, beta]
+    g_in = [t.float().to(dev).requires_grad_(True) for t in ins]
+    r_in = [t.clone().requires_grad_(True) for t in ins]
+    vg, sg, _, _ = ops.VladAssignAggregate.apply(g_in[0], g_in[1], g_in[2], g_in[3], 1e-3, N)
+    vr, sr = ref(*r_in)
+    assert rel(vg, vr) <= 2e-5 and rel(sg, sr) <= 2e-5, (rel(vg, vr), rel(sg, sr))
+    ((vg * up_v.float().to(dev)).sum() + (sg * up_s.float().to(dev)).sum()).backward()
+    ((vr * up_v).sum() + (sr * up_s).sum()).backward()
+    for i, (a, b) in enumerate(zip(g_in, r_in)):
+        assert rel(a.grad, b.grad) <= 2e-3, "grad of input %d: %.3e" % (i, rel(a.grad, b.grad))   # 'fast' backward products
+    with torch.no_grad():
+        again = ops.VladAssignAggregate.apply(g_in[0], g_in[1], g_in[2], g_in[3], 1e-3, N)[1]
+    assert torch.equal(again, sg)
+
+
 def test_vlad_aggregate(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(4)

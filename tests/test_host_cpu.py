@@ -195,3 +195,16 @@ def test_plain_c_example_builds_against_the_header():
     r = subprocess.run(["make", "-C", os.path.join(root, "examples")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert os.path.exists(os.path.join(root, "examples", "epcnet_forward"))
+
+
+def test_step_inputs_recognised_as_slices_of_one_buffer():
+    """training._joined_along_dim1: the concat of train.py:252 is skipped only for the exact consecutive dim-1 slices."""
+    import torch
+    T = H.pkg("training")
+    joined = torch.empty(2, 18, 5, 3)
+    parts = torch.split(joined, [1, 2, 14, 1], 1)
+    assert T._joined_along_dim1(parts) is joined
+    assert T._joined_along_dim1((parts[0], parts[2], parts[1], parts[3])) is None          # wrong order
+    assert T._joined_along_dim1(parts[:3]) is None                                        # not the whole buffer
+    assert T._joined_along_dim1(tuple(p.clone() for p in parts)) is None                  # separate tensors
+    assert T._joined_along_dim1(torch.split(joined[:, :, :4], [1, 2, 14, 1], 1)) is None  # slices of a sub-view
