@@ -1201,6 +1201,204 @@ extern "C" int epc_bn_relu_rownorm_fwd(const float* z, const float* mean, const 
     return EPC_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Backward of conv5's tail, f = l2_normalize(relu(bn(z))) (models/epc-net.py:136-148), in TWO passes over (df, z) -- the
+// separate operators (row-norm backward, BatchNorm sums, BatchNorm apply) made three, with the (rows, 1024) intermediate
+// written and read twice and the saved f read once: 2.4 GB per step against 1.5 GB here.  Neither f nor the row-norm's input
+// gradient exists in memory: both passes recompute u = relu(bn(z)) and f = u * rn from z with the forward's own expressions.
+//   pass 1: per row  t = sum_c df f  (rowdot, kept for pass 2);  d = [u > 0] rn (df - f t)   (rn df where the norm was clamped)
+//           per column  dbeta = sum_r d,  dgamma = sum_r d zhat -- one partial per workgroup, added in ascending order
+//   pass 2: dz = gamma rstd (d - dbeta / rows - zhat dgamma / rows)
+// A wave owns a row at a time: lane l holds columns 256 u + 4 l .. + 3 (four float4 per operand: 1 KB per wave-instruction), so
+// the row's dot product is in-wave and the column sums are in-lane over the wave's rows.
+// ----------------------------------------------------------------------------------------------------------------
+#define BRB_ROWS 64   // rows per workgroup (16 per wave)
+
+__global__ __launch_bounds__(256) void bn_relu_rownorm_bwd_sums_kernel(
+    const float* __restrict__ df, const float* __restrict__ z, const float* __restrict__ rn_in, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int rows,
+    float* __restrict__ rowdot, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[4][BRN_C];   // coefficients s, t, mean, rstd; then the waves' sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < BRN_C; c += 256) {
+        const BnAffine a = bn_affine(mean[c], var[c], gamma[c], beta[c], eps);
+        lds[0][c] = a.s, lds[1][c] = a.t, lds[2][c] = mean[c], lds[3][c] = 1.0f / sqrtf(var[c] + eps);
+    }
+    __syncthreads();
+    float cs[16], ct[16], mu[16], rs[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 256 * u + 4 * lane + e;
+            cs[4 * u + e] = lds[0][c], ct[4 * u + e] = lds[1][c], mu[4 * u + e] = lds[2][c], rs[4 * u + e] = lds[3][c];
+        }
+    float s0[16], s1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s0[k] = s1[k] = 0.f;
+    const int row0 = blockIdx.x * BRB_ROWS + wave;
+    for (int q = 0; q < BRB_ROWS / 4; ++q) {
+        const int row = row0 + 4 * q;          // wave-uniform
+        if (row >= rows) break;
+        const float4* g4 = reinterpret_cast<const float4*>(df + (size_t)row * BRN_C);
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * BRN_C);
+        float4 gv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = g4[lane + 64 * u], zv[u] = z4[lane + 64 * u];
+        const float rn = rn_in[row];
+        float g[16], zz[16], f[16];
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[4 * u] = gv[u].x, g[4 * u + 1] = gv[u].y, g[4 * u + 2] = gv[u].z, g[4 * u + 3] = gv[u].w;
+            zz[4 * u] = zv[u].x, zz[4 * u + 1] = zv[u].y, zz[4 * u + 2] = zv[u].z, zz[4 * u + 3] = zv[u].w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * u + e;
+                const float uu = fmaxf(zz[k] * cs[k] + ct[k], 0.f);   // bn_value: the forward's expression
+                f[k] = uu * rn;
+                t += g[k] * f[k];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0) rowdot[row] = t;
+        const bool clamped = rn >= 0.99e6f;   // sum u^2 <= 1e-12: f = u * 1e6, no projection term (rownorm_kernel)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float du = clamped ? g[k] * rn : rn * (g[k] - f[k] * t);
+            const float d = f[k] > 0.f ? du : 0.f;       // f > 0 exactly where bn(z) > 0 (rn > 0)
+            s0[k] += d;
+            s1[k] += d * ((zz[k] - mu[k]) * rs[k]);
+        }
+    }
+    __syncthreads();   // the coefficients are in registers: the LDS rows now carry the waves' sums
+    float* red = &lds[0][0];   // [wave][1024], one quantity per round
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            *reinterpret_cast<float4*>(red + wave * BRN_C + 256 * u + 4 * lane) =
+                qn ? make_float4(s1[4 * u], s1[4 * u + 1], s1[4 * u + 2], s1[4 * u + 3])
+                   : make_float4(s0[4 * u], s0[4 * u + 1], s0[4 * u + 2], s0[4 * u + 3]);
+        __syncthreads();
+        float* out = partial + ((size_t)blockIdx.x * 2 + qn) * BRN_C;
+        for (int c = tid; c < BRN_C; c += 256)
+            out[c] = (red[c] + red[BRN_C + c]) + (red[2 * BRN_C + c] + red[3 * BRN_C + c]);   // waves in a fixed order
+        __syncthreads();
+    }
+}
+
+// out[e] = sum over p < P of part[p][e] in a fixed order (64 groups take every 64th partial each and meet in group order):
+// partial_sum_kernel for MANY partials (conv5's 1152 x 2048 floats), 1024 threads = 16 float4 columns x 64 groups.
+__global__ __launch_bounds__(1024) void partial_sum_wide_kernel(const float* __restrict__ part, int P, int E,
+                                                                float* __restrict__ out) {
+    __shared__ float4 acc[64][16];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e4 = blockIdx.x * 16 + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 * 4 < E) {
+        const float4* src = reinterpret_cast<const float4*>(part) + e4;
+        const size_t stride = (size_t)E / 4;
+        int p = grp;
+        for (; p + 192 < P; p += 256) {
+            const float4 a = src[(size_t)p * stride], b = src[(size_t)(p + 64) * stride], c = src[(size_t)(p + 128) * stride],
+                         d = src[(size_t)(p + 192) * stride];
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            s.x += b.x, s.y += b.y, s.z += b.z, s.w += b.w;
+            s.x += c.x, s.y += c.y, s.z += c.z, s.w += c.w;
+            s.x += d.x, s.y += d.y, s.z += d.z, s.w += d.w;
+        }
+        for (; p < P; p += 64) {
+            const float4 a = src[(size_t)p * stride];
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+        }
+    }
+    acc[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && e4 * 4 < E) {
+        float4 t = acc[0][col];
+#pragma unroll 8
+        for (int g = 1; g < 64; ++g) t.x += acc[g][col].x, t.y += acc[g][col].y, t.z += acc[g][col].z, t.w += acc[g][col].w;
+        reinterpret_cast<float4*>(out)[e4] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_rownorm_bwd_apply_kernel(
+    const float* __restrict__ df, const float* __restrict__ z, const float* __restrict__ rn_in,
+    const float* __restrict__ rowdot, const float* __restrict__ mean, const float* __restrict__ var,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ dbeta,
+    const float* __restrict__ dgamma, float eps, float inv_rows, int rows, float* __restrict__ dz) {
+    __shared__ __attribute__((aligned(16))) float lds[6][BRN_C];   // s, t, mean, k1, dbeta / rows, rstd dgamma / rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < BRN_C; c += 256) {
+        const float m = mean[c], r = 1.0f / sqrtf(var[c] + eps), ga = gamma[c];
+        const BnAffine a = bn_affine(m, var[c], ga, beta[c], eps);
+        lds[0][c] = a.s, lds[1][c] = a.t, lds[2][c] = m;
+        lds[3][c] = ga * r, lds[4][c] = dbeta[c] * inv_rows, lds[5][c] = r * (dgamma[c] * inv_rows);
+    }
+    __syncthreads();
+    float cs[16], ct[16], mu[16], k1[16], bb[16], gg[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 256 * u + 4 * lane + e, k = 4 * u + e;
+            cs[k] = lds[0][c], ct[k] = lds[1][c], mu[k] = lds[2][c], k1[k] = lds[3][c], bb[k] = lds[4][c], gg[k] = lds[5][c];
+        }
+    const int row0 = blockIdx.x * BRB_ROWS + wave;
+    for (int q = 0; q < BRB_ROWS / 4; ++q) {
+        const int row = row0 + 4 * q;
+        if (row >= rows) break;
+        const float4* g4 = reinterpret_cast<const float4*>(df + (size_t)row * BRN_C);
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * BRN_C);
+        float4 gv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = g4[lane + 64 * u], zv[u] = z4[lane + 64 * u];
+        const float rn = rn_in[row], t = rowdot[row];
+        const bool clamped = rn >= 0.99e6f;
+        float4* o4 = reinterpret_cast<float4*>(dz + (size_t)row * BRN_C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * u + e;
+                const float uu = fmaxf(zz[e] * cs[k] + ct[k], 0.f);
+                const float f = uu * rn;
+                const float du = clamped ? g[e] * rn : rn * (g[e] - f * t);
+                const float d = f > 0.f ? du : 0.f;
+                o[e] = k1[k] * (d - bb[k] - (zz[e] - mu[k]) * gg[k]);
+            }
+            o4[lane + 64 * u] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+extern "C" size_t epc_bn_relu_rownorm_bwd_partial_floats(int rows) {
+    return rows > 0 ? (size_t)((rows + BRB_ROWS - 1) / BRB_ROWS) * 2 * BRN_C : 0;
+}
+
+extern "C" int epc_bn_relu_rownorm_bwd(const float* df, const float* z, const float* rn, const float* mean, const float* var,
+                                       const float* gamma, const float* beta, float eps, int rows, int C, float* dz,
+                                       float* dbeta_dgamma, float* rowdot, float* partials, size_t partial_floats,
+                                       void* stream) {
+    EPC_CHECK_ARG(df && z && rn && mean && var && gamma && beta && dz && dbeta_dgamma && rowdot && partials, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C == BRN_C, "implemented for the 1024 channels of conv5");
+    EPC_CHECK_ARG(partial_floats >= epc_bn_relu_rownorm_bwd_partial_floats(rows), "partials buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int wgs = (rows + BRB_ROWS - 1) / BRB_ROWS;
+    hipLaunchKernelGGL(bn_relu_rownorm_bwd_sums_kernel, dim3(wgs), dim3(256), 0, st, df, z, rn, mean, var, gamma, beta, eps, rows,
+                       rowdot, partials);
+    hipLaunchKernelGGL(partial_sum_wide_kernel, dim3(2 * BRN_C / 4 / 16), dim3(1024), 0, st, partials, wgs, 2 * BRN_C,
+                       dbeta_dgamma);
+    hipLaunchKernelGGL(bn_relu_rownorm_bwd_apply_kernel, dim3(wgs), dim3(256), 0, st, df, z, rn, rowdot, mean, var, gamma, beta,
+                       dbeta_dgamma, dbeta_dgamma + BRN_C, eps, 1.0f / rows, rows, dz);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
 // dz = gamma*rstd * (dyr - dbeta/rows - zhat * dgamma/rows); the ReLU mask is recomputed from z with the forward's
 // own expression (bn_value), so the forward output is neither stored for it nor read here.
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,

@@ -247,7 +247,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
             rn = torch.empty(rows, dtype=torch.float32, device=z.device)
             L.check(L.lib().epc_bn_relu_rownorm_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                     beta.data_ptr(), float(eps), rows, C, y.data_ptr(), rn.data_ptr(), _st()))
-            ctx.save_for_backward(x, W, z, mean, var, gamma, beta, y, rn)
+            ctx.save_for_backward(x, W, z, mean, var, gamma, beta, rn)
         else:
             y = torch.empty_like(z)
             L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -263,16 +263,17 @@ class LinearBatchNormTrain(torch.autograd.Function):
         if dy is None:
             return (None,) * 8
         if ctx.rownorm:
-            x, W, z, mean, var, gamma, beta, f, rn = ctx.saved_tensors
+            x, W, z, mean, var, gamma, beta, rn = ctx.saved_tensors
         else:
             x, W, z, mean, var, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         rows, C = z.shape
         cin = x.shape[1]
         if ctx.rownorm:
-            d = torch.empty_like(z)
-            L.check(L.lib().epc_rownorm_bwd(dy.data_ptr(), f.data_ptr(), rn.data_ptr(), rows, C, d.data_ptr(), _st()))
-            dy = d
+            dz, dgamma, dbeta = _bn_relu_rownorm_bwd(dy, z, rn, mean, var, gamma, beta, ctx.eps)
+            dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
+            dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
+            return dx, dW, None, dgamma, dbeta, None, None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
         ws, n = _ws(rows, C, z.device)
@@ -289,7 +290,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
             return dx, dW, None, dgamma, dbeta, None, None, None
         dz = torch.empty_like(z)
         L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
-                                         beta.data_ptr(), ctx.eps, 1 if ctx.rownorm else ctx.relu, rows, C, dz.data_ptr(),
+                                         beta.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(),
                                          dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, _st()))
         dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
@@ -298,7 +299,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
 
 class BatchNormReluRowNorm(torch.autograd.Function):
     """l2_normalize(relu(batch_norm_train(z)), 1) for conv5's 1024 channels (models/epc-net.py:136-148) without
-    materialising the BatchNorm output: (f, mean, var).  Backward = row-norm backward, then the BatchNorm backward."""
+    materialising the BatchNorm output: (f, mean, var).  Backward: two passes over (df, z) (epc_bn_relu_rownorm_bwd)."""
 
     @staticmethod
     def forward(ctx, z, gamma, beta, eps):
@@ -312,7 +313,7 @@ class BatchNormReluRowNorm(torch.autograd.Function):
         rn = torch.empty(rows, dtype=torch.float32, device=z.device)
         L.check(L.lib().epc_bn_relu_rownorm_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                 beta.data_ptr(), float(eps), rows, C, f.data_ptr(), rn.data_ptr(), _st()))
-        ctx.save_for_backward(z, mean, var, gamma, beta, f, rn)
+        ctx.save_for_backward(z, mean, var, gamma, beta, rn)
         ctx.eps = float(eps)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)
@@ -322,19 +323,23 @@ class BatchNormReluRowNorm(torch.autograd.Function):
     def backward(ctx, df, _dm, _dv):
         if df is None:
             return None, None, None, None
-        z, mean, var, gamma, beta, f, rn = ctx.saved_tensors
-        df = df.contiguous()
-        rows, C = z.shape
-        dy = torch.empty_like(z)
-        L.check(L.lib().epc_rownorm_bwd(df.data_ptr(), f.data_ptr(), rn.data_ptr(), rows, C, dy.data_ptr(), _st()))
-        dz = torch.empty_like(z)
-        dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
-        ws, n = _ws(rows, C, z.device)
-        L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
-                                         beta.data_ptr(), ctx.eps, 1, rows, C, dz.data_ptr(), dgamma.data_ptr(),
-                                         dbeta.data_ptr(), ws.data_ptr(), n, _st()))
+        z, mean, var, gamma, beta, rn = ctx.saved_tensors
+        dz, dgamma, dbeta = _bn_relu_rownorm_bwd(df.contiguous(), z, rn, mean, var, gamma, beta, ctx.eps)
         return dz, dgamma, dbeta, None
+
+
+def _bn_relu_rownorm_bwd(df, z, rn, mean, var, gamma, beta, eps):
+    """Backward of f = l2_normalize(relu(bn_train(z))) (epc_bn_relu_rownorm_bwd): (dz, dgamma, dbeta)."""
+    rows, C = z.shape
+    dz = torch.empty_like(z)
+    sums = torch.empty((2, C), dtype=torch.float32, device=z.device)
+    rowdot = torch.empty(rows, dtype=torch.float32, device=z.device)
+    pf = L.lib().epc_bn_relu_rownorm_bwd_partial_floats(rows)
+    part = _splitk_ws(pf, z.device)
+    L.check(L.lib().epc_bn_relu_rownorm_bwd(df.data_ptr(), z.data_ptr(), rn.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), float(eps), rows, C, dz.data_ptr(),
+                                            sums.data_ptr(), rowdot.data_ptr(), part.data_ptr(), part.numel(), _st()))
+    return dz, sums[1], sums[0]
 
 
 def bn_inference(z, mean, var, gamma, beta, eps=BN_EPS, relu=False):

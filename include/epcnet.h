@@ -364,6 +364,13 @@ int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const f
  * on (df, f, rn), then epc_bn_apply_bwd with relu = 1 (it recomputes the mask from z). */
 int epc_bn_relu_rownorm_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                             float eps, int rows, int C, float* f, float* rn, void* stream);
+/* Its backward in two passes over (df, z) (f is recomputed from z, rn; the row-norm's input gradient is never written):
+ * dz (rows, C); dbeta_dgamma (2, C): row 0 = dbeta, row 1 = dgamma; rowdot: rows floats of scratch (sum_c df f per row);
+ * partials: caller-owned scratch of epc_bn_relu_rownorm_bwd_partial_floats(rows).  Sums added in a fixed order. */
+size_t epc_bn_relu_rownorm_bwd_partial_floats(int rows);
+int epc_bn_relu_rownorm_bwd(const float* df, const float* z, const float* rn, const float* mean, const float* var,
+                            const float* gamma, const float* beta, float eps, int rows, int C, float* dz, float* dbeta_dgamma,
+                            float* rowdot, float* partials, size_t partial_floats, void* stream);
 
 /* VLAD normalisations in one launch (loupe.py:284,292-298): v = raw - a_sum (x) w2; intra-normalisation over the F axis
  * per (cloud, cluster); L2 normalisation of the flattened (F*C) vector per cloud.  raw, out: (num_clouds, F, C) with

@@ -174,6 +174,55 @@ def test_rownorm_and_softmax(dev):
     run_pair(lambda a: ops.Softmax64.apply(a), lambda a: torch.softmax(a, 1), [a], dev)
 
 
+@pytest.mark.parametrize("rows", [2048, 1000, 77])
+def test_conv5_tail_node(dev, rows):
+    """f = l2_normalize(relu(batch_norm_train(z))) over 1024 channels (models/epc-net.py:136-148) as ops.BatchNormReluRowNorm and
+    as the tail of ops.LinearBatchNormTrain(rownorm=True): output, moments and the gradients (the fused two-pass backward
+    epc_bn_relu_rownorm_bwd) against float64, a row whose channels are all switched off included; bit-equal across two runs."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(rows)
+    z = torch.randn(rows, 1024, dtype=torch.float64, generator=g) * 2 + torch.randn(1024, dtype=torch.float64, generator=g)
+    z[3] = -50.0                                    # relu(bn(z)) == 0 on the whole row: the l2_normalize clamp
+    gamma = torch.rand(1024, dtype=torch.float64, generator=g) + 0.5
+    beta = torch.randn(1024, dtype=torch.float64, generator=g) * 0.3
+    up = torch.randn(rows, 1024, dtype=torch.float64, generator=g)
+
+    def tail(z, gamma, beta):
+        mean, var = z.mean(0), z.var(0, unbiased=False)
+        u = torch.relu(gamma * (z - mean) / torch.sqrt(var + 1e-3) + beta)
+        return u * torch.rsqrt(torch.clamp((u * u).sum(1, keepdim=True), min=1e-12)), mean, var
+
+    r_in = [t.clone().requires_grad_(True) for t in (z, gamma, beta)]
+    fr, mr, vr = tail(*r_in)
+    assert float(fr[3].abs().max()) == 0.0
+    (fr * up).sum().backward()
+    runs = []
+    for _ in range(2):
+        g_in = [t.float().to(dev).requires_grad_(True) for t in (z, gamma, beta)]
+        f, mean, var = ops.BatchNormReluRowNorm.apply(g_in[0], g_in[1], g_in[2], 1e-3)
+        (f * up.float().to(dev)).sum().backward()
+        assert rel(f, fr) <= 2e-5 and rel(mean, mr) <= 2e-5 and rel(var, vr) <= 2e-5
+        for name, a, r in zip(("z", "gamma", "beta"), g_in, r_in):
+            assert rel(a.grad, r.grad) <= 1e-4, "grad of %s: %.3e" % (name, rel(a.grad, r.grad))
+        runs.append([t.grad for t in g_in])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    # the same tail behind the 256 -> 1024 product (conv5): gradients of x, W, gamma, beta
+    x = torch.randn(rows, 256, dtype=torch.float64, generator=g)
+    W = torch.randn(256, 1024, dtype=torch.float64, generator=g) / 16
+    b = torch.randn(1024, dtype=torch.float64, generator=g)
+    r_in = [t.clone().requires_grad_(True) for t in (x, W, gamma, beta)]
+    fr, mr, vr = tail(r_in[0] @ r_in[1] + b, r_in[2], r_in[3])
+    (fr * up).sum().backward()
+    g_in = [t.float().to(dev).requires_grad_(True) for t in (x, W, gamma, beta)]
+    if ops.fused_linear_bn_ok(rows, 256, 1024):
+        f, mean, var = ops.LinearBatchNormTrain.apply(g_in[0], g_in[1], b.float().to(dev), g_in[2], g_in[3], 1e-3, 1, True)
+        (f * up.float().to(dev)).sum().backward()
+        assert rel(f, fr) <= 2e-5 and rel(mean, mr) <= 2e-5 and rel(var, vr) <= 2e-5
+        for name, a, r in zip(("x", "W", "gamma", "beta"), g_in, r_in):
+            assert rel(a.grad, r.grad) <= 2e-4, "grad of %s: %.3e" % (name, rel(a.grad, r.grad))
+
+
 def test_context_gating_product(dev):
     """loupe.py:99-100: y * sigmoid(g) and both gradients, including saturated gates."""
     ops = H.pkg("ops")
