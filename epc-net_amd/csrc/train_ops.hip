@@ -577,68 +577,79 @@ extern "C" int epc_gemm_splitk_det(const float* A, const float* B, float* C, con
 // ---- y = x W + b together with the batch statistics a training-mode BatchNorm on y needs -------------------------------
 // The GEMM's epilogue leaves, per row tile of `tile_rows` rows (the last one shorter) and column, (S1, S2, p): the sums of
 // (v - p) and (v - p)^2 with p the tile's first-row value.  A tile's own moments are mean_t = p + S1 / n_t and
-// M2_t = S2 - S1^2 / n_t; tiles are merged pairwise (Chan et al.): mean += d n_t / (n + n_t), M2 += M2_t + d^2 n n_t / (n + n_t),
-// d = mean_t - mean -- all in double precision, in a fixed order (population variance = M2 / rows, tf.nn.moments).
-struct Moments {
-    double n, mean, m2;
-};
-__device__ __forceinline__ void moments_merge(Moments& a, double nt, double mean_t, double m2_t) {
-    if (nt <= 0.0) return;
-    const double tot = a.n + nt, d = mean_t - a.mean;
-    a.mean += d * (nt / tot);
-    a.m2 += m2_t + d * d * (a.n * nt / tot);
-    a.n = tot;
-}
-__device__ __forceinline__ void moments_add_tile(Moments& a, float S1, float S2, float p, double nt) {
-    if (nt <= 0.0) return;
-    const double s1 = (double)S1, s2 = (double)S2;
-    moments_merge(a, nt, (double)p + s1 / nt, fmax(s2 - s1 * s1 / nt, 0.0));
-}
-
-__global__ __launch_bounds__(256) void moments_finalize_kernel(const float* __restrict__ stats, int tiles, int N, int rows,
-                                                               int tile_rows, const float* __restrict__ bias,
-                                                               float* __restrict__ mean, float* __restrict__ var) {
-    // 64 columns per workgroup; thread (column, part) merges tiles part, part + 4, ... (8 independent loads in flight), the four
-    // parts meet in LDS in a fixed order: deterministic, and the serial chain is tiles / 4 long instead of tiles
-    __shared__ Moments pm[4][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    Moments acc{0.0, 0.0, 0.0};
-    auto n_of = [&](int t) { return (double)min(tile_rows, rows - t * tile_rows); };
-    if (c < N) {
-        int t = part;
-        for (; t + 28 < tiles; t += 32) {
-            float a[8], b[8], p[8];
+// M2_t = S2 - S1^2 / n_t; the tiles are pooled in double precision in a fixed order (population variance = M2 / rows,
+// tf.nn.moments).
+template <int COLS, int PARTS>
+__global__ __launch_bounds__(COLS * PARTS) void moments_finalize_kernel(const float* __restrict__ stats, int tiles, int N, int rows,
+                                                                        int tile_rows, const float* __restrict__ bias,
+                                                                        float* __restrict__ mean, float* __restrict__ var) {
+    // COLS columns per workgroup; thread (column, part) takes tiles part, part + PARTS, ...; the parts meet in LDS in a fixed order:
+    // deterministic.  Pooled moments in double precision, two sweeps over the tiles' (sum, sum of squares, pivot):
+    //   mean = sum_t (n_t p_t + S1_t) / rows;   M2 = sum_t [ (S2_t - S1_t^2 / n_t) + n_t (p_t + S1_t / n_t - mean)^2 ]
+    // -- no division per tile (1 / n_t is one constant for every full tile).  Few columns per workgroup ON PURPOSE: the partials
+    // were written by other XCDs, every first touch misses L2, and ONE CU draws ~10 B per clock from beyond it -- a thin layer's
+    // 221 KB of partials through one 64-column workgroup took 12 us (rocprofv3) whatever its arithmetic; eight workgroups of
+    // 8 columns take a quarter of that.
+    __shared__ double sm[PARTS][COLS];
+    const int cl = threadIdx.x % COLS, part = threadIdx.x / COLS;
+    const int c = blockIdx.x * COLS + cl;
+    const bool on = c < N;
+    const double inv_full = 1.0 / (double)tile_rows;
+    auto n_of = [&](int t) { return min(tile_rows, rows - t * tile_rows); };
+    // a sweep visits the thread's tiles MF_CHUNK at a time with ALL of a chunk's loads in flight at once
+    constexpr int MF_CHUNK = 5;
+    auto sweep = [&](auto&& f) {
+        for (int t0 = part; t0 < tiles; t0 += MF_CHUNK * PARTS) {
+            float v1[MF_CHUNK], v2[MF_CHUNK], vp[MF_CHUNK];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = stats[((size_t)(t + 4 * u) * 3 + 0) * N + c];
-                b[u] = stats[((size_t)(t + 4 * u) * 3 + 1) * N + c];
-                p[u] = stats[((size_t)(t + 4 * u) * 3 + 2) * N + c];
+            for (int u = 0; u < MF_CHUNK; ++u) {
+                const int t = min(t0 + u * PARTS, tiles - 1);
+                v1[u] = stats[((size_t)t * 3 + 0) * N + c], v2[u] = stats[((size_t)t * 3 + 1) * N + c];
+                vp[u] = stats[((size_t)t * 3 + 2) * N + c];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) moments_add_tile(acc, a[u], b[u], p[u], n_of(t + 4 * u));
+            for (int u = 0; u < MF_CHUNK; ++u) {
+                const int t = t0 + u * PARTS;
+                if (t < tiles && n_of(t) > 0) f(n_of(t), (double)v1[u], (double)v2[u], (double)vp[u]);
+            }
         }
-        for (; t < tiles; t += 4)
-            moments_add_tile(acc, stats[((size_t)t * 3 + 0) * N + c], stats[((size_t)t * 3 + 1) * N + c],
-                             stats[((size_t)t * 3 + 2) * N + c], n_of(t));
-    }
-    pm[part][cl] = acc;
+    };
+    double a = 0.0;
+    if (on) sweep([&](int nt, double s1, double, double pv) { a += (double)nt * pv + s1; });
+    sm[part][cl] = a;
     __syncthreads();
-    if (part == 0 && c < N) {
-        Moments m = pm[0][cl];
-        moments_merge(m, pm[1][cl].n, pm[1][cl].mean, pm[1][cl].m2);
-        moments_merge(m, pm[2][cl].n, pm[2][cl].mean, pm[2][cl].m2);
-        moments_merge(m, pm[3][cl].n, pm[3][cl].mean, pm[3][cl].m2);
-        mean[c] = (float)(m.mean + (bias ? (double)bias[c] : 0.0));
-        var[c] = (float)fmax(m.m2 / rows, 0.0);
+    double tot = 0.0;
+    for (int q = 0; q < PARTS; ++q) tot += sm[q][cl];
+    const double mu = tot / (double)rows;
+    __syncthreads();
+    double b = 0.0;
+    if (on)
+        sweep([&](int nt, double s1, double s2, double pv) {
+            const double inv = nt == tile_rows ? inv_full : 1.0 / (double)nt;
+            const double d = pv + s1 * inv - mu;
+            b += fmax(s2 - s1 * s1 * inv, 0.0) + (double)nt * d * d;
+        });
+    sm[part][cl] = b;
+    __syncthreads();
+    if (part == 0 && on) {
+        double m2 = 0.0;
+        for (int q = 0; q < PARTS; ++q) m2 += sm[q][cl];
+        mean[c] = (float)(mu + (bias ? (double)bias[c] : 0.0));
+        var[c] = (float)fmax(m2 / (double)rows, 0.0);
     }
+}
+#define MF_COLS 8
+#define MF_PARTS 64
+static void launch_moments_finalize(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
+                                    float* var, hipStream_t st) {
+    hipLaunchKernelGGL((moments_finalize_kernel<MF_COLS, MF_PARTS>), dim3((N + MF_COLS - 1) / MF_COLS), dim3(MF_COLS * MF_PARTS), 0,
+                       st, stats, tiles, N, rows, tile_rows, bias, mean, var);
 }
 
 extern "C" int epc_gemm_stats_tiles(int M) { return M >= 128 ? (M + 127) / 128 : (M + 63) / 64; }
 
 __global__ void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                      int rows, float* __restrict__ z, float* __restrict__ stats, unsigned int* __restrict__ counter,
-                                      float* __restrict__ mean, float* __restrict__ var);   // (below)
+                                      int rows, float* __restrict__ z, float* __restrict__ stats);   // (below)
 
 extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
@@ -653,10 +664,9 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
         ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(C)) & 15) == 0) {
         // the thin layers: one pass, one partial per 256 rows (fewer than the tiles the caller sized `stats` for)
         const int wgs = (M + 255) / 256;
-        hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, B, bias, M, C, stats, (unsigned int*)nullptr,
-                           (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, B, bias, M, C, stats);
         EPC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(256), 0, st, stats, wgs, 64, M, 256 /* LS_ROWS_PER_WG */, bias, mean, var);
+        launch_moments_finalize(stats, wgs, 64, M, 256 /* LS_ROWS_PER_WG */, bias, mean, var, st);
         EPC_CHECK_LAUNCH();
         return EPC_OK;
     }
@@ -668,8 +678,7 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     else if (bign) launch_gemm_split<1, 2>(g, 1, 3, st);
     else launch_gemm_split<1, 1>(g, 1, 3, st);
     EPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3((N + 63) / 64), dim3(256), 0, st, stats, tiles, N, M, M >= 128 ? 128 : 64, bias,
-                       mean, var);
+    launch_moments_finalize(stats, tiles, N, M, M >= 128 ? 128 : 64, bias, mean, var, st);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -684,14 +693,12 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
 #define LS_ROWS_PER_WG (4 * 32 * LS_TILES_PER_WAVE)
 static_assert(LS_ROWS_PER_WG == 256, "epc_gemm_f32_stats passes 256 to moments_finalize_kernel");
 
-// `counter` (optional): a zero word of the caller's column-reduction workspace.  With it the workgroup that finishes LAST adds
-// the partials (ascending order, double precision: moments_finalize_kernel's arithmetic) and writes mean / var itself -- no
-// finalize launch; it leaves the word zero.  Partials cross workgroups through agent-scope stores / loads (colreduce_kernel).
+// One partial (sum, sum of squares, pivot) per workgroup; moments_finalize_kernel merges them.  (Until round 3 the workgroup that
+// finished LAST merged them itself, behind a counter and agent-scope loads: one launch less, but that tail -- an atomic round
+// trip, then 72 dependent uncached loads per thread -- took 15 of the kernel's 31 us; the separate 1024-thread finish takes 4.)
 __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                              const float* __restrict__ bias, int rows,
-                                                             float* __restrict__ z, float* __restrict__ stats,
-                                                             unsigned int* __restrict__ counter, float* __restrict__ mean,
-                                                             float* __restrict__ var) {
+                                                             float* __restrict__ z, float* __restrict__ stats) {
     __shared__ u32x4 Wf[2][4][3][64];                                  // [out tile][k-step][piece][lane]: 24 KB
     __shared__ __attribute__((aligned(16))) float sred[3][3][64];      // waves 1..3: [wave][sum, sum of squares, pivot][column]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -797,59 +804,21 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
                 t1 += sred[w - 1][0][c] + nw * dp;
                 t2 += sred[w - 1][1][c] + (2.0f * dp) * sred[w - 1][0][c] + nw * dp * dp;
             }
-            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 0) * 64 + c], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 1) * 64 + c], t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&stats[((size_t)blockIdx.x * 3 + 2) * 64 + c], piv[nt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stats[((size_t)blockIdx.x * 3 + 0) * 64 + c] = t1;
+            stats[((size_t)blockIdx.x * 3 + 1) * 64 + c] = t2;
+            stats[((size_t)blockIdx.x * 3 + 2) * 64 + c] = piv[nt];
         }
-    }
-    if (!counter) return;
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    {
-        // the workgroup that arrives last merges the partials (ascending order within a part, parts in order: double precision,
-        // moments_finalize_kernel's arithmetic)
-        const int c = tid & 63, part = tid >> 6, nb = gridDim.x;
-        Moments acc{0.0, 0.0, 0.0};
-        auto n_of = [&](int b_) { return (double)min(LS_ROWS_PER_WG, rows - b_ * LS_ROWS_PER_WG); };
-        auto ld = [&](int b_, int k_) {
-            return __hip_atomic_load(&stats[((size_t)b_ * 3 + k_) * 64 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        int b_ = part;
-        for (; b_ + 28 < nb; b_ += 32) {
-            float u1[8], u2[8], u3[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) u1[u] = ld(b_ + 4 * u, 0), u2[u] = ld(b_ + 4 * u, 1), u3[u] = ld(b_ + 4 * u, 2);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) moments_add_tile(acc, u1[u], u2[u], u3[u], n_of(b_ + 4 * u));
-        }
-        for (; b_ < nb; b_ += 4) moments_add_tile(acc, ld(b_, 0), ld(b_, 1), ld(b_, 2), n_of(b_));
-        __shared__ Moments fin[4][64];
-        fin[part][c] = acc;
-        __syncthreads();
-        if (part == 0) {
-            Moments m = fin[0][c];
-            moments_merge(m, fin[1][c].n, fin[1][c].mean, fin[1][c].m2);
-            moments_merge(m, fin[2][c].n, fin[2][c].mean, fin[2][c].m2);
-            moments_merge(m, fin[3][c].n, fin[3][c].mean, fin[3][c].m2);
-            mean[c] = (float)(m.mean + (bias ? (double)bias[c] : 0.0));
-            var[c] = (float)fmax(m.m2 / rows, 0.0);
-        }
-        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// Column reductions over the rows of (rows, C) tensors, ONE launch each: every workgroup reduces a 256-row x 64-column
-// panel (float4 per lane, 16 row groups) to a partial, and the workgroup that finishes a column panel LAST (a counter
-// per panel, release/acquire fences around it) adds the partials in a fixed order and writes the result -- no separate
-// finalize launch, still deterministic.  The counters live at the head of the caller's workspace: they must be zero on
-// entry and are left zero on exit (a workspace is zeroed once and then reused; one workspace per stream).
+// Column reductions over the rows of (rows, C) tensors: every workgroup reduces a 256-row x 64-column panel (float4 per lane,
+// 16 row groups) to a partial; colreduce_finish_kernel (16 columns per workgroup: 64 groups take every 64th partial each
+// and meet in LDS in group order) adds the partials in a fixed order and writes the result -- deterministic.  (Until round 3
+// the workgroup that finished a column panel LAST did this itself behind a counter: one launch less, but its tail -- an
+// atomic round trip and five rounds of dependent uncached loads -- was half of the kernel's 20 us on the 64-channel layers.)
+// The workspace keeps its layout (CR_COUNTERS unused words, then the partials); nothing in it needs to be zero any more.
 //   kind 0: sum_r x                         -> out0 = scale * sum                      (bias gradients)
 //   kind 1: sum_r (x - x0), sum_r (x - x0)^2 with x0 = row 0 of the column (one pass; the shift keeps the second
 //           moment free of cancellation)   -> out0 = mean, out1 = POPULATION variance (tf.nn.moments)
@@ -878,12 +847,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ var,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, int relu, int rows, int C, float scale,
-                                                        float* __restrict__ partial, unsigned int* __restrict__ counters,
-                                                        float* __restrict__ out0, float* __restrict__ out1) {
+                                                        float* __restrict__ partial) {
     constexpr int NQ = KIND == 0 ? 1 : 2;
     __shared__ float red[NQ][16][64];
     __shared__ __attribute__((aligned(16))) float coef[4][64];   // kind 2: s, t (ReLU mask), mean, rstd per column
-    __shared__ int s_last;
     const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
     // grid = (column panels, row panels): the column panels of one row panel are neighbours in dispatch order, so a 4-KB row
     // of a 1024-wide tensor is read by workgroups that run together (row panels fastest left every row to be visited by 16
@@ -948,79 +915,58 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
         if (NQ == 2) red[1][rg][4 * l16 + q] = s1[q];
     }
     __syncthreads();
-    // Partials cross workgroups (and XCDs, each with its own L2) through agent-scope stores and loads: they go to the
-    // memory side directly, so no L2 write-back / invalidate fence is needed (a __threadfence() here costs a whole-L2
-    // write-back per workgroup: the step was 3 ms slower with it) -- only that a workgroup's stores have been
-    // acknowledged (vmcnt(0)) before it bumps the panel's counter.
     if (tid < 64 * NQ) {
         const int q = tid >> 6, l = tid & 63;
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[q][g][l];
-        if (by * 64 + l < C)
-            __hip_atomic_store(&partial[((size_t)q * nb + bx) * C + by * 64 + l], t, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+        if (by * 64 + l < C) partial[((size_t)q * nb + bx) * C + by * 64 + l] = t;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        s_last = __hip_atomic_fetch_add(&counters[by], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                 (unsigned)(nb - 1);
-    __syncthreads();
-    if (!s_last) return;
-    // the last workgroup of this column panel finishes the reduction: 16 groups x (16 lanes x 4 columns), every group
-    // walks its share of the row panels 4 independent loads at a time, fixed order -> deterministic
+}
+
+// 16 columns per workgroup (4 float4 columns x 64 groups): the partials come from other XCDs (L2 misses), and several small
+// workgroups on several CUs draw them faster than one large one (moments_finalize_kernel).
+#define CF_COLS 16
+template <int KIND>
+__global__ __launch_bounds__(256) void colreduce_finish_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                                                               int nb, int C, float scale, float* __restrict__ out0,
+                                                               float* __restrict__ out1) {
+    constexpr int NQ = KIND == 0 ? 1 : 2;
+    __shared__ float red[NQ][64][CF_COLS];
+    const int tid = threadIdx.x, l4 = tid & 3, rg = tid >> 2;
+    const int c = blockIdx.x * CF_COLS + 4 * l4;
     float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const float* p0 = partial + c;
         const float* p1 = partial + (size_t)nb * C + c;
-        auto ld = [](const float* p, float (&o)[4]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        int bidx = rg;
-        for (; bidx + 48 < nb; bidx += 64) {
-            float u0[4][4], u1[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ld(p0 + (size_t)(bidx + 16 * u) * C, u0[u]);
-                if (NQ == 2) ld(p1 + (size_t)(bidx + 16 * u) * C, u1[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    t0[q] += u0[u][q];
-                    if (NQ == 2) t1[q] += u1[u][q];
-                }
-        }
-        for (; bidx < nb; bidx += 16) {
-            float u0[4], u1[4];
-            ld(p0 + (size_t)bidx * C, u0);
-            if (NQ == 2) ld(p1 + (size_t)bidx * C, u1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                t0[q] += u0[q];
-                if (NQ == 2) t1[q] += u1[q];
+#pragma unroll 5
+        for (int b = rg; b < nb; b += 64) {
+            const float4 u0 = *reinterpret_cast<const float4*>(p0 + (size_t)b * C);
+            t0[0] += u0.x, t0[1] += u0.y, t0[2] += u0.z, t0[3] += u0.w;
+            if (NQ == 2) {
+                const float4 u1 = *reinterpret_cast<const float4*>(p1 + (size_t)b * C);
+                t1[0] += u1.x, t1[1] += u1.y, t1[2] += u1.z, t1[3] += u1.w;
             }
         }
     }
-    __syncthreads();   // red[] is reused
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        red[0][rg][4 * l16 + q] = t0[q];
-        if (NQ == 2) red[1][rg][4 * l16 + q] = t1[q];
+        red[0][rg][4 * l4 + q] = t0[q];
+        if (NQ == 2) red[NQ - 1][rg][4 * l4 + q] = t1[q];
     }
     __syncthreads();
-    const int l = tid & 63;
-    const int cc = by * 64 + l;
-    if (tid < 64 && cc < C) {
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            a0 += red[0][g][l];
-            if (NQ == 2) a1 += red[1][g][l];
-        }
+    const int l = tid % CF_COLS, qn = tid / CF_COLS;
+    const int cc = blockIdx.x * CF_COLS + l;
+    float a = 0.f;
+    if (qn < NQ && cc < C) {
+#pragma unroll 16
+        for (int g = 0; g < 64; ++g) a += red[qn][g][l];
+    }
+    __syncthreads();
+    if (qn < NQ && cc < C) red[qn][0][l] = a;
+    __syncthreads();
+    if (tid < CF_COLS && cc < C) {
+        const float a0 = red[0][0][l], a1 = NQ == 2 ? red[NQ - 1][0][l] : 0.f;
         if (KIND == 0) {
             out0[cc] = a0 * scale;
         } else if (KIND == 1) {
@@ -1032,7 +978,6 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
             out1[cc] = a1;
         }
     }
-    if (tid == 0) counters[by] = 0u;   // ready for the next launch on this workspace
 }
 
 extern "C" size_t epc_colreduce_workspace_bytes(int rows, int C) {
@@ -1050,8 +995,8 @@ static int colreduce_check(const char* who, int rows, int C, const void* workspa
     return EPC_OK;
 }
 
-// y = x W + b for a 64 -> 64 layer TOGETHER with the batch moments of y, one launch (linear_stats64_kernel with its in-kernel
-// finish).  `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64); zero counters, left zero).
+// y = x W + b for a 64 -> 64 layer TOGETHER with the batch moments of y (linear_stats64_kernel + the finish).
+// `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64)).
 extern "C" int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,
                                   void* workspace, size_t workspace_bytes, void* stream) {
     EPC_CHECK_ARG(x && W && z && mean && var, "null pointer");
@@ -1060,8 +1005,8 @@ extern "C" int epc_linear_stats64(const float* x, const float* W, const float* b
     unsigned int* counters = (unsigned int*)workspace;
     float* part = (float*)(counters + CR_COUNTERS);
     const int wgs = (rows + LS_ROWS_PER_WG - 1) / LS_ROWS_PER_WG;   // <= the 256-row panels the workspace is sized for
-    hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, W, bias, rows, z, part, counters,
-                       mean, var);
+    hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, W, bias, rows, z, part);
+    launch_moments_finalize(part, wgs, 64, rows, LS_ROWS_PER_WG, bias, mean, var, (hipStream_t)stream);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1075,7 +1020,9 @@ extern "C" int epc_col_moments(const float* x, int rows, int C, float* mean, flo
     unsigned int* counters = (unsigned int*)workspace;
     float* part = (float*)(counters + CR_COUNTERS);
     hipLaunchKernelGGL(colreduce_kernel<1>, dim3((C + 63) / 64, nb), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f / rows, part, counters, mean, var);
+                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f / rows, part);
+    hipLaunchKernelGGL(colreduce_finish_kernel<1>, dim3((C + CF_COLS - 1) / CF_COLS), dim3(256), 0, (hipStream_t)stream, part, x, nb, C,
+                       1.0f / rows, mean, var);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1089,7 +1036,9 @@ extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* wo
     unsigned int* counters = (unsigned int*)workspace;
     float* part = (float*)(counters + CR_COUNTERS);
     hipLaunchKernelGGL(colreduce_kernel<0>, dim3((C + 63) / 64, nb), dim3(256), 0, (hipStream_t)stream, x, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f, part, counters, out, nullptr);
+                       nullptr, nullptr, nullptr, 0.f, 0, rows, C, 1.0f, part);
+    hipLaunchKernelGGL(colreduce_finish_kernel<0>, dim3((C + CF_COLS - 1) / CF_COLS), dim3(256), 0, (hipStream_t)stream, part, x, nb, C, 1.0f,
+                       out, (float*)nullptr);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1456,7 +1405,8 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* me
     float* part = (float*)(counters + CR_COUNTERS);
     const dim3 grid(nb, (C + 63) / 64);
     hipLaunchKernelGGL(colreduce_kernel<2>, dim3(grid.y, grid.x), dim3(256), 0, st, z, dy, mean, var, gamma, beta, eps, relu, rows, C, 1.0f,
-                       part, counters, dbeta, dgamma);
+                       part);
+    hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3((C + CF_COLS - 1) / CF_COLS), dim3(256), 0, st, part, z, nb, C, 1.0f, dbeta, dgamma);
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid.y, grid.x), dim3(256), 0, st, dy, z, mean, var, gamma, beta, dbeta, dgamma, eps,
                        1.0f / rows, relu, rows, C, dz);
     EPC_CHECK_LAUNCH();
@@ -1698,7 +1648,8 @@ extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float*
     unsigned int* counters = (unsigned int*)workspace;
     float* part = (float*)(counters + CR_COUNTERS);
     hipLaunchKernelGGL(colreduce_kernel<2>, dim3(1, nb), dim3(256), 0, st, z, dy, mean, var, gamma, beta, eps, relu, rows, 64, 1.0f,
-                       part, counters, dbeta, dgamma);
+                       part);
+    hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3(64 / CF_COLS), dim3(256), 0, st, part, z, nb, 64, 1.0f, dbeta, dgamma);
     const int wgs = (rows + LB_ROWS_PER_WG - 1) / LB_ROWS_PER_WG;
     hipLaunchKernelGGL(linear_bn_bwd64_kernel, dim3(wgs), dim3(256), 0, st, dy, z, x, W, mean, var, gamma, beta, dbeta, dgamma, eps,
                        1.0f / rows, relu, rows, dx, dw_partials);
