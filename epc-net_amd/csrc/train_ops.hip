@@ -648,8 +648,24 @@ static void launch_moments_finalize(const float* stats, int tiles, int N, int ro
 
 extern "C" int epc_gemm_stats_tiles(int M) { return M >= 128 ? (M + 127) / 128 : (M + 63) / 64; }
 
-__global__ void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                      int rows, float* __restrict__ z, float* __restrict__ stats);   // (below)
+struct BnAffine {  // y = z * s + t, the expression the forward and the backward mask must share bit for bit
+    float s, t;
+};
+__device__ __forceinline__ BnAffine bn_affine(float mean, float var, float gamma, float beta, float eps) {
+    BnAffine a;
+    a.s = (1.0f / sqrtf(var + eps)) * gamma;
+    a.t = beta - mean * a.s;
+    return a;
+}
+__device__ __forceinline__ float bn_value(float z, const BnAffine& a) { return z * a.s + a.t; }
+
+struct BnParams {   // a training-mode BatchNorm (+ReLU) applied to an operand AS IT IS LOADED: null mean = none
+    const float *mean, *var, *gamma, *beta;
+    float eps;
+};
+__global__ void linear_stats64_kernel(const float* __restrict__ x, BnParams xbn, const float* __restrict__ W,
+                                      const float* __restrict__ bias, int rows, float* __restrict__ z,
+                                      float* __restrict__ stats);   // (below)
 
 extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
@@ -664,7 +680,8 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
         ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(C)) & 15) == 0) {
         // the thin layers: one pass, one partial per 256 rows (fewer than the tiles the caller sized `stats` for)
         const int wgs = (M + 255) / 256;
-        hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, B, bias, M, C, stats);
+        hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, st, A, BnParams{nullptr, nullptr, nullptr, nullptr, 0.f}, B,
+                           bias, M, C, stats);
         EPC_CHECK_LAUNCH();
         launch_moments_finalize(stats, wgs, 64, M, 256 /* LS_ROWS_PER_WG */, bias, mean, var, st);
         EPC_CHECK_LAUNCH();
@@ -696,13 +713,21 @@ static_assert(LS_ROWS_PER_WG == 256, "epc_gemm_f32_stats passes 256 to moments_f
 // One partial (sum, sum of squares, pivot) per workgroup; moments_finalize_kernel merges them.  (Until round 3 the workgroup that
 // finished LAST merged them itself, behind a counter and agent-scope loads: one launch less, but that tail -- an atomic round
 // trip, then 72 dependent uncached loads per thread -- took 15 of the kernel's 31 us; the separate 1024-thread finish takes 4.)
-__global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                             const float* __restrict__ bias, int rows,
-                                                             float* __restrict__ z, float* __restrict__ stats) {
+// xbn: the layer's input is relu(bn(x)) of the PREVIOUS layer's pre-activation x, formed as the rows are loaded (conv_a -> conv_b
+// of a block, models/epc-net.py:77-85: the activation between them is never written).
+__global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __restrict__ x, BnParams xbn,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             int rows, float* __restrict__ z, float* __restrict__ stats) {
     __shared__ u32x4 Wf[2][4][3][64];                                  // [out tile][k-step][piece][lane]: 24 KB
     __shared__ __attribute__((aligned(16))) float sred[3][3][64];      // waves 1..3: [wave][sum, sum of squares, pivot][column]
+    __shared__ __attribute__((aligned(16))) float xcoef[2][64];        // xbn: s, t per input channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    const bool with_bn = xbn.mean != nullptr;
+    if (with_bn && tid < 64) {
+        const BnAffine a = bn_affine(xbn.mean[tid], xbn.var[tid], xbn.gamma[tid], xbn.beta[tid], xbn.eps);
+        xcoef[0][tid] = a.s, xcoef[1][tid] = a.t;
+    }
     // B[k = in][n = out] = W[k][n]: lane (n = 32 nt + i, k group h) of k-step s holds W[16 s + 8 h .. + 7][n]
     for (int f = tid; f < 2 * 4 * 64; f += 256) {
         const int l = f & 63, s4 = (f >> 6) & 3, nt = f >> 8;
@@ -743,8 +768,18 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             float4 u0 = xr[t][s4][0], u1 = xr[t][s4][1];
-            if (!ok) u0 = u1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            if (with_bn) {   // channels 16 s4 + 8 h .. + 7 of the row: the forward's own expression (bn_value), then the ReLU
+                const float4 c0 = *reinterpret_cast<const float4*>(&xcoef[0][16 * s4 + 8 * h]), c1 = *reinterpret_cast<const float4*>(&xcoef[0][16 * s4 + 8 * h + 4]);
+                const float4 t0 = *reinterpret_cast<const float4*>(&xcoef[1][16 * s4 + 8 * h]), t1 = *reinterpret_cast<const float4*>(&xcoef[1][16 * s4 + 8 * h + 4]);
+                const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ct[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q] * cs[q] + ct[q], 0.f);
+            }
+            if (!ok) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
             split8x3(v, a0[s4], a1[s4], a2[s4]);
         }
 #pragma unroll
@@ -831,16 +866,6 @@ __global__ __launch_bounds__(256) void linear_stats64_kernel(const float* __rest
 #endif
 #define CR_COUNTERS 64   // counter slots at the head of the workspace: C <= 4096
 
-struct BnAffine {  // y = z * s + t, the expression the forward and the backward mask must share bit for bit
-    float s, t;
-};
-__device__ __forceinline__ BnAffine bn_affine(float mean, float var, float gamma, float beta, float eps) {
-    BnAffine a;
-    a.s = (1.0f / sqrtf(var + eps)) * gamma;
-    a.t = beta - mean * a.s;
-    return a;
-}
-__device__ __forceinline__ float bn_value(float z, const BnAffine& a) { return z * a.s + a.t; }
 
 template <int KIND>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -997,15 +1022,34 @@ static int colreduce_check(const char* who, int rows, int C, const void* workspa
 
 // y = x W + b for a 64 -> 64 layer TOGETHER with the batch moments of y (linear_stats64_kernel + the finish).
 // `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64)).
+static int linear_stats64_impl(const float* x, BnParams xbn, const float* W, const float* bias, int rows, float* z, float* mean,
+                               float* var, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+    return linear_stats64_impl(x, BnParams{nullptr, nullptr, nullptr, nullptr, 0.f}, W, bias, rows, z, mean, var, workspace,
+                               workspace_bytes, stream);
+}
+
+// The same with the layer's input formed on the fly: x_in = relu(batch_norm(x_pre)) with the given batch moments and affine
+// parameters of the layer that produced x_pre (conv_a -> conv_b inside a block: the activation between them is never written).
+extern "C" int epc_linear_stats64_bn(const float* x_pre, const float* in_mean, const float* in_var, const float* in_gamma,
+                                     const float* in_beta, float eps, const float* W, const float* bias, int rows, float* z,
+                                     float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(in_mean && in_var && in_gamma && in_beta, "null pointer");
+    return linear_stats64_impl(x_pre, BnParams{in_mean, in_var, in_gamma, in_beta, eps}, W, bias, rows, z, mean, var, workspace,
+                               workspace_bytes, stream);
+}
+
+static int linear_stats64_impl(const float* x, BnParams xbn, const float* W, const float* bias, int rows, float* z, float* mean,
+                               float* var, void* workspace, size_t workspace_bytes, void* stream) {
     EPC_CHECK_ARG(x && W && z && mean && var, "null pointer");
     EPC_CHECK_ARG(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(z)) & 15) == 0, "x and z must be 16-byte aligned");
     if (int rc = colreduce_check("epc_linear_stats64: workspace too small", rows, 64, workspace, workspace_bytes)) return rc;
     unsigned int* counters = (unsigned int*)workspace;
     float* part = (float*)(counters + CR_COUNTERS);
     const int wgs = (rows + LS_ROWS_PER_WG - 1) / LS_ROWS_PER_WG;   // <= the 256-row panels the workspace is sized for
-    hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, W, bias, rows, z, part);
+    hipLaunchKernelGGL(linear_stats64_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, x, xbn, W, bias, rows, z, part);
     launch_moments_finalize(part, wgs, 64, rows, LS_ROWS_PER_WG, bias, mean, var, (hipStream_t)stream);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -1051,7 +1095,8 @@ extern "C" int epc_col_sum(const float* x, int rows, int C, float* out, void* wo
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ var, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int relu, int rows,
-                                                           int C, float* __restrict__ y) {
+                                                           int C, const float* __restrict__ addend, float* __restrict__ y) {
+    // addend (optional, (rows, C)): y = act(bn(z)) + addend -- the block's residual, out = t + x1 (models/epc-net.py:86)
     __shared__ __attribute__((aligned(16))) float coef[2][64];
     const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
     if (tid < 64 && blockIdx.x * 64 + tid < C) {
@@ -1077,6 +1122,10 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
             const float t = bn_value(in[q], af[q]);
             out[q] = relu ? fmaxf(t, 0.f) : t;
         }
+        if (addend) {
+            const float4 a = *reinterpret_cast<const float4*>(addend + o);
+            out[0] += a.x, out[1] += a.y, out[2] += a.z, out[3] += a.w;
+        }
         *reinterpret_cast<float4*>(y + o) = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
@@ -1086,7 +1135,18 @@ extern "C" int epc_bn_apply_fwd(const float* z, const float* mean, const float* 
     EPC_CHECK_ARG(z && mean && var && gamma && beta && y, "null pointer");
     EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "C must be a multiple of 4");
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((C + 63) / 64, (rows + CR_ROWS - 1) / CR_ROWS), dim3(256), 0,
-                       (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows, C, y);
+                       (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows, C, (const float*)nullptr, y);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_bn_apply_add_fwd(const float* z, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, int relu, int rows, int C, const float* addend, float* y,
+                                    void* stream) {
+    EPC_CHECK_ARG(z && mean && var && gamma && beta && addend && y, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "C must be a multiple of 4");
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((C + 63) / 64, (rows + CR_ROWS - 1) / CR_ROWS), dim3(256), 0,
+                       (hipStream_t)stream, z, mean, var, gamma, beta, eps, relu, rows, C, addend, y);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1436,8 +1496,13 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ W,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float eps,
-    float inv_rows, int relu, int rows, float* __restrict__ dx, float* __restrict__ dWpart) {
+    float inv_rows, int relu, int rows, float* __restrict__ dx, float* __restrict__ dWpart, BnParams xbn,
+    const float* __restrict__ dx_addend) {
+    // xbn: the layer's input was relu(bn(x)) of the previous layer's pre-activation x (epc_linear_stats64_bn): the dW operand is
+    // formed the same way as it is loaded.  dx_addend (rows, 64): dx leaves as W dz + addend (the gradient that reaches the same
+    // tensor by the block's residual path, so that the neighbour backward gathers ONE tensor).
     __shared__ __attribute__((aligned(16))) float coef[6][64];          // s, t (mask), mean, k1, dbeta/rows, rstd dgamma/rows
+    __shared__ float xcoef[2][64];
     __shared__ u32x4 Wf[2][4][2][64];                                    // W as A fragments: [in tile][k-step][hi, lo][lane]
     __shared__ __attribute__((aligned(16))) float red[2][4][16][64];     // parked dW partials: [slot][tile][register][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1447,6 +1512,10 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
         const BnAffine a = bn_affine(mu, var[tid], ga, beta[tid], eps);
         coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mu;
         coef[3][tid] = ga * rs, coef[4][tid] = dbeta[tid] * inv_rows, coef[5][tid] = rs * (dgamma[tid] * inv_rows);
+        if (xbn.mean) {
+            const BnAffine xa = bn_affine(xbn.mean[tid], xbn.var[tid], xbn.gamma[tid], xbn.beta[tid], xbn.eps);
+            xcoef[0][tid] = xa.s, xcoef[1][tid] = xa.t;
+        }
     }
     // W (in, out) row-major: A[m = in][k = out]; lane (m = 32 mt + i, k group h) of k-step s holds W[m][16 s + 8 h .. + 7]
     for (int f = tid; f < 2 * 4 * 64; f += 256) {
@@ -1512,9 +1581,14 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
                 }
                 if (ok) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(dx + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h) =
-                            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    for (int g = 0; g < 4; ++g) {
+                        float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                        if (dx_addend) {
+                            const float4 a = *reinterpret_cast<const float4*>(dx_addend + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h);
+                            v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+                        }
+                        *reinterpret_cast<float4*>(dx + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h) = v;
+                    }
                 }
             }
         }
@@ -1529,6 +1603,11 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = x[(size_t)min(base + 16 * s2 + 8 * h + q, rows - 1) * 64 + 32 * mt + i];
+                if (xbn.mean) {
+                    const float xs = xcoef[0][32 * mt + i], xt = xcoef[1][32 * mt + i];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q] * xs + xt, 0.f);
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = (base + 16 * s2 + 8 * h + q < rows) ? v[q] : 0.f;
                 split8(v, xh[mt][s2], xl[mt][s2]);
@@ -1636,11 +1715,12 @@ extern "C" size_t epc_linear_bn_bwd64_partial_floats(int rows) {
     return rows > 0 ? (size_t)((rows + LB_ROWS_PER_WG - 1) / LB_ROWS_PER_WG) * 4096 : 0;
 }
 
-extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float* x, const float* W, const float* mean,
-                                   const float* var, const float* gamma, const float* beta, float eps, int relu, int rows,
-                                   float* dx, float* dW, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                                   float* dw_partials, size_t dw_partial_floats, void* stream) {
+static int linear_bn_bwd64_impl(const float* dy, const float* z, const float* x, BnParams xbn, const float* W, const float* mean,
+                                const float* var, const float* gamma, const float* beta, float eps, int relu, int rows,
+                                float* dx, const float* dx_addend, float* dW, float* dgamma, float* dbeta, void* workspace,
+                                size_t workspace_bytes, float* dw_partials, size_t dw_partial_floats, void* stream) {
     EPC_CHECK_ARG(dy && z && x && W && mean && var && gamma && beta && dW && dgamma && dbeta && dw_partials, "null pointer");
+    EPC_CHECK_ARG(dx || !dx_addend, "dx_addend without dx");
     if (int rc = colreduce_check("epc_linear_bn_bwd64: workspace too small", rows, 64, workspace, workspace_bytes)) return rc;
     EPC_CHECK_ARG(dw_partial_floats >= epc_linear_bn_bwd64_partial_floats(rows), "dW partial buffer too small (epc_linear_bn_bwd64_partial_floats)");
     hipStream_t st = (hipStream_t)stream;
@@ -1652,10 +1732,34 @@ extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float*
     hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3(64 / CF_COLS), dim3(256), 0, st, part, z, nb, 64, 1.0f, dbeta, dgamma);
     const int wgs = (rows + LB_ROWS_PER_WG - 1) / LB_ROWS_PER_WG;
     hipLaunchKernelGGL(linear_bn_bwd64_kernel, dim3(wgs), dim3(256), 0, st, dy, z, x, W, mean, var, gamma, beta, dbeta, dgamma, eps,
-                       1.0f / rows, relu, rows, dx, dw_partials);
+                       1.0f / rows, relu, rows, dx, dw_partials, xbn, dx_addend);
     hipLaunchKernelGGL(partial_sum_kernel, dim3(4096 / 4 / 16), dim3(256), 0, st, dw_partials, wgs, 4096, dW);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
+}
+
+extern "C" int epc_linear_bn_bwd64(const float* dy, const float* z, const float* x, const float* W, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, float eps, int relu, int rows,
+                                   float* dx, float* dW, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                   float* dw_partials, size_t dw_partial_floats, void* stream) {
+    return linear_bn_bwd64_impl(dy, z, x, BnParams{nullptr, nullptr, nullptr, nullptr, 0.f}, W, mean, var, gamma, beta, eps, relu,
+                                rows, dx, nullptr, dW, dgamma, dbeta, workspace, workspace_bytes, dw_partials, dw_partial_floats,
+                                stream);
+}
+
+// The same for a layer inside a fused block: in_* (all four or none): the layer's input was relu(batch_norm(x)) of the previous
+// layer's pre-activation x (epc_linear_stats64_bn) and is re-formed as x is loaded; dx_addend (optional, (rows, 64)): dx leaves
+// as dz W^T + dx_addend.
+extern "C" int epc_linear_bn_bwd64_ex(const float* dy, const float* z, const float* x, const float* in_mean, const float* in_var,
+                                      const float* in_gamma, const float* in_beta, const float* W, const float* mean,
+                                      const float* var, const float* gamma, const float* beta, float eps, int relu, int rows,
+                                      float* dx, const float* dx_addend, float* dW, float* dgamma, float* dbeta, void* workspace,
+                                      size_t workspace_bytes, float* dw_partials, size_t dw_partial_floats, void* stream) {
+    const bool any = in_mean || in_var || in_gamma || in_beta, all = in_mean && in_var && in_gamma && in_beta;
+    EPC_CHECK_ARG(any == all, "in_mean, in_var, in_gamma, in_beta: all four or none");
+    return linear_bn_bwd64_impl(dy, z, x, BnParams{in_mean, in_var, in_gamma, in_beta, eps}, W, mean, var, gamma, beta, eps, relu,
+                                rows, dx, dx_addend, dW, dgamma, dbeta, workspace, workspace_bytes, dw_partials, dw_partial_floats,
+                                stream);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1991,6 +2095,7 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
                                                                    const int32_t* __restrict__ roff,
                                                                    const int32_t* __restrict__ rlist, int total_points,
                                                                    float kdiv, const float* __restrict__ ddiff,
+                                                                   const float* __restrict__ own_minus,
                                                                    float* __restrict__ dx) {
     // ddiff (optional): the gradient of diff = xm - x of the fused forward.  Then the rows gathered are dxm + ddiff and
     // the point's own -ddiff is added:  dx[j] = (sum_i (dxm[i] + ddiff[i])) / k - ddiff[j]
@@ -2033,6 +2138,10 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
     }
     float4 own = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ddiff) own = d4[(size_t)j * 16 + q];
+    if (own_minus) {   // the gathered tensor is the SUM dxm + ddiff: the point's own ddiff = sum - dxm
+        const float4 a = s4[(size_t)j * 16 + q], b = reinterpret_cast<const float4*>(own_minus)[(size_t)j * 16 + q];
+        own = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
     reinterpret_cast<float4*>(dx)[(size_t)j * 16 + q] =
         make_float4(acc.x / kdiv - own.x, acc.y / kdiv - own.y, acc.z / kdiv - own.z, acc.w / kdiv - own.w);
 }
@@ -2070,7 +2179,7 @@ extern "C" int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz,
     const unsigned blocks = (unsigned)((total + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
-                       (float)knn, (const float*)nullptr, dx);
+                       (float)knn, (const float*)nullptr, (const float*)nullptr, dx);
     hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
                        (int)total, n, (float)knn, (const float*)nullptr, dx);
     EPC_CHECK_LAUNCH();
@@ -2088,9 +2197,28 @@ extern "C" int epc_neighbour_mean_diff_bwd_gather(const float* dxm, const float*
     const unsigned blocks = (unsigned)((total + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, dxm, rdeg, roff, rlist, (int)total,
-                       (float)knn, ddiff, dx);
+                       (float)knn, ddiff, (const float*)nullptr, dx);
     hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, dxm, xyz, cnt, kth, cap,
                        (int)total, n, (float)knn, ddiff, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// The same from the SUM s = dxm + ddiff (written by epc_linear_bn_bwd64_ex with dx_addend = dxm): half the gathered bytes;
+// dx = mask^T s / k - (s - dxm).
+extern "C" int epc_neighbour_mean_diff_bwd_gather_sum(const float* s, const float* dxm, const float* xyz, const int32_t* cnt,
+                                                      const float* kth, int cap, const int32_t* rdeg, const int32_t* roff,
+                                                      const int32_t* rlist, int num_clouds, int n, int knn, float* dx,
+                                                      void* stream) {
+    EPC_CHECK_ARG(s && dxm && xyz && cnt && kth && rdeg && roff && rlist && dx, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
+    const long total = (long)num_clouds * n;
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(neighbour_gather_bwd_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, s, rdeg, roff, rlist,
+                       (int)total, (float)knn, (const float*)nullptr, dxm, dx);
+    hipLaunchKernelGGL(neighbour_scatter_overflow_kernel, dim3(blocks), dim3(256), 0, st, s, xyz, cnt, kth, cap, (int)total, n,
+                       (float)knn, (const float*)nullptr, dx);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

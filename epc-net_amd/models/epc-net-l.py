@@ -54,19 +54,14 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
     point_cloud = ops.morton_sort(point_cloud)           # re-ordering only (permutation-invariant network)
     with variable_scope(backbone_scope):
         dpist = ops.KnnGraph(point_cloud)
-        def nmean_and_diff(x):                               # x1 = matmul(dpist, x) / float(k);  x1 - x
-            xm, d = ops.NeighbourMeanDiff.apply(x.reshape(-1, 64), dpist, k)
-            return xm.reshape(x.shape), d.reshape(x.shape)
         conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
                                                   scope=scope, bn_decay=bn_decay)
         outs = []
         inp = point_cloud
         for b in (1, 2):
             x = conv(inp, 64, 'conv%d' % b)
-            xb, t = nmean_and_diff(x)
-            t = conv(t, 64, 'conv%d_a' % b)
-            t = conv(t, 64, 'conv%d_b' % b)
-            inp = t + xb
+            # x1 = matmul(dpist, x) / k; t = conv_b(conv_a(x1 - x)); t + x1: one node in training (tf_util.proxyconv_tail)
+            inp = tf_util.proxyconv_tail(x, dpist, k, 'conv%d_a' % b, 'conv%d_b' % b, bn_decay=bn_decay, is_training=is_training)
             outs.append(inp)
         x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
         feats = x

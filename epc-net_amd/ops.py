@@ -18,8 +18,8 @@ _WORKSPACES = {}
 
 
 def _ws(rows, C, device):
-    """The column-reduction workspace of (device, current stream): zeroed when it is created or grown, reused afterwards
-    -- the kernels leave its completion counters at zero (include/epcnet.h, workspace contract)."""
+    """The column-reduction workspace of (device, current stream), reused by every reduction of that stream
+    (include/epcnet.h, workspace contract)."""
     n = L.lib().epc_colreduce_workspace_bytes(int(rows), int(C))
     key = (device.index, int(_st() or 0))
     buf = _WORKSPACES.get(key)
@@ -342,6 +342,15 @@ def _bn_relu_rownorm_bwd(df, z, rn, mean, var, gamma, beta, eps):
     return dz, sums[1], sums[0]
 
 
+def bn_apply_train(z, mean, var, gamma, beta, eps, relu):
+    """act(batch_norm(z)) with GIVEN batch moments (epc_bn_apply_fwd), no autograd: what a fused node leaves unmaterialised."""
+    z = z.detach().contiguous()
+    y = torch.empty_like(z)
+    L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     float(eps), int(bool(relu)), z.shape[0], z.shape[1], y.data_ptr(), _st()))
+    return y
+
+
 def bn_inference(z, mean, var, gamma, beta, eps=BN_EPS, relu=False):
     """Inference-mode BN with stored statistics (no gradient path is needed by the reference in this mode)."""
     z = z.contiguous()
@@ -430,6 +439,79 @@ class NeighbourMeanDiff(torch.autograd.Function):
                                                            roff.data_ptr(), rlist.data_ptr(), g.num_clouds, g.n, ctx.k,
                                                            dx.data_ptr(), _st()))
         return dx, None, None
+
+
+class ProxyConvTail(torch.autograd.Function):
+    """The rest of a ProxyConv block behind its leading conv (models/epc-net.py:70-86) as ONE node:
+        x1 = matmul(mask, x) / k;  t = x1 - x;  t = conv_a(t);  t = conv_b(t);  out = t + x1        (conv = 64 -> 64 + BN + ReLU)
+    -> (out, z_a, mean_a, var_a, z_b, mean_b, var_b) (the pre-activations and batch moments: moving averages, mask taps).
+    What the single node buys: the activation between conv_a and conv_b is never written (conv_b forms relu(bn(z_a)) as it loads
+    z_a, forward and backward), the residual is added inside conv_b's BatchNorm pass, and in the backward conv_a's input gradient
+    leaves with the residual path's gradient already added, so the neighbour backward gathers ONE tensor instead of two."""
+
+    @staticmethod
+    def forward(ctx, x, graph, k, Wa, ba, ga, bta, Wb, bb, gb, btb, eps):
+        x = x.contiguous()
+        rows = x.shape[0]
+        assert x.shape[1] == 64 and Wa.shape == (64, 64) and Wb.shape == (64, 64) and _GEMM_PRECISION == "bf16x6"
+        Wa, Wb = Wa.contiguous(), Wb.contiguous()
+        g = graph
+        lib = L.lib()
+        xm, diff = torch.empty_like(x), torch.empty_like(x)
+        L.check(lib.epc_neighbour_mean_diff_fwd(x.data_ptr(), g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(),
+                                                g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, int(k), xm.data_ptr(),
+                                                diff.data_ptr(), _st()))
+        za, ma, va = _gemm_with_stats(diff, Wa, ba)
+        zb = torch.empty_like(za)
+        mb = torch.empty(64, dtype=torch.float32, device=x.device)
+        vb = torch.empty(64, dtype=torch.float32, device=x.device)
+        ws, n = _ws(rows, 64, x.device)
+        L.check(lib.epc_linear_stats64_bn(za.data_ptr(), ma.data_ptr(), va.data_ptr(), ga.data_ptr(), bta.data_ptr(), float(eps),
+                                          Wb.data_ptr(), bb.data_ptr() if bb is not None else None, rows, zb.data_ptr(),
+                                          mb.data_ptr(), vb.data_ptr(), ws.data_ptr(), n, _st()))
+        out = torch.empty_like(x)
+        L.check(lib.epc_bn_apply_add_fwd(zb.data_ptr(), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(), btb.data_ptr(), float(eps), 1,
+                                         rows, 64, xm.data_ptr(), out.data_ptr(), _st()))
+        ctx.save_for_backward(diff, Wa, za, ma, va, ga, bta, Wb, zb, mb, vb, gb, btb)
+        ctx.graph, ctx.k, ctx.eps = graph, int(k), float(eps)
+        ctx.mark_non_differentiable(za, ma, va, zb, mb, vb)
+        ctx.set_materialize_grads(False)
+        return out, za, ma, va, zb, mb, vb
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        if dout is None:
+            return (None,) * 12
+        diff, Wa, za, ma, va, ga, bta, Wb, zb, mb, vb, gb, btb = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows = za.shape[0]
+        dev = za.device
+        lib, g, eps = L.lib(), ctx.graph, ctx.eps
+        new = lambda: torch.empty(64, dtype=torch.float32, device=dev)
+        ws, n = _ws(rows, 64, dev)
+        pf = lib.epc_linear_bn_bwd64_partial_floats(rows)
+        part = _splitk_ws(pf, dev)
+        # conv_b: its input is relu(bn(z_a)), re-formed from z_a
+        dta, dWb, dgb, dbtb = torch.empty_like(za), torch.empty_like(Wb), new(), new()
+        L.check(lib.epc_linear_bn_bwd64_ex(dout.data_ptr(), zb.data_ptr(), za.data_ptr(), ma.data_ptr(), va.data_ptr(),
+                                           ga.data_ptr(), bta.data_ptr(), Wb.data_ptr(), mb.data_ptr(), vb.data_ptr(),
+                                           gb.data_ptr(), btb.data_ptr(), eps, 1, rows, dta.data_ptr(), None, dWb.data_ptr(),
+                                           dgb.data_ptr(), dbtb.data_ptr(), ws.data_ptr(), n, part.data_ptr(), part.numel(), _st()))
+        # conv_a: the gradient of its input (xm - x) leaves as s = ddiff + dout, dout being what reaches xm by the residual
+        s, dWa, dga, dbta = torch.empty_like(za), torch.empty_like(Wa), new(), new()
+        L.check(lib.epc_linear_bn_bwd64_ex(dta.data_ptr(), za.data_ptr(), diff.data_ptr(), None, None, None, None, Wa.data_ptr(),
+                                           ma.data_ptr(), va.data_ptr(), ga.data_ptr(), bta.data_ptr(), eps, 1, rows, s.data_ptr(),
+                                           dout.data_ptr(), dWa.data_ptr(), dga.data_ptr(), dbta.data_ptr(), ws.data_ptr(), n,
+                                           part.data_ptr(), part.numel(), _st()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(za)
+            rdeg, roff, rlist = g.transposed()
+            L.check(lib.epc_neighbour_mean_diff_bwd_gather_sum(s.data_ptr(), dout.data_ptr(), g.xyz.data_ptr(), g.cnt.data_ptr(),
+                                                               g.kth.data_ptr(), L.EPC_KNN_CAP, rdeg.data_ptr(), roff.data_ptr(),
+                                                               rlist.data_ptr(), g.num_clouds, g.n, ctx.k, dx.data_ptr(), _st()))
+        # (bias gradients in front of a training-mode BatchNorm are exactly zero: LinearBatchNormTrain)
+        return dx, None, None, dWa, None, dga, dbta, dWb, None, dgb, dbtb, None
 
 
 class RowL2Normalize(torch.autograd.Function):

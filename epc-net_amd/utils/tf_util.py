@@ -225,6 +225,41 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
     return y.reshape(tuple(inputs.shape[:-1]) + (num_output_channels,))
 
 
+def proxyconv_tail(x, graph, k, scope_a, scope_b, bn_decay=None, is_training=None):
+    """x1 = matmul(mask, x) / k; t = conv_b(conv_a(x1 - x)); return t + x1 -- models/epc-net.py:70-86 (and :88-132 for the
+    other blocks) behind a block's leading conv, both convs 64 -> 64 with BatchNorm and ReLU.  Not a function of the reference's
+    tf_util: a fusion point.  In training (f32-accurate arithmetic) it is ONE autograd node (ops.ProxyConvTail); otherwise the
+    same graph op by op."""
+    from .. import ops
+    shape = tuple(x.shape)
+    x2 = x.reshape(-1, 64)
+    rows = int(x2.shape[0])
+    if not (is_training and ops.fused_linear_bn_ok(rows, 64, 64)):
+        xm, d = ops.NeighbourMeanDiff.apply(x2, graph, k)
+        t = conv1d(d.reshape(shape), 64, 1, padding='VALID', stride=1, bn=True, is_training=is_training, scope=scope_a,
+                   bn_decay=bn_decay)
+        t = conv1d(t, 64, 1, padding='VALID', stride=1, bn=True, is_training=is_training, scope=scope_b, bn_decay=bn_decay)
+        return t + xm.reshape(shape)
+    L.require_gpu()
+    wa, ba, _ = declare_conv1d(scope_a, 64, 64, 1, True, 1e-3, True)
+    wb, bb, _ = declare_conv1d(scope_b, 64, 64, 1, True, 1e-3, True)
+    with variable_scope(scope_a):
+        beta_a, gamma_a, em_a, ev_a = _bn_variables("bn", 64)
+    with variable_scope(scope_b):
+        beta_b, gamma_b, em_b, ev_b = _bn_variables("bn", 64)
+    out, za, ma, va, zb, mb, vb = ops.ProxyConvTail.apply(x2, graph, k, wa.reshape(64, 64), ba, gamma_a, beta_a,
+                                                          wb.reshape(64, 64), bb, gamma_b, beta_b, 1e-3)
+    decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+    for scope, z, mean, var, gamma, beta, em, ev in ((scope_a, za, ma, va, gamma_a, beta_a, em_a, ev_a),
+                                                     (scope_b, zb, mb, vb, gamma_b, beta_b, em_b, ev_b)):
+        with variable_scope(scope):
+            _ema_update(em, mean, decay)
+            _ema_update(ev, var, decay)
+            if RELU_MASK_TAPS is not None:      # (test hook: the layer's activation is not materialised by the fused node)
+                _tap_relu_mask(ops.bn_apply_train(z, mean, var, gamma, beta, 1e-3, True))
+    return out.reshape(shape)
+
+
 def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None):
     """conv1d(kernel 1, bn=True, relu) followed by tf.nn.l2_normalize over the channels of every point -- the pair
     models/epc-net.py:136-148 applies to conv5's output -- returned as (B*L, C).  Not a function of the reference's

@@ -310,26 +310,40 @@ int epc_linear_smallk_dw(const float* x, const float* dy, int rows, int cin, int
                          size_t partial_floats, void* stream);
 
 /* y = x W + b for a 64 -> 64 layer (x, y: (rows, 64) row-major, 16-byte aligned; W: (64 in, 64 out)) TOGETHER with the batch
- * moments of y (mean, population variance: tf.nn.moments) in ONE launch: one pass over the rows in the f32-accurate six-product
- * arithmetic, per-workgroup pivot-shifted column sums (as epc_gemm_f32_stats), and the workgroup that finishes last merges
- * them in ascending order in double precision.
- * `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64); zero counters, left zero).
+ * moments of y (mean, population variance: tf.nn.moments): one pass over the rows in the f32-accurate six-product
+ * arithmetic with per-workgroup pivot-shifted column sums (as epc_gemm_f32_stats), and a small second launch that pools
+ * them in a fixed order in double precision.
+ * `workspace`: the column-reduction workspace (epc_colreduce_workspace_bytes(rows, 64)).
  * Replaces tf.nn.conv1d + bias_add + tf.nn.moments of utils/tf_util.py:94-99, 472 for the thin layers. */
 int epc_linear_stats64(const float* x, const float* W, const float* bias, int rows, float* z, float* mean, float* var,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the layer's input formed as it is loaded: x_in = relu(batch_norm(x_pre)) from the batch moments and affine
+ * parameters of the layer that produced x_pre (conv*_a -> conv*_b, models/epc-net.py:77-85: the activation between the two
+ * layers is never written). */
+int epc_linear_stats64_bn(const float* x_pre, const float* in_mean, const float* in_var, const float* in_gamma,
+                          const float* in_beta, float eps, const float* W, const float* bias, int rows, float* z, float* mean,
+                          float* var, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of a 64 -> 64 layer followed by a training-mode BatchNorm (+ReLU) (utils/tf_util.py:94-106 from the gradient side:
  * the thin layers conv*_a / conv*_b / conv2..4 of models/epc-net.py:66-132) in three launches instead of four GEMM-sized ones:
  * the BatchNorm column sums (dbeta, dgamma), ONE pass over the rows that forms dz in registers and produces dx = dz W^T
  * (dx may be NULL) and the per-workgroup partials of dW = x^T dz (dz is never written), and an ORDERED sum of the partials:
  * dW is the same bits on every run.  dy, z, x: (rows, 64) row-major; W: (64 in, 64 out); `workspace`: the column-reduction
- * workspace (epc_colreduce_workspace_bytes(rows, 64), zero counters: workspace contract above); `dw_partials`:
+ * workspace (epc_colreduce_workspace_bytes(rows, 64): workspace contract below); `dw_partials`:
  * epc_linear_bn_bwd64_partial_floats(rows) floats of scratch.  Two bf16 pieces per operand (epc_gemm_f32_fast's arithmetic). */
 size_t epc_linear_bn_bwd64_partial_floats(int rows);
 int epc_linear_bn_bwd64(const float* dy, const float* z, const float* x, const float* W, const float* mean, const float* var,
                         const float* gamma, const float* beta, float eps, int relu, int rows, float* dx, float* dW,
                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, float* dw_partials,
                         size_t dw_partial_floats, void* stream);
+/* The same for a layer inside a fused block.  in_* (all four or none): the layer's input was relu(batch_norm(x)) of the previous
+ * layer's pre-activation x (epc_linear_stats64_bn) and is re-formed as x is loaded.  dx_addend (optional, (rows, 64)): dx leaves
+ * as dz W^T + dx_addend -- the gradient reaching the same tensor by the block's residual path (models/epc-net.py:86). */
+int epc_linear_bn_bwd64_ex(const float* dy, const float* z, const float* x, const float* in_mean, const float* in_var,
+                           const float* in_gamma, const float* in_beta, const float* W, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, int relu, int rows, float* dx, const float* dx_addend,
+                           float* dW, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, float* dw_partials,
+                           size_t dw_partial_floats, void* stream);
 
 /* Split-K WITHOUT atomics (the forward products of the training step: the same bits on every run).  Every K slice stores its
  * partial product in `workspace` (batch * splitk * M * N floats) and a second launch adds the slices in ascending order (+ bias,
@@ -339,11 +353,11 @@ int epc_gemm_splitk_det(const float* A, const float* B, float* C, const float* b
                         long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
                         int pieces, float* workspace, size_t workspace_floats, void* stream);
 
-/* Column reductions over the rows of (rows, C) tensors, C a multiple of 4 (at most 4096).  Each is ONE launch: the
- * workgroup that finishes a column panel last adds the per-panel partial sums in a fixed order (deterministic).
- * WORKSPACE CONTRACT: epc_colreduce_workspace_bytes(rows, C) bytes, 16-byte aligned; its first 256 bytes are
- * completion counters that must be ZERO on entry and are left zero on exit -- zero a workspace once, then reuse it for
- * any number of calls on ONE stream (calls sharing a workspace must be stream-ordered).
+/* Column reductions over the rows of (rows, C) tensors, C a multiple of 4 (at most 4096): per-panel partial sums, then a small
+ * second launch that adds them in a fixed order (deterministic).
+ * WORKSPACE CONTRACT: epc_colreduce_workspace_bytes(rows, C) bytes, 16-byte aligned, contents arbitrary (the completion
+ * counters of earlier versions are gone); reuse it for any number of calls on ONE stream (calls sharing a workspace must be
+ * stream-ordered).
  * epc_col_moments: tf.nn.moments -- mean and POPULATION variance (utils/tf_util.py:472), one pass over x. */
 size_t epc_colreduce_workspace_bytes(int rows, int C);
 int epc_col_moments(const float* x, int rows, int C, float* mean, float* var, void* workspace, size_t workspace_bytes,
@@ -355,6 +369,9 @@ int epc_col_sum(const float* x, int rows, int C, float* out, void* workspace, si
  * with the forward's own expression, so the forward output is not an input.  Workspace: contract above. */
 int epc_bn_apply_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                      float eps, int relu, int rows, int C, float* y, void* stream);
+/* y = act(batch_norm(z)) + addend: the block's residual, t + x1 (models/epc-net.py:86), in the same pass. */
+int epc_bn_apply_add_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                         float eps, int relu, int rows, int C, const float* addend, float* y, void* stream);
 int epc_bn_apply_bwd(const float* dy, const float* z, const float* mean, const float* var, const float* gamma,
                      const float* beta, float eps, int relu, int rows, int C, float* dz, float* dgamma, float* dbeta,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -407,6 +424,11 @@ int epc_neighbour_mean_diff_fwd(const float* x, const float* xyz, const int32_t*
 int epc_neighbour_mean_diff_bwd_gather(const float* dxm, const float* ddiff, const float* xyz, const int32_t* cnt,
                                        const float* kth, int cap, const int32_t* rdeg, const int32_t* roff,
                                        const int32_t* rlist, int num_clouds, int n, int knn, float* dx, void* stream);
+/* The same from the SUM s = dxm + ddiff (epc_linear_bn_bwd64_ex with dx_addend = dxm writes it): one gathered tensor instead
+ * of two; dx = mask^T s / knn - (s - dxm). */
+int epc_neighbour_mean_diff_bwd_gather_sum(const float* s, const float* dxm, const float* xyz, const int32_t* cnt,
+                                           const float* kth, int cap, const int32_t* rdeg, const int32_t* roff,
+                                           const int32_t* rlist, int num_clouds, int n, int knn, float* dx, void* stream);
 
 /* The kNN graph transposed: for every point j the points i whose neighbour list holds j (rows with more than `cap`
  * entries are not listed).  rdeg, roff, cursor: (num_clouds*n) int32; rlist: (num_clouds*n*cap) int32 holding absolute

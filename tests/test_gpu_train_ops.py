@@ -164,6 +164,65 @@ def test_neighbour_mean_and_diff(dev, kind, n):
     run_pair(fused, ref, [x], dev)
 
 
+@pytest.mark.parametrize("kind,n", [("uniform", 512), ("lattice", 512), ("uniform", 333)])
+def test_proxyconv_tail_node(dev, kind, n):
+    """ops.ProxyConvTail -- x1 = mask x / k; conv_b(conv_a(x1 - x)) + x1 (models/epc-net.py:70-86) as one node -- against float64:
+    the output, both layers' batch moments, and the gradients of x and of both layers' weights / gamma / beta; bit-equal across two
+    runs; and the op-by-op path (NeighbourMeanDiff, two LinearBatchNormTrain, add) gives the same numbers."""
+    ops = H.pkg("ops")
+    B = 3
+    pc = O.synthetic_clouds(B, n, 1, kind)
+    mask = torch.tensor(O.pairwise_distance_mask(pc), dtype=torch.float64)
+    graph = ops.KnnGraph(torch.from_numpy(pc).to(dev))
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(B * n, 64, dtype=torch.float64, generator=g)
+    mk = lambda *sh, sc=1.0: torch.randn(*sh, dtype=torch.float64, generator=g) * sc
+    Wa, Wb, ba, bb = mk(64, 64, sc=0.2), mk(64, 64, sc=0.2), mk(64, sc=0.1), mk(64, sc=0.1)
+    ga, gb, bta, btb = 1 + mk(64, sc=0.1), 1 + mk(64, sc=0.1), mk(64, sc=0.2), mk(64, sc=0.2)
+    up = mk(B * n, 64)
+
+    def bn_relu(z, gamma, beta):
+        m, v = z.mean(0), z.var(0, unbiased=False)
+        return torch.relu((z - m) * torch.rsqrt(v + 1e-3) * gamma + beta), m, v
+
+    def ref(x, Wa, ga, bta, Wb, gb, btb):
+        xm = torch.matmul(mask, x.reshape(B, n, 64)).reshape(-1, 64) / 20.0
+        t, ma, va = bn_relu((xm - x) @ Wa + ba, ga, bta)
+        t, mb, vb = bn_relu(t @ Wb + bb, gb, btb)
+        return t + xm, ma, va, mb, vb
+
+    ins = [x, Wa, ga, bta, Wb, gb, btb]
+    r_in = [t.clone().requires_grad_(True) for t in ins]
+    out_r, ma_r, va_r, mb_r, vb_r = ref(*r_in)
+    (out_r * up).sum().backward()
+    f32 = lambda t: t.float().to(dev)
+    runs = []
+    for _ in range(2):
+        g_in = [f32(t).requires_grad_(True) for t in ins]
+        xg, Wag, gag, btag, Wbg, gbg, btbg = g_in
+        out, za, ma, va, zb, mb, vb = ops.ProxyConvTail.apply(xg, graph, 20, Wag, f32(ba), gag, btag, Wbg, f32(bb), gbg, btbg, 1e-3)
+        (out * f32(up)).sum().backward()
+        assert rel(out, out_r) <= 2e-5
+        for a, r in ((ma, ma_r), (va, va_r), (mb, mb_r), (vb, vb_r)):
+            assert rel(a, r) <= 2e-5
+        for name, a, r in zip(("x", "Wa", "gamma_a", "beta_a", "Wb", "gamma_b", "beta_b"), g_in, r_in):
+            assert rel(a.grad, r.grad) <= 2e-4, "grad of %s: %.3e" % (name, rel(a.grad, r.grad))
+        runs.append([out.detach()] + [t.grad for t in g_in])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    # op by op
+    g_in = [f32(t).requires_grad_(True) for t in ins]
+    xg, Wag, gag, btag, Wbg, gbg, btbg = g_in
+    xm, d = ops.NeighbourMeanDiff.apply(xg, graph, 20)
+    t, _, _ = ops.LinearBatchNormTrain.apply(d, Wag, f32(ba), gag, btag, 1e-3, 1, False)
+    t, _, _ = ops.LinearBatchNormTrain.apply(t, Wbg, f32(bb), gbg, btbg, 1e-3, 1, False)
+    out2 = t + xm
+    (out2 * f32(up)).sum().backward()
+    assert rel(out2, runs[0][0]) <= 1e-6
+    for a, b in zip([t.grad for t in g_in], runs[0][1:]):
+        assert rel(a, b) <= 2e-5
+
+
 def test_rownorm_and_softmax(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(3)
