@@ -1492,6 +1492,230 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* me
 #endif
 #define LB_ROWS_PER_WG (4 * 32 * LB_TILES_PER_WAVE)
 
+#ifndef LB_COLUMN_LOADS
+// dW = x^T dz needs both operands with the ROWS as k: lane = channel, eight consecutive rows per k-step.  The first form of this
+// kernel (kept under -DLB_COLUMN_LOADS) read x, dy and z a second time in that layout -- 96 lane-coalesced dword loads per
+// 32-row tile next to the 16 float4 loads of the row layout -- and was bound by issuing them (29 us per layer).  Here every
+// tensor is read ONCE, in the row layout; the bf16 pieces of x and of dz go through a per-wave LDS image [row][channel]
+// (128-B rows, 16-B chunks XOR-swizzled) and come back transposed by ds_read_b64_tr_b16: lane 4q + p of a 16-lane group
+// addresses row r0 + q, channels c0 + 4p .. + 3; lane i receives channel c0 + i of the four rows.  One image (8 KB: hi + lo)
+// per wave serves x, then dz.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LB_IMG_BYTES 4096   // one piece: 32 rows x 128 B
+__device__ __forceinline__ int lb_img_off(int row, int chunk) {   // byte offset of 16-byte chunk `chunk` (0..7) of row `row`
+    return 128 * row + 16 * (chunk ^ (((row >> 1) & 1) << 2) ^ (((row >> 2) & 1) << 1));
+}
+// the A / B fragment (k = rows 16 s2 + 8 h .. + 7, m or n = channel 32 t + (lane & 31)) of one piece, read transposed
+__device__ __forceinline__ bf16x8 lb_tr_frag(const char* img, int t, int s2, int lane) {
+    const int g16 = lane >> 4, l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+    const int chunk = 4 * t + 2 * (g16 & 1) + (pp >> 1);
+    const int r0 = 16 * s2 + 8 * (g16 >> 1);
+    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + lb_img_off(r0 + q, chunk) + 8 * (pp & 1)));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + lb_img_off(r0 + 4 + q, chunk) + 8 * (pp & 1)));
+    const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_bn_bwd64_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ W,
+    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float eps,
+    float inv_rows, int relu, int rows, float* __restrict__ dx, float* __restrict__ dWpart, BnParams xbn,
+    const float* __restrict__ dx_addend) {
+    // xbn: the layer's input was relu(bn(x)) of the previous layer's pre-activation x (epc_linear_stats64_bn): the dW operand is
+    // formed the same way as it is loaded.  dx_addend (rows, 64): dx leaves as W dz + addend (the gradient that reaches the same
+    // tensor by the block's residual path, so that the neighbour backward gathers ONE tensor).
+    __shared__ __attribute__((aligned(16))) float coef[6][64];          // s, t (mask), mean, k1, dbeta/rows, rstd dgamma/rows
+    __shared__ __attribute__((aligned(16))) float xcoef[2][64];
+    __shared__ u32x4 Wf[2][4][2][64];                                    // W as A fragments: [in tile][k-step][hi, lo][lane]
+    __shared__ __attribute__((aligned(16))) char img[4][2 * LB_IMG_BYTES];   // per wave: hi + lo image; at the end the parked dW partials
+    static_assert(sizeof(img) >= 2 * 4 * 16 * 64 * sizeof(float), "the parked partials alias the images");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    if (tid < 64) {
+        const float mu = mean[tid], rs = 1.0f / sqrtf(var[tid] + eps), ga = gamma[tid];
+        const BnAffine a = bn_affine(mu, var[tid], ga, beta[tid], eps);
+        coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mu;
+        coef[3][tid] = ga * rs, coef[4][tid] = dbeta[tid] * inv_rows, coef[5][tid] = rs * (dgamma[tid] * inv_rows);
+        if (xbn.mean) {
+            const BnAffine xa = bn_affine(xbn.mean[tid], xbn.var[tid], xbn.gamma[tid], xbn.beta[tid], xbn.eps);
+            xcoef[0][tid] = xa.s, xcoef[1][tid] = xa.t;
+        }
+    }
+    // W (in, out) row-major: A[m = in][k = out]; lane (m = 32 mt + i, k group h) of k-step s holds W[m][16 s + 8 h .. + 7]
+    for (int f = tid; f < 2 * 4 * 64; f += 256) {
+        const int l = f & 63, s4 = (f >> 6) & 3, mt = f >> 8;
+        const float* src = W + (size_t)(32 * mt + (l & 31)) * 64 + 16 * s4 + 8 * (l >> 5);
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8 ph, pl;
+        split8(v, ph, pl);
+        Wf[mt][s4][0][l] = __builtin_bit_cast(u32x4, ph);
+        Wf[mt][s4][1][l] = __builtin_bit_cast(u32x4, pl);
+    }
+    __syncthreads();
+
+    f32x16 accW[2][2];   // [in tile mt][out tile nt]: register 4g + e = in channel 32 mt + 8 g + 4 h + e, lane = out channel 32 nt + i
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[mt][nt][r] = 0.f;
+
+    char* my = img[wave];
+    auto ld8 = [&](const float* p, float (&v)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    };
+    auto c8 = [&](const float* c, float (&v)[8]) {   // eight consecutive per-channel coefficients from LDS
+        const float4 a = *reinterpret_cast<const float4*>(c), b = *reinterpret_cast<const float4*>(c + 4);
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    };
+    auto put = [&](int s4, bf16x8 ph, bf16x8 pl) {   // the lane's row i, channels 16 s4 + 8 h .. + 7 = chunk 2 s4 + h
+        const int o = lb_img_off(i, 2 * s4 + h);
+        *reinterpret_cast<u32x4*>(my + o) = __builtin_bit_cast(u32x4, ph);
+        *reinterpret_cast<u32x4*>(my + LB_IMG_BYTES + o) = __builtin_bit_cast(u32x4, pl);
+    };
+
+#pragma unroll 1
+    for (int t = 0; t < LB_TILES_PER_WAVE; ++t) {
+        const int base = blockIdx.x * LB_ROWS_PER_WG + (wave * LB_TILES_PER_WAVE + t) * 32;   // wave-uniform
+        if (base >= rows) break;
+        const int row = base + i;
+        const bool ok = row < rows;
+        const size_t o = (size_t)(ok ? row : 0) * 64 + 8 * h;
+        // ---- dz (row layout): B fragments of dx^T = W dz^T as they stand; its bf16 pieces also go to the image ----
+        bf16x8 zh[4], zl[4];
+        {
+            float gv[4][8], zv[4][8];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) ld8(dy + o + 16 * s4, gv[s4]), ld8(z + o + 16 * s4, zv[s4]);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                asm volatile("" ::: "memory");   // (keeps a k-step's coefficient reads next to their use: hoisted, they took 190 registers)
+                float cs[8], ct[8], mu[8], k1[8], bb[8], gg[8], dzv[8];
+                const int c0 = 16 * s4 + 8 * h;
+                c8(&coef[0][c0], cs), c8(&coef[1][c0], ct), c8(&coef[2][c0], mu), c8(&coef[3][c0], k1), c8(&coef[4][c0], bb),
+                    c8(&coef[5][c0], gg);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = (relu && !(zv[s4][q] * cs[q] + ct[q] > 0.f)) ? 0.f : gv[s4][q];   // the forward's own expression
+                    const float v = k1[q] * (d - bb[q] - (zv[s4][q] - mu[q]) * gg[q]);
+                    dzv[q] = ok ? v : 0.f;
+                }
+                split8(dzv, zh[s4], zl[s4]);
+                put(s4, zh[s4], zl[s4]);
+            }
+        }
+        // x's rows are requested now: they land under the dx products
+        float xv[4][8];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) ld8(x + o + 16 * s4, xv[s4]);
+        if (dx) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, Wf[mt][s4][0][lane]), wl = __builtin_bit_cast(bf16x8, Wf[mt][s4][1][lane]);
+                    acc = mfma_bf16(wl, zh[s4], acc);
+                    acc = mfma_bf16(wh, zl[s4], acc);
+                    acc = mfma_bf16(wh, zh[s4], acc);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4 v = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                        if (dx_addend) {
+                            const float4 a = *reinterpret_cast<const float4*>(dx_addend + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h);
+                            v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+                        }
+                        *reinterpret_cast<float4*>(dx + (size_t)row * 64 + 32 * mt + 8 * g + 4 * h) = v;
+                    }
+                }
+            }
+        }
+        // ---- dz^T: the B fragments of dW (k = rows, n = out channel), read transposed from the image ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own image writes have landed before its reads)
+        bf16x8 dh[2][2], dl[2][2];   // [out tile][k-step]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dh[nt][s2] = lb_tr_frag(my, nt, s2, lane), dl[nt][s2] = lb_tr_frag(my + LB_IMG_BYTES, nt, s2, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // they are in registers: the image may be overwritten
+        // ---- x (row layout) -> bf16 pieces -> image -> A fragments of dW (k = rows, m = in channel) ----
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            asm volatile("" ::: "memory");
+            if (xbn.mean) {
+                float cs[8], ct[8];
+                c8(&xcoef[0][16 * s4 + 8 * h], cs), c8(&xcoef[1][16 * s4 + 8 * h], ct);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xv[s4][q] = fmaxf(xv[s4][q] * cs[q] + ct[q], 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[s4][q] = ok ? xv[s4][q] : 0.f;   // (a select, not a branch)
+            bf16x8 ph, pl;
+            split8(xv[s4], ph, pl);
+            put(s4, ph, pl);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 xh = lb_tr_frag(my, mt, s2, lane), xl = lb_tr_frag(my + LB_IMG_BYTES, mt, s2, lane);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    accW[mt][nt] = mfma_bf16(xl, dh[nt][s2], accW[mt][nt]);
+                    accW[mt][nt] = mfma_bf16(xh, dl[nt][s2], accW[mt][nt]);
+                    accW[mt][nt] = mfma_bf16(xh, dh[nt][s2], accW[mt][nt]);
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile overwrites the image
+    }
+    // ---- the four waves' partials meet pairwise, ((w0 + w1) + (w2 + w3)): a fixed order; wave 0 stores the workgroup's ----
+    __syncthreads();   // every wave is done with its image: the parked partials alias them
+    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(&img[0][0]);   // [slot][tile][register][lane]
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[slot][mt * 2 + nt][r][lane] = accW[mt][nt][r];
+    };
+    auto take = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW[mt][nt][r] += red[slot][mt * 2 + nt][r][lane];
+    };
+    if (wave & 1) park(wave >> 1);
+    __syncthreads();
+    if (!(wave & 1)) take(wave >> 1);
+    __syncthreads();
+    if (wave == 2) park(0);
+    __syncthreads();
+    if (wave == 0) {
+        take(0);
+        float* out = dWpart + (size_t)blockIdx.x * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(32 * mt + mfma_row(r, h)) * 64 + 32 * nt + i] = accW[mt][nt][r];
+    }
+}
+#else
 __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x, const float* __restrict__ W,
     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
@@ -1674,6 +1898,8 @@ __global__ __launch_bounds__(256) void linear_bn_bwd64_kernel(
                 for (int r = 0; r < 16; ++r) out[(32 * mt + mfma_row(r, h)) * 64 + 32 * nt + i] = accW[mt][nt][r];
     }
 }
+
+#endif   // LB_COLUMN_LOADS
 
 // out[e] = sum over p < P of part[p][e], added in ascending p whatever the launch geometry (16 groups of a workgroup take
 // every 16th partial each, their sums meet in LDS in group order: a fixed tree): the ordered counterpart of an atomic
