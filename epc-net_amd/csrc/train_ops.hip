@@ -37,6 +37,7 @@ struct GemmArgs {
     float* stats;   // optional (split kernel, splitk == 1, batch == 1): per row tile the column sums of A.B and of (A.B)^2
     float* partial; // optional (splitk > 1): slice blockIdx.z stores its (M, N) partial product here instead of adding it to C
                     // atomically; splitk_reduce_kernel then adds the slices in ascending order (deterministic split-K)
+    float a_scale = 1.f, b_scale = 1.f, descale = 1.f;   // PIECES == 4 (split-fp16): powers of two, descale = 1 / (a_scale b_scale)
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -178,16 +179,35 @@ __device__ __forceinline__ void fetch_fragments(const float* __restrict__ P, lon
     }
 }
 
+// PIECES == 4: TWO fp16 pieces of the operand times `scale` (a power of two chosen by the caller so that the operand's values sit
+// high in fp16's range; clamped to it), three products hi*lo + lo*hi + hi*hi on the fp16 MFMA: 2^-22 per product at half the
+// matrix work of the three-piece bf16 form -- for products whose operands are bounded by construction (BatchNorm / l2-normalised
+// activations against weights: conv5, the VLAD assignment).
+template <int PIECES>
+struct PieceCount {
+    static constexpr int value = PIECES == 4 ? 2 : PIECES;
+};
+
 template <int BLOCKS, int PIECES>
 __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) / 256][8], bool k_contig,
-                                                u32x4 (*dst)[2][PIECES][64], int tid) {
+                                                u32x4 (*dst)[2][PieceCount<PIECES>::value][64], int tid, float scale = 1.f) {
     constexpr int ROWS = 32 * BLOCKS;
 #pragma unroll
     for (int u = 0; u < (ROWS * 4) / 256; ++u) {
         const int f = tid + 256 * u;
         const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
         const int l2 = (row & 31) + 32 * (kg & 1);
-        if constexpr (PIECES == 1) {
+        if constexpr (PIECES == 4) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xs = fminf(fmaxf(v[u][j] * scale, -65504.f), 65504.f);
+                hi[j] = (_Float16)xs;
+                lo[j] = (_Float16)(xs - (float)hi[j]);
+            }
+            dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, hi);
+            dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, lo);
+        } else if constexpr (PIECES == 1) {
             bf16x8 p0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) p0[j] = (__bf16)v[u][j];
@@ -209,8 +229,9 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
 template <int WM, int WN, int PIECES, bool SWAP = false, int G_PF = 1>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ u32x4 As[2 * WM][2][PIECES][64];  // 4 KB per WM per piece
-    __shared__ u32x4 Bs[2 * WN][2][PIECES][64];
+    constexpr int NP = PieceCount<PIECES>::value;
+    __shared__ u32x4 As[2 * WM][2][NP][64];  // 4 KB per WM per piece
+    __shared__ u32x4 Bs[2 * WN][2][NP][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -246,8 +267,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
         }
     auto k_tile = [&](int kt, auto slotc) {
         constexpr int slot = decltype(slotc)::value;
-        store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid);
-        store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid);
+        store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid, g.a_scale);
+        store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid, g.b_scale);
         __syncthreads();
         if (kt + G_PF * S_BK < k1) {  // in flight under the MFMAs of this tile and of the G_PF - 1 after it
             fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + G_PF * S_BK, k1, va[slot], tid);
@@ -255,9 +276,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 a[WM][PIECES], b[WN][PIECES];
+            bf16x8 a[WM][NP], b[WN][NP];   // (fp16 pieces travel in the same 16-byte registers)
 #pragma unroll
-            for (int pc = 0; pc < PIECES; ++pc) {
+            for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
                 for (int rb = 0; rb < WM; ++rb) a[rb][pc] = __builtin_bit_cast(bf16x8, As[WM * wm + rb][s][pc][lane]);
 #pragma unroll
@@ -268,7 +289,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
                 for (int cb = 0; cb < WN; ++cb) {
                     f32x16 c = acc[rb][cb];
-                    auto mm = [&](int pa, int pb) { c = SWAP ? mfma_bf16(b[cb][pb], a[rb][pa], c) : mfma_bf16(a[rb][pa], b[cb][pb], c); };
+                    auto mm = [&](int pa, int pb) {
+                        if constexpr (PIECES == 4) {
+                            const f16x8 fa = __builtin_bit_cast(f16x8, a[rb][pa]), fb = __builtin_bit_cast(f16x8, b[cb][pb]);
+                            c = SWAP ? mfma_f16(fb, fa, c) : mfma_f16(fa, fb, c);
+                        } else {
+                            c = SWAP ? mfma_bf16(b[cb][pb], a[rb][pa], c) : mfma_bf16(a[rb][pa], b[cb][pb], c);
+                        }
+                    };
                     if constexpr (PIECES == 3) {
                         mm(2, 0);
                         mm(0, 2);
@@ -289,6 +317,14 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
         k_tile(kt, std::integral_constant<int, 0>{});
         if constexpr (G_PF > 1)
             if (kt + S_BK < k1) k_tile(kt + S_BK, std::integral_constant<int, 1>{});
+    }
+    if constexpr (PIECES == 4) {   // the operands were scaled by powers of two: exact to undo
+#pragma unroll
+        for (int rb = 0; rb < WM; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][cb][r] *= g.descale;
     }
     // Column statistics of the product for a training-mode BatchNorm that follows (epc_gemm_f32_stats): per row tile and column
     // the PIVOT p = the product's value in the tile's first row, and the sums of (v - p) and (v - p)^2 over the tile's valid rows
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     // With the statistics epilogue the lane = column layout stays (column sums are in-lane), but its plain stores -- 16 dword
     // store instructions per 32 x 32 tile -- go through a per-wave LDS tile (the operand buffers are free now) and leave as
     // float4 rows: 4 store instructions per tile, each writing eight whole 128-B rows.
-    if constexpr (!SWAP && WM == 2 && PIECES == 3) {
+    if constexpr (!SWAP && WM == 2 && (PIECES == 3 || PIECES == 4)) {
         if (g.stats && g.N % 4 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<size_t>(C) & 15) == 0 &&
             (!g.bias || (reinterpret_cast<size_t>(g.bias) & 15) == 0)) {
             float* stg = reinterpret_cast<float*>(&As[0][0][0][0]) + wave * (32 * 36);   // 4 x 4.6 KB of the 24-KB A buffer
@@ -453,6 +489,8 @@ static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStrea
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 1>), grid, dim3(256), 0, st, g);
     else if (pieces == 2)
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 2>), grid, dim3(256), 0, st, g);
+    else if (pieces == 4)   // (the split-fp16 form exists with the statistics epilogue only: epc_gemm_f16x3_stats)
+        hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 4>), grid, dim3(256), 0, st, g);
     else
         hipLaunchKernelGGL((gemm_split_kernel<WM, WN, 3>), grid, dim3(256), 0, st, g);
 }
@@ -667,16 +705,37 @@ __global__ void linear_stats64_kernel(const float* __restrict__ x, BnParams xbn,
                                       const float* __restrict__ bias, int rows, float* __restrict__ z,
                                       float* __restrict__ stats);   // (below)
 
+static int gemm_stats_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                           long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, int pieces,
+                           float a_scale, float b_scale, void* stream);
+
 extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
                                   float* var, void* stream) {
+    return gemm_stats_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, stats, stats_floats, mean, var, 3, 1.f, 1.f, stream);
+}
+
+// The same product in the split-fp16 three-product arithmetic (2^-22 per product, half the matrix work): A * 2^a_scale_log2 and
+// B * 2^b_scale_log2 are split into fp16 hi + lo (values beyond fp16's range are clamped to it), the product is un-scaled
+// exactly.  For operands bounded by construction -- choose the scales so that typical magnitudes land in [2^-3, 2^12].
+extern "C" int epc_gemm_f16x3_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
+                                    long sAk, long sBk, long sBn, int ldc, int a_scale_log2, int b_scale_log2, float* stats,
+                                    size_t stats_floats, float* mean, float* var, void* stream) {
+    EPC_CHECK_ARG(a_scale_log2 >= -30 && a_scale_log2 <= 30 && b_scale_log2 >= -30 && b_scale_log2 <= 30, "scale exponents out of range");
+    return gemm_stats_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, stats, stats_floats, mean, var, 4,
+                           ldexpf(1.f, a_scale_log2), ldexpf(1.f, b_scale_log2), stream);
+}
+
+static int gemm_stats_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                           long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, int pieces,
+                           float a_scale, float b_scale, void* stream) {
     EPC_CHECK_ARG(A && B && C && stats && mean && var, "null pointer");
     EPC_CHECK_ARG(M >= 64 && N >= 64 && K >= 32 && ldc >= N, "the statistics epilogue exists in the split-bf16 kernel: M, N >= 64, K >= 32");
     const int tiles = epc_gemm_stats_tiles(M);
     EPC_CHECK_ARG(stats_floats >= (size_t)tiles * 3 * N, "statistics buffer too small (epc_gemm_stats_tiles(M) * 3 * N floats)");
     hipStream_t st = (hipStream_t)stream;
 #ifndef EPC_NO_THIN_FORWARD
-    if (N == 64 && K == 64 && sAm == 64 && sAk == 1 && sBk == 64 && sBn == 1 && ldc == 64 &&
+    if (pieces == 3 && N == 64 && K == 64 && sAm == 64 && sAk == 1 && sBk == 64 && sBn == 1 && ldc == 64 &&
         ((reinterpret_cast<size_t>(A) | reinterpret_cast<size_t>(C)) & 15) == 0) {
         // the thin layers: one pass, one partial per 256 rows (fewer than the tiles the caller sized `stats` for)
         const int wgs = (M + 255) / 256;
@@ -689,11 +748,12 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
     }
 #endif
     GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, 0, 0, 0, 1, 0, stats, nullptr};
+    g.a_scale = a_scale, g.b_scale = b_scale, g.descale = 1.0f / (a_scale * b_scale);
     const bool bigm = M >= 128, bign = N >= 128;
-    if (bigm && bign) launch_gemm_split<2, 2>(g, 1, 3, st);
-    else if (bigm) launch_gemm_split<2, 1>(g, 1, 3, st);
-    else if (bign) launch_gemm_split<1, 2>(g, 1, 3, st);
-    else launch_gemm_split<1, 1>(g, 1, 3, st);
+    if (bigm && bign) launch_gemm_split<2, 2>(g, 1, pieces, st);
+    else if (bigm) launch_gemm_split<2, 1>(g, 1, pieces, st);
+    else if (bign) launch_gemm_split<1, 2>(g, 1, pieces, st);
+    else launch_gemm_split<1, 1>(g, 1, pieces, st);
     EPC_CHECK_LAUNCH();
     launch_moments_finalize(stats, tiles, N, M, M >= 128 ? 128 : 64, bias, mean, var, st);
     EPC_CHECK_LAUNCH();

@@ -43,7 +43,7 @@ EXPORTS = [
     "epc_pairwise_topk_ws", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
-    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
+    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
     "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64", "epc_gate_fwd",
@@ -115,6 +115,7 @@ _lib.epc_gemm_f32.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_long, c_lon
 _lib.epc_gemm_f32_fast.argtypes = _lib.epc_gemm_f32.argtypes
 _lib.epc_gemm_stats_tiles.argtypes = [c_int]
 _lib.epc_gemm_f32_stats.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int, _P, c_size_t, _P, _P, _P]
+_lib.epc_gemm_f16x3_stats.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]
 _lib.epc_gemm_bf16.argtypes = _lib.epc_gemm_f32.argtypes
 _lib.epc_gemm_splitk_det.argtypes = _lib.epc_gemm_f32.argtypes[:-1] + [c_int, _P, c_size_t, _P]
 _lib.epc_linear_smallk_fwd.argtypes = [_P, _P, _P, c_int, c_int, c_int, _P, _P]

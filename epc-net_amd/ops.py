@@ -205,8 +205,25 @@ class BatchNormTrain(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None
 
 
-def _gemm_with_stats(x, W, b):
-    """z = x @ W + b and the batch moments of z from the GEMM's own epilogue (epc_gemm_f32_stats): (z, mean, var)."""
+# The two wide forward products of the training step whose operands are bounded by construction -- conv5 (BatchNorm'd block
+# outputs against its weights) and the VLAD assignment (l2-normalised features against the cluster weights) -- take the
+# split-fp16 three-product arithmetic (epc_gemm_f16x3_stats: 2^-22 per product, half the matrix work of the six-product form).
+# (operand scale exponents: activations, weights)
+_FWD_F16X3 = True
+F16X3_CONV5 = (8, 12)      # |block output| < 2^7 (clamped beyond), |w| < 2^3
+F16X3_ASSIGN = (14, 12)    # |f| <= 1, |w| < 2^3
+
+
+def set_forward_f16x3(on: bool) -> bool:
+    """Enable / disable the split-fp16 arithmetic of those two products (off: the six-product form everywhere)."""
+    global _FWD_F16X3
+    prev, _FWD_F16X3 = _FWD_F16X3, bool(on)
+    return prev
+
+
+def _gemm_with_stats(x, W, b, f16x3=None):
+    """z = x @ W + b and the batch moments of z from the GEMM's own epilogue (epc_gemm_f32_stats): (z, mean, var).
+    ``f16x3`` = (activation, weight) scale exponents: the split-fp16 form (epc_gemm_f16x3_stats) when enabled."""
     rows, cin = x.shape
     cout = W.shape[1]
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
@@ -219,6 +236,12 @@ def _gemm_with_stats(x, W, b):
         return z, mean, var
     tiles = L.lib().epc_gemm_stats_tiles(rows)
     stats = torch.empty(tiles * 3 * cout, dtype=torch.float32, device=x.device)   # per row tile: sum, sum of squares, pivot
+    if f16x3 is not None and _FWD_F16X3:
+        L.check(L.lib().epc_gemm_f16x3_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
+                                             rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
+                                             int(f16x3[0]), int(f16x3[1]), stats.data_ptr(), stats.numel(), mean.data_ptr(),
+                                             var.data_ptr(), _st()))
+        return z, mean, var
     L.check(L.lib().epc_gemm_f32_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
                                        rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
                                        stats.data_ptr(), stats.numel(), mean.data_ptr(), var.data_ptr(), _st()))
@@ -240,7 +263,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm):
         x = x.contiguous()
-        z, mean, var = _gemm_with_stats(x, W, b)
+        z, mean, var = _gemm_with_stats(x, W, b, F16X3_CONV5 if W.shape[1] == 1024 else None)   # conv5 of either network
         rows, C = z.shape
         if rownorm:
             y = torch.empty_like(z)
@@ -653,7 +676,7 @@ class VladAssignAggregate(torch.autograd.Function):
         rows, F = f.shape
         assert Wc.shape == (F, 64) and rows % n_points == 0
         if fused_linear_bn_ok(rows, F, 64):
-            z, mean, var = _gemm_with_stats(f, Wc, None)
+            z, mean, var = _gemm_with_stats(f, Wc, None, F16X3_ASSIGN)
         else:
             z = gemm(f, Wc)
             mean = torch.empty(64, dtype=torch.float32, device=f.device)

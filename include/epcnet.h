@@ -294,6 +294,14 @@ int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bia
 int epc_gemm_stats_tiles(int M);
 int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                        long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, void* stream);
+/* The same product in the split-fp16 three-product arithmetic (2^-22 per product at half the matrix work of the six-product
+ * form): A * 2^a_scale_log2 and B * 2^b_scale_log2 are split into fp16 hi + lo as they are staged (magnitudes beyond fp16's range
+ * are clamped to it) and the product is un-scaled exactly.  For operands that are bounded by construction (BatchNorm / l2-normalised
+ * activations against weights: conv5 of models/epc-net.py:136, the assignment of loupe.py:255); choose the exponents so that typical
+ * magnitudes land high in fp16's range. */
+int epc_gemm_f16x3_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                         long sBk, long sBn, int ldc, int a_scale_log2, int b_scale_log2, float* stats, size_t stats_floats,
+                         float* mean, float* var, void* stream);
 
 /* Same interface, operands rounded to ONE bf16 value each (f32 data in memory, f32 accumulation, one product): the
  * "bf16" training configuration of BASELINE.json configs[2].  2^-9 relative per operand. */

@@ -223,6 +223,44 @@ def test_proxyconv_tail_node(dev, kind, n):
         assert rel(a, b) <= 2e-5
 
 
+@pytest.mark.parametrize("which,rows,cin,cout", [("conv5", 4096, 256, 1024), ("assign", 3000, 1024, 64)])
+def test_split_fp16_stats_product(dev, which, rows, cin, cout):
+    """ops._gemm_with_stats in the split-fp16 three-product form (epc_gemm_f16x3_stats: conv5 and the VLAD assignment of the
+    training forward) against float64: the product to 4e-6 of its largest entry and the moments to 2e-5 over four decades of
+    operand magnitude, as close as the six-product form within a factor of eight; magnitudes beyond fp16's range are clamped
+    (finite output)."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(cin)
+    scales = ops.F16X3_CONV5 if which == "conv5" else ops.F16X3_ASSIGN
+    for amp in (1.0, 1e-2, 1e-4, 30.0):
+        if which == "conv5":
+            x = torch.randn(rows, cin, dtype=torch.float64, generator=g).clamp(min=-0.5) * amp      # relu-like, heavy on one side
+        else:
+            x = torch.randn(rows, cin, dtype=torch.float64, generator=g).clamp(min=0)
+            x = x / x.norm(dim=1, keepdim=True) * min(amp, 1.0)
+        W = torch.randn(cin, cout, dtype=torch.float64, generator=g) / np.sqrt(cin)
+        b = torch.randn(cout, dtype=torch.float64, generator=g) * 0.1
+        ref = x @ W + b
+        xg, Wg, bg = x.float().to(dev), W.float().to(dev), b.float().to(dev)
+        z3, m3, v3 = ops._gemm_with_stats(xg, Wg, bg, scales)
+        z6, m6, v6 = ops._gemm_with_stats(xg, Wg, bg)
+        ref32 = (x.float().double() @ W.float().double()) + b.float().double()     # what the rounded operands give exactly
+        e3, e6 = rel(z3, ref32), rel(z6, ref32)
+        assert e3 <= 4e-6 and e3 <= max(8 * e6, 5e-7), (which, amp, e3, e6)
+        assert rel(m3, ref32.mean(0)) <= 2e-5 and rel(v3, ref32.var(0, unbiased=False)) <= 2e-5
+        assert rel(z3, ref) <= 2e-5
+    big = xg.clone()
+    big[0, 0] = 1e9
+    z, _, _ = ops._gemm_with_stats(big, Wg, bg, scales)
+    assert bool(torch.isfinite(z).all())
+    prev = ops.set_forward_f16x3(False)
+    try:
+        z6b, _, _ = ops._gemm_with_stats(xg, Wg, bg, scales)
+        assert torch.equal(z6b, z6)
+    finally:
+        ops.set_forward_f16x3(prev)
+
+
 def test_rownorm_and_softmax(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(3)
