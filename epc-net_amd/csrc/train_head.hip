@@ -38,6 +38,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
     const float* pr = raw + (size_t)b * F * 64;
     const float as = a_sum[b * 64 + c];
     float ss = 0.f;
+#pragma unroll 8
     for (int f = g; f < F; f += VN_GROUPS) {
         const float v = pr[f * 64 + c] - as * w2[f * 64 + c];
         ss += v * v;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
     for (int q = 0; q < 64; ++q) tot += s_tot[q];
     const float rb = 1.0f / sqrtf(fmaxf(tot, L2_EPS));
     float* po = out + (size_t)b * F * 64;
+#pragma unroll 8
     for (int f = g; f < F; f += VN_GROUPS) {
         const float v = pr[f * 64 + c] - as * w2[f * 64 + c];
         po[f * 64 + c] = (v * rc) * rb;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const float* pd = dout + (size_t)b * F * 64;
     const float* po = out + (size_t)b * F * 64;
     float T = 0.f, Q = 0.f;
+#pragma unroll 8
     for (int f = g; f < F; f += VN_GROUPS) {
         const float o = po[f * 64 + c], d = pd[f * 64 + c];
         T += d * o;
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const float inv_rb = 1.0f / rb;
     float* pw = draw + (size_t)b * F * 64;
     float da = 0.f;
+#pragma unroll 8
     for (int f = g; f < F; f += VN_GROUPS) {
         const float o = po[f * 64 + c], d = pd[f * 64 + c];
         const float dv = rc * (rb * (d - o * S) - (o * inv_rb) * Sc);

@@ -66,14 +66,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             const int e = tid + 256 * u;
             const int kk = a_kc ? e % G_BK : e / G_BM, mm = a_kc ? e / G_BK : e % G_BM;
             const int gm = m0 + mm, gk = kt + kk;
-            As[kk][mm] = (gm < g.M && gk < k1) ? A[(size_t)gm * g.sAm + (size_t)gk * g.sAk] : 0.f;
+            // (loads from clamped indices, zeroed afterwards: a guarded load is an exec-masked branch with a full wait at its
+            // join -- the 16 loads of a k-tile went out one memory round trip at a time: 27-44 us for the step's three
+            // 18-row products)
+            const float v = A[(size_t)min(gm, g.M - 1) * g.sAm + (size_t)min(gk, k1 - 1) * g.sAk];
+            As[kk][mm] = (gm < g.M && gk < k1) ? v : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < (G_BN * G_BK) / 256; ++u) {
             const int e = tid + 256 * u;
             const int nn = b_nc ? e % G_BN : e / G_BK, kk = b_nc ? e / G_BN : e % G_BK;
             const int gn = n0 + nn, gk = kt + kk;
-            Bs[kk][nn] = (gn < g.N && gk < k1) ? B[(size_t)gk * g.sBk + (size_t)gn * g.sBn] : 0.f;
+            const float v = B[(size_t)min(gk, k1 - 1) * g.sBk + (size_t)min(gn, g.N - 1) * g.sBn];
+            Bs[kk][nn] = (gn < g.N && gk < k1) ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -97,6 +102,67 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                     *p = g.accumulate ? *p + v : v;
             }
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Products with at most 32 rows (the 18-row context-gating layer of a training tuple, loupe.py:84-100, forward and input
+// gradient): the tile kernels above run them as FOUR workgroups walking K in eight barrier-separated steps -- 27-46 us of
+// latency for 2 MFLOP.  Here A (M x K) sits in LDS, a workgroup owns 16 output columns and 16 interleaved K slices
+// (thread = column x slice: all of its B values are requested at once), every thread keeps M running sums in plain f32 FMAs
+// and the slices meet in LDS in order.  One pass, deterministic.
+// ----------------------------------------------------------------------------------------------------------------
+#define SM_MAX_M 32
+#define SM_COLS 16
+#define SM_SLICES 16
+template <int MM>   // M rounded up to a multiple of 8: the rows past M are zeros in LDS, so the inner loop carries no row test
+__global__ __launch_bounds__(256) void gemm_small_m_kernel(GemmArgs g) {
+    extern __shared__ float sm_lds[];   // A as [MM][K], then red[SM_SLICES][MM][SM_COLS]
+    float* xs = sm_lds;
+    float* red = sm_lds + (size_t)MM * g.K;
+    const int tid = threadIdx.x, c = tid & (SM_COLS - 1), sl = tid / SM_COLS;
+    const int n = blockIdx.x * SM_COLS + c;
+    const int total = g.M * g.K;
+    if (g.sAk == 1 && g.sAm == g.K && (g.K & 3) == 0 && (reinterpret_cast<size_t>(g.A) & 15) == 0) {   // dense rows: float4 copies
+        const float4* src = reinterpret_cast<const float4*>(g.A);
+        float4* dst = reinterpret_cast<float4*>(xs);
+#pragma unroll 4
+        for (int e = tid; e < total / 4; e += 256) dst[e] = src[e];
+    } else {
+#pragma unroll 8
+        for (int e = tid; e < total; e += 256) xs[e] = g.A[(size_t)(e / g.K) * g.sAm + (size_t)(e % g.K) * g.sAk];
+    }
+    for (int e = total + tid; e < MM * g.K; e += 256) xs[e] = 0.f;
+    __syncthreads();
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+    const float* bp = g.B + (size_t)min(n, g.N - 1) * g.sBn;
+    for (int k0 = sl; k0 < g.K; k0 += 16 * SM_SLICES) {   // 16 of the thread's B values in flight per round (K = 256: one round)
+        float b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) b[u] = bp[(size_t)min(k0 + u * SM_SLICES, g.K - 1) * g.sBk];   // clamped, zeroed below
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + u * SM_SLICES;
+            const float bv = k < g.K ? b[u] : 0.f;
+            const float* xk = xs + min(k, g.K - 1);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) acc[m] += xk[(size_t)m * g.K] * bv;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m) red[(sl * MM + m) * SM_COLS + c] = acc[m];
+    __syncthreads();
+    for (int o = tid; o < g.M * SM_COLS; o += 256) {
+        const int m = o / SM_COLS, cc = o % SM_COLS, col = blockIdx.x * SM_COLS + cc;
+        if (col >= g.N) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < SM_SLICES; ++q) t += red[(q * MM + m) * SM_COLS + cc];
+        if (g.bias) t += g.bias[col];
+        float* p = g.C + (size_t)m * g.ldc + col;
+        *p = g.accumulate ? *p + t : t;
     }
 }
 
@@ -580,6 +646,19 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         }
         return EPC_OK;
     };
+    {   // at most 32 rows, one product, no split: A in LDS, plain f32 (gemm_small_m_kernel)
+        const int mm = (M + 7) / 8 * 8;
+        const size_t lds = ((size_t)mm * K + (size_t)SM_SLICES * mm * SM_COLS) * sizeof(float);
+        if (M <= SM_MAX_M && batch == 1 && splitk == 1 && lds <= 64 * 1024) {
+            const dim3 sgrid((N + SM_COLS - 1) / SM_COLS);
+            if (mm == 8) hipLaunchKernelGGL(gemm_small_m_kernel<8>, sgrid, dim3(256), lds, st, g);
+            else if (mm == 16) hipLaunchKernelGGL(gemm_small_m_kernel<16>, sgrid, dim3(256), lds, st, g);
+            else if (mm == 24) hipLaunchKernelGGL(gemm_small_m_kernel<24>, sgrid, dim3(256), lds, st, g);
+            else hipLaunchKernelGGL(gemm_small_m_kernel<32>, sgrid, dim3(256), lds, st, g);
+            EPC_CHECK_LAUNCH();
+            return EPC_OK;
+        }
+    }
 #ifndef EPC_GEMM_F32_ONLY
     // sides of at least 64: the split-bf16 kernel with the tile that fits; short sides stay on the f32 MFMA kernel
     if (M >= 64 && N >= 64 && K >= 32) {

@@ -37,7 +37,8 @@ def run_pair(fn_gpu, fn_ref, inputs, dev, tol=2e-5):
 
 
 @pytest.mark.parametrize("rows,cin,cout", [(4096, 64, 64), (1000, 3, 64), (2048, 256, 1024), (72, 16384, 256), (300, 1024, 64),
-                                           (333, 64, 64), (255, 64, 64)])   # 64 -> 64: the specialised layer kernel (ragged / just below its threshold)
+                                           (333, 64, 64), (255, 64, 64),   # 64 -> 64: the specialised layer kernel (ragged / just below its threshold)
+                                           (18, 256, 256), (1, 100, 40), (32, 333, 72)])   # <= 32 rows: gemm_small_m_kernel (the gating layer; ragged N, K)
 def test_linear(dev, rows, cin, cout):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(0)
