@@ -33,20 +33,25 @@ def get_learning_rate(epoch: int, base_learning_rate: float) -> float:
 
 
 def _joined_along_dim1(parts):
-    """The tensor of which ``parts`` are the consecutive dim-1 slices (torch.split views of one contiguous buffer), or None."""
-    base = parts[0]._base
-    if base is None or not base.is_contiguous() or any(p._base is not base for p in parts):
+    """The tensor of which ``parts`` are the consecutive dim-1 slices -- views of ONE storage with the same strides, each starting
+    where the previous one ends -- as a view of that storage, or None.  (train.py:252's concat is then the buffer itself.)"""
+    p0 = parts[0]
+    try:
+        store = p0.untyped_storage().data_ptr()
+    except Exception:
         return None
-    if base.dim() != parts[0].dim() or base.shape[1] != sum(int(p.shape[1]) for p in parts):
-        return None
-    at = 0
+    at = p0.storage_offset()
     for p in parts:
-        if p.dim() != base.dim() or p.stride() != base.stride() or p.shape[0] != base.shape[0] or p.shape[2:] != base.shape[2:]:
+        if p.dim() != p0.dim() or p.dim() < 2 or p.dtype != p0.dtype or p.untyped_storage().data_ptr() != store:
             return None
-        if p.storage_offset() != base.storage_offset() + at * base.stride(1):
+        if p.stride() != p0.stride() or p.shape[0] != p0.shape[0] or p.shape[2:] != p0.shape[2:] or p.storage_offset() != at:
             return None
-        at += int(p.shape[1])
-    return base
+        at += int(p.shape[1]) * int(p.stride(1))
+    total = sum(int(p.shape[1]) for p in parts)
+    joined = p0.as_strided((p0.shape[0], total) + tuple(p0.shape[2:]), p0.stride(), p0.storage_offset())
+    if p0.shape[0] > 1 and total * int(p0.stride(1)) > int(p0.stride(0)):
+        return None            # (rows of the leading dim would overlap: not slices of one (B, total, ...) tensor)
+    return joined
 
 
 class TrainStep:
@@ -264,7 +269,7 @@ class TrainStep:
             # the four inputs are slices of ONE buffer in train.py:252's order, so that its concat is the buffer itself
             joined = torch.empty((query.shape[0], sum(s[1] for s in shapes)) + tuple(query.shape[2:]), dtype=query.dtype,
                                  device=dev)
-            g = {"shapes": shapes, "dp": dp, "in": list(torch.split(joined, [s[1] for s in shapes], 1)),
+            g = {"shapes": shapes, "dp": dp, "joined": joined, "in": list(torch.split(joined, [s[1] for s in shapes], 1)),
                  "lr_t": torch.zeros(1, dtype=torch.float32, device=dev),
                  "bn_decay": torch.zeros((), dtype=torch.float32, device=dev)}
             for dst, src in zip(g["in"], inputs):
@@ -301,8 +306,12 @@ class TrainStep:
                 with torch.cuda.graph(g["graph2"], pool=g["graph"].pool()):
                     self._apply(self._unpack_mean(g["ex"], ws), g["lr_t"], t)
             self._graph = g
-        for dst, src in zip(g["in"], inputs):
-            dst.copy_(src)
+        src = _joined_along_dim1(inputs)
+        if src is not None:                       # the caller's four slices of one tuple tensor: one copy, not four
+            g["joined"].copy_(src)
+        else:
+            for dst, s_ in zip(g["in"], inputs):
+                dst.copy_(s_)
         g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
         g["bn_decay"].fill_(bn_decay)
         g["graph"].replay()

@@ -201,10 +201,15 @@ def test_step_inputs_recognised_as_slices_of_one_buffer():
     """training._joined_along_dim1: the concat of train.py:252 is skipped only for the exact consecutive dim-1 slices."""
     import torch
     T = H.pkg("training")
-    joined = torch.empty(2, 18, 5, 3)
-    parts = torch.split(joined, [1, 2, 14, 1], 1)
-    assert T._joined_along_dim1(parts) is joined
+    joined = torch.arange(2 * 18 * 5 * 3, dtype=torch.float32).reshape(2, 18, 5, 3)
+    sizes = [1, 2, 14, 1]
+    parts = torch.split(joined, sizes, 1)
+    assert torch.equal(T._joined_along_dim1(parts), joined)
+    assert T._joined_along_dim1(parts).data_ptr() == joined.data_ptr()
     assert T._joined_along_dim1((parts[0], parts[2], parts[1], parts[3])) is None          # wrong order
-    assert T._joined_along_dim1(parts[:3]) is None                                        # not the whole buffer
+    assert torch.equal(T._joined_along_dim1(parts[:3]), joined[:, :17])                   # a prefix is still a slice run
     assert T._joined_along_dim1(tuple(p.clone() for p in parts)) is None                  # separate tensors
-    assert T._joined_along_dim1(torch.split(joined[:, :, :4], [1, 2, 14, 1], 1)) is None  # slices of a sub-view
+    t = torch.arange(18 * 5 * 3, dtype=torch.float32).reshape(18, 5, 3)                   # bench.py's tuples: t[None, a:b]
+    q = (t[None, 0:1], t[None, 1:3], t[None, 3:17], t[None, 17:18])
+    assert torch.equal(T._joined_along_dim1(q), t[None])
+    assert T._joined_along_dim1((t[None, 0:1], t[None, 2:3])) is None                     # a gap
