@@ -292,6 +292,20 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
 // quad: the epilogue is float4 stores -- a quarter of the store instructions of the lane = column layout, whose 64 dword stores
 // per wave made the wide-output products (conv5 forward, the VLAD feature gradient: 302 MB written) store-issue-bound.  Used for
 // plain outputs (no statistics epilogue, which wants a column per lane; no split-K; N, ldc multiples of 4).
+#ifdef GEMM_STAMPS
+// Diagnostic build only (scripts/gemm_stamps.py): per wave the shader cycles of each phase of the k-tile loop, summed over its
+// k-tiles -- [store (split + LDS writes), barrier 1, fetch issue, MFMA phase (LDS reads + products), barrier 2, epilogue, total].
+__device__ unsigned int gemm_stamp_buf[32768][8];
+extern "C" int epc_debug_gemm_stamps(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(gemm_stamp_buf), bytes < sizeof(gemm_stamp_buf) ? bytes : sizeof(gemm_stamp_buf)) == hipSuccess ? 0 : -3;
+}
+#define GS_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#define GS_ADD(dst, a, b) dst += (unsigned)((b) - (a))
+#else
+#define GS_T(var)
+#define GS_ADD(dst, a, b)
+#endif
+
 template <int WM, int WN, int PIECES, bool SWAP = false, int G_PF = 1>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -331,15 +345,26 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
             fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, k0 + pf * S_BK, k1, va[pf], tid);
             fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0 + pf * S_BK, k1, vb[pf], tid);
         }
+#ifdef GEMM_STAMPS
+    unsigned st_store = 0, st_b1 = 0, st_fetch = 0, st_mfma = 0, st_b2 = 0;
+    GS_T(t_begin);
+#endif
     auto k_tile = [&](int kt, auto slotc) {
         constexpr int slot = decltype(slotc)::value;
+        GS_T(t0);
         store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid, g.a_scale);
         store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid, g.b_scale);
+        GS_T(t1);
         __syncthreads();
+        GS_T(t2);
         if (kt + G_PF * S_BK < k1) {  // in flight under the MFMAs of this tile and of the G_PF - 1 after it
             fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + G_PF * S_BK, k1, va[slot], tid);
             fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + G_PF * S_BK, k1, vb[slot], tid);
         }
+        GS_T(t3);
+        GS_ADD(st_store, t0, t1);
+        GS_ADD(st_b1, t1, t2);
+        GS_ADD(st_fetch, t2, t3);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 a[WM][NP], b[WN][NP];   // (fp16 pieces travel in the same 16-byte registers)
@@ -376,7 +401,11 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
                     acc[rb][cb] = c;
                 }
         }
+        GS_T(t4);
         __syncthreads();
+        GS_T(t5);
+        GS_ADD(st_mfma, t3, t4);
+        GS_ADD(st_b2, t4, t5);
     };
     // (the register slot is a compile-time constant: a runtime index would send va / vb to scratch memory)
     for (int kt = k0; kt < k1; kt += G_PF * S_BK) {
@@ -392,6 +421,23 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rb][cb][r] *= g.descale;
     }
+#ifdef GEMM_STAMPS
+    GS_T(t_loop_end);
+    struct StampWriter {
+        unsigned a, b, c, d, e;
+        unsigned long long t0, t1;
+        int slot, lane;
+        __device__ ~StampWriter() {
+            const unsigned long long tend = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && slot < 32768) {
+                gemm_stamp_buf[slot][0] = a, gemm_stamp_buf[slot][1] = b, gemm_stamp_buf[slot][2] = c, gemm_stamp_buf[slot][3] = d;
+                gemm_stamp_buf[slot][4] = e, gemm_stamp_buf[slot][5] = (unsigned)(tend - t1), gemm_stamp_buf[slot][6] = (unsigned)(tend - t0);
+                gemm_stamp_buf[slot][7] = (unsigned)(t1 - t0);
+            }
+        }
+    } stamp_writer{st_store, st_b1, st_fetch, st_mfma, st_b2, t_begin, t_loop_end,
+                   (int)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave), lane};
+#endif
     // Column statistics of the product for a training-mode BatchNorm that follows (epc_gemm_f32_stats): per row tile and column
     // the PIVOT p = the product's value in the tile's first row, and the sums of (v - p) and (v - p)^2 over the tile's valid rows
     // (of the product without the bias).  Shifted by a value of the column itself the sums stay at the scale of the column's
