@@ -192,7 +192,9 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     int has_next, int total_points, int n, float kdiv, float* __restrict__ out, int out_stride, int out_off,
     float* __restrict__ x_next) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_next_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_next_tile = 0;
     for (int o = tid * 4; o < BLK_PACK_S; o += BLK_THREADS * 4) st4(lds + o, ld4(pack + o));
     __syncthreads();
     const float* wa = lds;
@@ -206,15 +208,16 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* tin = tia + 128;
     float* st = lds + BLK_PACK_S + wave * 32 * ST_STRIDE;
 
+    // A workgroup owns a contiguous range of 32-point tiles -- the ranges differ by at most one tile -- and its waves draw
+    // tiles from it one at a time (an LDS counter) until it is empty.  The launch sizes the grid (epc_proxyconv_block_fwd):
+    // one workgroup per 12 tiles (every wave one tile), or -- for grids of a few rounds -- ONE persistent workgroup per CU, so
+    // that every CU gets the same work and stages the 49-KB weight pack once.  Which wave computes a tile does not enter
+    // its arithmetic.
+    const int ntiles = total_points / 32;
     const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int g0 = (bid * BLK_WAVES + wave) * 32;
-    if (g0 >= total_points) return;  // no further workgroup barriers below
-    // a wave's 32 points lie in one cloud: wave-uniform bases + 32-bit lane offsets (saddr addressing, no 64-bit VALU math)
-    const int cloud_base = __builtin_amdgcn_readfirstlane((g0 / n) * n);
+    const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
+    const int t_begin = bid * per + min(bid, rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
     const int p = lane >> 4, q = lane & 15;
-    const char* xc = reinterpret_cast<const char*>(x) + (size_t)cloud_base * 256;  // 256-B rows
-    auto row32 = [&](int row) { return *reinterpret_cast<const float4*>(xc + (unsigned)(row * 256 + q * 16)); };
-    const int wg0 = __builtin_amdgcn_readfirstlane(g0);
     const bool u16 = idx_u16 != 0;
     const float rk = 1.0f / kdiv;
     // a / kdiv, correctly rounded for ordinary operands: quotient estimate + one exact-remainder correction
@@ -222,6 +225,17 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
         const float q0 = a * rk;
         return __builtin_fmaf(__builtin_fmaf(-q0, kdiv, a), rk, q0);
     };
+  for (;;) {   // (no workgroup barriers inside)
+    int t_draw = 0;
+    if (lane == 0) t_draw = atomicAdd(&s_next_tile, 1);
+    const int tile = t_begin + __builtin_amdgcn_readfirstlane(t_draw);
+    if (tile >= t_end) break;
+    const int g0 = tile * 32;
+    // a wave's 32 points lie in one cloud: wave-uniform bases + 32-bit lane offsets (saddr addressing, no 64-bit VALU math)
+    const int cloud_base = __builtin_amdgcn_readfirstlane((g0 / n) * n);
+    const char* xc = reinterpret_cast<const char*>(x) + (size_t)cloud_base * 256;  // 256-B rows
+    auto row32 = [&](int row) { return *reinterpret_cast<const float4*>(xc + (unsigned)(row * 256 + q * 16)); };
+    const int wg0 = __builtin_amdgcn_readfirstlane(g0);
 
     // ---- gather-mean, 4 points per pass ----
     float4 xm[8];
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
         st4(out + (size_t)(g0 + 4 * s + p) * out_stride + out_off + 4 * q, o);
         st4(row, o);
     }
-    if (!has_next) return;
+    if (!has_next) continue;
 
     // ---- next block's leading conv ----
     inv_row = stage_to_bop(st, bh, bl, lane);
@@ -339,6 +353,7 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
 #pragma unroll
     for (int s = 0; s < 8; ++s)
         st4(x_next + (size_t)(g0 + 4 * s + p) * 64 + 4 * q, ld4(st + (4 * s + p) * ST_STRIDE + 4 * q));
+  }
 }
 
 // ---- fp16 rows, fp16 activations (EPC-Net) ---------------------------------------------------------------------------
@@ -627,7 +642,21 @@ extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const fl
         return EPC_EHIP;
     }
     const int wpb = f16 ? BLK16_WAVES : BLK_WAVES;
-    const unsigned blocks = (unsigned)((total + wpb * 32 - 1) / (wpb * 32));
+    unsigned blocks = (unsigned)((total + wpb * 32 - 1) / (wpb * 32));
+    if (!f16) {
+        // The f32 kernel's workgroups walk a tile range (its comment): with one workgroup per 12 tiles a grid of a few rounds
+        // leaves CUs idle in the last one (64 clouds: 683 workgroups on 256 CUs = 2.67 rounds), so up to eight rounds the grid
+        // is ONE persistent workgroup per CU (154 KB of LDS admit no second one): 64 clouds 0.097 -> 0.087 ms per block,
+        // step 1.168 -> 1.125 ms on one box, same bits.  Longer grids keep the short workgroups (EPC-Net-L at batch 256,
+        // 10.7 rounds: 1.784 ms against 1.801 persistent).
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            num_cus = v;
+        }
+        if (blocks > (unsigned)num_cus && blocks <= 8u * (unsigned)num_cus) blocks = (unsigned)num_cus;
+    }
     if (f16)
         hipLaunchKernelGGL(proxyconv_block_f16_kernel, dim3(blocks), dim3(BLK16_THREADS), lds_bytes, (hipStream_t)stream,
                            (const unsigned short*)x16, xyz, idx, idx_u16, cnt, kth, cap, (const float*)packed_block, has_next,
