@@ -213,10 +213,17 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     // one workgroup per 12 tiles (every wave one tile), or -- for grids of a few rounds -- ONE persistent workgroup per CU, so
     // that every CU gets the same work and stages the 49-KB weight pack once.  Which wave computes a tile does not enter
     // its arithmetic.
+    // The workgroups of one XCD (blockIdx % 8: they share an L2) sweep their XCD's range TOGETHER, four tiles per workgroup
+    // and step -- at any time the XCD works inside a window of a few hundred tiles (a cloud or two of gathered rows: the 4-MB
+    // L2 holds them), as the short workgroups did.  (A private contiguous quarter-cloud per workgroup put eight clouds behind
+    // one L2 at a time: FETCH_SIZE doubled.)
     const int ntiles = total_points / 32;
-    const int bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
-    const int t_begin = bid * per + min(bid, rem), t_end = t_begin + per + (bid < rem ? 1 : 0);
+    const int nwg = (int)gridDim.x, per = ntiles / nwg, rem = ntiles % nwg;
+    auto first_tile_of = [&](int wg) { return wg * per + min(wg, rem); };   // balanced contiguous partition, in workgroup order
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int xcd_wgs = xq + (xcd < xr ? 1 : 0);
+    const int xcd_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;     // (xcd_contiguous_block's order)
+    const int t_begin = first_tile_of(xcd_first), t_end = first_tile_of(xcd_first + xcd_wgs);
     const int p = lane >> 4, q = lane & 15;
     const bool u16 = idx_u16 != 0;
     const float rk = 1.0f / kdiv;
@@ -228,7 +235,8 @@ __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
   for (;;) {   // (no workgroup barriers inside)
     int t_draw = 0;
     if (lane == 0) t_draw = atomicAdd(&s_next_tile, 1);
-    const int tile = t_begin + __builtin_amdgcn_readfirstlane(t_draw);
+    const int d = __builtin_amdgcn_readfirstlane(t_draw);
+    const int tile = t_begin + (d >> 2) * (xcd_wgs * 4) + slot * 4 + (d & 3);
     if (tile >= t_end) break;
     const int g0 = tile * 32;
     // a wave's 32 points lie in one cloud: wave-uniform bases + 32-bit lane offsets (saddr addressing, no 64-bit VALU math)
