@@ -33,11 +33,11 @@ def make_store(arch, weights, device):
     return st
 
 
-def make_engine(arch, weights, device="cuda", micro_batch=0, precision="fast"):
+def make_engine(arch, weights, device="cuda", micro_batch=0, precision="fast", in_flight=None):
     """`precision`: 'fast' (EPC-Net's f16 + f6 kernels; EPC-Net-L ignores it) / 'f32' (f32-equivalent split arithmetic everywhere)."""
     E = pkg("engine")
     st = make_store(arch, weights, device)
-    return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch, precision=precision), st
+    return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch, precision=precision, in_flight=in_flight), st
 
 
 def run_stages(eng, xyz):

@@ -571,7 +571,7 @@ def test_last_status_refuses_after_a_multi_lane_call(dev):
     lane, so there are no "status words of the last pass" to report: last_status must raise, not return another call's words."""
     L = H.pkg("lib")
     w = O.seeded_weights("epc-net-l", 0)
-    eng, _ = H.make_engine("epc-net-l", w, dev, micro_batch=4)
+    eng, _ = H.make_engine("epc-net-l", w, dev, micro_batch=4, in_flight=2)
     pc = torch.from_numpy(O.synthetic_clouds(12, 256, 3)).to(dev)
     one = eng.forward(pc[:4])
     assert eng.last_status(4) == [0, 0, 0, 0]
