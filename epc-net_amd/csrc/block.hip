@@ -22,6 +22,9 @@
 #define BLK_WAVES 12  // f32 kernel: 12 x 8.7 KB staging tiles + the 49-KB weight pack = 154 KB (3 waves per SIMD)
 #endif
 #define BLK_THREADS (64 * BLK_WAVES)
+#ifndef BLK_PERSIST_MAX_ROUNDS
+#define BLK_PERSIST_MAX_ROUNDS 4096   // grids of up to this many rounds of short workgroups run as one persistent workgroup per CU (i.e. always)
+#endif
 #define ST_STRIDE 68  // floats per staged row: 64 + 4 pad -> conflict-free b128 reads in both layouts
 #define BLK_PACK EPC_BLOCK_PACK_FLOATS
 #define BLK_PACK_S EPC_BLOCK_PACK_FLOATS_S   // f32 kernel: the three layers' inverse column scales follow the layer packs
@@ -653,17 +656,17 @@ extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const fl
     unsigned blocks = (unsigned)((total + wpb * 32 - 1) / (wpb * 32));
     if (!f16) {
         // The f32 kernel's workgroups walk a tile range (its comment): with one workgroup per 12 tiles a grid of a few rounds
-        // leaves CUs idle in the last one (64 clouds: 683 workgroups on 256 CUs = 2.67 rounds), so up to eight rounds the grid
-        // is ONE persistent workgroup per CU (154 KB of LDS admit no second one): 64 clouds 0.097 -> 0.087 ms per block,
-        // step 1.168 -> 1.125 ms on one box, same bits.  Longer grids keep the short workgroups (EPC-Net-L at batch 256,
-        // 10.7 rounds: 1.784 ms against 1.801 persistent).
+        // leaves CUs idle in the last one (64 clouds: 683 workgroups on 256 CUs = 2.67 rounds), and every workgroup stages the
+        // 49-KB weight pack.  So a grid beyond one round is ONE persistent workgroup per CU (154 KB of LDS admit no second
+        // one).  Same box, same bits: EPC-Net, 64 clouds: 0.097 -> 0.084 ms per block, step 1.168 -> 1.123 ms; EPC-Net-L,
+        // 256 clouds (10.7 rounds): 1.839 -> 1.769 ms.
         static int num_cus = 0;
         if (num_cus == 0) {
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
             num_cus = v;
         }
-        if (blocks > (unsigned)num_cus && blocks <= 8u * (unsigned)num_cus) blocks = (unsigned)num_cus;
+        if (blocks > (unsigned)num_cus && blocks <= (unsigned)BLK_PERSIST_MAX_ROUNDS * (unsigned)num_cus) blocks = (unsigned)num_cus;
     }
     if (f16)
         hipLaunchKernelGGL(proxyconv_block_f16_kernel, dim3(blocks), dim3(BLK16_THREADS), lds_bytes, (hipStream_t)stream,
