@@ -4,7 +4,7 @@ import torch
 import bench
 ops = bench.pkg("ops")
 dev = torch.device("cuda:0")
-R = 18 * 4096
+R = int(os.environ.get("ROWS", 18 * 4096))
 def timed(fn, n=200):
     for _ in range(10): fn()
     torch.cuda.synchronize()
