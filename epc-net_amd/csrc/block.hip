@@ -176,18 +176,6 @@ __device__ __forceinline__ int list_entry(const void* lists, size_t slot, bool u
     return u16 ? (int)reinterpret_cast<const unsigned short*>(lists)[slot] : reinterpret_cast<const int32_t*>(lists)[slot];
 }
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so
-// giving each group a CONTIGUOUS range of tiles keeps all tiles of a cloud -- which gather from the same rows of x --
-// behind one L2 instead of eight.  Speed only: any mapping is correct.
-__device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
-#ifndef BLK_NO_XCD_REMAP
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any grid size
-#else
-    return bid;
-#endif
-}
-
 // ---- f32 rows, scaled split-fp16 layers (EPC_PRECISION_F32 and EPC-Net-L; f32-equivalent at every stage boundary) ----
 __global__ __launch_bounds__(BLK_THREADS) void proxyconv_block_kernel(
     const float* __restrict__ x, const float* __restrict__ xyz, const void* __restrict__ idx, int idx_u16,

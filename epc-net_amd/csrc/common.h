@@ -205,3 +205,16 @@ __device__ __forceinline__ uint2 pack_half4(const float4& y) {
     w.y = (unsigned)__builtin_bit_cast(unsigned short, h2) | ((unsigned)__builtin_bit_cast(unsigned short, h3) << 16);
     return w;
 }
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group), so
+// giving each group a CONTIGUOUS range of tiles keeps all tiles of a cloud -- which gather from the same rows of x --
+// behind one L2 instead of eight.  Speed only: any mapping is correct.
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
+#ifndef BLK_NO_XCD_REMAP
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;  // bijective for any grid size
+#else
+    return bid;
+#endif
+}
+

@@ -2269,7 +2269,8 @@ __global__ __launch_bounds__(256) void neighbour_mean_kernel(const float* __rest
                                                              const float* __restrict__ kth, int cap, int total_points,
                                                              int n, float kdiv, float* __restrict__ dst,
                                                              float* __restrict__ diff) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    // (XCD-aware: consecutive workgroups -- consecutive points of a cloud, gathering from the same rows -- behind ONE L2: common.h)
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int g = t >> 4, q = t & 15;
     if (g >= total_points) return;
     const int cloud_base = (g / n) * n;
@@ -2512,7 +2513,7 @@ __global__ __launch_bounds__(256) void neighbour_gather_bwd_kernel(const float* 
     // the point's own -ddiff is added:  dx[j] = (sum_i (dxm[i] + ddiff[i])) / k - ddiff[j]
     // 16 lanes x float4 per point (four points per wave, like the forward gather): a quarter of the load instructions of the
     // lane = channel form; eight list entries and their eight (sixteen) rows in flight per round, added in list order.
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;   // (XCD-aware, like the forward gather)
     const int j = t >> 4, q = t & 15;
     if (j >= total_points) return;
     const int deg = rdeg[j];
