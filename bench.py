@@ -33,13 +33,16 @@ Objects on the JSON line:
   configs      bounded legs for the other BASELINE.json configs, each timed like the main region (barrier + synchronize on
                both sides, max over ranks):
                train_step      configs[2]: one quadruplet step (1 + 2 + 14 + 1 clouds x 4096, train.py:238-277, 484-495), a
-                               FRESH tuple every step (the loss stays non-zero), HIP-graph replay at N = 1, data-parallel over
-                               tuples with one flat RCCL all-reduce at N > 1;
+                               FRESH tuple every step (the loss stays non-zero), HIP-graph replay at every N (data-parallel over
+                               tuples at N > 1: two graphs around one flat RCCL all-reduce), f32-accurate arithmetic, with its
+                               own `roofline`; `eager` = the same step without graphs (side number);
+               train_step_bf16 the same step with one bf16 value per GEMM operand (the arithmetic configs[2] names);
                epc_net_l_b256  configs[3]: EPC-Net-L inference at batch 256 per GPU, with its own roofline;
                retrieval       configs[4] composed end to end (retrieval.evaluate_sharded = evaluate.py:293-332): 23 runs x
                                (400 + 120) synthetic clouds EXTRACTED sharded over the ranks, ONE RCCL all-gather of the
                                descriptors, every rank ranks its share of the queries against each run's database
-                               (epc_pairwise_topk, k = 25), ONE RCCL gather of the neighbour lists, recall booked on rank 0.
+                               (epc_pairwise_topk, k = 25) and books them on its device, ONE RCCL all-reduce of the per-pair
+                               integer counters (no host loop, no serial tail on rank 0: `serial_ms`).
                                The process group is RCCL at N = 1 as well (a world of one rank: rccl_exercised true).
   pipeline_hbm HBM bytes one step moves (PMC counters of the committed profile x launches per step) over the step time,
                against 8 TB/s -- the north_star's "fraction of the HBM roofline"; secondary, the path is not HBM-bound.
@@ -337,46 +340,65 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
     return res, elapsed
 
 
-def train_step_leg(H, steps, warmup):
-    """configs[2]: the quadruplet step at full size, a fresh tuple every step."""
+def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0):
+    """configs[2]: the quadruplet step at full size, a fresh tuple every step.  HIP-graph replay at EVERY world size (one graph
+    at N = 1; at N > 1 the two graphs around the flat RCCL all-reduce, training.TrainStep._graphed_step).  ``precision``:
+    "bf16x6" = the f32-accurate split arithmetic (the reference computes in float32), "bf16" = one bf16 value per GEMM operand,
+    the arithmetic BASELINE.json configs[2] names.  ``eager_steps`` > 0: a side number without graphs (launch-bound)."""
     import torch
     TR = pkg("training")
     store = build_store("epc-net", H.device, 0)                # every rank starts from the same weights
     params = dict(PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5,
-                  MARGIN_2=0.2)
+                  MARGIN_2=0.2, TRAIN_PRECISION=precision)
     ts = TR.TrainStep(params, store, outer=OUTER)
     g = torch.Generator(device="cpu")
     g.manual_seed(7000 + H.rank)                               # data-parallel over tuples: every rank its own tuples
     n_tuples = 8
     tuples = [(torch.rand((18, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(H.device) for _ in range(n_tuples)]
-    use_graph = H.world == 1
     losses = []
 
-    def one(k):
-        t = tuples[k % n_tuples]
-        loss, _, _ = ts.step(t[None, 0:1], t[None, 1:3], t[None, 3:17], t[None, 17:18], epoch=0, graph=use_graph)
-        losses.append(loss.clone() if use_graph else loss)
+    def run(use_graph):
+        def one(k):
+            t = tuples[k % n_tuples]
+            loss, _, _ = ts.step(t[None, 0:1], t[None, 1:3], t[None, 3:17], t[None, 17:18], epoch=0, graph=use_graph)
+            losses.append(loss)
+        return one
 
     for k in range(warmup):
-        one(k)
+        run(True)(k)
     del losses[:]
-    elapsed = H.timed(one, steps)
+    elapsed = H.timed(run(True), steps)
     loss_vals = [float(x) for x in losses]
     flops = 3.0 * FLOPS_PER_CLOUD["epc-net"] * 18
-    return {"workload": "EPC-Net quadruplet training step, 1 + 2 + 14 + 1 clouds x 4096 pts per GPU (BASELINE.json configs[2]; "
-                        "train.py:238-277, 484-495), fresh tuple every step, %s"
-                        % ("HIP-graph replay" if use_graph else "eager launches + one flat RCCL all-reduce of gradients and moving statistics"),
-            "value": round(H.world * steps / elapsed, 2), "unit": "tuples/s (18 clouds each)", "steps": steps,
-            "ms_per_step": round(elapsed / steps * 1e3, 4), "dtype": "bf16x6 forward / bf16x3 backward GEMMs (f32-accurate)",
-            "tflops": round(flops * steps / elapsed / 1e12, 2), "algorithmic_flops_per_step": flops,
-            "loss_first": round(loss_vals[0], 5), "loss_last": round(loss_vals[-1], 5),
-            "loss_mean": round(sum(loss_vals) / len(loss_vals), 5)}
+    tflops = flops * steps / elapsed / 1e12
+    out = {"workload": "EPC-Net quadruplet training step, 1 + 2 + 14 + 1 clouds x 4096 pts per GPU (BASELINE.json configs[2]; "
+                       "train.py:238-277, 484-495), fresh tuple every step, HIP-graph replay%s"
+                       % ("" if H.world == 1 else " (two graphs around one flat RCCL all-reduce of gradients and moving statistics)"),
+           "value": round(H.world * steps / elapsed, 2), "unit": "tuples/s (18 clouds each)", "steps": steps,
+           "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "dtype": ("bf16x6 / f16x3 forward, bf16x3 backward GEMMs (f32-accurate)" if precision == "bf16x6" else
+                     "bf16 GEMM operands, f32 accumulate, f32 tensors and statistics"),
+           "tflops": round(tflops, 2), "algorithmic_flops_per_step": flops,
+           # the whole step against the dense 16-bit matrix peak (96 % of its FLOPs are dense contractions, SURVEY.md 8d)
+           "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "vs_f32_mfma_peak": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+                        "kernel": "whole step (forward + backward + Adam + moving averages), all launches of the replayed graph"},
+           "loss_first": round(loss_vals[0], 5), "loss_last": round(loss_vals[-1], 5),
+           "loss_mean": round(sum(loss_vals) / len(loss_vals), 5)}
+    if eager_steps > 0:
+        for k in range(3):
+            run(False)(k)
+        e2 = H.timed(run(False), eager_steps)
+        out["eager"] = {"ms_per_step": round(e2 / eager_steps * 1e3, 4), "steps": eager_steps,
+                        "note": "the same step launched from Python without HIP graphs (host launch-bound): a side number"}
+    return out
 
 
 def retrieval_leg(H, E, steps, warmup, rccl):
     """configs[4] composed end to end (evaluate.py:293-332): EXTRACTION of 23 runs x (400 database + 120 query) synthetic clouds
     sharded over the ranks -> ONE RCCL all-gather of the descriptors -> every rank ranks its share of the queries against each
-    database run (epc_pairwise_topk, k = 25) -> ONE RCCL gather of the neighbour lists -> rank 0 books recall@N / top-1 %.
+    database run (epc_pairwise_topk, k = 25) and books them on its device -> ONE RCCL all-reduce of the integer counters.
     retrieval.evaluate_sharded is the product entry point; a step = one whole evaluation."""
     import numpy as np
     import torch
@@ -407,16 +429,23 @@ def retrieval_leg(H, E, steps, warmup, rccl):
     extract = lambda chunk: eng.forward(chunk, check=False)
     prev = D.force_collective(bool(rccl))                     # a world of one still issues its RCCL collectives
     tms, result = [], {}
+    import time as _time
+    t_pack = _time.perf_counter()
+    packed = R.pack_truth(truth, [n_db] * runs, [n_q] * runs).to(H.device)     # once per dataset (like loading the pickles)
+    t_pack = _time.perf_counter() - t_pack
     try:
-        def one(_k):
+        def one(_k, vectors=False):
             tm = {}
-            result["res"] = R.evaluate_sharded(extract, dbs, qs, truth if rank == 0 else None, device=H.device,
-                                               batch_size=64, timings=tm)
+            result["res"] = R.evaluate_sharded(extract, dbs, qs, packed, device=H.device, batch_size=64, timings=tm,
+                                               return_vectors=vectors)
             tms.append(tm)
         for i in range(warmup):
             one(i)
         del tms[:]
         elapsed = H.timed(one, steps)
+        timed_tms = list(tms)
+        one(0, vectors=True)                                  # (untimed) the descriptors, for the float64 check below
+        tms = timed_tms
     finally:
         D.force_collective(prev)
     total = runs * (n_db + n_q)
@@ -439,15 +468,19 @@ def retrieval_leg(H, E, steps, warmup, rccl):
         gather_ms = agg("all_gather")
         out = {"workload": "Oxford-scale evaluate(): %d runs x (%d database + %d query) synthetic clouds x %d pts = %d clouds "
                            "extracted (EPC-Net, f32-equivalent arithmetic, batch 64) sharded over %d rank(s) -> one all-gather of the "
-                           "256-d descriptors -> exact top-25 of every query against each other run's database -> one index "
-                           "gather -> recall bookkeeping on rank 0 (BASELINE.json configs[4]; evaluate.py:293-332, 351-537; "
-                           "retrieval.evaluate_sharded)" % (runs, n_db, n_q, N_POINTS, total, world),
+                           "256-d descriptors -> exact top-25 of every query against each other run's database, each rank "
+                           "ranking AND booking its share of the queries on the device -> one all-reduce of the per-pair integer "
+                           "counters (BASELINE.json configs[4]; evaluate.py:293-332, 351-537; retrieval.evaluate_sharded)" % (runs, n_db, n_q, N_POINTS, total, world),
                "rccl_exercised": bool(rccl), "backend": D.backend_name(), "rccl_ranks": world,
                "value": round(total * steps / elapsed, 1), "unit": "clouds/s evaluated end to end", "steps": steps,
                "ms_per_step": round(ms, 3),
-               "phase_ms_rank0": {"extract": agg("extract"), "all_gather": gather_ms, "rank": agg("rank"),
-                                  "index_gather": agg("index_gather"), "book_host": agg("book")},
-               "all_gather_bytes": tms[-1]["all_gather_bytes"],
+               "phase_ms_rank0": {"extract": agg("extract"), "all_gather": gather_ms, "rank_book": agg("rank_book"),
+                                  "reduce": agg("reduce"), "finish_host": agg("finish"), "book_host": agg("finish")},
+               # what does NOT shrink with the number of ranks: the two collectives and the few numpy operations that turn the
+               # reduced counters into the averages (extraction, ranking and booking are sharded)
+               "serial_ms": round(gather_ms + agg("reduce") + agg("finish"), 3),
+               "pack_truth_once_ms": round(t_pack * 1e3, 1),
+               "all_gather_bytes": tms[-1]["all_gather_bytes"], "reduce_bytes": tms[-1]["reduce_bytes"],
                "all_gather_GBps": round(tms[-1]["all_gather_bytes"] * (world - 1) / max(world, 1) / (gather_ms * 1e-3) / 1e9, 3)
                                   if world > 1 and gather_ms > 0 else None,
                "ordered_pairs": runs * (runs - 1), "queries_ranked": runs * (runs - 1) * n_q,
@@ -543,7 +576,8 @@ def main():
 
     configs = {}
     if not args.no_configs and args.arch == "epc-net":
-        configs["train_step"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12)
+        configs["train_step"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, eager_steps=6)
+        configs["train_step_bf16"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, precision="bf16")
         stl = build_store("epc-net-l", device, seed=0)
         leg, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 256, max(10, min(50, args.steps)), min(args.warmup, 10), 0.0,
                                 every, 1)

@@ -255,3 +255,94 @@ extern "C" int epc_lazy_quadruplet_loss_bwd(const float* q, const float* pos, co
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Distillation terms (kd_train.py:330-340, 376-383): square_error_sum / square_error_mean of two equally shaped tensors --
+// the student's and the teacher's descriptors ("soft labels", rows x 256) and, with GAMMA != 0, their l2-normalised point
+// features (rows x 1024: 302 MB each at 18 x 4096 rows).  loss = scale * sum (a - b)^2 (scale = 1, or 1 / n for the mean).
+// Forward: ONE read of a and b -- every workgroup reduces a contiguous slice to a partial (lanes, then waves, in a fixed order),
+// the finish adds the partials in ascending order in double: bit-reproducible.  Backward: da = (2 scale dloss) (a - b), one pass;
+// b (the teacher's output) gets no gradient (kd_train.py feeds it through a placeholder).
+// ----------------------------------------------------------------------------------------------------------------
+#define SQ_WG_ELEMS (256 * 4 * 16)   // elements per workgroup: 16 float4 per thread
+
+__global__ __launch_bounds__(256) void sq_err_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[4];
+    const long base = (long)blockIdx.x * SQ_WG_ELEMS;
+    float s = 0.f;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const long o = base + ((long)u * 256 + threadIdx.x) * 4;
+        if (o + 3 < n) {
+            const float4 x = *reinterpret_cast<const float4*>(a + o), y = *reinterpret_cast<const float4*>(b + o);
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        } else {
+            for (long e = o; e < n && e < o + 4; ++e) {
+                const float d = a[e] - b[e];
+                s += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sq_err_finish_kernel(const float* __restrict__ partial, int count, float scale,
+                                                            float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int p = threadIdx.x; p < count; p += 256) s += (double)partial[p];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+
+__global__ __launch_bounds__(256) void sq_err_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                         float scale2, const float* __restrict__ dloss,
+                                                         float* __restrict__ da) {
+    const float w = scale2 * dloss[0];
+    const long o = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (o + 3 < n) {
+        const float4 x = *reinterpret_cast<const float4*>(a + o), y = *reinterpret_cast<const float4*>(b + o);
+        *reinterpret_cast<float4*>(da + o) = make_float4(w * (x.x - y.x), w * (x.y - y.y), w * (x.z - y.z), w * (x.w - y.w));
+    } else {
+        for (long e = o; e < n && e < o + 4; ++e) da[e] = w * (a[e] - b[e]);
+    }
+}
+
+extern "C" size_t epc_sq_err_partial_floats(long n) { return n > 0 ? (size_t)((n + SQ_WG_ELEMS - 1) / SQ_WG_ELEMS) : 0; }
+
+extern "C" int epc_sq_err_fwd(const float* a, const float* b, long n, int mean, float* loss, float* partials,
+                              size_t partial_floats, void* stream) {
+    EPC_CHECK_ARG(a && b && loss && partials, "null pointer");
+    EPC_CHECK_ARG(n > 0 && n < (1L << 40), "bad element count");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b)) & 15) == 0, "a and b must be 16-byte aligned");
+    const size_t wgs = epc_sq_err_partial_floats(n);
+    EPC_CHECK_ARG(partial_floats >= wgs, "partial buffer too small (epc_sq_err_partial_floats)");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sq_err_partial_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, b, n, partials);
+    hipLaunchKernelGGL(sq_err_finish_kernel, dim3(1), dim3(256), 0, st, partials, (int)wgs, mean ? 1.0f / (float)n : 1.0f, loss);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_sq_err_bwd(const float* a, const float* b, long n, int mean, const float* dloss, float* da, void* stream) {
+    EPC_CHECK_ARG(a && b && dloss && da, "null pointer");
+    EPC_CHECK_ARG(n > 0 && n < (1L << 40), "bad element count");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(da)) & 15) == 0,
+                  "a, b and da must be 16-byte aligned");
+    const long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(sq_err_bwd_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, n,
+                       mean ? 2.0f / (float)n : 2.0f, dloss, da);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

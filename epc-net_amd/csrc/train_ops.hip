@@ -38,6 +38,11 @@ struct GemmArgs {
     float* partial; // optional (splitk > 1): slice blockIdx.z stores its (M, N) partial product here instead of adding it to C
                     // atomically; splitk_reduce_kernel then adds the slices in ascending order (deterministic split-K)
     float a_scale = 1.f, b_scale = 1.f, descale = 1.f;   // PIECES == 4 (split-fp16): powers of two, descale = 1 / (a_scale b_scale)
+    // Range guard of the split-fp16 form: the PIECES == 4 kernel ORs 1 into *range_flag when a scaled operand value is
+    // not finite or leaves fp16's range (flag_mode 1); the six-product kernel launched behind it returns at once unless the word is
+    // set (flag_mode 2) -- an in-stream, in-graph fallback with no host round trip.  Null: no guard.
+    unsigned int* range_flag = nullptr;
+    int flag_mode = 0;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -256,8 +261,10 @@ struct PieceCount {
 
 template <int BLOCKS, int PIECES>
 __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) / 256][8], bool k_contig,
-                                                u32x4 (*dst)[2][PieceCount<PIECES>::value][64], int tid, float scale = 1.f) {
+                                                u32x4 (*dst)[2][PieceCount<PIECES>::value][64], int tid, float scale = 1.f,
+                                                bool* out_of_range = nullptr) {
     constexpr int ROWS = 32 * BLOCKS;
+    bool bad = false;
 #pragma unroll
     for (int u = 0; u < (ROWS * 4) / 256; ++u) {
         const int f = tid + 256 * u;
@@ -267,7 +274,9 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
             f16x8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float xs = fminf(fmaxf(v[u][j] * scale, -65504.f), 65504.f);
+                const float raw = v[u][j] * scale;
+                bad |= !(fabsf(raw) <= 65504.f);      // beyond fp16's range, or NaN (fmaxf / fminf would turn a NaN into a finite value)
+                const float xs = fminf(fmaxf(raw, -65504.f), 65504.f);
                 hi[j] = (_Float16)xs;
                 lo[j] = (_Float16)(xs - (float)hi[j]);
             }
@@ -285,6 +294,9 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
             dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, p1);
             if constexpr (PIECES == 3) dst[row >> 5][kg >> 1][2][l2] = __builtin_bit_cast(u32x4, p2);
         }
+    }
+    if constexpr (PIECES == 4) {
+        if (out_of_range) *out_of_range |= bad;
     }
 }
 
@@ -312,10 +324,12 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     constexpr int NP = PieceCount<PIECES>::value;
     __shared__ u32x4 As[2 * WM][2][NP][64];  // 4 KB per WM per piece
     __shared__ u32x4 Bs[2 * WN][2][NP][64];
+    if (g.flag_mode == 2 && __hip_atomic_load(g.range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // fallback not needed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    bool range_bad = false;
     const int batch = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
     const float* A = g.A + (size_t)batch * g.bA;
     const float* B = g.B + (size_t)batch * g.bB;
@@ -352,8 +366,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
     auto k_tile = [&](int kt, auto slotc) {
         constexpr int slot = decltype(slotc)::value;
         GS_T(t0);
-        store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid, g.a_scale);
-        store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid, g.b_scale);
+        store_fragments<2 * WM, PIECES>(va[slot], a_kc, As, tid, g.a_scale, &range_bad);
+        store_fragments<2 * WN, PIECES>(vb[slot], b_kc, Bs, tid, g.b_scale, &range_bad);
         GS_T(t1);
         __syncthreads();
         GS_T(t2);
@@ -414,6 +428,7 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
             if (kt + S_BK < k1) k_tile(kt + S_BK, std::integral_constant<int, 1>{});
     }
     if constexpr (PIECES == 4) {   // the operands were scaled by powers of two: exact to undo
+        if (g.flag_mode == 1 && __any(range_bad) && lane == 0) atomicOr(g.range_flag, 1u);
 #pragma unroll
         for (int rb = 0; rb < WM; ++rb)
 #pragma unroll
@@ -841,12 +856,18 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
 }
 
 // The same product in the split-fp16 three-product arithmetic (2^-22 per product, half the matrix work): A * 2^a_scale_log2 and
-// B * 2^b_scale_log2 are split into fp16 hi + lo (values beyond fp16's range are clamped to it), the product is un-scaled
-// exactly.  For operands bounded by construction -- choose the scales so that typical magnitudes land in [2^-3, 2^12].
+// B * 2^b_scale_log2 are split into fp16 hi + lo, the product is un-scaled exactly.  For operands bounded by construction --
+// choose the scales so that typical magnitudes land in [2^-3, 2^12].  RANGE GUARD: a scaled operand value that is
+// NaN, infinite or beyond fp16's range (|x| >= 2^(16 - a_scale_log2): nothing bounds a BatchNorm output -- z-hat reaches
+// sqrt(rows), gamma is learned) sets a device word, and the six-product split-bf16 kernel launched right behind -- a no-op
+// otherwise -- recomputes C and the statistics in float32's range: the result is then exactly epc_gemm_f32_stats', NaN / Inf
+// propagate as there, and a diverged step shows a NaN loss instead of a finite wrong one.  The word is the LAST float of `stats`
+// (stats_floats >= epc_gemm_stats_tiles(M) * 3 * N + 1); it is zeroed by a memset in front of the product.
 extern "C" int epc_gemm_f16x3_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
                                     long sAk, long sBk, long sBn, int ldc, int a_scale_log2, int b_scale_log2, float* stats,
                                     size_t stats_floats, float* mean, float* var, void* stream) {
     EPC_CHECK_ARG(a_scale_log2 >= -30 && a_scale_log2 <= 30 && b_scale_log2 >= -30 && b_scale_log2 <= 30, "scale exponents out of range");
+    EPC_CHECK_ARG(stats_floats >= (size_t)epc_gemm_stats_tiles(M) * 3 * N + 1, "statistics buffer too small (epc_gemm_stats_tiles(M) * 3 * N + 1 floats: the last one is the range word)");
     return gemm_stats_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, stats, stats_floats, mean, var, 4,
                            ldexpf(1.f, a_scale_log2), ldexpf(1.f, b_scale_log2), stream);
 }
@@ -875,10 +896,28 @@ static int gemm_stats_impl(const float* A, const float* B, float* C, const float
     GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, 0, 0, 0, 1, 0, stats, nullptr};
     g.a_scale = a_scale, g.b_scale = b_scale, g.descale = 1.0f / (a_scale * b_scale);
     const bool bigm = M >= 128, bign = N >= 128;
-    if (bigm && bign) launch_gemm_split<2, 2>(g, 1, pieces, st);
-    else if (bigm) launch_gemm_split<2, 1>(g, 1, pieces, st);
-    else if (bign) launch_gemm_split<1, 2>(g, 1, pieces, st);
-    else launch_gemm_split<1, 1>(g, 1, pieces, st);
+    auto launch = [&](const GemmArgs& ga, int pc) {
+        if (bigm && bign) launch_gemm_split<2, 2>(ga, 1, pc, st);
+        else if (bigm) launch_gemm_split<2, 1>(ga, 1, pc, st);
+        else if (bign) launch_gemm_split<1, 2>(ga, 1, pc, st);
+        else launch_gemm_split<1, 1>(ga, 1, pc, st);
+    };
+    if (pieces == 4) {   // split-fp16 with the range guard: flag word = the last float of `stats`
+        g.range_flag = reinterpret_cast<unsigned int*>(stats + (size_t)tiles * 3 * N);
+        g.flag_mode = 1;
+        if (hipMemsetAsync(g.range_flag, 0, sizeof(unsigned int), st) != hipSuccess) {
+            epc_set_error("epc_gemm_f16x3_stats: hipMemsetAsync failed");
+            return EPC_EHIP;
+        }
+        launch(g, 4);
+        EPC_CHECK_LAUNCH();
+        GemmArgs f = g;   // the six-product form in float32's range, run only when the word is set
+        f.a_scale = f.b_scale = f.descale = 1.f;
+        f.flag_mode = 2;
+        launch(f, 3);
+    } else {
+        launch(g, pieces);
+    }
     EPC_CHECK_LAUNCH();
     launch_moments_finalize(stats, tiles, N, M, M >= 128 ? 128 : 64, bias, mean, var, st);
     EPC_CHECK_LAUNCH();

@@ -64,11 +64,13 @@ class DistillStep(TrainStep):
             soft_s = out_vecs.reshape(-1, out_vecs.shape[-1])
             loss_q = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
                                                      p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))     # :371
-        red = torch.sum if self.loss_type == "square_error_sum" else torch.mean
-        loss_soft = red((soft_s - soft_t) ** 2)
+        from . import ops
+        mean = self.loss_type == "square_error_mean"
+        soft_s = soft_s.reshape(soft_t.shape)
+        loss_soft = ops.SquaredError.apply(soft_s, soft_t, mean)                                        # :376 / :382
         if fea_t is not None:
-            d = fea_s - fea_t if self.gamma != 0.0 else (fea_s.detach() - fea_t)
-            loss_fea = red(d ** 2)
+            # GAMMA == 0: the term carries no gradient (logged only) -- detach, so that no (rows, 1024) gradient is formed
+            loss_fea = ops.SquaredError.apply(fea_s if self.gamma != 0.0 else fea_s.detach(), fea_t, mean)   # :380 / :383
         else:
             loss_fea = torch.zeros((), device=soft_s.device)
         loss = loss_q * self.beta + loss_soft * self.alpha + loss_fea * self.gamma                      # :387

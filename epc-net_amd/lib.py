@@ -25,7 +25,8 @@ EPC_KNN_SELECT = 20
 EPC_KNN_CAP = 32
 EPC_ERANGE = -5
 STATUS_NAMES = {0: "EPC_OK", -1: "EPC_EINVAL", -2: "EPC_ENOMEM", -3: "EPC_EHIP", -4: "EPC_ENOTFOUND", -5: "EPC_ERANGE"}
-# epc_cfg.precision (include/epcnet.h): f32-equivalent split-bf16 arithmetic / EPC-Net's f16 + f6 fast arithmetic
+# epc_cfg.precision (include/epcnet.h): f32-equivalent arithmetic (conv layers scaled split-fp16 x3, assignment / aggregate
+# split-bf16 x3, f32 tensors in HBM except the 3-byte `feat` map) / EPC-Net's f16 + f6 fast arithmetic
 EPC_PRECISION_F32 = 0
 EPC_PRECISION_FAST = 1
 PRECISION_IDS = {"f32": EPC_PRECISION_F32, "fast": EPC_PRECISION_FAST}
@@ -47,7 +48,7 @@ EXPORTS = [
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
     "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64", "epc_gate_fwd",
-    "epc_gate_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
+    "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -160,6 +161,10 @@ _lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
 _lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_gate_fwd.argtypes = [_P, _P, ctypes.c_long, _P, _P]
 _lib.epc_gate_bwd.argtypes = [_P, _P, _P, ctypes.c_long, _P, _P, _P]
+_lib.epc_sq_err_partial_floats.restype = c_size_t
+_lib.epc_sq_err_partial_floats.argtypes = [c_long]
+_lib.epc_sq_err_fwd.argtypes = [_P, _P, c_long, c_int, _P, _P, c_size_t, _P]
+_lib.epc_sq_err_bwd.argtypes = [_P, _P, c_long, c_int, _P, _P, _P]
 _lib.epc_adam_step.argtypes = [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_int, _P]
 _lib.epc_adam_step_dev.argtypes = [_P, _P, _P, _P, c_long, _P, c_float, c_float, c_float, _P]
 _lib.epc_ema_update.argtypes = [_P, _P, c_long, c_float, _P, _P]

@@ -63,7 +63,8 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
             # x1 = matmul(dpist, x) / k; t = conv_b(conv_a(x1 - x)); t + x1: one node in training (tf_util.proxyconv_tail)
             inp = tf_util.proxyconv_tail(x, dpist, k, 'conv%d_a' % b, 'conv%d_b' % b, bn_decay=bn_decay, is_training=is_training)
             outs.append(inp)
-        x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
+        with tf_util.bounded_operands(ops.F16X3_CONV5):                  # conv5: BatchNorm'd block outputs against its weights
+            x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
         feats = x
         x = x.unsqueeze(2)                                               # :88
     with variable_scope('VLAD'):

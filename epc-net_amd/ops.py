@@ -209,9 +209,11 @@ class BatchNormTrain(torch.autograd.Function):
 # outputs against its weights) and the VLAD assignment (l2-normalised features against the cluster weights) -- take the
 # split-fp16 three-product arithmetic (epc_gemm_f16x3_stats: 2^-22 per product, half the matrix work of the six-product form).
 # (operand scale exponents: activations, weights)
+# A scaled value beyond fp16's range (or a NaN / Inf) makes the library recompute the product in the six-product form, in the same
+# stream (epc_gemm_f16x3_stats' range guard): nothing is clamped silently.
 _FWD_F16X3 = True
-F16X3_CONV5 = (8, 12)      # |block output| < 2^7 (clamped beyond), |w| < 2^3
-F16X3_ASSIGN = (14, 12)    # |f| <= 1, |w| < 2^3
+F16X3_CONV5 = (8, 12)      # block outputs below 2^8 = 256 and |w| < 2^4 = 16 take the fast form
+F16X3_ASSIGN = (14, 12)    # |f| <= 1, |w| < 2^4
 
 
 def set_forward_f16x3(on: bool) -> bool:
@@ -235,7 +237,7 @@ def _gemm_with_stats(x, W, b, f16x3=None):
                                            z.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
         return z, mean, var
     tiles = L.lib().epc_gemm_stats_tiles(rows)
-    stats = torch.empty(tiles * 3 * cout, dtype=torch.float32, device=x.device)   # per row tile: sum, sum of squares, pivot
+    stats = torch.empty(tiles * 3 * cout + 1, dtype=torch.float32, device=x.device)   # per row tile: sum, sum of squares, pivot (+ the f16x3 range word)
     if f16x3 is not None and _FWD_F16X3:
         L.check(L.lib().epc_gemm_f16x3_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
                                              rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
@@ -261,9 +263,11 @@ class LinearBatchNormTrain(torch.autograd.Function):
     training-mode BatchNorm is exactly zero and is not computed."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm):
+    def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm, f16x3=None):
         x = x.contiguous()
-        z, mean, var = _gemm_with_stats(x, W, b, F16X3_CONV5 if W.shape[1] == 1024 else None)   # conv5 of either network
+        # f16x3: the (activation, weight) scale exponents of the split-fp16 form, passed by the call site that knows its operands
+        # are BatchNorm'd block outputs (conv5 of either network: tf_util.conv1d_l2_normalized / conv1d with 1024 outputs)
+        z, mean, var = _gemm_with_stats(x, W, b, f16x3)
         rows, C = z.shape
         if rownorm:
             y = torch.empty_like(z)
@@ -284,7 +288,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         if dy is None:
-            return (None,) * 8
+            return (None,) * 9
         if ctx.rownorm:
             x, W, z, mean, var, gamma, beta, rn = ctx.saved_tensors
         else:
@@ -296,7 +300,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
             dz, dgamma, dbeta = _bn_relu_rownorm_bwd(dy, z, rn, mean, var, gamma, beta, ctx.eps)
             dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
             dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
-            return dx, dW, None, dgamma, dbeta, None, None, None
+            return dx, dW, None, dgamma, dbeta, None, None, None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
         ws, n = _ws(rows, C, z.device)
@@ -310,14 +314,14 @@ class LinearBatchNormTrain(torch.autograd.Function):
                                                 var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ctx.eps, ctx.relu, rows,
                                                 dx.data_ptr() if dx is not None else None, dW.data_ptr(), dgamma.data_ptr(),
                                                 dbeta.data_ptr(), ws.data_ptr(), n, part.data_ptr(), part.numel(), _st()))
-            return dx, dW, None, dgamma, dbeta, None, None, None
+            return dx, dW, None, dgamma, dbeta, None, None, None, None
         dz = torch.empty_like(z)
         L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                          beta.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(),
                                          dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, _st()))
         dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
-        return dx, dW, None, dgamma, dbeta, None, None, None
+        return dx, dW, None, dgamma, dbeta, None, None, None, None
 
 
 class BatchNormReluRowNorm(torch.autograd.Function):
@@ -756,6 +760,34 @@ class GateMul(torch.autograd.Function):
         L.check(L.lib().epc_gate_bwd(dout.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), dy.data_ptr(), dg.data_ptr(),
                                      _st()))
         return dy, dg
+
+
+class SquaredError(torch.autograd.Function):
+    """square_error_sum / square_error_mean (kd_train.py:330-340) of the student's tensor ``a`` against the teacher's ``b``:
+    sum (or mean) of (a - b)^2 in one read of both (epc_sq_err_fwd); only ``a`` gets a gradient (the reference feeds the
+    teacher's outputs through placeholders, kd_train.py:786-790)."""
+
+    @staticmethod
+    def forward(ctx, a, b, mean):
+        a, b = a.contiguous(), b.detach().contiguous()
+        assert a.shape == b.shape and a.dtype == torch.float32 and b.dtype == torch.float32
+        n = a.numel()
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        pf = L.lib().epc_sq_err_partial_floats(n)
+        part = _splitk_ws(pf, a.device)
+        L.check(L.lib().epc_sq_err_fwd(a.data_ptr(), b.data_ptr(), n, int(bool(mean)), loss.data_ptr(), part.data_ptr(),
+                                       part.numel(), _st()))
+        ctx.save_for_backward(a, b)
+        ctx.mean = int(bool(mean))
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a)
+        dloss = dloss.contiguous().float()
+        L.check(L.lib().epc_sq_err_bwd(a.data_ptr(), b.data_ptr(), a.numel(), ctx.mean, dloss.data_ptr(), da.data_ptr(), _st()))
+        return da, None, None
 
 
 def morton_sort(xyz):

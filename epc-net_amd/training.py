@@ -186,6 +186,14 @@ class TrainStep:
             tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9, scope=self.outer or None)
         return loss, grads
 
+    def _lr_t(self, lr: float, t: int) -> float:
+        """Adam's bias-corrected rate exactly as epc_adam_multi forms it from its float arguments (csrc/train_ops.hip:
+        (double)lr * sqrt(1 - pow((double)beta2, t)) / (1 - pow((double)beta1, t)), lr / beta1 / beta2 passed as C floats), so that
+        a replayed graph (device-resident rate) and an eager step (rate formed by the library) apply the same bits."""
+        import numpy as np
+        f = lambda v: float(np.float32(v))
+        return f(lr) * math.sqrt(1.0 - f(self.beta2) ** t) / (1.0 - f(self.beta1) ** t)
+
     def _apply(self, grads, lr, t) -> None:
         """tf.train.AdamOptimizer(learning_rate).minimize (train.py:273-277): all 62 updates in one launch."""
         names = self.trainable_names()
@@ -239,18 +247,16 @@ class TrainStep:
 
     def _average_over_ranks(self, grads):
         """Data parallelism over tuples: one flat all-reduce of the gradients and of the BatchNorm moving
-        statistics this step updated, so that every rank applies the same update.  Returns the averaged gradients (the
-        input list is averaged in place as well).  Single process without force_collective: nothing to do."""
+        statistics this step updated, so that every rank applies the same update.  Returns the averaged gradients (views of
+        the flat exchange buffer; the input list is left as it is).  Single process without force_collective: the input list."""
         from . import distributed as D
         if not D.collectives_active():
             return grads
         import torch.distributed as dist
         ex = self._pack(grads)
         dist.all_reduce(ex["flat"], op=dist.ReduceOp.SUM)
-        avg = self._unpack_mean(ex, D.world()[1])
-        with torch.no_grad():
-            torch._foreach_copy_(list(grads), avg)
-        return avg
+        return self._unpack_mean(ex, D.world()[1])     # views of the exchange buffer: what Adam consumes (no copy back:
+        #                                                `grads` may hold shared read-only zero tensors, ops.const_zeros_like)
 
     # -- HIP-graph replay ------------------------------------------------------------------------------------------------
     def _state_tensors(self):
@@ -274,7 +280,7 @@ class TrainStep:
                  "bn_decay": torch.zeros((), dtype=torch.float32, device=dev)}
             for dst, src in zip(g["in"], inputs):
                 dst.copy_(src)
-            g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
+            g["lr_t"].fill_(self._lr_t(lr, t))
             g["bn_decay"].fill_(bn_decay)
             # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored.
             # No collective here: every rank restores its own snapshot, so the ranks stay in step.
@@ -312,7 +318,7 @@ class TrainStep:
         else:
             for dst, s_ in zip(g["in"], inputs):
                 dst.copy_(s_)
-        g["lr_t"].fill_(lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t))
+        g["lr_t"].fill_(self._lr_t(lr, t))
         g["bn_decay"].fill_(bn_decay)
         g["graph"].replay()
         if dp:

@@ -167,13 +167,33 @@ def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope):
     return batch_norm_template(inputs, is_training, scope, [0, 1], bn_decay)
 
 
-def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=False):
+# A call site that KNOWS its layer's operands are bounded by construction (conv5: BatchNorm'd block outputs against its weights)
+# wraps the call in ``bounded_operands((activation, weight) scale exponents)``: the fused Linear + BatchNorm node then takes the
+# split-fp16 three-product arithmetic (ops.F16X3_CONV5; epc_gemm_f16x3_stats, guarded against values that leave its range).  Never
+# inferred from a layer's width.
+_F16X3_HINT = None
+
+
+class bounded_operands:
+    def __init__(self, exps):
+        self.exps = exps
+
+    def __enter__(self):
+        global _F16X3_HINT
+        self.prev, _F16X3_HINT = _F16X3_HINT, self.exps
+
+    def __exit__(self, *exc):
+        global _F16X3_HINT
+        _F16X3_HINT = self.prev
+
+
+def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=False, f16x3=None):
     """Linear + training-mode BatchNorm (+ReLU, + conv5's row norm) as one autograd node whose batch statistics come from the
     GEMM's epilogue (ops.LinearBatchNormTrain), with the moving-average updates of batch_norm_template."""
     from .. import ops
     C = int(w2d.shape[1])
     beta, gamma, ema_mean, ema_var = _bn_variables(scope_bn, C)
-    y, mean, var = ops.LinearBatchNormTrain.apply(inputs2d, w2d, b, gamma, beta, 1e-3, int(relu_flag), bool(rownorm))
+    y, mean, var = ops.LinearBatchNormTrain.apply(inputs2d, w2d, b, gamma, beta, 1e-3, int(relu_flag), bool(rownorm), f16x3)
     decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
     _ema_update(ema_mean, mean, decay)
     _ema_update(ema_var, var, decay)
@@ -204,7 +224,7 @@ def _dense_impl(inputs2d, w2d, b, bn, scope_bn, activation_fn, bn_decay, is_trai
     if activation_fn not in (None, relu):
         raise NotImplementedError("only activation_fn=tf.nn.relu / None are used by EPC-Net")
     if bn and is_training and ops.fused_linear_bn_ok(int(inputs2d.shape[0]), int(w2d.shape[0]), int(w2d.shape[1])):
-        return _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, want_relu)
+        return _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, want_relu, f16x3=_F16X3_HINT)
     z = ops.Linear.apply(inputs2d, w2d, b, bool(bn and is_training))
     if bn:
         return batch_norm_template(z, bool(is_training), scope_bn, None, bn_decay, activation_relu=want_relu)
@@ -276,7 +296,8 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     with variable_scope(scope):
         x2 = inputs.reshape(-1, cin)
         if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
-            f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True)
+            f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True,
+                                f16x3=ops.F16X3_CONV5)      # conv5: BatchNorm'd block outputs against its weights
             _tap_relu_mask(f)          # (the row norm is a positive factor: f > 0 exactly where the ReLU's output is)
             return f
         z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)

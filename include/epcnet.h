@@ -40,10 +40,22 @@ typedef enum epc_status {
 
 /* Arithmetic of the inference path (epc_cfg.precision).  The reference computes in float32 (models/epc-net.py:24-26
  * tf.placeholder(tf.float32 ...), every op of utils/tf_util.py:52-107).
- *   EPC_PRECISION_F32  f32-equivalent: every dense contraction runs on the bf16 MFMA with BOTH operands split
- *                      hi = bf16(x), lo = bf16(x - hi) and three products (lo*hi + hi*lo + hi*hi, f32 accumulate: 2^-16
- *                      relative per product); every tensor that crosses HBM is float32.  No range restriction beyond
- *                      float32's.  EPC-Net-L always runs in this arithmetic.
+ *   EPC_PRECISION_F32  f32-equivalent (the default; EPC-Net-L always).  Every dense contraction is a SPLIT product on the
+ *                      16-bit matrix pipe with f32 accumulation -- three MFMA products (lo*hi + hi*lo + hi*hi) per algorithmic one:
+ *                        - the conv layers (the 64 -> 64 layers of the ProxyConv blocks, conv5 of both models): SCALED split-fp16
+ *                          ("f16x3").  Every row of the activation operand and every column of the BN-folded weight operand is
+ *                          multiplied by a power of two that brings its largest magnitude into [2^14, 2^15) (exact), then split
+ *                          hi = fp16(v), lo = fp16(v - hi): 22 significant bits, no range restriction beyond float32's; the
+ *                          accumulator is un-scaled by inv_row * inv_col in the epilogue.  2^-21 relative per product;
+ *                        - the soft assignment (feat . cluster_weights) and the VLAD aggregate (assign^T . feat): split-bf16
+ *                          ("bf16x3": hi = bf16(v), lo = bf16(v - hi); bf16 keeps float32's range, which the un-normalised
+ *                          features need).  2^-16 relative per product, on operands the later normalisations average;
+ *                        - conv1 (3 -> 64), the kNN distances, every normalisation, sum and the head: float32 VALU arithmetic.
+ *                      Tensors that cross HBM between stages are float32, with ONE exception inside the pipeline: `feat`, the
+ *                      (points, 1024) conv5 map between epc_conv5_assign_f32_fwd and epc_vlad_aggregate_f32_fwd, is stored as
+ *                      3-byte values (the upper 24 bits of the float32, rounded) -- the 16 significant bits its only reader
+ *                      keeps when it splits into bf16 hi + lo.  Measured 2-3e-7 from the float32 oracle on ordinary weights,
+ *                      <= 1e-4 on the adversarial set (tests/test_gpu_adversarial.py).
  *   EPC_PRECISION_FAST EPC-Net only: one fp16 value per activation, weights fp16 hi + MX-fp6 lo, fp16 tensors in HBM
  *                      (DESIGN.md 2).  Folded weights must satisfy |W' * 256| <= 65504 (checked by
  *                      epc_net_pack_weights: EPC_ERANGE) and activations must stay inside fp16's range (checked by the
@@ -52,7 +64,7 @@ typedef enum epc_status {
 #define EPC_PRECISION_F32 0
 #define EPC_PRECISION_FAST 1
 
-/* Per-cloud status bits (int32 per cloud; epc_net_forward keeps them in its workspace and epc_net_forward_status copies
+/* Per-cloud status bits (int32 per cloud; epc_net_forward keeps them in its workspace and epc_net_last_status copies
  * them out).  A cloud with a non-zero status gets a NaN descriptor: the reference returns NaN for a cloud with a NaN/Inf
  * coordinate as well (every a_ij of utils/tf_util.py:651-656 involving the point is NaN). */
 #define EPC_STATUS_NONFINITE_INPUT 1 /* a coordinate of the cloud is NaN or +-Inf                                 */
@@ -182,7 +194,8 @@ int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* i
  *   x_next = conv_{b+1}(out) (when has_next).
  * `out` is written with row stride `out_stride` elements at column offset `out_off` (the concat buffer of
  * models/epc-net.py:134).  Two forms, selected by x16 and matching the arch the weights were packed for:
- *   x16 == NULL (EPC-Net-L pack): f32 rows x -> out, x_next (f32); split-bf16 (x3) MFMA layers, f32-accurate.
+ *   x16 == NULL (f32-equivalent pack of either model): f32 rows x -> out, x_next (f32); scaled split-fp16 (f16x3) MFMA
+ *     layers, f32-accurate (EPC_PRECISION_F32 above).
  *   x16 != NULL (EPC-Net pack):   fp16 rows x16 -> out16, x_next16 (fp16; x, out, x_next are ignored): every tensor that
  *     crosses HBM is fp16 and every MFMA operand is one fp16 value per activation against fp16 hi+lo weights; sums,
  *     mean, xm - x, t + xm and the accumulators are f32.  The roundings are independent per point and channel and
@@ -470,6 +483,15 @@ int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out,
 /* Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout * s, dg = dout * y * s * (1 - s). */
 int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
 int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, float* dy, float* dg, void* stream);
+
+/* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
+ * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials
+ * added in a fixed order (bit-reproducible).  bwd: da = 2 (a - b) dloss[0] (/ n); b -- the teacher's output, fed through a
+ * placeholder in the reference -- has no gradient.  a, b, da 16-byte aligned; partials: epc_sq_err_partial_floats(n) floats. */
+size_t epc_sq_err_partial_floats(long n);
+int epc_sq_err_fwd(const float* a, const float* b, long n, int mean, float* loss, float* partials, size_t partial_floats,
+                   void* stream);
+int epc_sq_err_bwd(const float* a, const float* b, long n, int mean, const float* dloss, float* da, void* stream);
 
 /* tf.train.AdamOptimizer.apply (train.py:273): t = 1-based step count for the bias correction. */
 int epc_adam_step(float* w, float* m, float* v, const float* g, long n, float lr, float beta1, float beta2, float eps,

@@ -36,6 +36,46 @@ def _l2n(x, dim):
     return x * torch.rsqrt(torch.clamp(ss, min=O.L2_EPS))
 
 
+def _round_bf16(t):
+    """Round to the nearest bf16 value (ties to even), keep the dtype."""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def bf16_product_rule(M: int, N: int, K: int) -> bool:
+    """Which products of the "bf16" training arithmetic (BASELINE.json configs[2]; params["TRAIN_PRECISION"] = "bf16") round
+    their operands to bf16: the ones the matrix-pipe GEMM kernel takes -- every side at least 64 (K at least 32).  Products with
+    at most 32 rows (the 18-row gating / fc layers) and K = 3 (conv1) are computed in float32 by their own small kernels."""
+    return M >= 64 and N >= 64 and K >= 32
+
+
+class _RoundedMatmul(torch.autograd.Function):
+    """C = A @ B (2-D, or 3-D with a leading batch dimension) with the operands of every product rounded to bf16 where
+    ``bf16_product_rule`` says so, forward AND backward (dA = dC B^T, dB = A^T dC each round their own two operands): the
+    arithmetic of a training step whose GEMMs take one bf16 value per operand and accumulate in float32 -- restated in the
+    oracle's dtype, so that what is left between it and the HIP step is accumulation order."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        M, K, N = A.shape[-2], A.shape[-1], B.shape[-1]
+        if bf16_product_rule(M, N, K):
+            return torch.matmul(_round_bf16(A), _round_bf16(B))
+        return torch.matmul(A, B)
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        M, K, N = A.shape[-2], A.shape[-1], B.shape[-1]
+        r = lambda t, on: _round_bf16(t) if on else t
+        on_a = bf16_product_rule(M, K, N)          # dA (M, K) = dC (M, N) @ B^T (N, K)
+        dA = torch.matmul(r(dC, on_a), r(B, on_a).transpose(-1, -2))
+        on_b = bf16_product_rule(K, N, M)          # dB (K, N) = A^T (K, M) @ dC (M, N)
+        dB = torch.matmul(r(A, on_b).transpose(-1, -2), r(dC, on_b))
+        if B.dim() == 2 and dB.dim() == 3:
+            dB = dB.sum(0)
+        return dA, dB
+
+
 class TorchOracle:
     def __init__(self, weights: Dict[str, np.ndarray], arch="epc-net", params=None, dtype=torch.float64,
                  outer="query_triplets"):
@@ -57,6 +97,14 @@ class TorchOracle:
         # chosen otherwise.
         self.relu_masks: Optional[Dict[str, np.ndarray]] = None
         self.relu_mask_disagreement: Dict[str, int] = {}
+        # "bf16": every dense product rounds its operands to bf16 where the HIP step's bf16 arithmetic does (_RoundedMatmul)
+        self.gemm_rounding: Optional[str] = None
+
+    def _mm(self, A, B):
+        """A (rows, K) @ B (K, N) (or batched 3-D @ 3-D) in the step's GEMM arithmetic."""
+        if self.gemm_rounding == "bf16":
+            return _RoundedMatmul.apply(A, B)
+        return torch.matmul(A, B)
 
     def _relu(self, y, scope):
         if self.relu_masks is None or scope not in self.relu_masks:
@@ -80,7 +128,8 @@ class TorchOracle:
 
     def conv1d(self, x, scope, training, bn_decay):
         W = self.w[scope + "/weights"]
-        z = x @ W.reshape(W.shape[-2], W.shape[-1]) + self.w[scope + "/biases"]
+        z = self._mm(x.reshape(-1, x.shape[-1]), W.reshape(W.shape[-2], W.shape[-1])).reshape(
+            tuple(x.shape[:-1]) + (W.shape[-1],)) + self.w[scope + "/biases"]
         return self._relu(self._tfutil_bn(z, scope, (0, 1), training, bn_decay), scope)
 
     def _slim_bn(self, x, scope, training, fused):
@@ -98,7 +147,9 @@ class TorchOracle:
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward(self, point_cloud: np.ndarray, is_training: bool, bn_decay: Optional[float] = None,
-                mask: Optional[np.ndarray] = None) -> torch.Tensor:
+                mask: Optional[np.ndarray] = None, return_features: bool = False):
+        """``return_features``: the KD variants' second output (models/kd_epc-net.py:158, models/kd_epc-net-l.py:102):
+        (l2_normalize(conv5 output reshaped to (-1, 1024), 1), descriptors), rows in the INPUT point order."""
         B, P, N, D = point_cloud.shape
         pc32 = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(B * P, N, D)
         if mask is None:
@@ -118,25 +169,28 @@ class TorchOracle:
             inp = t + xm
             outs.append(inp)
         x = self.conv1d(torch.cat(outs, dim=-1), "fastdgcnn/conv5", tr, bd)
+        features = _l2n(x.reshape(-1, 1024), 1) if return_features else None
         if self.arch == "epc-net":
             G = self.p["GROUPS"]
             f = _l2n(x.reshape(-1, 1024), 1)
-            act = f @ self.w["VLAD/cluster_weights"]
+            act = self._mm(f, self.w["VLAD/cluster_weights"])
             act = torch.softmax(self._slim_bn(act, "VLAD/cluster_bn", tr, fused=False), dim=1).reshape(-1, N, 64)
             a_sum = act.sum(dim=-2, keepdim=True)
             a = a_sum * self.w["VLAD/cluster_weights2"]
-            vlad = torch.matmul(act.transpose(1, 2), f.reshape(-1, N, 1024)).transpose(1, 2) - a
+            # (the HIP step forms vlad[b] = f[b]^T @ act[b] directly: the product whose shape the rounding rule sees)
+            vlad = self._mm(f.reshape(-1, N, 1024).transpose(1, 2), act) - a
             vlad = _l2n(vlad, 1).reshape(-1, 64 * 1024)
             vlad = _l2n(vlad, 1)
-            y = vlad.reshape(-1, 65536 // G) @ self.w["VLAD/hidden1_weights"]
+            y = self._mm(vlad.reshape(-1, 65536 // G), self.w["VLAD/hidden1_weights"])
             y = self._slim_bn(y, "VLAD/bn", tr, fused=True).reshape(-1, G, 256).sum(dim=-2)
-            gates = torch.sigmoid(self._slim_bn(y @ self.w["VLAD/gating_weights"], "VLAD/gating_bn", tr, fused=True))
+            gates = torch.sigmoid(self._slim_bn(self._mm(y, self.w["VLAD/gating_weights"]), "VLAD/gating_bn", tr, fused=True))
             out = y * gates
         else:
             net = x.max(dim=1).values
-            z = net @ self.w["VLAD/fc1/weights"] + self.w["VLAD/fc1/biases"]
+            z = self._mm(net, self.w["VLAD/fc1/weights"]) + self.w["VLAD/fc1/biases"]
             out = self._relu(self._tfutil_bn(z, "VLAD/fc1", (0,), tr, bd), "VLAD/fc1")
-        return _l2n(out, 1).reshape(B, P, self.p["FEATURE_OUTPUT_DIM"])
+        out = _l2n(out, 1).reshape(B, P, self.p["FEATURE_OUTPUT_DIM"])
+        return (features, out) if return_features else out
 
 
 def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
@@ -150,13 +204,14 @@ def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
 def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, other_neg, step: int, epoch: int,
                adam_m: Optional[Dict[str, np.ndarray]] = None, adam_v: Optional[Dict[str, np.ndarray]] = None,
                arch="epc-net", params=None, m1=0.5, m2=0.2, base_lr=5e-5, batch_num_queries=1, dtype=torch.float64,
-               relu_masks: Optional[Dict[str, np.ndarray]] = None):
+               relu_masks: Optional[Dict[str, np.ndarray]] = None, gemm_rounding: Optional[str] = None):
     """One reference training step (train.py:251-277, 484-495): returns dict(loss, grads, new_weights, adam_m, adam_v).
 
     ``step`` = value of the global-step variable BEFORE the step (``batch``, train.py:246): bn_decay is evaluated with
     it; Adam's bias correction uses t = step + 1 (TensorFlow's beta*_power are multiplied after each apply)."""
     orc = TorchOracle(weights, arch, params, dtype)
     orc.relu_masks = relu_masks        # None = the reference's relu; a dict pins the masks (see TorchOracle.__init__)
+    orc.gemm_rounding = gemm_rounding  # None = exact products; "bf16" = the configs[2] arithmetic (TorchOracle.__init__)
     vecs = np.concatenate([query, positives, negatives, other_neg], axis=1)          # train.py:252
     bn_decay = O.get_bn_decay(step, batch_num_queries)
     out = orc.forward(vecs, True, bn_decay)
@@ -183,3 +238,52 @@ def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, othe
     return {"loss": float(loss.detach()), "grads": g_out, "new_weights": new_w, "adam_m": am, "adam_v": av,
             "lr": lr, "bn_decay": bn_decay, "descriptors": out.detach().numpy(),
             "relu_mask_disagreement": dict(orc.relu_mask_disagreement)}
+
+
+def distill_step(teacher_weights: Dict[str, np.ndarray], student_weights: Dict[str, np.ndarray], query, positives, negatives,
+                 other_neg, alpha: float = 0.1, beta: float = 1.0, gamma: float = 0.0, loss_type: str = "square_error_sum",
+                 step: int = 0, teacher_arch="epc-net", student_arch="epc-net-l", params=None, m1=0.5, m2=0.2,
+                 batch_num_queries=1, dtype=torch.float64, relu_masks: Optional[Dict[str, np.ndarray]] = None,
+                 mask: Optional[np.ndarray] = None):
+    """One distillation step of the reference up to the gradients (kd_train.py:255-425, configs/epc-net-l-d.yaml):
+
+      teacher (kd_train.py:262-279): ``out_fea, out_vecs = MODEL_teacher.forward(vecs, is_training=False)`` -- fed False at
+        :762 "always False" -- soft_label = reshape(out_vecs, [-1, 256]); its outputs reach the student graph through
+        placeholders (:786-790), so nothing flows back into the teacher;
+      student (:355-387): ``out_fea_student, out_vecs = MODEL_student.forward(vecs, is_training=True, bn_decay)``;
+        loss_q = lazy_quadruplet_loss(split(out_vecs), MARGIN_1, MARGIN_2) (:371);
+        square_error_sum (:330-331, :376-380): loss_soft = sum((soft_s - soft_t)^2), loss_fea = sum((fea_s - fea_t)^2);
+        square_error_mean (:336-337, :381-383): the same with means;  any other LOSS_TYPE leaves loss_fea undefined (:387);
+        loss = loss_q * beta + loss_soft * alpha + loss_fea * gamma (:387);  minimize over the student's variables (:401-403).
+
+    Returns dict(loss, loss_q, loss_soft, loss_fea, grads {student name: array}, descriptors, relu_mask_disagreement).
+    Weight names are the oracle's (relative to ``query_triplets``) for both models.  ``relu_masks`` pins the STUDENT's ReLU
+    masks (TorchOracle.__init__); ``mask``: the kNN mask of the tuple (both models share the clouds), computed when None."""
+    if loss_type not in ("square_error_sum", "square_error_mean"):
+        raise NameError("name 'loss_fea' is not defined")
+    vecs = np.concatenate([query, positives, negatives, other_neg], axis=1)
+    B, P, N, D = vecs.shape
+    if mask is None:
+        mask = O.pairwise_distance_mask(np.ascontiguousarray(vecs, dtype=np.float32).reshape(B * P, N, D))
+    teacher = TorchOracle(teacher_weights, teacher_arch, params, dtype)
+    with torch.no_grad():
+        fea_t, out_t = teacher.forward(vecs, False, None, mask=mask, return_features=True)
+    soft_t = out_t.reshape(-1, out_t.shape[-1])
+    student = TorchOracle(student_weights, student_arch, params, dtype)
+    student.relu_masks = relu_masks
+    bn_decay = O.get_bn_decay(step, batch_num_queries)
+    fea_s, out_s = student.forward(vecs, True, bn_decay, mask=mask, return_features=True)
+    npos, nneg = positives.shape[1], negatives.shape[1]
+    q, pos, neg, oth = torch.split(out_s, [1, npos, nneg, 1], dim=1)
+    loss_q = lazy_quadruplet_loss(q, pos, neg, oth, m1, m2)
+    red = torch.sum if loss_type == "square_error_sum" else torch.mean
+    loss_soft = red((out_s.reshape(-1, out_s.shape[-1]) - soft_t) ** 2)
+    loss_fea = red((fea_s - fea_t) ** 2)
+    loss = loss_q * beta + loss_soft * alpha + loss_fea * gamma
+    grads = torch.autograd.grad(loss, [student.w[k] for k in student.trainable], allow_unused=True)
+    g_out = {k: (np.zeros(tuple(student.w[k].shape)) if g is None else g.detach().numpy())
+             for k, g in zip(student.trainable, grads)}
+    return {"loss": float(loss.detach()), "loss_q": float(loss_q.detach()), "loss_soft": float(loss_soft.detach()),
+            "loss_fea": float(loss_fea.detach()), "grads": g_out, "descriptors": out_s.detach().numpy(),
+            "teacher_descriptors": out_t.detach().numpy(), "bn_decay": bn_decay, "new_stats": {k: v.numpy().copy() for k, v in student.new_stats.items()},
+            "relu_mask_disagreement": dict(student.relu_mask_disagreement)}

@@ -33,8 +33,9 @@ def make_store(arch, weights, device):
     return st
 
 
-def make_engine(arch, weights, device="cuda", micro_batch=0, precision="fast", in_flight=None):
-    """`precision`: 'fast' (EPC-Net's f16 + f6 kernels; EPC-Net-L ignores it) / 'f32' (f32-equivalent split arithmetic everywhere)."""
+def make_engine(arch, weights, device="cuda", micro_batch=0, precision=None, in_flight=None):
+    """`precision`: None = the PRODUCT default (engine.py: 'f32', the f32-equivalent split arithmetic) / 'f32' / 'fast' (EPC-Net's
+    f16 + f6 kernels, an explicit opt-in; EPC-Net-L ignores it).  Tests whose subject is the fast path pass 'fast'."""
     E = pkg("engine")
     st = make_store(arch, weights, device)
     return E.InferenceEngine(arch, PARAMS, st, outer=OUTER, micro_batch=micro_batch, precision=precision, in_flight=in_flight), st

@@ -163,7 +163,7 @@ def _sync_worker(rank, ws, port, ret):
         for k, v in st.vars.items():
             if k not in st.trainable:
                 v.add_(float(rank + 1))                    # pretend this step updated the moving statistics differently
-    ts._average_over_ranks(grads)
+    grads = ts._average_over_ranks(grads)                  # (returns the averaged gradients: views of the exchange buffer)
     flat = torch.cat([x.reshape(-1) for x in grads] + [v.detach().reshape(-1) for v in st.vars.values()])
     both = [torch.zeros_like(flat) for _ in range(ws)]
     dist.all_gather(both, flat)
@@ -242,20 +242,24 @@ def _eval_worker(rank, ws, port, ret, force):
     D.force_collective(force)
     dbs, qs, truth = _synthetic_runs()
     tm = {}
-    res = R.evaluate_sharded(_cpu_extract, dbs, qs, (lambda m, n: truth[(m, n)]) if rank == 0 else None,
-                             device=torch.device("cpu"), search=_oracle_search, batch_size=8, timings=tm)
+    # every rank books ITS share of the queries (device-side, integer counters) and the ranks all-reduce the counters: every
+    # rank needs the truth sets, every rank gets the result.  Rank 1 passes the packed form (what repeated evaluations use).
+    tr = (lambda m, n: truth[(m, n)]) if rank == 0 else R.pack_truth(lambda m, n: truth[(m, n)], list(map(len, dbs)), list(map(len, qs)))
+    res = R.evaluate_sharded(_cpu_extract, dbs, qs, tr, device=torch.device("cpu"), search=_oracle_search, batch_size=8,
+                             timings=tm)
     assert tm["clouds_total"] == sum(map(len, dbs)) + sum(map(len, qs))
+    assert tm["reduce_bytes"] == (len(dbs) * len(qs) * 28 + 1) * 8
+    ref = _single_process_reference(dbs, qs, truth)
+    assert np.array_equal(res["ave_recall"], ref["ave_recall"]), (res["ave_recall"], ref["ave_recall"])
+    assert res["ave_one_percent_recall"] == ref["ave_one_percent_recall"]
+    assert res["average_similarity"] == ref["average_similarity"]
+    assert res["ave_recall"][-1] > 20.0            # the synthetic truth really is retrieved: not a vacuous comparison
     if rank == 0:
-        ref = _single_process_reference(dbs, qs, truth)
-        assert np.array_equal(res["ave_recall"], ref["ave_recall"]), (res["ave_recall"], ref["ave_recall"])
-        assert res["ave_one_percent_recall"] == ref["ave_one_percent_recall"]
-        assert res["average_similarity"] == ref["average_similarity"]
-        assert res["ave_recall"][-1] > 20.0            # the synthetic truth really is retrieved: not a vacuous comparison
         for m, d in enumerate(dbs):
             assert np.array_equal(res["database_vectors"][m], _cpu_extract(d).numpy())
         ret.put("ok")
     else:
-        assert res is None
+        assert "database_vectors" not in res
     dist.barrier()
     dist.destroy_process_group()
 
@@ -263,7 +267,8 @@ def _eval_worker(rank, ws, port, ret, force):
 @pytest.mark.parametrize("ws,force", [(2, False), (1, True)])
 def test_evaluate_sharded_equals_single_rank(ws, force):
     """extraction sharded over the ranks -> one all-gather -> every rank ranks its query share -> one
-    index gather -> rank 0 books the recall; the numbers must equal the single-process evaluate_runs bit for bit.
+    all-reduce of the per-pair integer counters each rank booked for ITS queries (no host loop, no serial
+    tail on rank 0); the numbers must equal the single-process evaluate_runs bit for bit ON EVERY RANK.
     (1, True) = a world of one with the collectives forced on: the code path the 1-GPU nccl test takes."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -286,6 +291,46 @@ def test_evaluate_sharded_without_process_group():
     assert np.array_equal(res["ave_recall"], ref["ave_recall"])
     assert res["ave_one_percent_recall"] == ref["ave_one_percent_recall"]
     assert res["average_similarity"] == ref["average_similarity"]
+
+
+def test_sharded_counters_equal_single_rank_counters_and_the_loop_form():
+    """The device-side bookkeeping (retrieval._book_rows) for any split of the queries over ranks: the summed integer counters are
+    those of one rank, and they are the reference-shaped loop's numbers (recall_from_indices_loop) pair by pair -- also with
+    invalid (-1) slots, a database run shorter than 25 rows, truth entries outside the database and a 1 % threshold above 1."""
+    R = H.pkg("retrieval")
+    rng = np.random.RandomState(11)
+    n_db, n_q = [260, 19, 57], [14, 9, 21]
+    unit = lambda n: (lambda v: (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32))(rng.randn(n, 256))
+    dbv, qv = [torch.from_numpy(unit(n)) for n in n_db], [torch.from_numpy(unit(n)) for n in n_q]
+    truth = {(m, n): [list(rng.choice(n_db[m] + 4, size=rng.randint(0, 5), replace=False)) if i else [1]
+                      for i in range(n_q[n])] for m in range(3) for n in range(3)}
+
+    def search(db, q, k):
+        d, i = O.knn_bruteforce(db.numpy(), q.numpy(), min(k, db.shape[0]))
+        i = i.astype(np.int32)
+        i[i % 17 == 3] = -1     # "no such neighbour" slots (a function of the entry, not of the row's position in the call)
+        return torch.from_numpy(d.astype(np.float32)), torch.from_numpy(i)
+
+    packed = R.pack_truth(lambda m, n: truth[(m, n)], n_db, n_q)
+    one, sim1 = R._rank_and_book(dbv, qv, packed, search, 0, 1, torch.device("cpu"))
+    for ws in (2, 3, 5):
+        parts = [R._rank_and_book(dbv, qv, packed, search, r, ws, torch.device("cpu")) for r in range(ws)]
+        assert torch.equal(sum(p[0] for p in parts), one) and int(sum(p[1] for p in parts)) == int(sim1)
+    K = R.NUM_NEIGHBORS
+    sims = []
+    for m in range(3):
+        for n in range(3):
+            if m == n:
+                continue
+            _, ind = search(dbv[m], qv[n], K)
+            rec, sim, opr = R.recall_from_indices_loop(ind.numpy(), dbv[m].numpy(), qv[n].numpy(), truth[(m, n)])
+            c = one[m * 3 + n].numpy()
+            ne = c[K + 1]
+            assert ne == sum(1 for t in truth[(m, n)] if len(t))
+            assert np.array_equal(np.cumsum(c[:K]) / float(ne) * 100, rec) and c[K] / float(ne) * 100 == opr
+            assert c[K + 2] == len(sim)
+            sims.extend(sim)
+    assert abs(int(sim1) / float(1 << R.SIM_FIXED_BITS) - float(np.sum(sims))) < 1e-5
 
 
 def test_all_gather_var_rows_world2_gloo():

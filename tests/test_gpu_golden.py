@@ -49,14 +49,16 @@ def test_g1_knn_graph(dev, kind, n, seed):
     assert np.array_equal(np.bitwise_xor.reduce(np.where(sel, idx, 0), axis=-1)[whole], GOLD[key + "ixor"][whole])
 
 
-def test_g2_proxyconv_block(dev):
+@pytest.mark.parametrize("prec", ["f32", "fast"])
+def test_g2_proxyconv_block(dev, prec):
     w = O.seeded_weights("epc-net", 5)
     pc = O.synthetic_clouds(2, 256, 5, "lidar")
     ref = GOLD["g2/block1"]
-    eng, _ = H.make_engine("epc-net", w, dev)
+    eng, _ = H.make_engine("epc-net", w, dev, precision=prec)
     got = H.run_stages(eng, torch.from_numpy(pc).to(dev))
     blk = got["cat"][..., :64].float().cpu().numpy()
-    assert np.abs(blk - ref).max() <= 1e-3 * np.abs(ref).max()          # fp16 rows (include/epcnet.h)
+    # the default arithmetic keeps f32 rows (2e-5, the stage bar); the fast one fp16 rows (include/epcnet.h)
+    assert np.abs(blk - ref).max() <= (2e-5 if prec == "f32" else 1e-3) * np.abs(ref).max()
     # the f32 operator chain (training / unfused path): neighbour mean and block output at f32 accuracy
     V, tf_util, ops = H.pkg("variables"), H.pkg("utils.tf_util"), H.pkg("ops")
     x = torch.from_numpy(pc).to(dev)

@@ -20,7 +20,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _kd_store(dev, wt, ws):
+def _kd_store(dev, wt, ws, N=N):
     """One store holding the teacher under teacher/query_triplets (fastdgcnn) and the student under
     student/query_triplets (BACKBONE), filled with oracle-named weights."""
     V = H.pkg("variables")
@@ -117,6 +117,80 @@ def test_distill_step(dev):
     assert float(l2) == pytest.approx(float(a2["loss_q"]) + 0.1 * float(a2["loss_soft"]) + 0.5 * float(a2["loss_fea"]), rel=1e-5)
     with pytest.raises(NameError):                                      # kd_train.py:373-387 for LOSS_TYPE "mse"
         KD.DistillStep(dict(params, LOSS_TYPE="mse"), st).compute_loss(q, pos, neg, oth, False, None)
+
+
+@pytest.mark.parametrize("n,gamma,loss_type", [(256, 0.0, "square_error_sum"), (256, 0.5, "square_error_sum"),
+                                               (256, 0.5, "square_error_mean"), (4096, 0.0, "square_error_sum"),
+                                               (4096, 0.5, "square_error_sum")])
+def test_distill_step_matches_the_float64_oracle(dev, n, gamma, loss_type):
+    """the distillation step of kd_train.py:255-425 against its float64 restatement
+    (oracle/epcnet_oracle_torch.distill_step: teacher in inference mode, student in training mode, loss = beta * quadruplet +
+    alpha * soft term + gamma * feature term, gradients of the student's 30 trainable tensors).  Loss terms to 1e-5 relative; with
+    the ReLU masks of the HIP forward pinned in the oracle every student gradient to 1e-3 relative L2 -- at 18 x 256 and at the
+    full 18 x 4096, without (GAMMA 0, the shipped config) and with the feature term."""
+    import epcnet_oracle_torch as T
+    wt, ws = O.seeded_weights("epc-net", 2), O.seeded_weights("epc-net-l", 3)
+    st, _, _ = _kd_store(dev, wt, ws, n)
+    KD, TR, TFU = H.pkg("kd_training"), H.pkg("training"), H.pkg("utils.tf_util")
+    alpha, beta = 0.1, 1.0
+    params = dict(H.PARAMS, ARCH_TEACHER="kd_epc-net", ARCH_STUDENT="kd_epc-net-l", LOSS_TYPE=loss_type, ALPHA=alpha, BETA=beta,
+                  GAMMA=gamma, BATCH_NUM_QUERIES=1, BASE_LEARNING_RATE=1e-3, DECAY_STEP=200000, MARGIN_1=0.5, MARGIN_2=0.2)
+    ds = KD.DistillStep(params, st, feature_loss_when_unused=True)
+    pcs = O.synthetic_clouds(18, n, 5)
+    to = lambda a: torch.from_numpy(a).to(dev)
+    grads = {}
+    orig = H.pkg("ops").adam_multi
+
+    def spy(ws_, ms, vs, gs, lr, t, *a):
+        for w, g in zip(ws_, gs):
+            for k, t_ in st.vars.items():
+                if t_.data_ptr() == w.data_ptr():
+                    grads[k] = g.detach().cpu().numpy().copy()
+        return orig(ws_, ms, vs, gs, lr, t, *a)
+
+    H.pkg("ops").adam_multi = spy
+    TR.ops.adam_multi = spy
+    TFU.RELU_MASK_TAPS = {}
+    try:
+        loss, _, _ = ds.step(to(pcs[None, :1]), to(pcs[None, 1:3]), to(pcs[None, 3:17]), to(pcs[None, 17:]), epoch=1)
+    finally:
+        H.pkg("ops").adam_multi = orig
+        TR.ops.adam_multi = orig
+        masks, TFU.RELU_MASK_TAPS = TFU.RELU_MASK_TAPS, None
+    torch.cuda.synchronize()
+    pre = "student/query_triplets/"
+    masks = {k[len(pre):].replace("BACKBONE/", "fastdgcnn/"): v.cpu().numpy() for k, v in masks.items() if k.startswith(pre)}
+    assert len(masks) == 8, sorted(masks)
+    # the training forward Morton-sorts every cloud (teacher and student alike): the oracle gets the sorted clouds, so that the
+    # pinned masks' rows and the feature rows correspond; the loss and the gradients do not depend on the order
+    srt = H.pkg("ops").morton_sort(to(pcs)).cpu().numpy()[None]
+    ref = T.distill_step(wt, ws, srt[:, :1], srt[:, 1:3], srt[:, 3:17], srt[:, 17:], alpha=alpha, beta=beta, gamma=gamma,
+                         loss_type=loss_type, step=0, relu_masks=masks)
+    aux = ds.last_aux
+    flips = sum(ref["relu_mask_disagreement"].values())
+    total = sum(int(np.prod(m.shape)) for m in masks.values())
+    assert flips <= 2e-5 * total, (flips, total)
+    assert float(aux["loss_q"]) == pytest.approx(ref["loss_q"], rel=2e-5, abs=1e-6)
+    assert float(aux["loss_soft"]) == pytest.approx(ref["loss_soft"], rel=1e-5)
+    assert float(aux["loss_fea"]) == pytest.approx(ref["loss_fea"], rel=1e-5)
+    assert float(loss) == pytest.approx(ref["loss"], rel=1e-5)
+    worst = (0.0, "")
+    assert len(ref["grads"]) == 32
+    for k, g_ref in ref["grads"].items():
+        name = pre + k.replace("fastdgcnn/", "BACKBONE/")
+        g = grads[name].reshape(g_ref.shape)
+        if k.endswith("/biases") and not k.startswith("VLAD/fc1"):
+            assert np.abs(g).max() <= 5e-5          # in front of a training-mode BatchNorm: exactly zero (rounding noise in TF)
+            continue
+        if k == "VLAD/fc1/biases":                  # also in front of a training-mode BatchNorm (utils/tf_util.py:339-344)
+            assert np.abs(g).max() <= 5e-5
+            continue
+        rel_l2 = np.linalg.norm(g - g_ref) / max(np.linalg.norm(g_ref), 1e-30)
+        worst = max(worst, (rel_l2, k))
+        assert rel_l2 <= 1e-3, "mask-pinned student gradient of %s: relative L2 error %.3e" % (k, rel_l2)
+    print("distill step 18x%d gamma %.1f %s: loss terms q %.6f soft %.6f fea %.6f; worst student gradient rel L2 %.2e (%s), "
+          "%d of %d mask elements differ" % (n, gamma, loss_type, ref["loss_q"], ref["loss_soft"], ref["loss_fea"], worst[0],
+                                             worst[1], flips, total))
 
 
 def _dataset(T, n, seed=0):

@@ -612,7 +612,7 @@ def test_plain_c_caller(dev):
 def test_full_size_properties(dev, prec):
     """BASELINE.json configs[1] at full size (64 x 4096 x 3): properties that need no oracle run of that size.
     (a) unit-norm, finite descriptors; (b) a cloud's descriptor does not depend on its batch (bit-identical alone, in a
-    batch of 64, and at another position); (c) kNN lists of sampled queries: ascending, self included, every listed j
+    batch of 64, and at another position); (d) four sampled clouds of the batch against the oracle; (c) kNN lists of sampled queries: ascending, self included, every listed j
     satisfies a_ij >= kth and the count equals |{j : a_ij >= kth}| with a_ij evaluated by the oracle's formula."""
     w = O.seeded_weights("epc-net", 0)
     eng, _ = H.make_engine("epc-net", w, dev, precision=prec)
@@ -624,6 +624,12 @@ def test_full_size_properties(dev, prec):
     assert torch.equal(alone[0], out[17])
     rolled = eng.forward(torch.roll(x, shifts=5, dims=0))
     assert torch.equal(rolled[22], out[17])
+    # (d) four sampled clouds of the 64-batch against the oracle (the whole batch would take the numpy oracle minutes)
+    sel = [0, 17, 40, 63]
+    ref, _ = O.forward(pc[sel][:, None], w, arch="epc-net")
+    err = np.linalg.norm(out[sel].cpu().numpy() - ref.reshape(4, -1), axis=1).max()
+    print("EPC-Net 64 x 4096 (%s): descriptor L2 error on 4 sampled clouds of the batch %.3e" % (prec, err))
+    assert err <= DESC_TOL
     ops = H.pkg("ops")
     tf_util = H.pkg("utils.tf_util")
     srt = ops.morton_sort(x[:4])

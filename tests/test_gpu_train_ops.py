@@ -228,8 +228,10 @@ def test_proxyconv_tail_node(dev, kind, n):
 def test_split_fp16_stats_product(dev, which, rows, cin, cout):
     """ops._gemm_with_stats in the split-fp16 three-product form (epc_gemm_f16x3_stats: conv5 and the VLAD assignment of the
     training forward) against float64: the product to 4e-6 of its largest entry and the moments to 2e-5 over four decades of
-    operand magnitude, as close as the six-product form within a factor of eight; magnitudes beyond fp16's range are clamped
-    (finite output)."""
+    operand magnitude, as close as the six-product form within a factor of eight.  RANGE GUARD: a value that leaves the
+    scaled fp16 range (|x| >= 256 for conv5's activations), an Inf or a NaN makes the library recompute the product in the
+    six-product form inside the same stream -- the outputs are then exactly that form's, NaN rows and statistics included: nothing is
+    clamped to a finite wrong value."""
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(cin)
     scales = ops.F16X3_CONV5 if which == "conv5" else ops.F16X3_ASSIGN
@@ -250,10 +252,24 @@ def test_split_fp16_stats_product(dev, which, rows, cin, cout):
         assert e3 <= 4e-6 and e3 <= max(8 * e6, 5e-7), (which, amp, e3, e6)
         assert rel(m3, ref32.mean(0)) <= 2e-5 and rel(v3, ref32.var(0, unbiased=False)) <= 2e-5
         assert rel(z3, ref) <= 2e-5
-    big = xg.clone()
-    big[0, 0] = 1e9
-    z, _, _ = ops._gemm_with_stats(big, Wg, bg, scales)
-    assert bool(torch.isfinite(z).all())
+    for bad in (1e9, 300.0 if which == "conv5" else 5.0, float("inf"), float("nan")):
+        big = xg.clone()
+        big[7, 3] = bad
+        z, m, v = ops._gemm_with_stats(big, Wg, bg, scales)
+        z6g, m6g, v6g = ops._gemm_with_stats(big, Wg, bg)
+        same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(b, nan=12345.0))
+        assert same(z, z6g) and same(m, m6g) and same(v, v6g), bad
+        if bad != bad:
+            assert bool(torch.isnan(z[7]).all()) and bool(torch.isnan(m).all())       # a NaN reaches the loss
+        elif bad == 1e9:
+            assert float(z[7].abs().max()) > 1e6                                       # not saturated at 255.9
+    bigw = Wg.clone()
+    bigw[3, 5] = 40.0                                                                  # a weight beyond 2^4: the same guard
+    z, m, v = ops._gemm_with_stats(xg, bigw, bg, scales)
+    z6g, m6g, v6g = ops._gemm_with_stats(xg, bigw, bg)
+    assert torch.equal(z, z6g) and torch.equal(m, m6g) and torch.equal(v, v6g)
+    z3b, _, _ = ops._gemm_with_stats(xg, Wg, bg, scales)                               # and the guard leaves no state behind
+    assert torch.equal(z3b, z3)
     prev = ops.set_forward_f16x3(False)
     try:
         z6b, _, _ = ops._gemm_with_stats(xg, Wg, bg, scales)

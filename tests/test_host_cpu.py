@@ -24,6 +24,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L.lib(), name), name
     assert L.lib().epc_version() >= 100
+    # ... and the prose may not name entry points that do not exist (the header spoke of an
+    # `epc_net_forward_status`): every epc_* identifier in the header, comments included, and in the documents a binder reads, is an
+    # exported symbol or one of the header's types
+    types = {"epc_cfg", "epc_status", "epc_profile"}
+    for doc in ("include/epcnet.h", "INTEGRATION.md", "DESIGN.md", "README.md", "epc-net_amd/lib.py", "epc-net_amd/engine.py"):
+        text = open(os.path.join(ROOT, doc)).read()
+        unknown = {n for n in re.findall(r"\bepc_[a-z0-9_]+\b", text) if n not in declared and n not in types}
+        assert not unknown, "%s names entry points the library does not have: %s" % (doc, sorted(unknown))
+    # the precision prose describes the arithmetic the kernels run (csrc/common.h split8_f16s, csrc/conv5_f32.hip)
+    assert "split-fp16" in header and "3-byte" in header and "epc_net_forward_status" not in header
 
 
 def test_cfg_struct_layout_and_sizes():

@@ -130,3 +130,30 @@ def test_get_recall_semantics_against_sklearn():
     assert np.array_equal(rec, rec2) and one == one2 and np.allclose(sim, sim2)
     assert max(int(round(250 / 100.0)), 1) == 2 and max(int(round(50 / 100.0)), 1) == 1  # banker's rounding, :470
     assert rec.shape == (25,) and np.all(np.diff(rec) >= 0)
+
+
+def test_distill_oracle_composition_and_finite_difference():
+    """oracle/epcnet_oracle_torch.distill_step (kd_train.py:255-425): loss = beta * quadruplet + alpha * soft + gamma * feature
+    term with the teacher in inference mode; its autograd gradient of a student weight against a central finite difference of
+    the same float64 function; the teacher gets no gradient by construction (its forward runs under no_grad)."""
+    import epcnet_oracle_torch as T
+    wt, ws = O.seeded_weights("epc-net", 2), O.seeded_weights("epc-net-l", 3)
+    pcs = O.synthetic_clouds(18, 64, 5)
+    tup = (pcs[None, :1], pcs[None, 1:3], pcs[None, 3:17], pcs[None, 17:])
+    for lt in ("square_error_sum", "square_error_mean"):
+        r = T.distill_step(wt, ws, *tup, alpha=0.1, beta=1.0, gamma=0.5, loss_type=lt)
+        assert abs(r["loss"] - (r["loss_q"] + 0.1 * r["loss_soft"] + 0.5 * r["loss_fea"])) < 1e-10
+        soft_s, soft_t = r["descriptors"].reshape(-1, 256), r["teacher_descriptors"].reshape(-1, 256)
+        red = np.sum if lt == "square_error_sum" else np.mean
+        assert abs(r["loss_soft"] - red((soft_s - soft_t) ** 2)) < 1e-9
+    with pytest.raises(NameError):
+        T.distill_step(wt, ws, *tup, loss_type="mse")
+    r = T.distill_step(wt, ws, *tup, gamma=0.5)
+    assert len(r["grads"]) == 32
+    k, idx, eps = "fastdgcnn/conv2_a/weights", (0, 3, 5), 1e-6
+    w2 = {a: b.astype(np.float64).copy() for a, b in ws.items()}
+    w2[k][idx] += eps
+    up = T.distill_step(wt, w2, *tup, gamma=0.5)["loss"]
+    w2[k][idx] -= 2 * eps
+    dn = T.distill_step(wt, w2, *tup, gamma=0.5)["loss"]
+    assert abs((up - dn) / (2 * eps) - r["grads"][k][idx]) < 1e-5 * max(1.0, abs(r["grads"][k][idx]))
