@@ -648,12 +648,7 @@ extern "C" int epc_proxyconv_block_fwd(const float* x, const void* x16, const fl
         // 49-KB weight pack.  So a grid beyond one round is ONE persistent workgroup per CU (154 KB of LDS admit no second
         // one).  Same box, same bits: EPC-Net, 64 clouds: 0.097 -> 0.084 ms per block, step 1.168 -> 1.123 ms; EPC-Net-L,
         // 256 clouds (10.7 rounds): 1.839 -> 1.769 ms.
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            num_cus = v;
-        }
+        const int num_cus = epc_device_cu_count();   // per device id (common.h; ADVICE r3: was one static for the first device seen)
         if (blocks > (unsigned)num_cus && blocks <= (unsigned)BLK_PERSIST_MAX_ROUNDS * (unsigned)num_cus) blocks = (unsigned)num_cus;
     }
     if (f16)

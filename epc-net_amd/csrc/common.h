@@ -137,6 +137,19 @@ __host__ __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
 }
 
 void epc_set_error(const char* fmt, ...);
+// Compute units of the CURRENT device, cached per device id (a read-mostly table of ints: a racing first call writes the same
+// value twice).  256 when the query fails.
+static inline int epc_device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cus[dev];
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return v;
+}
 // library-internal launchers (not part of the C ABI)
 int epc_conv1_launch(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
                      int32_t* status, int n, void* stream);

@@ -264,23 +264,27 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
                                                 u32x4 (*dst)[2][PieceCount<PIECES>::value][64], int tid, float scale = 1.f,
                                                 bool* out_of_range = nullptr) {
     constexpr int ROWS = 32 * BLOCKS;
-    bool bad = false;
+    unsigned carry = 0;
 #pragma unroll
     for (int u = 0; u < (ROWS * 4) / 256; ++u) {
         const int f = tid + 256 * u;
         const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
         const int l2 = (row & 31) + 32 * (kg & 1);
         if constexpr (PIECES == 4) {
+            // No clamp: a scaled value beyond fp16's range becomes +-Inf in hi (and NaN in lo), a NaN stays NaN -- the product is then
+            // garbage, the range word is set and the six-product kernel behind recomputes everything (range guard, below).  Detected on
+            // the packed halves, two per dword: an exponent field of all ones (0x7C00) carries into the sign position when 0x0400 is added.
             f16x8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float raw = v[u][j] * scale;
-                bad |= !(fabsf(raw) <= 65504.f);      // beyond fp16's range, or NaN (fmaxf / fminf would turn a NaN into a finite value)
-                const float xs = fminf(fmaxf(raw, -65504.f), 65504.f);
+                const float xs = v[u][j] * scale;
                 hi[j] = (_Float16)xs;
                 lo[j] = (_Float16)(xs - (float)hi[j]);
             }
-            dst[row >> 5][kg >> 1][0][l2] = __builtin_bit_cast(u32x4, hi);
+            const u32x4 hw = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) carry |= (hw[w] & 0x7C007C00u) + 0x04000400u;
+            dst[row >> 5][kg >> 1][0][l2] = hw;
             dst[row >> 5][kg >> 1][1][l2] = __builtin_bit_cast(u32x4, lo);
         } else if constexpr (PIECES == 1) {
             bf16x8 p0;
@@ -296,7 +300,7 @@ __device__ __forceinline__ void store_fragments(const float (&v)[(BLOCKS * 128) 
         }
     }
     if constexpr (PIECES == 4) {
-        if (out_of_range) *out_of_range |= bad;
+        if (out_of_range) *out_of_range |= (carry & 0x80008000u) != 0;
     }
 }
 
@@ -853,6 +857,13 @@ extern "C" int epc_gemm_f32_stats(const float* A, const float* B, float* C, cons
                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
                                   float* var, void* stream) {
     return gemm_stats_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, stats, stats_floats, mean, var, 3, 1.f, 1.f, stream);
+}
+
+// The same with ONE bf16 value per operand (BASELINE.json configs[2]'s "bf16" training arithmetic): one product, f32 accumulate.
+extern "C" int epc_gemm_bf16_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm,
+                                   long sAk, long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean,
+                                   float* var, void* stream) {
+    return gemm_stats_impl(A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, stats, stats_floats, mean, var, 1, 1.f, 1.f, stream);
 }
 
 // The same product in the split-fp16 three-product arithmetic (2^-22 per product, half the matrix work): A * 2^a_scale_log2 and

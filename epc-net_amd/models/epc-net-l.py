@@ -56,15 +56,10 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
         dpist = ops.KnnGraph(point_cloud)
         conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
                                                   scope=scope, bn_decay=bn_decay)
-        outs = []
-        inp = point_cloud
-        for b in (1, 2):
-            x = conv(inp, 64, 'conv%d' % b)
-            # x1 = matmul(dpist, x) / k; t = conv_b(conv_a(x1 - x)); t + x1: one node in training (tf_util.proxyconv_tail)
-            inp = tf_util.proxyconv_tail(x, dpist, k, 'conv%d_a' % b, 'conv%d_b' % b, bn_decay=bn_decay, is_training=is_training)
-            outs.append(inp)
+        # conv1 .. conv2_b and the concat of the two block outputs (:62-83): one fused chain in training (tf_util.proxyconv_backbone)
+        cat = tf_util.proxyconv_backbone(point_cloud, dpist, k, 2, bn_decay=bn_decay, is_training=is_training)
         with tf_util.bounded_operands(ops.F16X3_CONV5):                  # conv5: BatchNorm'd block outputs against its weights
-            x = conv(torch.cat(outs, dim=-1), 1024, 'conv5')
+            x = conv(cat, 1024, 'conv5')
         feats = x
         x = x.unsqueeze(2)                                               # :88
     with variable_scope('VLAD'):

@@ -71,16 +71,8 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
     point_cloud = ops.morton_sort(point_cloud)           # re-ordering only (permutation-invariant network)
     with variable_scope(backbone_scope):
         dpist = ops.KnnGraph(point_cloud)                    # tf_util.pairwise_distance_mask in index form (:63)
-        conv = lambda x, n, scope: tf_util.conv1d(x, n, 1, padding='VALID', stride=1, bn=True, is_training=is_training,
-                                                  scope=scope, bn_decay=bn_decay)
-        outs = []
-        inp = point_cloud
-        for b in (1, 2, 3, 4):
-            x = conv(inp, 64, 'conv%d' % b)
-            # x1 = matmul(dpist, x) / k; t = conv_b(conv_a(x1 - x)); t + x1: one node in training (tf_util.proxyconv_tail)
-            inp = tf_util.proxyconv_tail(x, dpist, k, 'conv%d_a' % b, 'conv%d_b' % b, bn_decay=bn_decay, is_training=is_training)
-            outs.append(inp)
-        x = torch.cat(outs, dim=-1)                          # :134
+        # conv1 .. conv4_b and the concat of the four block outputs (:66-134): one fused chain in training (tf_util.proxyconv_backbone)
+        x = tf_util.proxyconv_backbone(point_cloud, dpist, k, 4, bn_decay=bn_decay, is_training=is_training)
         # conv5 (:136-139) and the per-point l2_normalize of :147-148 (which the reference applies inside the VLAD scope)
         net = tf_util.conv1d_l2_normalized(x, 1024, 'conv5', bn_decay=bn_decay, is_training=is_training)
     with variable_scope('VLAD'):

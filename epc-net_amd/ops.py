@@ -231,28 +231,29 @@ def _gemm_with_stats(x, W, b, f16x3=None):
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     mean = torch.empty(cout, dtype=torch.float32, device=x.device)
     var = torch.empty(cout, dtype=torch.float32, device=x.device)
-    if cin == 64 and cout == 64 and x.is_contiguous() and W.is_contiguous():
+    if cin == 64 and cout == 64 and x.is_contiguous() and W.is_contiguous() and _GEMM_PRECISION == "bf16x6":
         ws, n = _ws(rows, 64, x.device)      # the thin layers: one launch, moments finished by the last workgroup
         L.check(L.lib().epc_linear_stats64(x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, rows,
                                            z.data_ptr(), mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
         return z, mean, var
     tiles = L.lib().epc_gemm_stats_tiles(rows)
     stats = torch.empty(tiles * 3 * cout + 1, dtype=torch.float32, device=x.device)   # per row tile: sum, sum of squares, pivot (+ the f16x3 range word)
-    if f16x3 is not None and _FWD_F16X3:
+    if f16x3 is not None and _FWD_F16X3 and _GEMM_PRECISION == "bf16x6":
         L.check(L.lib().epc_gemm_f16x3_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
                                              rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
                                              int(f16x3[0]), int(f16x3[1]), stats.data_ptr(), stats.numel(), mean.data_ptr(),
                                              var.data_ptr(), _st()))
         return z, mean, var
-    L.check(L.lib().epc_gemm_f32_stats(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
-                                       rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
-                                       stats.data_ptr(), stats.numel(), mean.data_ptr(), var.data_ptr(), _st()))
+    fn = L.lib().epc_gemm_bf16_stats if _GEMM_PRECISION == "bf16" else L.lib().epc_gemm_f32_stats
+    L.check(fn(x.data_ptr(), W.data_ptr(), z.data_ptr(), b.data_ptr() if b is not None else None,
+               rows, cout, cin, x.stride(0), x.stride(1), W.stride(0), W.stride(1), cout,
+               stats.data_ptr(), stats.numel(), mean.data_ptr(), var.data_ptr(), _st()))
     return z, mean, var
 
 
 def fused_linear_bn_ok(rows, cin, cout):
-    """Shapes the statistics epilogue covers (the split-bf16 GEMM kernel) in the f32-accurate arithmetic."""
-    return _GEMM_PRECISION == "bf16x6" and rows >= 64 and cout >= 64 and cin >= 32
+    """Shapes the statistics epilogue covers (the split GEMM kernel, either arithmetic of the step)."""
+    return rows >= 64 and cout >= 64 and cin >= 32
 
 
 class LinearBatchNormTrain(torch.autograd.Function):
@@ -397,6 +398,20 @@ class KnnGraph:
         self.num_clouds, self.n = int(xyz.shape[0]), int(xyz.shape[1])
         self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
         self._transposed = None
+        self._overflow = None
+
+    def overflow(self):
+        """(ovf_cnt (clouds,), ovf_list (clouds, n)): per cloud the points whose own list overflowed (cnt > cap: exact ties of
+        duplicated / zero-padded clouds) -- the transposed graph does not list them, the chain's gather backward visits them with
+        the exact test (epc_knn_overflow_lists).  Built on first use."""
+        if self._overflow is None:
+            dev = self.xyz.device
+            oc = torch.empty(self.num_clouds, dtype=torch.int32, device=dev)
+            ol = torch.empty((self.num_clouds, self.n), dtype=torch.int32, device=dev)
+            L.check(L.lib().epc_knn_overflow_lists(self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n, oc.data_ptr(),
+                                                   ol.data_ptr(), _st()))
+            self._overflow = (oc, ol)
+        return self._overflow
 
     def transposed(self):
         """(rdeg, roff, rlist): for every point the points that list it (epc_knn_transpose), built on first use -- the
@@ -539,6 +554,192 @@ class ProxyConvTail(torch.autograd.Function):
                                                                rlist.data_ptr(), g.num_clouds, g.n, ctx.k, dx.data_ptr(), _st()))
         # (bias gradients in front of a training-mode BatchNorm are exactly zero: LinearBatchNormTrain)
         return dx, None, None, dWa, None, dga, dbta, dWb, None, dgb, dbtb, None
+
+
+def chain_ok(rows):
+    """The fused backbone chain (ProxyConvChain) covers both GEMM arithmetics of the step and any row count."""
+    return rows >= 1
+
+
+class ProxyConvChain(torch.autograd.Function):
+    """The whole 64-channel backbone behind conv1's product as ONE autograd node on the fused chain launches of
+    csrc/train_chain.hip (models/epc-net.py:66-134 in training mode): for block b = 1 .. nblocks
+        x = relu(bn0_b(z0_b));  xm = matmul(mask, x) / k;  d = xm - x;  za = d Wa + ba;  zb = relu(bna(za)) Wb + bb;
+        out_b = relu(bnb(zb)) + xm -> columns [64 (b - 1), 64 b) of the concat (:134);  z0_{b+1} = out_b W0_{b+1} + b0_{b+1}
+    with z0_1 = conv1's pre-activation (the input; its K = 3 product keeps its own small kernels).  Every BatchNorm is in
+    training mode: batch moments from the producer's partials, pooled in the consumer's prologue.  Forward: 3 launches per block
+    (+ 1 for z0_1's moments); backward: 4 per block + 2 -- against 9 + 1 and ~14 of the per-layer operators.
+
+    apply(z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, *params) with params = for block 1: gamma0, beta0, then
+    Wa, ba, gamma_a, beta_a, Wb, bb, gamma_b, beta_b; for every later block: W0, b0, gamma0, beta0 and the same eight.
+    Returns (cat (rows, 64 nblocks), then per block: [z0 -- blocks after the first --], mean0, var0, za, mean_a, var_a, zb, mean_b,
+    var_b) -- the pre-activations
+    and batch moments feed the moving averages and the test hook's mask taps; only cat is differentiable.  Bias gradients in front of
+    a training-mode BatchNorm are exactly zero and are not computed (LinearBatchNormTrain)."""
+
+    @staticmethod
+    def _split(nblocks, params):
+        blocks, at = [], 0
+        for b in range(nblocks):
+            n = 10 if b == 0 else 12
+            p = list(params[at:at + n])
+            at += n
+            if b == 0:
+                p = [None, None] + p
+            blocks.append(p)      # [W0, b0, g0, bt0, Wa, ba, ga, bta, Wb, bb, gb, btb]
+        assert at == len(params)
+        return blocks
+
+    @staticmethod
+    def forward(ctx, z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, *params):
+        lib = L.lib()
+        z01 = z01.contiguous()
+        rows = int(z01.shape[0])
+        assert z01.shape[1] == 64 and rows == graph.num_clouds * graph.n
+        dev = z01.device
+        blocks = ProxyConvChain._split(nblocks, [p.contiguous() if p is not None else None for p in params])
+        P = lib.epc_chain_parts(rows)
+        width = 64 * nblocks
+        new = lambda: torch.empty((rows, 64), dtype=torch.float32, device=dev)
+        vec = lambda: torch.empty(64, dtype=torch.float32, device=dev)
+        stats = lambda: torch.empty(P * 192, dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        cat = torch.empty((rows, width), dtype=torch.float32, device=dev)
+        g = graph
+        st0 = stats()
+        L.check(lib.epc_chain_stats(z01.data_ptr(), rows, st0.data_ptr(), _st()))
+        z0, in_stats, in_bias = z01, st0, None
+        saved, outs = [], []
+        for b, (W0, b0, g0, bt0, Wa, ba, ga, bta, Wb, bb, gb, btb) in enumerate(blocks):
+            m0, v0, ma, va, mb, vb = vec(), vec(), vec(), vec(), vec(), vec()
+            xm, d, za, zb = new(), new(), new(), new()
+            st_a, st_b = stats(), stats()
+            L.check(lib.epc_chain_fwd_gather(z0.data_ptr(), in_stats.data_ptr(), ptr(in_bias), m0.data_ptr(), v0.data_ptr(),
+                                             g0.data_ptr(), bt0.data_ptr(), float(eps), g.xyz.data_ptr(), g.idx.data_ptr(),
+                                             g.cnt.data_ptr(), g.kth.data_ptr(), L.EPC_KNN_CAP, g.num_clouds, g.n, int(k),
+                                             Wa.data_ptr(), ptr(ba), xm.data_ptr(), d.data_ptr(), za.data_ptr(), st_a.data_ptr(),
+                                             int(pieces_fwd), _st()))
+            L.check(lib.epc_chain_fwd_linear(za.data_ptr(), st_a.data_ptr(), ptr(ba), ma.data_ptr(), va.data_ptr(), ga.data_ptr(),
+                                             bta.data_ptr(), float(eps), None, None, 0, Wb.data_ptr(), ptr(bb), zb.data_ptr(),
+                                             st_b.data_ptr(), rows, int(pieces_fwd), _st()))
+            slice_ptr = cat.data_ptr() + 4 * 64 * b
+            if b + 1 < nblocks:
+                W0n, b0n = blocks[b + 1][0], blocks[b + 1][1]
+                z0n, st0n = new(), stats()
+                L.check(lib.epc_chain_fwd_linear(zb.data_ptr(), st_b.data_ptr(), ptr(bb), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(),
+                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, W0n.data_ptr(),
+                                                 ptr(b0n), z0n.data_ptr(), st0n.data_ptr(), rows, int(pieces_fwd), _st()))
+            else:
+                z0n, st0n, b0n = None, None, None
+                L.check(lib.epc_chain_fwd_linear(zb.data_ptr(), st_b.data_ptr(), ptr(bb), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(),
+                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, None, None, None,
+                                                 None, rows, int(pieces_fwd), _st()))
+            saved += [z0, d, za, zb, m0, v0, ma, va, mb, vb]
+            outs += ([z0] if b > 0 else []) + [m0, v0, za, ma, va, zb, mb, vb]      # (block 1's z0 is the input itself)
+            z0, in_stats, in_bias = z0n, st0n, b0n
+        ctx.save_for_backward(cat, *saved, *[p for p in params])
+        ctx.graph, ctx.k, ctx.eps, ctx.nblocks = graph, int(k), float(eps), int(nblocks)
+        ctx.pieces_bwd, ctx.n_params = int(pieces_bwd), len(params)
+        ctx.mark_non_differentiable(*outs)
+        ctx.set_materialize_grads(False)
+        return (cat,) + tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dcat, *_unused):
+        nb = ctx.nblocks
+        n_in = 7 + ctx.n_params
+        if dcat is None:
+            return (None,) * n_in
+        lib = L.lib()
+        sv = ctx.saved_tensors
+        cat = sv[0]
+        per = [sv[1 + 10 * b: 11 + 10 * b] for b in range(nb)]          # z0, d, za, zb, m0, v0, ma, va, mb, vb
+        params = list(sv[1 + 10 * nb:])
+        blocks = ProxyConvChain._split(nb, params)
+        dcat = dcat.contiguous()
+        rows, width = int(cat.shape[0]), int(cat.shape[1])
+        dev = cat.device
+        g, eps, k, pc = ctx.graph, ctx.eps, ctx.k, ctx.pieces_bwd
+        P = lib.epc_chain_parts(rows)
+        new = lambda: torch.empty((rows, 64), dtype=torch.float32, device=dev)
+        vec = lambda: torch.empty(64, dtype=torch.float32, device=dev)
+        sums = lambda: torch.empty(P * 128, dtype=torch.float32, device=dev)
+        n_layers = 3 * nb - 1
+        parts = _splitk_ws(n_layers * P * 4096, dev)[: n_layers * P * 4096].view(n_layers, P * 4096)
+        layer_dw, layer_at = [], 0
+        rdeg, roff, rlist = g.transposed()
+        ovc, ovl = g.overflow()
+        grads = [None] * ctx.n_params
+        at_of = lambda b: 0 if b == 0 else 10 + 12 * (b - 1)          # index of block b's first parameter in `params`
+        z_b, m_b, v_b = per[nb - 1][3], per[nb - 1][8], per[nb - 1][9]
+        sums_b = sums()
+        last = dcat.data_ptr() + 4 * 64 * (nb - 1)
+        L.check(lib.epc_chain_sums(last, width, z_b.data_ptr(), m_b.data_ptr(), v_b.data_ptr(), blocks[nb - 1][10].data_ptr(),
+                                   blocks[nb - 1][11].data_ptr(), eps, rows, sums_b.data_ptr(), _st()))
+        gout = None
+        dz01 = None
+        for b in range(nb - 1, -1, -1):
+            z0, d, za, zb, m0, v0, ma, va, mb, vb = per[b]
+            W0, b0, g0, bt0, Wa, ba, ga, bta, Wb, bb, gb, btb = blocks[b]
+            base = at_of(b) + (2 if b == 0 else 4)                   # Wa's index
+            dy_ptr, dy_stride = (gout.data_ptr(), 64) if gout is not None else (dcat.data_ptr() + 4 * 64 * b, width)
+            # conv_b: its input is relu(bn_a(za)), re-formed from za; leaves conv_a's BatchNorm sums
+            dya, dgb, dbtb, sums_a = new(), vec(), vec(), sums()
+            L.check(lib.epc_chain_bwd_linear(dy_ptr, dy_stride, zb.data_ptr(), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(),
+                                             btb.data_ptr(), eps, sums_b.data_ptr(), dgb.data_ptr(), dbtb.data_ptr(), Wb.data_ptr(),
+                                             za.data_ptr(), 64, ma.data_ptr(), va.data_ptr(), ga.data_ptr(), bta.data_ptr(),
+                                             dya.data_ptr(), None, 0, parts[layer_at].data_ptr(), za.data_ptr(), ma.data_ptr(),
+                                             va.data_ptr(), ga.data_ptr(), bta.data_ptr(), sums_a.data_ptr(), rows, pc, _st()))
+            dWb = torch.empty_like(Wb)
+            layer_dw.append(dWb)
+            layer_at += 1
+            grads[base + 4], grads[base + 6], grads[base + 7] = dWb, dgb, dbtb
+            # conv_a: the gradient of its input d = xm - x leaves as s = dd + dout (dout reaches xm by the residual path)
+            s_, dga, dbta = new(), vec(), vec()
+            L.check(lib.epc_chain_bwd_linear(dya.data_ptr(), 64, za.data_ptr(), ma.data_ptr(), va.data_ptr(), ga.data_ptr(),
+                                             bta.data_ptr(), eps, sums_a.data_ptr(), dga.data_ptr(), dbta.data_ptr(), Wa.data_ptr(),
+                                             d.data_ptr(), 64, None, None, None, None, s_.data_ptr(), dy_ptr, dy_stride,
+                                             parts[layer_at].data_ptr(), None, None, None, None, None, None, rows, pc, _st()))
+            dWa = torch.empty_like(Wa)
+            layer_dw.append(dWa)
+            layer_at += 1
+            grads[base + 0], grads[base + 2], grads[base + 3] = dWa, dga, dbta
+            # the gather's transpose: dx = mask^T s / k - (s - dout); leaves the leading BatchNorm's sums
+            dxx, sums_0 = new(), sums()
+            L.check(lib.epc_chain_bwd_gather(s_.data_ptr(), dy_ptr, dy_stride, rdeg.data_ptr(), roff.data_ptr(), rlist.data_ptr(),
+                                             ovc.data_ptr(), ovl.data_ptr(), g.xyz.data_ptr(), g.kth.data_ptr(), g.num_clouds, g.n,
+                                             k, z0.data_ptr(), m0.data_ptr(), v0.data_ptr(), g0.data_ptr(), bt0.data_ptr(), eps,
+                                             sums_0.data_ptr(), dxx.data_ptr(), _st()))
+            dg0, dbt0 = vec(), vec()
+            if b > 0:
+                # the leading conv: its input is the previous block's output (a slice of cat); its dx, plus the concat's gradient of
+                # that slice, is d(out_{b-1}); leaves the previous block's conv_b BatchNorm sums
+                pz = per[b - 1]
+                pgb, pbtb = blocks[b - 1][10], blocks[b - 1][11]
+                gnew, sums_prev = new(), sums()
+                prev_slice = 4 * 64 * (b - 1)
+                L.check(lib.epc_chain_bwd_linear(dxx.data_ptr(), 64, z0.data_ptr(), m0.data_ptr(), v0.data_ptr(), g0.data_ptr(),
+                                                 bt0.data_ptr(), eps, sums_0.data_ptr(), dg0.data_ptr(), dbt0.data_ptr(),
+                                                 W0.data_ptr(), cat.data_ptr() + prev_slice, width, None, None, None, None,
+                                                 gnew.data_ptr(), dcat.data_ptr() + prev_slice, width, parts[layer_at].data_ptr(),
+                                                 pz[3].data_ptr(), pz[8].data_ptr(), pz[9].data_ptr(), pgb.data_ptr(), pbtb.data_ptr(),
+                                                 sums_prev.data_ptr(), rows, pc, _st()))
+                dW0 = torch.empty_like(W0)
+                layer_dw.append(dW0)
+                layer_at += 1
+                a0 = at_of(b)
+                grads[a0 + 0], grads[a0 + 2], grads[a0 + 3] = dW0, dg0, dbt0
+                gout, sums_b = gnew, sums_prev
+            else:
+                dz01 = new()
+                L.check(lib.epc_chain_bn_bwd(dxx.data_ptr(), z0.data_ptr(), m0.data_ptr(), v0.data_ptr(), g0.data_ptr(), bt0.data_ptr(),
+                                             eps, sums_0.data_ptr(), dg0.data_ptr(), dbt0.data_ptr(), rows, dz01.data_ptr(), _st()))
+                grads[0], grads[1] = dg0, dbt0
+        import ctypes
+        pa = (ctypes.c_void_p * n_layers)(*[parts[l].data_ptr() for l in range(n_layers)])
+        pw = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in layer_dw])
+        L.check(lib.epc_chain_dw_sum(n_layers, pa, pw, rows, _st()))
+        return (dz01 if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(grads)
 
 
 class RowL2Normalize(torch.autograd.Function):

@@ -254,7 +254,7 @@ def proxyconv_tail(x, graph, k, scope_a, scope_b, bn_decay=None, is_training=Non
     shape = tuple(x.shape)
     x2 = x.reshape(-1, 64)
     rows = int(x2.shape[0])
-    if not (is_training and ops.fused_linear_bn_ok(rows, 64, 64)):
+    if not (is_training and ops.fused_linear_bn_ok(rows, 64, 64) and ops._GEMM_PRECISION == "bf16x6"):
         xm, d = ops.NeighbourMeanDiff.apply(x2, graph, k)
         t = conv1d(d.reshape(shape), 64, 1, padding='VALID', stride=1, bn=True, is_training=is_training, scope=scope_a,
                    bn_decay=bn_decay)
@@ -278,6 +278,78 @@ def proxyconv_tail(x, graph, k, scope_a, scope_b, bn_decay=None, is_training=Non
             if RELU_MASK_TAPS is not None:      # (test hook: the layer's activation is not materialised by the fused node)
                 _tap_relu_mask(ops.bn_apply_train(z, mean, var, gamma, beta, 1e-3, True))
     return out.reshape(shape)
+
+
+# False: the training backbone is built from the per-layer operators (conv1d / proxyconv_tail) instead of the fused chain --
+# the second implementation the tests hold the chain to.
+USE_CHAIN = True
+
+
+def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None):
+    """The ProxyConv backbone of models/epc-net.py:66-134 (four blocks) / models/epc-net-l.py:62-83 (two) up to the concat:
+        for b: x = conv_b(in) [conv1 on the coordinates, conv2.. on the previous block's output]; x1 = matmul(mask, x) / k;
+               t = conv_b_b(conv_b_a(x1 - x)); in = t + x1
+        return concat of the blocks' outputs (B, N, 64 nblocks)
+    every conv = 1x1 + BatchNorm + ReLU.  Not a function of the reference's tf_util: a fusion point.  In training it is conv1's
+    product (ops.Linear, K = 3) followed by ONE autograd node on the fused chain launches (ops.ProxyConvChain); otherwise the same
+    graph op by op (conv1d / proxyconv_tail).  Variables, moving-average updates and the mask-tap test hook as conv1d's."""
+    import torch
+    from .. import ops
+    B, N, cin = (int(v) for v in point_cloud.shape)
+    rows = B * N
+    if not (is_training and USE_CHAIN and ops.chain_ok(rows)):
+        outs, inp = [], point_cloud
+        for b in range(1, nblocks + 1):
+            x = conv1d(inp, 64, 1, padding='VALID', stride=1, bn=True, is_training=is_training, scope='conv%d' % b, bn_decay=bn_decay)
+            inp = proxyconv_tail(x, graph, k, 'conv%d_a' % b, 'conv%d_b' % b, bn_decay=bn_decay, is_training=is_training)
+            outs.append(inp)
+        return torch.cat(outs, dim=-1)
+    L.require_gpu()
+    params, bns = [], []          # bns: (scope, gamma, beta, ema_mean, ema_var) in the node's output order
+    w1 = b1 = None
+    for b in range(1, nblocks + 1):
+        w, bias, _ = declare_conv1d('conv%d' % b, cin if b == 1 else 64, 64, 1, True, 1e-3, True)
+        with variable_scope('conv%d' % b):
+            beta, gamma, em, ev = _bn_variables("bn", 64)
+        if b == 1:
+            w1, b1 = w.reshape(cin, 64), bias
+            params += [gamma, beta]
+        else:
+            params += [w.reshape(64, 64), bias, gamma, beta]
+        bns.append(('conv%d' % b, gamma, beta, em, ev))
+        for sfx in ('_a', '_b'):
+            w, bias, _ = declare_conv1d('conv%d%s' % (b, sfx), 64, 64, 1, True, 1e-3, True)
+            with variable_scope('conv%d%s' % (b, sfx)):
+                beta, gamma, em, ev = _bn_variables("bn", 64)
+            params += [w.reshape(64, 64), bias, gamma, beta]
+            bns.append(('conv%d%s' % (b, sfx), gamma, beta, em, ev))
+    z01 = ops.Linear.apply(point_cloud.reshape(rows, cin), w1, b1, True)        # conv1's product (bias in front of a BatchNorm)
+    pf, pb = (3, 2) if ops._GEMM_PRECISION == "bf16x6" else (1, 1)
+    res = ops.ProxyConvChain.apply(z01, graph, int(k), 1e-3, int(nblocks), pf, pb, *params)
+    cat, rest = res[0], list(res[1:])
+    decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+    at = 0
+    for li, (scope, gamma, beta, em, ev) in enumerate(bns):
+        if li % 3 == 0 and li > 0:          # a later block's leading conv: its pre-activation is an output of the node
+            z = rest[at]
+            at += 1
+        elif li == 0:
+            z = z01
+        else:
+            z = None
+        if li % 3 == 0:
+            mean, var = rest[at], rest[at + 1]
+            at += 2
+        else:
+            z, mean, var = rest[at], rest[at + 1], rest[at + 2]
+            at += 3
+        with variable_scope(scope):
+            _ema_update(em, mean, decay)
+            _ema_update(ev, var, decay)
+            if RELU_MASK_TAPS is not None:      # (test hook: the layer's activation is not materialised by the fused node)
+                _tap_relu_mask(ops.bn_apply_train(z, mean, var, gamma, beta, 1e-3, True))
+    assert at == len(rest)
+    return cat.reshape(B, N, 64 * nblocks)
 
 
 def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None):

@@ -307,6 +307,9 @@ int epc_gemm_f32_fast(const float* A, const float* B, float* C, const float* bia
 int epc_gemm_stats_tiles(int M);
 int epc_gemm_f32_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                        long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, void* stream);
+/* epc_gemm_f32_stats with ONE bf16 value per operand (one product, f32 accumulate): the "bf16" training arithmetic. */
+int epc_gemm_bf16_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                        long sBk, long sBn, int ldc, float* stats, size_t stats_floats, float* mean, float* var, void* stream);
 /* The same product in the split-fp16 three-product arithmetic (2^-22 per product at half the matrix work of the six-product
  * form): A * 2^a_scale_log2 and B * 2^b_scale_log2 are split into fp16 hi + lo as they are staged (magnitudes beyond fp16's range
  * are clamped to it) and the product is un-scaled exactly.  For operands that are bounded by construction (BatchNorm / l2-normalised
@@ -483,6 +486,56 @@ int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out,
 /* Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout * s, dg = dout * y * s * (1 - s). */
 int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
 int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, float* dy, float* dg, void* stream);
+
+/* ---- The 64-channel backbone of the training step as a chain of fused launches (csrc/train_chain.hip) -----------------------
+ * models/epc-net.py:66-134 in training mode (utils/tf_util.py:52-107, 454-519): every 64 -> 64 layer is followed by a training-mode
+ * BatchNorm + ReLU whose batch statistics need all rows.  A producer leaves per-workgroup PARTIALS -- epc_chain_parts(rows) of
+ * them, one per 256 rows: moment partials [parts][3][64] (sums of (v - p), (v - p)^2 and the pivot p of its pre-activation WITHOUT
+ * the bias) or BatchNorm-backward sum partials [parts][2][64] (sum dy [mask], sum dy [mask] zhat) -- and the CONSUMER pools them in
+ * its prologue (double precision, fixed order; workgroup 0 writes the pooled mean / var, resp. dbeta / dgamma).  A BatchNorm + ReLU
+ * is applied to an operand as it is loaded.  (rows, 64) tensors are dense f32 unless a stride (in floats) is given; `pieces`:
+ * forward 3 = six bf16 products per f32 product (f32-accurate) or 1 = one bf16 value per operand; backward 2 or 1. */
+int epc_chain_parts(int rows);
+/* moment partials of z (rows, 64) as it stands (the first block's z0 = conv1's output, models/epc-net.py:66) */
+int epc_chain_stats(const float* z, int rows, float* stats, void* stream);
+/* a = relu(bn(zin)) (+ resid); a -> a_out (row stride a_stride; NULL: not written); W != NULL: z_out = a W + bias, stats_out = its
+ * moment partials.  in_stats != NULL: the BatchNorm's batch moments are pooled from it (+ in_bias) and written to in_mean / in_var;
+ * NULL: in_mean / in_var are read.  conv_b of a block (:78-79); a block's tail + the next block's leading conv (:81-83). */
+int epc_chain_fwd_linear(const float* zin, const float* in_stats, const float* in_bias, float* in_mean, float* in_var,
+                         const float* in_gamma, const float* in_beta, float eps, const float* resid, float* a_out, int a_stride,
+                         const float* W, const float* bias, float* z_out, float* stats_out, int rows, int pieces, void* stream);
+/* models/epc-net.py:70-76: x = relu(bn(z0)) formed as the rows are gathered; xm = mask x / knn over the kNN lists of
+ * epc_knn_topk (int32, cap slots; rows with cnt > cap take the exact scan); d = xm - x; z_out = d W + bias + moment partials. */
+int epc_chain_fwd_gather(const float* z0, const float* in_stats, const float* in_bias, float* in_mean, float* in_var,
+                         const float* in_gamma, const float* in_beta, float eps, const float* xyz, const int32_t* idx,
+                         const int32_t* cnt, const float* kth, int cap, int num_clouds, int n, int knn, const float* W,
+                         const float* bias, float* xm, float* d, float* z_out, float* stats_out, int pieces, void* stream);
+/* Backward of y = relu(bn(z)), z = in W + b for one 64 -> 64 layer: the BatchNorm's sums are pooled from `sums` (-> dgamma, dbeta);
+ * dz = gamma rstd (dy [mask] - dbeta / rows - zhat dgamma / rows); dx = dz W^T (+ dx_addend); dw_partials[parts][64][64] += in^T dz
+ * with in = x, or relu(bn_x(x)) when x_mean .. x_beta are given; zp != NULL: psums = the sum partials of (dx + addend) against the
+ * BatchNorm (p_mean .. p_beta) of pre-activation zp -- what the next backward layer pools. */
+int epc_chain_bwd_linear(const float* dy, int dy_stride, const float* z, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, const float* sums, float* dgamma, float* dbeta, const float* W,
+                         const float* x, int x_stride, const float* x_mean, const float* x_var, const float* x_gamma,
+                         const float* x_beta, float* dx, const float* dx_addend, int addend_stride, float* dw_partials,
+                         const float* zp, const float* p_mean, const float* p_var, const float* p_gamma, const float* p_beta,
+                         float* psums, int rows, int pieces, void* stream);
+/* Backward of the gather layer: dx[j] = (sum over the points i that select j of s[i]) / knn - (s[j] - dout[j]) over the transposed
+ * graph of epc_knn_transpose plus the overflow lists of epc_knn_overflow_lists (no atomics); psums = the sum partials of dx against
+ * the BatchNorm (mean .. beta) of z0. */
+int epc_chain_bwd_gather(const float* s, const float* dout, int dout_stride, const int32_t* rdeg, const int32_t* roff,
+                         const int32_t* rlist, const int32_t* ovf_cnt, const int32_t* ovf_list, const float* xyz, const float* kth,
+                         int num_clouds, int n, int knn, const float* z0, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, float* psums, float* dx, void* stream);
+/* sum partials of (dy, z) for the chain's last layer; dz of a BatchNorm + ReLU alone with pooled sums (the first block's leading
+ * BatchNorm); dW[l] = the sum of layer l's workgroup partials, ascending, for up to 16 layers in one launch. */
+int epc_chain_sums(const float* dy, int dy_stride, const float* z, const float* mean, const float* var, const float* gamma,
+                   const float* beta, float eps, int rows, float* psums, void* stream);
+int epc_chain_bn_bwd(const float* dy, const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                     float eps, const float* sums, float* dgamma, float* dbeta, int rows, float* dz, void* stream);
+int epc_chain_dw_sum(int layers, const float* const* partials, float* const* dW, int rows, void* stream);
+/* per cloud the points whose neighbour list overflowed (cnt > cap), ascending: ovf_cnt (num_clouds), ovf_list (num_clouds, n) */
+int epc_knn_overflow_lists(const int32_t* cnt, int cap, int num_clouds, int n, int32_t* ovf_cnt, int32_t* ovf_list, void* stream);
 
 /* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
  * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials

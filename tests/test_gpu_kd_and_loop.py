@@ -176,16 +176,21 @@ def test_distill_step_matches_the_float64_oracle(dev, n, gamma, loss_type):
     assert float(loss) == pytest.approx(ref["loss"], rel=1e-5)
     worst = (0.0, "")
     assert len(ref["grads"]) == 32
+    scale = max(np.linalg.norm(v) for v in ref["grads"].values())
     for k, g_ref in ref["grads"].items():
         name = pre + k.replace("fastdgcnn/", "BACKBONE/")
         g = grads[name].reshape(g_ref.shape)
-        if k.endswith("/biases") and not k.startswith("VLAD/fc1"):
-            assert np.abs(g).max() <= 5e-5          # in front of a training-mode BatchNorm: exactly zero (rounding noise in TF)
-            continue
-        if k == "VLAD/fc1/biases":                  # also in front of a training-mode BatchNorm (utils/tf_util.py:339-344)
-            assert np.abs(g).max() <= 5e-5
+        if k.endswith("/biases") or np.linalg.norm(g_ref) <= 1e-9:
+            # exactly-zero true gradients: every bias sits in front of a training-mode BatchNorm, and EPC-Net-L's conv5 beta shifts
+            # every cloud's pooled feature alike, which fc1's training-mode BatchNorm over the tuple removes (both sides hold
+            # rounding noise there)
+            assert np.abs(g).max() <= 5e-5, (k, np.abs(g).max())
             continue
         rel_l2 = np.linalg.norm(g - g_ref) / max(np.linalg.norm(g_ref), 1e-30)
+        # (a tensor whose true gradient is a tiny remainder -- EPC-Net-L's conv5 beta under the feature term, which breaks the exact
+        # cancellation above by 1e-7 of the network's gradient scale -- is held by that scale: float32 noise, not a relative error)
+        if np.linalg.norm(g - g_ref) <= 1e-6 * scale:
+            continue
         worst = max(worst, (rel_l2, k))
         assert rel_l2 <= 1e-3, "mask-pinned student gradient of %s: relative L2 error %.3e" % (k, rel_l2)
     print("distill step 18x%d gamma %.1f %s: loss terms q %.6f soft %.6f fea %.6f; worst student gradient rel L2 %.2e (%s), "
