@@ -322,8 +322,10 @@ extern "C" int epc_debug_gemm_stamps(void* host, size_t bytes) {
 #define GS_ADD(dst, a, b)
 #endif
 
+// (the split-fp16 instantiation of the 128 x 128 tile sits at the edge of three waves per SIMD -- 163 registers; the range guard's
+// state pushed it to 179 = two waves and 189 -> 238 us on conv5's forward product -- so it is held there explicitly)
 template <int WM, int WN, int PIECES, bool SWAP = false, int G_PF = 1>
-__global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (PIECES == 4 && WM == 2 && WN == 2) ? 3 : 1) void gemm_split_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int NP = PieceCount<PIECES>::value;
     __shared__ u32x4 As[2 * WM][2][NP][64];  // 4 KB per WM per piece

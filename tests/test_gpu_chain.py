@@ -77,7 +77,7 @@ def test_chain_equals_the_per_layer_operators(dev, arch, ncl, n, kind):
         worst = max(worst, (rel, k))
         assert rel <= bar_grad, (k, rel)
     for k, vb in b[2].items():
-        assert np.abs(a[2][k] - vb).max() <= 2e-6 + (2e-6 if kind == "uniform" else 1e-5) * np.abs(vb).max(), k
+        assert np.abs(a[2][k] - vb).max() <= 2e-6 + (2e-6 if kind == "uniform" else 5e-5) * np.abs(vb).max(), k
     print("chain vs per-layer operators, %s %dx%d (%s): cat max diff %.2e, worst gradient rel L2 %.2e (%s)"
           % (arch, ncl, n, kind, np.abs(a[0] - b[0]).max(), worst[0], worst[1]))
 
