@@ -576,15 +576,32 @@ def main():
 
     configs = {}
     if not args.no_configs and args.arch == "epc-net":
-        configs["train_step"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, eager_steps=6)
-        configs["train_step_bf16"] = train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, precision="bf16")
-        stl = build_store("epc-net-l", device, seed=0)
-        leg, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 256, max(10, min(50, args.steps)), min(args.warmup, 10), 0.0,
-                                every, 1)
-        leg["workload"] = "EPC-Net-L inference, batch 256x4096x3 fp32 per GPU (BASELINE.json configs[3]; models/epc-net-l.py:29-102)"
-        configs["epc_net_l_b256"] = leg
-        configs["retrieval"] = retrieval_leg(H, E, steps=3, warmup=1, rccl=rccl)
-        if rank == 0 and rccl_why:
+        # The bounded legs may not take the headline down with them: a leg that raises is reported as {"error": ...} (on every rank the
+        # same way: the legs' collectives raise on all ranks or on none).
+        def guarded(name, fn):
+            try:
+                configs[name] = fn()
+            except Exception as e:                              # noqa: BLE001  (reported on the line, not swallowed)
+                import traceback
+                configs[name] = {"error": repr(e), "where": traceback.format_exc().strip().splitlines()[-3:]}
+                try:
+                    import torch
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+
+        guarded("train_step", lambda: train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, eager_steps=6))
+        guarded("train_step_bf16", lambda: train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, precision="bf16"))
+
+        def l_leg():
+            stl = build_store("epc-net-l", device, seed=0)
+            leg, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 256, max(10, min(50, args.steps)), min(args.warmup, 10), 0.0,
+                                    every, 1)
+            leg["workload"] = "EPC-Net-L inference, batch 256x4096x3 fp32 per GPU (BASELINE.json configs[3]; models/epc-net-l.py:29-102)"
+            return leg
+        guarded("epc_net_l_b256", l_leg)
+        guarded("retrieval", lambda: retrieval_leg(H, E, steps=3, warmup=1, rccl=rccl))
+        if rank == 0 and rccl_why and isinstance(configs.get("retrieval"), dict):
             configs["retrieval"]["rccl_unavailable"] = rccl_why
 
     # HBM bytes of ONE step = the PMC bytes per launch of the pipeline's kernels (profiles/pmc_hbm_current.json, collected

@@ -72,6 +72,8 @@ class TrainStep:
         # GEMM arithmetic of the step (ops.set_gemm_precision): "bf16x6" = f32-accurate like the reference's fp32 graph
         # (default); "bf16" = one bf16 value per operand, the arithmetic BASELINE.json configs[2] names
         self.precision = params.get("TRAIN_PRECISION", "bf16x6")
+        # data-parallel steps: cut the backward at the backbone's output and exchange the head's gradients under the backbone's backward
+        self.overlap_exchange = bool(params.get("DP_OVERLAP", True))
 
     # -- checkpoint-shaped optimizer state ---------------------------------------------------------------------------
     def optimizer_state(self) -> Dict[str, torch.Tensor]:
@@ -139,9 +141,9 @@ class TrainStep:
         """One training step; returns (loss, learning_rate, bn_decay).  Inputs: (B,1,N,3), (B,P,N,3), (B,Nn,N,3), (B,1,N,3).
         ``graph=True`` records the step into HIP graphs on first use and replays them afterwards -- the step is launch-bound
         from Python otherwise.  Single rank: ONE graph (forward, backward, moving averages, Adam).  Data-parallel ranks
-        (SURVEY.md 8e): TWO graphs around the one flat all-reduce -- [forward, backward, moving averages, pack gradients +
-        statistics into the flat exchange buffer] -> RCCL all-reduce (eager, on the same stream) -> [mean, unpack the
-        statistics, Adam].  The schedule values (learning rate with Adam's bias correction, BN decay) live in device memory
+        (SURVEY.md 8e): THREE graphs around two all-reduces -- [forward, head backward, pack the head's gradients] -> RCCL all-reduce
+        of those (asynchronous) || [backbone backward, moving averages, pack the rest] -> RCCL all-reduce of the rest -> [mean, unpack
+        the statistics, Adam].  The schedule values (learning rate with Adam's bias correction, BN decay) live in device memory
         and are refreshed before every replay, so replays follow train.py:138-157 exactly like eager steps."""
         p = self.params
         B = int(query.shape[0])
@@ -159,14 +161,20 @@ class TrainStep:
         return (loss.detach().clone() if graph else loss.detach()), lr, bn_decay
 
     # -- the three phases of a step ------------------------------------------------------------------------------------
-    def _forward_backward(self, query, positives, negatives, other_neg, bn_decay):
+    def _forward_backward(self, query, positives, negatives, other_neg, bn_decay, between=None):
         """Forward in training mode, loss, backward, and the moving-average updates of this step (UPDATE_OPS,
-        train.py:275-277).  Returns (loss, gradients in trainable_names() order)."""
+        train.py:275-277).  Returns (loss, gradients in trainable_names() order).
+        ``between`` (data-parallel steps): the backward is cut at the backbone's output (tf_util.BACKBONE_TAP) -- first the head
+        (loss -> VLAD -> conv5: every gradient above the cut, 95 % of the bytes), then ``between(head_names, head_grads)`` is called
+        (it packs them and starts their exchange), then the backbone's backward runs under that exchange.  Same kernels in the same
+        order as the uncut backward: same bits."""
         from .utils import tf_util
         from .loupe import SLIM_DECAY
-        for name in self.trainable_names():
+        names = self.trainable_names()
+        for name in names:
             self.store.vars[name].grad = None
         tf_util.defer_ema_updates()                 # the 34 moving-average updates are applied in one launch below
+        tf_util.BACKBONE_TAP = None
         prev = ops.set_gemm_precision(self.precision)
         try:
             try:
@@ -174,17 +182,38 @@ class TrainStep:
             except BaseException:
                 tf_util._deferred_ema = None        # a failed forward applies nothing
                 raise
-            loss.backward()
+            tap = tf_util.BACKBONE_TAP
+            if between is not None and tap is not None and tap.requires_grad:
+                below = set(id(self.store.vars[n]) for n in names if self._below_tap(n))
+                head = [n for n in names if id(self.store.vars[n]) not in below]
+                got = torch.autograd.grad(loss, [tap] + [self.store.vars[n] for n in head], allow_unused=True)
+                with torch.no_grad():
+                    head_grads = [g if g is not None else ops.const_zeros_like(self.store.vars[n]) for n, g in zip(head, got[1:])]
+                    between(head, head_grads)
+                if got[0] is not None:
+                    torch.autograd.backward([tap], [got[0]])
+                for n, g in zip(head, head_grads):
+                    self.store.vars[n].grad = g
+            else:
+                loss.backward()
         finally:
             ops.set_gemm_precision(prev)
+            tf_util.BACKBONE_TAP = None
         with torch.no_grad():
             grads = []
-            for name in self.trainable_names():
+            for name in names:
                 w = self.store.vars[name]
                 grads.append(w.grad if w.grad is not None else ops.const_zeros_like(w))
             # data-parallel runs average the moving statistics too: apply the updates before the exchange
             tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9, scope=self.outer or None)
         return loss, grads
+
+    def _below_tap(self, name: str) -> bool:
+        """Is this variable's gradient formed BELOW the backbone's output (by the backbone's backward)?  The 64-channel layers:
+        conv1 .. conv4_b (conv5 and everything under VLAD/ sit above the cut)."""
+        rel = name[len(self.outer) + 1:] if self.outer and name.startswith(self.outer + "/") else name
+        parts = rel.split("/")
+        return len(parts) >= 2 and parts[0] != "VLAD" and parts[1].startswith("conv") and not parts[1].startswith("conv5")
 
     def _lr_t(self, lr: float, t: int) -> float:
         """Adam's bias-corrected rate exactly as epc_adam_multi forms it from its float arguments (csrc/train_ops.hip:
@@ -206,28 +235,48 @@ class TrainStep:
         trainable = set(self.store.trainable)
         return [v for k, v in self.store.vars.items() if k.startswith(pre) and k not in trainable]
 
-    def _exchange_layout(self, grads):
-        """The flat f32 exchange buffer of data-parallel steps: [gradients | moving statistics], every tensor at a
-        64-float (256-byte) boundary.  ONE RCCL message per step (18.8 MB of gradients + 10 KB of statistics for EPC-Net:
-        xGMI rings are per-link bound, so one large message, not 62 + 34 small ones)."""
-        tensors = list(grads) + self._statistics()
-        key = tuple((tuple(x.shape), x.dtype) for x in tensors)
+    def _exchange_layout(self):
+        """The flat f32 exchange buffer of data-parallel steps: [gradients formed ABOVE the backbone's output | gradients formed
+        below it | moving statistics], every tensor at a 64-float (256-byte) boundary.  Two RCCL messages per step: the head's
+        17.9 MB (EPC-Net: hidden1_weights, conv5, the VLAD tensors) start as soon as the head's backward has formed them and travel
+        while the backbone's backward runs; the backbone's 0.2 MB + 10 KB of statistics follow it (xGMI rings are per-link bound:
+        few large messages, not 62 + 34 small ones).  ``views``: the gradients' slots in trainable_names() order."""
+        names = self.trainable_names()
+        stats = self._statistics()
+        tensors = [self.store.vars[n] for n in names]
+        key = tuple((n, tuple(x.shape)) for n, x in zip(names, tensors)) + tuple(tuple(x.shape) for x in stats)
         ex = self._exchange
         if ex is None or ex["key"] != key or ex["flat"].device != tensors[0].device:
-            offs, o = [], 0
-            for x in tensors:
-                offs.append(o)
+            head = [i for i, n in enumerate(names) if not self._below_tap(n)]
+            below = [i for i, n in enumerate(names) if self._below_tap(n)]
+            offs, o = {}, 0
+            for i in head:
+                offs[i] = o
+                o += (tensors[i].numel() + 63) // 64 * 64
+            head_end = o
+            for i in below:
+                offs[i] = o
+                o += (tensors[i].numel() + 63) // 64 * 64
+            stat_offs = []
+            for x in stats:
+                stat_offs.append(o)
                 o += (x.numel() + 63) // 64 * 64
             flat = torch.zeros(max(o, 64), dtype=torch.float32, device=tensors[0].device)
-            views = [flat[a:a + x.numel()].view(x.shape) for a, x in zip(offs, tensors)]
-            ex = self._exchange = {"key": key, "flat": flat, "views": views, "n_grads": len(grads)}
+            views = [flat[offs[i]:offs[i] + tensors[i].numel()].view(tensors[i].shape) for i in range(len(names))]
+            stat_views = [flat[a:a + x.numel()].view(x.shape) for a, x in zip(stat_offs, stats)]
+            ex = self._exchange = {"key": key, "flat": flat, "views": views, "stat_views": stat_views, "head_end": head_end,
+                                   "head": head, "below": below, "index": {n: i for i, n in enumerate(names)}}
         return ex
 
-    def _pack(self, grads):
-        ex = self._exchange_layout(grads)
+    def _pack_head(self, ex, head_names, head_grads):
         with torch.no_grad():
-            torch._foreach_copy_(ex["views"], list(grads) + self._statistics())
-        return ex
+            torch._foreach_copy_([ex["views"][ex["index"][n]] for n in head_names], list(head_grads))
+
+    def _pack_rest(self, ex, grads, packed_head: bool):
+        """The gradients not yet in the buffer (all of them when the backward was not cut) and the moving statistics."""
+        with torch.no_grad():
+            idx = ex["below"] if packed_head else list(range(len(grads)))
+            torch._foreach_copy_([ex["views"][i] for i in idx] + ex["stat_views"], [grads[i] for i in idx] + self._statistics())
 
     def _unpack_mean(self, ex, world_size: int):
         """After the all-reduce(sum): mean over the ranks in place, statistics back into the variables; returns the averaged
@@ -235,28 +284,57 @@ class TrainStep:
         with torch.no_grad():
             if world_size > 1:
                 ex["flat"].mul_(1.0 / world_size)
-            ng = ex["n_grads"]
-            torch._foreach_copy_(self._statistics(), ex["views"][ng:])
-        return ex["views"][:ng]
+            torch._foreach_copy_(self._statistics(), ex["stat_views"])
+        return ex["views"]
+
+    def _exchange_rest(self, ex, packed_head: bool):
+        """The blocking part of the exchange: the message(s) not yet under way."""
+        import torch.distributed as dist
+        if packed_head:
+            dist.all_reduce(ex["flat"][ex["head_end"]:], op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(ex["flat"], op=dist.ReduceOp.SUM)
 
     def _eager_step(self, query, positives, negatives, other_neg, lr, bn_decay, t):
-        loss, grads = self._forward_backward(query, positives, negatives, other_neg, bn_decay)
-        grads = self._average_over_ranks(grads)
-        self._apply(grads, lr, t)
+        from . import distributed as D
+        if not D.collectives_active():
+            loss, grads = self._forward_backward(query, positives, negatives, other_neg, bn_decay)
+            self._apply(grads, lr, t)
+            return loss
+        # Data parallelism over tuples (SURVEY.md 8e): every rank its own tuple and batch statistics; gradients and moving statistics
+        # are averaged so that every rank applies the same update.  The head's gradients travel under the backbone's backward.
+        import torch.distributed as dist
+        self._ensure_exchange()
+        ex = self._exchange_layout()
+        pending = []
+
+        def between(head_names, head_grads):
+            self._pack_head(ex, head_names, head_grads)
+            pending.append(dist.all_reduce(ex["flat"][:ex["head_end"]], op=dist.ReduceOp.SUM, async_op=True))
+
+        loss, grads = self._forward_backward(query, positives, negatives, other_neg, bn_decay,
+                                             between=between if self.overlap_exchange else None)
+        self._pack_rest(ex, grads, bool(pending))
+        self._exchange_rest(ex, bool(pending))
+        for w in pending:
+            w.wait()
+        self._apply(self._unpack_mean(ex, D.world()[1]), lr, t)
         return loss
 
+    def _ensure_exchange(self):
+        pass
+
     def _average_over_ranks(self, grads):
-        """Data parallelism over tuples: one flat all-reduce of the gradients and of the BatchNorm moving
-        statistics this step updated, so that every rank applies the same update.  Returns the averaged gradients (views of
-        the flat exchange buffer; the input list is left as it is).  Single process without force_collective: the input list."""
+        """One flat all-reduce of a list of gradients (trainable_names() order) and of the moving statistics: the uncut form of the
+        exchange, kept for callers that hold finished gradients.  Returns the averaged gradients (views of the flat exchange buffer;
+        the input list is left as it is).  Single process without force_collective: the input list."""
         from . import distributed as D
         if not D.collectives_active():
             return grads
-        import torch.distributed as dist
-        ex = self._pack(grads)
-        dist.all_reduce(ex["flat"], op=dist.ReduceOp.SUM)
-        return self._unpack_mean(ex, D.world()[1])     # views of the exchange buffer: what Adam consumes (no copy back:
-        #                                                `grads` may hold shared read-only zero tensors, ops.const_zeros_like)
+        ex = self._exchange_layout()
+        self._pack_rest(ex, grads, False)
+        self._exchange_rest(ex, False)
+        return self._unpack_mean(ex, D.world()[1])     # (no copy back: `grads` may hold shared read-only zero tensors)
 
     # -- HIP-graph replay ------------------------------------------------------------------------------------------------
     def _state_tensors(self):
@@ -282,15 +360,20 @@ class TrainStep:
                 dst.copy_(src)
             g["lr_t"].fill_(self._lr_t(lr, t))
             g["bn_decay"].fill_(bn_decay)
+            ex = self._exchange_layout() if dp else None
             # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored.
             # No collective here: every rank restores its own snapshot, so the ranks stay in step.
             snap = [x.detach().clone() for x in self._state_tensors()]
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                loss, grads = self._forward_backward(*g["in"], g["bn_decay"])
+                cut = []
+                loss, grads = self._forward_backward(*g["in"], g["bn_decay"],
+                                                     between=(lambda hn, hg: (self._pack_head(ex, hn, hg), cut.append(1)))
+                                                     if dp and self.overlap_exchange else None)
                 if dp:
-                    grads = self._unpack_mean(self._pack(grads), 1)
+                    self._pack_rest(ex, grads, bool(cut))
+                    grads = self._unpack_mean(ex, 1)
                 self._apply(grads, g["lr_t"], t)
             torch.cuda.current_stream(dev).wait_stream(side)
             with torch.no_grad():
@@ -304,13 +387,38 @@ class TrainStep:
                     g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"])
                     self._apply(grads, g["lr_t"], t)
             else:
+                # Data-parallel: [forward, head backward, pack head] | RCCL (head, asynchronous) | [backbone backward, moving averages,
+                # pack rest] | RCCL (rest) | [mean, unpack, Adam] -- the captures end and begin INSIDE the step, at the cut of its
+                # backward (the `between` callback runs on this thread, between two autograd calls).
                 ws = D.world()[1]
-                with torch.cuda.graph(g["graph"]):
-                    g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"])
-                    g["ex"] = self._pack(grads)
+                g["graph_mid"] = torch.cuda.CUDAGraph() if self.overlap_exchange else None
                 g["graph2"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g["graph2"], pool=g["graph"].pool()):
-                    self._apply(self._unpack_mean(g["ex"], ws), g["lr_t"], t)
+                g["cut"] = False
+                torch.cuda.synchronize(dev)
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(torch.cuda.current_stream(dev))
+
+                def between(hn, hg):
+                    self._pack_head(ex, hn, hg)
+                    g["graph"].capture_end()
+                    g["graph_mid"].capture_begin(pool=g["graph"].pool())
+                    g["cut"] = True
+
+                with torch.cuda.stream(cap):
+                    g["graph"].capture_begin()
+                    try:
+                        g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"],
+                                                                  between=between if self.overlap_exchange else None)
+                        self._pack_rest(ex, grads, g["cut"])
+                    finally:
+                        (g["graph_mid"] if g["cut"] else g["graph"]).capture_end()
+                    g["graph2"].capture_begin(pool=g["graph"].pool())
+                    try:
+                        self._apply(self._unpack_mean(ex, ws), g["lr_t"], t)
+                    finally:
+                        g["graph2"].capture_end()
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                g["ex"] = ex
             self._graph = g
         src = _joined_along_dim1(inputs)
         if src is not None:                       # the caller's four slices of one tuple tensor: one copy, not four
@@ -323,7 +431,14 @@ class TrainStep:
         g["graph"].replay()
         if dp:
             import torch.distributed as dist
-            dist.all_reduce(g["ex"]["flat"], op=dist.ReduceOp.SUM)        # same stream: ordered between the two replays
+            ex = g["ex"]
+            pending = None
+            if g["cut"]:
+                pending = dist.all_reduce(ex["flat"][:ex["head_end"]], op=dist.ReduceOp.SUM, async_op=True)
+                g["graph_mid"].replay()                                     # the backbone's backward, under the head's exchange
+            self._exchange_rest(ex, g["cut"])                               # same stream: ordered between the replays
+            if pending is not None:
+                pending.wait()
             g["graph2"].replay()
         return g["loss"]
 

@@ -283,6 +283,10 @@ def proxyconv_tail(x, graph, k, scope_a, scope_b, bn_decay=None, is_training=Non
 # False: the training backbone is built from the per-layer operators (conv1d / proxyconv_tail) instead of the fused chain --
 # the second implementation the tests hold the chain to.
 USE_CHAIN = True
+# The backbone's output tensor of the LAST training forward (the concat of the block outputs, models/epc-net.py:134): where a
+# data-parallel step cuts its backward in two, so that the exchange of the head's gradients (17.8 of EPC-Net's 18.8 MB: hidden1_weights
+# and conv5) travels while the backbone's backward runs (training.TrainStep).
+BACKBONE_TAP = None
 
 
 def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None):
@@ -349,7 +353,9 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
             if RELU_MASK_TAPS is not None:      # (test hook: the layer's activation is not materialised by the fused node)
                 _tap_relu_mask(ops.bn_apply_train(z, mean, var, gamma, beta, 1e-3, True))
     assert at == len(rest)
-    return cat.reshape(B, N, 64 * nblocks)
+    global BACKBONE_TAP
+    BACKBONE_TAP = cat.reshape(B, N, 64 * nblocks)
+    return BACKBONE_TAP
 
 
 def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None):

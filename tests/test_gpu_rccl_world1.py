@@ -101,14 +101,16 @@ def _state(ts, st):
                      [ts.v[n].reshape(-1) for n in names])
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_data_parallel_train_step_through_rccl(rccl, graph):
-    """TrainStep.step with the data-parallel exchange live (pack -> RCCL all-reduce -> mean -> unpack -> Adam; with graph=True
-    the two HIP graphs around the eager all-reduce) must leave exactly the state of the plain single-process step."""
+@pytest.mark.parametrize("graph,overlap", [(False, True), (True, True), (False, False), (True, False)])
+def test_data_parallel_train_step_through_rccl(rccl, graph, overlap):
+    """TrainStep.step with the data-parallel exchange live must leave exactly the state of the plain single-process step.
+    overlap (the default): the backward is cut at the backbone's output, the head's gradients (17.9 of 18.8 MB) start their RCCL
+    all-reduce asynchronously and travel under the backbone's backward, the rest follows -- eager, and as THREE HIP graphs around the
+    two collectives; without it: one flat all-reduce after the whole backward (two graphs)."""
     D = rccl
     dev = torch.device("cuda:0")
     TR, V = H.pkg("training"), H.pkg("variables")
-    params = dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1)
+    params = dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, DP_OVERLAP=overlap)
     states, losses = [], []
     for dp in (False, True):
         D.force_collective(dp)
@@ -120,8 +122,10 @@ def test_data_parallel_train_step_through_rccl(rccl, graph):
             ls.append(float(loss))
         if dp:
             assert ts._exchange is not None and ts._exchange["flat"].numel() >= 4704832      # the flat RCCL message
+            assert ts._exchange["head_end"] >= 4600000 and len(ts._exchange["below"]) == 48     # conv1 .. conv4_b: 12 layers x (W, b, gamma, beta)
             if graph:
-                assert ts._graph["dp"] and "graph2" in ts._graph
+                assert ts._graph["dp"] and "graph2" in ts._graph and ts._graph["cut"] == overlap
+                assert (ts._graph["graph_mid"] is not None) == overlap
         states.append(_state(ts, st).cpu())
         losses.append(ls)
     D.force_collective(True)
