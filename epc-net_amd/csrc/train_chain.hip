@@ -25,8 +25,16 @@
 // linear_stats64_kernel / linear_bn_bwd64_kernel (train_ops.hip), which these kernels replace inside the step.
 #include "common.h"
 
-#define CH_ROWS_PER_WG 256   // rows per workgroup = rows per partial: 4 waves x 2 tiles of 32 rows
-#define CH_TILES_PER_WAVE 2
+// Geometry.  A workgroup takes `wg_rows` consecutive rows (= one partial), a multiple of 32; its waves take the 32-row tiles
+// wave, wave + nw, ... .  wg_rows is chosen on the host so that the grid is ONE workgroup per CU whenever the rows allow it
+// (epc_chain_wg_rows: tiles / CUs rounded up -- 9 tiles for the 73 728 rows of an 18 x 4096 tuple on 256 CUs, 11 for 22 clouds):
+// fixed 256-row workgroups were 288 on 256 CUs, i.e. 32 CUs with twice the work of the others, and these kernels are one dependent
+// chain per wave -- the kernel took as long as its busiest CU.  One tile per wave where the registers allow (forward: up to 12 waves),
+// otherwise strided tiles (backward: up to 8 waves).
+#define CH_MAX_TILES 16      // tiles per workgroup (wg_rows <= 512)
+#define CH_FWD_MAX_WAVES 8     // the row-streaming forward layer: two waves per SIMD (at three its weight fragments spill)
+#define CH_GATHER_MAX_WAVES 12 // the gather layer: three waves per SIMD, one tile each -- bytes in flight are what it is short of
+#define CH_BWD_MAX_WAVES 8
 
 typedef short ch_s16x4 __attribute__((ext_vector_type(4)));
 typedef short ch_s16x8 __attribute__((ext_vector_type(8)));
@@ -82,6 +90,7 @@ __device__ __forceinline__ void ch_st8(float* p, const float (&v)[8]) {
 struct ChBn {
     const float* stats;   // partials [parts][3][64]: sums of (v - p), (v - p)^2 and the pivot p, of the product WITHOUT `bias`; null: mean / var given
     int parts;
+    int part_rows;        // rows per partial (the last one shorter)
     const float* bias;    // added to the pooled mean (may be null)
     float* mean;          // pooled: written by workgroup 0;  given: read
     float* var;
@@ -98,15 +107,14 @@ struct ChBn {
 // ch_bn_finish (after the caller has ISSUED its loads) merges the slices and leaves the layer's s, t in coef[0..1][64] (LDS).  A
 // pooled prologue costs ~7 us of dependent steps when written naively (scripts/time_chain.py): the affine parameters are requested
 // first, the partials in one or two trips, and the rows travel under the merge.
-#define CH_POOL_CHUNK 18   // moment partials per slice and round trip: 16 x 18 = the 288 partials of an 18 x 4096 tuple in ONE trip
+#define CH_POOL_CHUNK 8    // moment partials per slice and round trip (24 float4 in flight per thread): 256 partials in two trips
 struct ChBnRegs {          // per-thread state between the two halves (threads 0..63: the column's affine parameters / given moments)
     float gamma, beta, bias, mean, var;
 };
 __device__ __forceinline__ ChBnRegs ch_bn_begin(const ChBn& bn, int rows, double* scratch) {
-    // (which THREAD takes which slice rotates with the workgroup: every workgroup reads the same partials, and 36 of them per XCD asking
-    // for the same L2 lines in the same order at the same moment queue up on those lines' channels.  The slices and the order in which
-    // they merge do not depend on it: same bits.)
-    const int tid = threadIdx.x, cq = tid & 15, ps = ((tid >> 4) + (int)blockIdx.x) & 15;
+    // 16 slices when the workgroup has 256 threads or more (the first 256 pool), fewer in the small grids of short inputs
+    const int tid = threadIdx.x, cq = tid & 15, ps = tid >> 4;
+    const int nslices = min((int)blockDim.x >> 4, 16);
     ChBnRegs r;
     r.gamma = r.beta = r.bias = r.mean = r.var = 0.f;
     if (tid < 64) {
@@ -114,14 +122,14 @@ __device__ __forceinline__ ChBnRegs ch_bn_begin(const ChBn& bn, int rows, double
         if (bn.bias) r.bias = bn.bias[tid];
         if (!bn.stats) r.mean = bn.mean[tid], r.var = bn.var[tid];
     }
-    if (!bn.stats) return r;
+    if (!bn.stats || ps >= nslices) return r;
     double N[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, PL[4] = {0, 0, 0, 0};
     bool first = true;
-    for (int t0 = ps; t0 < bn.parts; t0 += 16 * CH_POOL_CHUNK) {
+    for (int t0 = ps; t0 < bn.parts; t0 += nslices * CH_POOL_CHUNK) {
         float4 v1[CH_POOL_CHUNK], v2[CH_POOL_CHUNK], vp[CH_POOL_CHUNK];
 #pragma unroll
         for (int u = 0; u < CH_POOL_CHUNK; ++u) {
-            const int t = min(t0 + 16 * u, bn.parts - 1);
+            const int t = min(t0 + nslices * u, bn.parts - 1);
             const float* p = bn.stats + (size_t)t * 192 + 4 * cq;
 #ifdef CH_ABL_NOLOAD
             v1[u] = v2[u] = vp[u] = make_float4((float)t, 1.f, 2.f, (float)cq);
@@ -132,9 +140,9 @@ __device__ __forceinline__ ChBnRegs ch_bn_begin(const ChBn& bn, int rows, double
         }
 #pragma unroll
         for (int u = 0; u < CH_POOL_CHUNK; ++u) {
-            const int t = t0 + 16 * u;
+            const int t = t0 + nslices * u;
             if (t < bn.parts) {
-                const double nt = (double)min(CH_ROWS_PER_WG, rows - t * CH_ROWS_PER_WG);
+                const double nt = (double)min(bn.part_rows, rows - t * bn.part_rows);
                 const float s1[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w}, s2[4] = {v2[u].x, v2[u].y, v2[u].z, v2[u].w},
                             pv[4] = {vp[u].x, vp[u].y, vp[u].z, vp[u].w};
 #pragma unroll
@@ -173,7 +181,8 @@ __device__ __forceinline__ void ch_bn_finish(const ChBn& bn, const ChBnRegs& r, 
         if (bn.stats) {
             const double p0 = scratch[(3 * 16 + 0) * 64 + tid];
             double a = scratch[(1 * 16 + 0) * 64 + tid], b = scratch[(2 * 16 + 0) * 64 + tid];
-            for (int s = 1; s < 16; ++s) {
+            const int nslices = min((int)blockDim.x >> 4, 16);
+            for (int s = 1; s < nslices; ++s) {
                 const double n = scratch[(0 * 16 + s) * 64 + tid];
                 if (n > 0.0) {
                     const double as = scratch[(1 * 16 + s) * 64 + tid], bs = scratch[(2 * 16 + s) * 64 + tid];
@@ -194,39 +203,42 @@ __device__ __forceinline__ void ch_bn_finish(const ChBn& bn, const ChBnRegs& r, 
     __syncthreads();
 }
 
-#define CH_POOL_CHUNK_S 18 // sum partials per slice and round trip (36 float4 in flight per thread: ONE round trip for 288 partials)
+#define CH_POOL_CHUNK_S 16 // sum partials per slice and round trip (32 float4 in flight per thread: ONE round trip for 256 partials)
 // The two column sums of a BatchNorm backward (sum dy [mask], sum dy [mask] zhat) pooled from a producer's partials
 // [parts][2][64]: thread (cq, ps) adds partials ps, ps + 16, ... in double, the slices meet in order.  scratch: 2 * 16 * 64
 // doubles.  Results in s_sum[2][64] (LDS); workgroup 0 also writes dbeta = sum 0, dgamma = sum 1.  Ends with a barrier.
 __device__ __forceinline__ void ch_pool_sums(const float* __restrict__ psums, int parts, double* scratch, float (*s_sum)[64],
                                              float* dbeta, float* dgamma) {
-    const int tid = threadIdx.x, cq = tid & 15, ps = ((tid >> 4) + (int)blockIdx.x) & 15;   // (rotated like ch_bn_begin's)
+    const int tid = threadIdx.x, cq = tid & 15, ps = tid >> 4;
+    const int nslices = min((int)blockDim.x >> 4, 16);
     double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int t0 = ps; t0 < parts; t0 += 16 * CH_POOL_CHUNK_S) {
+    for (int t0 = ps; ps < nslices && t0 < parts; t0 += nslices * CH_POOL_CHUNK_S) {
         float4 v[CH_POOL_CHUNK_S][2];
 #pragma unroll
         for (int u = 0; u < CH_POOL_CHUNK_S; ++u) {
-            const int t = min(t0 + 16 * u, parts - 1);
+            const int t = min(t0 + nslices * u, parts - 1);
             const float* p = psums + (size_t)t * 128 + 4 * cq;
             v[u][0] = *reinterpret_cast<const float4*>(p), v[u][1] = *reinterpret_cast<const float4*>(p + 64);
         }
 #pragma unroll
         for (int u = 0; u < CH_POOL_CHUNK_S; ++u)
-            if (t0 + 16 * u < parts) {
+            if (t0 + nslices * u < parts) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     a[k][0] += (double)v[u][k].x, a[k][1] += (double)v[u][k].y, a[k][2] += (double)v[u][k].z, a[k][3] += (double)v[u][k].w;
             }
     }
+    if (ps < nslices) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) scratch[(k * 16 + ps) * 64 + 4 * cq + q] = a[k][q];
+            for (int q = 0; q < 4; ++q) scratch[(k * 16 + ps) * 64 + 4 * cq + q] = a[k][q];
+    }
     __syncthreads();
-    if (tid < 128) {
-        const int k = tid >> 6, c = tid & 63;
+    for (int o = tid; o < 128; o += blockDim.x) {   // (a 64-thread workgroup of a short input takes both sums in turn)
+        const int k = o >> 6, c = o & 63;
         double t = 0.0;
-        for (int s = 0; s < 16; ++s) t += scratch[(k * 16 + s) * 64 + c];
+        for (int s = 0; s < nslices; ++s) t += scratch[(k * 16 + s) * 64 + c];
         s_sum[k][c] = (float)t;
         if (blockIdx.x == 0) (k ? dgamma : dbeta)[c] = (float)t;
     }
@@ -249,33 +261,71 @@ struct ChFwdLinearArgs {
     const float* bias;
     float* z_out;
     float* stats_out;
-    int rows;
+    int rows, wg_rows;
     float eps;
 };
 
+// The moment partial of a workgroup from its waves' (sum, sum of squares, pivot, rows): wave 0 rebases the others onto its own pivot
+// in wave order (fixed order: registers, lane halves, waves) and stores [3][64] at `out`.
+//   sum (v - p0) = sum (v - pw) + n (pw - p0),  sum (v - p0)^2 = sum (v - pw)^2 + 2 (pw - p0) sum (v - pw) + n (pw - p0)^2
+// sred: [waves][3][64], snrows: [waves].  Called by every thread; contains the barrier.
+__device__ __forceinline__ void ch_store_stats(float (&s1)[2], float (&s2)[2], const float (&piv)[2], int my_rows, float (*sred)[3][64],
+                                               int* snrows, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+    }
+    if (wave > 0 && h == 0) {
+        sred[wave][0][i] = s1[0], sred[wave][0][32 + i] = s1[1];
+        sred[wave][1][i] = s2[0], sred[wave][1][32 + i] = s2[1];
+        sred[wave][2][i] = piv[0], sred[wave][2][32 + i] = piv[1];
+    }
+    if (lane == 0) snrows[wave] = my_rows;
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = 32 * nt + i;
+            float t1 = s1[nt], t2 = s2[nt];
+            for (int w = 1; w < nw; ++w) {
+                const float n_w = (float)snrows[w];
+                if (n_w > 0.f) {
+                    const float dp = sred[w][2][c] - piv[nt];
+                    t1 += sred[w][0][c] + n_w * dp;
+                    t2 += sred[w][1][c] + (2.0f * dp) * sred[w][0][c] + n_w * dp * dp;
+                }
+            }
+            out[0 * 64 + c] = t1, out[1 * 64 + c] = t2, out[2 * 64 + c] = piv[nt];
+        }
+    }
+}
+
 template <int PF>
-__global__ __launch_bounds__(256, 2) void chain_fwd_linear_kernel(ChFwdLinearArgs g) {
+__global__ __launch_bounds__(64 * CH_FWD_MAX_WAVES) void chain_fwd_linear_kernel(ChFwdLinearArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double scratch[];   // 4 * 16 * 64 doubles: the pooling slices
     __shared__ u32x4 Wf[2][4][PF][64];
-    __shared__ __attribute__((aligned(16))) double scratch[4 * 16 * 64];
     __shared__ __attribute__((aligned(16))) float coef[2][64];
     __shared__ __attribute__((aligned(16))) float s_mean[64], s_var[64];
-    __shared__ __attribute__((aligned(16))) float sred[3][3][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sred[CH_FWD_MAX_WAVES][3][64];
+    __shared__ int snrows[CH_FWD_MAX_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int rows = g.rows;
-    // Prologue order: the partials (one round trip, folded in registers) -> the wave's ROWS are requested -> the slices merge and the
-    // weights are staged while the rows travel.  A wave is alone on its SIMD in these grids (1152 waves on 1024 SIMDs): nothing else
-    // covers a round trip.
+    const int wg0 = blockIdx.x * g.wg_rows, tiles = min(g.wg_rows, rows - wg0 + 31) / 32;   // tiles of this workgroup (>= 1)
+    // Prologue order: the partials (folded in registers) -> the wave's first ROWS are requested -> the slices merge and the weights
+    // are staged while the rows travel.
     const ChBnRegs bnr = ch_bn_begin(g.bn, rows, scratch);
-    float zr[CH_TILES_PER_WAVE][4][8];
+    float zr[4][8];
+    {
+        const int row = min(wg0 + wave * 32 + i, rows - 1);
 #pragma unroll
-    for (int t = 0; t < CH_TILES_PER_WAVE; ++t) {
-        const int row = min((int)blockIdx.x * CH_ROWS_PER_WG + (wave * CH_TILES_PER_WAVE + t) * 32 + i, rows - 1);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) ch_ld8(g.zin + (size_t)row * 64 + 16 * s4 + 8 * h, zr[t][s4]);
+        for (int s4 = 0; s4 < 4; ++s4) ch_ld8(g.zin + (size_t)row * 64 + 16 * s4 + 8 * h, zr[s4]);
     }
     if (g.W) {   // B[k = in][n = out]: lane (n = 32 nt + i, k group h) of k-step s holds W[16 s + 8 h .. + 7][n]
-        for (int f = tid; f < 2 * 4 * 64; f += 256) {
+        for (int f = tid; f < 2 * 4 * 64; f += blockDim.x) {
             const int l = f & 63, s4 = (f >> 6) & 3, nt = f >> 8;
             const float* src = g.W + (size_t)(16 * s4 + 8 * (l >> 5)) * 64 + 32 * nt + (l & 31);
             float v[8];
@@ -290,13 +340,18 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_linear_kernel(ChFwdLinearArg
     ch_bn_finish(g.bn, bnr, rows, g.eps, scratch, s_mean, s_var, coef);   // (its barriers also cover Wf)
 
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, piv[2] = {0.f, 0.f};
+    int my_rows = 0;
     const float b0 = g.bias ? g.bias[i] : 0.f, b1 = g.bias ? g.bias[32 + i] : 0.f;
-#pragma unroll
-    for (int t = 0; t < CH_TILES_PER_WAVE; ++t) {
-        const int base = blockIdx.x * CH_ROWS_PER_WG + (wave * CH_TILES_PER_WAVE + t) * 32;   // wave-uniform
-        if (base >= rows) break;
+#pragma unroll 1
+    for (int tl = wave; tl < tiles; tl += nw) {
+        const int base = wg0 + tl * 32;   // wave-uniform, < rows
         const int row = base + i;
         const bool ok = row < rows;
+        if (tl != wave) {                 // (the first tile's rows were requested in the prologue)
+            const int r = min(row, rows - 1);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) ch_ld8(g.zin + (size_t)r * 64 + 16 * s4 + 8 * h, zr[s4]);
+        }
         bf16x8 a[4][PF];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -304,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_linear_kernel(ChFwdLinearArg
             float cs[8], ct[8], v[8];
             ch_ld8(&coef[0][c0], cs), ch_ld8(&coef[1][c0], ct);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fmaxf(zr[t][s4][q] * cs[q] + ct[q], 0.f);
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(zr[s4][q] * cs[q] + ct[q], 0.f);
             if (g.resid) {
                 float r[8];
                 ch_ld8(g.resid + (size_t)(ok ? row : 0) * 64 + c0, r);
@@ -332,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_linear_kernel(ChFwdLinearArg
                 acc = ch_prod<PF>(a[s4], w, acc);
             }
             const float bv = nt ? b1 : b0;
-            if (t == 0) piv[nt] = __shfl(acc[0], i);   // row `base` of the wave's first tile
+            if (tl == wave) piv[nt] = __shfl(acc[0], i);   // row `base` of the wave's first tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = base + mfma_row(r, h);
@@ -345,38 +400,10 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_linear_kernel(ChFwdLinearArg
                 }
             }
         }
+        my_rows += min(32, rows - base);
     }
     if (!g.W) return;
-    // fixed order: registers, lane halves, waves 0..3 (each rebased onto wave 0's pivot)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        s1[nt] += __shfl_xor(s1[nt], 32);
-        s2[nt] += __shfl_xor(s2[nt], 32);
-    }
-    if (wave > 0 && h == 0) {
-        sred[wave - 1][0][i] = s1[0], sred[wave - 1][0][32 + i] = s1[1];
-        sred[wave - 1][1][i] = s2[0], sred[wave - 1][1][32 + i] = s2[1];
-        sred[wave - 1][2][i] = piv[0], sred[wave - 1][2][32 + i] = piv[1];
-    }
-    __syncthreads();
-    if (wave == 0 && h == 0) {
-        const int wg_rows = min(CH_ROWS_PER_WG, rows - (int)blockIdx.x * CH_ROWS_PER_WG);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int c = 32 * nt + i;
-            float t1 = s1[nt], t2 = s2[nt];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float nw = (float)max(0, min(32 * CH_TILES_PER_WAVE, wg_rows - w * 32 * CH_TILES_PER_WAVE));
-                const float dp = nw > 0.f ? sred[w - 1][2][c] - piv[nt] : 0.f;
-                t1 += sred[w - 1][0][c] + nw * dp;
-                t2 += sred[w - 1][1][c] + (2.0f * dp) * sred[w - 1][0][c] + nw * dp * dp;
-            }
-            g.stats_out[((size_t)blockIdx.x * 3 + 0) * 64 + c] = t1;
-            g.stats_out[((size_t)blockIdx.x * 3 + 1) * 64 + c] = t2;
-            g.stats_out[((size_t)blockIdx.x * 3 + 2) * 64 + c] = piv[nt];
-        }
-    }
+    ch_store_stats(s1, s2, piv, my_rows, sred, snrows, g.stats_out + (size_t)blockIdx.x * 192);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -401,25 +428,28 @@ struct ChFwdGatherArgs {
     float* d;
     float* z_out;
     float* stats_out;
-    int rows;
+    int rows, wg_rows;
     float eps;
 };
 #define CH_STG_STRIDE 68   // floats per row of the staging tile (272 B: conflict-free float4 rows both ways)
+#define CH_STG_FLOATS (32 * CH_STG_STRIDE)
 
 template <int PF>
-__global__ __launch_bounds__(256, 2) void chain_fwd_gather_kernel(ChFwdGatherArgs g) {
+__global__ __launch_bounds__(64 * CH_GATHER_MAX_WAVES) void chain_fwd_gather_kernel(ChFwdGatherArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double scratch[];   // pooling slices (4 * 16 * 64 doubles); then one staging tile per wave
     __shared__ u32x4 Wf[2][4][PF][64];
-    __shared__ __attribute__((aligned(16))) double scratch[4 * 32 * CH_STG_STRIDE / 2];   // pooling (4 * 16 * 64 doubles); then the staging tiles
     __shared__ __attribute__((aligned(16))) float coef[2][64];
     __shared__ __attribute__((aligned(16))) float s_mean[64], s_var[64];
-    __shared__ __attribute__((aligned(16))) float sred[3][3][64];
-    static_assert(4 * 32 * CH_STG_STRIDE / 2 >= 4 * 16 * 64, "the pooling scratch aliases the staging tiles");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sred[CH_GATHER_MAX_WAVES][3][64];
+    __shared__ int snrows[CH_GATHER_MAX_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int p4 = lane >> 4, q = lane & 15;
     const int rows = g.rows;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);   // a cloud's tiles behind ONE L2 (speed only)
-    for (int f = tid; f < 2 * 4 * 64; f += 256) {
+    const int wg0 = lb * g.wg_rows, tiles = min(g.wg_rows, rows - wg0 + 31) / 32;
+    const ChBnRegs bnr = ch_bn_begin(g.bn, rows, scratch);
+    for (int f = tid; f < 2 * 4 * 64; f += blockDim.x) {
         const int l = f & 63, s4 = (f >> 6) & 3, nt = f >> 8;
         const float* src = g.W + (size_t)(16 * s4 + 8 * (l >> 5)) * 64 + 32 * nt + (l & 31);
         float v[8];
@@ -430,24 +460,23 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_gather_kernel(ChFwdGatherArg
 #pragma unroll
         for (int pc = 0; pc < PF; ++pc) Wf[nt][s4][pc][l] = __builtin_bit_cast(u32x4, p[pc]);
     }
-    {   // (pooling writes mean / var from workgroup 0 of the DISPATCH order: any one workgroup will do)
-        const ChBnRegs bnr = ch_bn_begin(g.bn, rows, scratch);
-        ch_bn_finish(g.bn, bnr, rows, g.eps, scratch, s_mean, s_var, coef);
-    }
+    // (pooling writes mean / var from workgroup 0 of the DISPATCH order: any one workgroup will do)
+    ch_bn_finish(g.bn, bnr, rows, g.eps, scratch, s_mean, s_var, coef);
     const float4 cs = *reinterpret_cast<const float4*>(&coef[0][4 * q]), ct = *reinterpret_cast<const float4*>(&coef[1][4 * q]);
     auto act = [&](const float4& v) {   // relu(bn0(.)) of the lane's four channels: the forward's own expression
         return make_float4(fmaxf(v.x * cs.x + ct.x, 0.f), fmaxf(v.y * cs.y + ct.y, 0.f), fmaxf(v.z * cs.z + ct.z, 0.f),
                            fmaxf(v.w * cs.w + ct.w, 0.f));
     };
-    float* stg = reinterpret_cast<float*>(scratch) + wave * (32 * CH_STG_STRIDE);
+    __syncthreads();   // every wave has its coefficients: the pooling slices may be overwritten by the staging tiles
+    float* stg = reinterpret_cast<float*>(scratch) + wave * CH_STG_FLOATS;
     const float4* z4 = reinterpret_cast<const float4*>(g.z0);
 
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, piv[2] = {0.f, 0.f};
+    int my_rows = 0;
     const float b0 = g.bias ? g.bias[i] : 0.f, b1 = g.bias ? g.bias[32 + i] : 0.f;
 #pragma unroll 1
-    for (int t = 0; t < CH_TILES_PER_WAVE; ++t) {
-        const int base = lb * CH_ROWS_PER_WG + (wave * CH_TILES_PER_WAVE + t) * 32;   // wave-uniform
-        if (base >= rows) break;
+    for (int tl = wave; tl < tiles; tl += nw) {
+        const int base = wg0 + tl * 32;   // wave-uniform, < rows
 #pragma unroll 1
         for (int r8 = 0; r8 < 8; ++r8) {
             const int pt = base + 4 * r8 + p4;
@@ -518,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_gather_kernel(ChFwdGatherArg
                 acc = ch_prod<PF>(a[s4], w, acc);
             }
             const float bv = nt ? b1 : b0;
-            if (t == 0) piv[nt] = __shfl(acc[0], i);
+            if (tl == wave) piv[nt] = __shfl(acc[0], i);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = base + mfma_row(r, h);
@@ -531,36 +560,9 @@ __global__ __launch_bounds__(256, 2) void chain_fwd_gather_kernel(ChFwdGatherArg
                 }
             }
         }
+        my_rows += min(32, rows - base);
     }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        s1[nt] += __shfl_xor(s1[nt], 32);
-        s2[nt] += __shfl_xor(s2[nt], 32);
-    }
-    if (wave > 0 && h == 0) {
-        sred[wave - 1][0][i] = s1[0], sred[wave - 1][0][32 + i] = s1[1];
-        sred[wave - 1][1][i] = s2[0], sred[wave - 1][1][32 + i] = s2[1];
-        sred[wave - 1][2][i] = piv[0], sred[wave - 1][2][32 + i] = piv[1];
-    }
-    __syncthreads();
-    if (wave == 0 && h == 0) {
-        const int wg_rows = min(CH_ROWS_PER_WG, rows - lb * CH_ROWS_PER_WG);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int c = 32 * nt + i;
-            float t1 = s1[nt], t2 = s2[nt];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float nw = (float)max(0, min(32 * CH_TILES_PER_WAVE, wg_rows - w * 32 * CH_TILES_PER_WAVE));
-                const float dp = nw > 0.f ? sred[w - 1][2][c] - piv[nt] : 0.f;
-                t1 += sred[w - 1][0][c] + nw * dp;
-                t2 += sred[w - 1][1][c] + (2.0f * dp) * sred[w - 1][0][c] + nw * dp * dp;
-            }
-            g.stats_out[((size_t)lb * 3 + 0) * 64 + c] = t1;
-            g.stats_out[((size_t)lb * 3 + 1) * 64 + c] = t2;
-            g.stats_out[((size_t)lb * 3 + 2) * 64 + c] = piv[nt];
-        }
-    }
+    ch_store_stats(s1, s2, piv, my_rows, sred, snrows, g.stats_out + (size_t)lb * 192);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -598,7 +600,7 @@ struct ChBwdLinearArgs {
     const float* zp;
     ChBnGiven pbn;
     float* psums;
-    int rows;
+    int rows, wg_rows;
     float eps;
 };
 #define CH_IMG_BYTES 4096   // one piece of the transposition image: 32 rows x 128 B
@@ -623,22 +625,22 @@ __device__ __forceinline__ bf16x8 ch_tr_frag(const char* img, int t, int s2, int
 }
 
 template <int PB>
-__global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArgs g) {
+__global__ __launch_bounds__(64 * CH_BWD_MAX_WAVES) void chain_bwd_linear_kernel(ChBwdLinearArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char img_all[];   // per wave: hi + lo image (2 * CH_IMG_BYTES); also the pooling scratch
+                                                                      // (16 KB) and, at the end, the parked partials (16 KB per parked wave)
     __shared__ __attribute__((aligned(16))) float coef[6][64];    // s, t (mask), mean, k1, dbeta / rows, rstd dgamma / rows
     __shared__ __attribute__((aligned(16))) float xcoef[2][64];   // the input's BatchNorm: s, t
     __shared__ __attribute__((aligned(16))) float pcoef[4][64];   // the producer's BatchNorm: s, t (mask), mean, rstd
     __shared__ __attribute__((aligned(16))) float s_sum[2][64];
     __shared__ u32x4 Wf[2][4][PB][64];                             // W as A fragments: [in tile][k-step][piece][lane]
-    __shared__ __attribute__((aligned(16))) char img[4][2 * CH_IMG_BYTES];   // per wave: hi + lo image; also pooling scratch and, at the end, the parked partials
-    __shared__ __attribute__((aligned(16))) float sumt[4][CH_SUMT_WORDS];    // per wave: [2 quantities][32 rows][8 channels] of the producer's sums
-    static_assert(sizeof(img) >= 2 * 16 * 64 * sizeof(double), "the pooling scratch aliases the images");
-    static_assert(sizeof(img) >= 2 * 4 * 16 * 64 * sizeof(float), "the parked partials alias the images");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float sumt[CH_BWD_MAX_WAVES][CH_SUMT_WORDS];   // per wave: [2 quantities][32 rows][8 channels] of the producer's sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int rows = g.rows;
+    const int wg0 = blockIdx.x * g.wg_rows, tiles = min(g.wg_rows, rows - wg0 + 31) / 32;
     const float inv_rows = 1.0f / (float)rows;
     // W (in, out) row-major: A[m = in][k = out]; lane (m = 32 mt + i, k group h) of k-step s holds W[m][16 s + 8 h .. + 7]
-    for (int f = tid; f < 2 * 4 * 64; f += 256) {
+    for (int f = tid; f < 2 * 4 * 64; f += blockDim.x) {
         const int l = f & 63, s4 = (f >> 6) & 3, mt = f >> 8;
         float v[8];
         ch_ld8(g.W + (size_t)(32 * mt + (l & 31)) * 64 + 16 * s4 + 8 * (l >> 5), v);
@@ -650,14 +652,14 @@ __global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArg
     // the wave's first tile of dy and z is requested BEFORE the prologue's dependent round trips (pooling the sum partials, the
     // coefficients): in flight under all of it (later tiles' at the head of their body; clamped rows)
     float gv0[4][8], zv0[4][8];
-    auto request_tile = [&](int t, float (&gv)[4][8], float (&zv)[4][8]) {
-        const int r = min((int)blockIdx.x * CH_ROWS_PER_WG + (wave * CH_TILES_PER_WAVE + t) * 32 + i, rows - 1);
+    auto request_tile = [&](int tl, float (&gv)[4][8], float (&zv)[4][8]) {
+        const int r = min(wg0 + tl * 32 + i, rows - 1);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
             ch_ld8(g.dy + (size_t)r * g.dy_stride + 16 * s4 + 8 * h, gv[s4]), ch_ld8(g.z + (size_t)r * 64 + 16 * s4 + 8 * h, zv[s4]);
     };
-    request_tile(0, gv0, zv0);
-    ch_pool_sums(g.sums, g.parts, reinterpret_cast<double*>(&img[0][0]), s_sum, g.dbeta, g.dgamma);
+    request_tile(wave, gv0, zv0);
+    ch_pool_sums(g.sums, g.parts, reinterpret_cast<double*>(img_all), s_sum, g.dbeta, g.dgamma);
     if (tid < 64) {
         const float mu = g.bn.mean[tid], rs = 1.0f / sqrtf(g.bn.var[tid] + g.eps), ga = g.bn.gamma[tid];
         const ChBnAffine a = ch_bn_affine(mu, g.bn.var[tid], ga, g.bn.beta[tid], g.eps);
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArg
     for (int o = 0; o < 8; ++o) psum[o] = 0.f;
     float* mysum = sumt[wave];
 
-    char* my = img[wave];
+    char* my = img_all + (size_t)wave * 2 * CH_IMG_BYTES;
     auto put = [&](int s4, const bf16x8 (&p)[PB]) {   // the lane's row i, channels 16 s4 + 8 h .. + 7 = chunk 2 s4 + h
         const int o = ch_img_off(i, 2 * s4 + h);
 #pragma unroll
@@ -697,9 +699,8 @@ __global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArg
     };
 
     // one tile of 32 rows; gv / zv: its dy and z rows, already requested
-    auto do_tile = [&](int t, float (&gv)[4][8], float (&zv)[4][8]) {
-        const int base = blockIdx.x * CH_ROWS_PER_WG + (wave * CH_TILES_PER_WAVE + t) * 32;   // wave-uniform
-        if (base >= rows) return;
+    auto do_tile = [&](int tl, float (&gv)[4][8], float (&zv)[4][8]) {
+        const int base = wg0 + tl * 32;   // wave-uniform, < rows
         const int row = base + i;
         const bool ok = row < rows;
         const size_t rsafe = (size_t)(ok ? row : 0);
@@ -823,31 +824,33 @@ __global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArg
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // before the next tile overwrites the image
     };
-    do_tile(0, gv0, zv0);
+    if (wave < tiles) do_tile(wave, gv0, zv0);
 #pragma unroll 1
-    for (int t = 1; t < CH_TILES_PER_WAVE; ++t) {   // (their rows are requested at the head of the body: a prefetch under the previous
-        float gv[4][8], zv[4][8];                   //  tile would keep 64 more registers live beside accW)
-        request_tile(t, gv, zv);
-        do_tile(t, gv, zv);
+    for (int tl = wave + nw; tl < tiles; tl += nw) {   // (their rows are requested at the head of the body: a prefetch under the previous
+        float gv[4][8], zv[4][8];                      //  tile would keep 64 more registers live beside accW)
+        request_tile(tl, gv, zv);
+        do_tile(tl, gv, zv);
     }
-    // ---- the producer's sums: over the 32 rows of a lane half (butterfly: every lane ends with the half's total), then over the
-    //      four waves in order: one partial per workgroup ----
+    // ---- the producer's sums: the waves' column sums meet in wave order: one partial per workgroup ----
     __syncthreads();   // every wave is done with its image: what follows aliases them
     if (g.zp) {
-        float (*pred)[2][64] = reinterpret_cast<float (*)[2][64]>(&img[0][0]);   // [wave][sum][channel]
+        float (*pred)[2][64] = reinterpret_cast<float (*)[2][64]>(img_all);   // [wave][sum][channel]
         if (lane < 16) {
 #pragma unroll
             for (int o = 0; o < 8; ++o) pred[wave][(lane >> 3) & 1][32 * (o >> 2) + 8 * (o & 3) + (lane & 7)] = psum[o];
         }
         __syncthreads();
-        if (tid < 128) {
-            const int k = tid >> 6, c = tid & 63;
-            g.psums[((size_t)blockIdx.x * 2 + k) * 64 + c] = ((pred[0][k][c] + pred[1][k][c]) + pred[2][k][c]) + pred[3][k][c];
+        for (int o = tid; o < 128; o += blockDim.x) {   // (a one-wave workgroup of a short input takes both sums in turn)
+            const int k = o >> 6, c = o & 63;
+            float t = pred[0][k][c];
+            for (int w = 1; w < nw; ++w) t += pred[w][k][c];
+            g.psums[((size_t)blockIdx.x * 2 + k) * 64 + c] = t;
         }
         __syncthreads();
     }
-    // ---- the four waves' dW partials meet pairwise, ((w0 + w1) + (w2 + w3)): a fixed order; wave 0 stores the workgroup's ----
-    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(&img[0][0]);   // [slot][tile][register][lane]
+    // ---- the waves' dW partials meet in a fixed binary tree, ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)) with absent waves
+    //      left out; wave 0 stores the workgroup's.  A parked partial is 16 KB: the images of two waves. ----
+    float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(img_all);   // [slot][tile][register][lane]
     auto park = [&](int slot) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -864,14 +867,15 @@ __global__ __launch_bounds__(256, 2) void chain_bwd_linear_kernel(ChBwdLinearArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accW[mt][nt][r] += red[slot][mt * 2 + nt][r][lane];
     };
-    if (wave & 1) park(wave >> 1);
-    __syncthreads();
-    if (!(wave & 1)) take(wave >> 1);
-    __syncthreads();
-    if (wave == 2) park(0);
-    __syncthreads();
+#pragma unroll
+    for (int step = 1; step < CH_BWD_MAX_WAVES; step <<= 1) {
+        // waves that are odd multiples of `step` park (slot = wave / (2 step)); their even partners take -- if the parker exists
+        if ((wave & (2 * step - 1)) == step) park(wave / (2 * step));
+        __syncthreads();
+        if ((wave & (2 * step - 1)) == 0 && wave + step < nw) take(wave / (2 * step));
+        __syncthreads();
+    }
     if (wave == 0) {
-        take(0);
         float* out = g.dWpart + (size_t)blockIdx.x * 4096;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -900,7 +904,7 @@ struct ChBwdGatherArgs {
     const int32_t* ovf_list;   // per cloud n slots: their in-cloud indices, ascending
     const float* xyz;
     const float* kth;
-    int n, total;
+    int n, total, wg_rows;
     float kdiv;
     const float* z0;
     ChBnGiven bn;
@@ -909,7 +913,7 @@ struct ChBwdGatherArgs {
     float eps;
 };
 
-// 1024 threads: 64 points in flight per workgroup, four sequential points per 16-lane slot (256 rows per workgroup = one partial).
+// 1024 threads: 64 points in flight per workgroup, wg_rows / 64 sequential points per 16-lane slot (one partial per workgroup).
 // (256 threads walking 16 points each took 107 us per launch at 18 x 4096: the chain degree -> offset -> list -> rows is four
 // dependent round trips per point, and only waves in flight hide them.)
 #define CH_GB_THREADS 1024
@@ -929,10 +933,9 @@ __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGa
     const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
     const float4* s4 = reinterpret_cast<const float4*>(g.s);
     float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int wg_end = min(g.total, (lb + 1) * g.wg_rows);
 #pragma unroll 1
-    for (int it = 0; it < CH_ROWS_PER_WG / CH_GB_SLOTS; ++it) {
-        const int j = lb * CH_ROWS_PER_WG + it * CH_GB_SLOTS + slot;
-        if (j >= g.total) break;
+    for (int j = lb * g.wg_rows + slot; j < wg_end; j += CH_GB_SLOTS) {
         const int deg = g.rdeg[j];
         const int32_t* lst = g.rlist + g.roff[j];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1005,10 +1008,10 @@ __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGa
 //                         the first block's leading BatchNorm (its layer, conv1 with K = 3, keeps its own small kernels)
 //   chain_dw_sum_kernel   dW[l] = sum over the workgroup partials of layer l, ascending, every layer of the chain in ONE launch
 // ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chain_stats_kernel(const float* __restrict__ z, int rows, float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void chain_stats_kernel(const float* __restrict__ z, int rows, int wg_rows, float* __restrict__ stats) {
     __shared__ __attribute__((aligned(16))) float red[2][16][64];
     const int tid = threadIdx.x, q = tid & 15, rg = tid >> 4;
-    const int r0 = blockIdx.x * CH_ROWS_PER_WG, r1 = min(rows, r0 + CH_ROWS_PER_WG);
+    const int r0 = blockIdx.x * wg_rows, r1 = min(rows, r0 + wg_rows);
     const float4 pv = *reinterpret_cast<const float4*>(z + (size_t)r0 * 64 + 4 * q);   // the pivot: the workgroup's first row
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
 #pragma unroll 4
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(256) void chain_stats_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void chain_sums_kernel(const float* __restrict__ dy, int dy_stride, const float* __restrict__ z,
-                                                         ChBnGiven bn, float eps, int rows, float* __restrict__ psums) {
+                                                         ChBnGiven bn, float eps, int rows, int wg_rows, float* __restrict__ psums) {
     __shared__ __attribute__((aligned(16))) float pcoef[4][64];
     __shared__ __attribute__((aligned(16))) float red[2][16][64];
     const int tid = threadIdx.x, q = tid & 15, rg = tid >> 4;
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(256) void chain_sums_kernel(const float* __restrict
     __syncthreads();
     const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][4 * q]), qt = *reinterpret_cast<const float4*>(&pcoef[1][4 * q]);
     const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
-    const int r0 = blockIdx.x * CH_ROWS_PER_WG, r1 = min(rows, r0 + CH_ROWS_PER_WG);
+    const int r0 = blockIdx.x * wg_rows, r1 = min(rows, r0 + wg_rows);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
@@ -1074,7 +1077,7 @@ __global__ __launch_bounds__(256) void chain_sums_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void chain_bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, ChBnGiven bn,
                                                            const float* __restrict__ sums, int parts, float* dgamma, float* dbeta,
-                                                           float eps, int rows, float* __restrict__ dz) {
+                                                           float eps, int rows, int wg_rows, float* __restrict__ dz) {
     __shared__ __attribute__((aligned(16))) double scratch[2 * 16 * 64];
     __shared__ __attribute__((aligned(16))) float s_sum[2][64];
     __shared__ __attribute__((aligned(16))) float coef[6][64];
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(256) void chain_bn_bwd_kernel(const float* __restri
         cs[e] = coef[0][4 * q + e], ct[e] = coef[1][4 * q + e], mu[e] = coef[2][4 * q + e];
         k1[e] = coef[3][4 * q + e], bb[e] = coef[4][4 * q + e], gg[e] = coef[5][4 * q + e];
     }
-    const int r0 = blockIdx.x * CH_ROWS_PER_WG, r1 = min(rows, r0 + CH_ROWS_PER_WG);
+    const int r0 = blockIdx.x * wg_rows, r1 = min(rows, r0 + wg_rows);
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
         const size_t o = (size_t)r * 64 + 4 * q;
@@ -1174,11 +1177,34 @@ __global__ __launch_bounds__(256) void knn_overflow_list_kernel(const int32_t* _
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 static bool ch_aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 
-extern "C" int epc_chain_parts(int rows) { return rows > 0 ? (rows + CH_ROWS_PER_WG - 1) / CH_ROWS_PER_WG : 0; }
+// rows per workgroup (= per partial): the 32-row tiles spread evenly over the CUs, at most CH_MAX_TILES per workgroup
+static int ch_wg_rows(int rows) {
+    const int tiles = (rows + 31) / 32, cus = epc_device_cu_count();
+    int t = (tiles + cus - 1) / cus;
+    t = t < 1 ? 1 : (t > CH_MAX_TILES ? CH_MAX_TILES : t);
+    return 32 * t;
+}
+extern "C" int epc_chain_parts(int rows) {
+    if (rows <= 0) return 0;
+    const int r = ch_wg_rows(rows);
+    return (rows + r - 1) / r;
+}
+static int ch_waves(int rows, int cap) {
+    const int t = ch_wg_rows(rows) / 32;
+    return t < cap ? t : cap;
+}
+static int ch_set_lds(const void* fn, size_t bytes, const char* who) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        epc_set_error("%s: hipFuncSetAttribute failed", who);
+        return EPC_EHIP;
+    }
+    return EPC_OK;
+}
 
-static ChBn make_bn(const float* stats, int parts, const float* bias, float* mean, float* var, const float* gamma, const float* beta) {
+static ChBn make_bn(const float* stats, int rows, const float* bias, float* mean, float* var, const float* gamma, const float* beta) {
     ChBn b;
-    b.stats = stats, b.parts = parts, b.bias = bias, b.mean = mean, b.var = var, b.gamma = gamma, b.beta = beta;
+    b.stats = stats, b.parts = epc_chain_parts(rows), b.part_rows = ch_wg_rows(rows), b.bias = bias, b.mean = mean, b.var = var;
+    b.gamma = gamma, b.beta = beta;
     return b;
 }
 
@@ -1194,12 +1220,13 @@ extern "C" int epc_chain_fwd_linear(const float* zin, const float* in_stats, con
                       (!a_out || a_stride % 4 == 0),
                   "tensors must be 16-byte aligned, strides multiples of 4");
     ChFwdLinearArgs g;
-    g.zin = zin, g.bn = make_bn(in_stats, epc_chain_parts(rows), in_bias, in_mean, in_var, in_gamma, in_beta);
+    g.zin = zin, g.bn = make_bn(in_stats, rows, in_bias, in_mean, in_var, in_gamma, in_beta);
     g.resid = resid, g.a_out = a_out, g.a_stride = a_stride, g.W = W, g.bias = bias, g.z_out = z_out, g.stats_out = stats_out;
-    g.rows = rows, g.eps = eps;
-    const dim3 grid(epc_chain_parts(rows));
-    if (pieces == 3) hipLaunchKernelGGL(chain_fwd_linear_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(chain_fwd_linear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.rows = rows, g.wg_rows = ch_wg_rows(rows), g.eps = eps;
+    const dim3 grid(epc_chain_parts(rows)), block(64 * ch_waves(rows, CH_FWD_MAX_WAVES));
+    const size_t lds = 4 * 16 * 64 * sizeof(double);
+    if (pieces == 3) hipLaunchKernelGGL(chain_fwd_linear_kernel<3>, grid, block, lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(chain_fwd_linear_kernel<1>, grid, block, lds, (hipStream_t)stream, g);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1216,12 +1243,17 @@ extern "C" int epc_chain_fwd_gather(const float* z0, const float* in_stats, cons
                   "tensors must be 16-byte aligned");
     const int rows = num_clouds * n;
     ChFwdGatherArgs g;
-    g.z0 = z0, g.bn = make_bn(in_stats, epc_chain_parts(rows), in_bias, in_mean, in_var, in_gamma, in_beta);
+    g.z0 = z0, g.bn = make_bn(in_stats, rows, in_bias, in_mean, in_var, in_gamma, in_beta);
     g.xyz = xyz, g.idx = idx, g.cnt = cnt, g.kth = kth, g.cap = cap, g.n = n, g.kdiv = (float)knn, g.W = W, g.bias = bias;
-    g.xm = xm, g.d = d, g.z_out = z_out, g.stats_out = stats_out, g.rows = rows, g.eps = eps;
-    const dim3 grid(epc_chain_parts(rows));
-    if (pieces == 3) hipLaunchKernelGGL(chain_fwd_gather_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(chain_fwd_gather_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.xm = xm, g.d = d, g.z_out = z_out, g.stats_out = stats_out, g.rows = rows, g.wg_rows = ch_wg_rows(rows), g.eps = eps;
+    const int nw = ch_waves(rows, CH_GATHER_MAX_WAVES);
+    const dim3 grid(epc_chain_parts(rows)), block(64 * nw);
+    size_t lds = (size_t)nw * CH_STG_FLOATS * sizeof(float);
+    if (lds < 4 * 16 * 64 * sizeof(double)) lds = 4 * 16 * 64 * sizeof(double);
+    const void* fn = pieces == 3 ? reinterpret_cast<const void*>(chain_fwd_gather_kernel<3>) : reinterpret_cast<const void*>(chain_fwd_gather_kernel<1>);
+    if (int rc = ch_set_lds(fn, lds, __func__)) return rc;
+    if (pieces == 3) hipLaunchKernelGGL(chain_fwd_gather_kernel<3>, grid, block, lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(chain_fwd_gather_kernel<1>, grid, block, lds, (hipStream_t)stream, g);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1251,10 +1283,15 @@ extern "C" int epc_chain_bwd_linear(const float* dy, int dy_stride, const float*
     g.dy = dy, g.dy_stride = dy_stride, g.z = z, g.bn = make_given(mean, var, gamma, beta), g.sums = sums, g.parts = epc_chain_parts(rows);
     g.dgamma = dgamma, g.dbeta = dbeta, g.W = W, g.x = x, g.x_stride = x_stride, g.xbn = make_given(x_mean, x_var, x_gamma, x_beta);
     g.dx = dx, g.dx_addend = dx_addend, g.addend_stride = addend_stride, g.dWpart = dw_partials;
-    g.zp = zp, g.pbn = make_given(p_mean, p_var, p_gamma, p_beta), g.psums = psums, g.rows = rows, g.eps = eps;
-    const dim3 grid(epc_chain_parts(rows));
-    if (pieces == 2) hipLaunchKernelGGL(chain_bwd_linear_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(chain_bwd_linear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.zp = zp, g.pbn = make_given(p_mean, p_var, p_gamma, p_beta), g.psums = psums, g.rows = rows, g.wg_rows = ch_wg_rows(rows), g.eps = eps;
+    const int nw = ch_waves(rows, CH_BWD_MAX_WAVES);
+    const dim3 grid(epc_chain_parts(rows)), block(64 * nw);
+    size_t lds = (size_t)nw * 2 * CH_IMG_BYTES;
+    if (lds < 2 * 16 * 64 * sizeof(double)) lds = 2 * 16 * 64 * sizeof(double);
+    const void* fn = pieces == 2 ? reinterpret_cast<const void*>(chain_bwd_linear_kernel<2>) : reinterpret_cast<const void*>(chain_bwd_linear_kernel<1>);
+    if (int rc = ch_set_lds(fn, lds, __func__)) return rc;
+    if (pieces == 2) hipLaunchKernelGGL(chain_bwd_linear_kernel<2>, grid, block, lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(chain_bwd_linear_kernel<1>, grid, block, lds, (hipStream_t)stream, g);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1270,8 +1307,8 @@ extern "C" int epc_chain_bwd_gather(const float* s, const float* dout, int dout_
                   "tensors must be 16-byte aligned, strides multiples of 4");
     ChBwdGatherArgs g;
     g.s = s, g.dout = dout, g.dout_stride = dout_stride, g.rdeg = rdeg, g.roff = roff, g.rlist = rlist, g.ovf_cnt = ovf_cnt, g.ovf_list = ovf_list, g.xyz = xyz;
-    g.kth = kth, g.n = n, g.total = num_clouds * n, g.kdiv = (float)knn, g.z0 = z0, g.bn = make_given(mean, var, gamma, beta);
-    g.psums = psums, g.dx = dx, g.eps = eps;
+    g.kth = kth, g.n = n, g.total = num_clouds * n, g.wg_rows = ch_wg_rows(g.total), g.kdiv = (float)knn, g.z0 = z0;
+    g.bn = make_given(mean, var, gamma, beta), g.psums = psums, g.dx = dx, g.eps = eps;
     hipLaunchKernelGGL(chain_bwd_gather_kernel, dim3(epc_chain_parts(g.total)), dim3(CH_GB_THREADS), 0, (hipStream_t)stream, g);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -1279,7 +1316,7 @@ extern "C" int epc_chain_bwd_gather(const float* s, const float* dout, int dout_
 
 extern "C" int epc_chain_stats(const float* z, int rows, float* stats, void* stream) {
     EPC_CHECK_ARG(z && stats && rows > 0 && ch_aligned16(z), "null pointer / bad shape / alignment");
-    hipLaunchKernelGGL(chain_stats_kernel, dim3(epc_chain_parts(rows)), dim3(256), 0, (hipStream_t)stream, z, rows, stats);
+    hipLaunchKernelGGL(chain_stats_kernel, dim3(epc_chain_parts(rows)), dim3(256), 0, (hipStream_t)stream, z, rows, ch_wg_rows(rows), stats);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1289,7 +1326,7 @@ extern "C" int epc_chain_sums(const float* dy, int dy_stride, const float* z, co
     EPC_CHECK_ARG(dy && z && mean && var && gamma && beta && psums && rows > 0, "null pointer / bad shape");
     EPC_CHECK_ARG(ch_aligned16(dy) && ch_aligned16(z) && dy_stride % 4 == 0, "tensors must be 16-byte aligned, strides multiples of 4");
     hipLaunchKernelGGL(chain_sums_kernel, dim3(epc_chain_parts(rows)), dim3(256), 0, (hipStream_t)stream, dy, dy_stride, z,
-                       make_given(mean, var, gamma, beta), eps, rows, psums);
+                       make_given(mean, var, gamma, beta), eps, rows, ch_wg_rows(rows), psums);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -1300,7 +1337,7 @@ extern "C" int epc_chain_bn_bwd(const float* dy, const float* z, const float* me
     EPC_CHECK_ARG(dy && z && mean && var && gamma && beta && sums && dgamma && dbeta && dz && rows > 0, "null pointer / bad shape");
     EPC_CHECK_ARG(ch_aligned16(dy) && ch_aligned16(z) && ch_aligned16(dz) && ch_aligned16(sums), "tensors must be 16-byte aligned");
     hipLaunchKernelGGL(chain_bn_bwd_kernel, dim3(epc_chain_parts(rows)), dim3(256), 0, (hipStream_t)stream, dy, z,
-                       make_given(mean, var, gamma, beta), sums, epc_chain_parts(rows), dgamma, dbeta, eps, rows, dz);
+                       make_given(mean, var, gamma, beta), sums, epc_chain_parts(rows), dgamma, dbeta, eps, rows, ch_wg_rows(rows), dz);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
