@@ -399,11 +399,13 @@ class KnnGraph:
         self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
         self._transposed = None
         self._overflow = None
+        self._pending = None
 
     def overflow(self):
         """(ovf_cnt (clouds,), ovf_list (clouds, n)): per cloud the points whose own list overflowed (cnt > cap: exact ties of
         duplicated / zero-padded clouds) -- the transposed graph does not list them, the chain's gather backward visits them with
         the exact test (epc_knn_overflow_lists).  Built on first use."""
+        self.join()
         if self._overflow is None:
             dev = self.xyz.device
             oc = torch.empty(self.num_clouds, dtype=torch.int32, device=dev)
@@ -416,17 +418,73 @@ class KnnGraph:
     def transposed(self):
         """(rdeg, roff, rlist): for every point the points that list it (epc_knn_transpose), built on first use -- the
         backward of every block of a step gathers over it."""
+        self.join()
         if self._transposed is None:
-            M = self.num_clouds * self.n
-            dev = self.xyz.device
-            rdeg = torch.empty(M, dtype=torch.int32, device=dev)
-            roff = torch.empty(M, dtype=torch.int32, device=dev)
-            cursor = torch.empty(M, dtype=torch.int32, device=dev)
-            rlist = torch.empty(M * L.EPC_KNN_CAP, dtype=torch.int32, device=dev)
+            rdeg, roff, cursor, rlist, oc, ol = self._build_transposed()
             L.check(L.lib().epc_knn_transpose(self.idx.data_ptr(), self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n,
                                               rdeg.data_ptr(), roff.data_ptr(), cursor.data_ptr(), rlist.data_ptr(), _st()))
-            self._transposed = (rdeg, roff, rlist)
+            L.check(L.lib().epc_knn_overflow_lists(self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n, oc.data_ptr(),
+                                                   ol.data_ptr(), _st()))
+            self._transposed, self._overflow = (rdeg, roff, rlist), (oc, ol)
         return self._transposed
+
+    def _build_transposed(self):
+        M = self.num_clouds * self.n
+        dev = self.xyz.device
+        rdeg = torch.empty(M, dtype=torch.int32, device=dev)
+        roff = torch.empty(M, dtype=torch.int32, device=dev)
+        cursor = torch.empty(M, dtype=torch.int32, device=dev)
+        rlist = torch.empty(M * L.EPC_KNN_CAP, dtype=torch.int32, device=dev)
+        oc = torch.empty(self.num_clouds, dtype=torch.int32, device=dev)
+        ol = torch.empty((self.num_clouds, self.n), dtype=torch.int32, device=dev)
+        self._scratch = cursor
+        return rdeg, roff, cursor, rlist, oc, ol
+
+    def prefetch_backward_lists(self):
+        """Start the transposed graph and the overflow lists -- needed by the BACKWARD only -- on a side stream now, under the forward
+        (training steps: tf_util.proxyconv_backbone).  Their kernels are small and latency-bound (count, scan, fill, sort: 90 us of a
+        step's critical path when run in line); the buffers are allocated on the calling stream, which joins in ``join`` -- at the
+        first use, or when a data-parallel step cuts its capture (training.TrainStep)."""
+        if self._transposed is not None or self._pending is not None:
+            return
+        dev = self.xyz.device
+        rdeg, roff, cursor, rlist, oc, ol = self._build_transposed()
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(cur)                      # the lists of this graph are complete on the calling stream
+        with torch.cuda.stream(side):
+            L.check(L.lib().epc_knn_transpose(self.idx.data_ptr(), self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n,
+                                              rdeg.data_ptr(), roff.data_ptr(), cursor.data_ptr(), rlist.data_ptr(), _st()))
+            L.check(L.lib().epc_knn_overflow_lists(self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n, oc.data_ptr(),
+                                                   ol.data_ptr(), _st()))
+        self._transposed, self._overflow, self._pending = (rdeg, roff, rlist), (oc, ol), side
+        _PENDING.append(self)
+
+    def join(self):
+        """The calling stream waits for the side work of ``prefetch_backward_lists`` (no-op when there is none)."""
+        if self._pending is not None:
+            torch.cuda.current_stream(self.xyz.device).wait_stream(self._pending)
+            self._pending = None
+            if self in _PENDING:
+                _PENDING.remove(self)
+
+
+_SIDE = {}
+_PENDING = []
+
+
+def _side_stream(dev):
+    s_ = _SIDE.get(dev.index)
+    if s_ is None:
+        s_ = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    return s_
+
+
+def join_side_work():
+    """Join every kNN graph's pending side-stream work into the calling stream (a step that ends a HIP-graph capture between its
+    forward and its backward must leave no forked stream behind)."""
+    for g in list(_PENDING):
+        g.join()
 
 
 class NeighbourMean(torch.autograd.Function):

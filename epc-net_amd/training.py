@@ -189,6 +189,7 @@ class TrainStep:
                 got = torch.autograd.grad(loss, [tap] + [self.store.vars[n] for n in head], allow_unused=True)
                 with torch.no_grad():
                     head_grads = [g if g is not None else ops.const_zeros_like(self.store.vars[n]) for n, g in zip(head, got[1:])]
+                    ops.join_side_work()      # (a capture may end inside `between`: no forked stream may be left behind)
                     between(head, head_grads)
                 if got[0] is not None:
                     torch.autograd.backward([tap], [got[0]])

@@ -287,6 +287,10 @@ USE_CHAIN = True
 # data-parallel step cuts its backward in two, so that the exchange of the head's gradients (17.8 of EPC-Net's 18.8 MB: hidden1_weights
 # and conv5) travels while the backbone's backward runs (training.TrainStep).
 BACKBONE_TAP = None
+# The transposed graph and the overflow lists are needed by the backward only; starting them on a side stream under the forward
+# (ops.KnnGraph.prefetch_backward_lists) was measured and does NOT pay -- 3.17-3.18 ms per step with it, 3.14-3.15 without, same box:
+# the forward's kernels already hold every CU, a forked stream inside the HIP graph adds dependencies, nothing overlaps.  Off.
+PREFETCH_BACKWARD_LISTS = False
 
 
 def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None):
@@ -309,6 +313,8 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
             outs.append(inp)
         return torch.cat(outs, dim=-1)
     L.require_gpu()
+    if PREFETCH_BACKWARD_LISTS:
+        graph.prefetch_backward_lists()  # the transposed graph (backward only) starts now, on a side stream, under the forward
     params, bns = [], []          # bns: (scope, gamma, beta, ema_mean, ema_var) in the node's output order
     w1 = b1 = None
     for b in range(1, nblocks + 1):
