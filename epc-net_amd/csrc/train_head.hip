@@ -346,3 +346,152 @@ extern "C" int epc_sq_err_bwd(const float* a, const float* b, long n, int mean, 
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// The VLAD feature gradient (backward of loupe.py:255-291 with respect to the point features), a product with K = 128 and a
+// 302-MB output at the training tuple's size:
+//     df[b][n][f] = sum_k a[b][n][k] dvlad[b][f][k]  +  sum_k dz[b][n][k] Wc[f][k]             (rows = B n_points, F = 1024, k < 64)
+// The generic tile GEMM took 184 us for it (plus 35 us of torch.cat to build its [a | dz] and [dvlad^T ; Wc^T] operands): 4608
+// workgroups of four short k-tiles each, every one re-reading and re-splitting operand tiles other workgroups have split already,
+// for an output that takes 67 us to write.  Here the wave's 32 rows of [a | dz] are RESIDENT as bf16 hi + lo fragments (64
+// registers, read and split once), the cloud's right operand is packed once per step into fragment order (vlad_df_pack_kernel:
+// 512 KB per cloud) and streams through a double-buffered 16-KB LDS chunk of 32 output columns shared by the workgroup's waves (global ->
+// registers under the previous chunk's products -> LDS), one barrier per chunk; the wave writes whole 128-byte row segments.
+// Measured at 18 x 4096 rows (scripts/time_df.py): 114 us against 160-175 us for torch.cat + the generic product, the same bits.
+// Four-wave workgroups (three per CU at 146 registers): eight-wave ones at 128 registers spilled and took 136-165 us.  Arithmetic: two bf16 pieces per operand, three products
+// (epc_gemm_f32_fast's); PIECES = 1: one bf16 value per operand.
+// ----------------------------------------------------------------------------------------------------------------
+#define VDF_WAVES 4
+#define VDF_CHUNK_U4 (8 * 2 * 64)    // u32x4 per 32-column chunk: [k-step 8][piece 2][lane 64] = 16 KB
+#ifndef VDF_NT
+#define VDF_NT 1                      // 32-column chunks per LDS stage (2 = a row's 64 columns leave as one 256-byte run: measured slower, 160 vs 136 us)
+#endif
+
+// Bp[b][chunk c][k-step s][piece][lane (i, h)][8 bf16]: value j = B[k = 16 s + 8 h + j][f = 32 c + i], B = [dvlad[b]^T ; Wc^T]
+__global__ __launch_bounds__(256) void vlad_df_pack_kernel(const float* __restrict__ dvlad, const float* __restrict__ Wc, int F,
+                                                           u32x4* __restrict__ Bp) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    for (int e = threadIdx.x; e < 8 * 64; e += 256) {
+        const int s = e >> 6, l = e & 63, i = l & 31, h = l >> 5;
+        const int f = 32 * c + i, k0 = 16 * s + 8 * h;
+        const float* src = k0 < 64 ? dvlad + ((size_t)b * F + f) * 64 + k0 : Wc + (size_t)f * 64 + (k0 - 64);
+        const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        u32x4* dst = Bp + ((size_t)b * (F / 32) + c) * VDF_CHUNK_U4 + (size_t)s * 128 + l;
+        dst[0] = __builtin_bit_cast(u32x4, hi);
+        dst[64] = __builtin_bit_cast(u32x4, lo);
+    }
+}
+
+template <int PIECES>
+__global__ __launch_bounds__(64 * VDF_WAVES, 3) void vlad_df_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+                                                                    const u32x4* __restrict__ Bp, int n_points, int F,
+                                                                    float* __restrict__ df) {
+    __shared__ u32x4 Bs[2][VDF_NT * VDF_CHUNK_U4];   // 2 x 16 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x * VDF_WAVES + wave;            // 32-row tile of the cloud
+    const int r0 = tile * 32;
+    const bool live = r0 < n_points;                            // (a wave past the cloud's end only helps staging)
+    const int rl = min(r0 + i, n_points - 1);
+    const size_t row = (size_t)b * n_points + rl;
+    const int stages = F / (32 * VDF_NT);
+    const u32x4* src = Bp + (size_t)b * (F / 32) * VDF_CHUNK_U4;
+    // a stage's fragments travel global -> registers -> LDS in two steps, so that the loads of stage st + 1 are in flight under the
+    // products and stores of stage st (a plain copy loop waits for its loads before the wave's first MFMA: 32 exposed round trips)
+    constexpr int PER = VDF_NT * VDF_CHUNK_U4 / (64 * VDF_WAVES);
+    static_assert(VDF_NT * VDF_CHUNK_U4 % (64 * VDF_WAVES) == 0, "a stage is a whole number of 16-byte pieces per thread");
+    u32x4 pre[PER];
+    auto request = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)st * VDF_NT * VDF_CHUNK_U4 + tid + u * 64 * VDF_WAVES];
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 64 * VDF_WAVES] = pre[u];
+    };
+    request(0);   // (while the A rows travel)
+    // A[m = row i][k]: lane (i, h) of k-step s holds k = 16 s + 8 h .. + 7: s < 4 from a, s >= 4 from dz
+    bf16x8 ah[8], al[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float* p = (s < 4 ? a : dz) + row * 64 + 16 * (s & 3) + 8 * h;
+        const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        if (r0 + i >= n_points) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        if constexpr (PIECES == 2) {
+            split8(v, ah[s], al[s]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ah[s][j] = (__bf16)v[j];
+        }
+    }
+    deposit(0);
+    __syncthreads();
+    for (int st = 0; st < stages; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < stages) request(st + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests AHEAD of this stage's work (hipcc sinks loads to their use otherwise)
+        if (live) {
+            f32x16 acc[VDF_NT];
+#pragma unroll
+            for (int nt = 0; nt < VDF_NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int nt = 0; nt < VDF_NT; ++nt) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[buf][nt * VDF_CHUNK_U4 + s * 128 + lane]);
+                    if constexpr (PIECES == 2) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, Bs[buf][nt * VDF_CHUNK_U4 + s * 128 + 64 + lane]);
+                        acc[nt] = mfma_bf16(al[s], bh, acc[nt]);
+                        acc[nt] = mfma_bf16(ah[s], bl, acc[nt]);
+                    }
+                    acc[nt] = mfma_bf16(ah[s], bh, acc[nt]);
+                }
+            // D[m = row][n = column]: lane = column, register r = row mfma_row(r, h): 128-byte row segments per store.  (Through a per-wave
+            // LDS image as float4 rows -- four store instructions instead of sixteen -- measured 121 against 114 us: not store-issue-bound.)
+            float* out = df + ((size_t)b * n_points + r0) * F + 32 * VDF_NT * st + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = mfma_row(r, h);
+                if (r0 + rr < n_points) {
+#pragma unroll
+                    for (int nt = 0; nt < VDF_NT; ++nt) out[(size_t)rr * F + 32 * nt] = acc[nt][r];
+                }
+            }
+        }
+        if (st + 1 < stages) deposit(buf ^ 1);   // (the other buffer: its last readers passed the barrier at the end of stage st - 1)
+        __syncthreads();
+    }
+}
+
+extern "C" size_t epc_vlad_df_packed_bytes(int num_clouds, int F) {
+    return num_clouds > 0 && F > 0 ? (size_t)num_clouds * (F / 32) * VDF_CHUNK_U4 * sizeof(u32x4) : 0;
+}
+
+extern "C" int epc_vlad_df(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points, int F,
+                           int pieces, void* packed, size_t packed_bytes, float* df, void* stream) {
+    EPC_CHECK_ARG(a && dz && dvlad && Wc && packed && df, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && F >= 32 * VDF_NT && F % (32 * VDF_NT) == 0 && (pieces == 2 || pieces == 1), "bad shape (64 clusters, F a multiple of 64; pieces: 2 or 1)");
+    EPC_CHECK_ARG(num_clouds <= 65535, "too many clouds");
+    EPC_CHECK_ARG(packed_bytes >= epc_vlad_df_packed_bytes(num_clouds, F), "packed buffer too small (epc_vlad_df_packed_bytes)");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(dz) | reinterpret_cast<size_t>(dvlad) | reinterpret_cast<size_t>(Wc) |
+                    reinterpret_cast<size_t>(packed) | reinterpret_cast<size_t>(df)) & 15) == 0,
+                  "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vlad_df_pack_kernel, dim3(F / 32, num_clouds), dim3(256), 0, st, dvlad, Wc, F, (u32x4*)packed);
+    const int tiles = (n_points + 31) / 32;
+    const dim3 grid((tiles + VDF_WAVES - 1) / VDF_WAVES, num_clouds);
+    if (pieces == 2) hipLaunchKernelGGL(vlad_df_kernel<2>, grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df);
+    else hipLaunchKernelGGL(vlad_df_kernel<1>, grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -50,7 +50,7 @@ EXPORTS = [
     "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64", "epc_gate_fwd",
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
-    "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
+    "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -175,6 +175,9 @@ _lib.epc_chain_sums.argtypes = [_P, c_int] + [_P] * 5 + [c_float, c_int, _P, _P]
 _lib.epc_chain_bn_bwd.argtypes = [_P] * 6 + [c_float, _P, _P, _P, c_int, _P, _P]
 _lib.epc_chain_dw_sum.argtypes = [c_int, _P, _P, c_int, _P]
 _lib.epc_knn_overflow_lists.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P]
+_lib.epc_vlad_df_packed_bytes.restype = c_size_t
+_lib.epc_vlad_df_packed_bytes.argtypes = [c_int, c_int]
+_lib.epc_vlad_df.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]
 _lib.epc_sq_err_partial_floats.restype = c_size_t
 _lib.epc_sq_err_partial_floats.argtypes = [c_long]
 _lib.epc_sq_err_fwd.argtypes = [_P, _P, c_long, c_int, _P, _P, c_size_t, _P]

@@ -993,9 +993,18 @@ class VladAssignAggregate(torch.autograd.Function):
         dWc = gemm(f, dz, trans_a=True, splitk=_splitk_for(F, 64, rows), fast=True, deterministic=True)
         df = None
         if ctx.needs_input_grad[0]:
-            lhs = torch.cat((a, dz), dim=1).view(B, N, 128)                                    # [a | dz]
-            rhs = torch.cat((dvlad.transpose(1, 2), Wc.t().unsqueeze(0).expand(B, 64, F)), dim=1)   # [dvlad^T ; Wc^T]  (B, 128, F)
-            df = gemm(lhs, rhs, fast=True).view(rows, F)
+            if F % 64 == 0 and Wc.is_contiguous():
+                # df = a dvlad^T + dz Wc^T in one pass, no concatenated operands (epc_vlad_df)
+                df = torch.empty((rows, F), dtype=torch.float32, device=f.device)
+                nbytes = L.lib().epc_vlad_df_packed_bytes(B, F)
+                packed = _splitk_ws((nbytes + 3) // 4, f.device)
+                L.check(L.lib().epc_vlad_df(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, F,
+                                            1 if _GEMM_PRECISION == "bf16" else 2, packed.data_ptr(), packed.numel() * 4,
+                                            df.data_ptr(), _st()))
+            else:
+                lhs = torch.cat((a, dz), dim=1).view(B, N, 128)                                    # [a | dz]
+                rhs = torch.cat((dvlad.transpose(1, 2), Wc.t().unsqueeze(0).expand(B, 64, F)), dim=1)   # [dvlad^T ; Wc^T]  (B, 128, F)
+                df = gemm(lhs, rhs, fast=True).view(rows, F)
         return df, dWc, dgamma, dbeta, None, None
 
 

@@ -537,6 +537,15 @@ int epc_chain_dw_sum(int layers, const float* const* partials, float* const* dW,
 /* per cloud the points whose neighbour list overflowed (cnt > cap), ascending: ovf_cnt (num_clouds), ovf_list (num_clouds, n) */
 int epc_knn_overflow_lists(const int32_t* cnt, int cap, int num_clouds, int n, int32_t* ovf_cnt, int32_t* ovf_list, void* stream);
 
+/* Backward of loupe.py:255-291 with respect to the point features: df[b][n][f] = sum_k a[b][n][k] dvlad[b][f][k] + sum_k dz[b][n][k] Wc[f][k]
+ * (a, dz: (num_clouds n_points, 64) -- the soft assignment and the gradient of its pre-BatchNorm logits; dvlad (num_clouds, F, 64);
+ * Wc = cluster_weights (F, 64); df (num_clouds n_points, F)).  One pass: the rows' operand resident in registers, the cloud's right
+ * operand packed into `packed` (epc_vlad_df_packed_bytes, caller-owned scratch) and streamed through LDS.  pieces: 2 = two bf16 pieces
+ * per operand, three products (the backward arithmetic of epc_gemm_f32_fast); 1 = one bf16 value per operand. */
+size_t epc_vlad_df_packed_bytes(int num_clouds, int F);
+int epc_vlad_df(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points, int F, int pieces,
+                void* packed, size_t packed_bytes, float* df, void* stream);
+
 /* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
  * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials
  * added in a fixed order (bit-reproducible).  bwd: da = 2 (a - b) dloss[0] (/ n); b -- the teacher's output, fed through a
