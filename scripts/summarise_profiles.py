@@ -25,7 +25,7 @@ def lib_sha256():
     return h.hexdigest()
 
 
-LIB_SHA = lib_sha256()
+LIB_SHA = os.environ.get("EPCNET_LIB_SHA") or lib_sha256()   # (override: summarising a collection off the box, after the tree's library was rebuilt)
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
