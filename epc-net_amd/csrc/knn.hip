@@ -19,6 +19,7 @@
 //
 // knn_topk_stream_kernel (any N): same two passes with candidates streamed through an LDS tile, no culling.
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef KNN_THREADS
 #define KNN_THREADS 1024   // re-tuned on Hilbert-ordered clouds (r01_o): 1024 0.248 ms, 512 0.262, 256 0.372 per 64 clouds
@@ -193,7 +194,13 @@ __global__ __launch_bounds__(KNN_THREADS, BATCH == 4 ? 8 : 1) void knn_topk_cull
     static_assert(32 % BPT == 0, "a tile's batch bits must not straddle a mask word");
     unsigned int* hitmask = reinterpret_cast<unsigned int*>(s_margin + 4) + (threadIdx.x >> 6) * MASKW;
     const int cloud = blockIdx.y;
+#ifdef KNN_WAVE_VECTOR   // (tuning: the wave index as the compiler sees it from threadIdx, a vector value)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#else
+    // the wave index is uniform, which the compiler cannot tell from threadIdx: through readfirstlane the tile numbers of the walk and
+    // the tile addresses are scalar values
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
     const float* pc = xyz + (size_t)cloud * n * 3;
 
     bool bad = false;   // a NaN / Inf coordinate (or one whose square overflows): |p|^2 is not a finite number
@@ -442,6 +449,368 @@ __global__ __launch_bounds__(KNN_THREADS, BATCH == 4 ? 8 : 1) void knn_topk_cull
         cnt[(size_t)cloud * n + i] = (int32_t)count;
         kth_out[(size_t)cloud * n + i] = kth;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// knn_topk_quad_kernel (round 4): FOUR lanes per query.  The culled kernel above is one query per lane: a wave's time is its
+// own dependent chain (LDS read -> distance -> compare -> vote -> branch, ~18 k vector instructions), whatever the grid; a
+// small grid (the 18 clouds of a training tuple: 72 workgroups on 256 CUs) waits for that chain with three quarters of the
+// chip idle.  Here a wave holds 16 queries x 4 lanes; lane `sub` of a query's quad evaluates the candidates 4u + sub of a
+// 32-point tile (consecutive 16-byte LDS addresses per quad: conflict-free) and keeps the 20 smallest d' of ITS quarter of the
+// candidates.  Same selection, bit for bit:
+//   * threshold.  thr_q = the LARGEST of the four lists' fifth values (two DPP exchanges): 4 x 5 candidates lie at or below it,
+//     so thr_q >= the final 20th distance kth at all times.  A candidate with d' >= thr_q is not needed: at that moment every
+//     list holds five values <= thr_q, values a list only ever replaces by smaller ones, so the union keeps 20 values <= d'.  A
+//     candidate with d' < kth is always pushed (kth <= thr_q) and never evicted (a list's 20th value cannot fall below kth, the
+//     20th of a superset).  Hence the union of the four lists always contains the 20 smallest.  Tiles and batches are culled
+//     against thr_q (non-strict, for pass 2), insertion is attempted when d' < thr_q.
+//   * kth = the 20th smallest of the union: after the scan the lanes of a pair push each other's list through their own
+//     network (both then hold the pair's 20 smallest), then the pairs do the same -- 40 pushes at most, cut short wave-wide as
+//     soon as no lane's list would change (lists are ascending).
+//   * pass 2 re-visits the flagged batches in ascending order; the four lanes' hits of one u are consecutive j, so a lane's slot
+//     is the query's running count + the number of hits on lower lanes of its quad (one ballot per u).
+//   * box tests in two levels, four per vote: lane `sub` tests the sub-th of the next four SUPER-tiles (boxes of four consecutive
+//     tiles) of the outward walk; a super-tile that passes has its four tiles tested by one more vote (lane `sub` the sub-th tile).
+//     ~20 votes per wave instead of the culled kernel's 128; a test may use a threshold that is a few scans old -- conservative
+//     (thresholds only tighten).
+//   * the batches that produced a hit are flagged in eight wave-uniform 64-bit words (scalar registers); pass 2 walks the set bits.
+// A wave's 16 queries are neighbours on the Hilbert curve, a tighter group than 64: fewer tiles pass the vote.
+// ---------------------------------------------------------------------------------------------------------------------
+#define KQ_LANES 4
+
+// DPP reads of a register need two wait states after the VALU write of it.  The compiler's hazard recogniser does not look
+// inside asm blocks -- and the lists are written by one (topk_insert_dist) -- so the exchanges are asm with their own s_nop.
+__device__ __forceinline__ float quad_max(float v) {
+    float r;   // volatile: must not be sunk into a divergent region (a lane's partners have to be active when it reads them)
+    asm volatile("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(v));
+    return r;
+}
+template <int STEP>
+__device__ __forceinline__ float dpp_quad_swap(float v) {   // the value of lane ^ 1 (STEP 0) / lane ^ 2 (STEP 1)
+    float r;
+    if (STEP == 0)
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    else
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+
+template <int KSEL, bool CONV1, int HMW>   // HMW: 64-bit hit-mask words, 2 bits per tile (4: up to 128 tiles, 8: up to 256)
+__global__ __launch_bounds__(KNN_THREADS, 8) void knn_topk_quad_kernel(const float* __restrict__ xyz, int n, int cap,
+                                                                       int32_t* __restrict__ idx, int32_t* __restrict__ cnt,
+                                                                       float* __restrict__ kth_out,
+                                                                       const float* __restrict__ conv1_pack,
+                                                                       float* __restrict__ x32, unsigned short* __restrict__ x16,
+                                                                       int idx_u16, int32_t* __restrict__ status, int rounds) {
+    static_assert(KNN_CT == 32 && KSEL == 20, "written for 32-point tiles and the 20-slot list");
+    extern __shared__ __attribute__((aligned(16))) float4 cand[];  // [npad] points, then 2 float4 per tile (lo, hi)
+    const int ntiles = (n + KNN_CT - 1) / KNN_CT;
+    const int npad = ntiles * KNN_CT;
+    float4* bb = cand + npad;
+    float* s_margin = reinterpret_cast<float*>(bb + 2 * ntiles);
+    // one bit per (tile, 16-candidate batch) that produced a hit in pass 1: 2 x 256 tiles at most = eight wave-uniform 64-bit words
+    // (scalar registers: set by scalar selects, walked by s_ff1 in pass 2 -- no LDS traffic, no loop over unflagged tiles)
+    static_assert(HMW * 32 * KNN_CT <= KNN_LDS_MAX_N, "mask words beyond the largest cloud");
+    const int cloud = blockIdx.y;
+    // (readfirstlane: the wave index is uniform, which the compiler cannot tell from threadIdx -- tile numbers, tile addresses and
+    // the hit mask then live in scalar registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), sub = lane & 3;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int wg_queries = nwaves * 16 * rounds;   // the host sizes the workgroup and the number of 16-query groups per wave (launch_knn)
+    const float* pc = xyz + (size_t)cloud * n * 3;
+
+    bool bad = false;
+    for (int j = tid; j < npad; j += nthreads) {
+        float4 v = make_float4(0.f, 0.f, 0.f, INFINITY);
+        if (j < n) {
+            v.x = pc[3 * j + 0];
+            v.y = pc[3 * j + 1];
+            v.z = pc[3 * j + 2];
+            v.w = sq3(v.x, v.y, v.z);
+            bad |= !(v.w <= 3.4028234664e38f);
+        }
+        cand[j] = v;
+    }
+    if (status && blockIdx.x == 0 && wave_any(bad) && lane == 0) atomicOr(status + cloud, EPC_STATUS_NONFINITE_INPUT);
+    __syncthreads();
+    if constexpr (CONV1) {   // conv1 of the workgroup's own points (as in the culled kernel)
+        const int q = tid & 15;
+        const float4 w0 = *reinterpret_cast<const float4*>(conv1_pack + 4 * q);
+        const float4 w1 = *reinterpret_cast<const float4*>(conv1_pack + 64 + 4 * q);
+        const float4 w2 = *reinterpret_cast<const float4*>(conv1_pack + 128 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(conv1_pack + 192 + 4 * q);
+        const int p0 = blockIdx.x * wg_queries;
+        const int np = min(wg_queries, n - p0);
+        bool ovf = false;
+        for (int t = tid; t < np * 16; t += nthreads) {
+            const int g = p0 + (t >> 4);
+            const float4 pt = cand[g];
+            const float4 y = conv1_quad(pt.x, pt.y, pt.z, w0, w1, w2, b);
+            const size_t row = (size_t)cloud * n + g;
+            if (x32) *reinterpret_cast<float4*>(x32 + row * 64 + 4 * q) = y;
+            if (x16) {
+                reinterpret_cast<uint2*>(x16)[row * 16 + q] = pack_half4(y);
+                ovf |= fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)) > 65504.0f;
+            }
+        }
+        if (status && x16 && wave_any(ovf) && lane == 0) atomicOr(status + cloud, EPC_STATUS_FP16_RANGE);
+    }
+    for (int t = wave * 2 + (lane >> 5); t < ntiles; t += nwaves * 2) {
+        const float4 v = cand[t * KNN_CT + (lane & 31)];
+        const bool ok = v.w != INFINITY;
+        float lx = ok ? v.x : INFINITY, ly = ok ? v.y : INFINITY, lz = ok ? v.z : INFINITY;
+        float hx = ok ? v.x : -INFINITY, hy = ok ? v.y : -INFINITY, hz = ok ? v.z : -INFINITY;
+#pragma unroll
+        for (int off = KNN_CT / 2; off >= 1; off >>= 1) {
+            lx = fminf(lx, __shfl_xor(lx, off));
+            ly = fminf(ly, __shfl_xor(ly, off));
+            lz = fminf(lz, __shfl_xor(lz, off));
+            hx = fmaxf(hx, __shfl_xor(hx, off));
+            hy = fmaxf(hy, __shfl_xor(hy, off));
+            hz = fmaxf(hz, __shfl_xor(hz, off));
+        }
+        if ((lane & 31) == 0) {
+            bb[2 * t] = make_float4(lx, ly, lz, 0.f);
+            bb[2 * t + 1] = make_float4(hx, hy, hz, 0.f);
+        }
+    }
+    __syncthreads();
+    // boxes of four consecutive tiles ("super-tiles"): the walk tests those first
+    const int nst = (ntiles + 3) >> 2;
+    float4* sbb = reinterpret_cast<float4*>(s_margin + 4);   // [2 * nst]
+    for (int t = tid; t < nst; t += nthreads) {
+        float4 lo = bb[8 * t], hi = bb[8 * t + 1];
+        for (int r = 1; r < 4 && 4 * t + r < ntiles; ++r) {
+            const float4 l = bb[8 * t + 2 * r], h = bb[8 * t + 2 * r + 1];
+            lo.x = fminf(lo.x, l.x), lo.y = fminf(lo.y, l.y), lo.z = fminf(lo.z, l.z);
+            hi.x = fmaxf(hi.x, h.x), hi.y = fmaxf(hi.y, h.y), hi.z = fmaxf(hi.z, h.z);
+        }
+        sbb[2 * t] = lo, sbb[2 * t + 1] = hi;
+    }
+    if (wave == 0) {
+        float m = 0.f;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float4 lo = bb[2 * t], hi = bb[2 * t + 1];
+            const float ax = fmaxf(fabsf(lo.x), fabsf(hi.x)), ay = fmaxf(fabsf(lo.y), fabsf(hi.y)),
+                        az = fmaxf(fabsf(lo.z), fabsf(hi.z));
+            m = fmaxf(m, ax * ax + ay * ay + az * az);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) *s_margin = m * (256.0f * 5.9604645e-08f);
+    }
+    __syncthreads();
+    const float margin = *s_margin;
+
+    // the image above is built once per workgroup; a wave then takes `rounds` groups of 16 queries, one after the other
+    for (int round = 0; round < rounds; ++round) {
+    const int i0 = blockIdx.x * wg_queries + (round * nwaves + wave) * 16;   // the group's first query (wave-uniform)
+    if (i0 >= n) break;
+    const int i = i0 + (lane >> 2);
+    const bool valid = i < n;
+    unsigned long long hm[HMW];
+#pragma unroll
+    for (int w = 0; w < HMW; ++w) hm[w] = 0ull;
+    float xi = 0.f, yi = 0.f, zi = 0.f, sqi = 0.f;
+    if (valid) {
+        const float4 me = cand[i];
+        xi = me.x, yi = me.y, zi = me.z, sqi = me.w;
+    }
+    float top[KSEL];
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) top[s] = valid ? INFINITY : -INFINITY;
+
+    auto lower_bound = [&](const float4* boxes, int c) {
+        const float4 lo = boxes[2 * c], hi = boxes[2 * c + 1];
+        const float dx = fmaxf(fmaxf(lo.x - xi, xi - hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(lo.y - yi, yi - hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(lo.z - zi, zi - hi.z), 0.f);
+        return dx * dx + dy * dy + dz * dz - margin;
+    };
+    auto pos_sq_dist = [&](const float4& q) {
+#pragma clang fp contract(off)
+        const float inner = (xi * q.x + yi * q.y) + zi * q.z;
+        return __builtin_fmaf(-2.0f, inner, sqi) + q.w;
+    };
+    // An upper bound of the query's 20th distance from the four lists: the largest of their FIFTH values -- 4 x 5 candidates lie at
+    // or below it.  (The smallest of their 20th values is a bound too, and a loose one: a list sees a quarter of the candidates, its
+    // 20th value is about the query's 80th; with it alone a wave scanned 57 tiles instead of 17.)
+    auto thr_q = [&]() { return quad_max(top[4]); };
+    auto scan1 = [&](int c) {
+        KSTAT(1);
+        const float4* tp = cand + c * KNN_CT + sub;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = tp[16 * ub + 4 * u];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = pos_sq_dist(q[u]);
+            float dmin;
+            asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, %0, %4" : "=&v"(dmin) : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]));
+            float thr = thr_q();
+            if (wave_any(dmin <= thr)) {
+                KSTAT(2);
+                const int bit = c * 2 + ub;
+                const unsigned long long bv = 1ull << (bit & 63);
+#pragma unroll
+                for (int w = 0; w < HMW; ++w) hm[w] |= (bit >> 6) == w ? bv : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (wave_any(d[u] < thr)) {
+                        KSTAT(3);
+                        topk_insert_dist(top, d[u]);
+                        thr = thr_q();
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- pass 1: outwards from the wave's own super-tile (four tiles); a vote tests four super-tiles (lane `sub` the sub-th of
+    // them), a super-tile that passes has its four tiles tested by one more vote, and the tiles that pass are scanned ----
+    const int t0 = i0 / KNN_CT;   // wave-uniform: the tile that holds the wave's 16 queries
+    const int T0 = t0 >> 2;
+    const int kmax = 2 * max(T0, nst - 1 - T0);   // visiting order k -> super-tile: T0, T0-1, T0+1, T0-2, T0+2, ...
+    auto super_of = [&](int k) { return T0 + ((k & 1) ? -((k + 1) >> 1) : (k >> 1)); };
+    for (int kk = 0; kk <= kmax; kk += 4) {
+        const int S = super_of(kk + sub);
+        const bool in_s = S >= 0 && S < nst;
+        KSTAT(0);
+        const float lbs = in_s ? lower_bound(sbb, S) : INFINITY;   // (a list that is not full yet has threshold +inf: test `in` too)
+        const float thr_s = thr_q();
+        const unsigned long long ms = __builtin_amdgcn_ballot_w64(in_s && lbs <= thr_s);
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            if (!(ms & (0x1111111111111111ull << s))) continue;
+            const int c0 = 4 * super_of(kk + s);
+            const bool in = c0 + sub < ntiles;
+            KSTAT(0);
+            const float lb = in ? lower_bound(bb, c0 + sub) : INFINITY;
+            const float thr = thr_q();
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in && lb <= thr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m & (0x1111111111111111ull << r)) scan1(c0 + r);
+        }
+    }
+    // ---- the quad's four lists -> the 20th smallest of their union, in every lane ----
+    // The lanes of a pair first: c[s] = min(X[s], Y[19 - s]) holds the 20 smallest of two ascending lists X, Y (the lower half of a
+    // bitonic merge), rising then falling.  Forty compare-exchanges sort it: the bitonic merge network for 32 values with the twelve
+    // -inf pads behind the 20 real ones folded away at compile time (an exchange with a pad is a move, i.e. a renaming).  120
+    // instructions without a vote or a branch -- pushing the partner's list through the insertion network took ~450 with twenty of
+    // each.  (Both lanes of a pair compute the same multiset: s <-> 19 - s.)
+    {
+        float c[KSEL];
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) {
+            const float o = dpp_quad_swap<0>(top[KSEL - 1 - s]);
+            asm("v_min_f32 %0, %1, %2" : "=v"(c[s]) : "v"(top[s]), "v"(o));
+        }
+        constexpr unsigned char CE[40][2] = {
+            {0, 16}, {1, 17}, {2, 18},  {3, 19},  {16, 8},  {17, 9},  {18, 10}, {19, 11}, {4, 12},  {5, 13},
+            {6, 14}, {7, 15}, {16, 4},  {17, 5},  {18, 6},  {19, 7},  {8, 12},  {9, 13},  {10, 14}, {11, 15},
+            {0, 2},  {1, 3},  {16, 18}, {17, 19}, {4, 6},   {5, 7},   {8, 10},  {9, 11},  {12, 14}, {13, 15},
+            {0, 1},  {2, 3},  {16, 17}, {18, 19}, {4, 5},   {6, 7},   {8, 9},   {10, 11}, {12, 13}, {14, 15}};
+#pragma unroll
+        for (int e = 0; e < 40; ++e) {
+            float lo, hi;
+            asm("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(c[CE[e][0]]), "v"(c[CE[e][1]]));
+            c[CE[e][0]] = lo, c[CE[e][1]] = hi;
+        }
+        constexpr unsigned char ORDER[KSEL] = {0, 1, 2, 3, 16, 17, 18, 19, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};   // ascending
+#pragma unroll
+        for (int s = 0; s < KSEL; ++s) top[s] = c[ORDER[s]];
+    }
+    // the two pairs: only the 20th smallest of the union is needed, and for two ascending lists X, Y that is
+    // max over s of min(X[s], Y[19 - s]) (the lower half of a bitonic merge) -- 20 exchanges, no votes, no network
+    float top20 = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < KSEL; ++s) {
+        const float o = dpp_quad_swap<1>(top[KSEL - 1 - s]);
+        float m;
+        asm("v_min_f32 %0, %1, %2" : "=v"(m) : "v"(top[s]), "v"(o));
+        asm("v_max_f32 %0, %1, %2" : "=v"(top20) : "v"(top20), "v"(m));
+    }
+    const float kth = 0.0f - top20;
+
+    // ---- pass 2: emit {j : d'_ij <= -kth} ascending ----
+    unsigned int count = 0;
+    char* lists = reinterpret_cast<char*>(idx) + (size_t)cloud * n * cap * (idx_u16 ? 2 : 4);
+    const float dk = -kth;
+    const unsigned int ucap = (unsigned int)cap;
+    const unsigned int qshift = lane & ~3u, below = (1u << sub) - 1u;
+    auto pass2 = [&](auto wide) {
+        constexpr int ESZ = decltype(wide)::value ? 4 : 2;
+        const unsigned int row = (unsigned int)(valid ? i : 0) * ucap * ESZ;
+        const int words = (2 * ntiles + 63) >> 6;
+        for (int w = 0; w < words; ++w) {
+            unsigned long long flagged = hm[0];
+#pragma unroll
+            for (int v = 1; v < HMW; ++v) flagged = w == v ? hm[v] : flagged;
+            while (flagged) {
+                const int bit = __builtin_ctzll(flagged);
+                flagged &= flagged - 1ull;
+                const int c = (w * 64 + bit) >> 1, ub = bit & 1;
+                KSTAT(4);
+                const float4* tp = cand + c * KNN_CT + sub;
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = tp[16 * ub + 4 * u];
+                float d[4];
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    d[u] = pos_sq_dist(q[u]);
+                    hit |= d[u] <= dk;
+                }
+                if (wave_any(hit)) {
+                    KSTAT(5);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool h = d[u] <= dk;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
+                        if (m == 0ull) continue;
+                        const unsigned int qb = (unsigned int)(m >> qshift) & 15u;
+                        const unsigned int pos = count + __builtin_popcount(qb & below);
+                        if (h && valid && pos < ucap) {
+                            char* slot = lists + (row + pos * ESZ);
+                            const int j = c * KNN_CT + 16 * ub + 4 * u + sub;
+                            if (ESZ == 4)
+                                *reinterpret_cast<int32_t*>(slot) = j;
+                            else
+                                *reinterpret_cast<unsigned short*>(slot) = (unsigned short)j;
+                        }
+                        count += __builtin_popcount(qb);
+                    }
+                }
+            }
+        }
+    };
+    if (idx_u16)
+        pass2(std::false_type{});
+    else
+        pass2(std::true_type{});
+    if (valid && sub == 0) {
+        if (count < (unsigned int)KSEL) {   // NaN / Inf coordinates only (see the culled kernel)
+            const size_t row = ((size_t)cloud * n + i) * cap;
+            for (unsigned int c = count; c < (unsigned int)KSEL; ++c) {
+                if (idx_u16)
+                    reinterpret_cast<unsigned short*>(idx)[row + c] = (unsigned short)i;
+                else
+                    idx[row + c] = i;
+            }
+        }
+        cnt[(size_t)cloud * n + i] = (int32_t)count;
+        kth_out[(size_t)cloud * n + i] = kth;
+    }
+    }   // round
 }
 
 #ifdef KNN_COLLECT   // built and measured in round 2, NOT the default: see the verdict at the end of this comment
@@ -838,6 +1207,12 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
     mask[((size_t)cloud * n + i) * n + j] = (a >= kth[(size_t)cloud * n + i]) ? 1.0f : 0.0f;
 }
 
+// EPC_KNN_QUAD=0 selects the one-lane form (tuning, and the parity tests that hold the two forms against each other)
+static int epc_knn_quad_mode() {
+    const char* e = getenv("EPC_KNN_QUAD");
+    return (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) ? e[0] - '0' : -1;
+}
+
 static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
                       const float* conv1_pack, float* x32, void* x16, int idx_u16, int32_t* status, void* stream,
                       const char* who) {
@@ -874,12 +1249,7 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
         const size_t lds_bytes = ((size_t)ntiles * KNN_CT + 2 * (size_t)ntiles + 2) * sizeof(float4) +
                                  (size_t)KNN_WAVES * (KNN_LDS_MAX_N / 4 / 32) * sizeof(unsigned int);   // (sized for the 4-wide form's masks)
         // grids of more than one workgroup per CU run the 4-wide form, two workgroups to a CU (comment at the kernel)
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            num_cus = v;
-        }
+        const int num_cus = epc_device_cu_count();
 #ifdef KNN_FORCE_BATCH
         const bool wide_grid = KNN_FORCE_BATCH == 4;
 #else
@@ -897,7 +1267,44 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
                            (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, C1 ? conv1_pack : nullptr, C1 ? x32 : nullptr,     \
                            C1 ? (unsigned short*)x16 : nullptr, C1 ? idx_u16 : 0, status);                                      \
     } while (0)
-        if (conv1_pack) {
+        // four lanes per query (knn_topk_quad_kernel) unless EPC_KNN_QUAD=0 asks for the one-lane form: measured faster at every
+        // batch of 4096-point clouds (1 cloud 0.047 vs 0.156 ms, 18: 0.073 vs 0.167, 64: 0.149 vs 0.189, 256: 0.483 vs 0.536)
+        const bool quad = epc_knn_quad_mode() != 0;
+        if (quad) {
+            // 16-query groups per workgroup: as many as spread the grid over two workgroups per CU in ONE round (two cloud images fit
+            // a CU's LDS): up to 16 waves, each taking `rounds` groups one after the other -- the LDS image (the whole cloud, its
+            // boxes) is built once per workgroup, and no CU holds 32 waves while others hold 16 or none
+            const int groups = (n + 15) / 16;
+            const long slots = 2L * num_cus;
+            int per_wg = (int)(((long)groups * num_clouds + slots - 1) / slots);   // groups per workgroup
+            per_wg = min(max(per_wg, 4), groups);
+            while (per_wg < groups && (long)((groups + per_wg - 1) / per_wg) * num_clouds > slots) ++per_wg;   // (rounding per cloud)
+            const int rounds = (per_wg + KNN_WAVES - 1) / KNN_WAVES;
+            const int g = (per_wg + rounds - 1) / rounds;
+            const int wgs = (groups + g * rounds - 1) / (g * rounds);
+            const dim3 qgrid(wgs, num_clouds), qblock(64 * g);
+#define EPC_KNN_QLAUNCH(C1, W)                                                                                                   \
+    do {                                                                                                                        \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_topk_quad_kernel<EPC_KNN_SELECT, C1, W>),         \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                        \
+        if (e_ != hipSuccess) {                                                                                                 \
+            epc_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_));                                           \
+            return EPC_EHIP;                                                                                                    \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((knn_topk_quad_kernel<EPC_KNN_SELECT, C1, W>), qgrid, qblock, lds_bytes,                             \
+                           (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, C1 ? conv1_pack : nullptr, C1 ? x32 : nullptr,     \
+                           C1 ? (unsigned short*)x16 : nullptr, C1 ? idx_u16 : 0, status, rounds);                              \
+    } while (0)
+            const bool small = ntiles <= 128;
+            if (conv1_pack) {
+                if (small) EPC_KNN_QLAUNCH(true, 4);
+                else EPC_KNN_QLAUNCH(true, 8);
+            } else {
+                if (small) EPC_KNN_QLAUNCH(false, 4);
+                else EPC_KNN_QLAUNCH(false, 8);
+            }
+#undef EPC_KNN_QLAUNCH
+        } else if (conv1_pack) {
             if (wide_grid) EPC_KNN_LAUNCH(true, 4);
             else EPC_KNN_LAUNCH(true, 8);
         } else {

@@ -2899,6 +2899,154 @@ extern "C" int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, 
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// The soft assignment behind its product (loupe.py:255-276) in one pass each way.
+//   forward : a = softmax(batch_norm(z)) over the 64 clusters and a_sum = sum of a over the cloud's points.  z is read once
+//             and a written once (batch-norm output, softmax and the column sums were three passes: 5 x 19 MB at 18 x 4096
+//             rows instead of 2 x).  A row is 16 lanes x float4; the maximum and the sum cross the 16 lanes by four
+//             exchanges; thread (row group, 4 columns) adds its rows in order, the 16 row groups are added in order, the
+//             CS_SEG segments of a cloud by cloud_colsum64_finish_kernel: the same bits every run.
+//   backward: dpre = a (dy - sum(dy a)), dy = da + dsum[cloud]  (softmax64_kernel<true, true>) with BatchNorm's two column
+//             sums (sum dpre, sum dpre zhat: colreduce_kernel<2>'s partials, same layout) from the registers that hold dpre;
+//             dpre is written into dz, colreduce_finish_kernel<2> adds the partials, bn_apply_bwd_kernel turns dz into the
+//             BatchNorm input gradient in place.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assign_softmax_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ var, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int n_points,
+                                                                 float* __restrict__ a, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float coef[2][64];
+    __shared__ float red[16][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int seg = blockIdx.x, b = blockIdx.y;
+    if (tid < 64) {
+        const BnAffine c = bn_affine(mean[tid], var[tid], gamma[tid], beta[tid], eps);
+        coef[0][tid] = c.s, coef[1][tid] = c.t;
+    }
+    __syncthreads();
+    BnAffine af[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) af[q].s = coef[0][4 * l16 + q], af[q].t = coef[1][4 * l16 + q];
+    const int len = (n_points + CS_SEG - 1) / CS_SEG;
+    const int r0 = seg * len, r1 = min(n_points, r0 + len);
+    const size_t base = (size_t)b * n_points * 64 + 4 * l16;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const size_t o = base + (size_t)r * 64;
+        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        float p[4] = {bn_value(v.x, af[0]), bn_value(v.y, af[1]), bn_value(v.z, af[2]), bn_value(v.w, af[3])};
+        float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = expf(p[q] - m);
+        float s = (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p[q] = p[q] / s;
+            cs[q] += p[q];
+        }
+        *reinterpret_cast<float4*>(a + o) = make_float4(p[0], p[1], p[2], p[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[rg][4 * l16 + q] = cs[q];
+    __syncthreads();
+    if (tid < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][tid];
+        part[((size_t)b * CS_SEG + seg) * 64 + tid] = t;
+    }
+}
+
+extern "C" int epc_assign_softmax_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                                      float eps, int num_clouds, int n_points, float* a, float* a_sum, float* partials,
+                                      size_t partial_floats, void* stream) {
+    EPC_CHECK_ARG(z && mean && var && gamma && beta && a && a_sum && partials && num_clouds > 0 && n_points > 0, "bad argument");
+    EPC_CHECK_ARG(partial_floats >= epc_cloud_colsum64_partial_floats(num_clouds), "partials buffer too small");
+    hipLaunchKernelGGL(assign_softmax_fwd_kernel, dim3(CS_SEG, num_clouds), dim3(256), 0, (hipStream_t)stream, z, mean, var,
+                       gamma, beta, eps, n_points, a, partials);
+    const int total = num_clouds * 64;
+    hipLaunchKernelGGL(cloud_colsum64_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
+                       total, a_sum);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+__global__ __launch_bounds__(256) void assign_softmax_bwd_kernel(const float* __restrict__ da, const float* __restrict__ dsum,
+                                                                 const float* __restrict__ a, const float* __restrict__ z,
+                                                                 const float* __restrict__ mean, const float* __restrict__ var,
+                                                                 float eps, int n_points, int rows, float* __restrict__ dpre,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[2][16][64];
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    const int bx = blockIdx.x, nb = gridDim.x;
+    const int r0 = bx * CR_ROWS, r1 = min(rows, r0 + CR_ROWS);
+    float mu[4], rs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mu[q] = mean[4 * l16 + q], rs[q] = 1.0f / sqrtf(var[4 * l16 + q] + eps);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const size_t o = (size_t)r * 64 + 4 * l16;
+        const float4 g = *reinterpret_cast<const float4*>(da + o), y = *reinterpret_cast<const float4*>(a + o);
+        const float4 zv = *reinterpret_cast<const float4*>(z + o);
+        float dy[4] = {g.x, g.y, g.z, g.w};
+        if (dsum) {
+            const float4 e = *reinterpret_cast<const float4*>(dsum + (size_t)(r / n_points) * 64 + 4 * l16);
+            dy[0] += e.x, dy[1] += e.y, dy[2] += e.z, dy[3] += e.w;
+        }
+        const float yy[4] = {y.x, y.y, y.z, y.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+        float s = (dy[0] * yy[0] + dy[1] * yy[1]) + (dy[2] * yy[2] + dy[3] * yy[3]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        float d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            d[q] = yy[q] * (dy[q] - s);
+            s0[q] += d[q];
+            s1[q] += d[q] * ((zz[q] - mu[q]) * rs[q]);
+        }
+        *reinterpret_cast<float4*>(dpre + o) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[0][rg][4 * l16 + q] = s0[q], red[1][rg][4 * l16 + q] = s1[q];
+    __syncthreads();
+    if (tid < 128) {
+        const int q = tid >> 6, l = tid & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[q][g][l];
+        partial[((size_t)q * nb + bx) * 64 + l] = t;
+    }
+}
+
+extern "C" int epc_assign_softmax_bwd(const float* da, const float* dsum, const float* a, const float* z, const float* mean,
+                                      const float* var, const float* gamma, const float* beta, float eps, int num_clouds,
+                                      int n_points, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    EPC_CHECK_ARG(da && a && z && mean && var && gamma && beta && dz && dgamma && dbeta && num_clouds > 0 && n_points > 0,
+                  "bad argument");
+    const long rows_l = (long)num_clouds * n_points;
+    EPC_CHECK_ARG(rows_l < (1l << 31), "too many rows");
+    const int rows = (int)rows_l;
+    if (int rc = colreduce_check("epc_assign_softmax_bwd: workspace too small", rows, 64, workspace, workspace_bytes)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    float* part = (float*)((unsigned int*)workspace + CR_COUNTERS);
+    hipLaunchKernelGGL(assign_softmax_bwd_kernel, dim3(nb), dim3(256), 0, st, da, dsum, a, z, mean, var, eps, n_points, rows, dz,
+                       part);
+    hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3(64 / CF_COLS), dim3(256), 0, st, part, z, nb, 64, 1.0f, dbeta, dgamma);
+    // dz holds dpre: every element is read and then overwritten by the thread that owns it
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(1, nb), dim3(256), 0, st, (const float*)dz, z, mean, var, gamma, beta, dbeta,
+                       dgamma, eps, 1.0f / rows, 0, rows, 64, dz);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout*s, dg = dout*y*s*(1-s).
 // ----------------------------------------------------------------------------------------------------------------
 __global__ void gate_fwd_kernel(const float* __restrict__ y, const float* __restrict__ g, long n, float* __restrict__ out) {

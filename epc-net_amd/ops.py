@@ -946,18 +946,17 @@ class VladAssignAggregate(torch.autograd.Function):
             var = torch.empty(64, dtype=torch.float32, device=f.device)
             ws, n = _ws(rows, 64, f.device)
             L.check(L.lib().epc_col_moments(z.data_ptr(), rows, 64, mean.data_ptr(), var.data_ptr(), ws.data_ptr(), n, _st()))
-        pre = torch.empty_like(z)
-        L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                         float(eps), 0, rows, 64, pre.data_ptr(), _st()))
-        a = torch.empty_like(z)
-        L.check(L.lib().epc_softmax64_fwd(pre.data_ptr(), rows, a.data_ptr(), _st()))
         B = rows // n_points
-        f3, a3 = f.view(B, n_points, F), a.view(B, n_points, 64)
-        vlad = gemm(f3, a3, trans_a=True, splitk=max(1, min(8, n_points // 256)), deterministic=True)
+        a = torch.empty_like(z)
         a_sum = torch.empty((B, 1, 64), dtype=torch.float32, device=f.device)
         nparts = L.lib().epc_cloud_colsum64_partial_floats(B)
-        parts = torch.empty(nparts, dtype=torch.float32, device=f.device)
-        L.check(L.lib().epc_cloud_colsum64(a.data_ptr(), B, n_points, a_sum.data_ptr(), parts.data_ptr(), nparts, _st()))
+        parts = _splitk_ws(nparts, f.device)
+        # a = softmax(batch_norm(z)) and a_sum in one pass over z (epc_assign_softmax_fwd)
+        L.check(L.lib().epc_assign_softmax_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               float(eps), B, n_points, a.data_ptr(), a_sum.data_ptr(), parts.data_ptr(),
+                                               parts.numel(), _st()))
+        f3, a3 = f.view(B, n_points, F), a.view(B, n_points, 64)
+        vlad = gemm(f3, a3, trans_a=True, splitk=max(1, min(8, n_points // 256)), deterministic=True)
         ctx.save_for_backward(f, Wc, z, mean, var, gamma, beta, a)
         ctx.eps, ctx.n_points = float(eps), int(n_points)
         ctx.mark_non_differentiable(mean, var)
@@ -976,20 +975,17 @@ class VladAssignAggregate(torch.autograd.Function):
         dvlad = dvlad.contiguous()
         # da = f dvlad + (for every point of the cloud) the gradient of a_sum, the latter added inside the softmax backward
         da = gemm(f3, dvlad, fast=True)
-        dpre = torch.empty_like(z)
-        if dasum is not None:
-            dasum = dasum.contiguous()
-            L.check(L.lib().epc_softmax64_bwd_bcast(da.data_ptr(), dasum.data_ptr(), N, a.data_ptr(), rows, dpre.data_ptr(),
-                                                    _st()))
-        else:
-            L.check(L.lib().epc_softmax64_bwd(da.data_ptr(), a.data_ptr(), rows, dpre.data_ptr(), _st()))
         dz = torch.empty_like(z)
         dgamma = torch.empty(64, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(64, dtype=torch.float32, device=z.device)
         ws, n = _ws(rows, 64, z.device)
-        L.check(L.lib().epc_bn_apply_bwd(dpre.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
-                                         beta.data_ptr(), ctx.eps, 0, rows, 64, dz.data_ptr(), dgamma.data_ptr(),
-                                         dbeta.data_ptr(), ws.data_ptr(), n, _st()))
+        if dasum is not None:
+            dasum = dasum.contiguous()
+        # softmax backward (+ the a_sum gradient of every point's cloud) with BatchNorm's sums, then dz in place
+        L.check(L.lib().epc_assign_softmax_bwd(da.data_ptr(), dasum.data_ptr() if dasum is not None else None, a.data_ptr(),
+                                               z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                               ctx.eps, B, N, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n,
+                                               _st()))
         dWc = gemm(f, dz, trans_a=True, splitk=_splitk_for(F, 64, rows), fast=True, deterministic=True)
         df = None
         if ctx.needs_input_grad[0]:

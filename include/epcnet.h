@@ -167,7 +167,9 @@ int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, 
  *             products/sums rounded individually (no FMA), inner = (x x' + y y') + z z';
  *   cnt[i]  = #{j : a_ij >= kth[i]}  (>= 20; ties and zero-padded clouds make it larger);
  *   idx[i]  = the first min(cnt, cap) such j in ascending order (cap slots per point).
- * The dense mask the reference materialises is mask[i][j] = (a_ij >= kth[i]). */
+ * The dense mask the reference materialises is mask[i][j] = (a_ij >= kth[i]).
+ * n <= 8192: the cloud sits in LDS and four lanes share a query; the environment variable EPC_KNN_QUAD=0 (read at every launch: a
+ * tuning and test aid) selects the older one-lane-per-query kernel -- the same kth, cnt and idx bit for bit. */
 int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
                  void* stream);
 
@@ -482,6 +484,20 @@ int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n_points, co
 size_t epc_cloud_colsum64_partial_floats(int num_clouds);
 int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out, float* partials, size_t partial_floats,
                        void* stream);
+
+/* The soft assignment behind its product, one pass each way (loupe.py:255-276; what epc_bn_apply_fwd + epc_softmax64_fwd +
+ * epc_cloud_colsum64, and epc_softmax64_bwd_bcast + epc_bn_apply_bwd, do in five and four launches):
+ *   fwd: a (num_clouds * n_points, 64) = softmax(batch_norm(z; mean, var, gamma, beta, eps)) and a_sum (num_clouds, 64) = the sum of
+ *        a over each cloud's points, added in a fixed order; partials = epc_cloud_colsum64_partial_floats(num_clouds) floats.
+ *   bwd: from da (gradient of a), dsum (num_clouds, 64) (gradient of a_sum, may be NULL), a and z:  dz (gradient of z; also used
+ *        as scratch for the softmax's input gradient), dgamma, dbeta (64 each).  workspace: epc_colreduce_workspace_bytes(rows, 64),
+ *        16-byte aligned. */
+int epc_assign_softmax_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                           int num_clouds, int n_points, float* a, float* a_sum, float* partials, size_t partial_floats,
+                           void* stream);
+int epc_assign_softmax_bwd(const float* da, const float* dsum, const float* a, const float* z, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, int num_clouds, int n_points, float* dz, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout * s, dg = dout * y * s * (1 - s). */
 int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
