@@ -96,6 +96,9 @@ extern "C" int epc_debug_c5_stamps(void* host, size_t bytes) {
 #ifndef C5_START_STAGGER
 #define C5_START_STAGGER 0   // shader cycles between the start phases of first-round workgroups (0 = none)
 #endif
+#ifndef C5_PREFETCH_DISTANCE
+#define C5_PREFETCH_DISTANCE 256   // workgroups ahead (= CUs: one workgroup per CU at a time)
+#endif
 #ifndef C5_ASYM
 #define C5_ASYM 1   // 0: the lock-step schedule (every wave chain, epilogue, barrier), kept for the A/B measurement
 #endif
@@ -113,7 +116,12 @@ struct C5fLds {  // VLAD kernel; offsets in floats (4 B)
     // per-wave 32 x 32 f32 transpose tile (row stride 36) of the final epilogue: aliases the W5 stream buffers, dead by then
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
+    static constexpr int OFF_PF = OFF_CBN + 128;           // (C5_PREFETCH builds: 1 KB per wave where prefetch loads land, never read)
+#ifdef C5_PREFETCH
+    static constexpr int TOTAL = OFF_PF + 8 * 256;
+#else
     static constexpr int TOTAL = OFF_CBN + 128;
+#endif
 };
 
 // The wave's 32 x CIN input block as scaled split-fp16 fragments (common.h): lane (li, q) holds, for point group p and k-step s,
@@ -332,9 +340,24 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_vlad_f32_kernel(const float*
     // One interval = everything between two chunk barriers.  `late` waves (4-7) run the epilogue of the PREVIOUS chunk before this
     // chunk's chain (see Schedule at the top of the file).
     const bool late = C5_ASYM && wave_u >= 4;
+#ifdef C5_PREFETCH
+    const long pf_tile = (long)blockIdx.x + C5_PREFETCH_DISTANCE;
+    const bool pf_ok = CIN == 256 && (pf_tile + 1) * (C5_WAVES * 32) <= (long)total_points;
+    const float* pf_src = cat + (size_t)pf_tile * (C5_WAVES * 32) * CIN;   // 256 KB: 32 pieces of 8 KB (64 lines of 128 B)
+#endif
     auto interval = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         C5_T(t0);
+#ifdef C5_PREFETCH
+        // Experiment (round 4; measured: 0.476-0.495 ms against 0.472-0.473 without -- not in the product): touch
+        // the rows of the tile this CU's NEXT workgroup will probably take (blockIdx + the
+        // number of CUs: same XCD by construction), one 128-byte line per lane, four wave-instructions per wave spread over four
+        // intervals; the data lands in a dead LDS kilobyte.  Issued before the chunk's DMA pieces, so the counted waits below
+        // cover it.
+        if (pf_ok && c >= C5_PREFETCH && c < C5_PREFETCH + 4)
+            glds16(pf_src + (size_t)((c - C5_PREFETCH) * C5_WAVES + wave_u) * 2048, lane * 128u,
+                   lds_base + 4u * (L::OFF_PF + wave_u * 256));
+#endif
         if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
         C5_T(t1);
         if (late && c > 0) epilogue(c - 1);
