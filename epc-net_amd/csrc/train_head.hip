@@ -385,12 +385,34 @@ __global__ __launch_bounds__(256) void vlad_df_pack_kernel(const float* __restri
     }
 }
 
-template <int PIECES>
-__global__ __launch_bounds__(64 * VDF_WAVES, 3) void vlad_df_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+// TAIL (conv5's features, F = 1024): the gradient does not leave as df but as du, the gradient of conv5's BatchNorm OUTPUT -- the
+// backward of f = l2_normalize(relu(bn(z5))) (models/epc-net.py:136-148) applied to the accumulators while they are in registers:
+//     u = relu(z5 s + t),  f = u rn,  du = [f > 0] rn (df - f t_row),   t_row = sum_c df f  (the row's dot product)
+// together with the two column sums the BatchNorm backward needs (sum du, sum du zhat), as one partial per workgroup.  t_row is
+// known BEFORE df exists: sum_c df_c f_c = sum_k a_k (f . dvlad_k) + sum_k dz_k (f . Wc_k) = sum_k (a_k da_k + dz_k zc_k), 64-wide dot
+// products of tensors the assignment's backward holds anyway (epc_assign_softmax_bwd's rowdot).  What this removes from the step
+// is a whole pass over (df, z5) -- epc_bn_relu_rownorm_bwd's sums kernel, 154 us at 18 x 4096 rows -- for one extra read of z5
+// here; the apply pass that follows reads (du, z5) where it read (df, z5).
+struct VdfTail {
+    const float* z5;     // (rows, F) conv5's pre-activation
+    const float* rn;     // (rows) reciprocal row norms of the forward (>= 0.99e6: the clamped zero row, du = df rn)
+    const float* trow;   // (rows) t_row
+    const float *mean, *var, *gamma, *beta;   // conv5's BatchNorm (F each)
+    float eps;
+    float* partials;     // [workgroups][2][F]
+};
+
+template <int PIECES, bool TAIL>
+__global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(const float* __restrict__ a, const float* __restrict__ dz,
                                                                     const u32x4* __restrict__ Bp, int n_points, int F,
-                                                                    float* __restrict__ df) {
+                                                                    float* __restrict__ df, VdfTail tail) {
     __shared__ u32x4 Bs[2][VDF_NT * VDF_CHUNK_U4];   // 2 x 16 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float coef[TAIL ? 4 : 1][TAIL ? 1024 : 1];   // per column: s, t, mean, rstd
+    __shared__ __attribute__((aligned(16))) float rowc[TAIL ? VDF_WAVES : 1][2][32];      // per wave and row: rn, rn * t_row (0 when clamped)
+    __shared__ float psum[2][TAIL ? VDF_WAVES : 1][2][32];                               // per stage parity and wave: the two sums of 32 columns
+    // (the wave index through readfirstlane: the tile's row base is then a scalar, and the sixteen rows a lane loads or stores per
+    // stage are sixteen scalar bases + ONE vector offset instead of sixteen 64-bit vector addresses)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int tile = blockIdx.x * VDF_WAVES + wave;            // 32-row tile of the cloud
@@ -432,11 +454,53 @@ __global__ __launch_bounds__(64 * VDF_WAVES, 3) void vlad_df_kernel(const float*
             for (int j = 0; j < 8; ++j) ah[s][j] = (__bf16)v[j];
         }
     }
+    if constexpr (TAIL) {
+        for (int c = tid; c < F; c += 64 * VDF_WAVES) {
+            const float rs = 1.0f / sqrtf(tail.var[c] + tail.eps), sc = rs * tail.gamma[c];
+            coef[0][c] = sc, coef[1][c] = tail.beta[c] - tail.mean[c] * sc, coef[2][c] = tail.mean[c], coef[3][c] = rs;
+        }
+        if (h == 0) {
+            const bool in = r0 + i < n_points;
+            const float rnv = in ? tail.rn[row] : 0.f, tv = in ? tail.trow[row] : 0.f;
+            rowc[wave][0][i] = rnv;
+            rowc[wave][1][i] = rnv >= 0.99e6f ? 0.f : rnv * tv;
+        }
+    }
     deposit(0);
     __syncthreads();
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    // rows of the tile as scalar bases: row (r & 3) + 8 (r >> 2) of the tile, + 4 h rows and the column in the vector offset
+    const size_t tile_base = ((size_t)b * n_points + r0) * F;   // (scalar: b, r0)
+    const unsigned voff = 4u * h * (unsigned)F + i;
+    float zn[TAIL ? 16 : 1];
+    auto zload = [&](int st) {
+        if constexpr (TAIL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* zb = tail.z5 + tile_base + (size_t)((r & 3) + 8 * (r >> 2)) * F + 32 * st;
+                zn[r] = zb[voff];
+            }
+        }
+    };
+    if constexpr (TAIL) {
+        if (live) zload(0);
+    }
     for (int st = 0; st < stages; ++st) {
         const int buf = st & 1;
         if (st + 1 < stages) request(st + 1);
+        float zv[TAIL ? 16 : 1];
+        if constexpr (TAIL) {
+            // this stage's z5 values were requested a stage ago (an HBM round trip is longer than a stage's products); request the next
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zv[r] = zn[r];
+            if (live && st + 1 < stages) zload(st + 1);
+            // the previous stage's column sums: four waves -> one partial (the barrier at the end of that stage published them)
+            if (st > 0 && tid < 64) {
+                const int q = tid >> 5, c = tid & 31;
+                const float v = (psum[buf ^ 1][0][q][c] + psum[buf ^ 1][1][q][c]) + (psum[buf ^ 1][2][q][c] + psum[buf ^ 1][3][q][c]);
+                tail.partials[((size_t)wg * 2 + q) * F + 32 * (st - 1) + c] = v;
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the requests AHEAD of this stage's work (hipcc sinks loads to their use otherwise)
         if (live) {
             f32x16 acc[VDF_NT];
@@ -458,18 +522,47 @@ __global__ __launch_bounds__(64 * VDF_WAVES, 3) void vlad_df_kernel(const float*
                 }
             // D[m = row][n = column]: lane = column, register r = row mfma_row(r, h): 128-byte row segments per store.  (Through a per-wave
             // LDS image as float4 rows -- four store instructions instead of sixteen -- measured 121 against 114 us: not store-issue-bound.)
-            float* out = df + ((size_t)b * n_points + r0) * F + 32 * VDF_NT * st + i;
+            if constexpr (TAIL) {
+                static_assert(!TAIL || VDF_NT == 1, "the tail epilogue is written for one 32-column chunk per stage");
+                const int c = 32 * st + i;
+                const float cs = coef[0][c], ct = coef[1][c], mu = coef[2][c], rs = coef[3][c];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = mfma_row(r, h);
+                    const float rnv = rowc[wave][0][rr], rt = rowc[wave][1][rr];
+                    const float f = fmaxf(zv[r] * cs + ct, 0.f) * rnv;       // bn_value(z, affine), the forward's own expression
+                    const float du = rnv * acc[0][r] - rt * f;
+                    const float d = f > 0.f ? du : 0.f;
+                    s1 += d;
+                    s2 += d * ((zv[r] - mu) * rs);
+                    acc[0][r] = d;
+                }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (h == 0) psum[buf][wave][0][i] = s1, psum[buf][wave][1][i] = s2;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = mfma_row(r, h);
                 if (r0 + rr < n_points) {
+                    float* ob = df + tile_base + (size_t)((r & 3) + 8 * (r >> 2)) * F + 32 * VDF_NT * st;
 #pragma unroll
-                    for (int nt = 0; nt < VDF_NT; ++nt) out[(size_t)rr * F + 32 * nt] = acc[nt][r];
+                    for (int nt = 0; nt < VDF_NT; ++nt) ob[voff + 32 * nt] = acc[nt][r];
                 }
             }
+        } else if constexpr (TAIL) {
+            if (h == 0) psum[buf][wave][0][i] = 0.f, psum[buf][wave][1][i] = 0.f;
         }
         if (st + 1 < stages) deposit(buf ^ 1);   // (the other buffer: its last readers passed the barrier at the end of stage st - 1)
         __syncthreads();
+    }
+    if constexpr (TAIL) {
+        if (tid < 64) {
+            const int q = tid >> 5, c = tid & 31, pb = (stages - 1) & 1;
+            const float v = (psum[pb][0][q][c] + psum[pb][1][q][c]) + (psum[pb][2][q][c] + psum[pb][3][q][c]);
+            tail.partials[((size_t)wg * 2 + q) * F + 32 * (stages - 1) + c] = v;
+        }
     }
 }
 
@@ -490,8 +583,42 @@ extern "C" int epc_vlad_df(const float* a, const float* dz, const float* dvlad, 
     hipLaunchKernelGGL(vlad_df_pack_kernel, dim3(F / 32, num_clouds), dim3(256), 0, st, dvlad, Wc, F, (u32x4*)packed);
     const int tiles = (n_points + 31) / 32;
     const dim3 grid((tiles + VDF_WAVES - 1) / VDF_WAVES, num_clouds);
-    if (pieces == 2) hipLaunchKernelGGL(vlad_df_kernel<2>, grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df);
-    else hipLaunchKernelGGL(vlad_df_kernel<1>, grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df);
+    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{});
+    else hipLaunchKernelGGL((vlad_df_kernel<1, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{});
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_vlad_df_tail_partial_floats(int num_clouds, int n_points) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    const size_t tiles = (n_points + 31) / 32;
+    return (size_t)num_clouds * ((tiles + VDF_WAVES - 1) / VDF_WAVES) * 2 * 1024;
+}
+
+extern "C" int epc_vlad_df_tail(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points,
+                                int pieces, void* packed, size_t packed_bytes, const float* z5, const float* rn, const float* trow,
+                                const float* mean, const float* var, const float* gamma, const float* beta, float eps, float* du,
+                                float* dbeta_dgamma, float* partials, size_t partial_floats, void* stream) {
+    constexpr int F = 1024;
+    EPC_CHECK_ARG(a && dz && dvlad && Wc && packed && z5 && rn && trow && mean && var && gamma && beta && du && dbeta_dgamma && partials,
+                  "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && num_clouds <= 65535 && n_points > 0 && n_points % 32 == 0 && (pieces == 2 || pieces == 1) &&
+                      (long)num_clouds * n_points * F < (1L << 32),
+                  "bad shape (n_points a multiple of 32; rows * 1024 < 2^32)");
+    EPC_CHECK_ARG(packed_bytes >= epc_vlad_df_packed_bytes(num_clouds, F), "packed buffer too small (epc_vlad_df_packed_bytes)");
+    EPC_CHECK_ARG(partial_floats >= epc_vlad_df_tail_partial_floats(num_clouds, n_points), "partials buffer too small");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(dz) | reinterpret_cast<size_t>(dvlad) | reinterpret_cast<size_t>(Wc) |
+                    reinterpret_cast<size_t>(packed) | reinterpret_cast<size_t>(du) | reinterpret_cast<size_t>(partials) |
+                    reinterpret_cast<size_t>(dbeta_dgamma)) & 15) == 0,
+                  "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(vlad_df_pack_kernel, dim3(F / 32, num_clouds), dim3(256), 0, st, dvlad, Wc, F, (u32x4*)packed);
+    const int tiles = (n_points + 31) / 32;
+    const dim3 grid((tiles + VDF_WAVES - 1) / VDF_WAVES, num_clouds);
+    const VdfTail tail{z5, rn, trow, mean, var, gamma, beta, eps, partials};
+    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail);
+    else hipLaunchKernelGGL((vlad_df_kernel<1, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail);
+    epc_partial_sum_wide_launch(partials, (int)(grid.x * grid.y), 2 * F, dbeta_dgamma, stream);   // [0, F): sum du; [F, 2F): sum du zhat
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

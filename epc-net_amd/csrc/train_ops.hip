@@ -1622,6 +1622,12 @@ __global__ __launch_bounds__(256) void bn_relu_rownorm_bwd_apply_kernel(
     }
 }
 
+// library-internal: out[e] = sum over the P partials of part[p][e], e < E (E a multiple of 64), in partial_sum_wide_kernel's fixed order
+int epc_partial_sum_wide_launch(const float* partials, int P, int E, float* out, void* stream) {
+    hipLaunchKernelGGL(partial_sum_wide_kernel, dim3(E / 4 / 16), dim3(1024), 0, (hipStream_t)stream, partials, P, E, out);
+    return EPC_OK;
+}
+
 extern "C" size_t epc_bn_relu_rownorm_bwd_partial_floats(int rows) {
     return rows > 0 ? (size_t)((rows + BRB_ROWS - 1) / BRB_ROWS) * 2 * BRN_C : 0;
 }
@@ -1706,6 +1712,65 @@ extern "C" int epc_bn_apply_bwd(const float* dy, const float* z, const float* me
     hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3((C + CF_COLS - 1) / CF_COLS), dim3(256), 0, st, part, z, nb, C, 1.0f, dbeta, dgamma);
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(grid.y, grid.x), dim3(256), 0, st, dy, z, mean, var, gamma, beta, dbeta, dgamma, eps,
                        1.0f / rows, relu, rows, C, dz);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// bn_apply_bwd_kernel without a mask for conv5's 1024 channels in the shape of bn_relu_rownorm_bwd_apply_kernel: a wave takes whole
+// 4-KB rows (the 64-column panels of the general kernel read 256-byte row segments: 189 us against 165 at 18 x 4096 rows).
+__global__ __launch_bounds__(256) void bn_apply_bwd_given_wide_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                                                      const float* __restrict__ dgamma, float eps, float inv_rows,
+                                                                      int rows, float* __restrict__ dz) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mu[16], k1[16], bb[16], gg[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 256 * u + 4 * lane + e, k = 4 * u + e;
+            const float r = 1.0f / sqrtf(var[c] + eps);
+            mu[k] = mean[c], k1[k] = gamma[c] * r, bb[k] = dbeta[c] * inv_rows, gg[k] = r * (dgamma[c] * inv_rows);
+        }
+    const int row0 = blockIdx.x * BRB_ROWS + wave;
+    for (int q = 0; q < BRB_ROWS / 4; ++q) {
+        const int row = row0 + 4 * q;
+        if (row >= rows) break;
+        const float4* g4 = reinterpret_cast<const float4*>(dy + (size_t)row * BRN_C);
+        const float4* z4 = reinterpret_cast<const float4*>(z + (size_t)row * BRN_C);
+        float4 gv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = g4[lane + 64 * u], zv[u] = z4[lane + 64 * u];
+        float4* o4 = reinterpret_cast<float4*>(dz + (size_t)row * BRN_C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, zz[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * u + e;
+                o[e] = k1[k] * (g[e] - bb[k] - (zz[e] - mu[k]) * gg[k]);
+            }
+            o4[lane + 64 * u] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// The last step of a BatchNorm backward whose column sums are known already (epc_vlad_df_tail leaves them):
+// dz = gamma rstd (dy - dbeta / rows - zhat dgamma / rows), no ReLU mask (dy is masked).  dz may be dy (in place).
+extern "C" int epc_bn_apply_bwd_given(const float* dy, const float* z, const float* mean, const float* var, const float* gamma,
+                                      const float* beta, const float* dbeta, const float* dgamma, float eps, int rows, int C,
+                                      float* dz, void* stream) {
+    EPC_CHECK_ARG(dy && z && mean && var && gamma && beta && dbeta && dgamma && dz, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && C > 0 && C % 4 == 0, "C must be a multiple of 4");
+    const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
+    if (C == BRN_C)
+        hipLaunchKernelGGL(bn_apply_bwd_given_wide_kernel, dim3((rows + BRB_ROWS - 1) / BRB_ROWS), dim3(256), 0, (hipStream_t)stream, dy,
+                           z, mean, var, gamma, dbeta, dgamma, eps, 1.0f / rows, rows, dz);
+    else
+        hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, (hipStream_t)stream, dy, z, mean, var, gamma, beta,
+                           dbeta, dgamma, eps, 1.0f / rows, 0, rows, C, dz);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -2979,7 +3044,7 @@ __global__ __launch_bounds__(256) void assign_softmax_bwd_kernel(const float* __
                                                                  const float* __restrict__ a, const float* __restrict__ z,
                                                                  const float* __restrict__ mean, const float* __restrict__ var,
                                                                  float eps, int n_points, int rows, float* __restrict__ dpre,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, float* __restrict__ rowdot) {
     __shared__ float red[2][16][64];
     const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
     const int bx = blockIdx.x, nb = gridDim.x;
@@ -2994,6 +3059,12 @@ __global__ __launch_bounds__(256) void assign_softmax_bwd_kernel(const float* __
         const float4 g = *reinterpret_cast<const float4*>(da + o), y = *reinterpret_cast<const float4*>(a + o);
         const float4 zv = *reinterpret_cast<const float4*>(z + o);
         float dy[4] = {g.x, g.y, g.z, g.w};
+        if (rowdot) {   // sum_k a_k da_k with da as the product left it (before the a_sum gradient): the first half of t_row
+            float t1 = (g.x * y.x + g.y * y.y) + (g.z * y.z + g.w * y.w);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) t1 += __shfl_xor(t1, off);
+            if (l16 == 0) rowdot[r] = t1;
+        }
         if (dsum) {
             const float4 e = *reinterpret_cast<const float4*>(dsum + (size_t)(r / n_points) * 64 + 4 * l16);
             dy[0] += e.x, dy[1] += e.y, dy[2] += e.z, dy[3] += e.w;
@@ -3023,9 +3094,41 @@ __global__ __launch_bounds__(256) void assign_softmax_bwd_kernel(const float* __
     }
 }
 
+// bn_apply_bwd_kernel for the assignment's 64 columns without a ReLU, dz in place of dpre, and the second half of t_row:
+// rowdot[r] += sum_k dz[r][k] z[r][k]  (z = f Wc, the assignment's pre-BatchNorm product)
+__global__ __launch_bounds__(256) void assign_dz_rowdot_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ var, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                               float eps, float inv_rows, int rows, float* __restrict__ dz,
+                                                               float* __restrict__ rowdot) {
+    const int tid = threadIdx.x, l16 = tid & 15, rg = tid >> 4;
+    float mu[4], k1[4], bb[4], gg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = 4 * l16 + q;
+        const float rs = 1.0f / sqrtf(var[c] + eps);
+        mu[q] = mean[c], k1[q] = gamma[c] * rs, bb[q] = dbeta[c] * inv_rows, gg[q] = rs * (dgamma[c] * inv_rows);
+    }
+    const int r0 = blockIdx.x * CR_ROWS, r1 = min(rows, r0 + CR_ROWS);
+#pragma unroll 2
+    for (int r = r0 + rg; r < r1; r += 16) {
+        const size_t o = (size_t)r * 64 + 4 * l16;
+        const float4 zv = *reinterpret_cast<const float4*>(z + o), gv = *reinterpret_cast<const float4*>(dz + o);
+        const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, gi[4] = {gv.x, gv.y, gv.z, gv.w};
+        float out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = k1[q] * (gi[q] - bb[q] - (zi[q] - mu[q]) * gg[q]);
+        *reinterpret_cast<float4*>(dz + o) = make_float4(out[0], out[1], out[2], out[3]);
+        float t2 = (out[0] * zi[0] + out[1] * zi[1]) + (out[2] * zi[2] + out[3] * zi[3]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) t2 += __shfl_xor(t2, off);
+        if (l16 == 0) rowdot[r] += t2;
+    }
+}
+
 extern "C" int epc_assign_softmax_bwd(const float* da, const float* dsum, const float* a, const float* z, const float* mean,
                                       const float* var, const float* gamma, const float* beta, float eps, int num_clouds,
-                                      int n_points, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                      int n_points, float* dz, float* dgamma, float* dbeta, float* rowdot, void* workspace,
                                       size_t workspace_bytes, void* stream) {
     EPC_CHECK_ARG(da && a && z && mean && var && gamma && beta && dz && dgamma && dbeta && num_clouds > 0 && n_points > 0,
                   "bad argument");
@@ -3037,11 +3140,15 @@ extern "C" int epc_assign_softmax_bwd(const float* da, const float* dsum, const 
     const int nb = (rows + CR_ROWS - 1) / CR_ROWS;
     float* part = (float*)((unsigned int*)workspace + CR_COUNTERS);
     hipLaunchKernelGGL(assign_softmax_bwd_kernel, dim3(nb), dim3(256), 0, st, da, dsum, a, z, mean, var, eps, n_points, rows, dz,
-                       part);
+                       part, rowdot);
     hipLaunchKernelGGL(colreduce_finish_kernel<2>, dim3(64 / CF_COLS), dim3(256), 0, st, part, z, nb, 64, 1.0f, dbeta, dgamma);
     // dz holds dpre: every element is read and then overwritten by the thread that owns it
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(1, nb), dim3(256), 0, st, (const float*)dz, z, mean, var, gamma, beta, dbeta,
-                       dgamma, eps, 1.0f / rows, 0, rows, 64, dz);
+    if (rowdot)
+        hipLaunchKernelGGL(assign_dz_rowdot_kernel, dim3(nb), dim3(256), 0, st, z, mean, var, gamma, dbeta, dgamma, eps, 1.0f / rows,
+                           rows, dz, rowdot);
+    else
+        hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(1, nb), dim3(256), 0, st, (const float*)dz, z, mean, var, gamma, beta, dbeta,
+                           dgamma, eps, 1.0f / rows, 0, rows, 64, dz);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -57,14 +57,21 @@ class DistillStep(TrainStep):
         vecs = torch.cat([query, positives, negatives, other_neg], 1)
         need_fea = self.gamma != 0.0 or self.feature_loss_when_unused
         fea_t, soft_t = self.teacher_outputs(vecs, need_fea)
+        from . import ops
+        fuse_was = ops.FUSE_TAIL_BACKWARD
+        if self.gamma != 0.0:
+            ops.FUSE_TAIL_BACKWARD = False      # the features get a second gradient (loss_fea): their backward cannot be pre-empted
+        try:
+            with variable_scope(self.outer):
+                fea_s, out_vecs = self.model.forward(vecs, is_training, bn_decay=bn_decay, params=p)     # :365
+        finally:
+            ops.FUSE_TAIL_BACKWARD = fuse_was
         with variable_scope(self.outer):
-            fea_s, out_vecs = self.model.forward(vecs, is_training, bn_decay=bn_decay, params=p)         # :365
             q_vec, pos_vecs, neg_vecs, other_neg_vec = torch.split(
                 out_vecs, [1, int(positives.shape[1]), int(negatives.shape[1]), 1], 1)
             soft_s = out_vecs.reshape(-1, out_vecs.shape[-1])
             loss_q = self.model.lazy_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg_vec,
                                                      p.get("MARGIN_1", 0.5), p.get("MARGIN_2", 0.2))     # :371
-        from . import ops
         mean = self.loss_type == "square_error_mean"
         soft_s = soft_s.reshape(soft_t.shape)
         loss_soft = ops.SquaredError.apply(soft_s, soft_t, mean)                                        # :376 / :382

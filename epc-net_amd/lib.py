@@ -51,7 +51,7 @@ EXPORTS = [
     "epc_assign_softmax_fwd", "epc_assign_softmax_bwd", "epc_gate_fwd",
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
-    "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
+    "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_vlad_df_tail_partial_floats", "epc_vlad_df_tail", "epc_bn_apply_bwd_given", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -164,7 +164,11 @@ _lib.epc_cloud_colsum64_partial_floats.argtypes = [c_int]
 _lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
 _lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, ctypes.c_size_t, _P]
-_lib.epc_assign_softmax_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, ctypes.c_size_t, _P]
+_lib.epc_assign_softmax_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
+_lib.epc_vlad_df_tail_partial_floats.argtypes = [c_int, c_int]
+_lib.epc_vlad_df_tail_partial_floats.restype = ctypes.c_size_t
+_lib.epc_vlad_df_tail.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, ctypes.c_size_t, _P]
+_lib.epc_bn_apply_bwd_given.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P]
 _lib.epc_gate_fwd.argtypes = [_P, _P, ctypes.c_long, _P, _P]
 _lib.epc_gate_bwd.argtypes = [_P, _P, _P, ctypes.c_long, _P, _P, _P]
 _lib.epc_chain_parts.argtypes = [c_int]

@@ -122,7 +122,9 @@ class _VladBase(PoolingBaseModel):
             # :255-263, :272-274, :286-291 as one autograd node (the two gradients of x are one product: ops.VladAssignAggregate)
             from .utils.tf_util import _ema_update
             beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)
-            vlad, a_sum, mean, var = ops.VladAssignAggregate.apply(x, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N)   # a_sum: :276
+            link = ops.tail_link_of(reshaped_input) if tuple(reshaped_input.shape) == tuple(x.shape) else None
+            vlad, a_sum, mean, var = ops.VladAssignAggregate.apply(x, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N,
+                                                                   link)   # a_sum: :276
             _ema_update(mm, mean, SLIM_DECAY, scheduled=False)
             _ema_update(mv, var, SLIM_DECAY, scheduled=False)          # (the unfused slim op: population variance)
         else:

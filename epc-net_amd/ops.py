@@ -3,6 +3,8 @@ calls into libepcnet_hip.so (``csrc/train_ops.hip``).  autograd is used as the t
 in these functions and no CPU fallback.  Reference semantics are cited per operator."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import lib as L
@@ -256,6 +258,29 @@ def fused_linear_bn_ok(rows, cin, cout):
     return rows >= 64 and cout >= 64 and cin >= 32
 
 
+# conv5's tail and the VLAD assignment / aggregation are two autograd nodes whose backward passes share work: the feature gradient df
+# the second one forms is what the first one's backward reads twice (row dot products + BatchNorm sums, then dz).  A TailLink, handed
+# from the first node's call site to the second's, lets the second continue its product through the tail's backward while the
+# accumulators are in registers (epc_vlad_df_tail): it then returns du -- the gradient of the BatchNorm output -- in df's place and
+# leaves the column sums in the link; the first node's backward finishes with one pass.  Only legal when the features have no other
+# consumer with a gradient (knowledge distillation with GAMMA != 0 has one: kd_training turns FUSE_TAIL_BACKWARD off).
+FUSE_TAIL_BACKWARD = True
+
+
+class TailLink:
+    __slots__ = ("z", "rn", "mean", "var", "gamma", "beta", "eps", "du", "sums")
+
+    def __init__(self):
+        self.z = self.rn = self.mean = self.var = self.gamma = self.beta = None
+        self.eps = 0.0
+        self.du = self.sums = None
+
+
+def tail_link_of(f):
+    """The TailLink of a feature tensor made by tf_util.conv1d_l2_normalized in training mode (None otherwise)."""
+    return getattr(f, "_epc_tail_link", None)
+
+
 class LinearBatchNormTrain(torch.autograd.Function):
     """Linear followed by BatchNormTrain (utils/tf_util.py:94-106 in training mode) as ONE node: the batch statistics come out
     of the GEMM's epilogue instead of a pass over z.  ``rownorm``: conv5's tail -- l2_normalize(relu(bn(z))) over the channels
@@ -264,8 +289,9 @@ class LinearBatchNormTrain(torch.autograd.Function):
     training-mode BatchNorm is exactly zero and is not computed."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm, f16x3=None):
+    def forward(ctx, x, W, b, gamma, beta, eps, relu, rownorm, f16x3=None, link=None):
         x = x.contiguous()
+        ctx.link = link if rownorm else None
         # f16x3: the (activation, weight) scale exponents of the split-fp16 form, passed by the call site that knows its operands
         # are BatchNorm'd block outputs (conv5 of either network: tf_util.conv1d_l2_normalized / conv1d with 1024 outputs)
         z, mean, var = _gemm_with_stats(x, W, b, f16x3)
@@ -276,6 +302,9 @@ class LinearBatchNormTrain(torch.autograd.Function):
             L.check(L.lib().epc_bn_relu_rownorm_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                                     beta.data_ptr(), float(eps), rows, C, y.data_ptr(), rn.data_ptr(), _st()))
             ctx.save_for_backward(x, W, z, mean, var, gamma, beta, rn)
+            if ctx.link is not None:
+                lk = ctx.link
+                lk.z, lk.rn, lk.mean, lk.var, lk.gamma, lk.beta, lk.eps = z, rn, mean, var, gamma, beta, float(eps)
         else:
             y = torch.empty_like(z)
             L.check(L.lib().epc_bn_apply_fwd(z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -289,7 +318,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dm, _dv):
         if dy is None:
-            return (None,) * 9
+            return (None,) * 10
         if ctx.rownorm:
             x, W, z, mean, var, gamma, beta, rn = ctx.saved_tensors
         else:
@@ -298,10 +327,23 @@ class LinearBatchNormTrain(torch.autograd.Function):
         rows, C = z.shape
         cin = x.shape[1]
         if ctx.rownorm:
-            dz, dgamma, dbeta = _bn_relu_rownorm_bwd(dy, z, rn, mean, var, gamma, beta, ctx.eps)
+            lk = ctx.link
+            if lk is not None and lk.du is not None:
+                # the consumer's backward went through the tail already (epc_vlad_df_tail): dy IS du, the column sums are known
+                du, sums = lk.du, lk.sums
+                lk.du = lk.sums = None
+                if dy.data_ptr() != du.data_ptr():
+                    raise EpcNetError("conv5's features have a second consumer with a gradient: set ops.FUSE_TAIL_BACKWARD = False")
+                dbeta, dgamma = sums[0], sums[1]
+                dz = du          # in place (out of place measured the same: 2.92 ms)
+                L.check(L.lib().epc_bn_apply_bwd_given(du.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
+                                                       beta.data_ptr(), dbeta.data_ptr(), dgamma.data_ptr(), ctx.eps, rows, C,
+                                                       dz.data_ptr(), _st()))
+            else:
+                dz, dgamma, dbeta = _bn_relu_rownorm_bwd(dy, z, rn, mean, var, gamma, beta, ctx.eps)
             dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
             dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
-            return dx, dW, None, dgamma, dbeta, None, None, None, None
+            return dx, dW, None, dgamma, dbeta, None, None, None, None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device)
         ws, n = _ws(rows, C, z.device)
@@ -315,14 +357,14 @@ class LinearBatchNormTrain(torch.autograd.Function):
                                                 var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ctx.eps, ctx.relu, rows,
                                                 dx.data_ptr() if dx is not None else None, dW.data_ptr(), dgamma.data_ptr(),
                                                 dbeta.data_ptr(), ws.data_ptr(), n, part.data_ptr(), part.numel(), _st()))
-            return dx, dW, None, dgamma, dbeta, None, None, None, None
+            return dx, dW, None, dgamma, dbeta, None, None, None, None, None
         dz = torch.empty_like(z)
         L.check(L.lib().epc_bn_apply_bwd(dy.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
                                          beta.data_ptr(), ctx.eps, ctx.relu, rows, C, dz.data_ptr(),
                                          dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n, _st()))
         dx = gemm(dz, W, trans_b=True, fast=True) if ctx.needs_input_grad[0] else None
         dW = gemm(x, dz, trans_a=True, splitk=_splitk_for(cin, C, rows), fast=True, deterministic=True)
-        return dx, dW, None, dgamma, dbeta, None, None, None, None
+        return dx, dW, None, dgamma, dbeta, None, None, None, None, None
 
 
 class BatchNormReluRowNorm(torch.autograd.Function):
@@ -934,9 +976,10 @@ class VladAssignAggregate(torch.autograd.Function):
     aggregation's split-K slices added in a fixed order), backward products in two pieces, like the separate operators."""
 
     @staticmethod
-    def forward(ctx, f, Wc, gamma, beta, eps, n_points):
+    def forward(ctx, f, Wc, gamma, beta, eps, n_points, link=None):
         f = f.contiguous()
         rows, F = f.shape
+        ctx.link = link
         assert Wc.shape == (F, 64) and rows % n_points == 0
         if fused_linear_bn_ok(rows, F, 64):
             z, mean, var = _gemm_with_stats(f, Wc, None, F16X3_ASSIGN)
@@ -981,14 +1024,33 @@ class VladAssignAggregate(torch.autograd.Function):
         ws, n = _ws(rows, 64, z.device)
         if dasum is not None:
             dasum = dasum.contiguous()
+        lk = ctx.link
+        through_tail = (lk is not None and lk.z is not None and FUSE_TAIL_BACKWARD and ctx.needs_input_grad[0] and F == 1024
+                        and N % 32 == 0 and Wc.is_contiguous() and tuple(lk.z.shape) == (rows, F))
+        trow = torch.empty(rows, dtype=torch.float32, device=z.device) if through_tail else None
         # softmax backward (+ the a_sum gradient of every point's cloud) with BatchNorm's sums, then dz in place
         L.check(L.lib().epc_assign_softmax_bwd(da.data_ptr(), dasum.data_ptr() if dasum is not None else None, a.data_ptr(),
                                                z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                               ctx.eps, B, N, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), n,
-                                               _st()))
+                                               ctx.eps, B, N, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               trow.data_ptr() if through_tail else None, ws.data_ptr(), n, _st()))
         dWc = gemm(f, dz, trans_a=True, splitk=_splitk_for(F, 64, rows), fast=True, deterministic=True)
         df = None
-        if ctx.needs_input_grad[0]:
+        if through_tail:
+            # df continued through conv5's l2-norm / ReLU / BatchNorm-sums backward in the product's epilogue (epc_vlad_df_tail)
+            du = torch.empty((rows, F), dtype=torch.float32, device=f.device)
+            sums = torch.empty((2, F), dtype=torch.float32, device=f.device)
+            nbytes = L.lib().epc_vlad_df_packed_bytes(B, F)
+            pfl = L.lib().epc_vlad_df_tail_partial_floats(B, N)
+            scratch = _splitk_ws((nbytes + 3) // 4 + pfl, f.device)
+            part_ptr = scratch.data_ptr() + 4 * ((nbytes + 3) // 4)
+            L.check(L.lib().epc_vlad_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N,
+                                             1 if _GEMM_PRECISION == "bf16" else 2, scratch.data_ptr(), nbytes, lk.z.data_ptr(),
+                                             lk.rn.data_ptr(), trow.data_ptr(), lk.mean.data_ptr(), lk.var.data_ptr(),
+                                             lk.gamma.data_ptr(), lk.beta.data_ptr(), lk.eps, du.data_ptr(), sums.data_ptr(),
+                                             part_ptr, pfl, _st()))
+            lk.du, lk.sums = du, sums
+            df = du
+        elif ctx.needs_input_grad[0]:
             if F % 64 == 0 and Wc.is_contiguous():
                 # df = a dvlad^T + dz Wc^T in one pass, no concatenated operands (epc_vlad_df)
                 df = torch.empty((rows, F), dtype=torch.float32, device=f.device)
@@ -1001,7 +1063,7 @@ class VladAssignAggregate(torch.autograd.Function):
                 lhs = torch.cat((a, dz), dim=1).view(B, N, 128)                                    # [a | dz]
                 rhs = torch.cat((dvlad.transpose(1, 2), Wc.t().unsqueeze(0).expand(B, 64, F)), dim=1)   # [dvlad^T ; Wc^T]  (B, 128, F)
                 df = gemm(lhs, rhs, fast=True).view(rows, F)
-        return df, dWc, dgamma, dbeta, None, None
+        return df, dWc, dgamma, dbeta, None, None, None
 
 
 class GateMul(torch.autograd.Function):

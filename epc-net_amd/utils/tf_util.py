@@ -187,13 +187,15 @@ class bounded_operands:
         _F16X3_HINT = self.prev
 
 
-def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=False, f16x3=None):
+def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=False, f16x3=None, link=None):
     """Linear + training-mode BatchNorm (+ReLU, + conv5's row norm) as one autograd node whose batch statistics come from the
     GEMM's epilogue (ops.LinearBatchNormTrain), with the moving-average updates of batch_norm_template."""
     from .. import ops
     C = int(w2d.shape[1])
     beta, gamma, ema_mean, ema_var = _bn_variables(scope_bn, C)
-    y, mean, var = ops.LinearBatchNormTrain.apply(inputs2d, w2d, b, gamma, beta, 1e-3, int(relu_flag), bool(rownorm), f16x3)
+    y, mean, var = ops.LinearBatchNormTrain.apply(inputs2d, w2d, b, gamma, beta, 1e-3, int(relu_flag), bool(rownorm), f16x3, link)
+    if link is not None:
+        y._epc_tail_link = link      # (read by loupe.G_VLAD.forward: ops.tail_link_of)
     decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
     _ema_update(ema_mean, mean, decay)
     _ema_update(ema_var, var, decay)
@@ -381,7 +383,8 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
         x2 = inputs.reshape(-1, cin)
         if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
             f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True,
-                                f16x3=ops.F16X3_CONV5)      # conv5: BatchNorm'd block outputs against its weights
+                                f16x3=ops.F16X3_CONV5,      # conv5: BatchNorm'd block outputs against its weights
+                                link=ops.TailLink() if ops.FUSE_TAIL_BACKWARD else None)
             _tap_relu_mask(f)          # (the row norm is a positive factor: f > 0 exactly where the ReLU's output is)
             return f
         z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)

@@ -491,13 +491,15 @@ int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out,
  *        a over each cloud's points, added in a fixed order; partials = epc_cloud_colsum64_partial_floats(num_clouds) floats.
  *   bwd: from da (gradient of a), dsum (num_clouds, 64) (gradient of a_sum, may be NULL), a and z:  dz (gradient of z; also used
  *        as scratch for the softmax's input gradient), dgamma, dbeta (64 each).  workspace: epc_colreduce_workspace_bytes(rows, 64),
- *        16-byte aligned. */
+ *        16-byte aligned.  rowdot (rows floats, may be NULL): sum_k (a[r][k] da[r][k] + dz[r][k] z[r][k]) -- with da = f dvlad and
+ *        z = f Wc this IS sum_c df[r][c] f[r][c] of the feature gradient df = a dvlad^T + dz Wc^T, the row dot product the l2-norm
+ *        backward of the features needs, before df exists (epc_vlad_df_tail). */
 int epc_assign_softmax_fwd(const float* z, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                            int num_clouds, int n_points, float* a, float* a_sum, float* partials, size_t partial_floats,
                            void* stream);
 int epc_assign_softmax_bwd(const float* da, const float* dsum, const float* a, const float* z, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, int num_clouds, int n_points, float* dz, float* dgamma,
-                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                           float* dbeta, float* rowdot, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Context gating's product (loupe.py:99-100): out = y * sigmoid(g); bwd: dy = dout * s, dg = dout * y * s * (1 - s). */
 int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
@@ -561,6 +563,21 @@ int epc_knn_overflow_lists(const int32_t* cnt, int cap, int num_clouds, int n, i
 size_t epc_vlad_df_packed_bytes(int num_clouds, int F);
 int epc_vlad_df(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points, int F, int pieces,
                 void* packed, size_t packed_bytes, float* df, void* stream);
+/* epc_vlad_df for conv5's features (F = 1024) continued through the backward of f = l2_normalize(relu(batch_norm(z5)))
+ * (models/epc-net.py:136-148) while the product is in registers: writes du (rows, 1024), the gradient of the BatchNorm OUTPUT
+ * ([f > 0] rn (df - f trow)), instead of df, and dbeta_dgamma (2 x 1024: sum du, sum du zhat) -- what epc_bn_relu_rownorm_bwd's
+ * first pass over (df, z5) computes.  trow: the rows' dot products df . f (epc_assign_softmax_bwd's rowdot); rn: the forward's
+ * reciprocal row norms; mean .. beta, eps: conv5's BatchNorm.  Finish with epc_bn_apply_bwd_given(du, z5, ...) (in place).
+ * n_points a multiple of 32; partials: epc_vlad_df_tail_partial_floats floats of scratch. */
+size_t epc_vlad_df_tail_partial_floats(int num_clouds, int n_points);
+int epc_vlad_df_tail(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points, int pieces,
+                     void* packed, size_t packed_bytes, const float* z5, const float* rn, const float* trow, const float* mean,
+                     const float* var, const float* gamma, const float* beta, float eps, float* du, float* dbeta_dgamma,
+                     float* partials, size_t partial_floats, void* stream);
+/* dz = gamma rstd (dy - dbeta / rows - zhat dgamma / rows): the last step of a training-mode BatchNorm backward whose column sums
+ * are known (utils/tf_util.py:454-519 seen from the gradient side); dy carries its ReLU mask already; dz may be dy. */
+int epc_bn_apply_bwd_given(const float* dy, const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
+                           const float* dbeta, const float* dgamma, float eps, int rows, int C, float* dz, void* stream);
 
 /* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
  * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials
