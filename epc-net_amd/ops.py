@@ -3,8 +3,6 @@ calls into libepcnet_hip.so (``csrc/train_ops.hip``).  autograd is used as the t
 in these functions and no CPU fallback.  Reference semantics are cited per operator."""
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import lib as L
