@@ -44,7 +44,7 @@ def _check(pc, kth, idx, cnt):
 
 @pytest.mark.parametrize("kind,n,sort", [("uniform", 4096, True), ("lidar", 2048, True), ("uniform", 992, False), ("dup", 512, True),
                                          ("lattice", 512, False), ("zeros", 64, False), ("uniform", 20, False), ("uniform", 100, True),
-                                         ("lidar", 1000, True), ("dup", 4096, True)])
+                                         ("lidar", 1000, True), ("dup", 4096, True), ("uniform", 8192, True), ("lidar", 6000, False)])
 def test_both_forms_give_the_oracle_lists(dev, form, kind, n, sort):
     ops = H.pkg("ops")
     tf_util = H.pkg("utils.tf_util")
