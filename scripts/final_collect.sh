@@ -1,4 +1,6 @@
 mkdir -p gpurun_out/r4p
+# NOTE: collect on a CLEAN build of the library (make -B -C epc-net_amd/csrc): bench.py reads the counters only while the loaded
+# library has the hash stamped here, and the driver builds from scratch (objects left by ad-hoc hipcc runs gave another hash).
 python -m pytest tests -m gpu -x -q > gpurun_out/r4p/gpu_tests.log 2>&1; grep -a "passed\|failed" gpurun_out/r4p/gpu_tests.log | tail -2
 bash scripts/collect_profiles.sh r04_b > gpurun_out/r4p/collect.log 2>&1
 bash scripts/prof_train.sh r4p

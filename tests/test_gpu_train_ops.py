@@ -382,6 +382,58 @@ def test_assign_aggregate_node_with_cloud_sums(dev, B, N):
     assert torch.equal(again, sg)
 
 
+@pytest.mark.parametrize("B,N", [(3, 512), (2, 4096)])
+def test_tail_backward_inside_the_feature_gradient_product(dev, B, N):
+    """conv5's tail f = l2_normalize(relu(bn(x W5))) followed by the VLAD assignment / aggregation (models/epc-net.py:136-148,
+    loupe.py:255-291): with ops.FUSE_TAIL_BACKWARD the second node's backward continues through the first one's (epc_vlad_df_tail:
+    row dot products from the assignment's tensors, du and the BatchNorm sums from the product's accumulators).  Every gradient
+    must be the unfused path's up to the rounding of the re-associated dot products -- and both must be the float64 reference's."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(21)
+    rows = B * N
+    x = torch.randn(rows, 256, dtype=torch.float64, generator=g)
+    W5 = torch.randn(256, 1024, dtype=torch.float64, generator=g) / 16
+    g5 = 1 + 0.1 * torch.randn(1024, dtype=torch.float64, generator=g)
+    b5 = 0.1 * torch.randn(1024, dtype=torch.float64, generator=g)
+    Wc = torch.randn(1024, 64, dtype=torch.float64, generator=g) / 32
+    gc = 1 + 0.1 * torch.randn(64, dtype=torch.float64, generator=g)
+    bc = 0.1 * torch.randn(64, dtype=torch.float64, generator=g)
+    up_v = torch.randn(B, 1024, 64, dtype=torch.float64, generator=g)
+    up_s = torch.randn(B, 1, 64, dtype=torch.float64, generator=g)
+    ins = [x, W5, g5, b5, Wc, gc, bc]
+
+    def ref(x, W5, g5, b5, Wc, gc, bc):
+        z = x @ W5
+        u = torch.relu((z - z.mean(0)) * torch.rsqrt(z.var(0, unbiased=False) + 1e-3) * g5 + b5)
+        f = u / u.norm(dim=1, keepdim=True).clamp_min(1e-6)
+        zc = f @ Wc
+        a = torch.softmax((zc - zc.mean(0)) * torch.rsqrt(zc.var(0, unbiased=False) + 1e-3) * gc + bc, 1).reshape(B, N, 64)
+        return torch.matmul(f.reshape(B, N, 1024).transpose(1, 2), a), a.sum(dim=1, keepdim=True)
+
+    def run(fuse):
+        t = [v.float().to(dev).requires_grad_(True) for v in ins]
+        link = ops.TailLink() if fuse else None
+        bias = torch.zeros(1024, device=dev)
+        f, _, _ = ops.LinearBatchNormTrain.apply(t[0], t[1], bias, t[2], t[3], 1e-3, 1, True, None, link)
+        vg, sg, _, _ = ops.VladAssignAggregate.apply(f, t[4], t[5], t[6], 1e-3, N, link)
+        ((vg * up_v.float().to(dev)).sum() + (sg * up_s.float().to(dev)).sum()).backward()
+        return [v.grad for v in t]
+
+    was = ops.FUSE_TAIL_BACKWARD
+    try:
+        ops.FUSE_TAIL_BACKWARD = True
+        fused = run(True)
+        plain = run(False)
+    finally:
+        ops.FUSE_TAIL_BACKWARD = was
+    r = [v.clone().requires_grad_(True) for v in ins]
+    vr, sr = ref(*r)
+    ((vr * up_v).sum() + (sr * up_s).sum()).backward()
+    for i, (a, b, c) in enumerate(zip(fused, plain, r)):
+        assert rel(a, b) <= 2e-4, "fused vs unfused, input %d: %.3e" % (i, rel(a, b))
+        assert rel(a, c.grad) <= 3e-3 and rel(b, c.grad) <= 3e-3, "input %d vs float64: %.3e %.3e" % (i, rel(a, c.grad), rel(b, c.grad))
+
+
 def test_vlad_aggregate(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(4)
