@@ -342,7 +342,8 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
 
 def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0):
     """configs[2]: the quadruplet step at full size, a fresh tuple every step.  HIP-graph replay at EVERY world size (one graph
-    at N = 1; at N > 1 the two graphs around the flat RCCL all-reduce, training.TrainStep._graphed_step).  ``precision``:
+    at N = 1; at N > 1 three graphs around the two RCCL all-reduces -- the head's gradients travel under the backbone's backward,
+    training.TrainStep._graphed_step).  ``precision``:
     "bf16x6" = the f32-accurate split arithmetic (the reference computes in float32), "bf16" = one bf16 value per GEMM operand,
     the arithmetic BASELINE.json configs[2] names.  ``eager_steps`` > 0: a side number without graphs (launch-bound)."""
     import torch
