@@ -830,6 +830,13 @@ static void launch_moments_finalize(const float* stats, int tiles, int N, int ro
                        st, stats, tiles, N, rows, tile_rows, bias, mean, var);
 }
 
+// library-internal (conv5_f32.hip: epc_conv5_train_fwd leaves partials in the same (S1, S2, pivot) form)
+int epc_moments_finalize_launch(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
+                                float* var, void* stream) {
+    launch_moments_finalize(stats, tiles, N, rows, tile_rows, bias, mean, var, (hipStream_t)stream);
+    return EPC_OK;
+}
+
 extern "C" int epc_gemm_stats_tiles(int M) { return M >= 128 ? (M + 127) / 128 : (M + 63) / 64; }
 
 struct BnAffine {  // y = z * s + t, the expression the forward and the backward mask must share bit for bit

@@ -44,7 +44,7 @@ EXPORTS = [
     "epc_pairwise_topk_ws", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
-    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_gemm_bf16_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
+    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_conv5_train_pack_floats", "epc_conv5_train_stats_floats", "epc_conv5_train_fwd", "epc_gemm_bf16_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
     "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64",
@@ -165,6 +165,11 @@ _lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
 _lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
+_lib.epc_conv5_train_pack_floats.argtypes = [c_int]
+_lib.epc_conv5_train_pack_floats.restype = ctypes.c_size_t
+_lib.epc_conv5_train_stats_floats.argtypes = [c_int]
+_lib.epc_conv5_train_stats_floats.restype = ctypes.c_size_t
+_lib.epc_conv5_train_fwd.argtypes = [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P]
 _lib.epc_vlad_df_tail_partial_floats.argtypes = [c_int, c_int]
 _lib.epc_vlad_df_tail_partial_floats.restype = ctypes.c_size_t
 _lib.epc_vlad_df_tail.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, ctypes.c_size_t, _P]

@@ -279,6 +279,27 @@ def tail_link_of(f):
     return getattr(f, "_epc_tail_link", None)
 
 
+# conv5's training forward through epc_conv5_train_fwd instead of the generic statistics GEMM.  OFF: built in round 4 (the inference
+# kernels' shape: rows resident as split-fp16 fragments, weights streamed through a ring of LDS stages, the grid launched in slices
+# that fit the chip), parity-green (tests/test_gpu_train_ops.py), and no faster -- 129 + 77 us in two slices + 12 us of packing
+# against 206-228 us for the GEMM at 18 x 4096 rows.
+CONV5_TRAIN_KERNEL = False
+
+
+def _conv5_train_fwd(x, W, b):
+    rows, cin = x.shape
+    z = torch.empty((rows, 1024), dtype=torch.float32, device=x.device)
+    mean = torch.empty(1024, dtype=torch.float32, device=x.device)
+    var = torch.empty(1024, dtype=torch.float32, device=x.device)
+    pf = L.lib().epc_conv5_train_pack_floats(cin)
+    sf = L.lib().epc_conv5_train_stats_floats(rows)
+    scratch = _splitk_ws(pf + sf, x.device)
+    L.check(L.lib().epc_conv5_train_fwd(x.data_ptr(), cin, W.data_ptr(), b.data_ptr() if b is not None else None, rows, z.data_ptr(),
+                                        mean.data_ptr(), var.data_ptr(), scratch.data_ptr(), pf, scratch.data_ptr() + 4 * pf, sf,
+                                        _st()))
+    return z, mean, var
+
+
 class LinearBatchNormTrain(torch.autograd.Function):
     """Linear followed by BatchNormTrain (utils/tf_util.py:94-106 in training mode) as ONE node: the batch statistics come out
     of the GEMM's epilogue instead of a pass over z.  ``rownorm``: conv5's tail -- l2_normalize(relu(bn(z))) over the channels
@@ -292,7 +313,11 @@ class LinearBatchNormTrain(torch.autograd.Function):
         ctx.link = link if rownorm else None
         # f16x3: the (activation, weight) scale exponents of the split-fp16 form, passed by the call site that knows its operands
         # are BatchNorm'd block outputs (conv5 of either network: tf_util.conv1d_l2_normalized / conv1d with 1024 outputs)
-        z, mean, var = _gemm_with_stats(x, W, b, f16x3)
+        if (rownorm and CONV5_TRAIN_KERNEL and _GEMM_PRECISION == "bf16x6" and x.shape[1] == 256 and W.shape[1] == 1024
+                and x.shape[0] % 64 == 0 and W.is_contiguous()):
+            z, mean, var = _conv5_train_fwd(x, W, b)        # conv5 in the inference kernel's shape (epc_conv5_train_fwd)
+        else:
+            z, mean, var = _gemm_with_stats(x, W, b, f16x3)
         rows, C = z.shape
         if rownorm:
             y = torch.empty_like(z)

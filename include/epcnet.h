@@ -320,6 +320,16 @@ int epc_gemm_bf16_stats(const float* A, const float* B, float* C, const float* b
 int epc_gemm_f16x3_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                          long sBk, long sBn, int ldc, int a_scale_log2, int b_scale_log2, float* stats, size_t stats_floats,
                          float* mean, float* var, void* stream);
+/* conv5 of the training forward as a kernel of its own (models/epc-net.py:136 with is_training; utils/tf_util.py:94-106): z (rows, 1024)
+ * = x (rows, 256) W (256, 1024) + b and the batch moments of z (mean; POPULATION variance, tf.nn.moments) for the BatchNorm that
+ * follows -- what epc_gemm_f16x3_stats computes for these shapes, in the inference conv5 kernel's form: the rows resident as scaled
+ * split-fp16 fragments (three products, 2^-21; no range restriction: every row and every weight column carries its own power-of-two
+ * scale), W packed into fragment order by the call (it changes every step) and streamed through LDS.  rows a multiple of 64.
+ * pack / stats: scratch of epc_conv5_train_pack_floats(256) / epc_conv5_train_stats_floats(rows) floats, 16-byte aligned. */
+size_t epc_conv5_train_pack_floats(int cin);
+size_t epc_conv5_train_stats_floats(int rows);
+int epc_conv5_train_fwd(const float* x, int cin, const float* W, const float* b, int rows, float* z, float* mean, float* var,
+                        float* pack, size_t pack_floats, float* stats, size_t stats_floats, void* stream);
 
 /* Same interface, operands rounded to ONE bf16 value each (f32 data in memory, f32 accumulation, one product): the
  * "bf16" training configuration of BASELINE.json configs[2].  2^-9 relative per operand. */
