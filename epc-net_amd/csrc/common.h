@@ -154,7 +154,7 @@ static inline int epc_device_cu_count() {
 int epc_conv1_launch(const float* xyz, const void* packed_conv1, int num_points_total, float* x, void* x16,
                      int32_t* status, int n, void* stream);
 int epc_moments_finalize_launch(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
-                                float* var, void* stream);
+                                float* var, void* stream, int group_rows = 0);
 int epc_partial_sum_wide_launch(const float* partials, int P, int E, float* out, void* stream);
 int epc_sort_launch(const float* xyz, int num_clouds, int n, float* xyz_sorted, int32_t* perm, int32_t* status_zero,
                     void* stream);

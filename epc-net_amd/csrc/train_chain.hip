@@ -257,6 +257,7 @@ struct ChFwdLinearArgs {
     const float* resid;
     float* a_out;
     int a_stride;
+    unsigned short* a_out16;   // optional: the same activation as bf16, same row stride in ELEMENTS (the bf16 head's operand: train_head16.hip)
     const float* W;
     const float* bias;
     float* z_out;
@@ -367,6 +368,12 @@ __global__ __launch_bounds__(64 * CH_FWD_MAX_WAVES) void chain_fwd_linear_kernel
                 for (int q = 0; q < 8; ++q) v[q] += r[q];
             }
             if (g.a_out && ok) ch_st8(g.a_out + (size_t)row * g.a_stride + c0, v);
+            if (g.a_out16 && ok) {
+                bf16x8 pk;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pk[q] = (__bf16)v[q];
+                *reinterpret_cast<u32x4*>(g.a_out16 + (size_t)row * g.a_stride + c0) = __builtin_bit_cast(u32x4, pk);
+            }
             if (!ok) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = 0.f;
@@ -1210,9 +1217,10 @@ static ChBn make_bn(const float* stats, int rows, const float* bias, float* mean
 
 extern "C" int epc_chain_fwd_linear(const float* zin, const float* in_stats, const float* in_bias, float* in_mean, float* in_var,
                                     const float* in_gamma, const float* in_beta, float eps, const float* resid, float* a_out,
-                                    int a_stride, const float* W, const float* bias, float* z_out, float* stats_out, int rows,
-                                    int pieces, void* stream) {
+                                    int a_stride, void* a_out_bf16, const float* W, const float* bias, float* z_out, float* stats_out,
+                                    int rows, int pieces, void* stream) {
     EPC_CHECK_ARG(zin && in_mean && in_var && in_gamma && in_beta, "null pointer");
+    EPC_CHECK_ARG(!a_out_bf16 || (a_out && a_stride % 8 == 0 && ch_aligned16(a_out_bf16)), "the bf16 copy comes with a_out, 16-byte aligned, stride a multiple of 8");
     EPC_CHECK_ARG(rows > 0 && (pieces == 3 || pieces == 1), "bad shape (pieces: 3 or 1)");
     EPC_CHECK_ARG(!W || (z_out && stats_out), "a layer needs z_out and stats_out");
     EPC_CHECK_ARG(W || a_out, "nothing to do: neither a layer nor an activation output");
@@ -1221,7 +1229,7 @@ extern "C" int epc_chain_fwd_linear(const float* zin, const float* in_stats, con
                   "tensors must be 16-byte aligned, strides multiples of 4");
     ChFwdLinearArgs g;
     g.zin = zin, g.bn = make_bn(in_stats, rows, in_bias, in_mean, in_var, in_gamma, in_beta);
-    g.resid = resid, g.a_out = a_out, g.a_stride = a_stride, g.W = W, g.bias = bias, g.z_out = z_out, g.stats_out = stats_out;
+    g.resid = resid, g.a_out = a_out, g.a_stride = a_stride, g.a_out16 = (unsigned short*)a_out_bf16, g.W = W, g.bias = bias, g.z_out = z_out, g.stats_out = stats_out;
     g.rows = rows, g.wg_rows = ch_wg_rows(rows), g.eps = eps;
     const dim3 grid(epc_chain_parts(rows)), block(64 * ch_waves(rows, CH_FWD_MAX_WAVES));
     const size_t lds = 4 * 16 * 64 * sizeof(double);

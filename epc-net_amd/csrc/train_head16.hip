@@ -1,0 +1,978 @@
+// The head of the training step -- conv5, the per-point l2 norm, the VLAD soft assignment and aggregation (models/epc-net.py:136-148,
+// loupe.py:249-291), forward and backward -- with its (rows, 1024) tensors STORED AS bf16 (params["TRAIN_PRECISION"] = "bf16",
+// BASELINE.json configs[2]): f32 accumulators, f32 batch statistics, f32 master weights; one bf16 value per GEMM operand.
+//
+// Why a file of its own: at 18 x 4096 rows the (rows, 1024) tensors are 302 MB each in f32 and the generic tile GEMM moved them ~13 times
+// per step, every product re-reading and re-splitting f32 operand tiles (conv5's forward: 196 us for 15 us of matrix work).  Here every
+// kernel is ONE streaming pass over bf16 rows with the small operand resident or streamed through LDS, and the feature map
+// f = l2_normalize(relu(bn(z5))) is never written: BatchNorm + ReLU are applied to z5 as it is loaded (the row norm rn is a row factor
+// that moves to the other operand or to the epilogue).  All of them are HBM-bound by construction (MFMA, LDS and VALU time are each
+// below a third of the byte time at 5 TB/s), so the designs are the simplest ones that keep enough loads in flight.
+//
+//   tensors:  cat (rows, 256) f32 (the backbone's output, as the chain leaves it);  z5 (rows, 1024) bf16 = bf16(cat16 W5_16 + b5);
+//             rn (rows) f32;  za, a, dz, da (rows, 64) f32;  du / dz5 (rows, 1024) bf16 (in place);  dcat (rows, 256) f32.
+//   rounding points (restated by oracle/epcnet_oracle_torch.py: _Head16): operands of every product to bf16 once; z5, du and dz5 to
+//             bf16 as they are stored; batch statistics and column sums from the f32 values BEFORE that rounding.
+//
+//   forward   h16_conv5_fwd      z5 = bf16(cat W5 + b5), batch moments of conv5 from the accumulators            (epc-net.py:136-139)
+//             h16_rowgemm<2,X>   u = relu(bn(z5)); rn = rsqrt(max(sum u^2, 1e-12)); za = rn (u Wc), moments      (:147-148, loupe.py:255)
+//             (epc_assign_softmax_fwd, train_ops.hip: a = softmax(bn(za)), a_sum)                                   (loupe.py:257-276)
+//             h16_colgemm        vlad[b] = u[b]^T (rn a)[b]                                                         (loupe.py:286-291)
+//   backward  h16_rowgemm<2,X>   da = rn (u dvlad[b])
+//             (epc_assign_softmax_bwd: dz, the cluster BatchNorm's gradients, t_row)
+//             h16_colgemm        dWc = u^T (rn dz)
+//             h16_df_tail        du = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f t_row), sum du, sum du zhat
+//             h16_bn_bwd_apply   dz5 = gamma rstd (du - sum du / rows - zhat sum du zhat / rows)    (in place)
+//             h16_rowgemm<8>     dcat = dz5 W5^T
+//             h16_dw5            dW5 = cat^T dz5
+#include "common.h"
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ float bf2f(unsigned bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 p;
+    p[0] = (__bf16)lo;
+    p[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ bf16x8 cvt8(const float (&v)[8]) {
+    bf16x8 p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (__bf16)v[j];
+    return p;
+}
+
+struct H16Affine {   // y = z s + t: the expression train_ops.hip's bn_value evaluates (same association, contracted to one FMA)
+    float s, t;
+};
+__device__ __forceinline__ H16Affine h16_affine(float mean, float var, float gamma, float beta, float eps) {
+    H16Affine a;
+    a.s = (1.0f / sqrtf(var + eps)) * gamma;
+    a.t = beta - mean * a.s;
+    return a;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Operand packs: a (K, N) f32 matrix (any strides) as bf16 MFMA B fragments of v_mfma_f32_32x32x16_bf16 -- lane (i = l & 31, h = l >> 5)
+// holds B[k = 16 s + 8 h + j][column], j < 8.
+//   layout 0 (column chunks, conv5's forward): [chunk c < N / 64][k-step s < K / 16][nt < 2][lane]; column = 64 c + 2 i + nt -- the two
+//            accumulators of a lane are ADJACENT columns, so a 16-bit result row leaves as one dword per lane (128-byte runs).
+//   layout 1 (k chunks, the streamed products): [k chunk kc < K / 64][s' < 4][tile < N / 32][lane]; k = 64 kc + 16 s' + 8 h + j,
+//            column = 32 tile + i.
+// Packed once per step from the f32 master weights (1.5 MB of output at most): the rounding to bf16 happens here.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h16_pack_kernel(const float* __restrict__ W, long sk, long sn, long sbatch, int K, int N,
+                                                       int layout, u32x4* __restrict__ out) {
+    const long per = (long)K * N / 8;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    const int l = (int)(e & 63), i = l & 31, h = l >> 5;
+    long rest = e >> 6;
+    int k0, col;
+    if (layout == 0) {
+        const int nt = (int)(rest & 1);
+        rest >>= 1;
+        const int ks = K / 16;
+        const int s = (int)(rest % ks), c = (int)(rest / ks);
+        k0 = 16 * s + 8 * h, col = 64 * c + 2 * i + nt;
+    } else {
+        const int tiles = N / 32;
+        const int tile = (int)(rest % tiles);
+        rest /= tiles;
+        const int sp = (int)(rest & 3), kc = (int)(rest >> 2);
+        k0 = 64 * kc + 16 * sp + 8 * h, col = 32 * tile + i;
+    }
+    const float* src = W + (size_t)blockIdx.y * sbatch + (size_t)k0 * sk + (size_t)col * sn;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * sk];
+    out[(size_t)blockIdx.y * per + e] = __builtin_bit_cast(u32x4, cvt8(v));
+}
+
+static int h16_pack(const float* W, long sk, long sn, long sbatch, int batch, int K, int N, int layout, void* out, hipStream_t st) {
+    const long per = (long)K * N / 8;
+    hipLaunchKernelGGL(h16_pack_kernel, dim3((unsigned)((per + 255) / 256), batch), dim3(256), 0, st, W, sk, sn, sbatch, K, N, layout,
+                       (u32x4*)out);
+    return EPC_OK;
+}
+
+// Pivot-shifted column statistics of a workgroup's four 32-row waves, merged to the first wave's pivot (exact algebra on the shifted
+// sums): S1' = S1 + n d, S2' = S2 + 2 d S1 + n d^2 with d = p_w - p_0.  Output in moments_finalize_kernel's (S1, S2, pivot) form.
+__device__ __forceinline__ void h16_merge_stats(const float (*w)[3][64], const bool* live, int c, float& S1, float& S2, float& P) {
+    P = w[0][2][c];
+    S1 = w[0][0][c], S2 = w[0][1][c];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (live[q]) {
+            const float d = w[q][2][c] - P, s1 = w[q][0][c];
+            S1 += s1 + 32.f * d;
+            S2 += w[q][1][c] + 2.f * d * s1 + 32.f * d * d;
+        }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv5's forward: z5 = bf16(A W5 + b5) with A = cat (rows, 256), f32 or bf16, and the batch statistics of the product.
+// A wave's 32 rows are RESIDENT as bf16 fragments (64 registers, read once); W5 streams through a double-buffered 32-KB LDS stage of 64
+// output columns shared by the workgroup's four waves (global -> registers under the previous stage's products -> LDS), one barrier per
+// stage; a stage's result leaves as one dword (two adjacent columns) per lane and row: whole 128-byte runs.  Per stage and wave the
+// pivot-shifted column sums go to LDS; 64 threads merge the four waves of the PREVIOUS stage behind the barrier that exists anyway.
+// rows a multiple of 32.  stats: [workgroups][3][1024] (tile_rows = 128 for epc_moments_finalize_launch).
+// ----------------------------------------------------------------------------------------------------------------
+#define C5_KS 16
+#define C5_STAGE_U4 (8 * 2 * 64)   // 16 KB: half the k-steps of a 64-column chunk ([k-step 8][nt 2][lane])
+
+template <bool AF32>
+__global__ __launch_bounds__(256, AF32 ? 2 : 3) void h16_conv5_fwd_kernel(const void* __restrict__ A_, int rows, const u32x4* __restrict__ Bp,
+                                                                          const float* __restrict__ bias, unsigned* __restrict__ Z,
+                                                                          float* __restrict__ stats) {
+    // A stage = one HALF (128 k) of a 64-column chunk: 2 x 16 KB of LDS instead of 2 x 32, so that three workgroups share a CU (with the
+    // bf16 operand: 166 registers) and the 576 workgroups of the training tuple are resident at once -- with two per CU the last 64
+    // ran alone in a second round.
+    __shared__ u32x4 Bs[2][C5_STAGE_U4];
+    __shared__ float wst[2][4][3][64];
+    __shared__ bool wlive[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 128 + wave * 32;
+    const bool live = r0 < rows;
+    if (lane == 0) wlive[wave] = live;
+    constexpr int PER = C5_STAGE_U4 / 256;
+    u32x4 pre[PER];
+    auto request = [&](int step) {   // step = 2 chunk + half: the pack is [chunk][k-step][nt][lane], so halves are contiguous
+#pragma unroll
+        for (int u = 0; u < PER; ++u) pre[u] = Bp[(size_t)step * C5_STAGE_U4 + tid + u * 256];
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+    };
+    request(0);
+    bf16x8 ah[C5_KS];
+    {
+        const size_t row = (size_t)min(r0 + i, rows - 1);
+        if constexpr (AF32) {
+            const float* p = reinterpret_cast<const float*>(A_) + row * 256 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < C5_KS; ++s) {
+                const float4 x = ld4(p + 16 * s), y = ld4(p + 16 * s + 4);
+                const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+                ah[s] = cvt8(v);
+            }
+        } else {
+            const u16* p = reinterpret_cast<const u16*>(A_) + row * 256 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < C5_KS; ++s) ah[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 16 * s));
+        }
+    }
+    deposit(0);
+    __syncthreads();
+    const size_t zbase = (size_t)r0 * 512;            // dwords: a row is 512 of them
+    const unsigned voff = 4u * h * 512u + i;
+    auto flush_stats = [&](int st, int buf) {          // the four waves' sums of chunk st -> one (S1, S2, pivot) per column
+        if (tid < 64) {
+            float S1, S2, P;
+            h16_merge_stats(wst[buf], wlive, tid, S1, S2, P);
+            float* o = stats + (size_t)blockIdx.x * 3 * 1024 + 64 * st + tid;
+            o[0] = S1, o[1024] = S2, o[2048] = P;
+        }
+    };
+    for (int st = 0; st < 16; ++st) {
+        const int sb = st & 1;                         // parity of the statistics buffer
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        // first half: k-steps 0..7 from buffer 0 (the second half's fragments travel meanwhile)
+        request(2 * st + 1);
+        if (st > 0) flush_stats(st - 1, sb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                acc0 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[0][(s * 2 + 0) * 64 + lane]), acc0);
+                acc1 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[0][(s * 2 + 1) * 64 + lane]), acc1);
+            }
+        }
+        deposit(1);
+        __syncthreads();
+        // second half: k-steps 8..15 from buffer 1, then the chunk's epilogue
+        if (st + 1 < 16) request(2 * st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                acc0 = mfma_bf16(ah[8 + s], __builtin_bit_cast(bf16x8, Bs[1][(s * 2 + 0) * 64 + lane]), acc0);
+                acc1 = mfma_bf16(ah[8 + s], __builtin_bit_cast(bf16x8, Bs[1][(s * 2 + 1) * 64 + lane]), acc1);
+            }
+            // D: lane (i, h), register r = row mfma_row(r, h), columns 64 st + 2 i (acc0) and + 1 (acc1).  Pivot = the wave's row 0
+            const float p0 = __shfl(acc0[0], i), p1 = __shfl(acc1[0], i);
+            float a1 = 0.f, a2 = 0.f, b1s = 0.f, b2s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d0 = acc0[r] - p0, d1 = acc1[r] - p1;
+                a1 += d0, a2 += d0 * d0, b1s += d1, b2s += d1 * d1;
+            }
+            a1 += __shfl_xor(a1, 32), a2 += __shfl_xor(a2, 32), b1s += __shfl_xor(b1s, 32), b2s += __shfl_xor(b2s, 32);
+            if (h == 0) {
+                wst[sb][wave][0][2 * i] = a1, wst[sb][wave][1][2 * i] = a2, wst[sb][wave][2][2 * i] = p0;
+                wst[sb][wave][0][2 * i + 1] = b1s, wst[sb][wave][1][2 * i + 1] = b2s, wst[sb][wave][2][2 * i + 1] = p1;
+            }
+            const float2 bv = *reinterpret_cast<const float2*>(bias + 64 * st + 2 * i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned* ob = Z + zbase + (size_t)((r & 3) + 8 * (r >> 2)) * 512 + 32 * st;
+                ob[voff] = pack2bf(acc0[r] + bv.x, acc1[r] + bv.y);
+            }
+        }
+        if (st + 1 < 16) deposit(0);                   // (buffer 0's last readers passed the barrier in the middle of this chunk)
+        __syncthreads();
+    }
+    flush_stats(15, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Row-streamed product: out (rows, 32 NT) f32 = T(A) B with A (rows, 1024) bf16 streamed ONCE (16 bytes per lane and k-step, the next
+// 64-channel chunk requested under this chunk's products), B (1024, 32 NT) packed in layout 1 -- one matrix, or one per cloud -- and
+// streamed through a double-buffered LDS chunk of 64 k shared by the workgroup's four 32-row waves.
+//   XFORM: T = relu(batch_norm(.)) per channel (conv5's BatchNorm from its batch moments; coefficients in LDS) and the row factor
+//          rn = rsqrt(max(sum_c u^2, 1e-12)) from the f32 values of u, applied to the accumulators: out = rn (u16 B).
+//          rn_out != null: rn is written.  stats != null: column statistics of out ([workgroups][3][32 NT], tile_rows = 128).
+//   NT = 2: the assignment's product and its gradient (B = Wc / dvlad[cloud]);  NT = 8, no XFORM: dcat = dz5 W5^T.
+// Workgroups never straddle clouds: grid = (ceil(n_points / 128), clouds); n_points a multiple of 32.
+// ----------------------------------------------------------------------------------------------------------------
+struct H16Bn {
+    const float *mean, *var, *gamma, *beta;
+    float eps;
+};
+
+template <int NT, bool XFORM>
+__global__ __launch_bounds__(256, 2) void h16_rowgemm_kernel(const u16* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
+                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
+                                                             float* __restrict__ rn_out, float* __restrict__ stats) {
+    constexpr int CHUNK_U4 = 4 * NT * 64;
+    __shared__ u32x4 Bs[2][CHUNK_U4];
+    __shared__ __attribute__((aligned(16))) float coef[XFORM ? 2 : 1][XFORM ? 1024 : 4];
+    __shared__ float rowc[4][32];
+    __shared__ float wst[4][3][32 * NT];
+    __shared__ bool wlive[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int cloud = blockIdx.y;
+    const int r0 = blockIdx.x * 128 + wave * 32;               // within the cloud
+    const bool live = r0 < n_points;
+    if (lane == 0) wlive[wave] = live;
+    const u32x4* src = Bp + (size_t)cloud * b_cloud_stride_u4;
+    constexpr int PER = CHUNK_U4 / 256;
+    static_assert(CHUNK_U4 % 256 == 0, "a chunk is a whole number of 16-byte pieces per thread");
+    u32x4 pre[PER];
+    auto request = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * 256];
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+    };
+    request(0);
+    const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
+    const u16* arow = A + grow * 1024 + 8 * h;
+    u32x4 an[4];
+    auto aload = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) an[s] = *reinterpret_cast<const u32x4*>(arow + 64 * kc + 16 * s);
+    };
+    aload(0);
+    if constexpr (XFORM) {
+        for (int c = tid; c < 1024; c += 256) {
+            const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
+            coef[0][c] = a.s, coef[1][c] = a.t;
+        }
+    }
+    deposit(0);
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    float ss = 0.f;
+    for (int kc = 0; kc < 16; ++kc) {
+        const int buf = kc & 1;
+        u32x4 av[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) av[s] = an[s];
+        if (kc + 1 < 16) {
+            request(kc + 1);
+            aload(kc + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a;
+                if constexpr (XFORM) {
+                    const int c0 = 64 * kc + 16 * s + 8 * h;
+                    const float4 s0 = *reinterpret_cast<const float4*>(&coef[0][c0]), s1 = *reinterpret_cast<const float4*>(&coef[0][c0 + 4]);
+                    const float4 t0 = *reinterpret_cast<const float4*>(&coef[1][c0]), t1 = *reinterpret_cast<const float4*>(&coef[1][c0 + 4]);
+                    const float cs[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    const float ct[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    float u[8];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        u[2 * w] = fmaxf(bf_lo(av[s][w]) * cs[2 * w] + ct[2 * w], 0.f);
+                        u[2 * w + 1] = fmaxf(bf_hi(av[s][w]) * cs[2 * w + 1] + ct[2 * w + 1], 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += u[j] * u[j];
+                    a = cvt8(u);
+                } else {
+                    a = __builtin_bit_cast(bf16x8, av[s]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma_bf16(a, __builtin_bit_cast(bf16x8, Bs[buf][(s * NT + nt) * 64 + lane]), acc[nt]);
+            }
+        }
+        if (kc + 1 < 16) deposit(buf ^ 1);
+        __syncthreads();
+    }
+    if constexpr (XFORM) {
+        ss += __shfl_xor(ss, 32);
+        const float rnv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        if (h == 0) {
+            rowc[wave][i] = rnv;
+            if (rn_out && live) rn_out[grow] = rnv;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = rowc[wave][mfma_row(r, h)];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][r] *= f;
+            }
+        }
+    }
+    constexpr int N = 32 * NT;
+    if (live) {
+        const size_t obase = ((size_t)cloud * n_points + r0) * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* ob = out + obase + (size_t)mfma_row(r, h) * N + i;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ob[32 * nt] = acc[nt][r];
+        }
+    }
+    if (stats) {   // (workgroup-uniform)
+        if (live) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float p = __shfl(acc[nt][0], i);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[nt][r] - p;
+                    s1 += d, s2 += d * d;
+                }
+                s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+                if (h == 0) wst[wave][0][32 * nt + i] = s1, wst[wave][1][32 * nt + i] = s2, wst[wave][2][32 * nt + i] = p;
+            }
+        }
+        __syncthreads();
+        if (tid < N) {
+            // (N <= 64 here; the merge helper is written for 64-column rows)
+            float P = wst[0][2][tid], S1 = wst[0][0][tid], S2 = wst[0][1][tid];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (wlive[q]) {
+                    const float d = wst[q][2][tid] - P, s1 = wst[q][0][tid];
+                    S1 += s1 + 32.f * d;
+                    S2 += wst[q][1][tid] + 2.f * d * s1 + 32.f * d * d;
+                }
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            float* o = stats + wg * 3 * N + tid;
+            o[0] = S1, o[N] = S2, o[2 * N] = P;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Column product with the rows as the contraction: P[split][c][n] = sum over the workgroup's rows r of u[r][c] (rn[r] C[r][n]),
+// u = relu(batch_norm(z5)) -- the VLAD aggregation vlad[b] = f[b]^T a[b] (loupe.py:286-291; C = a) and the cluster weights' gradient
+// dWc = f^T dz (C = dz) with f = u rn never materialised.  z5 (rows, 1024) bf16 is read once chip-wide: a workgroup owns 128 channels
+// (8 bytes per lane and row: 256-byte runs) and a range of rows; the MFMA's A operand wants 8 consecutive ROWS of one channel per lane,
+// which is a register transposition of the 8 x 4 values a lane loads (free: the conversions write the fragments' elements directly), with
+// the BatchNorm coefficients of the lane's four channels in registers for the whole kernel.  C (rows, 64) f32 is read lane-coalesced
+// (one column per lane), scaled by rn and rounded.  The four waves take a quarter of the rows each and meet in LDS in a fixed order;
+// the splits of a cloud (or of everything) are added by h16_partial_reduce_kernel in ascending order: same bits every run.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void h16_colgemm_kernel(const u16* __restrict__ Z, H16Bn bn, const float* __restrict__ C,
+                                                             const float* __restrict__ rn, int rows_per_wg, int rows_per_batch,
+                                                             int splits, float* __restrict__ P) {
+    __shared__ float red[128 * 64];   // 32 KB: one wave's accumulators
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int batch = blockIdx.y / splits, split = blockIdx.y % splits;
+    const int rbeg = batch * rows_per_batch + split * rows_per_wg;
+    const int rend = min(rbeg + rows_per_wg, (batch + 1) * rows_per_batch);
+    const int per_wave = ((rows_per_wg + 63) / 64) * 16;          // rows per wave, a multiple of 16
+    const int wbeg = rbeg + wave * per_wave, wend = min(wbeg + per_wave, rend);
+    float cs[4], ct[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = m0 + 4 * i + q;
+        const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
+        cs[q] = a.s, ct[q] = a.t;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][nt][r] = 0.f;
+    const int last = max(rend - 1, rbeg);
+    uint2 zn[8];
+    float cn[2][8], rnn[8];
+    auto load = [&](int rb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + 8 * h + j;
+            const bool ok = row < wend;
+            const size_t rr = (size_t)min(row, last);
+            zn[j] = *reinterpret_cast<const uint2*>(Z + rr * 1024 + m0 + 4 * i);
+            rnn[j] = ok ? rn[rr] : 0.f;                        // (a row past the range contributes rn = 0)
+            cn[0][j] = C[rr * 64 + i];
+            cn[1][j] = C[rr * 64 + 32 + i];
+        }
+    };
+    if (wbeg < wend) load(wbeg);
+    for (int rb = wbeg; rb < wend; rb += 16) {
+        uint2 zv[8];
+        float cv[2][8], rv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zv[j] = zn[j], rv[j] = rnn[j], cv[0][j] = cn[0][j], cv[1][j] = cn[1][j];
+        if (rb + 16 < wend) load(rb + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[0][j] = (__bf16)fmaxf(bf_lo(zv[j].x) * cs[0] + ct[0], 0.f);
+            a[1][j] = (__bf16)fmaxf(bf_hi(zv[j].x) * cs[1] + ct[1], 0.f);
+            a[2][j] = (__bf16)fmaxf(bf_lo(zv[j].y) * cs[2] + ct[2], 0.f);
+            a[3][j] = (__bf16)fmaxf(bf_hi(zv[j].y) * cs[3] + ct[3], 0.f);
+            b[0][j] = (__bf16)(cv[0][j] * rv[j]);
+            b[1][j] = (__bf16)(cv[1][j] * rv[j]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[q][nt] = mfma_bf16(a[q], b[nt], acc[q][nt]);
+    }
+    // waves 3, 2, 1 hand their accumulators down in turn: ((w0 + w1) + w2) + w3 -- a fixed order
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((q * 2 + nt) * 16 + r) * 64 + lane] = acc[q][nt][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][nt][r] += red[((q * 2 + nt) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        // D: lane (i', h'), register r of (q, nt) = out[channel m0 + 4 mfma_row(r, h') + q][column 32 nt + i']
+        float* o = P + (size_t)blockIdx.y * 1024 * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = m0 + 4 * mfma_row(r, h) + q;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) o[(size_t)ch * 64 + 32 * nt + i] = acc[q][nt][r];
+            }
+    }
+}
+
+// out[b][e] = sum over s < splits of P[b splits + s][e], ascending s; one float4 per thread
+__global__ __launch_bounds__(256) void h16_partial_reduce_kernel(const float* __restrict__ P, int splits, long per, float* __restrict__ out) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= per) return;
+    const float* p = P + (size_t)blockIdx.y * splits * per + e;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * per);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * per + e) = s;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The VLAD feature gradient continued through conv5's tail backward (train_head.hip's vlad_df_kernel<1, true> on 16-bit tensors):
+//     df = [a | dz] [dvlad[b]^T ; Wc^T]  (K = 128);  u = relu(z5 s + t);  f = u rn;  du = [f > 0] (rn df - (rn t_row) f)
+// with z5 read and du written as bf16 -- two adjacent columns per lane, so both move as dwords in 128-byte runs (the pack gives the
+// two accumulators of a lane adjacent columns).  Column sums (sum du, sum du zhat) from the f32 values, one partial per workgroup.
+// ----------------------------------------------------------------------------------------------------------------
+#define DF_STAGE_U4 (8 * 2 * 64)   // 16 KB: [k-step 8][nt 2][lane]
+
+// Bp[b][chunk c < 16][s < 8][nt][lane (i, h)][8]: B[k = 16 s + 8 h + j][f = 64 c + 2 i + nt], B = [dvlad[b]^T ; Wc^T]
+__global__ __launch_bounds__(256) void h16_df_pack_kernel(const float* __restrict__ dvlad, const float* __restrict__ Wc,
+                                                          u32x4* __restrict__ Bp) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    for (int e = threadIdx.x; e < DF_STAGE_U4; e += 256) {
+        const int l = e & 63, nt = (e >> 6) & 1, s = e >> 7, i = l & 31, h = l >> 5;
+        const int f = 64 * c + 2 * i + nt, k0 = 16 * s + 8 * h;
+        const float* src = k0 < 64 ? dvlad + ((size_t)b * 1024 + f) * 64 + k0 : Wc + (size_t)f * 64 + (k0 - 64);
+        const float4 x = ld4(src), y = ld4(src + 4);
+        const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        Bp[((size_t)b * 16 + c) * DF_STAGE_U4 + e] = __builtin_bit_cast(u32x4, cvt8(v));
+    }
+}
+
+struct H16Tail {
+    const unsigned* z5;   // (rows, 512) dwords
+    const float *rn, *trow;
+    H16Bn bn;
+    float* partials;      // [workgroups][2][1024]
+};
+
+__global__ __launch_bounds__(256, 2) void h16_df_tail_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+                                                             const u32x4* __restrict__ Bp, int n_points, unsigned* __restrict__ du,
+                                                             H16Tail tail) {
+    __shared__ u32x4 Bs[2][DF_STAGE_U4];
+    __shared__ __attribute__((aligned(16))) float coef[4][1024];   // s, t, mean, rstd
+    __shared__ float rowc[4][2][32];
+    __shared__ float psum[2][4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    const bool live = r0 < n_points;
+    const size_t row = (size_t)b * n_points + min(r0 + i, n_points - 1);
+    const u32x4* src = Bp + (size_t)b * 16 * DF_STAGE_U4;
+    constexpr int PER = DF_STAGE_U4 / 256;
+    u32x4 pre[PER];
+    auto request = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)st * DF_STAGE_U4 + tid + u * 256];
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+    };
+    request(0);
+    bf16x8 ah[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float* p = (s < 4 ? a : dz) + row * 64 + 16 * (s & 3) + 8 * h;
+        const float4 x = ld4(p), y = ld4(p + 4);
+        const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        ah[s] = cvt8(v);
+    }
+    for (int c = tid; c < 1024; c += 256) {
+        const float rs = 1.0f / sqrtf(tail.bn.var[c] + tail.bn.eps);
+        const H16Affine af = h16_affine(tail.bn.mean[c], tail.bn.var[c], tail.bn.gamma[c], tail.bn.beta[c], tail.bn.eps);
+        coef[0][c] = af.s, coef[1][c] = af.t, coef[2][c] = tail.bn.mean[c], coef[3][c] = rs;
+    }
+    if (h == 0) {
+        const float rnv = live ? tail.rn[row] : 0.f, tv = live ? tail.trow[row] : 0.f;
+        rowc[wave][0][i] = rnv;
+        rowc[wave][1][i] = rnv >= 0.99e6f ? 0.f : rnv * tv;
+    }
+    deposit(0);
+    __syncthreads();
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t tile_base = ((size_t)b * n_points + r0) * 512;   // dwords
+    const unsigned voff = 4u * h * 512u + i;
+    unsigned zn[16];
+    auto zload = [&](int st) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zn[r] = (tail.z5 + tile_base + (size_t)((r & 3) + 8 * (r >> 2)) * 512 + 32 * st)[voff];
+    };
+    if (live) zload(0);
+    auto flush = [&](int st, int buf) {      // stage st's column sums: four waves -> one partial
+        if (tid < 128) {
+            const int q = tid >> 6, c = tid & 63;
+            const float v = (psum[buf][0][q][c] + psum[buf][1][q][c]) + (psum[buf][2][q][c] + psum[buf][3][q][c]);
+            tail.partials[((size_t)wg * 2 + q) * 1024 + 64 * st + c] = v;
+        }
+    };
+    for (int st = 0; st < 16; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < 16) request(st + 1);
+        unsigned zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = zn[r];
+        if (live && st + 1 < 16) zload(st + 1);
+        if (st > 0) flush(st - 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                acc0 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[buf][(s * 2 + 0) * 64 + lane]), acc0);
+                acc1 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[buf][(s * 2 + 1) * 64 + lane]), acc1);
+            }
+            const int c0 = 64 * st + 2 * i;
+            const float2 cs = *reinterpret_cast<const float2*>(&coef[0][c0]), ct = *reinterpret_cast<const float2*>(&coef[1][c0]);
+            const float2 mu = *reinterpret_cast<const float2*>(&coef[2][c0]), rs = *reinterpret_cast<const float2*>(&coef[3][c0]);
+            float s10 = 0.f, s20 = 0.f, s11 = 0.f, s21 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = mfma_row(r, h);
+                const float rnv = rowc[wave][0][rr], rt = rowc[wave][1][rr];
+                const float z0 = bf_lo(zv[r]), z1 = bf_hi(zv[r]);
+                const float f0 = fmaxf(z0 * cs.x + ct.x, 0.f) * rnv, f1 = fmaxf(z1 * cs.y + ct.y, 0.f) * rnv;
+                const float d0 = f0 > 0.f ? rnv * acc0[r] - rt * f0 : 0.f;
+                const float d1 = f1 > 0.f ? rnv * acc1[r] - rt * f1 : 0.f;
+                s10 += d0, s20 += d0 * ((z0 - mu.x) * rs.x);
+                s11 += d1, s21 += d1 * ((z1 - mu.y) * rs.y);
+                (du + tile_base + (size_t)((r & 3) + 8 * (r >> 2)) * 512 + 32 * st)[voff] = pack2bf(d0, d1);
+            }
+            s10 += __shfl_xor(s10, 32), s20 += __shfl_xor(s20, 32), s11 += __shfl_xor(s11, 32), s21 += __shfl_xor(s21, 32);
+            if (h == 0) {
+                psum[buf][wave][0][2 * i] = s10, psum[buf][wave][1][2 * i] = s20;
+                psum[buf][wave][0][2 * i + 1] = s11, psum[buf][wave][1][2 * i + 1] = s21;
+            }
+        } else if (h == 0) {
+            psum[buf][wave][0][2 * i] = 0.f, psum[buf][wave][1][2 * i] = 0.f;
+            psum[buf][wave][0][2 * i + 1] = 0.f, psum[buf][wave][1][2 * i + 1] = 0.f;
+        }
+        if (st + 1 < 16) deposit(buf ^ 1);
+        __syncthreads();
+    }
+    flush(15, 1);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// dz5 = gamma rstd (du - sum du / rows - zhat sum du zhat / rows) on bf16 rows, in place or not: the last step of conv5's BatchNorm
+// backward (utils/tf_util.py:454-519 from the gradient side) once the column sums are known.  A wave takes whole 2-KB rows, 16 bytes
+// per lane and half row; the sixteen channels of a lane keep their coefficients in registers.
+// ----------------------------------------------------------------------------------------------------------------
+#define BA_ROWS 16   // rows per workgroup (4 per wave)
+
+__global__ __launch_bounds__(256) void h16_bn_bwd_apply_kernel(const u32x4* __restrict__ du, const u32x4* __restrict__ z5, H16Bn bn,
+                                                               const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                               float inv_rows, int rows, u32x4* __restrict__ dz) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mu[16], k1[16], bb[16], gg[16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 512 * u + 8 * lane + e, k = 8 * u + e;
+            const float r = 1.0f / sqrtf(bn.var[c] + bn.eps);
+            mu[k] = bn.mean[c], k1[k] = bn.gamma[c] * r, bb[k] = dbeta[c] * inv_rows, gg[k] = r * (dgamma[c] * inv_rows);
+        }
+    const int row0 = blockIdx.x * BA_ROWS + wave;
+#pragma unroll
+    for (int q = 0; q < BA_ROWS / 4; ++q) {
+        const int row = row0 + 4 * q;
+        if (row >= rows) break;
+        const size_t o = (size_t)row * 128 + lane;     // u32x4 units: a row is 128 of them
+        const u32x4 g0 = du[o], g1 = du[o + 64], z0 = z5[o], z1 = z5[o + 64];
+        u32x4 o0, o1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = k1[2 * w] * (bf_lo(g0[w]) - bb[2 * w] - (bf_lo(z0[w]) - mu[2 * w]) * gg[2 * w]);
+            const float b = k1[2 * w + 1] * (bf_hi(g0[w]) - bb[2 * w + 1] - (bf_hi(z0[w]) - mu[2 * w + 1]) * gg[2 * w + 1]);
+            o0[w] = pack2bf(a, b);
+            const float c = k1[8 + 2 * w] * (bf_lo(g1[w]) - bb[8 + 2 * w] - (bf_lo(z1[w]) - mu[8 + 2 * w]) * gg[8 + 2 * w]);
+            const float d = k1[9 + 2 * w] * (bf_hi(g1[w]) - bb[9 + 2 * w] - (bf_hi(z1[w]) - mu[9 + 2 * w]) * gg[9 + 2 * w]);
+            o1[w] = pack2bf(c, d);
+        }
+        dz[o] = o0, dz[o + 64] = o1;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv5's weight gradient dW5 (256, 1024) = cat^T dz5 -- both operands (rows, .) row-major with the ROWS as the contraction, 73 728 deep at
+// the training tuple's size.  The generic tile GEMM took 163 us for it with a bf16 right operand (2-byte lane-coalesced fetches, re-split per
+// tile).  Here, as in h16_colgemm_kernel, a lane loads a few adjacent channels of 8 consecutive rows and the conversions write the MFMA
+// fragments (8 rows of ONE channel per lane) directly: cat as float4 (4 channels -> 4 A fragments), dz5 as a dword (2 columns -> 2 B
+// fragments).  A workgroup of eight waves owns all 256 input channels x 256 output columns (waves 2 x 4: 128 x 64 each) over a slice of
+// the rows; slices are added in ascending order by h16_partial_reduce_kernel.  cat is read 4 times chip-wide, dz5 once: the first version
+// (four waves, 128 columns, f32 cat: 8 x 75 MB of re-reads from beyond L2) took 171 us -- no faster than the tile GEMM.
+// ----------------------------------------------------------------------------------------------------------------
+template <bool AF32>
+__global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict__ cat_, const unsigned* __restrict__ dz5, int rows,
+                                                         int rows_per_wg, float* __restrict__ P) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n0 = blockIdx.x * 256 + 64 * wn;          // output columns n0 + 2 i + t
+    const int rbeg = blockIdx.y * rows_per_wg, rend = min(rbeg + rows_per_wg, rows);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
+    const int last = max(rend - 1, rbeg);
+    float4 an[8];
+    uint2 an16[8];
+    unsigned bn_[8];
+    auto load = [&](int rb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + 8 * h + j;
+            const size_t rr = (size_t)min(row, last);
+            if constexpr (AF32) an[j] = ld4(reinterpret_cast<const float*>(cat_) + rr * 256 + 128 * wm + 4 * i);
+            else an16[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(cat_) + rr * 256 + 128 * wm + 4 * i);
+            bn_[j] = row < rend ? dz5[rr * 512 + (n0 >> 1) + i] : 0u;     // (a row past the slice contributes zeros)
+        }
+    };
+    if (rbeg < rend) load(rbeg);
+    for (int rb = rbeg; rb < rend; rb += 16) {
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (AF32) {
+                a[0][j] = (__bf16)an[j].x, a[1][j] = (__bf16)an[j].y, a[2][j] = (__bf16)an[j].z, a[3][j] = (__bf16)an[j].w;
+            } else {
+                a[0][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].x & 0xffffu)), a[1][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].x >> 16));
+                a[2][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].y & 0xffffu)), a[3][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].y >> 16));
+            }
+            b[0][j] = __builtin_bit_cast(__bf16, (u16)(bn_[j] & 0xffffu)), b[1][j] = __builtin_bit_cast(__bf16, (u16)(bn_[j] >> 16));
+        }
+        if (rb + 16 < rend) load(rb + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(a[q], b[t], acc[q][t]);
+    }
+    // D: lane (i', h'), register r of (q, t) = dW5[channel 128 wm + 4 mfma_row(r, h') + q][column n0 + 2 i' + t]
+    float* o = P + (size_t)blockIdx.y * 256 * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 128 * wm + 4 * mfma_row(r, h) + q;
+            *reinterpret_cast<float2*>(o + (size_t)ch * 1024 + n0 + 2 * i) = make_float2(acc[q][0][r], acc[q][1][r]);
+        }
+}
+
+// bf16 rows -> f32 (test taps, the materialised features of the distillation variants): y = T(z) with T = identity, or
+// relu(batch_norm(z)) rn (the feature map f the fused kernels never write)
+__global__ __launch_bounds__(256) void h16_expand_kernel(const unsigned* __restrict__ z, H16Bn bn, const float* __restrict__ rn,
+                                                         long n_dwords, float* __restrict__ y) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_dwords) return;
+    const unsigned w = z[e];
+    float a = bf_lo(w), b = bf_hi(w);
+    if (bn.mean) {
+        const int c = (int)((2 * e) & 1023);
+        const H16Affine a0 = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
+        const H16Affine a1 = h16_affine(bn.mean[c + 1], bn.var[c + 1], bn.gamma[c + 1], bn.beta[c + 1], bn.eps);
+        const float r = rn ? rn[(2 * e) >> 10] : 1.f;
+        a = fmaxf(a * a0.s + a0.t, 0.f) * r, b = fmaxf(b * a1.s + a1.t, 0.f) * r;
+    }
+    *reinterpret_cast<float2*>(y + 2 * e) = make_float2(a, b);
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------------
+static bool h16_aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+extern "C" size_t epc_h16_conv5_fwd_scratch_bytes(int rows) {
+    if (rows <= 0) return 0;
+    return (size_t)256 * 1024 * 2 + (size_t)((rows + 127) / 128) * 3 * 1024 * sizeof(float);
+}
+
+extern "C" int epc_h16_conv5_fwd(const void* cat, int cat_is_bf16, const float* W5, const float* b5, int rows, void* z5, float* mean,
+                                 float* var, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(cat && W5 && b5 && z5 && mean && var && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0 && (long)rows * 1024 < (1L << 32), "rows must be a positive multiple of 32 (rows * 1024 < 2^32)");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_conv5_fwd_scratch_bytes(rows), "scratch too small (epc_h16_conv5_fwd_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(cat) && h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(b5), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h16_pack(W5, 1024, 1, 0, 1, 256, 1024, 0, scratch, st);
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)256 * 1024 * 2);
+    const int wgs = (rows + 127) / 128;
+    if (cat_is_bf16)
+        hipLaunchKernelGGL(h16_conv5_fwd_kernel<false>, dim3(wgs), dim3(256), 0, st, cat, rows, (const u32x4*)scratch, b5, (unsigned*)z5, stats);
+    else
+        hipLaunchKernelGGL(h16_conv5_fwd_kernel<true>, dim3(wgs), dim3(256), 0, st, cat, rows, (const u32x4*)scratch, b5, (unsigned*)z5, stats);
+    epc_moments_finalize_launch(stats, wgs, 1024, rows, 128, b5, mean, var, stream);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h16_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    const size_t pack = (size_t)(per_cloud_operand ? num_clouds : 1) * 1024 * 64 * 2;
+    return pack + (size_t)num_clouds * ((n_points + 127) / 128) * 3 * 64 * sizeof(float);
+}
+
+// za = rn (relu(bn(z5)) B): B = Wc (1024, 64) shared (per_cloud_operand = 0: the forward; rn and the batch moments of za are written when
+// their pointers are given) or B = dvlad (num_clouds, 1024, 64) (per_cloud_operand = 1: da of the backward).
+extern "C" int epc_h16_assign(const void* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                              const float* B, int per_cloud_operand, int num_clouds, int n_points, float* out, float* rn_out,
+                              float* mean_out, float* var_out, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && B && out && scratch, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && num_clouds <= 65535 && n_points > 0 && n_points % 32 == 0, "n_points must be a positive multiple of 32");
+    EPC_CHECK_ARG((mean_out == nullptr) == (var_out == nullptr), "mean_out and var_out come together");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_assign_scratch_bytes(num_clouds, n_points, per_cloud_operand), "scratch too small (epc_h16_assign_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = per_cloud_operand ? num_clouds : 1;
+    h16_pack(B, 64, 1, (long)1024 * 64, nb, 1024, 64, 1, scratch, st);
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)nb * 1024 * 64 * 2);
+    const dim3 grid((n_points + 127) / 128, num_clouds);
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    hipLaunchKernelGGL((h16_rowgemm_kernel<2, true>), grid, dim3(256), 0, st, (const u16*)z5, n_points, (const u32x4*)scratch,
+                       per_cloud_operand ? (long)(1024 * 64 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr);
+    if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h16_dx_scratch_bytes(void) { return (size_t)1024 * 256 * 2; }
+
+// dcat (rows, 256) f32 = dz5 (rows, 1024) bf16 times W5^T (W5: (256, 1024) f32, rounded to bf16 here)
+extern "C" int epc_h16_conv5_dx(const void* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(dz5 && W5 && dcat && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0, "rows must be a positive multiple of 32");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_dx_scratch_bytes(), "scratch too small (epc_h16_dx_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(dz5) && h16_aligned16(scratch) && h16_aligned16(dcat), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h16_pack(W5, 1, 1024, 0, 1, 1024, 256, 1, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
+    const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    hipLaunchKernelGGL((h16_rowgemm_kernel<8, false>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, (const u16*)dz5, rows,
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+static int h16_splits(int n_points) { return n_points >= 1024 ? 4 : (n_points >= 512 ? 2 : 1); }
+
+extern "C" size_t epc_h16_colgemm_scratch_bytes(int num_clouds, int n_points) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    return (size_t)num_clouds * h16_splits(n_points) * 1024 * 64 * sizeof(float);
+}
+
+// out = relu(bn(z5))^T (rn C): per cloud (per_cloud = 1: out (num_clouds, 1024, 64), the VLAD aggregation with C = a) or over all rows
+// (per_cloud = 0: out (1024, 64), the cluster weights' gradient with C = dz).  C: (rows, 64) f32.
+extern "C" int epc_h16_colgemm(const void* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                               const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && C && rn && out && scratch, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(n_points) <= 65535, "bad shape");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_colgemm_scratch_bytes(num_clouds, n_points), "scratch too small (epc_h16_colgemm_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = h16_splits(n_points);
+    const int rows_per_wg = (n_points + S - 1) / S;
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    hipLaunchKernelGGL(h16_colgemm_kernel, dim3(8, num_clouds * S), dim3(256), 0, st, (const u16*)z5, bn, C, rn, rows_per_wg, n_points, S,
+                       (float*)scratch);
+    const long per = 1024 * 64;
+    if (per_cloud)
+        hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), num_clouds), dim3(256), 0, st, (const float*)scratch, S, per, out);
+    else
+        hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), 1), dim3(256), 0, st, (const float*)scratch, num_clouds * S, per, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h16_df_tail_scratch_bytes(int num_clouds, int n_points) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    return (size_t)num_clouds * 16 * DF_STAGE_U4 * sizeof(u32x4) + (size_t)num_clouds * ((n_points + 127) / 128) * 2 * 1024 * sizeof(float);
+}
+
+// du (rows, 1024) bf16 and dbeta_dgamma (2, 1024) = (sum du, sum du zhat): see h16_df_tail_kernel
+extern "C" int epc_h16_df_tail(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points,
+                               const void* z5, const float* rn, const float* trow, const float* mean5, const float* var5,
+                               const float* gamma5, const float* beta5, float eps, void* du, float* dbeta_dgamma, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(a && dz && dvlad && Wc && z5 && rn && trow && mean5 && var5 && gamma5 && beta5 && du && dbeta_dgamma && scratch, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && num_clouds <= 65535 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * n_points * 1024 < (1L << 32),
+                  "bad shape (n_points a multiple of 32; rows * 1024 < 2^32)");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_df_tail_scratch_bytes(num_clouds, n_points), "scratch too small (epc_h16_df_tail_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(a) && h16_aligned16(dz) && h16_aligned16(dvlad) && h16_aligned16(Wc) && h16_aligned16(z5) && h16_aligned16(du) &&
+                      h16_aligned16(scratch) && h16_aligned16(dbeta_dgamma),
+                  "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(h16_df_pack_kernel, dim3(16, num_clouds), dim3(256), 0, st, dvlad, Wc, (u32x4*)scratch);
+    float* partials = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)num_clouds * 16 * DF_STAGE_U4 * sizeof(u32x4));
+    const dim3 grid((n_points + 127) / 128, num_clouds);
+    const H16Tail tail{(const unsigned*)z5, rn, trow, H16Bn{mean5, var5, gamma5, beta5, eps}, partials};
+    hipLaunchKernelGGL(h16_df_tail_kernel, grid, dim3(256), 0, st, a, dz, (const u32x4*)scratch, n_points, (unsigned*)du, tail);
+    epc_partial_sum_wide_launch(partials, (int)(grid.x * grid.y), 2 * 1024, dbeta_dgamma, stream);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_h16_bn_bwd_apply(const void* du, const void* z5, const float* mean5, const float* var5, const float* gamma5,
+                                    const float* beta5, float eps, const float* dbeta, const float* dgamma, int rows, void* dz5,
+                                    void* stream) {
+    EPC_CHECK_ARG(du && z5 && mean5 && var5 && gamma5 && beta5 && dbeta && dgamma && dz5, "null pointer");
+    EPC_CHECK_ARG(rows > 0, "bad shape");
+    EPC_CHECK_ARG(h16_aligned16(du) && h16_aligned16(z5) && h16_aligned16(dz5), "tensors must be 16-byte aligned");
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    hipLaunchKernelGGL(h16_bn_bwd_apply_kernel, dim3((rows + BA_ROWS - 1) / BA_ROWS), dim3(256), 0, (hipStream_t)stream, (const u32x4*)du,
+                       (const u32x4*)z5, bn, dbeta, dgamma, 1.0f / rows, rows, (u32x4*)dz5);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+static int h16_dw5_splits(int rows) {
+    const int cus = epc_device_cu_count();
+    int s = max(1, cus / 4);                              // 4 column tiles per slice: one workgroup (eight waves) per CU
+    while (s > 1 && (rows + s - 1) / s < 64) s >>= 1;     // (short inputs: at least 64 rows per slice)
+    return s;
+}
+
+extern "C" size_t epc_h16_conv5_dw_scratch_bytes(int rows) {
+    return rows > 0 ? (size_t)h16_dw5_splits(rows) * 256 * 1024 * sizeof(float) : 0;
+}
+
+// dW5 (256, 1024) f32 = cat^T dz5: cat (rows, 256) f32 (or bf16: cat_is_bf16), rounded to bf16 as it is loaded; dz5 (rows, 1024) bf16
+extern "C" int epc_h16_conv5_dw(const void* cat, int cat_is_bf16, const void* dz5, int rows, float* dW5, void* scratch, size_t scratch_bytes,
+                                void* stream) {
+    EPC_CHECK_ARG(cat && dz5 && dW5 && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && (long)rows * 1024 < (1L << 32), "bad shape");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_conv5_dw_scratch_bytes(rows), "scratch too small (epc_h16_conv5_dw_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(cat) && h16_aligned16(dz5) && h16_aligned16(dW5) && h16_aligned16(scratch), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = h16_dw5_splits(rows);
+    const int rows_per_wg = ((rows + S - 1) / S + 15) / 16 * 16;
+    if (cat_is_bf16)
+        hipLaunchKernelGGL(h16_dw5_kernel<false>, dim3(4, S), dim3(512), 0, st, cat, (const unsigned*)dz5, rows, rows_per_wg, (float*)scratch);
+    else
+        hipLaunchKernelGGL(h16_dw5_kernel<true>, dim3(4, S), dim3(512), 0, st, cat, (const unsigned*)dz5, rows, rows_per_wg, (float*)scratch);
+    const long per = 256 * 1024;
+    hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), 1), dim3(256), 0, st, (const float*)scratch, S, per, dW5);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// y (rows, 1024) f32 from bf16 rows: the values themselves (mean5 = NULL), or the feature map relu(bn(z5)) rn (rn may be NULL: no row
+// factor) -- what the fused kernels never write; for test taps and the distillation variants' second output.
+extern "C" int epc_h16_expand(const void* z, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                              const float* rn, int rows, float* y, void* stream) {
+    EPC_CHECK_ARG(z && y && rows > 0, "bad argument");
+    EPC_CHECK_ARG(!mean5 || (var5 && gamma5 && beta5), "the BatchNorm's four tensors come together");
+    const long n = (long)rows * 512;
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    hipLaunchKernelGGL(h16_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)z, bn, rn, n, y);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -43,6 +43,7 @@ struct GemmArgs {
     // set (flag_mode 2) -- an in-stream, in-graph fallback with no host round trip.  Null: no guard.
     unsigned int* range_flag = nullptr;
     int flag_mode = 0;
+    int b16 = 0;   // B is stored as bf16 (strides in elements): the training head's dz5 as the right operand of dW5 = cat^T dz5
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -203,9 +204,33 @@ __device__ __forceinline__ void split8x3(const float (&v)[8], bf16x8& p0, bf16x8
 template <int BLOCKS>  // 32-row blocks of this operand tile (2 * WM or 2 * WN)
 __device__ __forceinline__ void fetch_fragments(const float* __restrict__ P, long s_outer, long s_k, int outer0,
                                                 int outer_lim, int kt, int k_lim, float (&v)[(BLOCKS * 128) / 256][8],
-                                                int tid) {
+                                                int tid, bool is16 = false) {
     const bool k_contig = s_k == 1;
     constexpr int ROWS = 32 * BLOCKS;
+    if (is16) {   // (workgroup-uniform) the operand is stored as bf16: same fragments, two bytes per element
+        const unsigned short* P16 = reinterpret_cast<const unsigned short*>(P);
+        const bool inside = outer0 + ROWS <= outer_lim && kt + S_BK <= k_lim;
+#pragma unroll
+        for (int u = 0; u < (ROWS * 4) / 256; ++u) {
+            const int f = tid + 256 * u;
+            const int kg = k_contig ? (f & 3) : (f / ROWS), row = k_contig ? (f >> 2) : (f % ROWS);
+            const int go = outer0 + row, gk = kt + 8 * kg;
+            const unsigned short* src = P16 + (size_t)go * s_outer + (size_t)gk * s_k;
+            if (inside && k_contig && ((reinterpret_cast<size_t>(src) & 15) == 0)) {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(src);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][2 * q] = __uint_as_float(w[q] << 16), v[u][2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+            } else if (inside) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[u][jj] = __uint_as_float((unsigned)src[(size_t)jj * s_k] << 16);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    v[u][jj] = (go < outer_lim && gk + jj < k_lim) ? __uint_as_float((unsigned)src[(size_t)jj * s_k] << 16) : 0.f;
+            }
+        }
+        return;
+    }
     // Interior tiles (every row and all 32 k of the tile inside the matrix: all but the edge workgroups / the K tail) take a
     // BRANCH-FREE fetch -- the test is workgroup-uniform, so it is one scalar branch.  The guarded form below puts every
     // load in an exec-masked branch of its own, and hipcc then waits `vmcnt(0)` at each join before it merges the loaded
@@ -338,7 +363,8 @@ __global__ __launch_bounds__(256, (PIECES == 4 && WM == 2 && WN == 2) ? 3 : 1) v
     bool range_bad = false;
     const int batch = blockIdx.z / g.splitk, ks = blockIdx.z % g.splitk;
     const float* A = g.A + (size_t)batch * g.bA;
-    const float* B = g.B + (size_t)batch * g.bB;
+    const float* B = g.b16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(g.B) + (size_t)batch * g.bB)
+                           : g.B + (size_t)batch * g.bB;
     float* C = g.C + (size_t)batch * g.bC;
     int kchunk = (g.K + g.splitk - 1) / g.splitk;
     kchunk = (kchunk + S_BK - 1) / S_BK * S_BK;
@@ -363,7 +389,7 @@ __global__ __launch_bounds__(256, (PIECES == 4 && WM == 2 && WN == 2) ? 3 : 1) v
     for (int pf = 0; pf < G_PF; ++pf)
         if (k0 + pf * S_BK < k1) {
             fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, k0 + pf * S_BK, k1, va[pf], tid);
-            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0 + pf * S_BK, k1, vb[pf], tid);
+            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, k0 + pf * S_BK, k1, vb[pf], tid, g.b16 != 0);
         }
 #ifdef GEMM_STAMPS
     unsigned st_store = 0, st_b1 = 0, st_fetch = 0, st_mfma = 0, st_b2 = 0;
@@ -379,7 +405,7 @@ __global__ __launch_bounds__(256, (PIECES == 4 && WM == 2 && WN == 2) ? 3 : 1) v
         GS_T(t2);
         if (kt + G_PF * S_BK < k1) {  // in flight under the MFMAs of this tile and of the G_PF - 1 after it
             fetch_fragments<2 * WM>(A, g.sAm, g.sAk, m0, g.M, kt + G_PF * S_BK, k1, va[slot], tid);
-            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + G_PF * S_BK, k1, vb[slot], tid);
+            fetch_fragments<2 * WN>(B, g.sBn, g.sBk, n0, g.N, kt + G_PF * S_BK, k1, vb[slot], tid, g.b16 != 0);
         }
         GS_T(t3);
         GS_ADD(st_store, t0, t1);
@@ -630,7 +656,7 @@ static void launch_gemm_split(const GemmArgs& g, int batch, int pieces, hipStrea
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                      long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
-                     int pieces, void* stream, float* partial = nullptr, size_t partial_floats = 0);
+                     int pieces, void* stream, float* partial = nullptr, size_t partial_floats = 0, int b16 = 0);
 
 // C[b](m, n) = bias(n) + sum over the split-K slices IN ASCENDING ORDER of their partial products: the deterministic
 // counterpart of the atomic epilogue (same bits on every run), one float4 of C per thread.
@@ -680,8 +706,9 @@ extern "C" int epc_gemm_bf16(const float* A, const float* B, float* C, const flo
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                      long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate,
-                     int pieces, void* stream, float* partial, size_t partial_floats) {
+                     int pieces, void* stream, float* partial, size_t partial_floats, int b16) {
     EPC_CHECK_ARG(A && B && C, "null pointer");
+    EPC_CHECK_ARG(!b16 || (M >= 64 && N >= 64 && K >= 32), "a bf16 right operand needs every side of the product at least 64 (K at least 32)");
     EPC_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1 && ldc >= N, "bad shape");
     EPC_CHECK_ARG((long)batch * splitk <= 65535, "batch*splitk too large");
     hipStream_t st = (hipStream_t)stream;
@@ -705,6 +732,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         }
     }
     GemmArgs g{A, B, C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, bA, bB, bC, splitk, accumulate, nullptr, partial};
+    g.b16 = b16;
     auto finish = [&]() -> int {
         if (partial) {
             dim3 rgrid((unsigned)(((size_t)M * N / 4 + 255) / 256), batch);
@@ -716,7 +744,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     {   // at most 32 rows, one product, no split: A in LDS, plain f32 (gemm_small_m_kernel)
         const int mm = (M + 7) / 8 * 8;
         const size_t lds = ((size_t)mm * K + (size_t)SM_SLICES * mm * SM_COLS) * sizeof(float);
-        if (M <= SM_MAX_M && batch == 1 && splitk == 1 && lds <= 64 * 1024) {
+        if (M <= SM_MAX_M && batch == 1 && splitk == 1 && lds <= 64 * 1024 && !b16) {
             const dim3 sgrid((N + SM_COLS - 1) / SM_COLS);
             if (mm == 8) hipLaunchKernelGGL(gemm_small_m_kernel<8>, sgrid, dim3(256), lds, st, g);
             else if (mm == 16) hipLaunchKernelGGL(gemm_small_m_kernel<16>, sgrid, dim3(256), lds, st, g);
@@ -758,6 +786,18 @@ extern "C" int epc_gemm_splitk_det(const float* A, const float* B, float* C, con
                      workspace, workspace_floats);
 }
 
+// epc_gemm_splitk_det with the RIGHT operand stored as bf16 (strides and batch stride in elements): the training head's dW5 = cat^T dz5
+// (train_head16.hip keeps dz5 in bf16).  pieces: 1 (A rounded to one bf16 value) or 2 (A in two pieces: the bf16 operand is exact).
+extern "C" int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const float* bias, int M, int N, int K,
+                                       long sAm, long sAk, long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC,
+                                       int splitk, int accumulate, int pieces, float* workspace, size_t workspace_floats,
+                                       void* stream) {
+    EPC_CHECK_ARG(pieces == 1 || pieces == 2, "pieces must be 1 or 2");
+    EPC_CHECK_ARG(workspace || splitk == 1, "null workspace");
+    return gemm_impl(A, reinterpret_cast<const float*>(B16), C, bias, M, N, K, sAm, sAk, sBk, sBn, ldc, batch, bA, bB, bC, splitk,
+                     accumulate, pieces, stream, workspace, workspace_floats, 1);
+}
+
 // ---- y = x W + b together with the batch statistics a training-mode BatchNorm on y needs -------------------------------
 // The GEMM's epilogue leaves, per row tile of `tile_rows` rows (the last one shorter) and column, (S1, S2, p): the sums of
 // (v - p) and (v - p)^2 with p the tile's first-row value.  A tile's own moments are mean_t = p + S1 / n_t and
@@ -766,7 +806,8 @@ extern "C" int epc_gemm_splitk_det(const float* A, const float* B, float* C, con
 template <int COLS, int PARTS>
 __global__ __launch_bounds__(COLS * PARTS) void moments_finalize_kernel(const float* __restrict__ stats, int tiles, int N, int rows,
                                                                         int tile_rows, const float* __restrict__ bias,
-                                                                        float* __restrict__ mean, float* __restrict__ var) {
+                                                                        float* __restrict__ mean, float* __restrict__ var,
+                                                                        int group_rows = 0) {
     // COLS columns per workgroup; thread (column, part) takes tiles part, part + PARTS, ...; the parts meet in LDS in a fixed order:
     // deterministic.  Pooled moments in double precision, two sweeps over the tiles' (sum, sum of squares, pivot):
     //   mean = sum_t (n_t p_t + S1_t) / rows;   M2 = sum_t [ (S2_t - S1_t^2 / n_t) + n_t (p_t + S1_t / n_t - mean)^2 ]
@@ -779,7 +820,12 @@ __global__ __launch_bounds__(COLS * PARTS) void moments_finalize_kernel(const fl
     const int c = blockIdx.x * COLS + cl;
     const bool on = c < N;
     const double inv_full = 1.0 / (double)tile_rows;
-    auto n_of = [&](int t) { return min(tile_rows, rows - t * tile_rows); };
+    // rows of tile t.  group_rows > 0: the tiles never straddle groups of that many rows (a cloud's points: train_head16.hip) -- every
+    // group has ceil(group_rows / tile_rows) tiles, the last one shorter
+    const int tpg = group_rows > 0 ? (group_rows + tile_rows - 1) / tile_rows : 0;
+    auto n_of = [&](int t) {
+        return group_rows > 0 ? min(tile_rows, group_rows - (t % tpg) * tile_rows) : min(tile_rows, rows - t * tile_rows);
+    };
     // a sweep visits the thread's tiles MF_CHUNK at a time with ALL of a chunk's loads in flight at once
     constexpr int MF_CHUNK = 5;
     auto sweep = [&](auto&& f) {
@@ -825,15 +871,15 @@ __global__ __launch_bounds__(COLS * PARTS) void moments_finalize_kernel(const fl
 #define MF_COLS 8
 #define MF_PARTS 64
 static void launch_moments_finalize(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
-                                    float* var, hipStream_t st) {
+                                    float* var, hipStream_t st, int group_rows = 0) {
     hipLaunchKernelGGL((moments_finalize_kernel<MF_COLS, MF_PARTS>), dim3((N + MF_COLS - 1) / MF_COLS), dim3(MF_COLS * MF_PARTS), 0,
-                       st, stats, tiles, N, rows, tile_rows, bias, mean, var);
+                       st, stats, tiles, N, rows, tile_rows, bias, mean, var, group_rows);
 }
 
 // library-internal (conv5_f32.hip: epc_conv5_train_fwd leaves partials in the same (S1, S2, pivot) form)
 int epc_moments_finalize_launch(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
-                                float* var, void* stream) {
-    launch_moments_finalize(stats, tiles, N, rows, tile_rows, bias, mean, var, (hipStream_t)stream);
+                                float* var, void* stream, int group_rows) {
+    launch_moments_finalize(stats, tiles, N, rows, tile_rows, bias, mean, var, (hipStream_t)stream, group_rows);
     return EPC_OK;
 }
 

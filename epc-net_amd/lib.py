@@ -52,6 +52,9 @@ EXPORTS = [
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
     "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_vlad_df_tail_partial_floats", "epc_vlad_df_tail", "epc_bn_apply_bwd_given", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
+    "epc_h16_conv5_fwd_scratch_bytes", "epc_h16_conv5_fwd", "epc_h16_assign_scratch_bytes", "epc_h16_assign",
+    "epc_h16_colgemm_scratch_bytes", "epc_h16_colgemm", "epc_h16_df_tail_scratch_bytes", "epc_h16_df_tail", "epc_h16_bn_bwd_apply",
+    "epc_h16_dx_scratch_bytes", "epc_h16_conv5_dx", "epc_h16_conv5_dw_scratch_bytes", "epc_h16_conv5_dw", "epc_h16_expand", "epc_gemm_splitk_det_b16",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -178,7 +181,7 @@ _lib.epc_gate_fwd.argtypes = [_P, _P, ctypes.c_long, _P, _P]
 _lib.epc_gate_bwd.argtypes = [_P, _P, _P, ctypes.c_long, _P, _P, _P]
 _lib.epc_chain_parts.argtypes = [c_int]
 _lib.epc_chain_stats.argtypes = [_P, c_int, _P, _P]
-_lib.epc_chain_fwd_linear.argtypes = [_P] * 7 + [c_float, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, _P]
+_lib.epc_chain_fwd_linear.argtypes = [_P] * 7 + [c_float, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]
 _lib.epc_chain_fwd_gather.argtypes = [_P] * 7 + [c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]
 _lib.epc_chain_bwd_linear.argtypes = [_P, c_int] + [_P] * 5 + [c_float, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P] + \
     [_P] * 6 + [c_int, c_int, _P]
@@ -199,6 +202,27 @@ _lib.epc_adam_step_dev.argtypes = [_P, _P, _P, _P, c_long, _P, c_float, c_float,
 _lib.epc_ema_update.argtypes = [_P, _P, c_long, c_float, _P, _P]
 _lib.epc_adam_multi.argtypes = [c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P, _P]
 _lib.epc_ema_multi.argtypes = [c_int, _P, _P, _P, _P, c_float, c_float, _P, _P]
+_lib.epc_h16_conv5_fwd_scratch_bytes.restype = c_size_t
+_lib.epc_h16_conv5_fwd_scratch_bytes.argtypes = [c_int]
+_lib.epc_h16_conv5_fwd.argtypes = [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, c_size_t, _P]
+_lib.epc_h16_assign_scratch_bytes.restype = c_size_t
+_lib.epc_h16_assign_scratch_bytes.argtypes = [c_int, c_int, c_int]
+_lib.epc_h16_assign.argtypes = [_P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]
+_lib.epc_h16_colgemm_scratch_bytes.restype = c_size_t
+_lib.epc_h16_colgemm_scratch_bytes.argtypes = [c_int, c_int]
+_lib.epc_h16_colgemm.argtypes = [_P, _P, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_h16_df_tail_scratch_bytes.restype = c_size_t
+_lib.epc_h16_df_tail_scratch_bytes.argtypes = [c_int, c_int]
+_lib.epc_h16_df_tail.argtypes = [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, c_size_t, _P]
+_lib.epc_h16_bn_bwd_apply.argtypes = [_P, _P, _P, _P, _P, _P, c_float, _P, _P, c_int, _P, _P]
+_lib.epc_h16_dx_scratch_bytes.restype = c_size_t
+_lib.epc_h16_dx_scratch_bytes.argtypes = []
+_lib.epc_h16_conv5_dx.argtypes = [_P, _P, c_int, _P, _P, c_size_t, _P]
+_lib.epc_h16_conv5_dw_scratch_bytes.restype = c_size_t
+_lib.epc_h16_conv5_dw_scratch_bytes.argtypes = [c_int]
+_lib.epc_h16_conv5_dw.argtypes = [_P, c_int, _P, c_int, _P, _P, c_size_t, _P]
+_lib.epc_h16_expand.argtypes = [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, _P]
+_lib.epc_gemm_splitk_det_b16.argtypes = _lib.epc_gemm_splitk_det.argtypes
 _lib.epc_profile_create.argtypes = [POINTER(_P)]
 _lib.epc_profile_destroy.argtypes = [_P]
 _lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]

@@ -118,7 +118,18 @@ class _VladBase(PoolingBaseModel):
         if C != 64:
             raise NotImplementedError("cluster_size must be 64 (configs/*.yaml CLUSTER_SIZE)")
         x = reshaped_input.reshape(-1, F)
-        if self.add_batch_norm and self.is_training:
+        if isinstance(x, ops.LazyConv5Features):
+            # conv5 arrives un-evaluated (bf16 training arithmetic): conv5 + l2 norm + :255-291 as ONE node on bf16-stored tensors
+            if not (self.add_batch_norm and self.is_training and F == 1024 and ops.head16_ok(x.shape[0], 256, F, N)):
+                raise NotImplementedError("a lazy conv5 feature map needs the training-mode G_VLAD with add_batch_norm (F = 1024)")
+            from .utils.tf_util import _ema_update
+            beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)
+            vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead16.apply(
+                x.x, x.W, x.b, x.gamma, x.beta, x.eps, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N)
+            x.on_stats(mean5, var5, z5, rn)
+            _ema_update(mm, mean_c, SLIM_DECAY, scheduled=False)
+            _ema_update(mv, var_c, SLIM_DECAY, scheduled=False)
+        elif self.add_batch_norm and self.is_training:
             # :255-263, :272-274, :286-291 as one autograd node (the two gradients of x are one product: ops.VladAssignAggregate)
             from .utils.tf_util import _ema_update
             beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)

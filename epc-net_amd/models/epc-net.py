@@ -74,7 +74,8 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
         # conv1 .. conv4_b and the concat of the four block outputs (:66-134): one fused chain in training (tf_util.proxyconv_backbone)
         x = tf_util.proxyconv_backbone(point_cloud, dpist, k, 4, bn_decay=bn_decay, is_training=is_training)
         # conv5 (:136-139) and the per-point l2_normalize of :147-148 (which the reference applies inside the VLAD scope)
-        net = tf_util.conv1d_l2_normalized(x, 1024, 'conv5', bn_decay=bn_decay, is_training=is_training)
+        net = tf_util.conv1d_l2_normalized(x, 1024, 'conv5', bn_decay=bn_decay, is_training=is_training,
+                                           lazy=not return_features)     # (lazy: only G_VLAD.forward below consumes it)
     with variable_scope('VLAD'):
         NetVLAD = lp.G_VLAD(feature_size=1024, max_samples=num_points, cluster_size=params["CLUSTER_SIZE"],
                             output_dim=params["FEATURE_OUTPUT_DIM"], groups=params["GROUPS"], gating=True,

@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 
 from . import lib as L
+from .lib import EpcNetError
 
 BN_EPS = 1e-3
 
@@ -356,7 +357,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
                 du, sums = lk.du, lk.sums
                 lk.du = lk.sums = None
                 if dy.data_ptr() != du.data_ptr():
-                    raise EpcNetError("conv5's features have a second consumer with a gradient: set ops.FUSE_TAIL_BACKWARD = False")
+                    raise EpcNetError(-1, "conv5's features have a second consumer with a gradient: set ops.FUSE_TAIL_BACKWARD = False")
                 dbeta, dgamma = sums[0], sums[1]
                 dz = du          # in place (out of place measured the same: 2.92 ms)
                 L.check(L.lib().epc_bn_apply_bwd_given(du.data_ptr(), z.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(),
@@ -728,6 +729,11 @@ class ProxyConvChain(torch.autograd.Function):
         stats = lambda: torch.empty(P * 192, dtype=torch.float32, device=dev)
         ptr = lambda t: t.data_ptr() if t is not None else None
         cat = torch.empty((rows, width), dtype=torch.float32, device=dev)
+        # the bf16 head (Conv5VladHead16) reads the concat as bf16: written beside the f32 tensor by the launches that form it
+        cat16 = torch.empty((rows, width), dtype=torch.bfloat16, device=dev) if head16_ok(rows, width, 1024) else None
+        if cat16 is not None:
+            _CAT16.clear()
+            _CAT16[cat.data_ptr()] = cat16
         g = graph
         st0 = stats()
         L.check(lib.epc_chain_stats(z01.data_ptr(), rows, st0.data_ptr(), _st()))
@@ -743,19 +749,20 @@ class ProxyConvChain(torch.autograd.Function):
                                              Wa.data_ptr(), ptr(ba), xm.data_ptr(), d.data_ptr(), za.data_ptr(), st_a.data_ptr(),
                                              int(pieces_fwd), _st()))
             L.check(lib.epc_chain_fwd_linear(za.data_ptr(), st_a.data_ptr(), ptr(ba), ma.data_ptr(), va.data_ptr(), ga.data_ptr(),
-                                             bta.data_ptr(), float(eps), None, None, 0, Wb.data_ptr(), ptr(bb), zb.data_ptr(),
+                                             bta.data_ptr(), float(eps), None, None, 0, None, Wb.data_ptr(), ptr(bb), zb.data_ptr(),
                                              st_b.data_ptr(), rows, int(pieces_fwd), _st()))
             slice_ptr = cat.data_ptr() + 4 * 64 * b
+            slice16 = cat16.data_ptr() + 2 * 64 * b if cat16 is not None else None
             if b + 1 < nblocks:
                 W0n, b0n = blocks[b + 1][0], blocks[b + 1][1]
                 z0n, st0n = new(), stats()
                 L.check(lib.epc_chain_fwd_linear(zb.data_ptr(), st_b.data_ptr(), ptr(bb), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(),
-                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, W0n.data_ptr(),
+                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, slice16, W0n.data_ptr(),
                                                  ptr(b0n), z0n.data_ptr(), st0n.data_ptr(), rows, int(pieces_fwd), _st()))
             else:
                 z0n, st0n, b0n = None, None, None
                 L.check(lib.epc_chain_fwd_linear(zb.data_ptr(), st_b.data_ptr(), ptr(bb), mb.data_ptr(), vb.data_ptr(), gb.data_ptr(),
-                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, None, None, None,
+                                                 btb.data_ptr(), float(eps), xm.data_ptr(), slice_ptr, width, slice16, None, None, None,
                                                  None, rows, int(pieces_fwd), _st()))
             saved += [z0, d, za, zb, m0, v0, ma, va, mb, vb]
             outs += ([z0] if b > 0 else []) + [m0, v0, za, ma, va, zb, mb, vb]      # (block 1's z0 is the input itself)
@@ -1087,6 +1094,150 @@ class VladAssignAggregate(torch.autograd.Function):
                 rhs = torch.cat((dvlad.transpose(1, 2), Wc.t().unsqueeze(0).expand(B, 64, F)), dim=1)   # [dvlad^T ; Wc^T]  (B, 128, F)
                 df = gemm(lhs, rhs, fast=True).view(rows, F)
         return df, dWc, dgamma, dbeta, None, None, None
+
+
+# bf16 copies of concat buffers, by the f32 tensor's address: handed from ProxyConvChain.forward to Conv5VladHead16.forward (the tensors
+# in between are reshaped views).  One entry: the last chain forward's.
+_CAT16 = {}
+
+
+# The head of the bf16 training step on bf16-stored (rows, 1024) tensors (csrc/train_head16.hip): conv5, the per-point l2 norm, the soft
+# assignment and the aggregation as ONE autograd node whose kernels are single streaming passes -- the feature map f is never written.
+# Selected by set_gemm_precision("bf16") (params["TRAIN_PRECISION"] = "bf16") when the call sites hand conv5's operands over un-evaluated
+# (LazyConv5Features: tf_util.conv1d_l2_normalized(..., lazy=True) -> loupe.G_VLAD.forward).
+HEAD16 = True
+
+
+def head16_ok(rows, cin, cout, n_points=None):
+    return (HEAD16 and _GEMM_PRECISION == "bf16" and cin == 256 and cout == 1024 and rows % 32 == 0 and rows * 1024 < (1 << 32)
+            and (n_points is None or (n_points % 32 == 0 and rows % n_points == 0)))
+
+
+class LazyConv5Features:
+    """conv5's operands and BatchNorm variables, handed from tf_util.conv1d_l2_normalized to loupe.G_VLAD.forward so that
+    l2_normalize(relu(batch_norm(x W5 + b5))) (models/epc-net.py:136-148) and the VLAD assignment / aggregation (loupe.py:255-291)
+    run as one node (Conv5VladHead16).  ``on_stats(mean, var, z5, rn)`` is conv5's side of the bookkeeping (moving averages, the
+    mask-tap test hook), called by whoever evaluates the node.  ``shape`` = the feature map's."""
+
+    def __init__(self, x, W, b, gamma, beta, eps, on_stats):
+        self.x, self.W, self.b, self.gamma, self.beta, self.eps, self.on_stats = x, W, b, gamma, beta, float(eps), on_stats
+        self.shape = (int(x.shape[0]), int(W.shape[1]))
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        if shape in ((-1, self.shape[1]), self.shape):
+            return self
+        raise EpcNetError(-1, "conv5's lazy feature map can only be consumed as (rows, 1024) (loupe.G_VLAD.forward)")
+
+
+def _scratch_bytes(nbytes, device):
+    buf = _splitk_ws((int(nbytes) + 3) // 4, device)
+    return buf, buf.numel() * 4
+
+
+class Conv5VladHead16(torch.autograd.Function):
+    """(vlad (B, 1024, 64), a_sum (B, 1, 64), mean5, var5, mean_c, var_c, z5 (bf16), rn) from the backbone's output cat (rows, 256):
+        z5 = cat W5 + b5;  u = relu(batch_norm_train(z5));  f = u rn (tf.nn.l2_normalize over the channels);
+        za = f Wc;  a = softmax(batch_norm_train(za));  vlad[b] = f[b]^T a[b];  a_sum = sum of a over the cloud's points
+    (models/epc-net.py:136-148, loupe.py:255-291) on train_head16.hip: z5, du and dz5 are bf16 tensors, every product rounds its
+    operands to one bf16 value, statistics and accumulators are f32.  The bias gradient in front of a training-mode BatchNorm is
+    exactly zero and is not computed (LinearBatchNormTrain)."""
+
+    @staticmethod
+    def forward(ctx, cat, W5, b5, g5, bt5, eps5, Wc, gc, btc, epsc, n_points):
+        lib = L.lib()
+        cat, W5, Wc = cat.contiguous(), W5.contiguous(), Wc.contiguous()
+        rows = int(cat.shape[0])
+        B = rows // int(n_points)
+        dev = cat.device
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        z5 = torch.empty((rows, 1024), dtype=torch.bfloat16, device=dev)
+        mean5, var5 = f32(1024), f32(1024)
+        cat16 = _CAT16.pop(cat.data_ptr(), None)       # the chain's bf16 copy of this very tensor, when it made one
+        if cat16 is not None and tuple(cat16.shape) != (rows, 256):
+            cat16 = None
+        lhs = cat16 if cat16 is not None else cat
+        sc, n = _scratch_bytes(lib.epc_h16_conv5_fwd_scratch_bytes(rows), dev)
+        L.check(lib.epc_h16_conv5_fwd(lhs.data_ptr(), int(cat16 is not None), W5.data_ptr(), b5.data_ptr(), rows, z5.data_ptr(),
+                                      mean5.data_ptr(), var5.data_ptr(), sc.data_ptr(), n, _st()))
+        za, rn, mean_c, var_c = f32(rows, 64), f32(rows), f32(64), f32(64)
+        sc, n = _scratch_bytes(lib.epc_h16_assign_scratch_bytes(B, n_points, 0), dev)
+        L.check(lib.epc_h16_assign(z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5),
+                                   Wc.data_ptr(), 0, B, int(n_points), za.data_ptr(), rn.data_ptr(), mean_c.data_ptr(),
+                                   var_c.data_ptr(), sc.data_ptr(), n, _st()))
+        a, a_sum = f32(rows, 64), f32(B, 1, 64)
+        parts = _splitk_ws(lib.epc_cloud_colsum64_partial_floats(B), dev)
+        L.check(lib.epc_assign_softmax_fwd(za.data_ptr(), mean_c.data_ptr(), var_c.data_ptr(), gc.data_ptr(), btc.data_ptr(),
+                                           float(epsc), B, int(n_points), a.data_ptr(), a_sum.data_ptr(), parts.data_ptr(),
+                                           parts.numel(), _st()))
+        vlad = f32(B, 1024, 64)
+        sc, n = _scratch_bytes(lib.epc_h16_colgemm_scratch_bytes(B, n_points), dev)
+        L.check(lib.epc_h16_colgemm(z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5),
+                                    a.data_ptr(), rn.data_ptr(), B, int(n_points), 1, vlad.data_ptr(), sc.data_ptr(), n, _st()))
+        ctx.save_for_backward(lhs, W5, z5, mean5, var5, g5, bt5, rn, Wc, za, mean_c, var_c, gc, btc, a)
+        ctx.eps5, ctx.epsc, ctx.n_points = float(eps5), float(epsc), int(n_points)
+        ctx.mark_non_differentiable(mean5, var5, mean_c, var_c, z5, rn)
+        ctx.set_materialize_grads(False)
+        return vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn      # (z5, rn: for the call site's test hooks)
+
+    @staticmethod
+    def backward(ctx, dvlad, dasum, *_unused):
+        lib = L.lib()
+        cat, W5, z5, mean5, var5, g5, bt5, rn, Wc, za, mean_c, var_c, gc, btc, a = ctx.saved_tensors
+        rows = int(cat.shape[0])
+        N = ctx.n_points
+        B = rows // N
+        dev = cat.device
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        if dvlad is None:
+            dvlad = torch.zeros((B, 1024, 64), dtype=torch.float32, device=dev)
+        dvlad = dvlad.contiguous()
+        bn5 = (mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), ctx.eps5)
+        # da = f dvlad[cloud] (the a_sum gradient of every point's cloud is added inside the softmax backward)
+        da = f32(rows, 64)
+        sc, n = _scratch_bytes(lib.epc_h16_assign_scratch_bytes(B, N, 1), dev)
+        L.check(lib.epc_h16_assign(z5.data_ptr(), *bn5, dvlad.data_ptr(), 1, B, N, da.data_ptr(), None, None, None, sc.data_ptr(), n, _st()))
+        dz, dgc, dbtc, trow = f32(rows, 64), f32(64), f32(64), f32(rows)
+        ws, wn = _ws(rows, 64, dev)
+        L.check(lib.epc_assign_softmax_bwd(da.data_ptr(), dasum.contiguous().data_ptr() if dasum is not None else None, a.data_ptr(),
+                                           za.data_ptr(), mean_c.data_ptr(), var_c.data_ptr(), gc.data_ptr(), btc.data_ptr(), ctx.epsc,
+                                           B, N, dz.data_ptr(), dgc.data_ptr(), dbtc.data_ptr(), trow.data_ptr(), ws.data_ptr(), wn, _st()))
+        dWc = f32(1024, 64)
+        sc, n = _scratch_bytes(lib.epc_h16_colgemm_scratch_bytes(B, N), dev)
+        L.check(lib.epc_h16_colgemm(z5.data_ptr(), *bn5, dz.data_ptr(), rn.data_ptr(), B, N, 0, dWc.data_ptr(), sc.data_ptr(), n, _st()))
+        # du = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f trow), the BatchNorm's column sums, then dz5 in place
+        du = torch.empty((rows, 1024), dtype=torch.bfloat16, device=dev)
+        sums = f32(2, 1024)
+        sc, n = _scratch_bytes(lib.epc_h16_df_tail_scratch_bytes(B, N), dev)
+        L.check(lib.epc_h16_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, z5.data_ptr(), rn.data_ptr(),
+                                    trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(), sc.data_ptr(), n, _st()))
+        L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), *bn5, sums[0].data_ptr(), sums[1].data_ptr(), rows, du.data_ptr(),
+                                         _st()))
+        dcat = None
+        if ctx.needs_input_grad[0]:
+            dcat = f32(rows, 256)
+            sc, n = _scratch_bytes(lib.epc_h16_dx_scratch_bytes(), dev)
+            L.check(lib.epc_h16_conv5_dx(du.data_ptr(), W5.data_ptr(), rows, dcat.data_ptr(), sc.data_ptr(), n, _st()))
+        # dW5 = cat^T dz5, row slices added in a fixed order
+        dW5 = f32(256, 1024)
+        sc, n = _scratch_bytes(lib.epc_h16_conv5_dw_scratch_bytes(rows), dev)
+        L.check(lib.epc_h16_conv5_dw(cat.data_ptr(), int(cat.dtype == torch.bfloat16), du.data_ptr(), rows, dW5.data_ptr(), sc.data_ptr(),
+                                     n, _st()))
+        return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None
+
+
+def expand16(z16, bn=None, rn=None):
+    """(rows, 1024) f32 from a bf16 tensor of train_head16.hip: its values, or -- bn = (mean, var, gamma, beta, eps) -- the feature
+    map relu(batch_norm(z5)) rn the fused kernels never write (epc_h16_expand).  Test taps / materialised features."""
+    rows = int(z16.shape[0])
+    y = torch.empty((rows, 1024), dtype=torch.float32, device=z16.device)
+    if bn is None:
+        L.check(L.lib().epc_h16_expand(z16.data_ptr(), None, None, None, None, 0.0, None, rows, y.data_ptr(), _st()))
+    else:
+        mean, var, gamma, beta, eps = bn
+        L.check(L.lib().epc_h16_expand(z16.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                       rn.data_ptr() if rn is not None else None, rows, y.data_ptr(), _st()))
+    return y
 
 
 class GateMul(torch.autograd.Function):

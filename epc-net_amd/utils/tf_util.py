@@ -205,6 +205,10 @@ def _bn_train_fused(inputs2d, w2d, b, scope_bn, bn_decay, relu_flag, rownorm=Fal
 # Test hook (tests/test_gpu_train_step.py, mask-pinned gradient parity): when a dict, every ReLU'd layer records the boolean
 # mask `output > 0` of its (rows, C) activations under its full variable scope.  Never set by product code; eager steps only.
 RELU_MASK_TAPS = None
+# Test hook of the same kind for VALUES (tests/test_gpu_train_step.py, the bf16 step): when a dict, every layer whose pre-activation
+# is a rounding point of the bf16 arithmetic records it (as f32) under its scope, so that the float64 oracle can continue from the
+# values the HIP path actually stored instead of from its own (which round differently near a bf16 boundary).  Eager steps only.
+VALUE_TAPS = None
 
 
 def _tap_relu_mask(y) -> None:
@@ -360,17 +364,23 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
             _ema_update(ev, var, decay)
             if RELU_MASK_TAPS is not None:      # (test hook: the layer's activation is not materialised by the fused node)
                 _tap_relu_mask(ops.bn_apply_train(z, mean, var, gamma, beta, 1e-3, True))
+            if VALUE_TAPS is not None:
+                from ..variables import current_scope
+                VALUE_TAPS[current_scope()] = z.detach().clone()
     assert at == len(rest)
     global BACKBONE_TAP
     BACKBONE_TAP = cat.reshape(B, N, 64 * nblocks)
     return BACKBONE_TAP
 
 
-def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None):
+def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_training=None, lazy=False):
     """conv1d(kernel 1, bn=True, relu) followed by tf.nn.l2_normalize over the channels of every point -- the pair
     models/epc-net.py:136-148 applies to conv5's output -- returned as (B*L, C).  Not a function of the reference's
     tf_util: a fusion point.  In training the BatchNorm apply, the ReLU and the row norm are one pass over the
-    (rows, 1024) activations (ops.BatchNormReluRowNorm) and the un-normalised map is never written."""
+    (rows, 1024) activations (ops.BatchNormReluRowNorm) and the un-normalised map is never written.
+    ``lazy``: the caller hands the result to loupe.G_VLAD.forward and nowhere else -- in the bf16 training arithmetic the layer is
+    then NOT evaluated here: an ops.LazyConv5Features carries its operands into the VLAD node (ops.Conv5VladHead16), which never
+    writes the feature map at all."""
     from .. import ops
     cin = int(inputs.shape[-1])
     if not (is_training and num_output_channels == 1024):
@@ -381,6 +391,21 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     w, b, _ = declare_conv1d(scope, cin, num_output_channels, 1, True, 1e-3, True)
     with variable_scope(scope):
         x2 = inputs.reshape(-1, cin)
+        if lazy and ops.head16_ok(int(x2.shape[0]), cin, num_output_channels):
+            from ..variables import current_scope
+            beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
+            decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+            here = current_scope()
+
+            def on_stats(mean, var, z5, rn):
+                _ema_update(ema_mean, mean, decay)
+                _ema_update(ema_var, var, decay)
+                if RELU_MASK_TAPS is not None:      # (test hook: the feature map is never written -- expand it from z5)
+                    RELU_MASK_TAPS[here] = ops.expand16(z5, (mean, var, gamma, beta, 1e-3), None) > 0
+                if VALUE_TAPS is not None:
+                    VALUE_TAPS[here] = ops.expand16(z5)
+
+            return ops.LazyConv5Features(x2, w.reshape(cin, num_output_channels), b, gamma, beta, 1e-3, on_stats)
         if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
             f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True,
                                 f16x3=ops.F16X3_CONV5,      # conv5: BatchNorm'd block outputs against its weights

@@ -526,12 +526,15 @@ int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, floa
 int epc_chain_parts(int rows);
 /* moment partials of z (rows, 64) as it stands (the first block's z0 = conv1's output, models/epc-net.py:66) */
 int epc_chain_stats(const float* z, int rows, float* stats, void* stream);
-/* a = relu(bn(zin)) (+ resid); a -> a_out (row stride a_stride; NULL: not written); W != NULL: z_out = a W + bias, stats_out = its
- * moment partials.  in_stats != NULL: the BatchNorm's batch moments are pooled from it (+ in_bias) and written to in_mean / in_var;
- * NULL: in_mean / in_var are read.  conv_b of a block (:78-79); a block's tail + the next block's leading conv (:81-83). */
+/* a = relu(bn(zin)) (+ resid); a -> a_out (row stride a_stride; NULL: not written) and, a_out_bf16 != NULL, the same values rounded
+ * to bf16 at the same element stride (the concat buffer as the bf16 head's left operand: epc_h16_conv5_fwd / _dw); W != NULL:
+ * z_out = a W + bias, stats_out = its moment partials.  in_stats != NULL: the BatchNorm's batch moments are pooled from it (+ in_bias)
+ * and written to in_mean / in_var; NULL: in_mean / in_var are read.  conv_b of a block (:78-79); a block's tail + the next block's
+ * leading conv (:81-83). */
 int epc_chain_fwd_linear(const float* zin, const float* in_stats, const float* in_bias, float* in_mean, float* in_var,
                          const float* in_gamma, const float* in_beta, float eps, const float* resid, float* a_out, int a_stride,
-                         const float* W, const float* bias, float* z_out, float* stats_out, int rows, int pieces, void* stream);
+                         void* a_out_bf16, const float* W, const float* bias, float* z_out, float* stats_out, int rows, int pieces,
+                         void* stream);
 /* models/epc-net.py:70-76: x = relu(bn(z0)) formed as the rows are gathered; xm = mask x / knn over the kNN lists of
  * epc_knn_topk (int32, cap slots; rows with cnt > cap take the exact scan); d = xm - x; z_out = d W + bias + moment partials. */
 int epc_chain_fwd_gather(const float* z0, const float* in_stats, const float* in_bias, float* in_mean, float* in_var,
@@ -588,6 +591,61 @@ int epc_vlad_df_tail(const float* a, const float* dz, const float* dvlad, const 
  * are known (utils/tf_util.py:454-519 seen from the gradient side); dy carries its ReLU mask already; dz may be dy. */
 int epc_bn_apply_bwd_given(const float* dy, const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                            const float* dbeta, const float* dgamma, float eps, int rows, int C, float* dz, void* stream);
+
+/* ---- The head of the training step on bf16-stored tensors (csrc/train_head16.hip) -------------------------------------------------
+ * conv5 + per-point l2 norm + VLAD soft assignment + aggregation (models/epc-net.py:136-148, loupe.py:249-291 in training mode),
+ * forward and backward, for params["TRAIN_PRECISION"] = "bf16" (BASELINE.json configs[2]): the (rows, 1024) tensors -- conv5's
+ * pre-activation z5, the gradient du of its BatchNorm output, dz5 -- are bf16 in HBM (`void*` below: rows x 1024 x 2 bytes, row-major,
+ * 16-byte aligned); accumulators, batch statistics, column sums, rn and every (rows, 64) tensor are f32; every product rounds each
+ * operand to ONE bf16 value.  The feature map f = l2_normalize(relu(batch_norm(z5))) is never written: BatchNorm + ReLU are applied to
+ * z5 as it is loaded (mean5 .. beta5, eps = conv5's BatchNorm with its BATCH moments), the row factor rn in the epilogue or on the
+ * other operand.  rows = num_clouds * n_points, n_points a multiple of 32, rows * 1024 < 2^32.  scratch: caller-owned, 16-byte aligned,
+ * of the size the matching *_scratch_bytes function returns; deterministic (fixed summation orders, no atomics).
+ *
+ * epc_h16_conv5_fwd: z5 = bf16(cat W5 + b5) (cat: (rows, 256) f32, or bf16 when cat_is_bf16; W5 (256, 1024), b5 (1024) f32) and the batch
+ *   mean / population variance of conv5 (utils/tf_util.py:472-476) from the f32 accumulators.
+ * epc_h16_assign: out (rows, 64) = rn (u B), u = relu(bn(z5)), rn = rsqrt(max(sum_c u^2, 1e-12)) (tf.nn.l2_normalize, :147-148).
+ *   per_cloud_operand = 0: B = cluster_weights (1024, 64): the assignment's logits (loupe.py:255); rn_out (rows) and the batch moments
+ *   mean_out / var_out (64 each; slim.batch_norm's, :257-263) are written when not NULL.  per_cloud_operand = 1: B = dvlad
+ *   (num_clouds, 1024, 64): da = f dvlad[cloud], the assignment's gradient through the aggregation.
+ * epc_h16_colgemm: out = u^T (rn C), C (rows, 64) f32.  per_cloud = 1: out (num_clouds, 1024, 64) = f[b]^T C[b] -- the aggregation
+ *   vlad = f^T a (loupe.py:286-291); per_cloud = 0: out (1024, 64) over all rows -- dWc = f^T dz.
+ * epc_h16_df_tail: epc_vlad_df_tail on these tensors: du (rows, 1024) bf16 = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f trow) and
+ *   dbeta_dgamma (2, 1024) = (sum du, sum du zhat) from the f32 values.
+ * epc_h16_bn_bwd_apply: dz5 = gamma rstd (du - dbeta / rows - zhat dgamma / rows), bf16 in, bf16 out; dz5 may be du.
+ * epc_h16_conv5_dx: dcat (rows, 256) f32 = dz5 W5^T.
+ * epc_h16_conv5_dw: dW5 (256, 1024) f32 = cat^T dz5 (cat f32 or bf16), row slices added in a fixed order.
+ * epc_h16_expand: y (rows, 1024) f32 = the bf16 values (mean5 NULL) or relu(bn(z5)) rn (rn NULL: no row factor): the feature map
+ *   for callers that need it materialised (the distillation variants' second output, models/kd_epc-net.py:158) and for tests. */
+size_t epc_h16_conv5_fwd_scratch_bytes(int rows);
+int epc_h16_conv5_fwd(const void* cat, int cat_is_bf16, const float* W5, const float* b5, int rows, void* z5, float* mean, float* var,
+                      void* scratch, size_t scratch_bytes, void* stream);
+size_t epc_h16_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand);
+int epc_h16_assign(const void* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                   const float* B, int per_cloud_operand, int num_clouds, int n_points, float* out, float* rn_out, float* mean_out,
+                   float* var_out, void* scratch, size_t scratch_bytes, void* stream);
+size_t epc_h16_colgemm_scratch_bytes(int num_clouds, int n_points);
+int epc_h16_colgemm(const void* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                    const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
+                    size_t scratch_bytes, void* stream);
+size_t epc_h16_df_tail_scratch_bytes(int num_clouds, int n_points);
+int epc_h16_df_tail(const float* a, const float* dz, const float* dvlad, const float* Wc, int num_clouds, int n_points, const void* z5,
+                    const float* rn, const float* trow, const float* mean5, const float* var5, const float* gamma5, const float* beta5,
+                    float eps, void* du, float* dbeta_dgamma, void* scratch, size_t scratch_bytes, void* stream);
+int epc_h16_bn_bwd_apply(const void* du, const void* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5,
+                         float eps, const float* dbeta, const float* dgamma, int rows, void* dz5, void* stream);
+size_t epc_h16_dx_scratch_bytes(void);
+int epc_h16_conv5_dx(const void* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream);
+size_t epc_h16_conv5_dw_scratch_bytes(int rows);
+int epc_h16_conv5_dw(const void* cat, int cat_is_bf16, const void* dz5, int rows, float* dW5, void* scratch, size_t scratch_bytes,
+                     void* stream);
+int epc_h16_expand(const void* z, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                   const float* rn, int rows, float* y, void* stream);
+/* epc_gemm_splitk_det with the RIGHT operand stored as bf16 (strides and batch stride in elements; every side of the product at least
+ * 64, K at least 32).  pieces: 1 = A rounded to one bf16 value, 2 = A in two bf16 pieces (the bf16 operand is exact either way). */
+int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
+                            long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate, int pieces,
+                            float* workspace, size_t workspace_floats, void* stream);
 
 /* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
  * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials

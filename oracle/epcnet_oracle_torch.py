@@ -76,6 +76,88 @@ class _RoundedMatmul(torch.autograd.Function):
         return dA, dB
 
 
+class _Head16(torch.autograd.Function):
+    """conv5 + per-point l2 norm + VLAD soft assignment + aggregation (models/epc-net.py:136-148, loupe.py:255-291, training mode) with
+    the ROUNDING POINTS of the bf16-stored head of the HIP step (epc-net_amd/csrc/train_head16.hip), forward and backward written out:
+
+      forward   zacc = r(cat) r(W5) [f32 accumulators: exact here];  moments of conv5 from zacc (+ b5);  z5 = r(zacc + b5) [stored];
+                u = relu(z5 s5 + t5);  rn = rsqrt(max(sum_c u^2, 1e-12));  za = rn (r(u) r(Wc));  a = softmax(bn(za));
+                vlad[b] = r(u)[b]^T r(rn a)[b];  a_sum[b] = sum_n a[b]
+      backward  da = rn (r(u) r(dvlad[b]));  softmax / BatchNorm backward in exact arithmetic -> dz;  t = sum_k a da + sum_k dz za;
+                dWc = r(u)^T r(rn dz);  df = r([a | dz]) r([dvlad[b]^T ; Wc^T]);  f = u rn;  du = [f > 0] (rn df - (rn t) f);
+                dbeta5 = sum du, dgamma5 = sum du zhat5 [from the unrounded du];  dz5 = r(gamma5 rstd5 (r(du) - dbeta5 / R - zhat5 dgamma5 / R));
+                dcat = dz5 r(W5)^T;  dW5 = r(cat)^T dz5;  db5 = 0 (a bias in front of a training-mode BatchNorm)
+
+    r = round to bf16 (``rounding``) or the identity -- with the identity this is the exact function, and tests/test_oracle_cpu.py holds
+    the hand-written backward to autograd's of the plain composition.  ``mask``: conv5's ReLU mask pinned (TorchOracle.relu_masks);
+    ``z5_pin``: the stored z5 of the implementation under test, continued from instead of this function's own (TorchOracle.value_pins).
+    Returns (vlad (B, 1024, 64), a_sum (B, 1, 64), mean5, var5, mean_c, var_c, z5, u); only the first two are differentiable."""
+
+    @staticmethod
+    def forward(ctx, cat, W5, b5, g5, bt5, Wc, gc, btc, n_points, rounding, mask, z5_pin, eps):
+        r = _round_bf16 if rounding else (lambda t: t)
+        R = cat.shape[0]
+        B = R // n_points
+        cat_r, W5_r, Wc_r = r(cat), r(W5), r(Wc)
+        zacc = cat_r @ W5_r
+        mean5 = zacc.mean(0) + b5
+        var5 = ((zacc - zacc.mean(0)) ** 2).mean(0)
+        z5 = r(zacc + b5)
+        if z5_pin is not None:
+            z5 = z5_pin
+        rs5 = torch.rsqrt(var5 + eps)
+        s5 = g5 * rs5
+        pre = z5 * s5 + (bt5 - mean5 * s5)
+        m5 = (pre > 0) if mask is None else mask
+        u = pre * m5.to(pre.dtype)
+        rn = torch.rsqrt(torch.clamp((u * u).sum(1), min=O.L2_EPS))
+        u_r = r(u)
+        za = rn[:, None] * (u_r @ Wc_r)
+        mean_c = za.mean(0)
+        var_c = ((za - mean_c) ** 2).mean(0)
+        rs_c = torch.rsqrt(var_c + eps)
+        a = torch.softmax((za - mean_c) * (rs_c * gc) + btc, dim=1)
+        a3 = a.reshape(B, n_points, 64)
+        vlad = torch.matmul(u_r.reshape(B, n_points, -1).transpose(1, 2), r(rn[:, None] * a).reshape(B, n_points, 64))
+        a_sum = a3.sum(1, keepdim=True)
+        ctx.save_for_backward(cat_r, W5_r, Wc_r, z5, mean5, rs5, g5, m5, u, u_r, rn, za, mean_c, rs_c, gc, a)
+        ctx.n_points, ctx.r = n_points, r
+        ctx.mark_non_differentiable(mean5, var5, mean_c, var_c, z5, u)
+        return vlad, a_sum, mean5, var5, mean_c, var_c, z5, u
+
+    @staticmethod
+    def backward(ctx, dvlad, dasum, *_unused):
+        cat_r, W5_r, Wc_r, z5, mean5, rs5, g5, m5, u, u_r, rn, za, mean_c, rs_c, gc, a = ctx.saved_tensors
+        r, N = ctx.r, ctx.n_points
+        R = cat_r.shape[0]
+        B = R // N
+        if dvlad is None:
+            dvlad = torch.zeros((B, 1024, 64), dtype=cat_r.dtype)
+        dv_r = r(dvlad)
+        da = rn[:, None] * torch.matmul(u_r.reshape(B, N, -1), dv_r).reshape(R, 64)
+        dy = da if dasum is None else da + dasum.reshape(B, 1, 64).expand(B, N, 64).reshape(R, 64)
+        dpre = a * (dy - (dy * a).sum(1, keepdim=True))
+        zhat_c = (za - mean_c) * rs_c
+        dbtc = dpre.sum(0)
+        dgc = (dpre * zhat_c).sum(0)
+        dz = gc * rs_c * (dpre - dbtc / R - zhat_c * dgc / R)
+        trow = (a * da).sum(1) + (dz * za).sum(1)
+        dWc = u_r.t() @ r(rn[:, None] * dz)
+        lhs = r(torch.cat((a, dz), dim=1)).reshape(B, N, 128)
+        rhs = torch.cat((dv_r.transpose(1, 2), Wc_r.t().unsqueeze(0).expand(B, 64, Wc_r.shape[0])), dim=1)
+        df = torch.matmul(lhs, rhs).reshape(R, -1)
+        f = u * rn[:, None]
+        rt = torch.where(rn >= 0.99e6, torch.zeros_like(rn), rn * trow)          # (the clamped zero row: no projection term)
+        du = (rn[:, None] * df - rt[:, None] * f) * m5.to(df.dtype)
+        zhat5 = (z5 - mean5) * rs5
+        dbt5 = du.sum(0)
+        dg5 = (du * zhat5).sum(0)
+        dz5 = r(g5 * rs5 * (r(du) - dbt5 / R - zhat5 * dg5 / R))
+        dcat = dz5 @ W5_r.t()
+        dW5 = cat_r.t() @ dz5
+        return dcat, dW5, torch.zeros_like(mean5), dg5, dbt5, dWc, dgc, dbtc, None, None, None, None, None
+
+
 class TorchOracle:
     def __init__(self, weights: Dict[str, np.ndarray], arch="epc-net", params=None, dtype=torch.float64,
                  outer="query_triplets"):
@@ -97,8 +179,16 @@ class TorchOracle:
         # chosen otherwise.
         self.relu_masks: Optional[Dict[str, np.ndarray]] = None
         self.relu_mask_disagreement: Dict[str, int] = {}
-        # "bf16": every dense product rounds its operands to bf16 where the HIP step's bf16 arithmetic does (_RoundedMatmul)
+        # "bf16": every dense product rounds its operands to bf16 where the HIP step's bf16 arithmetic does (_RoundedMatmul), and
+        # EPC-Net's head -- conv5 to the VLAD aggregation -- has the rounding points of the bf16-STORED head (_Head16)
         self.gemm_rounding: Optional[str] = None
+        # Value pinning (tests/test_gpu_train_step.py, the bf16 step): {scope: array of the layer's pre-activation as the HIP step
+        # stored it}.  A layer named here continues from that value (its own result's gradient path kept: z + (pin - z).detach()) -- the
+        # two implementations then round the SAME numbers at every later rounding point, and what is left between their gradients is
+        # the arithmetic of each layer, not the compounded drift of twelve normalised layers.  ``value_pin_gap`` records, per layer,
+        # max |pin - z| / max |z|: a forward bug shows up there.
+        self.value_pins: Optional[Dict[str, np.ndarray]] = None
+        self.value_pin_gap: Dict[str, float] = {}
 
     def _mm(self, A, B):
         """A (rows, K) @ B (K, N) (or batched 3-D @ 3-D) in the step's GEMM arithmetic."""
@@ -130,7 +220,15 @@ class TorchOracle:
         W = self.w[scope + "/weights"]
         z = self._mm(x.reshape(-1, x.shape[-1]), W.reshape(W.shape[-2], W.shape[-1])).reshape(
             tuple(x.shape[:-1]) + (W.shape[-1],)) + self.w[scope + "/biases"]
+        z = self._pin(z, scope)
         return self._relu(self._tfutil_bn(z, scope, (0, 1), training, bn_decay), scope)
+
+    def _pin(self, z, scope):
+        if self.value_pins is None or scope not in self.value_pins:
+            return z
+        pin = torch.as_tensor(np.asarray(self.value_pins[scope], dtype=np.float64).reshape(tuple(z.shape)), dtype=z.dtype)
+        self.value_pin_gap[scope] = float((pin - z.detach()).abs().max() / z.detach().abs().max().clamp(min=1e-30))
+        return z + (pin - z).detach()
 
     def _slim_bn(self, x, scope, training, fused):
         g, b = self.w[scope + "/gamma"], self.w[scope + "/beta"]
@@ -144,6 +242,38 @@ class TorchOracle:
                 self.new_stats[scope + "/moving_variance"] = mv - (mv - var_upd) * (1 - O.SLIM_DECAY)
             return y
         return _bn_infer(x, g, b, mm, mv)
+
+    def _head16(self, cat, n_points, bn_decay):
+        """conv5 .. the VLAD aggregation in the bf16-stored arithmetic (_Head16), with the moving-average updates of the two
+        BatchNorms (tf_util's scheduled decay for conv5, slim's 0.999 with the population variance for cluster_bn)."""
+        sc = "fastdgcnn/conv5"
+        W5 = self.w[sc + "/weights"]
+        mask = None
+        if self.relu_masks is not None and sc in self.relu_masks:
+            mask = torch.as_tensor(np.asarray(self.relu_masks[sc]).reshape(-1, 1024), dtype=torch.bool)
+        pin = None
+        if self.value_pins is not None and sc in self.value_pins:
+            pin = torch.as_tensor(np.asarray(self.value_pins[sc], dtype=np.float64).reshape(-1, 1024), dtype=cat.dtype)
+            with torch.no_grad():     # (this layer's own stored value, from the pinned input: what the pin replaces)
+                own = _round_bf16(_round_bf16(cat) @ _round_bf16(W5.reshape(W5.shape[-2], W5.shape[-1])) + self.w[sc + "/biases"])
+                self.value_pin_gap[sc] = float((pin - own).abs().max() / own.abs().max().clamp(min=1e-30))
+        vlad, a_sum, mean5, var5, mean_c, var_c, z5, u = _Head16.apply(
+            cat, W5.reshape(W5.shape[-2], W5.shape[-1]), self.w[sc + "/biases"], self.w[sc + "/bn/gamma"], self.w[sc + "/bn/beta"],
+            self.w["VLAD/cluster_weights"], self.w["VLAD/cluster_bn/gamma"], self.w["VLAD/cluster_bn/beta"], n_points, True, mask, pin,
+            O.BN_EPS)
+        if mask is not None:
+            rs5 = torch.rsqrt(var5 + O.BN_EPS) * self.w[sc + "/bn/gamma"].detach()
+            pre = z5 * rs5 + (self.w[sc + "/bn/beta"].detach() - mean5 * rs5)
+            self.relu_mask_disagreement[sc] = int(((pre > 0) != mask).sum())
+        decay = 0.9 if bn_decay is None else bn_decay
+        mname, vname = O.ema_names(sc, self.outer)
+        with torch.no_grad():
+            self.new_stats[mname] = self.w[mname] - (1 - decay) * (self.w[mname] - mean5)
+            self.new_stats[vname] = self.w[vname] - (1 - decay) * (self.w[vname] - var5)
+            cm, cv = self.w["VLAD/cluster_bn/moving_mean"], self.w["VLAD/cluster_bn/moving_variance"]
+            self.new_stats["VLAD/cluster_bn/moving_mean"] = cm - (cm - mean_c) * (1 - O.SLIM_DECAY)
+            self.new_stats["VLAD/cluster_bn/moving_variance"] = cv - (cv - var_c) * (1 - O.SLIM_DECAY)
+        return vlad, a_sum
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward(self, point_cloud: np.ndarray, is_training: bool, bn_decay: Optional[float] = None,
@@ -168,17 +298,24 @@ class TorchOracle:
             t = self.conv1d(t, "fastdgcnn/conv%d_b" % b, tr, bd)
             inp = t + xm
             outs.append(inp)
-        x = self.conv1d(torch.cat(outs, dim=-1), "fastdgcnn/conv5", tr, bd)
-        features = _l2n(x.reshape(-1, 1024), 1) if return_features else None
+        head16 = self.arch == "epc-net" and self.gemm_rounding == "bf16" and tr and not return_features
+        if head16:
+            vlad, a_sum = self._head16(torch.cat(outs, dim=-1).reshape(-1, 256), N, bd)
+            features = None
+        else:
+            x = self.conv1d(torch.cat(outs, dim=-1), "fastdgcnn/conv5", tr, bd)
+            features = _l2n(x.reshape(-1, 1024), 1) if return_features else None
         if self.arch == "epc-net":
             G = self.p["GROUPS"]
-            f = _l2n(x.reshape(-1, 1024), 1)
-            act = self._mm(f, self.w["VLAD/cluster_weights"])
-            act = torch.softmax(self._slim_bn(act, "VLAD/cluster_bn", tr, fused=False), dim=1).reshape(-1, N, 64)
-            a_sum = act.sum(dim=-2, keepdim=True)
+            if not head16:
+                f = _l2n(x.reshape(-1, 1024), 1)
+                act = self._mm(f, self.w["VLAD/cluster_weights"])
+                act = torch.softmax(self._slim_bn(act, "VLAD/cluster_bn", tr, fused=False), dim=1).reshape(-1, N, 64)
+                a_sum = act.sum(dim=-2, keepdim=True)
+                # (the HIP step forms vlad[b] = f[b]^T @ act[b] directly: the product whose shape the rounding rule sees)
+                vlad = self._mm(f.reshape(-1, N, 1024).transpose(1, 2), act)
             a = a_sum * self.w["VLAD/cluster_weights2"]
-            # (the HIP step forms vlad[b] = f[b]^T @ act[b] directly: the product whose shape the rounding rule sees)
-            vlad = self._mm(f.reshape(-1, N, 1024).transpose(1, 2), act) - a
+            vlad = vlad - a
             vlad = _l2n(vlad, 1).reshape(-1, 64 * 1024)
             vlad = _l2n(vlad, 1)
             y = self._mm(vlad.reshape(-1, 65536 // G), self.w["VLAD/hidden1_weights"])
@@ -204,7 +341,8 @@ def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
 def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, other_neg, step: int, epoch: int,
                adam_m: Optional[Dict[str, np.ndarray]] = None, adam_v: Optional[Dict[str, np.ndarray]] = None,
                arch="epc-net", params=None, m1=0.5, m2=0.2, base_lr=5e-5, batch_num_queries=1, dtype=torch.float64,
-               relu_masks: Optional[Dict[str, np.ndarray]] = None, gemm_rounding: Optional[str] = None):
+               relu_masks: Optional[Dict[str, np.ndarray]] = None, gemm_rounding: Optional[str] = None,
+               value_pins: Optional[Dict[str, np.ndarray]] = None):
     """One reference training step (train.py:251-277, 484-495): returns dict(loss, grads, new_weights, adam_m, adam_v).
 
     ``step`` = value of the global-step variable BEFORE the step (``batch``, train.py:246): bn_decay is evaluated with
@@ -212,6 +350,7 @@ def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, othe
     orc = TorchOracle(weights, arch, params, dtype)
     orc.relu_masks = relu_masks        # None = the reference's relu; a dict pins the masks (see TorchOracle.__init__)
     orc.gemm_rounding = gemm_rounding  # None = exact products; "bf16" = the configs[2] arithmetic (TorchOracle.__init__)
+    orc.value_pins = value_pins        # None, or the stored pre-activations of the implementation under test (TorchOracle.__init__)
     vecs = np.concatenate([query, positives, negatives, other_neg], axis=1)          # train.py:252
     bn_decay = O.get_bn_decay(step, batch_num_queries)
     out = orc.forward(vecs, True, bn_decay)
@@ -237,7 +376,7 @@ def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, othe
         new_w[k] = v.numpy().copy()
     return {"loss": float(loss.detach()), "grads": g_out, "new_weights": new_w, "adam_m": am, "adam_v": av,
             "lr": lr, "bn_decay": bn_decay, "descriptors": out.detach().numpy(),
-            "relu_mask_disagreement": dict(orc.relu_mask_disagreement)}
+            "relu_mask_disagreement": dict(orc.relu_mask_disagreement), "value_pin_gap": dict(orc.value_pin_gap)}
 
 
 def distill_step(teacher_weights: Dict[str, np.ndarray], student_weights: Dict[str, np.ndarray], query, positives, negatives,

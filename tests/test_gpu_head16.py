@@ -1,0 +1,144 @@
+"""GPU tests of the bf16-stored head of the training step (epc-net_amd/csrc/train_head16.hip through ops.Conv5VladHead16 and the C ABI)
+against the float64 restatement with the same rounding points (oracle/epcnet_oracle_torch.py: _Head16; held to autograd's gradients of
+the plain graph in tests/test_oracle_cpu.py).  models/epc-net.py:136-148, loupe.py:255-291 in training mode."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _inputs(B, N, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    R = B * N
+    leaves = dict(cat=rnd(R, 256), W5=rnd(256, 1024) * 0.08, b5=rnd(1024) * 0.1, g5=1 + 0.2 * rnd(1024), bt5=0.3 * rnd(1024),
+                  Wc=rnd(1024, 64) * 0.2, gc=1 + 0.2 * rnd(64), btc=0.3 * rnd(64))
+    cot = (rnd(B, 1024, 64), rnd(B, 1, 64))
+    return leaves, cot
+
+
+def _bf16(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+@pytest.mark.parametrize("B,N", [(3, 96), (5, 32), (18, 256), (2, 1024), (4, 4096)])
+def test_head16_node_matches_the_rounded_restatement(dev, B, N):
+    import epcnet_oracle_torch as T
+    ops = H.pkg("ops")
+    leaves, (wv, wa) = _inputs(B, N, 11 + N, dev)
+    names = list(leaves)
+    prev = ops.set_gemm_precision("bf16")
+    try:
+        xs = [leaves[k].float().to(dev).requires_grad_(True) for k in names]
+        vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead16.apply(xs[0], xs[1], xs[2], xs[3], xs[4], EPS, xs[5], xs[6],
+                                                                                    xs[7], EPS, N)
+        loss = (vlad * wv.float().to(dev)).sum() + (a_sum * wa.float().to(dev)).sum()
+        grads = torch.autograd.grad(loss, xs, allow_unused=True)
+        z5f = ops.expand16(z5).double().cpu()
+        mask = (ops.expand16(z5, (mean5, var5, xs[3].detach(), xs[4].detach(), EPS), None) > 0).cpu()
+        # the same call again: bit-identical results (fixed summation orders, no atomics)
+        d_ = [x.detach() for x in xs]
+        again = ops.Conv5VladHead16.apply(d_[0], d_[1], d_[2], d_[3], d_[4], EPS, d_[5], d_[6], d_[7], EPS, N)
+        assert torch.equal(again[0], vlad) and torch.equal(again[6], z5)
+    finally:
+        ops.set_gemm_precision(prev)
+    torch.cuda.synchronize()
+    assert z5.dtype == torch.bfloat16 and tuple(z5.shape) == (B * N, 1024)
+
+    def oracle(pin, msk):
+        ys = [leaves[k].clone().requires_grad_(True) for k in names]
+        out = T._Head16.apply(*ys, N, True, msk, pin, EPS)
+        g = torch.autograd.grad((out[0] * wv).sum() + (out[1] * wa).sum(), ys, allow_unused=True)
+        return out, g
+
+    # 1. the stored z5 against the restatement's own: the same bf16 value except where the f32 accumulation order moved a sum across a
+    #    rounding boundary (one bf16 ulp there)
+    free, _ = oracle(None, None)
+    z_ref = free[6]
+    d = (z5f - z_ref).abs()
+    assert float((d > 0).double().mean()) <= 2e-3, "z5 differs from the restatement's in %.2e of the elements" % float((d > 0).double().mean())
+    # (one bf16 ulp; the absolute term: a sum that cancels to ~1e-6 carries the f32 accumulation's own error, many of ITS ulps)
+    assert bool((d <= 2.0 ** -7 * z_ref.abs() + 2e-5).all()), float((d - 2.0 ** -7 * z_ref.abs()).max())
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    assert rel(mean5, free[2]) <= 5e-6 and rel(var5, free[3]) <= 5e-5, (rel(mean5, free[2]), rel(var5, free[3]))
+    # 2. continued from the stored z5 and the forward's masks: outputs, statistics, every gradient
+    pinned, g_ref = oracle(z5f, mask)
+    u = pinned[7]
+    rn_ref = torch.rsqrt(torch.clamp((u * u).sum(1), min=1e-12))
+    fwd = dict(vlad=rel(vlad.detach(), pinned[0]), a_sum=rel(a_sum.detach(), pinned[1]), mean_c=rel(mean_c, pinned[4]),
+               var_c=rel(var_c, pinned[5]), rn=rel(rn, rn_ref))
+    print("head16 %dx%d forward vs the rounded restatement (max error / max magnitude): %s" % (
+        B, N, ", ".join("%s %.1e" % kv for kv in fwd.items())))
+    # (an operand u that sits on a bf16 rounding boundary may round the other way: 2^-9 of single products)
+    assert fwd["vlad"] <= 1e-3 and fwd["a_sum"] <= 1e-3 and fwd["mean_c"] <= 1e-3 and fwd["var_c"] <= 1e-3 and fwd["rn"] <= 1e-5, fwd
+    worst = (0.0, "")
+    for k, g, gr in zip(names, grads, g_ref):
+        if k == "b5":
+            assert g is None                          # exactly zero in front of a training-mode BatchNorm: not computed
+            continue
+        e = float((g.double().cpu() - gr).norm() / gr.norm().clamp(min=1e-30))
+        worst = max(worst, (e, k))
+    print("head16 %dx%d: worst gradient relative L2 error vs the rounded restatement %.2e (%s)" % (B, N, worst[0], worst[1]))
+    # (what is left: f32 accumulation order, and du / dz5 elements that round the other way -- 2^-9 of single elements)
+    assert worst[0] <= 3e-3, worst
+
+
+def test_gemm_b16_entry(dev):
+    """epc_gemm_splitk_det_b16: C = A^T B with B stored as bf16 (dW5 = cat^T dz5's shape), slices added in a fixed order."""
+    L, ops = H.pkg("lib"), H.pkg("ops")
+    g = torch.Generator().manual_seed(3)
+    R = 4608
+    A = torch.randn(R, 256, generator=g).to(dev)
+    Bf = torch.randn(R, 1024, generator=g)
+    B16 = Bf.to(torch.bfloat16).to(dev)
+    outs = []
+    for _ in range(2):
+        C = torch.empty((256, 1024), dtype=torch.float32, device=dev)
+        splitk = 8
+        ws = torch.empty(splitk * 256 * 1024, dtype=torch.float32, device=dev)
+        L.check(L.lib().epc_gemm_splitk_det_b16(A.data_ptr(), B16.data_ptr(), C.data_ptr(), None, 256, 1024, R, 1, 256, 1024, 1, 1024, 1,
+                                                0, 0, 0, splitk, 0, 1, ws.data_ptr(), ws.numel(), L.current_stream()))
+        outs.append(C)
+    # the head's own kernel for this product (epc_h16_conv5_dw), f32 and bf16 left operand: two implementations, one answer
+    for a_in, is16 in ((A, 0), (A.to(torch.bfloat16), 1)):
+        C = torch.empty((256, 1024), dtype=torch.float32, device=dev)
+        nb = L.lib().epc_h16_conv5_dw_scratch_bytes(R)
+        sc = torch.empty(nb, dtype=torch.uint8, device=dev)
+        L.check(L.lib().epc_h16_conv5_dw(a_in.data_ptr(), is16, B16.data_ptr(), R, C.data_ptr(), sc.data_ptr(), nb, L.current_stream()))
+        outs.append(C)
+    torch.cuda.synchronize()
+    ref = A.to(torch.bfloat16).double().cpu().t() @ B16.double().cpu()
+    for C in outs:
+        assert float((C.double().cpu() - ref).abs().max() / ref.abs().max()) <= 1e-5
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])
+    with pytest.raises(L.EpcNetError):
+        L.check(L.lib().epc_gemm_splitk_det_b16(A.data_ptr(), B16.data_ptr(), C.data_ptr(), None, 32, 1024, R, 1, 256, 1024, 1, 1024, 1,
+                                                0, 0, 0, 1, 0, 1, None, 0, L.current_stream()))
+
+
+def test_expand16_and_argument_checks(dev):
+    L, ops = H.pkg("lib"), H.pkg("ops")
+    z = torch.randn(64, 1024, device=dev).to(torch.bfloat16)
+    assert torch.equal(ops.expand16(z), z.float())
+    mean, var = torch.randn(1024, device=dev), torch.rand(1024, device=dev) + 0.5
+    gamma, beta = torch.randn(1024, device=dev), torch.randn(1024, device=dev)
+    rn = torch.rand(64, device=dev) + 0.5
+    f = ops.expand16(z, (mean, var, gamma, beta, EPS), rn)
+    s = gamma.double() / torch.sqrt(var.double() + EPS)
+    ref = torch.relu(z.double() * s + (beta.double() - mean.double() * s)) * rn.double()[:, None]
+    assert float((f.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # rows that are not a multiple of 32 are refused, not mis-tiled
+    with pytest.raises(L.EpcNetError):
+        sc = torch.empty(1 << 22, dtype=torch.uint8, device=dev)
+        L.check(L.lib().epc_h16_conv5_fwd(z.data_ptr(), 0, z.data_ptr(), z.data_ptr(), 48, z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                          sc.data_ptr(), sc.numel(), L.current_stream()))

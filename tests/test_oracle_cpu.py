@@ -157,3 +157,42 @@ def test_distill_oracle_composition_and_finite_difference():
     w2[k][idx] -= 2 * eps
     dn = T.distill_step(wt, w2, *tup, gamma=0.5)["loss"]
     assert abs((up - dn) / (2 * eps) - r["grads"][k][idx]) < 1e-5 * max(1.0, abs(r["grads"][k][idx]))
+
+
+def test_head16_restatement_without_rounding_is_the_plain_graph():
+    """oracle/epcnet_oracle_torch.py: _Head16 writes out the forward AND the backward of conv5 .. the VLAD aggregation so that it can
+    round where the bf16-stored head of the HIP step rounds.  With the rounding switched off it must BE the plain graph: its outputs equal
+    the composition's and its hand-written backward equals autograd's of that composition (float64, 1e-9) -- a derivation error in the
+    restatement cannot hide behind the rounding noise of the GPU comparison."""
+    import torch
+    import epcnet_oracle_torch as T
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 64
+    R = B * N
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    leaves = [rnd(R, 256), rnd(256, 1024) * 0.1, rnd(1024) * 0.1, 1 + 0.2 * rnd(1024), 0.3 * rnd(1024), rnd(1024, 64) * 0.2,
+              1 + 0.2 * rnd(64), 0.3 * rnd(64)]
+    wv, wa = rnd(B, 1024, 64), rnd(B, 1, 64)                  # random cotangents
+
+    def plain(cat, W5, b5, g5, bt5, Wc, gc, btc):
+        z = cat @ W5 + b5
+        y, _, _ = T._bn_train(z, g5, bt5, (0,))
+        f = T._l2n(torch.relu(y), 1)
+        za = f @ Wc
+        ya, _, _ = T._bn_train(za, gc, btc, (0,))
+        a = torch.softmax(ya, dim=1).reshape(B, N, 64)
+        return torch.matmul(f.reshape(B, N, 1024).transpose(1, 2), a), a.sum(1, keepdim=True)
+
+    outs = []
+    for fn in (plain, lambda *xs: T._Head16.apply(*xs, N, False, None, None, O.BN_EPS)[:2]):
+        xs = [x.clone().requires_grad_(True) for x in leaves]
+        vlad, a_sum = fn(*xs)
+        grads = torch.autograd.grad((vlad * wv).sum() + (a_sum * wa).sum(), xs, allow_unused=True)
+        outs.append((vlad.detach(), a_sum.detach(), grads))
+    (v0, s0, g0), (v1, s1, g1) = outs
+    assert (v0 - v1).abs().max() <= 1e-12 and (s0 - s1).abs().max() <= 1e-12
+    for k, (a, b) in enumerate(zip(g0, g1)):
+        if k == 2:       # b5: exactly zero in exact arithmetic (a bias in front of a training-mode BatchNorm); autograd holds rounding noise
+            assert a.abs().max() <= 1e-10 and b.abs().max() == 0
+            continue
+        assert (a - b).abs().max() <= 1e-9 * max(1.0, float(a.abs().max())), (k, float((a - b).abs().max()))
