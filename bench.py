@@ -32,11 +32,14 @@ Objects on the JSON line:
   fast         the EPC_PRECISION_FAST region: value, ms_per_step, stage_ms, roofline, overlapped (two steps in flight).
   configs      bounded legs for the other BASELINE.json configs, each timed like the main region (barrier + synchronize on
                both sides, max over ranks):
-               train_step      configs[2]: one quadruplet step (1 + 2 + 14 + 1 clouds x 4096, train.py:238-277, 484-495), a
-                               FRESH tuple every step (the loss stays non-zero), HIP-graph replay at every N (data-parallel over
-                               tuples at N > 1: two graphs around one flat RCCL all-reduce), f32-accurate arithmetic, with its
-                               own `roofline`; `eager` = the same step without graphs (side number);
-               train_step_bf16 the same step with one bf16 value per GEMM operand (the arithmetic configs[2] names);
+               train_step      configs[2]: one quadruplet step (1 + 2 + 14 + 1 = 18 clouds x 4096, the reference's tuple:
+                               configs/epc-net.yaml:28-34; train.py:238-277, 484-495), a FRESH tuple every step (the loss stays
+                               non-zero), HIP-graph replay at every N (data-parallel over tuples at N > 1: three graphs around
+                               the two RCCL all-reduces), f32-accurate arithmetic, with its own `roofline` (MFMA and, from the
+                               committed counters, HBM); `eager` = the same step without graphs (side number);
+               train_step_bf16 the same step in the arithmetic configs[2] names: bf16-stored (rows, 1024) activations and
+                               gradients, one bf16 value per GEMM operand, f32 accumulate / statistics / master weights;
+               train_step_22, train_step_bf16_22   both at BASELINE.json's literal size, 1 + 2 + 18 + 1 = 22 clouds;
                epc_net_l_b256  configs[3]: EPC-Net-L inference at batch 256 per GPU, with its own roofline;
                retrieval       configs[4] composed end to end (retrieval.evaluate_sharded = evaluate.py:293-332): 23 runs x
                                (400 + 120) synthetic clouds EXTRACTED sharded over the ranks, ONE RCCL all-gather of the
@@ -136,6 +139,8 @@ def self_launch(args, argv):
     import torch
     have = torch.cuda.device_count()
     n = min(args.gpus, have) if have > 0 else 0
+    if args.same_device and have > 0:
+        n = args.gpus                                          # every rank on cuda:0 (dry run of the N > 1 code on a 1-GPU box)
     if n < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     child_argv = [a for a in argv]
@@ -183,9 +188,21 @@ class Harness:
         import torch
         if self.dist is None:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.device)
+        # (a host tensor under gloo -- the dry-run backend --, a device tensor under RCCL)
+        on_host = self.dist.get_backend() == "gloo"
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if on_host else self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def all_ok(self, ok):
+        """True on every rank iff `ok` on every rank (a leg that failed on one rank is skipped / reported by all of them)."""
+        import torch
+        if self.dist is None:
+            return bool(ok)
+        on_host = self.dist.get_backend() == "gloo"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_host else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
 
     def timed(self, fn, steps):
         """K calls of fn(k) between fences; returns max-over-ranks seconds."""
@@ -340,7 +357,19 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
     return res, elapsed
 
 
-def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0):
+def train_counters(precision, n_clouds):
+    """Counter summary of the training step from the committed rocprofv3 PMC passes (profiles/pmc_train_current.json, collected by
+    scripts/collect_train_profiles.sh on the eager step of the same size) -- only while its lib_sha256 stamp is the loaded library's."""
+    doc = pmc_summary("pmc_train_current.json")
+    if not doc:
+        return None, _PMC_WHY.get("pmc_train_current.json")
+    leg = doc.get("legs", {}).get("%s_%d" % (precision, n_clouds))
+    if not leg:
+        return None, "profiles/pmc_train_current.json has no %s step at %d clouds" % (precision, n_clouds)
+    return leg, None
+
+
+def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0, n_neg=14):
     """configs[2]: the quadruplet step at full size, a fresh tuple every step.  HIP-graph replay at EVERY world size (one graph
     at N = 1; at N > 1 three graphs around the two RCCL all-reduces -- the head's gradients travel under the backbone's backward,
     training.TrainStep._graphed_step).  ``precision``:
@@ -355,13 +384,14 @@ def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0):
     g = torch.Generator(device="cpu")
     g.manual_seed(7000 + H.rank)                               # data-parallel over tuples: every rank its own tuples
     n_tuples = 8
-    tuples = [(torch.rand((18, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(H.device) for _ in range(n_tuples)]
+    ncl = 1 + 2 + n_neg + 1                                    # 18: the reference's tuple (configs/epc-net.yaml:28-34); 22: BASELINE.json's "18 neg"
+    tuples = [(torch.rand((ncl, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(H.device) for _ in range(n_tuples)]
     losses = []
 
     def run(use_graph):
         def one(k):
             t = tuples[k % n_tuples]
-            loss, _, _ = ts.step(t[None, 0:1], t[None, 1:3], t[None, 3:17], t[None, 17:18], epoch=0, graph=use_graph)
+            loss, _, _ = ts.step(t[None, 0:1], t[None, 1:3], t[None, 3:3 + n_neg], t[None, 3 + n_neg:], epoch=0, graph=use_graph)
             losses.append(loss)
         return one
 
@@ -370,21 +400,37 @@ def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0):
     del losses[:]
     elapsed = H.timed(run(True), steps)
     loss_vals = [float(x) for x in losses]
-    flops = 3.0 * FLOPS_PER_CLOUD["epc-net"] * 18
+    flops = 3.0 * FLOPS_PER_CLOUD["epc-net"] * ncl
     tflops = flops * steps / elapsed / 1e12
-    out = {"workload": "EPC-Net quadruplet training step, 1 + 2 + 14 + 1 clouds x 4096 pts per GPU (BASELINE.json configs[2]; "
+    ms = elapsed / steps * 1e3
+    ctr, ctr_why = train_counters(precision, ncl)
+    # The step's kernels are single passes over its tensors ("Training step"): it is priced against HBM as well --
+    # counter bytes per step (FETCH_SIZE x 2 + WRITE_SIZE summed over the step's launches) over the step time -- next to the
+    # algorithmic bytes of the tensors each kernel has to move once (profiles/pmc_train_current.json: model_bytes_per_step).
+    roof = {"bound": "hbm" if precision == "bf16" else "mfma", "achieved": round(tflops, 3), "peak": BF16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "vs_f32_mfma_peak": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+            "kernel": "whole step (forward + backward + Adam + moving averages), all launches of the replayed graph"}
+    if ctr:
+        gbps = ctr["hbm_bytes_per_step"] / (ms * 1e-3) / 1e9
+        roof.update({"traffic": int(ctr["hbm_bytes_per_step"]), "hbm_achieved_GBps": round(gbps, 1), "hbm_peak_GBps": 8000.0,
+                     "hbm_frac": round(gbps / 8000.0, 4), "model_bytes_per_step": ctr.get("model_bytes_per_step"),
+                     "traffic_over_model": round(ctr["hbm_bytes_per_step"] / ctr["model_bytes_per_step"], 3) if ctr.get("model_bytes_per_step") else None,
+                     "largest_kernels": ctr.get("largest_kernels")})
+    else:
+        roof["counters_unavailable"] = ctr_why
+    out = {"workload": "EPC-Net quadruplet training step, 1 + 2 + %d + 1 = %d clouds x 4096 pts per GPU (BASELINE.json configs[2]; "
                        "train.py:238-277, 484-495), fresh tuple every step, HIP-graph replay%s"
-                       % ("" if H.world == 1 else " (two graphs around one flat RCCL all-reduce of gradients and moving statistics)"),
-           "value": round(H.world * steps / elapsed, 2), "unit": "tuples/s (18 clouds each)", "steps": steps,
-           "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "dtype": ("bf16x6 / f16x3 forward, bf16x3 backward GEMMs (f32-accurate)" if precision == "bf16x6" else
-                     "bf16 GEMM operands, f32 accumulate, f32 tensors and statistics"),
+                       % (n_neg, ncl, "" if H.world == 1 else " (three graphs around the two all-reduces of the data-parallel step: "
+                          "the head's gradients travel under the backbone's backward)"),
+           "value": round(H.world * steps / elapsed, 2), "unit": "tuples/s (%d clouds each)" % ncl, "steps": steps,
+           "clouds_per_tuple": ncl, "ms_per_step": round(ms, 4),
+           "dtype": ("bf16x6 / f16x3 forward, bf16x3 backward GEMMs (f32-accurate), f32 tensors" if precision == "bf16x6" else
+                     "bf16: the (rows, 1024) activations and gradients of conv5 .. VLAD stored as bf16, one bf16 value per GEMM "
+                     "operand, f32 accumulate / statistics / master weights (the 64-channel backbone's tensors are f32)"),
            "tflops": round(tflops, 2), "algorithmic_flops_per_step": flops,
            # the whole step against the dense 16-bit matrix peak (96 % of its FLOPs are dense contractions)
-           "roofline": {"bound": "mfma", "achieved": round(tflops, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "vs_f32_mfma_peak": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
-                        "kernel": "whole step (forward + backward + Adam + moving averages), all launches of the replayed graph"},
+           "roofline": roof,
            "loss_first": round(loss_vals[0], 5), "loss_last": round(loss_vals[-1], 5),
            "loss_mean": round(sum(loss_vals) / len(loss_vals), 5)}
     if eager_steps > 0:
@@ -472,11 +518,11 @@ def retrieval_leg(H, E, steps, warmup, rccl):
                            "256-d descriptors -> exact top-25 of every query against each other run's database, each rank "
                            "ranking AND booking its share of the queries on the device -> one all-reduce of the per-pair integer "
                            "counters (BASELINE.json configs[4]; evaluate.py:293-332, 351-537; retrieval.evaluate_sharded)" % (runs, n_db, n_q, N_POINTS, total, world),
-               "rccl_exercised": bool(rccl), "backend": D.backend_name(), "rccl_ranks": world,
+               "rccl_exercised": bool(rccl), "backend": D.backend_name(), "rccl_ranks": world if rccl else 0, "ranks": world,
                "value": round(total * steps / elapsed, 1), "unit": "clouds/s evaluated end to end", "steps": steps,
                "ms_per_step": round(ms, 3),
                "phase_ms_rank0": {"extract": agg("extract"), "all_gather": gather_ms, "rank_book": agg("rank_book"),
-                                  "reduce": agg("reduce"), "finish_host": agg("finish"), "book_host": agg("finish")},
+                                  "reduce": agg("reduce"), "finish_host": agg("finish")},
                # what does NOT shrink with the number of ranks: the two collectives and the few numpy operations that turn the
                # reduced counters into the averages (extraction, ranking and booking are sharded)
                "serial_ms": round(gather_ms + agg("reduce") + agg("finish"), 3),
@@ -516,6 +562,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the train_step / epc_net_l_b256 / retrieval legs")
     ap.add_argument("--no-rccl", action="store_true", help="N = 1 only: do not create the world-of-one RCCL process group")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl = RCCL (the product's); gloo = the dry run of the N > 1 code on a box with fewer GPUs")
+    ap.add_argument("--same-device", action="store_true",
+                    help="every rank on cuda:0 (with --backend gloo: RCCL refuses two ranks on one GPU); numbers from it are not credit")
     ap.add_argument("--regions", type=int, default=7,
                     help="fenced regions of --steps steps each; value / ms_per_step = the median region (min / max reported)")
     args = ap.parse_args()
@@ -538,6 +588,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
+    if args.backend == "nccl" and args.same_device and world > 1:
+        raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # The process group is RCCL ("nccl") at every N -- at N = 1 too, a world of one rank (under torchrun --nproc-per-node 1 or
@@ -554,12 +608,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 or not args.no_rccl:
         try:
-            tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            rccl = True
+            if args.backend == "nccl":
+                tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                rccl = True
+            else:
+                tdist.init_process_group("gloo", rank=rank, world_size=world)
+                rccl_why = "--backend gloo: a dry run of the multi-rank code, not RCCL"
         except Exception as e:                                  # N = 1 only: the line then says so instead of dying
             if world > 1:
                 raise
-            rccl_why = "init_process_group('nccl') failed at world 1: %r" % (e,)
+            rccl_why = "init_process_group(%r) failed at world 1: %r" % (args.backend, e)
+    group_up = tdist.is_initialized()
     dist = tdist if world > 1 else None
     H = Harness(device, dist, world, rank)
     E = pkg("engine")
@@ -579,20 +638,31 @@ def main():
     if not args.no_configs and args.arch == "epc-net":
         # The bounded legs may not take the headline down with them: a leg that raises is reported as {"error": ...} (on every rank the
         # same way: the legs' collectives raise on all ranks or on none).
+        # A leg that raises is reported as {"error": ...} and the process exits non-zero AFTER the line is printed.  The
+        # failure modes that matter raise before a leg's first collective or on every rank alike; the ranks then agree, through
+        # one all-reduce of an ok flag behind every leg, on whether the leg counts (a rank that alone failed marks it failed everywhere).
         def guarded(name, fn):
+            ok = True
             try:
                 configs[name] = fn()
             except Exception as e:                              # noqa: BLE001  (reported on the line, not swallowed)
                 import traceback
+                ok = False
                 configs[name] = {"error": repr(e), "where": traceback.format_exc().strip().splitlines()[-3:]}
                 try:
                     import torch
                     torch.cuda.synchronize()
                 except Exception:
                     pass
+            if not H.all_ok(ok) and ok:
+                configs[name] = {"error": "the leg failed on another rank"}
 
-        guarded("train_step", lambda: train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, eager_steps=6))
-        guarded("train_step_bf16", lambda: train_step_leg(H, steps=max(10, min(60, args.steps)), warmup=12, precision="bf16"))
+        tsteps = max(10, min(60, args.steps))
+        guarded("train_step", lambda: train_step_leg(H, steps=tsteps, warmup=12, eager_steps=6))
+        guarded("train_step_bf16", lambda: train_step_leg(H, steps=tsteps, warmup=12, precision="bf16"))
+        # BASELINE.json configs[2] read literally: 1 query + 2 positives + 18 negatives (+ the other negative) = 22 clouds
+        guarded("train_step_22", lambda: train_step_leg(H, steps=tsteps, warmup=12, n_neg=18))
+        guarded("train_step_bf16_22", lambda: train_step_leg(H, steps=tsteps, warmup=12, precision="bf16", n_neg=18))
 
         def l_leg():
             stl = build_store("epc-net-l", device, seed=0)
@@ -654,11 +724,17 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch, store if args.arch != "epc-net" or not configs else build_store(args.arch, device, 0),
                                                 args.cpu_budget_s, args.cpu_clouds)
+        line["backend"] = {"name": args.backend if group_up else None, "rccl": bool(rccl), "ranks": world,
+                           "same_device": bool(args.same_device)}
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
-    if rccl:
+    if group_up:
         tdist.barrier()
         tdist.destroy_process_group()
+    failed = [k for k, v in configs.items() if isinstance(v, dict) and "error" in v]
+    if failed:
+        sys.stderr.write("bench.py: legs failed: %s\n" % ", ".join(failed))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -96,9 +96,6 @@ extern "C" int epc_debug_c5_stamps(void* host, size_t bytes) {
 #ifndef C5_START_STAGGER
 #define C5_START_STAGGER 0   // shader cycles between the start phases of first-round workgroups (0 = none)
 #endif
-#ifndef C5_PREFETCH_DISTANCE
-#define C5_PREFETCH_DISTANCE 256   // workgroups ahead (= CUs: one workgroup per CU at a time)
-#endif
 #ifndef C5_ASYM
 #define C5_ASYM 1   // 0: the lock-step schedule (every wave chain, epilogue, barrier), kept for the A/B measurement
 #endif
@@ -116,12 +113,7 @@ struct C5fLds {  // VLAD kernel; offsets in floats (4 B)
     // per-wave 32 x 32 f32 transpose tile (row stride 36) of the final epilogue: aliases the W5 stream buffers, dead by then
     static constexpr int OFF_T = OFF_W5;
     static constexpr int T_WAVE = 33 * 36;
-    static constexpr int OFF_PF = OFF_CBN + 128;           // (C5_PREFETCH builds: 1 KB per wave where prefetch loads land, never read)
-#ifdef C5_PREFETCH
-    static constexpr int TOTAL = OFF_PF + 8 * 256;
-#else
     static constexpr int TOTAL = OFF_CBN + 128;
-#endif
 };
 
 // The wave's 32 x CIN input block as scaled split-fp16 fragments (common.h): lane (li, q) holds, for point group p and k-step s,
@@ -341,24 +333,9 @@ __global__ __launch_bounds__(C5_THREADS) void conv5_vlad_f32_kernel(const float*
     // One interval = everything between two chunk barriers.  `late` waves (4-7) run the epilogue of the PREVIOUS chunk before this
     // chunk's chain (see Schedule at the top of the file).
     const bool late = C5_ASYM && wave_u >= 4;
-#ifdef C5_PREFETCH
-    const long pf_tile = (long)blockIdx.x + C5_PREFETCH_DISTANCE;
-    const bool pf_ok = CIN == 256 && (pf_tile + 1) * (C5_WAVES * 32) <= (long)total_points;
-    const float* pf_src = cat + (size_t)pf_tile * (C5_WAVES * 32) * CIN;   // 256 KB: 32 pieces of 8 KB (64 lines of 128 B)
-#endif
     auto interval = [&](int c, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         C5_T(t0);
-#ifdef C5_PREFETCH
-        // Experiment (round 4; measured: 0.476-0.495 ms against 0.472-0.473 without -- not in the product): touch
-        // the rows of the tile this CU's NEXT workgroup will probably take (blockIdx + the
-        // number of CUs: same XCD by construction), one 128-byte line per lane, four wave-instructions per wave spread over four
-        // intervals; the data lands in a dead LDS kilobyte.  Issued before the chunk's DMA pieces, so the counted waits below
-        // cover it.
-        if (pf_ok && c >= C5_PREFETCH && c < C5_PREFETCH + 4)
-            glds16(pf_src + (size_t)((c - C5_PREFETCH) * C5_WAVES + wave_u) * 2048, lane * 128u,
-                   lds_base + 4u * (L::OFF_PF + wave_u * 256));
-#endif
         if (c + 1 < 32) stage_chunk(c + 1, std::integral_constant<int, buf ^ 1>{});
         C5_T(t1);
         if (late && c > 0) epilogue(c - 1);
@@ -646,251 +623,6 @@ __global__ __launch_bounds__(C5M_THREADS, 4) void conv5_max_f32_kernel(const flo
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// conv5 of the TRAINING forward (models/epc-net.py:136 with is_training: z = x W + b and the batch moments of z; the BatchNorm,
-// ReLU and l2-norm that follow need the moments of ALL rows first and stay a pass of their own).  The generic tile GEMM took
-// 196-206 us for it at 18 x 4096 rows whatever its arithmetic (one bf16 product or three fp16 ones): it re-reads the 256-wide
-// rows once per 128-column tile and writes a 302-MB output through a statistics epilogue.  This is the inference kernels' shape
-// with z rows for an epilogue: the wave's input block RESIDENT as scaled split-fp16 fragments, W (packed by
-// conv5_train_pack_kernel every step: the weights change) streamed through LDS by LDS-DMA, three products on the 16x16x32 MFMA.
-//
-// Geometry.  Round 3 built this with 32-point tiles and 8-wave workgroups and dropped it (176 us against 187): at ~219 registers
-// two waves fit a SIMD, 2048 wave tiles at a time, and 18 x 4096 rows are 2304 -- an eighth of the work ran as a second round on
-// a quarter of the chip.  A first round-4 form -- 16 points per wave (one MFMA row group: 64 fragment registers), 4-wave
-// workgroups, three to a CU -- balanced the grid and took 250 us: every 64-row workgroup streams the whole 1-MB weight pack
-// (1.15 GB of LDS-DMA per launch) in stages so short (24 MFMAs per wave) that each waits for its successor's round trip.  So:
-//   * NW waves of 16 points share ONE weight stream (NW = 16: 256 rows per megabyte streamed), a stage is a 32-channel chunk
-//     (48 MFMAs per wave), and the stream runs THREE stages ahead through a ring of four 32-KB LDS buffers;
-//   * the grid is launched in slices that fit the chip: 256 workgroups of 16 waves, then the remainder (512 of the 4608
-//     16-point groups at 18 x 4096 rows) as 256 workgroups of 2 waves -- short stages again, but with the stream three stages
-//     ahead they run at the DMA's rate, not its latency.
-// Statistics: per wave and column (S1, S2, p) with p the wave's first row (sum of (v - p), (v - p)^2 over its 16 points); four
-// consecutive waves (64 rows) meet in LDS one stage later and leave ONE partial per 64 rows in the same form, (0, M2, mean), for
-// moments_finalize_kernel (tile_rows = 64) -- the same partition of the rows whatever the slices.
-// ---------------------------------------------------------------------------------------------------------------------------
-#define C5T_POINTS 16   // per wave
-#define C5T_RING 4
-template <int CIN>
-struct C5tLds {  // offsets in floats
-    static constexpr int W5_STAGE = 32 * CIN;                          // a chunk: 32 output channels, hi + lo fragments
-    static constexpr int OFF_W5 = 0;                                   // C5T_RING stage buffers
-    static constexpr int OFF_B5 = C5T_RING * W5_STAGE;
-    static constexpr int OFF_TI = OFF_B5 + 1024;
-    static constexpr int OFF_ST = OFF_TI + 1024;                       // [stage parity 2][wave 16][S1, S2, p][32 columns]
-    static constexpr int OFF_IS = OFF_ST + 2 * 16 * 3 * 32;            // per wave the inverse row scales of its (up to 32) points
-    static constexpr int TOTAL = OFF_IS + 16 * 32;
-};
-
-// pack (4-byte units): [W5p CIN*1024: fp16 hi + lo fragments, (chunk, group) contiguous as in fold_pack_conv5_kernel][bias 1024][tinv 1024]
-__global__ __launch_bounds__(256) void conv5_train_colscale_kernel(const float* __restrict__ W, const float* __restrict__ b, int cin,
-                                                                   float* __restrict__ pack) {
-    // 64 columns per workgroup, four k-slices of cin / 4 rows each (one thread walking a column's 256 rows took 63 us)
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const int k0 = sl * (cin / 4), k1 = k0 + cin / 4;
-    float m = 0.f;
-#pragma unroll 8
-    for (int k = k0; k < k1; ++k) m = fmaxf(m, fabsf(W[(size_t)k * 1024 + c]));
-    red[sl][cl] = m;
-    __syncthreads();
-    if (sl == 0) {
-        m = fmaxf(fmaxf(red[0][cl], red[1][cl]), fmaxf(red[2][cl], red[3][cl]));
-        float s, is;
-        row_scale_pow2(m, s, is);
-        pack[(size_t)cin * 1024 + c] = b ? b[c] : 0.f;
-        pack[(size_t)cin * 1024 + 1024 + c] = is;
-    }
-}
-__global__ void conv5_train_pack_kernel(const float* __restrict__ W, int cin, float* __restrict__ pack) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= cin * 1024) return;
-    const float* tinv = pack + (size_t)cin * 1024 + 1024;
-    unsigned short* dstW = reinterpret_cast<unsigned short*>(pack);
-    const int j = o & 7, lane = (o >> 3) & 63, rest = o >> 9;
-    const int steps = cin / 32;
-    const int s = rest % steps, g = (rest / steps) & 1, c = rest / (2 * steps);
-    const int k = 32 * s + 8 * (lane >> 4) + j, col = 32 * c + 16 * g + (lane & 15);
-    const float ws = W[(size_t)k * 1024 + col] * (1.0f / tinv[col]);   // exact: a power of two
-    const _Float16 hh = (_Float16)ws;
-    const _Float16 ll = (_Float16)(ws - (float)hh);
-    const size_t base = ((size_t)((c * 2 + g) * steps + s) * 2) * 512 + lane * 8 + j;
-    dstW[base] = __builtin_bit_cast(unsigned short, hh);
-    dstW[base + 512] = __builtin_bit_cast(unsigned short, ll);
-}
-
-// rows [row0, row0 + gridDim.x * NW * 16 NP) of x.  NP = point groups of 16 per wave: with 2 a weight fragment read from LDS
-// feeds six MFMAs instead of three -- at NP = 1 and 16 waves the kernel was bound by LDS reads (16 waves x 36 KB per 32-channel
-// stage: 3.6 us per stage whatever else was changed: 135 us) -- for 128 fragment registers instead of 64 (two waves per SIMD).
-template <int CIN, int NW, int NP>
-__global__ __launch_bounds__(64 * NW) void conv5_train_f32_kernel(const float* __restrict__ x, const float* __restrict__ pack,
-                                                                  int row0, int total_points, float* __restrict__ z,
-                                                                  float* __restrict__ stats) {
-    using L = C5tLds<CIN>;
-    constexpr int STEPS = CIN / 32;
-    constexpr int PTS = 16 * NP;                                       // points per wave
-    constexpr int GW = 64 / PTS;                                       // waves per 64-row statistics partial
-    static_assert((NP == 1 || NP == 2) && NW >= GW && NW <= 16 && (NW & (NW - 1)) == 0, "waves: a power of two, whole partials");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, q = lane >> 4;
-    const float* gw5 = pack;
-    const float* gb5 = pack + (size_t)CIN * 1024;
-    const float* gti = gb5 + 1024;
-    constexpr int PIECES = L::W5_STAGE / (NW * 256);                   // 1-KB LDS-DMA pieces per wave per stage
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)lds;
-    const unsigned lane_off = lane * 16;
-    auto stage_w5 = [&](int c) {      // chunk c -> ring buffer c % C5T_RING
-        const unsigned dst = lds_base + 4u * (L::OFF_W5 + (c & (C5T_RING - 1)) * L::W5_STAGE);
-#pragma unroll
-        for (int u = 0; u < PIECES; ++u) {
-            const int piece = u * NW + wave_u;
-            glds16(gw5 + (size_t)c * L::W5_STAGE + piece * 256, lane_off, dst + 4u * (piece * 256));
-        }
-    };
-    stage_w5(0);
-    stage_w5(1);
-    stage_w5(2);
-    for (int o = tid; o < 1024; o += 64 * NW) {
-        lds[L::OFF_B5 + o] = gb5[o];
-        lds[L::OFF_TI + o] = gti[o];
-    }
-    const int g0 = row0 + ((int)blockIdx.x * NW + wave_u) * PTS;
-    const bool active = g0 < total_points;
-    C5_LOAD_ROWS_SPLIT_N(NP, CIN, x, g0, active, li, q)
-    // register r of acc[p] belongs to point 16 p + 4 q + r, whose inverse row scale lives in the lane that loaded that point
-    if (q == 0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) lds[L::OFF_IS + wave * 32 + 16 * p + li] = inv_row[p];
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");   // the rows and chunk 0; chunks 1, 2 may be in flight
-    __syncthreads();
-    float isr[NP][4];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const float4 v = ld4(lds + L::OFF_IS + wave * 32 + 16 * p + 4 * q);
-        isr[p][0] = v.x, isr[p][1] = v.y, isr[p][2] = v.z, isr[p][3] = v.w;
-    }
-    // GW consecutive waves = 64 rows = one statistics partial, folded by 32 threads each one stage later.  Float arithmetic about
-    // the first wave's pivot p0 (a wave's (S1, S2, p) re-centred: d = p - p0, S1 + n d, S2 + 2 d S1 + n d^2): the partial leaves as
-    // (S1, S2, p0), the form the GEMM's epilogue writes.
-    const int first_group = (row0 + (int)blockIdx.x * NW * PTS) / 64;
-    auto fold_stage_stats = [&](int c) {
-        if (tid < 32 * (NW / GW)) {
-            const int grp = tid >> 5, col = tid & 31;
-            if ((first_group + grp) * 64 < total_points) {
-                const float* st = lds + L::OFF_ST + (c & 1) * (16 * 96) + (grp * GW) * 96 + col;
-                const float p0 = st[64];
-                float S1 = st[0], S2 = st[32];
-#pragma unroll
-                for (int w = 1; w < GW; ++w) {
-                    const float s1 = st[w * 96], s2 = st[w * 96 + 32], d = st[w * 96 + 64] - p0;
-                    S1 += s1 + (float)PTS * d;
-                    S2 += s2 + 2.0f * d * s1 + (float)PTS * d * d;
-                }
-                float* o = stats + (size_t)(first_group + grp) * 3 * 1024 + 32 * c + col;
-                o[0] = S1;
-                o[1024] = S2;
-                o[2048] = p0;
-            }
-        }
-    };
-    for (int c = 0; c < 32; ++c) {
-        if (c > 0) fold_stage_stats(c - 1);
-        if (c + 3 < 32) stage_w5(c + 3);
-        const float* w5c = lds + L::OFF_W5 + (c & (C5T_RING - 1)) * L::W5_STAGE;
-        // (six independent accumulator chains per point group instead of one chain of 24 MFMAs were measured at NP = 1: 134 -> 192 us
-        // at 128 registers; back-to-back MFMAs on one accumulator are forwarded, the chain is not the limit)
-        float v[2][NP][4];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const float* w5 = w5c + g * (16 * CIN);
-            f32x4v acc[NP];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) acc[p] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            f16x8 fa[2][2];   // fragment reads run one k-step ahead of their MFMAs: [ring slot][hi, lo]
-            fa[0][0] = ldfrag16(w5 + (0 * 64 + lane) * 4);
-            fa[0][1] = ldfrag16(w5 + (1 * 64 + lane) * 4);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                if (s + 1 < STEPS) {
-                    fa[(s + 1) & 1][0] = ldfrag16(w5 + (((s + 1) * 2 + 0) * 64 + lane) * 4);
-                    fa[(s + 1) & 1][1] = ldfrag16(w5 + (((s + 1) * 2 + 1) * 64 + lane) * 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const f16x8 wh = fa[s & 1][0], wl = fa[s & 1][1];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p] = mfma16_f16(xh[p][s], wl, acc[p]);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p] = mfma16_f16(xl[p][s], wh, acc[p]);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) acc[p] = mfma16_f16(xh[p][s], wh, acc[p]);
-            }
-            // v = acc * (inverse row scale * inverse column scale): the product; z = v + bias; the moments are those of v
-            const float ti = lds[L::OFF_TI + 32 * c + 16 * g + li];
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[g][p][r] = acc[p][r] * (isr[p][r] * ti);
-            const float pv = __shfl(v[g][0][0], li);      // the wave's first point (p = 0, q = 0, r = 0) of this lane's column
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = v[g][p][r] - pv;
-                    s1 += d;
-                    s2 += d * d;
-                }
-            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
-            if (q == 0) {
-                float* st = lds + L::OFF_ST + (c & 1) * (16 * 96) + wave * 96 + 16 * g + li;
-                st[0] = s1, st[32] = s2, st[64] = pv;
-            }
-        }
-        // z rows as WHOLE 128-byte lines.  A lane holds channel 16 g + li of points 4 q + r: stored as it stands, an instruction
-        // writes 64-byte pieces (four points x sixteen channels).  v_permlane32_swap exchanges the upper half-wave of group 0's
-        // register with the lower half-wave of group 1's: afterwards the lower lanes hold group 0 and the upper lanes group 1 of the
-        // SAME two points, 2 x 128 contiguous bytes per instruction.  (Measured with and without at NP = 1: 135 us both -- the
-        // kernel was LDS-bound -- kept because it is what the memory system prefers.)
-        if (active) {
-            const int half = lane >> 5, qq = q & 1;
-            const float b0 = lds[L::OFF_B5 + 32 * c + li], b1 = lds[L::OFF_B5 + 32 * c + 16 + li];
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                float* zb = z + (size_t)(g0 + 16 * p + 4 * qq) * 1024 + 32 * c + 16 * half + li;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][p][r] + b0), __float_as_uint(v[1][p][r] + b1), false, false);
-                    zb[(size_t)r * 1024] = __uint_as_float(sw[0]);            // points 4 qq + r      (q = 0, 1)
-                    zb[(size_t)(8 + r) * 1024] = __uint_as_float(sw[1]);      // points 4 (qq + 2) + r (q = 2, 3)
-                }
-            }
-        }
-        // Chunk c + 1 must have landed.  Vector-memory operations retire in issue order; behind chunk c + 1's pieces this wave has
-        // issued: the stores of stages c - 2, c - 1, c (8 NP each, where those stages exist) and the pieces of chunks c + 2, c + 3
-        // (where those exist) -- that many may stay in flight (at most 63: the counter's field).
-        constexpr int P = PIECES, S = 8 * NP;
-        constexpr auto cap = [](int n) { return n > 63 ? 63 : n; };
-        if (active) {
-            if (c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(2 * P + S)) : "memory");
-            else if (c == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(2 * P + 2 * S)) : "memory");
-            else if (c < 29) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(2 * P + 3 * S)) : "memory");
-            else if (c == 29) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(P + 3 * S)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(3 * S)) : "memory");
-        } else {
-            if (c < 29) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(2 * P)) : "memory");
-            else if (c == 29) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cap(P)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    fold_stage_stats(31);
-}
-
 static int c5_set_lds(const void* fn, size_t lds_bytes, const char* who) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) {
@@ -933,53 +665,6 @@ extern "C" int epc_conv5_maxpool_fwd(const float* cat, int cin, const void* pack
     const unsigned blocks = (unsigned)((total + C5M_WAVES * 32 - 1) / (C5M_WAVES * 32));
     hipLaunchKernelGGL((conv5_max_f32_kernel<128>), dim3(blocks), dim3(C5M_THREADS), lds_bytes, (hipStream_t)stream, cat,
                        (const float*)packed_conv5, (int)total, n, pooled);
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
-}
-
-extern "C" size_t epc_conv5_train_pack_floats(int cin) { return cin > 0 ? (size_t)cin * 1024 + 2048 : 0; }
-extern "C" size_t epc_conv5_train_stats_floats(int rows) { return rows > 0 ? (size_t)((rows + 63) / 64) * 3 * 1024 : 0; }
-
-template <int NW, int NP>
-static int c5t_launch(const float* x, const float* pack, int row0, int wgs, int rows, float* z, float* stats, hipStream_t st) {
-    const size_t lds_bytes = C5tLds<256>::TOTAL * sizeof(float);
-    if (int rc = c5_set_lds(reinterpret_cast<const void*>(conv5_train_f32_kernel<256, NW, NP>), lds_bytes, "epc_conv5_train_fwd")) return rc;
-    hipLaunchKernelGGL((conv5_train_f32_kernel<256, NW, NP>), dim3(wgs), dim3(64 * NW), lds_bytes, st, x, pack, row0, rows, z, stats);
-    return EPC_OK;
-}
-
-extern "C" int epc_conv5_train_fwd(const float* x, int cin, const float* W, const float* b, int rows, float* z, float* mean,
-                                   float* var, float* pack, size_t pack_floats, float* stats, size_t stats_floats, void* stream) {
-    EPC_CHECK_ARG(x && W && z && mean && var && pack && stats, "null pointer");
-    EPC_CHECK_ARG(cin == 256, "implemented for EPC-Net's 256 -> 1024 conv5 (models/epc-net.py:136)");
-    EPC_CHECK_ARG(rows > 0 && rows % 64 == 0, "rows must be a multiple of 64");
-    EPC_CHECK_ARG(pack_floats >= epc_conv5_train_pack_floats(cin) && stats_floats >= epc_conv5_train_stats_floats(rows),
-                  "pack / statistics buffer too small");
-    EPC_CHECK_ARG(((reinterpret_cast<size_t>(x) | reinterpret_cast<size_t>(z) | reinterpret_cast<size_t>(pack)) & 15) == 0,
-                  "x, z and pack must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv5_train_colscale_kernel, dim3(16), dim3(256), 0, st, W, b, cin, pack);
-    hipLaunchKernelGGL(conv5_train_pack_kernel, dim3(cin * 1024 / 256), dim3(256), 0, st, W, cin, pack);
-    // slices that fit the chip (one workgroup per CU: its ring of weight stages fills the LDS): 8-wave workgroups of 32-point waves
-    // (256 rows) while a full round of them is left, then the remainder with the widest workgroups that still give every CU one
-    // (2 waves = 64 rows at least: a workgroup holds whole statistics partials)
-    const int cus = epc_device_cu_count();
-    int row0 = 0;
-    while (row0 < rows) {
-        const int groups = (rows - row0) / 64;             // 64-row groups left
-        int nw = 8;                                        // waves of 32 points
-        while (nw > 2 && groups * 2 < (long)cus * nw) nw >>= 1;
-        const int per_wg = nw / 2;                         // groups per workgroup
-        int wgs = groups / per_wg;
-        if (wgs > cus && nw == 8) wgs = (wgs / cus) * cus; // whole rounds of the widest form; the rest goes to the next slice
-        int rc;
-        if (nw == 8) rc = c5t_launch<8, 2>(x, pack, row0, wgs, rows, z, stats, st);
-        else if (nw == 4) rc = c5t_launch<4, 2>(x, pack, row0, wgs, rows, z, stats, st);
-        else rc = c5t_launch<2, 2>(x, pack, row0, wgs, rows, z, stats, st);
-        if (rc != EPC_OK) return rc;
-        row0 += wgs * nw * 32;
-    }
-    epc_moments_finalize_launch(stats, rows / 64, 1024, rows, 64, b, mean, var, stream);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -1207,15 +1207,11 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* __restrict__
     mask[((size_t)cloud * n + i) * n + j] = (a >= kth[(size_t)cloud * n + i]) ? 1.0f : 0.0f;
 }
 
-// EPC_KNN_QUAD=0 selects the one-lane form (tuning, and the parity tests that hold the two forms against each other)
-static int epc_knn_quad_mode() {
-    const char* e = getenv("EPC_KNN_QUAD");
-    return (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) ? e[0] - '0' : -1;
-}
-
+// one_lane: the one-lane-per-query form of the LDS kernel instead of the four-lane one (epc_knn_topk_form: the parity tests and the
+// timing scripts hold the two against each other; the product entry points always pass false)
 static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
                       const float* conv1_pack, float* x32, void* x16, int idx_u16, int32_t* status, void* stream,
-                      const char* who) {
+                      const char* who, bool one_lane = false) {
     dim3 grid((n + KNN_THREADS - 1) / KNN_THREADS, num_clouds);
 #ifdef KNN_COLLECT
     {
@@ -1267,9 +1263,9 @@ static int launch_knn(const float* xyz, int num_clouds, int n, int cap, int32_t*
                            (hipStream_t)stream, xyz, n, cap, idx, cnt, kth, C1 ? conv1_pack : nullptr, C1 ? x32 : nullptr,     \
                            C1 ? (unsigned short*)x16 : nullptr, C1 ? idx_u16 : 0, status);                                      \
     } while (0)
-        // four lanes per query (knn_topk_quad_kernel) unless EPC_KNN_QUAD=0 asks for the one-lane form: measured faster at every
-        // batch of 4096-point clouds (1 cloud 0.047 vs 0.156 ms, 18: 0.073 vs 0.167, 64: 0.149 vs 0.189, 256: 0.483 vs 0.536)
-        const bool quad = epc_knn_quad_mode() != 0;
+        // four lanes per query (knn_topk_quad_kernel): measured faster than the one-lane form at every batch of 4096-point clouds
+        // (1 cloud 0.047 vs 0.156 ms, 18: 0.073 vs 0.167, 64: 0.149 vs 0.189, 256: 0.483 vs 0.536)
+        const bool quad = !one_lane;
         if (quad) {
             // 16-query groups per workgroup: as many as spread the grid over two workgroups per CU in ONE round (two cloud images fit
             // a CU's LDS): up to 16 waves, each taking `rounds` groups one after the other -- the LDS image (the whole cloud, its
@@ -1330,9 +1326,36 @@ extern "C" int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, in
     return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, nullptr, stream, __func__);
 }
 
+static int knn_topk_conv1_impl(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
+                               const void* packed_conv1, float* x, void* x16, int32_t* status, void* stream, bool one_lane);
+
+// Test / tuning entry points: epc_knn_topk and epc_knn_topk_conv1 with the LDS kernel's form chosen by the caller (form 0 = one lane
+// per query, the kernel of rounds 1-3; 1 = four lanes per query, what the product entry points run).  An explicit argument: the
+// library reads no environment and holds no global state.
+extern "C" int epc_knn_topk_form(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth, int form,
+                                 void* stream) {
+    EPC_CHECK_ARG(xyz && idx && cnt && kth, "null pointer");
+    EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT && cap >= EPC_KNN_SELECT && (form == 0 || form == 1),
+                  "need num_points >= 20, capacity >= 20, form 0 or 1");
+    if (num_clouds == 0) return EPC_OK;
+    return launch_knn(xyz, num_clouds, n, cap, idx, cnt, kth, nullptr, nullptr, nullptr, 0, nullptr, stream, __func__, form == 0);
+}
+
+extern "C" int epc_knn_topk_conv1_form(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt,
+                                       float* kth, const void* packed_conv1, float* x, void* x16, int32_t* status, int form,
+                                       void* stream) {
+    EPC_CHECK_ARG(form == 0 || form == 1, "form 0 or 1");
+    return knn_topk_conv1_impl(xyz, num_clouds, n, cap, idx, idx_u16, cnt, kth, packed_conv1, x, x16, status, stream, form == 0);
+}
+
 extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt,
                                   float* kth, const void* packed_conv1, float* x, void* x16, int32_t* status,
                                   void* stream) {
+    return knn_topk_conv1_impl(xyz, num_clouds, n, cap, idx, idx_u16, cnt, kth, packed_conv1, x, x16, status, stream, false);
+}
+
+static int knn_topk_conv1_impl(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
+                               const void* packed_conv1, float* x, void* x16, int32_t* status, void* stream, bool one_lane) {
     EPC_CHECK_ARG(xyz && idx && cnt && kth && packed_conv1 && (x || x16), "null pointer");
     EPC_CHECK_ARG(!idx_u16 || (n <= 65535 && n <= KNN_LDS_MAX_N), "2-byte lists need num_points <= 8192 (the LDS kernel)");
     EPC_CHECK_ARG(num_clouds >= 0 && num_clouds <= 65535 && n >= EPC_KNN_SELECT,
@@ -1345,7 +1368,7 @@ extern "C" int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int c
         return epc_conv1_launch(xyz, packed_conv1, num_clouds * n, x, x16, status, n, stream);   // (f32 rows: EPC-Net-L / F32 precision run at this size)
     }
     return launch_knn(xyz, num_clouds, n, cap, (int32_t*)idx, cnt, kth, (const float*)packed_conv1, x, x16, idx_u16, status,
-                      stream, __func__);
+                      stream, __func__, one_lane);
 }
 
 extern "C" int epc_knn_mask(const float* xyz, const float* kth, int num_clouds, int n, float* mask,

@@ -703,21 +703,73 @@ __global__ __launch_bounds__(256) void h16_bn_bwd_apply_kernel(const u32x4* __re
 
 // ----------------------------------------------------------------------------------------------------------------
 // conv5's weight gradient dW5 (256, 1024) = cat^T dz5 -- both operands (rows, .) row-major with the ROWS as the contraction, 73 728 deep at
-// the training tuple's size.  The generic tile GEMM took 163 us for it with a bf16 right operand (2-byte lane-coalesced fetches, re-split per
-// tile).  Here, as in h16_colgemm_kernel, a lane loads a few adjacent channels of 8 consecutive rows and the conversions write the MFMA
-// fragments (8 rows of ONE channel per lane) directly: cat as float4 (4 channels -> 4 A fragments), dz5 as a dword (2 columns -> 2 B
-// fragments).  A workgroup of eight waves owns all 256 input channels x 256 output columns (waves 2 x 4: 128 x 64 each) over a slice of
-// the rows; slices are added in ascending order by h16_partial_reduce_kernel.  cat is read 4 times chip-wide, dz5 once: the first version
-// (four waves, 128 columns, f32 cat: 8 x 75 MB of re-reads from beyond L2) took 171 us -- no faster than the tile GEMM.
+// the training tuple's size; the MFMA wants 8 consecutive rows of ONE channel per lane.  The generic tile GEMM took 163 us for it (2-byte
+// lane-coalesced fetches, operands re-split per tile); a first kernel here that fetched 8 / 4 bytes per lane straight into fragments and
+// re-read cat once per 128-column tile took 171 us, with 256-column tiles 97 us: hundreds of narrow load instructions per step and CU.
+// This one moves every byte ONCE per workgroup, 16 bytes per lane:
+//   * a workgroup (8 waves) owns all 256 input channels x 256 output columns over a slice of the rows, 64 rows per step;
+//   * wave w < 4 loads rows 16 w .. + 15 of cat (lane = 8 channels x 8 rows: eight 16-byte loads, two whole 512-byte rows per
+//     instruction), waves 4 .. 7 the same of dz5's 256 columns; an 8 x 8 transposition of 16-bit values in registers (32 byte-permutes)
+//     turns a lane's 8 rows x 8 channels into 8 fragment entries (8 rows of one channel each), written to LDS in fragment order;
+//   * after ONE barrier per step wave (wm, wn) reads its 4 + 2 fragments per k-step (conflict-free 16-byte reads) for a 128 x 64 tile:
+//     32 MFMAs per step and wave; LDS is double-buffered (2 x 64 KB), the next step's rows travel under the products.
+// Slices are added in ascending order by h16_partial_reduce_kernel (no atomics: the same bits every run).
 // ----------------------------------------------------------------------------------------------------------------
+#define DW_STEP_U4 (4 * 8 * 64)   // one operand of one 64-row step: [k-step 4][tile 8][lane 64] x 16 bytes = 32 KB
+
+// 8 rows x 8 sixteen-bit values (in[j] = the 8 values of row j) -> out[q] = the 8 rows of value q
+__device__ __forceinline__ void h16_transpose8x8(const u32x4 (&in)[8], u32x4 (&out)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            out[q][d] = __builtin_amdgcn_perm(in[2 * d + 1][q >> 1], in[2 * d][q >> 1], (q & 1) ? 0x07060302u : 0x05040100u);
+}
+
 template <bool AF32>
-__global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict__ cat_, const unsigned* __restrict__ dz5, int rows,
+__global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict__ cat_, const u16* __restrict__ dz5, int rows,
                                                          int rows_per_wg, float* __restrict__ P) {
+    extern __shared__ u32x4 dw_lds[];                  // [buffer 2][operand 2][DW_STEP_U4]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
-    const int n0 = blockIdx.x * 256 + 64 * wn;          // output columns n0 + 2 i + t
+    const int n0 = blockIdx.x * 256;
     const int rbeg = blockIdx.y * rows_per_wg, rend = min(rbeg + rows_per_wg, rows);
+    // loader role: operand (0 = cat, 1 = dz5), rows 16 piece + 8 hh + j of the step, values 8 c .. 8 c + 7
+    const int oper = wave >> 2, piece = wave & 3, c = lane & 31, hh = lane >> 5;
+    const int last = max(rend - 1, rbeg);
+    u32x4 in[8];
+    auto load = [&](int rb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + 16 * piece + 8 * hh + j;
+            const size_t rr = (size_t)min(row, last);
+            if (oper == 0) {
+                if constexpr (AF32) {
+                    const float* p = reinterpret_cast<const float*>(cat_) + rr * 256 + 8 * c;
+                    const float4 x = ld4(p), y = ld4(p + 4);
+                    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+                    in[j] = __builtin_bit_cast(u32x4, cvt8(v));
+                } else {
+                    in[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(cat_) + rr * 256 + 8 * c);
+                }
+            } else {
+                in[j] = *reinterpret_cast<const u32x4*>(dz5 + rr * 1024 + n0 + 8 * c);
+                if (row >= rend) in[j] = u32x4{0u, 0u, 0u, 0u};   // (a row past the slice contributes zeros)
+            }
+        }
+    };
+    // fragment entry of value q of this lane: k-step = piece, tile = c >> 2, lane (i = 8 (c & 3) + q, h = hh).  Entry L of tile T sits at
+    // position L ^ T of the tile's 64: one write instruction (fixed q) then spreads its 64 lanes over all 16-byte bank groups -- in
+    // lane order every lane of it landed on two of the sixteen (a 32-way conflict: the first version of this kernel took 99 us)
+    const int wr_tile = c >> 2;
+    const int wr_base = oper * DW_STEP_U4 + (piece * 8 + wr_tile) * 64;
+    const int wr_lane = 32 * hh + 8 * (c & 3);
+    auto deposit = [&](int buf) {
+        u32x4 out[8];
+        h16_transpose8x8(in, out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dw_lds[buf * 2 * DW_STEP_U4 + wr_base + ((wr_lane + q) ^ wr_tile)] = out[q];
+    };
     f32x16 acc[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -725,48 +777,43 @@ __global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict_
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
-    const int last = max(rend - 1, rbeg);
-    float4 an[8];
-    uint2 an16[8];
-    unsigned bn_[8];
-    auto load = [&](int rb) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = rb + 8 * h + j;
-            const size_t rr = (size_t)min(row, last);
-            if constexpr (AF32) an[j] = ld4(reinterpret_cast<const float*>(cat_) + rr * 256 + 128 * wm + 4 * i);
-            else an16[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(cat_) + rr * 256 + 128 * wm + 4 * i);
-            bn_[j] = row < rend ? dz5[rr * 512 + (n0 >> 1) + i] : 0u;     // (a row past the slice contributes zeros)
-        }
-    };
-    if (rbeg < rend) load(rbeg);
-    for (int rb = rbeg; rb < rend; rb += 16) {
-        bf16x8 a[4], b[2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (AF32) {
-                a[0][j] = (__bf16)an[j].x, a[1][j] = (__bf16)an[j].y, a[2][j] = (__bf16)an[j].z, a[3][j] = (__bf16)an[j].w;
-            } else {
-                a[0][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].x & 0xffffu)), a[1][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].x >> 16));
-                a[2][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].y & 0xffffu)), a[3][j] = __builtin_bit_cast(__bf16, (u16)(an16[j].y >> 16));
-            }
-            b[0][j] = __builtin_bit_cast(__bf16, (u16)(bn_[j] & 0xffffu)), b[1][j] = __builtin_bit_cast(__bf16, (u16)(bn_[j] >> 16));
-        }
-        if (rb + 16 < rend) load(rb + 16);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(a[q], b[t], acc[q][t]);
+    if (rbeg < rend) {
+        load(rbeg);
+        deposit(0);
     }
-    // D: lane (i', h'), register r of (q, t) = dW5[channel 128 wm + 4 mfma_row(r, h') + q][column n0 + 2 i' + t]
-    float* o = P + (size_t)blockIdx.y * 256 * 1024;
+    __syncthreads();
+    int buf = 0;
+    for (int rb = rbeg; rb < rend; rb += 64, buf ^= 1) {
+        const bool more = rb + 64 < rend;
+        if (more) load(rb + 64);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4* As = dw_lds + buf * 2 * DW_STEP_U4;
+        const u32x4* Bs = As + DW_STEP_U4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = __builtin_bit_cast(bf16x8, As[(ks * 8 + 4 * wm + q) * 64 + (lane ^ (4 * wm + q))]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t] = __builtin_bit_cast(bf16x8, Bs[(ks * 8 + 2 * wn + t) * 64 + (lane ^ (2 * wn + t))]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(a[q], b[t], acc[q][t]);
+        }
+        if (more) deposit(buf ^ 1);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
+        __syncthreads();
+    }
+    // D: lane (i, h), register r of (q, t) = dW5[channel 128 wm + 32 q + mfma_row(r, h)][column n0 + 64 wn + 32 t + i]
+    const int i = lane & 31, h = lane >> 5;
+    float* o = P + (size_t)blockIdx.y * 256 * 1024 + n0 + 64 * wn + i;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ch = 128 * wm + 4 * mfma_row(r, h) + q;
-            *reinterpret_cast<float2*>(o + (size_t)ch * 1024 + n0 + 2 * i) = make_float2(acc[q][0][r], acc[q][1][r]);
+            const int ch = 128 * wm + 32 * q + mfma_row(r, h);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o[(size_t)ch * 1024 + 32 * t] = acc[q][t][r];
         }
 }
 
@@ -953,11 +1000,18 @@ extern "C" int epc_h16_conv5_dw(const void* cat, int cat_is_bf16, const void* dz
     EPC_CHECK_ARG(h16_aligned16(cat) && h16_aligned16(dz5) && h16_aligned16(dW5) && h16_aligned16(scratch), "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int S = h16_dw5_splits(rows);
-    const int rows_per_wg = ((rows + S - 1) / S + 15) / 16 * 16;
+    const int rows_per_wg = ((rows + S - 1) / S + 63) / 64 * 64;
+    const size_t lds = (size_t)2 * 2 * DW_STEP_U4 * sizeof(u32x4);     // 128 KB
+    const void* fn = cat_is_bf16 ? reinterpret_cast<const void*>(h16_dw5_kernel<false>) : reinterpret_cast<const void*>(h16_dw5_kernel<true>);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        epc_set_error("epc_h16_conv5_dw: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
     if (cat_is_bf16)
-        hipLaunchKernelGGL(h16_dw5_kernel<false>, dim3(4, S), dim3(512), 0, st, cat, (const unsigned*)dz5, rows, rows_per_wg, (float*)scratch);
+        hipLaunchKernelGGL(h16_dw5_kernel<false>, dim3(4, S), dim3(512), lds, st, cat, (const u16*)dz5, rows, rows_per_wg, (float*)scratch);
     else
-        hipLaunchKernelGGL(h16_dw5_kernel<true>, dim3(4, S), dim3(512), 0, st, cat, (const unsigned*)dz5, rows, rows_per_wg, (float*)scratch);
+        hipLaunchKernelGGL(h16_dw5_kernel<true>, dim3(4, S), dim3(512), lds, st, cat, (const u16*)dz5, rows, rows_per_wg, (float*)scratch);
     const long per = 256 * 1024;
     hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), 1), dim3(256), 0, st, (const float*)scratch, S, per, dW5);
     EPC_CHECK_LAUNCH();

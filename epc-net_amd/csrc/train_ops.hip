@@ -876,7 +876,7 @@ static void launch_moments_finalize(const float* stats, int tiles, int N, int ro
                        st, stats, tiles, N, rows, tile_rows, bias, mean, var, group_rows);
 }
 
-// library-internal (conv5_f32.hip: epc_conv5_train_fwd leaves partials in the same (S1, S2, pivot) form)
+// library-internal (train_head16.hip leaves partials in the same (S1, S2, pivot) form)
 int epc_moments_finalize_launch(const float* stats, int tiles, int N, int rows, int tile_rows, const float* bias, float* mean,
                                 float* var, void* stream, int group_rows) {
     launch_moments_finalize(stats, tiles, N, rows, tile_rows, bias, mean, var, (hipStream_t)stream, group_rows);

@@ -3,7 +3,7 @@
 The reference is single-process / single-GPU; this is new, MI355X-first work:
 
   * inference BN uses stored statistics, so every cloud's descriptor is independent -> clouds are sharded over the
-    ranks with NO data-path collective during extraction (``shard_bounds``, ``extract_shard``);
+    ranks with NO data-path collective during extraction (``shard_bounds``; retrieval.evaluate_sharded);
   * retrieval needs every query to see the whole database -> ONE all-gather of the (n_r, 256) f32 descriptor shards
     (``all_gather_rows``; RCCL over xGMI when the backend is "nccl", gloo in the CPU tests).  An Oxford-scale database
     is ~10 MB, i.e. latency-bound: a single fused all-gather of equal-sized (padded) shards, not a ring of small sends;
@@ -103,14 +103,6 @@ def all_gather_var_rows(local: torch.Tensor, sizes: Sequence[int]) -> torch.Tens
     if min(sizes) == m:
         return out
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(ws)], dim=0)
-
-
-def extract_shard(extract: Callable[[object], torch.Tensor], clouds) -> Tuple[torch.Tensor, int]:
-    """Run ``extract`` (e.g. ``lambda x: engine.forward(x)``) on this rank's shard of ``clouds`` (n, N, 3)."""
-    rank, ws = world()
-    n = len(clouds)
-    a, b = shard_bounds(n, rank, ws)
-    return extract(clouds[a:b]), n
 
 
 def sharded_knn(database_local: torch.Tensor, n_db: int, queries_local: torch.Tensor, n_q: int, k: int,

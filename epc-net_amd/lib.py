@@ -38,13 +38,13 @@ EPC_STATUS_FP16_RANGE = 2
 EXPORTS = [
     "epc_last_error", "epc_version", "epc_net_packed_bytes", "epc_net_pack_weights", "epc_net_workspace_bytes",
     "epc_net_forward", "epc_net_forward_overlapped", "epc_net_last_status", "epc_conv5_assign_f32_fwd",
-    "epc_vlad_aggregate_f32_fwd", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
+    "epc_vlad_aggregate_f32_fwd", "epc_knn_topk", "epc_knn_topk_conv1", "epc_knn_topk_form", "epc_knn_topk_conv1_form", "epc_knn_mask", "epc_conv1_fwd", "epc_proxyconv_block_fwd",
     "epc_conv5_assign_fwd", "epc_vlad_aggregate_fwd", "epc_vlad_head_workspace_bytes", "epc_vlad_head_fwd",
     "epc_conv5_maxpool_fwd", "epc_fc_head_fwd", "epc_pairwise_topk", "epc_pairwise_topk_workspace_bytes",
     "epc_pairwise_topk_ws", "epc_net_packed_offset",
     "epc_profile_create", "epc_profile_destroy", "epc_net_forward_profiled", "epc_profile_elapsed_ms",
     "epc_morton_sort",
-    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_conv5_train_pack_floats", "epc_conv5_train_stats_floats", "epc_conv5_train_fwd", "epc_gemm_bf16_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
+    "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_gemm_bf16_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
     "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
     "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64",
@@ -97,6 +97,8 @@ _lib.epc_net_forward.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_
 _lib.epc_net_forward_overlapped.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, POINTER(_P), c_int]
 _lib.epc_knn_topk.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P]
 _lib.epc_knn_topk_conv1.argtypes = [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P]
+_lib.epc_knn_topk_form.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, c_int, _P]
+_lib.epc_knn_topk_conv1_form.argtypes = [_P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]
 _lib.epc_net_last_status.argtypes = [POINTER(EpcCfg), _P, c_int, POINTER(c_int32), _P]
 _lib.epc_knn_mask.argtypes = [_P, _P, c_int, c_int, _P, _P]
 _lib.epc_conv1_fwd.argtypes = [_P, _P, c_int, _P, _P, _P]
@@ -168,11 +170,6 @@ _lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
 _lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
-_lib.epc_conv5_train_pack_floats.argtypes = [c_int]
-_lib.epc_conv5_train_pack_floats.restype = ctypes.c_size_t
-_lib.epc_conv5_train_stats_floats.argtypes = [c_int]
-_lib.epc_conv5_train_stats_floats.restype = ctypes.c_size_t
-_lib.epc_conv5_train_fwd.argtypes = [_P, c_int, _P, _P, c_int, _P, _P, _P, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P]
 _lib.epc_vlad_df_tail_partial_floats.argtypes = [c_int, c_int]
 _lib.epc_vlad_df_tail_partial_floats.restype = ctypes.c_size_t
 _lib.epc_vlad_df_tail.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, ctypes.c_size_t, _P]

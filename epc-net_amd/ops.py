@@ -280,27 +280,6 @@ def tail_link_of(f):
     return getattr(f, "_epc_tail_link", None)
 
 
-# conv5's training forward through epc_conv5_train_fwd instead of the generic statistics GEMM.  OFF: built in round 4 (the inference
-# kernels' shape: rows resident as split-fp16 fragments, weights streamed through a ring of LDS stages, the grid launched in slices
-# that fit the chip), parity-green (tests/test_gpu_train_ops.py), and no faster -- 129 + 77 us in two slices + 12 us of packing
-# against 206-228 us for the GEMM at 18 x 4096 rows.
-CONV5_TRAIN_KERNEL = False
-
-
-def _conv5_train_fwd(x, W, b):
-    rows, cin = x.shape
-    z = torch.empty((rows, 1024), dtype=torch.float32, device=x.device)
-    mean = torch.empty(1024, dtype=torch.float32, device=x.device)
-    var = torch.empty(1024, dtype=torch.float32, device=x.device)
-    pf = L.lib().epc_conv5_train_pack_floats(cin)
-    sf = L.lib().epc_conv5_train_stats_floats(rows)
-    scratch = _splitk_ws(pf + sf, x.device)
-    L.check(L.lib().epc_conv5_train_fwd(x.data_ptr(), cin, W.data_ptr(), b.data_ptr() if b is not None else None, rows, z.data_ptr(),
-                                        mean.data_ptr(), var.data_ptr(), scratch.data_ptr(), pf, scratch.data_ptr() + 4 * pf, sf,
-                                        _st()))
-    return z, mean, var
-
-
 class LinearBatchNormTrain(torch.autograd.Function):
     """Linear followed by BatchNormTrain (utils/tf_util.py:94-106 in training mode) as ONE node: the batch statistics come out
     of the GEMM's epilogue instead of a pass over z.  ``rownorm``: conv5's tail -- l2_normalize(relu(bn(z))) over the channels
@@ -314,11 +293,7 @@ class LinearBatchNormTrain(torch.autograd.Function):
         ctx.link = link if rownorm else None
         # f16x3: the (activation, weight) scale exponents of the split-fp16 form, passed by the call site that knows its operands
         # are BatchNorm'd block outputs (conv5 of either network: tf_util.conv1d_l2_normalized / conv1d with 1024 outputs)
-        if (rownorm and CONV5_TRAIN_KERNEL and _GEMM_PRECISION == "bf16x6" and x.shape[1] == 256 and W.shape[1] == 1024
-                and x.shape[0] % 64 == 0 and W.is_contiguous()):
-            z, mean, var = _conv5_train_fwd(x, W, b)        # conv5 in the inference kernel's shape (epc_conv5_train_fwd)
-        else:
-            z, mean, var = _gemm_with_stats(x, W, b, f16x3)
+        z, mean, var = _gemm_with_stats(x, W, b, f16x3)
         rows, C = z.shape
         if rownorm:
             y = torch.empty_like(z)
@@ -465,13 +440,11 @@ class KnnGraph:
         self.kth, self.idx, self.cnt = tf_util.knn_index(self.xyz)
         self._transposed = None
         self._overflow = None
-        self._pending = None
 
     def overflow(self):
         """(ovf_cnt (clouds,), ovf_list (clouds, n)): per cloud the points whose own list overflowed (cnt > cap: exact ties of
         duplicated / zero-padded clouds) -- the transposed graph does not list them, the chain's gather backward visits them with
         the exact test (epc_knn_overflow_lists).  Built on first use."""
-        self.join()
         if self._overflow is None:
             dev = self.xyz.device
             oc = torch.empty(self.num_clouds, dtype=torch.int32, device=dev)
@@ -484,7 +457,6 @@ class KnnGraph:
     def transposed(self):
         """(rdeg, roff, rlist): for every point the points that list it (epc_knn_transpose), built on first use -- the
         backward of every block of a step gathers over it."""
-        self.join()
         if self._transposed is None:
             rdeg, roff, cursor, rlist, oc, ol = self._build_transposed()
             L.check(L.lib().epc_knn_transpose(self.idx.data_ptr(), self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n,
@@ -506,51 +478,6 @@ class KnnGraph:
         self._scratch = cursor
         return rdeg, roff, cursor, rlist, oc, ol
 
-    def prefetch_backward_lists(self):
-        """Start the transposed graph and the overflow lists -- needed by the BACKWARD only -- on a side stream now, under the forward
-        (training steps: tf_util.proxyconv_backbone).  Their kernels are small and latency-bound (count, scan, fill, sort: 90 us of a
-        step's critical path when run in line); the buffers are allocated on the calling stream, which joins in ``join`` -- at the
-        first use, or when a data-parallel step cuts its capture (training.TrainStep)."""
-        if self._transposed is not None or self._pending is not None:
-            return
-        dev = self.xyz.device
-        rdeg, roff, cursor, rlist, oc, ol = self._build_transposed()
-        cur = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
-        side.wait_stream(cur)                      # the lists of this graph are complete on the calling stream
-        with torch.cuda.stream(side):
-            L.check(L.lib().epc_knn_transpose(self.idx.data_ptr(), self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n,
-                                              rdeg.data_ptr(), roff.data_ptr(), cursor.data_ptr(), rlist.data_ptr(), _st()))
-            L.check(L.lib().epc_knn_overflow_lists(self.cnt.data_ptr(), L.EPC_KNN_CAP, self.num_clouds, self.n, oc.data_ptr(),
-                                                   ol.data_ptr(), _st()))
-        self._transposed, self._overflow, self._pending = (rdeg, roff, rlist), (oc, ol), side
-        _PENDING.append(self)
-
-    def join(self):
-        """The calling stream waits for the side work of ``prefetch_backward_lists`` (no-op when there is none)."""
-        if self._pending is not None:
-            torch.cuda.current_stream(self.xyz.device).wait_stream(self._pending)
-            self._pending = None
-            if self in _PENDING:
-                _PENDING.remove(self)
-
-
-_SIDE = {}
-_PENDING = []
-
-
-def _side_stream(dev):
-    s_ = _SIDE.get(dev.index)
-    if s_ is None:
-        s_ = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
-    return s_
-
-
-def join_side_work():
-    """Join every kNN graph's pending side-stream work into the calling stream (a step that ends a HIP-graph capture between its
-    forward and its backward must leave no forked stream behind)."""
-    for g in list(_PENDING):
-        g.join()
 
 
 class NeighbourMean(torch.autograd.Function):

@@ -184,15 +184,21 @@ class TrainStep:
                 raise
             tap = tf_util.BACKBONE_TAP
             if between is not None and tap is not None and tap.requires_grad:
-                below = set(id(self.store.vars[n]) for n in names if self._below_tap(n))
-                head = [n for n in names if id(self.store.vars[n]) not in below]
+                # Which variables lie below the cut is a property of the GRAPH: those the backbone's output depends on
+                # (_split_at_tap walks the tape once per model structure).  A variable on neither side of the loss gets zeros;
+                # one on BOTH sides (shared above and below the cut) cannot be split and raises.
+                head, below = self._split_at_tap(loss, tap, names)
                 got = torch.autograd.grad(loss, [tap] + [self.store.vars[n] for n in head], allow_unused=True)
                 with torch.no_grad():
                     head_grads = [g if g is not None else ops.const_zeros_like(self.store.vars[n]) for n, g in zip(head, got[1:])]
-                    ops.join_side_work()      # (a capture may end inside `between`: no forked stream may be left behind)
                     between(head, head_grads)
                 if got[0] is not None:
                     torch.autograd.backward([tap], [got[0]])
+                    # every variable classified "below" must have been reached by the second phase (a mis-split would otherwise
+                    # freeze a layer silently: its missing gradient would be exchanged and applied as zeros)
+                    missing = [n for n in below if self.store.vars[n].grad is None and not self._bias_before_batchnorm(n)]
+                    if missing:
+                        raise RuntimeError("backward cut at the backbone's output: no gradient reached %s" % missing)
                 for n, g in zip(head, head_grads):
                     self.store.vars[n].grad = g
             else:
@@ -209,9 +215,45 @@ class TrainStep:
             tf_util.flush_ema_updates(SLIM_DECAY, bn_decay if bn_decay is not None else 0.9, scope=self.outer or None)
         return loss, grads
 
+    def _split_at_tap(self, loss, tap, names):
+        """(head, below): the trainable names whose gradient is formed above / below the backbone's output ``tap`` in THIS graph.
+        below = the variables ``tap`` depends on (reachable from tap.grad_fn); head = the rest.  A variable reachable from the
+        loss WITHOUT passing through ``tap`` and also from ``tap`` itself would need both phases' contributions added: not a
+        structure any shipped model has, refused instead of silently mis-split.  Cached per set of names (the walk costs a few
+        hundred nodes); ``_below_tap`` answers from the cache for the exchange layout."""
+        def leaves_under(root_fn, stop=None):
+            seen, out, stack = set(), set(), [root_fn]      # (the node OBJECTS are kept: the id of a collected wrapper is reused)
+            while stack:
+                fn = stack.pop()
+                if fn is None or fn in seen or fn is stop:
+                    continue
+                seen.add(fn)
+                v = getattr(fn, "variable", None)          # AccumulateGrad node of a leaf
+                if v is not None:
+                    out.add(id(v))
+                stack.extend(f for f, _ in fn.next_functions)
+            return out
+        under_tap = leaves_under(tap.grad_fn)
+        above = leaves_under(loss.grad_fn, stop=tap.grad_fn)
+        both = [n for n in names if id(self.store.vars[n]) in under_tap and id(self.store.vars[n]) in above]
+        if both:
+            raise RuntimeError("variables used on both sides of the backbone's output cannot be split by the backward cut: %s" % both)
+        below = [n for n in names if id(self.store.vars[n]) in under_tap]
+        head = [n for n in names if id(self.store.vars[n]) not in under_tap]
+        self._below_names = (tuple(names), frozenset(below))
+        return head, below
+
+    def _bias_before_batchnorm(self, name: str) -> bool:
+        """A conv bias in front of a training-mode BatchNorm: its gradient is exactly zero and the operators leave it undefined."""
+        return name.endswith("/biases")
+
     def _below_tap(self, name: str) -> bool:
-        """Is this variable's gradient formed BELOW the backbone's output (by the backbone's backward)?  The 64-channel layers:
-        conv1 .. conv4_b (conv5 and everything under VLAD/ sit above the cut)."""
+        """Is this variable's gradient formed BELOW the backbone's output?  Answered from the last graph walk (_split_at_tap);
+        before any cut step has run, from the layer names of the shipped models (the 64-channel layers conv1 .. conv4_b) -- the
+        exchange layout is rebuilt when the walk disagrees."""
+        cached = getattr(self, "_below_names", None)
+        if cached is not None and name in cached[0]:
+            return name in cached[1]
         rel = name[len(self.outer) + 1:] if self.outer and name.startswith(self.outer + "/") else name
         parts = rel.split("/")
         return len(parts) >= 2 and parts[0] != "VLAD" and parts[1].startswith("conv") and not parts[1].startswith("conv5")
@@ -245,7 +287,7 @@ class TrainStep:
         names = self.trainable_names()
         stats = self._statistics()
         tensors = [self.store.vars[n] for n in names]
-        key = tuple((n, tuple(x.shape)) for n, x in zip(names, tensors)) + tuple(tuple(x.shape) for x in stats)
+        key = (tuple((n, tuple(x.shape), self._below_tap(n)) for n, x in zip(names, tensors)) + tuple(tuple(x.shape) for x in stats))
         ex = self._exchange
         if ex is None or ex["key"] != key or ex["flat"].device != tensors[0].device:
             head = [i for i, n in enumerate(names) if not self._below_tap(n)]
@@ -305,25 +347,22 @@ class TrainStep:
         # Data parallelism over tuples: every rank its own tuple and batch statistics; gradients and moving statistics
         # are averaged so that every rank applies the same update.  The head's gradients travel under the backbone's backward.
         import torch.distributed as dist
-        self._ensure_exchange()
-        ex = self._exchange_layout()
         pending = []
 
         def between(head_names, head_grads):
+            ex = self._exchange_layout()      # (after the graph walk of this step: the layout follows the split it found)
             self._pack_head(ex, head_names, head_grads)
             pending.append(dist.all_reduce(ex["flat"][:ex["head_end"]], op=dist.ReduceOp.SUM, async_op=True))
 
         loss, grads = self._forward_backward(query, positives, negatives, other_neg, bn_decay,
                                              between=between if self.overlap_exchange else None)
+        ex = self._exchange_layout()
         self._pack_rest(ex, grads, bool(pending))
         self._exchange_rest(ex, bool(pending))
         for w in pending:
             w.wait()
         self._apply(self._unpack_mean(ex, D.world()[1]), lr, t)
         return loss
-
-    def _ensure_exchange(self):
-        pass
 
     def _average_over_ranks(self, grads):
         """One flat all-reduce of a list of gradients (trainable_names() order) and of the moving statistics: the uncut form of the
@@ -361,7 +400,6 @@ class TrainStep:
                 dst.copy_(src)
             g["lr_t"].fill_(self._lr_t(lr, t))
             g["bn_decay"].fill_(bn_decay)
-            ex = self._exchange_layout() if dp else None
             # warm-up on a side stream (lazy allocations, kernel attributes), on a snapshot of the state that is restored.
             # No collective here: every rank restores its own snapshot, so the ranks stay in step.
             snap = [x.detach().clone() for x in self._state_tensors()]
@@ -370,13 +408,14 @@ class TrainStep:
             with torch.cuda.stream(side):
                 cut = []
                 loss, grads = self._forward_backward(*g["in"], g["bn_decay"],
-                                                     between=(lambda hn, hg: (self._pack_head(ex, hn, hg), cut.append(1)))
+                                                     between=(lambda hn, hg: (self._pack_head(self._exchange_layout(), hn, hg), cut.append(1)))
                                                      if dp and self.overlap_exchange else None)
                 if dp:
-                    self._pack_rest(ex, grads, bool(cut))
-                    grads = self._unpack_mean(ex, 1)
+                    self._pack_rest(self._exchange_layout(), grads, bool(cut))
+                    grads = self._unpack_mean(self._exchange_layout(), 1)
                 self._apply(grads, g["lr_t"], t)
             torch.cuda.current_stream(dev).wait_stream(side)
+            ex = self._exchange_layout() if dp else None      # (after the warm-up's graph walk: the split the captures will see)
             with torch.no_grad():
                 for x, s0 in zip(self._state_tensors(), snap):
                     x.copy_(s0)
@@ -399,25 +438,34 @@ class TrainStep:
                 cap = torch.cuda.Stream(device=dev)
                 cap.wait_stream(torch.cuda.current_stream(dev))
 
+                open_graph = [None]        # the graph whose capture is open RIGHT NOW: the only one a failure may end
+
+                def begin(graph, **kw):
+                    graph.capture_begin(**kw)
+                    open_graph[0] = graph
+
+                def end():
+                    graph, open_graph[0] = open_graph[0], None
+                    if graph is not None:
+                        graph.capture_end()
+
                 def between(hn, hg):
                     self._pack_head(ex, hn, hg)
-                    g["graph"].capture_end()
-                    g["graph_mid"].capture_begin(pool=g["graph"].pool())
+                    end()
+                    begin(g["graph_mid"], pool=g["graph"].pool())
                     g["cut"] = True
 
                 with torch.cuda.stream(cap):
-                    g["graph"].capture_begin()
                     try:
+                        begin(g["graph"])
                         g["loss"], grads = self._forward_backward(*g["in"], g["bn_decay"],
                                                                   between=between if self.overlap_exchange else None)
                         self._pack_rest(ex, grads, g["cut"])
-                    finally:
-                        (g["graph_mid"] if g["cut"] else g["graph"]).capture_end()
-                    g["graph2"].capture_begin(pool=g["graph"].pool())
-                    try:
+                        end()
+                        begin(g["graph2"], pool=g["graph"].pool())
                         self._apply(self._unpack_mean(ex, ws), g["lr_t"], t)
                     finally:
-                        g["graph2"].capture_end()
+                        end()
                 torch.cuda.current_stream(dev).wait_stream(cap)
                 g["ex"] = ex
             self._graph = g

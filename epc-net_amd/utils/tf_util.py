@@ -88,16 +88,20 @@ def pairwise_distance_mask(pc: torch.Tensor, k: int = 20) -> torch.Tensor:
     return mask
 
 
-def knn_index(pc: torch.Tensor):
-    """Index form of the same graph: (kth (B,N) f32, idx (B,N,32) int32 ascending, cnt (B,N) int32)."""
+def knn_index(pc: torch.Tensor, form: Optional[int] = None):
+    """Index form of the same graph: (kth (B,N) f32, idx (B,N,32) int32 ascending, cnt (B,N) int32).
+    ``form`` (tests / timing scripts): 0 / 1 = the one-lane / four-lane form of the kernel (epc_knn_topk_form); None = the product's."""
     L.require_gpu()
     pc = pc.contiguous().float()
     B, N, _ = pc.shape
     idx = torch.empty((B, N, L.EPC_KNN_CAP), dtype=torch.int32, device=pc.device)
     cnt = torch.empty((B, N), dtype=torch.int32, device=pc.device)
     kth = torch.empty((B, N), dtype=torch.float32, device=pc.device)
-    L.check(L.lib().epc_knn_topk(L.ptr(pc), B, N, L.EPC_KNN_CAP, L.ptr(idx), L.ptr(cnt), L.ptr(kth),
-                                 L.current_stream()))
+    if form is None:
+        L.check(L.lib().epc_knn_topk(L.ptr(pc), B, N, L.EPC_KNN_CAP, L.ptr(idx), L.ptr(cnt), L.ptr(kth), L.current_stream()))
+    else:
+        L.check(L.lib().epc_knn_topk_form(L.ptr(pc), B, N, L.EPC_KNN_CAP, L.ptr(idx), L.ptr(cnt), L.ptr(kth), int(form),
+                                          L.current_stream()))
     return kth, idx, cnt
 
 
@@ -293,11 +297,6 @@ USE_CHAIN = True
 # data-parallel step cuts its backward in two, so that the exchange of the head's gradients (17.8 of EPC-Net's 18.8 MB: hidden1_weights
 # and conv5) travels while the backbone's backward runs (training.TrainStep).
 BACKBONE_TAP = None
-# The transposed graph and the overflow lists are needed by the backward only; starting them on a side stream under the forward
-# (ops.KnnGraph.prefetch_backward_lists) was measured and does NOT pay -- 3.17-3.18 ms per step with it, 3.14-3.15 without, same box:
-# the forward's kernels already hold every CU, a forked stream inside the HIP graph adds dependencies, nothing overlaps.  Off.
-PREFETCH_BACKWARD_LISTS = False
-
 
 def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None):
     """The ProxyConv backbone of models/epc-net.py:66-134 (four blocks) / models/epc-net-l.py:62-83 (two) up to the concat:
@@ -319,8 +318,6 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
             outs.append(inp)
         return torch.cat(outs, dim=-1)
     L.require_gpu()
-    if PREFETCH_BACKWARD_LISTS:
-        graph.prefetch_backward_lists()  # the transposed graph (backward only) starts now, on a side stream, under the forward
     params, bns = [], []          # bns: (scope, gamma, beta, ema_mean, ema_var) in the node's output order
     w1 = b1 = None
     for b in range(1, nblocks + 1):

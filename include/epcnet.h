@@ -190,6 +190,12 @@ int epc_conv1_fwd(const float* xyz, const void* packed_conv1, int num_points_tot
  * entry any consumer reads is a valid row number. */
 int epc_knn_topk_conv1(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
                        const void* packed_conv1, float* x, void* x16, int32_t* status, void* stream);
+/* Test / tuning entry points: epc_knn_topk and epc_knn_topk_conv1 with the form of the LDS kernel (num_points <= 8192) chosen by the
+ * caller -- form 0 = one lane per query, 1 = four lanes per query (what the two entry points above run).  Both forms leave bit-identical
+ * lists, counts and thresholds (tests/test_gpu_knn_forms.py); an explicit argument, because the library reads no environment. */
+int epc_knn_topk_form(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth, int form, void* stream);
+int epc_knn_topk_conv1_form(const float* xyz, int num_clouds, int n, int cap, void* idx, int idx_u16, int32_t* cnt, float* kth,
+                            const void* packed_conv1, float* x, void* x16, int32_t* status, int form, void* stream);
 
 /* models/epc-net.py:70-83 (and :87-100, :104-117, :121-132): one ProxyConv block after its leading conv:
  *   xm = (sum_{j in nbr(i)} x_j) / knn ; t = xm - x ; t = conv_a(t) ; t = conv_b(t) ; out = t + xm ;
@@ -320,16 +326,7 @@ int epc_gemm_bf16_stats(const float* A, const float* B, float* C, const float* b
 int epc_gemm_f16x3_stats(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                          long sBk, long sBn, int ldc, int a_scale_log2, int b_scale_log2, float* stats, size_t stats_floats,
                          float* mean, float* var, void* stream);
-/* conv5 of the training forward as a kernel of its own (models/epc-net.py:136 with is_training; utils/tf_util.py:94-106): z (rows, 1024)
- * = x (rows, 256) W (256, 1024) + b and the batch moments of z (mean; POPULATION variance, tf.nn.moments) for the BatchNorm that
- * follows -- what epc_gemm_f16x3_stats computes for these shapes, in the inference conv5 kernel's form: the rows resident as scaled
- * split-fp16 fragments (three products, 2^-21; no range restriction: every row and every weight column carries its own power-of-two
- * scale), W packed into fragment order by the call (it changes every step) and streamed through LDS.  rows a multiple of 64.
- * pack / stats: scratch of epc_conv5_train_pack_floats(256) / epc_conv5_train_stats_floats(rows) floats, 16-byte aligned. */
-size_t epc_conv5_train_pack_floats(int cin);
-size_t epc_conv5_train_stats_floats(int rows);
-int epc_conv5_train_fwd(const float* x, int cin, const float* W, const float* b, int rows, float* z, float* mean, float* var,
-                        float* pack, size_t pack_floats, float* stats, size_t stats_floats, void* stream);
+
 
 /* Same interface, operands rounded to ONE bf16 value each (f32 data in memory, f32 accumulation, one product): the
  * "bf16" training configuration of BASELINE.json configs[2].  2^-9 relative per operand. */

@@ -16,11 +16,11 @@ g = torch.Generator().manual_seed(0)
 mk = lambda p: (torch.rand((1, p, 4096, 3), generator=g) * 2 - 1).to(dev)
 q, pos, ng, oth = mk(1), mk(2), mk(neg), mk(1)
 use_graph = os.environ.get("GRAPH", "1") == "1"
-for _ in range(30):   # warm-up: graph capture, lazy allocations, and the dispatch stall a fresh process can see
+for _ in range(int(os.environ.get("WARM", "30"))):   # warm-up: graph capture, lazy allocations, and the dispatch stall a fresh process can see
     loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0, graph=use_graph)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 60
+K = int(os.environ.get("STEPS", "60"))
 for _ in range(K):
     loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0, graph=use_graph)
 torch.cuda.synchronize()

@@ -1,9 +1,8 @@
 """The two forms of the LDS kNN kernel -- one lane per query (knn_topk_culled_kernel) and four lanes per query
 (knn_topk_quad_kernel, the default) -- against the oracle's lists (utils/tf_util.py:647-666 in index form): thresholds,
 counts and list entries bit for bit, on both, for ordinary, tied, padded and ragged clouds, sorted or not, conv1 fused or not.
-EPC_KNN_QUAD=0 / 1 forces a form (read by the library at every launch)."""
+The form is an explicit argument of the test entry points epc_knn_topk_form / epc_knn_topk_conv1_form (include/epcnet.h)."""
 import ctypes
-import os
 
 import numpy as np
 import pytest
@@ -20,15 +19,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["0", "1"], ids=["one_lane", "four_lanes"])
+@pytest.fixture(params=[0, 1], ids=["one_lane", "four_lanes"])
 def form(request):
-    old = os.environ.get("EPC_KNN_QUAD")
-    os.environ["EPC_KNN_QUAD"] = request.param
-    yield request.param
-    if old is None:
-        del os.environ["EPC_KNN_QUAD"]
-    else:
-        os.environ["EPC_KNN_QUAD"] = old
+    return request.param
 
 
 def _check(pc, kth, idx, cnt):
@@ -52,7 +45,7 @@ def test_both_forms_give_the_oracle_lists(dev, form, kind, n, sort):
     x = torch.from_numpy(pc).to(dev)
     if sort and n % 32 == 0:
         x = ops.morton_sort(x)
-    kth, idx, cnt = tf_util.knn_index(x)
+    kth, idx, cnt = tf_util.knn_index(x, form=form)
     _check(x.cpu().numpy(), kth.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy())
 
 
@@ -70,26 +63,18 @@ def test_forms_agree_with_conv1_fused_and_short_lists(dev):
     xyz = H.pkg("ops").morton_sort(torch.from_numpy(np.nan_to_num(pc)).to(dev))
     xyz[2, 17, 1] = float("nan")
     out = {}
-    old = os.environ.get("EPC_KNN_QUAD")
-    try:
-        for f in ("0", "1"):
-            os.environ["EPC_KNN_QUAD"] = f
-            idx = torch.zeros((nc, n, 32), dtype=torch.int16, device=dev)
-            cnt = torch.zeros((nc, n), dtype=torch.int32, device=dev)
-            kth = torch.zeros((nc, n), device=dev)
-            x32 = torch.zeros((nc * n, 64), device=dev)
-            x16 = torch.zeros((nc * n, 64), dtype=torch.float16, device=dev)
-            status = torch.zeros((nc,), dtype=torch.int32, device=dev)
-            L.check(lib.epc_knn_topk_conv1(xyz.data_ptr(), nc, n, 32, idx.data_ptr(), 1, cnt.data_ptr(), kth.data_ptr(), pk,
-                                           x32.data_ptr(), x16.data_ptr(), status.data_ptr(), L.current_stream()))
-            torch.cuda.synchronize()
-            out[f] = [t.cpu().numpy() for t in (idx, cnt, kth, x32, x16, status)]
-    finally:
-        if old is None:
-            del os.environ["EPC_KNN_QUAD"]
-        else:
-            os.environ["EPC_KNN_QUAD"] = old
-    a, b = out["0"], out["1"]
+    for f in (0, 1):
+        idx = torch.zeros((nc, n, 32), dtype=torch.int16, device=dev)
+        cnt = torch.zeros((nc, n), dtype=torch.int32, device=dev)
+        kth = torch.zeros((nc, n), device=dev)
+        x32 = torch.zeros((nc * n, 64), device=dev)
+        x16 = torch.zeros((nc * n, 64), dtype=torch.float16, device=dev)
+        status = torch.zeros((nc,), dtype=torch.int32, device=dev)
+        L.check(lib.epc_knn_topk_conv1_form(xyz.data_ptr(), nc, n, 32, idx.data_ptr(), 1, cnt.data_ptr(), kth.data_ptr(), pk,
+                                            x32.data_ptr(), x16.data_ptr(), status.data_ptr(), f, L.current_stream()))
+        torch.cuda.synchronize()
+        out[f] = [t.cpu().numpy() for t in (idx, cnt, kth, x32, x16, status)]
+    a, b = out[0], out[1]
     keep = [0, 1, 3, 4]
     assert np.array_equal(a[5], b[5]) and a[5][2] != 0 and not a[5][keep].any()
     for u, v in zip(a[:3], b[:3]):

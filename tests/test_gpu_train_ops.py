@@ -434,34 +434,6 @@ def test_tail_backward_inside_the_feature_gradient_product(dev, B, N):
         assert rel(a, c.grad) <= 3e-3 and rel(b, c.grad) <= 3e-3, "input %d vs float64: %.3e %.3e" % (i, rel(a, c.grad), rel(b, c.grad))
 
 
-@pytest.mark.parametrize("rows", [64, 4096 + 64, 18 * 1024, 22 * 4096])
-def test_conv5_training_forward_kernel(dev, rows):
-    """epc_conv5_train_fwd (conv5 of the training forward in the inference kernel's shape): z = x W + b and the batch moments of z
-    against float64 -- grids of one, several and all three slice widths, a channel whose mean is far above its spread
-    (the pivot-shifted sums) and rows / weight columns of very different magnitude (the per-row / per-column scales)."""
-    ops = H.pkg("ops")
-    g = torch.Generator().manual_seed(31)
-    x = torch.randn(rows, 256, dtype=torch.float64, generator=g)
-    x[::7] *= 300.0
-    x[3::11] *= 1e-3
-    W = torch.randn(256, 1024, dtype=torch.float64, generator=g) / 16
-    W[:, 5] *= 1e3
-    W[:, 9] *= 1e-4
-    b = torch.randn(1024, dtype=torch.float64, generator=g)
-    b[17] = 3000.0
-    zr = x @ W + b
-    z, mean, var = ops._conv5_train_fwd(x.float().to(dev).contiguous(), W.float().to(dev).contiguous(), b.float().to(dev))
-    zc = z.cpu().double()
-    scale = (x.abs() @ W.abs()) + b.abs()                       # the magnitude each entry's rounding is relative to
-    assert ((zc - zr).abs() / scale).max() <= 3e-6
-    # moments of the float32 rows the kernel wrote (what the BatchNorm normalises), and of the exact product
-    assert rel(mean, zr.mean(0)) <= 2e-6
-    v_ref = zr.var(0, unbiased=False)
-    assert ((var.cpu().double() - v_ref).abs() / v_ref.clamp_min(1e-30)).max() <= 2e-4
-    z2, m2, v2 = ops._conv5_train_fwd(x.float().to(dev).contiguous(), W.float().to(dev).contiguous(), b.float().to(dev))
-    assert torch.equal(z, z2) and torch.equal(mean, m2) and torch.equal(var, v2)
-
-
 def test_vlad_aggregate(dev):
     ops = H.pkg("ops")
     g = torch.Generator().manual_seed(4)
