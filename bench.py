@@ -89,6 +89,33 @@ def pkg(name=""):
     return importlib.import_module("epc-net_amd" + ("." + name if name else ""))
 
 
+# Floor of every inference stage IN ITS PRESENT GEOMETRY ("Floor models": the arithmetic behind each line), EPC-Net,
+# EPC_PRECISION_F32, 64 clouds x 4096 points, at the 2.04 GHz the chip holds under this load (GRBM_GUI_ACTIVE / duration of the profiled
+# launches).  A stage at its floor moves only with a different algorithm / fewer instructions / fewer bytes, not with tuning.
+SHADER_GHZ = 2.04
+
+
+def stage_floors_epc_net_f32_b64():
+    cus, simds = 256, 1024
+    clk = SHADER_GHZ * 1e9
+    # kNN: 75.1 M vector instructions per launch (SQ_INSTS_VALU, profiles/pmc_compute_current.json) at one wave-instruction per SIMD
+    # and four cycles: VALU issue is the only resource the kernel saturates
+    knn = 75.1e6 / simds * 4 / clk
+    # ProxyConv block: 20 gathered 256-byte rows per point = 1.34 GB through the vector L1 at 64 B / clk / CU, plus the skeleton the
+    # ablations of docs/HISTORY_r01_r02.md:654-666 leave when the gather is removed (weight-pack staging, MFMA chain, epilogue): 0.020 ms
+    block = 1.34e9 / (cus * 64) / clk + 0.020e-3
+    # conv5 + assignment: 4 rounds of one 8-wave workgroup per CU; per workgroup a 256-KB prologue at 9 B / clk / CU (one CU's miss
+    # queue at HBM latency), then 32 chunks of: 120 MFMAs x 16 cycles per wave, two waves per SIMD (3840 cycles of matrix pipe), the
+    # two waves' 1900-cycle epilogues of which the half that fits under the MFMA issue slots (the vector pipe is blocked 8 of 16 cycles
+    # per 16x16x32 MFMA) is hidden: 3840 + (3800 - 1920) cycles per chunk
+    conv5 = 4 * (256 * 1024 / 9.0 + 32 * (3840 + (3800 - 1920))) / clk
+    # aggregate: the 3-byte feature map + assignment fragments, 905 MB per launch, at the 6.3 TB/s a streaming read reaches
+    aggregate = 905e6 / 6.3e12
+    return {"sort": 0.012, "knn": round(knn * 1e3, 4), "conv1": 0.0, "block1": round(block * 1e3, 4), "block2": round(block * 1e3, 4),
+            "block3": round(block * 1e3, 4), "block4": round(block * 1e3, 4), "conv5": round(conv5 * 1e3, 4),
+            "aggregate": round(aggregate * 1e3, 4), "head": 0.020}
+
+
 def build_store(arch, device, seed):
     V = pkg("variables")
     st = V.reset_default_store(device=device, seed=seed)
@@ -352,6 +379,14 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
            "roofline": roofline,
            "stage_ms": {k: round(v, 4) for k, v in stage.items()},
            "pipeline_tflops": round(batch * steps / elapsed * FLOPS_PER_CLOUD[arch] / 1e12, 3)}
+    if arch == "epc-net" and precision == "f32" and batch == 64:
+        fl = stage_floors_epc_net_f32_b64()
+        res["stage_floor_ms"] = fl
+        res["stage_floor"] = {"sum_ms": round(sum(fl.values()), 4), "step_over_floor": round(elapsed / steps * 1e3 / sum(fl.values()), 3),
+                              "model": "per-stage floors of the present kernels' geometry at %.2f GHz: kNN = vector instructions / issue rate; "
+                                       "block = L1 gather bytes / 64 B/clk/CU + skeleton; conv5 = 4 rounds x (256-KB prologue at 9 B/clk/CU + "
+                                       "32 chunks x (MFMA issue + the epilogue share the MFMA issue slots do not hide)); aggregate = feat "
+                                       "bytes / 6.3 TB/s (DESIGN.md 4, Floor models)" % SHADER_GHZ}
     if overlapped is not None:
         res["overlapped"] = overlapped
     return res, elapsed
@@ -703,6 +738,8 @@ def main():
             "regions": head["regions"],
             "roofline": head["roofline"], "stage_ms": head["stage_ms"], "pipeline_tflops": head["pipeline_tflops"],
         }
+        if "stage_floor_ms" in head:
+            line["stage_floor_ms"], line["stage_floor"] = head["stage_floor_ms"], head["stage_floor"]
         if args.requested_gpus and args.requested_gpus != world:
             line["config"]["requested_gpus"] = args.requested_gpus
             line["config"]["note"] = "the box shows %d GPU(s): ran on those" % world
@@ -710,6 +747,13 @@ def main():
             gbps = hbm_step / (head["ms_per_step"] * 1e-3) / 1e9
             line["pipeline_hbm"] = {"bytes_per_step": int(hbm_step), "achieved_GBps": round(gbps, 1), "peak_GBps": 8000.0,
                                     "frac": round(gbps / 8000.0, 4),
+                                    # SURVEY.md 8d's stage-boundary model: 18.2 MB per cloud -- it assumes conv5, the assignment and
+                                    # the aggregation fused, i.e. no feature map in HBM.  The map cannot go (the assignment needs a
+                                    # point's whole 1024-channel row before the first aggregate product; recomputing conv5 instead
+                                    # doubles the MFMA work) and 3-byte values are its narrowest form inside the 1e-4 bar
+                                    # (profiles/r04_storage_format_numerics.txt): the ratio is a design limit, not waste to recover
+                                    "model_bytes": int(18.2e6 * args.batch), "ratio": round(hbm_step / (18.2e6 * args.batch), 3),
+                                    "ratio_is": "the 3-byte feature map's round trip (conv5 writes it, the aggregate reads it): a design limit",
                                     "how": "PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/) x launches per step / ms_per_step"}
         elif args.arch == "epc-net" and args.batch == 64:
             line["pipeline_hbm"] = None
