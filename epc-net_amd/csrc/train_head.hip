@@ -622,3 +622,71 @@ extern "C" int epc_vlad_df_tail(const float* a, const float* dz, const float* dv
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// EPC-Net-L's global max over a cloud's points in training mode (models/epc-net-l.py:88-92: tf_util.max_pool2d with the kernel covering
+// all N points; utils/tf_util.py:349-372): out[b][c] = max_n x[b][n][c] and the row that holds it (the FIRST one on ties: the element
+// tf.nn.max_pool's gradient routes to), then dx = dy at that row, zero elsewhere.  A workgroup owns 64 channels of one cloud (256-byte
+// row segments), four row phases meet in LDS.  NaN propagates (a NaN entry wins).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_points_fwd_kernel(const float* __restrict__ x, int n, int C, float* __restrict__ out,
+                                                                 int32_t* __restrict__ arg) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6, b = blockIdx.y;
+    const bool on = c < C;
+    const float* p = x + (size_t)b * n * C + (on ? c : 0);
+    float best = -INFINITY;
+    int bi = 0;
+    bool nan = false;
+    for (int r = part; r < n; r += 4) {
+        const float v = p[(size_t)r * C];
+        if (v != v && !nan) nan = true, best = v, bi = r;
+        if (!nan && v > best) best = v, bi = r;
+    }
+    sv[part][threadIdx.x & 63] = best, si[part][threadIdx.x & 63] = bi;
+    __syncthreads();
+    if (part == 0 && on) {
+        const int l = threadIdx.x & 63;
+        float v = sv[0][l];
+        int idx = si[0][l];
+        for (int q = 1; q < 4; ++q) {
+            const float w = sv[q][l];
+            const int wi = si[q][l];
+            const bool vn = v != v, wn = w != w;
+            if ((wn && (!vn || wi < idx)) || (!vn && !wn && (w > v || (w == v && wi < idx)))) v = w, idx = wi;
+        }
+        out[(size_t)b * C + c] = v;
+        arg[(size_t)b * C + c] = idx;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_points_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, int n, int C,
+                                                                 long total, float* __restrict__ dx) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;      // one (cloud, channel) per thread
+    if (e >= total) return;
+    const long b = e / C, c = e % C;
+    dx[((size_t)b * n + arg[e]) * C + c] = dy[e];
+}
+
+extern "C" int epc_maxpool_points_fwd(const float* x, int num_clouds, int n, int C, float* out, int32_t* arg, void* stream) {
+    EPC_CHECK_ARG(x && out && arg, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && num_clouds <= 65535 && n > 0 && C > 0, "bad shape");
+    hipLaunchKernelGGL(maxpool_points_fwd_kernel, dim3((C + 63) / 64, num_clouds), dim3(256), 0, (hipStream_t)stream, x, n, C, out, arg);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_maxpool_points_bwd(const float* dy, const int32_t* arg, int num_clouds, int n, int C, float* dx, void* stream) {
+    EPC_CHECK_ARG(dy && arg && dx, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && C > 0, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dx, 0, (size_t)num_clouds * n * C * sizeof(float), st) != hipSuccess) {
+        epc_set_error("epc_maxpool_points_bwd: hipMemsetAsync failed");
+        return EPC_EHIP;
+    }
+    const long total = (long)num_clouds * C;
+    hipLaunchKernelGGL(maxpool_points_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, arg, n, C, total, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

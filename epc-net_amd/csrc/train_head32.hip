@@ -1,0 +1,274 @@
+// The head of the training step -- conv5, the per-point l2 norm, the VLAD soft assignment and aggregation (models/epc-net.py:136-148,
+// loupe.py:249-291), forward and backward -- in the DEFAULT, f32-accurate arithmetic on f32 tensors, as the streaming kernels of
+// train_head16.hip: one pass over the (rows, 1024) tensor per product, the small operand resident or streamed through LDS, and the feature
+// map f = l2_normalize(relu(bn(z5))) never written (BatchNorm + ReLU applied to z5 as it is loaded, the row norm in the epilogue or on the
+// other operand).  What it replaces: the generic tile GEMMs of train_ops.hip on this path -- conv5's forward 202 us, the BatchNorm /
+// ReLU / row-norm pass that WROTE f 114 us, the assignment product 100 us, the aggregation 95 us, f dvlad 73 us, f^T dz 94 us, dz5 W5^T
+// 153 us at 18 x 4096 rows -- every one of them re-reading and re-splitting f32 operand tiles per output tile.
+//
+//   arithmetic   conv5's forward: scaled split-fp16 (common.h "f16x3s": every row of cat and every column of W5 brought to [2^14, 2^15)
+//                by a power of two, hi + lo fp16, three products, 2^-21 per product, no range restriction) -- the inference kernels' form;
+//                the assignment, the aggregation and every backward product: two bf16 pieces per operand, three products
+//                (epc_gemm_f32_fast's: 2^-16 per product, averaged over the 1024 channels / a cloud's 4096 points -- the arithmetic of
+//                the inference path's assignment and aggregate).
+//   tensors      all f32: cat (rows, 256), z5 / du / dz5 (rows, 1024), za / a / dz / da (rows, 64), rn (rows), dcat (rows, 256).
+//   the rest of the head's backward (the feature gradient through conv5's tail: epc_vlad_df_tail; dz5: epc_bn_apply_bwd_given; dW5: the
+//   split-K tile product) stays on train_head.hip / train_ops.hip.
+#include "train_head_common.h"
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv5's weights as scaled split-fp16 B fragments: [chunk c < 16][k-step s < 16][nt < 2][hi, lo][lane] (v_mfma_f32_32x32x16_f16:
+// lane (i, h) holds W[16 s + 8 h + j][64 c + 32 nt + i] x colscale), and the inverse column scales [1024].  One workgroup per chunk.
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void h32_pack_conv5_kernel(const float* __restrict__ W, u32x4* __restrict__ out, float* __restrict__ inv_col) {
+    __shared__ float cmax[4][64];
+    __shared__ float cscale[64];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    {
+        const int col = tid & 63, part = tid >> 6;
+        float m = 0.f;
+        for (int k = 64 * part; k < 64 * part + 64; ++k) m = fmaxf(m, fabsf(W[(size_t)k * 1024 + 64 * c + col]));
+        cmax[part][col] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float m = fmaxf(fmaxf(cmax[0][tid], cmax[1][tid]), fmaxf(cmax[2][tid], cmax[3][tid]));
+        float s, inv;
+        row_scale_pow2(m, s, inv);
+        cscale[tid] = s;
+        inv_col[64 * c + tid] = inv;
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * 2 * 64; e += 256) {
+        const int l = e & 63, nt = (e >> 6) & 1, s = e >> 7, i = l & 31, h = l >> 5;
+        const float* src = W + (size_t)(16 * s + 8 * h) * 1024 + 64 * c + 32 * nt + i;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * 1024];
+        f16x8 hi, lo;
+        split8_f16s(v, cscale[32 * nt + i], hi, lo);
+        u32x4* dst = out + ((size_t)(c * 16 + s) * 2 + nt) * 2 * 64 + l;
+        dst[0] = __builtin_bit_cast(u32x4, hi);
+        dst[64] = __builtin_bit_cast(u32x4, lo);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// conv5's forward in the training step: z5 (rows, 1024) f32 = cat W5 + b5 and the batch statistics of the product (models/epc-net.py:136
+// with is_training; utils/tf_util.py:94-106, 472-476).  h16_conv5_fwd_kernel's shape in the scaled split-fp16 arithmetic: a wave's 32 rows
+// resident as hi + lo fragments (128 registers: the row's largest magnitude meets over the two lane halves, every eight raw values are
+// split in place), W5 streaming through double-buffered 32-KB LDS stages of 64 columns x 128 k (hi + lo), three products per k-step,
+// the accumulators un-scaled by inv_row x inv_col in the epilogue; lane = column: a row's 32 values leave as one 128-byte run.
+// ----------------------------------------------------------------------------------------------------------------
+#define C32_STAGE_U4 (8 * 2 * 2 * 64)   // 32 KB: [k-step 8][nt 2][hi, lo][lane]
+
+__global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __restrict__ A, int rows, const u32x4* __restrict__ Bp,
+                                                               const float* __restrict__ inv_col, const float* __restrict__ bias,
+                                                               float* __restrict__ Z, float* __restrict__ stats) {
+    __shared__ u32x4 Bs[2][C32_STAGE_U4];
+    __shared__ float wst[2][4][3][64];
+    __shared__ float rowc[4][32];
+    __shared__ bool wlive[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * 128 + wave * 32;
+    const bool live = r0 < rows;
+    if (lane == 0) wlive[wave] = live;
+    constexpr int PER = C32_STAGE_U4 / 256;
+    u32x4 pre[PER];
+    auto request = [&](int step) {   // step = 2 chunk + half: [chunk][k-step][nt][piece][lane], so halves are contiguous
+#pragma unroll
+        for (int u = 0; u < PER; ++u) pre[u] = Bp[(size_t)step * C32_STAGE_U4 + tid + u * 256];
+    };
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+    };
+    f16x8 ah[16], al[16];      // (the first stage's fragments are requested AFTER the split: the raw row and they do not fit together)
+    {
+        const float* p = A + (size_t)min(r0 + i, rows - 1) * 256 + 8 * h;
+        float4 raw[16][2];
+        float m = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            raw[s][0] = ld4(p + 16 * s), raw[s][1] = ld4(p + 16 * s + 4);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(raw[s][0].x), fabsf(raw[s][0].y)), fmaxf(fabsf(raw[s][0].z), fabsf(raw[s][0].w))));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(raw[s][1].x), fabsf(raw[s][1].y)), fmaxf(fabsf(raw[s][1].z), fabsf(raw[s][1].w))));
+        }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sc, inv;
+        row_scale_pow2(m, sc, inv);
+        if (h == 0) rowc[wave][i] = inv;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float v[8] = {raw[s][0].x, raw[s][0].y, raw[s][0].z, raw[s][0].w, raw[s][1].x, raw[s][1].y, raw[s][1].z, raw[s][1].w};
+            split8_f16s(v, sc, ah[s], al[s]);
+        }
+    }
+    request(0);
+    deposit(0);
+    __syncthreads();
+    auto flush_stats = [&](int st, int buf) {
+        if (tid < 64) {
+            float S1, S2, P;
+            h16_merge_stats(wst[buf], wlive, tid, S1, S2, P);
+            float* o = stats + (size_t)blockIdx.x * 3 * 1024 + 64 * st + tid;
+            o[0] = S1, o[1024] = S2, o[2048] = P;
+        }
+    };
+    float irow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) irow[r] = rowc[wave][mfma_row(r, h)];
+    for (int st = 0; st < 16; ++st) {
+        const int sb = st & 1;
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        auto half = [&](int buf, int s0) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, Bs[buf][((s * 2 + nt) * 2 + 0) * 64 + lane]);
+                    const f16x8 bl = __builtin_bit_cast(f16x8, Bs[buf][((s * 2 + nt) * 2 + 1) * 64 + lane]);
+                    acc[nt] = mfma_f16(al[s0 + s], bh, acc[nt]);
+                    acc[nt] = mfma_f16(ah[s0 + s], bl, acc[nt]);
+                    acc[nt] = mfma_f16(ah[s0 + s], bh, acc[nt]);
+                }
+        };
+        request(2 * st + 1);
+        if (st > 0) flush_stats(st - 1, sb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) half(0, 0);
+        deposit(1);
+        __syncthreads();
+        if (st + 1 < 16) request(2 * st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+            half(1, 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = 64 * st + 32 * nt + i;
+                const float ic = inv_col[col], bv = bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] *= irow[r] * ic;       // (powers of two: exact)
+                const float p = __shfl(acc[nt][0], i);                         // the wave's row 0
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[nt][r] - p;
+                    s1 += d, s2 += d * d;
+                }
+                s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+                if (h == 0) wst[sb][wave][0][32 * nt + i] = s1, wst[sb][wave][1][32 * nt + i] = s2, wst[sb][wave][2][32 * nt + i] = p;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Z[(size_t)(r0 + mfma_row(r, h)) * 1024 + col] = acc[nt][r] + bv;
+            }
+        }
+        if (st + 1 < 16) deposit(0);
+        __syncthreads();
+    }
+    flush_stats(15, 1);
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------------------------
+extern "C" size_t epc_h32_conv5_fwd_scratch_bytes(int rows) {
+    if (rows <= 0) return 0;
+    return (size_t)256 * 1024 * 4 + 1024 * sizeof(float) + (size_t)((rows + 127) / 128) * 3 * 1024 * sizeof(float);
+}
+
+extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float* b5, int rows, float* z5, float* mean, float* var,
+                                 void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(cat && W5 && b5 && z5 && mean && var && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0 && (long)rows * 1024 < (1L << 32), "rows must be a positive multiple of 32 (rows * 1024 < 2^32)");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_conv5_fwd_scratch_bytes(rows), "scratch too small (epc_h32_conv5_fwd_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(cat) && h16_aligned16(z5) && h16_aligned16(scratch), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    u32x4* pack = (u32x4*)scratch;
+    float* inv_col = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)256 * 1024 * 4);
+    float* stats = inv_col + 1024;
+    hipLaunchKernelGGL(h32_pack_conv5_kernel, dim3(16), dim3(256), 0, st, W5, pack, inv_col);
+    const int wgs = (rows + 127) / 128;
+    hipLaunchKernelGGL(h32_conv5_fwd_kernel, dim3(wgs), dim3(256), 0, st, cat, rows, (const u32x4*)pack, inv_col, b5, z5, stats);
+    epc_moments_finalize_launch(stats, wgs, 1024, rows, 128, b5, mean, var, stream);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h32_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    const size_t pack = (size_t)(per_cloud_operand ? num_clouds : 1) * 1024 * 64 * 2 * 3;
+    return pack + (size_t)num_clouds * ((n_points + 127) / 128) * 3 * 64 * sizeof(float);
+}
+
+// epc_h16_assign on f32 rows: out (rows, 64) = rn (relu(bn(z5)) B), three products.  per_cloud_operand = 0: B = cluster_weights (the
+// forward's logits; rn_out / mean_out / var_out written when given); 1: B = dvlad (num_clouds, 1024, 64) (da).
+extern "C" int epc_h32_assign(const float* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                              const float* B, int per_cloud_operand, int num_clouds, int n_points, float* out, float* rn_out,
+                              float* mean_out, float* var_out, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && B && out && scratch, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && num_clouds <= 65535 && n_points > 0 && n_points % 32 == 0, "n_points must be a positive multiple of 32");
+    EPC_CHECK_ARG((mean_out == nullptr) == (var_out == nullptr), "mean_out and var_out come together");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_assign_scratch_bytes(num_clouds, n_points, per_cloud_operand), "scratch too small (epc_h32_assign_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = per_cloud_operand ? num_clouds : 1;
+    // two pieces (three products, 2^-16 per product): the logits are sums of 1024 products whose errors average out (5e-7 of a logit,
+    // measured against the float64 graph: tests/test_gpu_head_stream.py) -- the six-product form took 116 us against 93
+    float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)nb * 1024 * 64 * 2 * 3);
+    const dim3 grid((n_points + 127) / 128, num_clouds);
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    h16_pack<2>(B, 64, 1, (long)1024 * 64, nb, 1024, 64, 1, 4, scratch, st);
+    hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, float, 2, 4>), grid, dim3(256), 0, st, z5, n_points, (const u32x4*)scratch,
+                       per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, (float*)nullptr);
+    if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h32_colgemm_scratch_bytes(int num_clouds, int n_points) {
+    if (num_clouds <= 0 || n_points <= 0) return 0;
+    return (size_t)num_clouds * h16_splits(n_points) * 1024 * 64 * sizeof(float);
+}
+
+// epc_h16_colgemm on f32 rows, two bf16 pieces per operand (three products): out = relu(bn(z5))^T (rn C)
+extern "C" int epc_h32_colgemm(const float* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                               const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && C && rn && out && scratch, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(n_points) <= 65535, "bad shape");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_colgemm_scratch_bytes(num_clouds, n_points), "scratch too small (epc_h32_colgemm_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = h16_splits(n_points);
+    const int rows_per_wg = (n_points + S - 1) / S;
+    const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    hipLaunchKernelGGL((hx_colgemm_kernel<float, 2>), dim3(16, num_clouds * S), dim3(256), 0, st, z5, bn, C, rn, rows_per_wg, n_points, S,
+                       (float*)scratch);
+    const long per = 1024 * 64;
+    if (per_cloud)
+        hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), num_clouds), dim3(256), 0, st, (const float*)scratch, S, per, out);
+    else
+        hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), 1), dim3(256), 0, st, (const float*)scratch, num_clouds * S, per, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" size_t epc_h32_dx_scratch_bytes(void) { return (size_t)1024 * 256 * 2 * 2; }
+
+// dcat (rows, 256) f32 = dz5 (rows, 1024) f32 times W5^T, two bf16 pieces per operand (three products)
+extern "C" int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(dz5 && W5 && dcat && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0, "rows must be a positive multiple of 32");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_dx_scratch_bytes(), "scratch too small (epc_h32_dx_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(dz5) && h16_aligned16(scratch) && h16_aligned16(dcat), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
+    const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, dz5, rows,
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -656,8 +656,8 @@ class ProxyConvChain(torch.autograd.Function):
         stats = lambda: torch.empty(P * 192, dtype=torch.float32, device=dev)
         ptr = lambda t: t.data_ptr() if t is not None else None
         cat = torch.empty((rows, width), dtype=torch.float32, device=dev)
-        # the bf16 head (Conv5VladHead16) reads the concat as bf16: written beside the f32 tensor by the launches that form it
-        cat16 = torch.empty((rows, width), dtype=torch.bfloat16, device=dev) if head16_ok(rows, width, 1024) else None
+        # the bf16 head (Conv5VladHead, mode "bf16") reads the concat as bf16: written beside the f32 tensor by the launches that form it
+        cat16 = torch.empty((rows, width), dtype=torch.bfloat16, device=dev) if head_stream_mode(rows, width, 1024) == "bf16" else None
         if cat16 is not None:
             _CAT16.clear()
             _CAT16[cat.data_ptr()] = cat16
@@ -1023,28 +1023,33 @@ class VladAssignAggregate(torch.autograd.Function):
         return df, dWc, dgamma, dbeta, None, None, None
 
 
-# bf16 copies of concat buffers, by the f32 tensor's address: handed from ProxyConvChain.forward to Conv5VladHead16.forward (the tensors
+# bf16 copies of concat buffers, by the f32 tensor's address: handed from ProxyConvChain.forward to Conv5VladHead.forward (the tensors
 # in between are reshaped views).  One entry: the last chain forward's.
 _CAT16 = {}
 
 
-# The head of the bf16 training step on bf16-stored (rows, 1024) tensors (csrc/train_head16.hip): conv5, the per-point l2 norm, the soft
-# assignment and the aggregation as ONE autograd node whose kernels are single streaming passes -- the feature map f is never written.
-# Selected by set_gemm_precision("bf16") (params["TRAIN_PRECISION"] = "bf16") when the call sites hand conv5's operands over un-evaluated
-# (LazyConv5Features: tf_util.conv1d_l2_normalized(..., lazy=True) -> loupe.G_VLAD.forward).
-HEAD16 = True
+# The head of the training step -- conv5, the per-point l2 norm, the soft assignment and the aggregation -- as ONE autograd node whose
+# kernels are single streaming passes over the (rows, 1024) tensors and never write the feature map f (csrc/train_head16.hip for
+# set_gemm_precision("bf16"): bf16-stored tensors, one bf16 value per operand; csrc/train_head32.hip for the default f32-accurate
+# arithmetic: f32 tensors, split products).  Taken when the call sites hand conv5's operands over un-evaluated (LazyConv5Features:
+# tf_util.conv1d_l2_normalized(..., lazy=True) -> loupe.G_VLAD.forward).  False: the per-layer operators (LinearBatchNormTrain with
+# the row norm + VladAssignAggregate) -- the second implementation the tests hold this one to.
+HEAD_STREAM = True
 
 
-def head16_ok(rows, cin, cout, n_points=None):
-    return (HEAD16 and _GEMM_PRECISION == "bf16" and cin == 256 and cout == 1024 and rows % 32 == 0 and rows * 1024 < (1 << 32)
-            and (n_points is None or (n_points % 32 == 0 and rows % n_points == 0)))
+def head_stream_mode(rows, cin, cout, n_points=None):
+    """"bf16" / "f32": the arithmetic of the streamed head for these shapes under the current GEMM precision; None: not applicable."""
+    if not (HEAD_STREAM and cin == 256 and cout == 1024 and rows % 32 == 0 and rows * 1024 < (1 << 32)
+            and (n_points is None or (n_points % 32 == 0 and rows % n_points == 0))):
+        return None
+    return "bf16" if _GEMM_PRECISION == "bf16" else "f32"
 
 
 class LazyConv5Features:
     """conv5's operands and BatchNorm variables, handed from tf_util.conv1d_l2_normalized to loupe.G_VLAD.forward so that
     l2_normalize(relu(batch_norm(x W5 + b5))) (models/epc-net.py:136-148) and the VLAD assignment / aggregation (loupe.py:255-291)
-    run as one node (Conv5VladHead16).  ``on_stats(mean, var, z5, rn)`` is conv5's side of the bookkeeping (moving averages, the
-    mask-tap test hook), called by whoever evaluates the node.  ``shape`` = the feature map's."""
+    run as one node (Conv5VladHead).  ``on_stats(mean, var, z5, rn)`` is conv5's side of the bookkeeping (moving averages, the
+    mask- and value-tap test hooks), called by whoever evaluates the node.  ``shape`` = the feature map's."""
 
     def __init__(self, x, W, b, gamma, beta, eps, on_stats):
         self.x, self.W, self.b, self.gamma, self.beta, self.eps, self.on_stats = x, W, b, gamma, beta, float(eps), on_stats
@@ -1062,47 +1067,56 @@ def _scratch_bytes(nbytes, device):
     return buf, buf.numel() * 4
 
 
-class Conv5VladHead16(torch.autograd.Function):
-    """(vlad (B, 1024, 64), a_sum (B, 1, 64), mean5, var5, mean_c, var_c, z5 (bf16), rn) from the backbone's output cat (rows, 256):
+class Conv5VladHead(torch.autograd.Function):
+    """(vlad (B, 1024, 64), a_sum (B, 1, 64), mean5, var5, mean_c, var_c, z5, rn) from the backbone's output cat (rows, 256):
         z5 = cat W5 + b5;  u = relu(batch_norm_train(z5));  f = u rn (tf.nn.l2_normalize over the channels);
         za = f Wc;  a = softmax(batch_norm_train(za));  vlad[b] = f[b]^T a[b];  a_sum = sum of a over the cloud's points
-    (models/epc-net.py:136-148, loupe.py:255-291) on train_head16.hip: z5, du and dz5 are bf16 tensors, every product rounds its
-    operands to one bf16 value, statistics and accumulators are f32.  The bias gradient in front of a training-mode BatchNorm is
-    exactly zero and is not computed (LinearBatchNormTrain)."""
+    (models/epc-net.py:136-148, loupe.py:255-291).  mode "bf16" (train_head16.hip): z5, du and dz5 are bf16 tensors, every product
+    rounds its operands to one bf16 value, statistics and accumulators are f32.  mode "f32" (train_head32.hip): f32 tensors, conv5's
+    forward in the scaled split-fp16 three-product arithmetic, every other product in three bf16 products
+    -- with the feature gradient through conv5's tail (epc_vlad_df_tail), epc_bn_apply_bwd_given and the split-K dW5 of the per-layer
+    operators.  The bias gradient in front of a training-mode BatchNorm is exactly zero and is not computed (LinearBatchNormTrain)."""
 
     @staticmethod
-    def forward(ctx, cat, W5, b5, g5, bt5, eps5, Wc, gc, btc, epsc, n_points):
+    def forward(ctx, cat, W5, b5, g5, bt5, eps5, Wc, gc, btc, epsc, n_points, mode):
         lib = L.lib()
         cat, W5, Wc = cat.contiguous(), W5.contiguous(), Wc.contiguous()
         rows = int(cat.shape[0])
-        B = rows // int(n_points)
+        N = int(n_points)
+        B = rows // N
         dev = cat.device
+        h16 = mode == "bf16"
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        z5 = torch.empty((rows, 1024), dtype=torch.bfloat16, device=dev)
+        z5 = torch.empty((rows, 1024), dtype=torch.bfloat16 if h16 else torch.float32, device=dev)
         mean5, var5 = f32(1024), f32(1024)
-        cat16 = _CAT16.pop(cat.data_ptr(), None)       # the chain's bf16 copy of this very tensor, when it made one
-        if cat16 is not None and tuple(cat16.shape) != (rows, 256):
-            cat16 = None
-        lhs = cat16 if cat16 is not None else cat
-        sc, n = _scratch_bytes(lib.epc_h16_conv5_fwd_scratch_bytes(rows), dev)
-        L.check(lib.epc_h16_conv5_fwd(lhs.data_ptr(), int(cat16 is not None), W5.data_ptr(), b5.data_ptr(), rows, z5.data_ptr(),
-                                      mean5.data_ptr(), var5.data_ptr(), sc.data_ptr(), n, _st()))
+        bn5 = lambda: (mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5))
+        lhs = cat
+        if h16:
+            cat16 = _CAT16.pop(cat.data_ptr(), None)       # the chain's bf16 copy of this very tensor, when it made one
+            if cat16 is not None and tuple(cat16.shape) == (rows, 256):
+                lhs = cat16
+            sc, n = _scratch_bytes(lib.epc_h16_conv5_fwd_scratch_bytes(rows), dev)
+            L.check(lib.epc_h16_conv5_fwd(lhs.data_ptr(), int(lhs is not cat), W5.data_ptr(), b5.data_ptr(), rows, z5.data_ptr(),
+                                          mean5.data_ptr(), var5.data_ptr(), sc.data_ptr(), n, _st()))
+        else:
+            sc, n = _scratch_bytes(lib.epc_h32_conv5_fwd_scratch_bytes(rows), dev)
+            L.check(lib.epc_h32_conv5_fwd(cat.data_ptr(), W5.data_ptr(), b5.data_ptr(), rows, z5.data_ptr(), mean5.data_ptr(),
+                                          var5.data_ptr(), sc.data_ptr(), n, _st()))
         za, rn, mean_c, var_c = f32(rows, 64), f32(rows), f32(64), f32(64)
-        sc, n = _scratch_bytes(lib.epc_h16_assign_scratch_bytes(B, n_points, 0), dev)
-        L.check(lib.epc_h16_assign(z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5),
-                                   Wc.data_ptr(), 0, B, int(n_points), za.data_ptr(), rn.data_ptr(), mean_c.data_ptr(),
-                                   var_c.data_ptr(), sc.data_ptr(), n, _st()))
+        assign = lib.epc_h16_assign if h16 else lib.epc_h32_assign
+        sc, n = _scratch_bytes((lib.epc_h16_assign_scratch_bytes if h16 else lib.epc_h32_assign_scratch_bytes)(B, N, 0), dev)
+        L.check(assign(z5.data_ptr(), *bn5(), Wc.data_ptr(), 0, B, N, za.data_ptr(), rn.data_ptr(), mean_c.data_ptr(), var_c.data_ptr(),
+                       sc.data_ptr(), n, _st()))
         a, a_sum = f32(rows, 64), f32(B, 1, 64)
         parts = _splitk_ws(lib.epc_cloud_colsum64_partial_floats(B), dev)
         L.check(lib.epc_assign_softmax_fwd(za.data_ptr(), mean_c.data_ptr(), var_c.data_ptr(), gc.data_ptr(), btc.data_ptr(),
-                                           float(epsc), B, int(n_points), a.data_ptr(), a_sum.data_ptr(), parts.data_ptr(),
-                                           parts.numel(), _st()))
+                                           float(epsc), B, N, a.data_ptr(), a_sum.data_ptr(), parts.data_ptr(), parts.numel(), _st()))
         vlad = f32(B, 1024, 64)
-        sc, n = _scratch_bytes(lib.epc_h16_colgemm_scratch_bytes(B, n_points), dev)
-        L.check(lib.epc_h16_colgemm(z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5),
-                                    a.data_ptr(), rn.data_ptr(), B, int(n_points), 1, vlad.data_ptr(), sc.data_ptr(), n, _st()))
+        sc, n = _scratch_bytes((lib.epc_h16_colgemm_scratch_bytes if h16 else lib.epc_h32_colgemm_scratch_bytes)(B, N), dev)
+        L.check((lib.epc_h16_colgemm if h16 else lib.epc_h32_colgemm)(z5.data_ptr(), *bn5(), a.data_ptr(), rn.data_ptr(), B, N, 1,
+                                                                     vlad.data_ptr(), sc.data_ptr(), n, _st()))
         ctx.save_for_backward(lhs, W5, z5, mean5, var5, g5, bt5, rn, Wc, za, mean_c, var_c, gc, btc, a)
-        ctx.eps5, ctx.epsc, ctx.n_points = float(eps5), float(epsc), int(n_points)
+        ctx.eps5, ctx.epsc, ctx.n_points, ctx.h16 = float(eps5), float(epsc), N, h16
         ctx.mark_non_differentiable(mean5, var5, mean_c, var_c, z5, rn)
         ctx.set_materialize_grads(False)
         return vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn      # (z5, rn: for the call site's test hooks)
@@ -1112,7 +1126,7 @@ class Conv5VladHead16(torch.autograd.Function):
         lib = L.lib()
         cat, W5, z5, mean5, var5, g5, bt5, rn, Wc, za, mean_c, var_c, gc, btc, a = ctx.saved_tensors
         rows = int(cat.shape[0])
-        N = ctx.n_points
+        N, h16 = ctx.n_points, ctx.h16
         B = rows // N
         dev = cat.device
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -1122,35 +1136,51 @@ class Conv5VladHead16(torch.autograd.Function):
         bn5 = (mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), ctx.eps5)
         # da = f dvlad[cloud] (the a_sum gradient of every point's cloud is added inside the softmax backward)
         da = f32(rows, 64)
-        sc, n = _scratch_bytes(lib.epc_h16_assign_scratch_bytes(B, N, 1), dev)
-        L.check(lib.epc_h16_assign(z5.data_ptr(), *bn5, dvlad.data_ptr(), 1, B, N, da.data_ptr(), None, None, None, sc.data_ptr(), n, _st()))
+        sc, n = _scratch_bytes((lib.epc_h16_assign_scratch_bytes if h16 else lib.epc_h32_assign_scratch_bytes)(B, N, 1), dev)
+        L.check((lib.epc_h16_assign if h16 else lib.epc_h32_assign)(z5.data_ptr(), *bn5, dvlad.data_ptr(), 1, B, N, da.data_ptr(), None,
+                                                                   None, None, sc.data_ptr(), n, _st()))
         dz, dgc, dbtc, trow = f32(rows, 64), f32(64), f32(64), f32(rows)
         ws, wn = _ws(rows, 64, dev)
         L.check(lib.epc_assign_softmax_bwd(da.data_ptr(), dasum.contiguous().data_ptr() if dasum is not None else None, a.data_ptr(),
                                            za.data_ptr(), mean_c.data_ptr(), var_c.data_ptr(), gc.data_ptr(), btc.data_ptr(), ctx.epsc,
                                            B, N, dz.data_ptr(), dgc.data_ptr(), dbtc.data_ptr(), trow.data_ptr(), ws.data_ptr(), wn, _st()))
         dWc = f32(1024, 64)
-        sc, n = _scratch_bytes(lib.epc_h16_colgemm_scratch_bytes(B, N), dev)
-        L.check(lib.epc_h16_colgemm(z5.data_ptr(), *bn5, dz.data_ptr(), rn.data_ptr(), B, N, 0, dWc.data_ptr(), sc.data_ptr(), n, _st()))
+        sc, n = _scratch_bytes((lib.epc_h16_colgemm_scratch_bytes if h16 else lib.epc_h32_colgemm_scratch_bytes)(B, N), dev)
+        L.check((lib.epc_h16_colgemm if h16 else lib.epc_h32_colgemm)(z5.data_ptr(), *bn5, dz.data_ptr(), rn.data_ptr(), B, N, 0,
+                                                                     dWc.data_ptr(), sc.data_ptr(), n, _st()))
         # du = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f trow), the BatchNorm's column sums, then dz5 in place
-        du = torch.empty((rows, 1024), dtype=torch.bfloat16, device=dev)
+        du = torch.empty_like(z5)
         sums = f32(2, 1024)
-        sc, n = _scratch_bytes(lib.epc_h16_df_tail_scratch_bytes(B, N), dev)
-        L.check(lib.epc_h16_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, z5.data_ptr(), rn.data_ptr(),
-                                    trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(), sc.data_ptr(), n, _st()))
-        L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), *bn5, sums[0].data_ptr(), sums[1].data_ptr(), rows, du.data_ptr(),
-                                         _st()))
+        if h16:
+            sc, n = _scratch_bytes(lib.epc_h16_df_tail_scratch_bytes(B, N), dev)
+            L.check(lib.epc_h16_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, z5.data_ptr(), rn.data_ptr(),
+                                        trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(), sc.data_ptr(), n, _st()))
+            L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), *bn5, sums[0].data_ptr(), sums[1].data_ptr(), rows,
+                                             du.data_ptr(), _st()))
+        else:
+            nbytes = lib.epc_vlad_df_packed_bytes(B, 1024)
+            pfl = lib.epc_vlad_df_tail_partial_floats(B, N)
+            scratch = _splitk_ws((nbytes + 3) // 4 + pfl, dev)
+            L.check(lib.epc_vlad_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, 2, scratch.data_ptr(), nbytes,
+                                         z5.data_ptr(), rn.data_ptr(), trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(),
+                                         scratch.data_ptr() + 4 * ((nbytes + 3) // 4), pfl, _st()))
+            L.check(lib.epc_bn_apply_bwd_given(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(),
+                                               sums[0].data_ptr(), sums[1].data_ptr(), ctx.eps5, rows, 1024, du.data_ptr(), _st()))
         dcat = None
         if ctx.needs_input_grad[0]:
             dcat = f32(rows, 256)
-            sc, n = _scratch_bytes(lib.epc_h16_dx_scratch_bytes(), dev)
-            L.check(lib.epc_h16_conv5_dx(du.data_ptr(), W5.data_ptr(), rows, dcat.data_ptr(), sc.data_ptr(), n, _st()))
+            sc, n = _scratch_bytes((lib.epc_h16_dx_scratch_bytes if h16 else lib.epc_h32_dx_scratch_bytes)(), dev)
+            L.check((lib.epc_h16_conv5_dx if h16 else lib.epc_h32_conv5_dx)(du.data_ptr(), W5.data_ptr(), rows, dcat.data_ptr(),
+                                                                           sc.data_ptr(), n, _st()))
         # dW5 = cat^T dz5, row slices added in a fixed order
-        dW5 = f32(256, 1024)
-        sc, n = _scratch_bytes(lib.epc_h16_conv5_dw_scratch_bytes(rows), dev)
-        L.check(lib.epc_h16_conv5_dw(cat.data_ptr(), int(cat.dtype == torch.bfloat16), du.data_ptr(), rows, dW5.data_ptr(), sc.data_ptr(),
-                                     n, _st()))
-        return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None
+        if h16:
+            dW5 = f32(256, 1024)
+            sc, n = _scratch_bytes(lib.epc_h16_conv5_dw_scratch_bytes(rows), dev)
+            L.check(lib.epc_h16_conv5_dw(cat.data_ptr(), int(cat.dtype == torch.bfloat16), du.data_ptr(), rows, dW5.data_ptr(),
+                                         sc.data_ptr(), n, _st()))
+        else:
+            dW5 = gemm(cat, du, trans_a=True, splitk=_splitk_for(256, 1024, rows), fast=True, deterministic=True)
+        return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None, None
 
 
 def expand16(z16, bn=None, rn=None):
@@ -1165,6 +1195,30 @@ def expand16(z16, bn=None, rn=None):
         L.check(L.lib().epc_h16_expand(z16.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                        rn.data_ptr() if rn is not None else None, rows, y.data_ptr(), _st()))
     return y
+
+
+class MaxPoolPoints(torch.autograd.Function):
+    """EPC-Net-L's global max over a cloud's points (models/epc-net-l.py:88-92: tf_util.max_pool2d with the kernel covering all N
+    points): (B, N, C) -> (B, C); the gradient goes to the row that held the maximum (the first on ties, tf.nn.max_pool's)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, N, C = (int(v) for v in x.shape)
+        out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+        L.check(L.lib().epc_maxpool_points_fwd(x.data_ptr(), B, N, C, out.data_ptr(), arg.data_ptr(), _st()))
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, N, C = ctx.shape
+        dx = torch.empty((B, N, C), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().epc_maxpool_points_bwd(dy.contiguous().data_ptr(), arg.data_ptr(), B, N, C, dx.data_ptr(), _st()))
+        return dx
 
 
 class GateMul(torch.autograd.Function):

@@ -5,8 +5,7 @@ optimizer update is a call into libepcnet_hip.so and there is no torch / CPU fal
 What the differentiable (``is_training=True``) path still leaves to torch, all of it glue on small or already-materialised
 tensors: the residual ``t + x1`` of each block and the concat of the four block outputs (models/epc-net.py:81,134 -- elementwise
 adds / one copy, with autograd's matching accumulations), the sum over the 4 group rows and the ``a_sum`` reduction of
-loupe.py:276,328, the sigmoid gate of loupe.py:97-99 on (B, 256), EPC-Net-L's global max over points (``max_pool2d``) and the
-ReLU of a BN-less layer.  The fused inference path has none of these.  Variables are created in the current
+loupe.py:276,328, the sigmoid gate of loupe.py:97-99 on (B, 256) and the ReLU of a BN-less layer.  The fused inference path has none of these.  Variables are created in the current
 ``variable_scope`` with the reference's names and initialisers, so a model built from these wrappers has the
 same state-dict as the reference checkpoint.
 
@@ -375,8 +374,8 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     models/epc-net.py:136-148 applies to conv5's output -- returned as (B*L, C).  Not a function of the reference's
     tf_util: a fusion point.  In training the BatchNorm apply, the ReLU and the row norm are one pass over the
     (rows, 1024) activations (ops.BatchNormReluRowNorm) and the un-normalised map is never written.
-    ``lazy``: the caller hands the result to loupe.G_VLAD.forward and nowhere else -- in the bf16 training arithmetic the layer is
-    then NOT evaluated here: an ops.LazyConv5Features carries its operands into the VLAD node (ops.Conv5VladHead16), which never
+    ``lazy``: the caller hands the result to loupe.G_VLAD.forward and nowhere else -- in training (ops.HEAD_STREAM) the layer is
+    then NOT evaluated here: an ops.LazyConv5Features carries its operands into the VLAD node (ops.Conv5VladHead), which never
     writes the feature map at all."""
     from .. import ops
     cin = int(inputs.shape[-1])
@@ -388,7 +387,7 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
     w, b, _ = declare_conv1d(scope, cin, num_output_channels, 1, True, 1e-3, True)
     with variable_scope(scope):
         x2 = inputs.reshape(-1, cin)
-        if lazy and ops.head16_ok(int(x2.shape[0]), cin, num_output_channels):
+        if lazy and ops.head_stream_mode(int(x2.shape[0]), cin, num_output_channels) is not None:
             from ..variables import current_scope
             beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
             decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
@@ -397,10 +396,13 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
             def on_stats(mean, var, z5, rn):
                 _ema_update(ema_mean, mean, decay)
                 _ema_update(ema_var, var, decay)
-                if RELU_MASK_TAPS is not None:      # (test hook: the feature map is never written -- expand it from z5)
-                    RELU_MASK_TAPS[here] = ops.expand16(z5, (mean, var, gamma, beta, 1e-3), None) > 0
+                if RELU_MASK_TAPS is not None:      # (test hook: the feature map is never written -- re-form the BatchNorm output from z5)
+                    if z5.dtype == torch.bfloat16:
+                        RELU_MASK_TAPS[here] = ops.expand16(z5, (mean, var, gamma, beta, 1e-3), None) > 0
+                    else:
+                        RELU_MASK_TAPS[here] = ops.bn_apply_train(z5, mean, var, gamma, beta, 1e-3, True) > 0
                 if VALUE_TAPS is not None:
-                    VALUE_TAPS[here] = ops.expand16(z5)
+                    VALUE_TAPS[here] = ops.expand16(z5) if z5.dtype == torch.bfloat16 else z5.detach().clone()
 
             return ops.LazyConv5Features(x2, w.reshape(cin, num_output_channels), b, gamma, beta, 1e-3, on_stats)
         if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
@@ -434,7 +436,9 @@ def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
     (models/epc-net-l.py:88-92); that is the one configuration implemented."""
     if inputs.dim() != 4 or list(kernel_size) != [int(inputs.shape[1]), int(inputs.shape[2])] or padding != 'VALID':
         raise NotImplementedError("max_pool2d is implemented for the global pool of models/epc-net-l.py:91 only")
-    return torch.amax(inputs, dim=(1, 2), keepdim=True)
+    from .. import ops
+    B, N, W, C = (int(v) for v in inputs.shape)
+    return ops.MaxPoolPoints.apply(inputs.reshape(B, N * W, C)).reshape(B, 1, 1, C)
 
 
 def _unused(name, where):

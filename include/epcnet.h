@@ -638,11 +638,36 @@ int epc_h16_conv5_dw(const void* cat, int cat_is_bf16, const void* dz5, int rows
                      void* stream);
 int epc_h16_expand(const void* z, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
                    const float* rn, int rows, float* y, void* stream);
+/* ---- The same head on f32 tensors in the f32-accurate arithmetic (csrc/train_head32.hip): the default training step ---------------
+ * The streaming kernels above with f32 rows (z5, du, dz5 are `float*`): one pass over the (rows, 1024) tensor per product, no feature map.
+ * Arithmetic: epc_h32_conv5_fwd scaled split-fp16 (every row of cat and every column of W5 brought into [2^14, 2^15) by a power of two,
+ * hi + lo fp16, three products: 2^-21 per product, no range restriction); epc_h32_assign, epc_h32_colgemm and epc_h32_conv5_dx two bf16
+ * pieces per operand, three products (epc_gemm_f32_fast's: 2^-16 per product).  Arguments as the bf16 head's entry points of the same name.  The rest of the head's backward on f32 tensors:
+ * epc_vlad_df_tail, epc_bn_apply_bwd_given, and the split-K tile product for dW5. */
+size_t epc_h32_conv5_fwd_scratch_bytes(int rows);
+int epc_h32_conv5_fwd(const float* cat, const float* W5, const float* b5, int rows, float* z5, float* mean, float* var, void* scratch,
+                      size_t scratch_bytes, void* stream);
+size_t epc_h32_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand);
+int epc_h32_assign(const float* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                   const float* B, int per_cloud_operand, int num_clouds, int n_points, float* out, float* rn_out, float* mean_out,
+                   float* var_out, void* scratch, size_t scratch_bytes, void* stream);
+size_t epc_h32_colgemm_scratch_bytes(int num_clouds, int n_points);
+int epc_h32_colgemm(const float* z5, const float* mean5, const float* var5, const float* gamma5, const float* beta5, float eps,
+                    const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
+                    size_t scratch_bytes, void* stream);
+size_t epc_h32_dx_scratch_bytes(void);
+int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream);
 /* epc_gemm_splitk_det with the RIGHT operand stored as bf16 (strides and batch stride in elements; every side of the product at least
  * 64, K at least 32).  pieces: 1 = A rounded to one bf16 value, 2 = A in two bf16 pieces (the bf16 operand is exact either way). */
 int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,
                             long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate, int pieces,
                             float* workspace, size_t workspace_floats, void* stream);
+
+/* EPC-Net-L's global max-pool over a cloud's points in training mode (models/epc-net-l.py:88-92; utils/tf_util.py:349-372 with the
+ * kernel covering all N points): out (num_clouds, C) = max over n of x (num_clouds, n, C), arg = the row holding it (the first on ties --
+ * where tf.nn.max_pool's gradient goes); bwd: dx = dy at that row, zero elsewhere (dx is cleared here).  NaN propagates. */
+int epc_maxpool_points_fwd(const float* x, int num_clouds, int n, int C, float* out, int32_t* arg, void* stream);
+int epc_maxpool_points_bwd(const float* dy, const int32_t* arg, int num_clouds, int n, int C, float* dx, void* stream);
 
 /* Distillation terms of kd_train.py:330-340, 376-383 (square_error_sum / square_error_mean between the student's and the
  * teacher's soft labels or point features): loss[0] = sum (a - b)^2 (mean != 0: divided by n), one read of both tensors, partials

@@ -25,7 +25,8 @@ def lib_sha256():
     return h.hexdigest()
 
 
-LIB_SHA = os.environ.get("EPCNET_LIB_SHA") or lib_sha256()   # (override: summarising a collection off the box, after the tree's library was rebuilt)
+LIB_SHA = lib_sha256()       # (no override: a summary carries the hash of the library in the tree it was made from, nothing else)
+SIDE = len(sys.argv) > 2 and sys.argv[2] == "side"   # a side collection (another arch / batch): per-tag files only, *_current.json untouched
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -68,20 +69,20 @@ if kernels:
     doc = {"command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 5 --warmup 2 "
                       "--no-cpu-baseline (separate passes for FETCH_SIZE and WRITE_SIZE; scripts/collect_profiles.sh)",
            "tag": tag, "lib_sha256": LIB_SHA, "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024)", "kernels": kernels}
-    for name in (tag + "_pmc_hbm.json", "pmc_hbm_current.json"):
+    for name in (tag + "_pmc_hbm.json",) + (() if SIDE else ("pmc_hbm_current.json",)):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
 # ---- compute-side counters -------------------------------------------------------------------------------------------
 # the launches of one bench step, per arithmetic (bench.py's pipeline_hbm sums bytes over them)
-LAUNCHES = {"f32": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel<20, true, 8>": 1, "proxyconv_block_kernel": 4,
+LAUNCHES = {"f32": {"morton_sort_kernel": 1, "void knn_topk_quad_kernel<20, true, 4>": 1, "proxyconv_block_kernel": 4,
                     "void conv5_vlad_f32_kernel<256>": 1, "vlad_aggregate_f32_kernel": 1, "void vlad_fold_kernel": 1,
                     "hidden_gemm_kernel": 1, "head_finish_kernel": 1},
-            "fast": {"morton_sort_kernel": 1, "void knn_topk_culled_kernel<20, true, 8>": 1, "proxyconv_block_f16_kernel": 4,
+            "fast": {"morton_sort_kernel": 1, "void knn_topk_quad_kernel<20, true, 4>": 1, "proxyconv_block_f16_kernel": 4,
                      "void conv5_kernel<256, 0, true, true>": 1, "vlad_aggregate_kernel": 1, "void vlad_fold_kernel": 1,
                      "hidden_gemm_kernel": 1, "head_finish_kernel": 1}}
-for name in (tag + "_pmc_hbm.json", "pmc_hbm_current.json"):
+for name in (tag + "_pmc_hbm.json",) + (() if SIDE else ("pmc_hbm_current.json",)):
     path = os.path.join(dst, name)
-    if kernels and os.path.exists(path):
+    if kernels and os.path.exists(path) and not SIDE:
         doc = json.load(open(path))
         doc["launches_per_step"] = LAUNCHES
         json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
@@ -142,7 +143,7 @@ if comp:
            "derived": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); valu_active_lane_fraction = "
                       "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); *_share = counter / SQ_WAVE_CYCLES; means per launch",
            "kernels": {k: {c: (round(v, 1) if isinstance(v, float) and v > 10 else v) for c, v in d.items()} for k, d in sorted(comp.items())}}
-    for name in (tag + "_pmc_compute.json", "pmc_compute_current.json"):
+    for name in (tag + "_pmc_compute.json",) + (() if SIDE else ("pmc_compute_current.json",)):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(doc, f, indent=1, sort_keys=True)
 line = os.path.join(src, "bench_line.json")

@@ -1,4 +1,4 @@
-"""GPU tests of the bf16-stored head of the training step (epc-net_amd/csrc/train_head16.hip through ops.Conv5VladHead16 and the C ABI)
+"""GPU tests of the bf16-stored head of the training step (epc-net_amd/csrc/train_head16.hip through ops.Conv5VladHead and the C ABI)
 against the float64 restatement with the same rounding points (oracle/epcnet_oracle_torch.py: _Head16; held to autograd's gradients of
 the plain graph in tests/test_oracle_cpu.py).  models/epc-net.py:136-148, loupe.py:255-291 in training mode."""
 import numpy as np
@@ -40,15 +40,15 @@ def test_head16_node_matches_the_rounded_restatement(dev, B, N):
     prev = ops.set_gemm_precision("bf16")
     try:
         xs = [leaves[k].float().to(dev).requires_grad_(True) for k in names]
-        vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead16.apply(xs[0], xs[1], xs[2], xs[3], xs[4], EPS, xs[5], xs[6],
-                                                                                    xs[7], EPS, N)
+        vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead.apply(xs[0], xs[1], xs[2], xs[3], xs[4], EPS, xs[5], xs[6],
+                                                                                  xs[7], EPS, N, "bf16")
         loss = (vlad * wv.float().to(dev)).sum() + (a_sum * wa.float().to(dev)).sum()
         grads = torch.autograd.grad(loss, xs, allow_unused=True)
         z5f = ops.expand16(z5).double().cpu()
         mask = (ops.expand16(z5, (mean5, var5, xs[3].detach(), xs[4].detach(), EPS), None) > 0).cpu()
         # the same call again: bit-identical results (fixed summation orders, no atomics)
         d_ = [x.detach() for x in xs]
-        again = ops.Conv5VladHead16.apply(d_[0], d_[1], d_[2], d_[3], d_[4], EPS, d_[5], d_[6], d_[7], EPS, N)
+        again = ops.Conv5VladHead.apply(d_[0], d_[1], d_[2], d_[3], d_[4], EPS, d_[5], d_[6], d_[7], EPS, N, "bf16")
         assert torch.equal(again[0], vlad) and torch.equal(again[6], z5)
     finally:
         ops.set_gemm_precision(prev)
@@ -91,6 +91,47 @@ def test_head16_node_matches_the_rounded_restatement(dev, B, N):
     print("head16 %dx%d: worst gradient relative L2 error vs the rounded restatement %.2e (%s)" % (B, N, worst[0], worst[1]))
     # (what is left: f32 accumulation order, and du / dz5 elements that round the other way -- 2^-9 of single elements)
     assert worst[0] <= 3e-3, worst
+
+
+@pytest.mark.parametrize("B,N", [(3, 96), (18, 256), (4, 4096)])
+def test_head32_node_matches_the_exact_graph(dev, B, N):
+    """The same node in the default f32-accurate arithmetic (csrc/train_head32.hip: f32 tensors, split products) against the EXACT
+    function -- _Head16 with the rounding off, i.e. the plain graph in float64 -- with the ReLU mask of the HIP forward pinned: outputs to
+    1e-5, every gradient to 1e-4 relative L2 (three-product backward GEMMs: 2^-16 per product, averaged over thousands of terms)."""
+    import epcnet_oracle_torch as T
+    ops = H.pkg("ops")
+    leaves, (wv, wa) = _inputs(B, N, 31 + N, dev)
+    names = list(leaves)
+    xs = [leaves[k].float().to(dev).requires_grad_(True) for k in names]
+    vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead.apply(xs[0], xs[1], xs[2], xs[3], xs[4], EPS, xs[5], xs[6],
+                                                                              xs[7], EPS, N, "f32")
+    loss = (vlad * wv.float().to(dev)).sum() + (a_sum * wa.float().to(dev)).sum()
+    grads = torch.autograd.grad(loss, xs, allow_unused=True)
+    assert z5.dtype == torch.float32
+    mask = (ops.bn_apply_train(z5, mean5, var5, xs[3].detach(), xs[4].detach(), EPS, True) > 0).cpu()
+    d_ = [x.detach() for x in xs]
+    again = ops.Conv5VladHead.apply(d_[0], d_[1], d_[2], d_[3], d_[4], EPS, d_[5], d_[6], d_[7], EPS, N, "f32")
+    assert torch.equal(again[0], vlad) and torch.equal(again[6], z5)
+    torch.cuda.synchronize()
+    ys = [leaves[k].clone().requires_grad_(True) for k in names]
+    out = T._Head16.apply(*ys, N, False, mask, None, EPS)
+    g_ref = torch.autograd.grad((out[0] * wv).sum() + (out[1] * wa).sum(), ys, allow_unused=True)
+    rel = lambda a, b: float((a.detach().double().cpu() - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    u = out[7]
+    rn_ref = torch.rsqrt(torch.clamp((u * u).sum(1), min=1e-12))
+    fwd = dict(z5=rel(z5, out[6]), mean5=rel(mean5, out[2]), var5=rel(var5, out[3]), vlad=rel(vlad, out[0]), a_sum=rel(a_sum, out[1]),
+               mean_c=rel(mean_c, out[4]), var_c=rel(var_c, out[5]), rn=rel(rn, rn_ref))
+    print("head32 %dx%d forward vs the exact graph (max error / max magnitude): %s" % (B, N, ", ".join("%s %.1e" % kv for kv in fwd.items())))
+    assert fwd["z5"] <= 2e-6 and fwd["mean5"] <= 2e-6 and fwd["var5"] <= 2e-5 and fwd["rn"] <= 2e-6, fwd
+    assert fwd["vlad"] <= 2e-5 and fwd["a_sum"] <= 1e-5 and fwd["mean_c"] <= 1e-5 and fwd["var_c"] <= 2e-5, fwd
+    worst = (0.0, "")
+    for k, g, gr in zip(names, grads, g_ref):
+        if k == "b5":
+            assert g is None
+            continue
+        worst = max(worst, (float((g.double().cpu() - gr).norm() / gr.norm().clamp(min=1e-30)), k))
+    print("head32 %dx%d: worst gradient relative L2 error vs the exact graph %.2e (%s)" % (B, N, worst[0], worst[1]))
+    assert worst[0] <= 1e-4, worst
 
 
 def test_gemm_b16_entry(dev):

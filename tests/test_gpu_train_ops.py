@@ -622,3 +622,34 @@ def test_lazy_quadruplet_loss_operator(dev, B, P, Nn, far):
         assert float(l64) == 0.0
     for a, b in zip(ins32, ins64):
         assert (a.grad.double().cpu() - b.grad).abs().max() <= 1e-5 * max(b.grad.abs().max().item(), 1.0)
+
+
+def test_maxpool_points_op(dev):
+    """EPC-Net-L's global max over a cloud's points in training mode (models/epc-net-l.py:88-92; utils/tf_util.py:349-372) as a library op:
+    values equal torch's, the gradient goes to the maximum's row -- the FIRST one on ties, as tf.nn.max_pool's gradient does -- and a
+    NaN entry wins."""
+    ops, tf_util = H.pkg("ops"), H.pkg("utils.tf_util")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5, 1000, 192, generator=g).to(dev).requires_grad_(True)
+    y = ops.MaxPoolPoints.apply(x)
+    ref = x.detach().amax(dim=1)
+    assert torch.equal(y, ref)
+    w = torch.randn(5, 192, generator=g).to(dev)
+    (gx,) = torch.autograd.grad((y * w).sum(), x)
+    xr = x.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad((xr.max(dim=1).values * w).sum(), xr)      # (continuous data: no ties, one arg-max per column)
+    assert torch.equal(gx, gr)
+    # the wrapper with the reference's name and shapes: (B, N, 1, C) -> (B, 1, 1, C)
+    z = tf_util.max_pool2d(x.detach().reshape(5, 1000, 1, 192), [1000, 1], "maxpool", padding="VALID")
+    assert tuple(z.shape) == (5, 1, 1, 192) and torch.equal(z.reshape(5, 192), ref)
+    # ties: the first row takes the gradient; NaN: propagates
+    t = torch.zeros(2, 64, 64, device=dev)
+    t[0, 7, :] = 3.0
+    t[0, 40, :] = 3.0
+    t[1, 5, 3] = float("nan")
+    t.requires_grad_(True)
+    yt = ops.MaxPoolPoints.apply(t)
+    (gt,) = torch.autograd.grad(yt[0].sum() + yt[1, :3].sum(), t)
+    assert float(gt[0, 7].sum()) == 64.0 and float(gt[0, 40].sum()) == 0.0 and float(gt[0].sum()) == 64.0
+    assert bool(torch.isnan(yt[1, 3])) and float(yt[1, 2]) == 0.0
+    assert float(gt[1, 0, :3].sum()) == 3.0      # (all-zero columns: row 0 is the first maximum)
