@@ -704,6 +704,27 @@ def main():
             leg, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 256, max(10, min(50, args.steps)), min(args.warmup, 10), 0.0,
                                     every, 1)
             leg["workload"] = "EPC-Net-L inference, batch 256x4096x3 fp32 per GPU (BASELINE.json configs[3]; models/epc-net-l.py:29-102)"
+            # `roofline` above is conv5 + max-pool's (the MFMA kernel); by TIME the leg is kNN + the two ProxyConv blocks (two thirds of
+            # it), neither of which is MFMA- or HBM-bound: kNN saturates VALU issue (286.6 M vector instructions per launch = 0.98 of
+            # the SIMDs' issue cycles), the blocks the vector L1 (gathered rows).  profiles/*_l_b256_pmc_compute.json (side collection).
+            sm = leg["stage_ms"]
+            tot = sum(sm.values())
+            dom = max(sm, key=sm.get)
+            leg["dominant_by_time"] = {
+                "stage": dom, "ms": sm[dom], "share_of_step": round(sm[dom] / tot, 3),
+                "knn_plus_blocks_share": round((sm["knn"] + sm["block1"] + sm["block2"]) / tot, 3),
+                "knn_floor_ms": round(286.6e6 / 1024 * 4 / (SHADER_GHZ * 1e9) * 1e3, 4),
+                "knn_bound": "VALU issue: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs (counters: 0.98 of the kernel's cycles)",
+                "block_floor_ms_each": round((4 * 1.34e9 / (256 * 64) / (SHADER_GHZ * 1e9) + 4 * 0.020e-3) * 1e3, 4),
+                "block_bound": "vector L1: 20 gathered 256-byte rows per point at 64 B/clk/CU, plus the skeleton (as EPC-Net's blocks)"}
+            # the one thing not measured before at this size: the same 256 clouds as two 128-cloud halves in flight on
+            # two HIP streams (kNN of one half beside the blocks / conv5 of the other); descriptors bit-identical (checked by the leg)
+            half, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 128, max(10, min(50, args.steps)), 4, 0.0, every, 2)
+            if "overlapped" in half:
+                ov = half["overlapped"]
+                leg["halves_overlapped"] = {"value": ov["value"], "unit": "clouds/s", "ms_per_256_clouds": round(2 * ov["ms_per_step"], 4),
+                                            "gain_over_one_stream": round(ov["value"] / leg["value"], 4),
+                                            "how": "two 128-cloud steps in flight (InferenceEngine.submit), same kernels, same results"}
             return leg
         guarded("epc_net_l_b256", l_leg)
         guarded("retrieval", lambda: retrieval_leg(H, E, steps=3, warmup=1, rccl=rccl))
