@@ -90,25 +90,25 @@ def pkg(name=""):
 
 
 # Floor of every inference stage IN ITS PRESENT GEOMETRY ("Floor models": the arithmetic behind each line), EPC-Net,
-# EPC_PRECISION_F32, 64 clouds x 4096 points, at the 2.04 GHz the chip holds under this load (GRBM_GUI_ACTIVE / duration of the profiled
-# launches).  A stage at its floor moves only with a different algorithm / fewer instructions / fewer bytes, not with tuning.
-SHADER_GHZ = 2.04
+# EPC_PRECISION_F32, 64 clouds x 4096 points.  Shader clocks from the profiled launches (GRBM_GUI_ACTIVE / 8 XCDs / duration): the
+# conv5 kernel -- the one that keeps the matrix pipe busy -- runs at 2.04 GHz, every other stage at 2.42 GHz.  A stage at its floor moves
+# only with a different algorithm / fewer instructions / fewer bytes, not with tuning.
+MFMA_GHZ, VALU_GHZ = 2.04, 2.42
 
 
 def stage_floors_epc_net_f32_b64():
     cus, simds = 256, 1024
-    clk = SHADER_GHZ * 1e9
-    # kNN: 75.1 M vector instructions per launch (SQ_INSTS_VALU, profiles/pmc_compute_current.json) at one wave-instruction per SIMD
-    # and four cycles: VALU issue is the only resource the kernel saturates
-    knn = 75.1e6 / simds * 4 / clk
+    # kNN: 75.06 M vector instructions per launch (SQ_INSTS_VALU, profiles/*_pmc_compute.json) at one wave-instruction per SIMD and
+    # four cycles: VALU issue is the only resource the kernel loads (0.84 of its cycles at this batch, 0.98 at EPC-Net-L's 256 clouds)
+    knn = 75.06e6 / simds * 4 / (VALU_GHZ * 1e9)
     # ProxyConv block: 20 gathered 256-byte rows per point = 1.34 GB through the vector L1 at 64 B / clk / CU, plus the skeleton the
     # ablations of docs/HISTORY_r01_r02.md:654-666 leave when the gather is removed (weight-pack staging, MFMA chain, epilogue): 0.020 ms
-    block = 1.34e9 / (cus * 64) / clk + 0.020e-3
+    block = 1.34e9 / (cus * 64) / (VALU_GHZ * 1e9) + 0.020e-3
     # conv5 + assignment: 4 rounds of one 8-wave workgroup per CU; per workgroup a 256-KB prologue at 9 B / clk / CU (one CU's miss
     # queue at HBM latency), then 32 chunks of: 120 MFMAs x 16 cycles per wave, two waves per SIMD (3840 cycles of matrix pipe), the
     # two waves' 1900-cycle epilogues of which the half that fits under the MFMA issue slots (the vector pipe is blocked 8 of 16 cycles
     # per 16x16x32 MFMA) is hidden: 3840 + (3800 - 1920) cycles per chunk
-    conv5 = 4 * (256 * 1024 / 9.0 + 32 * (3840 + (3800 - 1920))) / clk
+    conv5 = 4 * (256 * 1024 / 9.0 + 32 * (3840 + (3800 - 1920))) / (MFMA_GHZ * 1e9)
     # aggregate: the 3-byte feature map + assignment fragments, 905 MB per launch, at the 6.3 TB/s a streaming read reaches
     aggregate = 905e6 / 6.3e12
     return {"sort": 0.012, "knn": round(knn * 1e3, 4), "conv1": 0.0, "block1": round(block * 1e3, 4), "block2": round(block * 1e3, 4),
@@ -383,10 +383,10 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
         fl = stage_floors_epc_net_f32_b64()
         res["stage_floor_ms"] = fl
         res["stage_floor"] = {"sum_ms": round(sum(fl.values()), 4), "step_over_floor": round(elapsed / steps * 1e3 / sum(fl.values()), 3),
-                              "model": "per-stage floors of the present kernels' geometry at %.2f GHz: kNN = vector instructions / issue rate; "
+                              "model": "per-stage floors of the present kernels' geometry (conv5 at %.2f GHz, the other stages at %.2f): kNN = vector instructions / issue rate; "
                                        "block = L1 gather bytes / 64 B/clk/CU + skeleton; conv5 = 4 rounds x (256-KB prologue at 9 B/clk/CU + "
                                        "32 chunks x (MFMA issue + the epilogue share the MFMA issue slots do not hide)); aggregate = feat "
-                                       "bytes / 6.3 TB/s (DESIGN.md 4, Floor models)" % SHADER_GHZ}
+                                       "bytes / 6.3 TB/s (DESIGN.md 4, Floor models)" % (MFMA_GHZ, VALU_GHZ)}
     if overlapped is not None:
         res["overlapped"] = overlapped
     return res, elapsed
@@ -713,9 +713,9 @@ def main():
             leg["dominant_by_time"] = {
                 "stage": dom, "ms": sm[dom], "share_of_step": round(sm[dom] / tot, 3),
                 "knn_plus_blocks_share": round((sm["knn"] + sm["block1"] + sm["block2"]) / tot, 3),
-                "knn_floor_ms": round(286.6e6 / 1024 * 4 / (SHADER_GHZ * 1e9) * 1e3, 4),
+                "knn_floor_ms": round(286.6e6 / 1024 * 4 / (VALU_GHZ * 1e9) * 1e3, 4),
                 "knn_bound": "VALU issue: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs (counters: 0.98 of the kernel's cycles)",
-                "block_floor_ms_each": round((4 * 1.34e9 / (256 * 64) / (SHADER_GHZ * 1e9) + 4 * 0.020e-3) * 1e3, 4),
+                "block_floor_ms_each": round((4 * 1.34e9 / (256 * 64) / (VALU_GHZ * 1e9) + 4 * 0.020e-3) * 1e3, 4),
                 "block_bound": "vector L1: 20 gathered 256-byte rows per point at 64 B/clk/CU, plus the skeleton (as EPC-Net's blocks)"}
             # the one thing not measured before at this size: the same 256 clouds as two 128-cloud halves in flight on
             # two HIP streams (kNN of one half beside the blocks / conv5 of the other); descriptors bit-identical (checked by the leg)

@@ -177,7 +177,7 @@ struct H16Tail {
     float* partials;      // [workgroups][2][1024]
 };
 
-__global__ __launch_bounds__(256, 2) void h16_df_tail_kernel(const float* __restrict__ a, const float* __restrict__ dz,
+__global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __restrict__ a, const float* __restrict__ dz,
                                                              const u32x4* __restrict__ Bp, int n_points, unsigned* __restrict__ du,
                                                              H16Tail tail) {
     __shared__ u32x4 Bs[2][DF_STAGE_U4];

@@ -18,35 +18,39 @@
 
 // ----------------------------------------------------------------------------------------------------------------
 // conv5's weights as scaled split-fp16 B fragments: [chunk c < 16][k-step s < 16][nt < 2][hi, lo][lane] (v_mfma_f32_32x32x16_f16:
-// lane (i, h) holds W[16 s + 8 h + j][64 c + 32 nt + i] x colscale), and the inverse column scales [1024].  One workgroup per chunk.
+// lane (i, h) holds W[16 s + 8 h + j][64 c + 32 nt + i] x colscale), and the inverse column scales [1024].
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void h32_pack_conv5_kernel(const float* __restrict__ W, u32x4* __restrict__ out, float* __restrict__ inv_col) {
-    __shared__ float cmax[4][64];
-    __shared__ float cscale[64];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    // grid (16 chunks, 2 column tiles, 4 k quarters): 128 small workgroups (sixteen large ones took 21 us of the step's critical path);
+    // each finds the scales of its 32 columns (every quarter redundantly: 32 KB of reads) and packs 4 k-steps of them
+    __shared__ float cmax[8][32];
+    __shared__ float cscale[32];
+    const int c = blockIdx.x, nt = blockIdx.y, kq = blockIdx.z, tid = threadIdx.x;
     {
-        const int col = tid & 63, part = tid >> 6;
+        const int col = tid & 31, part = tid >> 5;
         float m = 0.f;
-        for (int k = 64 * part; k < 64 * part + 64; ++k) m = fmaxf(m, fabsf(W[(size_t)k * 1024 + 64 * c + col]));
+        for (int k = 32 * part; k < 32 * part + 32; ++k) m = fmaxf(m, fabsf(W[(size_t)k * 1024 + 64 * c + 32 * nt + col]));
         cmax[part][col] = m;
     }
     __syncthreads();
-    if (tid < 64) {
-        const float m = fmaxf(fmaxf(cmax[0][tid], cmax[1][tid]), fmaxf(cmax[2][tid], cmax[3][tid]));
-        float s, inv;
-        row_scale_pow2(m, s, inv);
-        cscale[tid] = s;
-        inv_col[64 * c + tid] = inv;
+    if (tid < 32) {
+        float m = cmax[0][tid];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) m = fmaxf(m, cmax[q][tid]);
+        float sc, inv;
+        row_scale_pow2(m, sc, inv);
+        cscale[tid] = sc;
+        if (kq == 0) inv_col[64 * c + 32 * nt + tid] = inv;
     }
     __syncthreads();
-    for (int e = tid; e < 16 * 2 * 64; e += 256) {
-        const int l = e & 63, nt = (e >> 6) & 1, s = e >> 7, i = l & 31, h = l >> 5;
+    {
+        const int l = tid & 63, s = 4 * kq + (tid >> 6), i = l & 31, h = l >> 5;
         const float* src = W + (size_t)(16 * s + 8 * h) * 1024 + 64 * c + 32 * nt + i;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * 1024];
         f16x8 hi, lo;
-        split8_f16s(v, cscale[32 * nt + i], hi, lo);
+        split8_f16s(v, cscale[i], hi, lo);
         u32x4* dst = out + ((size_t)(c * 16 + s) * 2 + nt) * 2 * 64 + l;
         dst[0] = __builtin_bit_cast(u32x4, hi);
         dst[64] = __builtin_bit_cast(u32x4, lo);
@@ -189,7 +193,7 @@ extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float*
     u32x4* pack = (u32x4*)scratch;
     float* inv_col = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)256 * 1024 * 4);
     float* stats = inv_col + 1024;
-    hipLaunchKernelGGL(h32_pack_conv5_kernel, dim3(16), dim3(256), 0, st, W5, pack, inv_col);
+    hipLaunchKernelGGL(h32_pack_conv5_kernel, dim3(16, 2, 4), dim3(256), 0, st, W5, pack, inv_col);
     const int wgs = (rows + 127) / 128;
     hipLaunchKernelGGL(h32_conv5_fwd_kernel, dim3(wgs), dim3(256), 0, st, cat, rows, (const u32x4*)pack, inv_col, b5, z5, stats);
     epc_moments_finalize_launch(stats, wgs, 1024, rows, 128, b5, mean, var, stream);
