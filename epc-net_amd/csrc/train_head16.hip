@@ -537,7 +537,7 @@ extern "C" int epc_h16_conv5_dx(const void* dz5, const float* W5, int rows, floa
 
 extern "C" size_t epc_h16_colgemm_scratch_bytes(int num_clouds, int n_points) {
     if (num_clouds <= 0 || n_points <= 0) return 0;
-    return (size_t)num_clouds * h16_splits(n_points) * 1024 * 64 * sizeof(float);
+    return (size_t)num_clouds * h16_splits(num_clouds, n_points, 8) * 1024 * 64 * sizeof(float);
 }
 
 // out = relu(bn(z5))^T (rn C): per cloud (per_cloud = 1: out (num_clouds, 1024, 64), the VLAD aggregation with C = a) or over all rows
@@ -546,11 +546,11 @@ extern "C" int epc_h16_colgemm(const void* z5, const float* mean5, const float* 
                                const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
                                size_t scratch_bytes, void* stream) {
     EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && C && rn && out && scratch, "null pointer");
-    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(n_points) <= 65535, "bad shape");
+    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(num_clouds, n_points, 8) <= 65535, "bad shape");
     EPC_CHECK_ARG(scratch_bytes >= epc_h16_colgemm_scratch_bytes(num_clouds, n_points), "scratch too small (epc_h16_colgemm_scratch_bytes)");
     EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const int S = h16_splits(n_points);
+    const int S = h16_splits(num_clouds, n_points, 8);
     const int rows_per_wg = (n_points + S - 1) / S;
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     hipLaunchKernelGGL((hx_colgemm_kernel<u16, 1>), dim3(8, num_clouds * S), dim3(256), 0, st, (const u16*)z5, bn, C, rn, rows_per_wg, n_points, S,

@@ -226,7 +226,7 @@ extern "C" int epc_h32_assign(const float* z5, const float* mean5, const float* 
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     h16_pack<2>(B, 64, 1, (long)1024 * 64, nb, 1024, 64, 1, 4, scratch, st);
     hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, float, 2, 4>), grid, dim3(256), 0, st, z5, n_points, (const u32x4*)scratch,
-                       per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, (float*)nullptr);
+                       per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr);
     if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -234,7 +234,7 @@ extern "C" int epc_h32_assign(const float* z5, const float* mean5, const float* 
 
 extern "C" size_t epc_h32_colgemm_scratch_bytes(int num_clouds, int n_points) {
     if (num_clouds <= 0 || n_points <= 0) return 0;
-    return (size_t)num_clouds * h16_splits(n_points) * 1024 * 64 * sizeof(float);
+    return (size_t)num_clouds * h16_splits(num_clouds, n_points, 16) * 1024 * 64 * sizeof(float);
 }
 
 // epc_h16_colgemm on f32 rows, two bf16 pieces per operand (three products): out = relu(bn(z5))^T (rn C)
@@ -242,11 +242,11 @@ extern "C" int epc_h32_colgemm(const float* z5, const float* mean5, const float*
                                const float* C, const float* rn, int num_clouds, int n_points, int per_cloud, float* out, void* scratch,
                                size_t scratch_bytes, void* stream) {
     EPC_CHECK_ARG(z5 && mean5 && var5 && gamma5 && beta5 && C && rn && out && scratch, "null pointer");
-    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(n_points) <= 65535, "bad shape");
+    EPC_CHECK_ARG(num_clouds > 0 && n_points > 0 && n_points % 32 == 0 && (long)num_clouds * h16_splits(num_clouds, n_points, 16) <= 65535, "bad shape");
     EPC_CHECK_ARG(scratch_bytes >= epc_h32_colgemm_scratch_bytes(num_clouds, n_points), "scratch too small (epc_h32_colgemm_scratch_bytes)");
     EPC_CHECK_ARG(h16_aligned16(z5) && h16_aligned16(scratch) && h16_aligned16(out), "tensors must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const int S = h16_splits(n_points);
+    const int S = h16_splits(num_clouds, n_points, 16);
     const int rows_per_wg = (n_points + S - 1) / S;
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     hipLaunchKernelGGL((hx_colgemm_kernel<float, 2>), dim3(16, num_clouds * S), dim3(256), 0, st, z5, bn, C, rn, rows_per_wg, n_points, S,
@@ -272,7 +272,7 @@ extern "C" int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, flo
     h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
     hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, dz5, rows,
-                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

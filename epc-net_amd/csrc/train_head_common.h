@@ -1,5 +1,7 @@
 // Shared by train_head16.hip (the head of the training step on bf16-stored tensors) and train_head32.hip (the same streaming kernels on
-// f32 tensors in the f32-accurate split arithmetic): bf16 helpers, the operand packs, and the row-streamed product.
+// f32 tensors in the f32-accurate split arithmetic): bf16 helpers, the operand packs, the row-streamed product (hx_rowgemm_kernel), the
+// column product with the rows as the contraction (hx_colgemm_kernel) and the ordered reduction of row-slice partials.  The kernels are
+// templates over the storage type of the (rows, 1024) tensor (u16 = bf16, float) and the number of bf16 pieces per operand.
 #pragma once
 #include "common.h"
 
@@ -131,7 +133,6 @@ __device__ __forceinline__ void h16_merge_stats(const float (*w)[3][64], const b
 //   XFORM: T = relu(batch_norm(.)) per channel (conv5's BatchNorm from its batch moments; coefficients in LDS) and the row factor
 //          rn = rsqrt(max(sum_c u^2, 1e-12)) from the f32 values of u, applied to the accumulators: out = rn (u B).
 //          rn_out != null: rn is written.  stats != null: column statistics of out ([workgroups][3][32 NT], tile_rows = 128).
-//          st_out != null (workgroup 0): the BatchNorm's per-channel scale and shift [2][1024], for the kernels that re-form u later.
 //   P: bf16 pieces per operand (hx_prod): 1 = the bf16 arithmetic; 2 / 3 = three / six products on f32 operands.
 //   NT = 2: the assignment's product and its gradient (B = Wc / dvlad[cloud]);  NT = 8, no XFORM: dcat = dz5 W5^T.
 // Workgroups never straddle clouds: grid = (ceil(n_points / 128), clouds); n_points a multiple of 32.
@@ -139,8 +140,7 @@ __device__ __forceinline__ void h16_merge_stats(const float (*w)[3][64], const b
 template <int NT, bool XFORM, typename TA, int P, int KSC>
 __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
-                                                            float* __restrict__ rn_out, float* __restrict__ stats,
-                                                            float* __restrict__ st_out = nullptr) {
+                                                            float* __restrict__ rn_out, float* __restrict__ stats) {
     constexpr bool A32 = sizeof(TA) == 4;
     constexpr int CHUNK_U4 = KSC * NT * P * 64;
     constexpr int CHUNKS = 64 / KSC;             // K = 1024 = 64 k-steps
@@ -172,30 +172,17 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
     const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
     const TA* arow = A + grow * 1024 + 8 * h;
     u32x4 an[KSC][AV];
-#ifdef HX_FAKE_COALESCED
-    // TIMING EXPERIMENT ONLY (wrong results): the same number of 16-byte loads over the same 32 rows, but every wave-instruction reads
-    // one contiguous kilobyte -- what the row-strided fragment loads would cost if they were coalesced
-    const TA* wbase = A + ((size_t)cloud * n_points + min(r0, n_points - 32)) * 1024 + lane * (16 / sizeof(TA));
-    auto aload = [&](int kc) {
-#pragma unroll
-        for (int s = 0; s < KSC; ++s)
-#pragma unroll
-            for (int w = 0; w < AV; ++w) an[s][w] = *reinterpret_cast<const u32x4*>(wbase + (size_t)(((KSC * kc + s) * AV + w) * (1024 / sizeof(TA))));
-    };
-#else
     auto aload = [&](int kc) {
 #pragma unroll
         for (int s = 0; s < KSC; ++s)
 #pragma unroll
             for (int w = 0; w < AV; ++w) an[s][w] = *reinterpret_cast<const u32x4*>(arow + 16 * (KSC * kc + s) + (A32 ? 4 * w : 0));
     };
-#endif
     aload(0);
     if constexpr (XFORM) {
         for (int c = tid; c < 1024; c += 256) {
             const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
             coef[0][c] = a.s, coef[1][c] = a.t;
-            if (st_out && blockIdx.x == 0 && blockIdx.y == 0) st_out[c] = a.s, st_out[1024 + c] = a.t;
         }
     }
     deposit(0);
@@ -467,5 +454,20 @@ static __global__ __launch_bounds__(256) void h16_partial_reduce_kernel(const fl
     *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * per + e) = s;
 }
 
-static inline int h16_splits(int n_points) { return n_points >= 1024 ? 4 : (n_points >= 512 ? 2 : 1); }
+// Row slices per cloud of the column product (hx_colgemm_kernel): `tiles` channel tiles x num_clouds x S workgroups of four waves, two
+// to a CU.  S is chosen so that the grid fills whole rounds of the chip's 2 x CUs workgroup slots: 8 x 18 x 4 = 576 workgroups ran as a
+// full round and a ninth of one; 8 x 18 x 3 = 432 run in one (0.84 of the slots).  At least 256 rows per slice (the four waves' partial
+// sums meet in LDS and leave as a 32-KB partial per slice); the 0.02 per slice prices those partials.
+static inline int h16_splits(int num_clouds, int n_points, int tiles) {
+    const long slots = 2L * epc_device_cu_count();
+    int best = 1;
+    double best_score = -1.0;
+    for (int s = 1; s <= 8 && (s == 1 || n_points / s >= 256); ++s) {
+        const long wgs = (long)tiles * num_clouds * s;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double score = (double)wgs / (double)(rounds * slots) - 0.02 * s;
+        if (score > best_score) best_score = score, best = s;
+    }
+    return best;
+}
 static inline bool h16_aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }

@@ -183,3 +183,46 @@ def test_expand16_and_argument_checks(dev):
         sc = torch.empty(1 << 22, dtype=torch.uint8, device=dev)
         L.check(L.lib().epc_h16_conv5_fwd(z.data_ptr(), 0, z.data_ptr(), z.data_ptr(), 48, z.data_ptr(), z.data_ptr(), z.data_ptr(),
                                           sc.data_ptr(), sc.numel(), L.current_stream()))
+
+
+def test_streamed_head_equals_the_per_layer_operators_in_a_training_step(dev):
+    """Two implementations of the head inside a whole EPC-Net step (default f32-accurate arithmetic): ops.HEAD_STREAM = True (the one
+    node of csrc/train_head32.hip) against False (LinearBatchNormTrain with the row norm + VladAssignAggregate through the feature map):
+    the same loss and the same 62 gradients to 1e-3 relative L2 -- the bar both are held to against the float64 oracle (measured: 2.5e-4
+    on VLAD/cluster_bn/beta, 64 sums of cancelling terms; three- vs six-product forward GEMMs, f32 accumulation orders)."""
+    from helpers import O
+    TR, ops = H.pkg("training"), H.pkg("ops")
+    w0 = O.seeded_weights("epc-net", 4)
+    pcs = O.synthetic_clouds(18, 256, 9)
+    tup = [torch.from_numpy(a).to(dev) for a in (pcs[None, :1], pcs[None, 1:3], pcs[None, 3:17], pcs[None, 17:])]
+    out = {}
+    for stream in (True, False):
+        st = H.make_store("epc-net", w0, dev)
+        ts = TR.TrainStep(dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1), st, outer=H.OUTER)
+        grads, orig, prev = {}, ops.adam_multi, ops.HEAD_STREAM
+
+        def spy(ws, ms, vs, gs, *a):
+            for w_, g in zip(ws, gs):
+                for k, t_ in st.vars.items():
+                    if t_.data_ptr() == w_.data_ptr():
+                        grads[k] = g.detach().double().cpu()
+            return orig(ws, ms, vs, gs, *a)
+
+        ops.adam_multi, ops.HEAD_STREAM = spy, stream
+        try:
+            loss, _, _ = ts.step(*tup, epoch=0)
+        finally:
+            ops.adam_multi, ops.HEAD_STREAM = orig, prev
+        out[stream] = (float(loss), grads)
+    (l1, g1), (l0, g0) = out[True], out[False]
+    assert l1 == pytest.approx(l0, rel=1e-5)
+    assert set(g1) == set(g0) and len(g1) == 62
+    worst = (0.0, "")
+    for k in g0:
+        n0 = float(g0[k].norm())
+        if k.endswith("/biases") or n0 <= 1e-12:
+            continue
+        worst = max(worst, (float((g1[k] - g0[k]).norm()) / n0, k))
+    print("streamed head vs per-layer operators, 18 x 256: worst gradient relative L2 difference %.2e (%s)" % worst)
+    assert worst[0] <= 1e-3, worst
+
