@@ -6,34 +6,35 @@
 // per step, every product re-reading and re-splitting f32 operand tiles (conv5's forward: 196 us for 15 us of matrix work).  Here every
 // kernel is ONE streaming pass over bf16 rows with the small operand resident or streamed through LDS, and the feature map
 // f = l2_normalize(relu(bn(z5))) is never written: BatchNorm + ReLU are applied to z5 as it is loaded (the row norm rn is a row factor
-// that moves to the other operand or to the epilogue).  All of them are HBM-bound by construction (MFMA, LDS and VALU time are each
-// below a third of the byte time at 5 TB/s), so the designs are the simplest ones that keep enough loads in flight.
+// that moves to the other operand or to the epilogue).  Their floors are byte times (189-453 MB per launch at the 5.5 TB/s a streaming
+// pass reaches); they run at 0.5-1.0 of them -- LDS fragment reads, MFMA issue and the epilogue's vector work, each below the byte time,
+// add up inside a wave instead of overlapping ("Training step": what bounds them, and what was tried).
 //
-//   tensors:  cat (rows, 256) f32 (the backbone's output, as the chain leaves it);  z5 (rows, 1024) bf16 = bf16(cat16 W5_16 + b5);
+//   tensors:  cat (rows, 256): the backbone's output, f32 and -- written beside it by the chain -- a bf16 copy, which is what these
+//             kernels read;  z5 (rows, 1024) bf16 = bf16(cat16 W5_16 + b5);
 //             rn (rows) f32;  za, a, dz, da (rows, 64) f32;  du / dz5 (rows, 1024) bf16 (in place);  dcat (rows, 256) f32.
 //   rounding points (restated by oracle/epcnet_oracle_torch.py: _Head16): operands of every product to bf16 once; z5, du and dz5 to
 //             bf16 as they are stored; batch statistics and column sums from the f32 values BEFORE that rounding.
 //
 //   forward   h16_conv5_fwd      z5 = bf16(cat W5 + b5), batch moments of conv5 from the accumulators            (epc-net.py:136-139)
-//             h16_rowgemm<2,X>   u = relu(bn(z5)); rn = rsqrt(max(sum u^2, 1e-12)); za = rn (u Wc), moments      (:147-148, loupe.py:255)
+//             hx_rowgemm<2,X>    u = relu(bn(z5)); rn = rsqrt(max(sum u^2, 1e-12)); za = rn (u Wc), moments      (:147-148, loupe.py:255)
 //             (epc_assign_softmax_fwd, train_ops.hip: a = softmax(bn(za)), a_sum)                                   (loupe.py:257-276)
-//             h16_colgemm        vlad[b] = u[b]^T (rn a)[b]                                                         (loupe.py:286-291)
-//   backward  h16_rowgemm<2,X>   da = rn (u dvlad[b])
+//             hx_colgemm         vlad[b] = u[b]^T (rn a)[b]                                                         (loupe.py:286-291)
+//   backward  hx_rowgemm<2,X>    da = rn (u dvlad[b])
 //             (epc_assign_softmax_bwd: dz, the cluster BatchNorm's gradients, t_row)
-//             h16_colgemm        dWc = u^T (rn dz)
+//             hx_colgemm         dWc = u^T (rn dz)
 //             h16_df_tail        du = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f t_row), sum du, sum du zhat
 //             h16_bn_bwd_apply   dz5 = gamma rstd (du - sum du / rows - zhat sum du zhat / rows)    (in place)
-//             h16_rowgemm<8>     dcat = dz5 W5^T
+//             hx_rowgemm<8>      dcat = dz5 W5^T
 //             h16_dw5            dW5 = cat^T dz5
-#include "common.h"
-
+// (hx_*: the templates of train_head_common.h, shared with the f32 head of train_head32.hip)
 #include "train_head_common.h"
 
 // ----------------------------------------------------------------------------------------------------------------
 // conv5's forward: z5 = bf16(A W5 + b5) with A = cat (rows, 256), f32 or bf16, and the batch statistics of the product.
-// A wave's 32 rows are RESIDENT as bf16 fragments (64 registers, read once); W5 streams through a double-buffered 32-KB LDS stage of 64
-// output columns shared by the workgroup's four waves (global -> registers under the previous stage's products -> LDS), one barrier per
-// stage; a stage's result leaves as one dword (two adjacent columns) per lane and row: whole 128-byte runs.  Per stage and wave the
+// A wave's 32 rows are RESIDENT as bf16 fragments (64 registers, read once); W5 streams through double-buffered 16-KB LDS stages (64
+// output columns x 128 k) shared by the workgroup's four waves (global -> registers under the previous stage's products -> LDS), one
+// barrier per stage; a column chunk's result leaves as one dword (two adjacent columns) per lane and row: whole 128-byte runs.  Per stage and wave the
 // pivot-shifted column sums go to LDS; 64 threads merge the four waves of the PREVIOUS stage behind the barrier that exists anyway.
 // rows a multiple of 32.  stats: [workgroups][3][1024] (tile_rows = 128 for epc_moments_finalize_launch).
 // ----------------------------------------------------------------------------------------------------------------

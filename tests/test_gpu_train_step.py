@@ -10,12 +10,14 @@ import helpers as H
 from helpers import O
 
 pytestmark = pytest.mark.gpu
-# relative L2 bar of the bf16 step's gradients against the operand-rounded float64 oracle (masks pinned).  Measured: all gradients
-# together 2.6e-2 (18 x 256) / 4.8e-2 (18 x 4096), the worst large tensor 8.2e-2 / 6.0e-2: an operand on a bf16 rounding boundary rounds
-# the other way in the restatement and twelve normalised layers amplify the 2^-9 steps -- the agreement two correct implementations of
-# this arithmetic reach (the operand-rounded oracle itself sits up to 4e-1 from the exact-product one); the cosine >= 0.9 it replaces
-# allowed 44 %.
-BF16_STEP_BAR = 1e-1
+# Relative L2 bars of the bf16 step's gradients against the float64 oracle with the SAME rounding points, the HIP forward's ReLU masks and
+# its stored pre-activations pinned (value pins: both sides round the same numbers at every later rounding point).  Measured (round 5,
+# 18 / 22 clouds): all gradients together 1.07e-2 / 1.10e-2 at 256 points, 1.83e-2-1.99e-2 / 1.94e-2-2.00e-2 at 4096; the worst LARGE
+# tensor (norm at least a tenth of the largest) 7.6e-2 / 5.9e-2 at 256 points (VLAD/cluster_weights2: sixty-four columns of a sum
+# over 256-point clouds), 1.8e-2 at 4096 (conv5's weights).  What is left between the two is f32 accumulation order and the du / dz5 /
+# operand elements that round the other way.  Before the pins the same comparison measured 8.2e-2 and the bars were 8e-2 / 1e-1.
+BF16_STEP_BAR_ALL = 3e-2
+BF16_STEP_BAR_LARGE = {256: 1e-1, 4096: 3e-2}
 
 
 @pytest.fixture(scope="module")
@@ -323,8 +325,8 @@ def test_bf16_precision_step_matches_the_operand_rounded_oracle(dev, n, nneg):
     print("bf16 step %dx%d: loss %.6f vs oracle %.6f, all gradients relative L2 error %.2e, worst large tensor %.2e (%s), worst tensor %.2e "
           "(%s), %d of %d mask elements differ, largest value-pin gap %.2e" % (ncl, n, float(loss), ref["loss"], total_rel, max(big)[0],
                                                                                  max(big)[1], worst[0], worst[1], flips, total, gap))
-    assert total_rel <= 0.8 * BF16_STEP_BAR, "bf16 step, all gradients: relative L2 error %.3e" % total_rel
-    assert max(big)[0] <= BF16_STEP_BAR, "bf16 step, gradient of %s: relative L2 error %.3e against the operand-rounded oracle" % (max(big)[1], max(big)[0])
+    assert total_rel <= BF16_STEP_BAR_ALL, "bf16 step, all gradients: relative L2 error %.3e" % total_rel
+    assert max(big)[0] <= BF16_STEP_BAR_LARGE[n], "bf16 step, gradient of %s: relative L2 error %.3e against the oracle with the same rounding points" % (max(big)[1], max(big)[0])
 
 
 def test_gemm_bf16_entry_matches_operand_rounded_reference(dev):
