@@ -690,3 +690,66 @@ extern "C" int epc_maxpool_points_bwd(const float* dy, const int32_t* arg, int n
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Two small sums of the VLAD head that were torch compositions (mul + reduce + neg; reshape + reduce):
+//   * cluster_weights2's gradient (loupe.py:284,292: vlad - a_sum (x) w2):  dw2[f][c] = - sum_b draw[b][f][c] a_sum[b][c], clouds in
+//     ascending order (what epc_vlad_normalize_bwd leaves to its caller: it crosses clouds);
+//   * the sum over the G group rows behind the grouped hidden projection (loupe.py:326-328): y[b][o] = sum_g x[b G + g][o], and its
+//     backward dx[b G + g][o] = dy[b][o].
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vlad_w2_grad_kernel(const float* __restrict__ draw, const float* __restrict__ a_sum, int B, long per,
+                                                           float* __restrict__ dw2) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;      // four consecutive clusters of one feature row
+    if (e >= per) return;
+    const int c = (int)(e & 63);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+        const float4 d = *reinterpret_cast<const float4*>(draw + (size_t)b * per + e);
+        const float4 a = *reinterpret_cast<const float4*>(a_sum + (size_t)b * 64 + c);
+        s.x += d.x * a.x, s.y += d.y * a.y, s.z += d.z * a.z, s.w += d.w * a.w;
+    }
+    *reinterpret_cast<float4*>(dw2 + e) = make_float4(-s.x, -s.y, -s.z, -s.w);
+}
+
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int G, int O, long total, int bwd, float* __restrict__ y) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    if (!bwd) {            // e = (b, o)
+        const long b = e / O, o = e % O;
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += x[(b * G + g) * O + o];
+        y[e] = s;
+    } else {               // e = (b G + g, o): x is dy (B, O)
+        const long row = e / O, o = e % O;
+        y[e] = x[(row / G) * O + o];
+    }
+}
+
+extern "C" int epc_vlad_w2_grad(const float* draw, const float* a_sum, int num_clouds, int F, int C, float* dw2, void* stream) {
+    EPC_CHECK_ARG(draw && a_sum && dw2, "null pointer");
+    EPC_CHECK_ARG(num_clouds > 0 && F > 0 && C == 64, "cluster_size must be 64");
+    EPC_CHECK_ARG(((reinterpret_cast<size_t>(draw) | reinterpret_cast<size_t>(a_sum) | reinterpret_cast<size_t>(dw2)) & 15) == 0,
+                  "tensors must be 16-byte aligned");
+    const long per = (long)F * 64;
+    hipLaunchKernelGGL(vlad_w2_grad_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, draw, a_sum, num_clouds,
+                       per, dw2);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_group_sum_fwd(const float* x, int rows_out, int G, int O, float* y, void* stream) {
+    EPC_CHECK_ARG(x && y && rows_out > 0 && G > 0 && O > 0, "bad argument");
+    const long total = (long)rows_out * O;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, G, O, total, 0, y);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_group_sum_bwd(const float* dy, int rows_out, int G, int O, float* dx, void* stream) {
+    EPC_CHECK_ARG(dy && dx && rows_out > 0 && G > 0 && O > 0, "bad argument");
+    const long total = (long)rows_out * G * O;
+    hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, G, O, total, 1, dx);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

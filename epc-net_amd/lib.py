@@ -57,7 +57,7 @@ EXPORTS = [
     "epc_h16_dx_scratch_bytes", "epc_h16_conv5_dx", "epc_h16_conv5_dw_scratch_bytes", "epc_h16_conv5_dw", "epc_h16_expand", "epc_gemm_splitk_det_b16",
     "epc_h32_conv5_fwd_scratch_bytes", "epc_h32_conv5_fwd", "epc_h32_assign_scratch_bytes", "epc_h32_assign",
     "epc_h32_colgemm_scratch_bytes", "epc_h32_colgemm", "epc_h32_dx_scratch_bytes", "epc_h32_conv5_dx",
-    "epc_maxpool_points_fwd", "epc_maxpool_points_bwd",
+    "epc_maxpool_points_fwd", "epc_maxpool_points_bwd", "epc_vlad_w2_grad", "epc_group_sum_fwd", "epc_group_sum_bwd",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -237,6 +237,9 @@ _lib.epc_h32_dx_scratch_bytes.argtypes = []
 _lib.epc_h32_conv5_dx.argtypes = _lib.epc_h16_conv5_dx.argtypes
 _lib.epc_maxpool_points_fwd.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_maxpool_points_bwd.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]
+_lib.epc_vlad_w2_grad.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]
+_lib.epc_group_sum_fwd.argtypes = [_P, c_int, c_int, c_int, _P, _P]
+_lib.epc_group_sum_bwd.argtypes = [_P, c_int, c_int, c_int, _P, _P]
 _lib.epc_profile_create.argtypes = [POINTER(_P)]
 _lib.epc_profile_destroy.argtypes = [_P]
 _lib.epc_net_forward_profiled.argtypes = [POINTER(EpcCfg), _P, _P, c_int, _P, _P, c_size_t, _P, _P]

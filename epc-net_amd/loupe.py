@@ -156,7 +156,7 @@ class _VladBase(PoolingBaseModel):
         vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                       # :322
         vlad = _slim_batch_norm(vlad, "bn", self.is_training, fused=True)                        # :323
         if G > 1:
-            vlad = vlad.reshape(-1, G, O).sum(dim=-2)                                            # :326-328
+            vlad = ops.GroupSum.apply(vlad, G)                                                   # :326-328
         if self.gating:
             vlad = self.context_gating(vlad)                                                     # :330-331
         return vlad

@@ -849,7 +849,8 @@ class VladNormalize(torch.autograd.Function):
                                                B, F, C, draw.data_ptr(), da.data_ptr(), _st()))
         dw2 = None
         if ctx.needs_input_grad[2]:
-            dw2 = -(draw * a_sum.reshape(B, 1, C)).sum(0, keepdim=True).reshape(w2.shape)
+            dw2 = torch.empty(w2.shape, dtype=torch.float32, device=out.device)
+            L.check(L.lib().epc_vlad_w2_grad(draw.data_ptr(), a_sum.data_ptr(), B, F, C, dw2.data_ptr(), _st()))
         return draw, da, dw2
 
 
@@ -1195,6 +1196,26 @@ def expand16(z16, bn=None, rn=None):
         L.check(L.lib().epc_h16_expand(z16.data_ptr(), mean.data_ptr(), var.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                        rn.data_ptr() if rn is not None else None, rows, y.data_ptr(), _st()))
     return y
+
+
+class GroupSum(torch.autograd.Function):
+    """tf.reduce_sum over the G group rows behind G_VLAD's shared hidden projection (loupe.py:326-328): (B G, O) -> (B, O)."""
+
+    @staticmethod
+    def forward(ctx, x, G):
+        x = x.contiguous()
+        rows, O = (int(v) for v in x.shape)
+        ctx.G, ctx.shape = int(G), (rows, O)
+        y = torch.empty((rows // int(G), O), dtype=torch.float32, device=x.device)
+        L.check(L.lib().epc_group_sum_fwd(x.data_ptr(), rows // int(G), int(G), O, y.data_ptr(), _st()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, O = ctx.shape
+        dx = torch.empty((rows, O), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().epc_group_sum_bwd(dy.contiguous().data_ptr(), rows // ctx.G, ctx.G, O, dx.data_ptr(), _st()))
+        return dx, None
 
 
 class MaxPoolPoints(torch.autograd.Function):

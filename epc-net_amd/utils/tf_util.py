@@ -3,9 +3,9 @@
 Tensors are ``torch.Tensor`` on a ROCm device; every contraction, normalisation, gather, reduction over points, loss and
 optimizer update is a call into libepcnet_hip.so and there is no torch / CPU fallback (``EpcNetError`` if no GPU is visible).
 What the differentiable (``is_training=True``) path still leaves to torch, all of it glue on small or already-materialised
-tensors: the residual ``t + x1`` of each block and the concat of the four block outputs (models/epc-net.py:81,134 -- elementwise
-adds / one copy, with autograd's matching accumulations), the sum over the 4 group rows and the ``a_sum`` reduction of
-loupe.py:276,328, the sigmoid gate of loupe.py:97-99 on (B, 256) and the ReLU of a BN-less layer.  The fused inference path has none of these.  Variables are created in the current
+tensors, and only on the per-layer path (``USE_CHAIN = False`` / inference-mode ``forward_ops``): the residual ``t + x1`` of each block
+and the concat of the four block outputs (models/epc-net.py:81,134 -- elementwise adds / one copy, with autograd's matching
+accumulations), the ``a_sum`` reduction of loupe.py:276 outside the fused assignment node, and the ReLU of a BN-less layer.  The fused inference path has none of these.  Variables are created in the current
 ``variable_scope`` with the reference's names and initialisers, so a model built from these wrappers has the
 same state-dict as the reference checkpoint.
 

@@ -663,6 +663,14 @@ int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const flo
                             long sBk, long sBn, int ldc, int batch, long bA, long bB, long bC, int splitk, int accumulate, int pieces,
                             float* workspace, size_t workspace_floats, void* stream);
 
+/* cluster_weights2's gradient (loupe.py:284,292; the part of the VLAD normalisation's backward that crosses clouds):
+ * dw2 (F, 64) = - sum over the clouds, in ascending order, of draw (num_clouds, F, 64) x a_sum (num_clouds, 64); 16-byte aligned. */
+int epc_vlad_w2_grad(const float* draw, const float* a_sum, int num_clouds, int F, int C, float* dw2, void* stream);
+/* The sum over the G group rows behind G_VLAD's shared hidden projection (loupe.py:326-328): y (rows_out, O) = sum_g x (rows_out G, O);
+ * bwd: dx (rows_out G, O) = dy (rows_out, O) repeated over the group. */
+int epc_group_sum_fwd(const float* x, int rows_out, int G, int O, float* y, void* stream);
+int epc_group_sum_bwd(const float* dy, int rows_out, int G, int O, float* dx, void* stream);
+
 /* EPC-Net-L's global max-pool over a cloud's points in training mode (models/epc-net-l.py:88-92; utils/tf_util.py:349-372 with the
  * kernel covering all N points): out (num_clouds, C) = max over n of x (num_clouds, n, C), arg = the row holding it (the first on ties --
  * where tf.nn.max_pool's gradient goes); bwd: dx = dy at that row, zero elsewhere (dx is cleared here).  NaN propagates. */

@@ -653,3 +653,32 @@ def test_maxpool_points_op(dev):
     assert float(gt[0, 7].sum()) == 64.0 and float(gt[0, 40].sum()) == 0.0 and float(gt[0].sum()) == 64.0
     assert bool(torch.isnan(yt[1, 3])) and float(yt[1, 2]) == 0.0
     assert float(gt[1, 0, :3].sum()) == 3.0      # (all-zero columns: row 0 is the first maximum)
+
+
+def test_vlad_w2_grad_and_group_sum_ops(dev):
+    """The two small sums of the VLAD head as library ops (loupe.py:284,292 and :326-328): cluster_weights2's gradient through
+    ops.VladNormalize and ops.GroupSum, forward and backward, against torch float64."""
+    ops = H.pkg("ops")
+    g = torch.Generator().manual_seed(4)
+    B, F, C = 5, 256, 64
+    raw, a_sum, w2 = (torch.randn(B, F, C, generator=g).to(dev), torch.rand(B, 1, C, generator=g).to(dev) * 30,
+                      (torch.randn(1, F, C, generator=g) * 0.1).to(dev))
+    xs = [t.clone().requires_grad_(True) for t in (raw, a_sum, w2)]
+    out = ops.VladNormalize.apply(*xs)
+    wgt = torch.randn(B, F, C, generator=g).to(dev)
+    gr = torch.autograd.grad((out * wgt).sum(), xs)
+    ys = [t.double().cpu().clone().requires_grad_(True) for t in (raw, a_sum, w2)]
+    v = ys[0] - ys[1] * ys[2]
+    v = v * torch.rsqrt(torch.clamp((v * v).sum(1, keepdim=True), min=1e-12))
+    flat = v.reshape(B, -1)
+    ref = (flat * torch.rsqrt(torch.clamp((flat * flat).sum(1, keepdim=True), min=1e-12))).reshape(B, F, C)
+    g_ref = torch.autograd.grad((ref * wgt.double().cpu()).sum(), ys)
+    assert float((out.double().cpu() - ref).abs().max()) <= 1e-6
+    for a, b in zip(gr, g_ref):
+        assert float((a.double().cpu() - b).norm() / b.norm()) <= 2e-5
+    x = torch.randn(6 * 4, 256, generator=g).to(dev).requires_grad_(True)
+    y = ops.GroupSum.apply(x, 4)
+    assert torch.allclose(y, x.detach().reshape(6, 4, 256).sum(1), atol=1e-6)
+    w = torch.randn(6, 256, generator=g).to(dev)
+    (gx,) = torch.autograd.grad((y * w).sum(), x)
+    assert torch.equal(gx, w[:, None, :].expand(6, 4, 256).reshape(24, 256))
