@@ -330,11 +330,26 @@ class TorchOracle:
         return (features, out) if return_features else out
 
 
-def lazy_quadruplet_loss(q, pos, neg, other, m1, m2):
-    """models/epc-net.py:269-284."""
-    best = ((pos - q) ** 2).sum(2).min(1).values.reshape(-1, 1)
-    l1 = torch.clamp(m1 + best - ((neg - q) ** 2).sum(2), min=0).max(1).values.mean()
-    l2 = torch.clamp(m2 + best - ((neg - other) ** 2).sum(2), min=0).max(1).values.mean()
+def lazy_quadruplet_loss(q, pos, neg, other, m1, m2, select_on=None):
+    """models/epc-net.py:269-284.  ``select_on`` = (q, pos, neg, other) of ANOTHER evaluation of the same descriptors (the
+    implementation under test's): the loss's three selections -- the closest positive, the hardest negative of each term -- are then made
+    on those numbers and applied to these (same function wherever the two evaluations select alike; descriptors of synthetic clouds lie
+    a rounding apart, and two different selections would compare two different gradients)."""
+    d_pos, d_neg, d_oth = ((pos - q) ** 2).sum(2), ((neg - q) ** 2).sum(2), ((neg - other) ** 2).sum(2)
+    if select_on is None:
+        best = d_pos.min(1).values.reshape(-1, 1)
+        l1 = torch.clamp(m1 + best - d_neg, min=0).max(1).values.mean()
+        l2 = torch.clamp(m2 + best - d_oth, min=0).max(1).values.mean()
+        return l1 + l2
+    qs, ps, ns, os_ = select_on
+    s_pos, s_neg, s_oth = ((ps - qs) ** 2).sum(2), ((ns - qs) ** 2).sum(2), ((ns - os_) ** 2).sum(2)
+    ib = s_pos.argmin(1, keepdim=True)
+    s_best = s_pos.gather(1, ib)
+    i1 = torch.clamp(m1 + s_best - s_neg, min=0).argmax(1, keepdim=True)
+    i2 = torch.clamp(m2 + s_best - s_oth, min=0).argmax(1, keepdim=True)
+    best = d_pos.gather(1, ib)
+    l1 = torch.clamp(m1 + best - d_neg, min=0).gather(1, i1).mean()
+    l2 = torch.clamp(m2 + best - d_oth, min=0).gather(1, i2).mean()
     return l1 + l2
 
 
@@ -356,7 +371,14 @@ def train_step(weights: Dict[str, np.ndarray], query, positives, negatives, othe
     out = orc.forward(vecs, True, bn_decay)
     npos, nneg = positives.shape[1], negatives.shape[1]
     q, pos, neg, oth = torch.split(out, [1, npos, nneg, 1], dim=1)                    # train.py:255
-    loss = lazy_quadruplet_loss(q, pos, neg, oth, m1, m2)
+    select_on = None
+    if value_pins is not None and "descriptors" in value_pins:
+        # the descriptors of the implementation under test: the loss SELECTS on them (lazy_quadruplet_loss), the values stay this
+        # oracle's own
+        pin = torch.as_tensor(np.asarray(value_pins["descriptors"], dtype=np.float64).reshape(tuple(out.shape)), dtype=out.dtype)
+        orc.value_pin_gap["descriptors"] = float((pin - out.detach()).abs().max() / out.detach().abs().max())
+        select_on = torch.split(pin, [1, npos, nneg, 1], dim=1)
+    loss = lazy_quadruplet_loss(q, pos, neg, oth, m1, m2, select_on)
     grads = torch.autograd.grad(loss, [orc.w[k] for k in orc.trainable], allow_unused=True)
     lr = O.get_learning_rate(epoch, base_lr)
     b1, b2, eps = 0.9, 0.999, 1e-8                                                    # tf.train.AdamOptimizer defaults

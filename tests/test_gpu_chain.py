@@ -92,12 +92,19 @@ def test_chain_is_bit_reproducible(dev):
         assert (a[1][k] is None and b[1][k] is None) or np.array_equal(a[1][k], b[1][k]), k
 
 
-def test_chain_bf16_arithmetic_tracks_the_f32_accurate_one(dev):
-    """pieces = 1 (one bf16 value per operand): the same chain, every product at 2^-9 per operand -- outputs within bf16's error of
-    the f32-accurate chain (the exact comparison of this arithmetic is against the operand-rounded oracle: test_gpu_train_step)."""
-    w = O.seeded_weights("epc-net-l", 4)
-    pc = O.synthetic_clouds(4, 256, 5)
-    a = _backbone("epc-net-l", w, pc, dev, True)
-    b = _backbone("epc-net-l", w, pc, dev, True, precision="bf16")
+@pytest.mark.parametrize("arch,ncl,n", [("epc-net-l", 4, 256), ("epc-net", 18, 4096)])
+def test_chain_bf16_arithmetic_tracks_the_f32_accurate_one(dev, arch, ncl, n):
+    """pieces = 1 (one bf16 value per operand; the chain's stored tensors stay float32): the same chain, every product at 2^-9 per
+    operand -- outputs within bf16's error of the f32-accurate chain at one tile per workgroup and at the training tuple's nine (5.5e-3
+    and 1.3e-2 relative L2 measured; the exact comparison of this arithmetic is against the oracle with the same rounding points:
+    test_gpu_train_step).  The bar is also what rejected STORING the chain's activations as bf16 (round 5: 1.4e-2 and 8.6e-2 -- the
+    neighbour difference xm - x cancels, and a rounded z0 goes through it -- for 0.03 ms of a 2.1-ms step: DESIGN.md)."""
+    w = O.seeded_weights(arch, 4)
+    pc = O.synthetic_clouds(ncl, n, 5)
+    a = _backbone(arch, w, pc, dev, True)
+    b = _backbone(arch, w, pc, dev, True, precision="bf16")
     rel = np.linalg.norm(a[0] - b[0]) / np.linalg.norm(a[0])
+    print("bf16-operand chain vs f32-accurate chain, %s %dx%d: cat rel L2 %.2e" % (arch, ncl, n, rel))
     assert 1e-5 < rel < 3e-2, rel
+    for k, va in a[2].items():
+        assert np.abs(b[2][k] - va).max() <= 2e-2 * max(np.abs(va).max(), 1e-3), k

@@ -295,6 +295,10 @@ def test_bf16_precision_step_matches_the_operand_rounded_oracle(dev, n, nneg):
     masks = {k[len(H.OUTER) + 1:]: v.cpu().numpy() for k, v in masks.items()}
     pins = {k[len(H.OUTER) + 1:]: v.cpu().numpy() for k, v in pins.items()}
     assert len(masks) == 13 and len(pins) == 13, (sorted(masks), sorted(pins))
+    # the loss's selections (closest positive, hardest negatives: argmin / argmax over descriptors of random clouds, a rounding apart
+    # from each other) are made on the HIP step's descriptors: one more value pin
+    aux = ts.last_aux
+    pins["descriptors"] = torch.cat([aux["q_vec"], aux["pos_vecs"], aux["neg_vecs"], aux["other_neg_vec"]], 1).double().cpu().numpy()
     srt = ops.morton_sort(torch.from_numpy(pcs).to(dev)).cpu().numpy()[None]
     sp = (srt[:, :1], srt[:, 1:3], srt[:, 3:3 + nneg], srt[:, 3 + nneg:])
     ref = T.train_step(w0, *sp, step=3, epoch=7, arch="epc-net", relu_masks=masks, gemm_rounding="bf16", value_pins=pins)
@@ -303,7 +307,7 @@ def test_bf16_precision_step_matches_the_operand_rounded_oracle(dev, n, nneg):
     gap = max(ref["value_pin_gap"].values())
     # (a layer's stored pre-activation against the oracle's own value of it, computed from the PREVIOUS layer's pinned value: one
     # layer of bf16-operand arithmetic apart -- a forward bug in any layer shows here)
-    assert len(ref["value_pin_gap"]) == 13 and gap <= 1e-2, ref["value_pin_gap"]
+    assert len(ref["value_pin_gap"]) == 14 and gap <= 1e-2, ref["value_pin_gap"]
     assert flips <= 2e-4 * total, (flips, total)
     assert float(loss) == pytest.approx(ref["loss"], rel=5e-3, abs=1e-5)
     worst = (0.0, "")

@@ -196,3 +196,29 @@ def test_head16_restatement_without_rounding_is_the_plain_graph():
             assert a.abs().max() <= 1e-10 and b.abs().max() == 0
             continue
         assert (a - b).abs().max() <= 1e-9 * max(1.0, float(a.abs().max())), (k, float((a - b).abs().max()))
+
+
+def test_selection_pinned_loss_is_the_loss_where_the_selections_agree():
+    """lazy_quadruplet_loss(select_on=...) (the bf16 step test's last value pin): selecting on the same descriptors is the plain loss,
+    value and gradient; selecting on other numbers applies THEIR closest positive / hardest negatives to these distances."""
+    import torch
+    import epcnet_oracle_torch as T
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    q, pos, neg, oth = mk(3, 1, 8).requires_grad_(True), mk(3, 2, 8), mk(3, 5, 8), mk(3, 1, 8)
+    a = T.lazy_quadruplet_loss(q, pos, neg, oth, 5.0, 2.0)
+    b = T.lazy_quadruplet_loss(q, pos, neg, oth, 5.0, 2.0, (q.detach(), pos, neg, oth))
+    assert float(a) == float(b)
+    assert torch.equal(torch.autograd.grad(a, q)[0], torch.autograd.grad(b, q)[0])
+    # selecting on OTHER numbers: their argmin / argmax, applied to these distances -- by hand
+    qs, ps, ns, os_ = mk(3, 1, 8), mk(3, 2, 8), mk(3, 5, 8), mk(3, 1, 8)
+    c = T.lazy_quadruplet_loss(q, pos, neg, oth, 5.0, 2.0, (qs, ps, ns, os_))
+    d_pos, d_neg, d_oth = ((pos - q) ** 2).sum(2), ((neg - q) ** 2).sum(2), ((neg - oth) ** 2).sum(2)
+    s_pos, s_neg, s_oth = ((ps - qs) ** 2).sum(2), ((ns - qs) ** 2).sum(2), ((ns - os_) ** 2).sum(2)
+    want = 0.0
+    for b_ in range(3):
+        ib = int(s_pos[b_].argmin())
+        i1 = int(torch.clamp(5.0 + s_pos[b_, ib] - s_neg[b_], min=0).argmax())
+        i2 = int(torch.clamp(2.0 + s_pos[b_, ib] - s_oth[b_], min=0).argmax())
+        want += float(torch.clamp(5.0 + d_pos[b_, ib] - d_neg[b_, i1], min=0) + torch.clamp(2.0 + d_pos[b_, ib] - d_oth[b_, i2], min=0)) / 3
+    assert float(c) == pytest.approx(want, rel=1e-12)
