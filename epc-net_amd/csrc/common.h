@@ -136,6 +136,28 @@ __host__ __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
     return c.f;
 }
 
+// Tail splitting of a row-tiled launch: `tiles` tiles of `chunks` equal column chunks on `slots` co-resident workgroups.  The first
+// `whole` tiles (the largest multiple of `slots` that fits) take a workgroup each; each of the rest is cut into `parts` workgroups of
+// chunks / parts chunks -- the last, partly filled round then costs a fraction of a tile's time instead of a whole one (576 tiles on
+// 512 slots: 1 + 1/8 rounds instead of 2; on 768 slots: four parts each, three full rounds of quarter tiles instead of a round in which a
+// quarter of the CUs carry a third more).  `parts` = the power of two that minimises the slot-time  rounds x (1 / parts + overhead), with
+// a workgroup's fixed cost (its prologue: the resident operand, the first stage) priced at 6 % of a tile.
+// Workgroup b < whole: tile b, every chunk; else tile whole + (b - whole) / parts, part (b - whole) % parts.
+static inline void epc_tail_split(int tiles, int slots, int chunks, int& whole, int& parts) {
+    whole = slots > 0 ? tiles / slots * slots : tiles;
+    const int rem = tiles - whole;
+    parts = 1;
+    if (rem <= 0 || slots <= 0) return;
+    const double overhead = 0.06;
+    double best = 1e30;
+    for (int p = 1; p <= chunks; p *= 2) {
+        if (chunks % p) break;
+        const long rounds = ((long)rem * p + slots - 1) / slots;
+        const double cost = (double)rounds * (1.0 / p + overhead);
+        if (cost < best - 1e-9) best = cost, parts = p;
+    }
+}
+
 void epc_set_error(const char* fmt, ...);
 // Compute units of the CURRENT device, cached per device id (a read-mostly table of ints: a racing first call writes the same
 // value twice).  256 when the query fails.

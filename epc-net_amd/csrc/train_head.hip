@@ -358,7 +358,8 @@ extern "C" int epc_sq_err_bwd(const float* a, const float* b, long n, int mean, 
 // 512 KB per cloud) and streams through a double-buffered 16-KB LDS chunk of 32 output columns shared by the workgroup's waves (global ->
 // registers under the previous chunk's products -> LDS), one barrier per chunk; the wave writes whole 128-byte row segments.
 // Measured at 18 x 4096 rows (scripts/time_df.py): 114 us against 160-175 us for torch.cat + the generic product, the same bits.
-// Four-wave workgroups (three per CU at 146 registers): eight-wave ones at 128 registers spilled and took 136-165 us.  Arithmetic: two bf16 pieces per operand, three products
+// Four-wave workgroups (three per CU at 146 registers; the tail form: two per CU, its tiles beyond a whole round cut into column parts --
+// epc_tail_split, 168 -> 136 us): eight-wave ones at 128 registers spilled and took 136-165 us.  Arithmetic: two bf16 pieces per operand, three products
 // (epc_gemm_f32_fast's); PIECES = 1: one bf16 value per operand.
 // ----------------------------------------------------------------------------------------------------------------
 #define VDF_WAVES 4
@@ -405,7 +406,7 @@ struct VdfTail {
 template <int PIECES, bool TAIL>
 __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(const float* __restrict__ a, const float* __restrict__ dz,
                                                                     const u32x4* __restrict__ Bp, int n_points, int F,
-                                                                    float* __restrict__ df, VdfTail tail) {
+                                                                    float* __restrict__ df, VdfTail tail, int whole, int parts) {
     __shared__ u32x4 Bs[2][VDF_NT * VDF_CHUNK_U4];   // 2 x 16 KB
     __shared__ __attribute__((aligned(16))) float coef[TAIL ? 4 : 1][TAIL ? 1024 : 1];   // per column: s, t, mean, rstd
     __shared__ __attribute__((aligned(16))) float rowc[TAIL ? VDF_WAVES : 1][2][32];      // per wave and row: rn, rn * t_row (0 when clamped)
@@ -414,13 +415,20 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
     // stage are sixteen scalar bases + ONE vector offset instead of sixteen 64-bit vector addresses)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int tile = blockIdx.x * VDF_WAVES + wave;            // 32-row tile of the cloud
+    // Work split (round 5): workgroup = (a 128-row tile of a cloud, a RANGE of the column stages).  The first `whole` tiles (a multiple of
+    // the co-resident workgroup count) take every stage; each of the rest is cut into `parts` workgroups (epc_tail_split): the last,
+    // partly filled round costs a fraction of a tile's time.  The sums' partials stay one per tile.
+    const int tpc = ((n_points + 31) / 32 + VDF_WAVES - 1) / VDF_WAVES;   // 128-row tiles per cloud
+    const int wg = (int)blockIdx.x < whole ? (int)blockIdx.x : whole + ((int)blockIdx.x - whole) / parts;
+    const int b = wg / tpc;
+    const int tile = (wg % tpc) * VDF_WAVES + wave;            // 32-row tile of the cloud
     const int r0 = tile * 32;
     const bool live = r0 < n_points;                            // (a wave past the cloud's end only helps staging)
     const int rl = min(r0 + i, n_points - 1);
     const size_t row = (size_t)b * n_points + rl;
     const int stages = F / (32 * VDF_NT);
+    const int st_begin = (int)blockIdx.x < whole ? 0 : (((int)blockIdx.x - whole) % parts) * (stages / parts);
+    const int st_end = (int)blockIdx.x < whole ? stages : st_begin + stages / parts;
     const u32x4* src = Bp + (size_t)b * (F / 32) * VDF_CHUNK_U4;
     // a stage's fragments travel global -> registers -> LDS in two steps, so that the loads of stage st + 1 are in flight under the
     // products and stores of stage st (a plain copy loop waits for its loads before the wave's first MFMA: 32 exposed round trips)
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
 #pragma unroll
         for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 64 * VDF_WAVES] = pre[u];
     };
-    request(0);   // (while the A rows travel)
+    request(st_begin);   // (while the A rows travel)
     // A[m = row i][k]: lane (i, h) of k-step s holds k = 16 s + 8 h .. + 7: s < 4 from a, s >= 4 from dz
     bf16x8 ah[8], al[8];
 #pragma unroll
@@ -466,9 +474,8 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
             rowc[wave][1][i] = rnv >= 0.99e6f ? 0.f : rnv * tv;
         }
     }
-    deposit(0);
+    deposit(st_begin & 1);
     __syncthreads();
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     // rows of the tile as scalar bases: row (r & 3) + 8 (r >> 2) of the tile, + 4 h rows and the column in the vector offset
     const size_t tile_base = ((size_t)b * n_points + r0) * F;   // (scalar: b, r0)
     const unsigned voff = 4u * h * (unsigned)F + i;
@@ -483,19 +490,19 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
         }
     };
     if constexpr (TAIL) {
-        if (live) zload(0);
+        if (live) zload(st_begin);
     }
-    for (int st = 0; st < stages; ++st) {
+    for (int st = st_begin; st < st_end; ++st) {
         const int buf = st & 1;
-        if (st + 1 < stages) request(st + 1);
+        if (st + 1 < st_end) request(st + 1);
         float zv[TAIL ? 16 : 1];
         if constexpr (TAIL) {
             // this stage's z5 values were requested a stage ago (an HBM round trip is longer than a stage's products); request the next
 #pragma unroll
             for (int r = 0; r < 16; ++r) zv[r] = zn[r];
-            if (live && st + 1 < stages) zload(st + 1);
+            if (live && st + 1 < st_end) zload(st + 1);
             // the previous stage's column sums: four waves -> one partial (the barrier at the end of that stage published them)
-            if (st > 0 && tid < 64) {
+            if (st > st_begin && tid < 64) {
                 const int q = tid >> 5, c = tid & 31;
                 const float v = (psum[buf ^ 1][0][q][c] + psum[buf ^ 1][1][q][c]) + (psum[buf ^ 1][2][q][c] + psum[buf ^ 1][3][q][c]);
                 tail.partials[((size_t)wg * 2 + q) * F + 32 * (st - 1) + c] = v;
@@ -554,14 +561,14 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
         } else if constexpr (TAIL) {
             if (h == 0) psum[buf][wave][0][i] = 0.f, psum[buf][wave][1][i] = 0.f;
         }
-        if (st + 1 < stages) deposit(buf ^ 1);   // (the other buffer: its last readers passed the barrier at the end of stage st - 1)
+        if (st + 1 < st_end) deposit(buf ^ 1);   // (the other buffer: its last readers passed the barrier at the end of stage st - 1)
         __syncthreads();
     }
     if constexpr (TAIL) {
         if (tid < 64) {
-            const int q = tid >> 5, c = tid & 31, pb = (stages - 1) & 1;
+            const int q = tid >> 5, c = tid & 31, pb = (st_end - 1) & 1;
             const float v = (psum[pb][0][q][c] + psum[pb][1][q][c]) + (psum[pb][2][q][c] + psum[pb][3][q][c]);
-            tail.partials[((size_t)wg * 2 + q) * F + 32 * (stages - 1) + c] = v;
+            tail.partials[((size_t)wg * 2 + q) * F + 32 * (st_end - 1) + c] = v;
         }
     }
 }
@@ -582,9 +589,10 @@ extern "C" int epc_vlad_df(const float* a, const float* dz, const float* dvlad, 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(vlad_df_pack_kernel, dim3(F / 32, num_clouds), dim3(256), 0, st, dvlad, Wc, F, (u32x4*)packed);
     const int tiles = (n_points + 31) / 32;
-    const dim3 grid((tiles + VDF_WAVES - 1) / VDF_WAVES, num_clouds);
-    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{});
-    else hipLaunchKernelGGL((vlad_df_kernel<1, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{});
+    const int wgs = (tiles + VDF_WAVES - 1) / VDF_WAVES * num_clouds;   // (three workgroups per CU: every tile whole)
+    const dim3 grid(wgs);
+    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{}, wgs, 1);
+    else hipLaunchKernelGGL((vlad_df_kernel<1, false>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, df, VdfTail{}, wgs, 1);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -614,11 +622,14 @@ extern "C" int epc_vlad_df_tail(const float* a, const float* dz, const float* dv
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(vlad_df_pack_kernel, dim3(F / 32, num_clouds), dim3(256), 0, st, dvlad, Wc, F, (u32x4*)packed);
     const int tiles = (n_points + 31) / 32;
-    const dim3 grid((tiles + VDF_WAVES - 1) / VDF_WAVES, num_clouds);
+    const int wgs = (tiles + VDF_WAVES - 1) / VDF_WAVES * num_clouds;
+    int whole, parts;
+    epc_tail_split(wgs, 2 * epc_device_cu_count(), F / (32 * VDF_NT), whole, parts);   // (two workgroups per CU: launch bounds of the tail form)
+    const dim3 grid(whole + (wgs - whole) * parts);
     const VdfTail tail{z5, rn, trow, mean, var, gamma, beta, eps, partials};
-    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail);
-    else hipLaunchKernelGGL((vlad_df_kernel<1, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail);
-    epc_partial_sum_wide_launch(partials, (int)(grid.x * grid.y), 2 * F, dbeta_dgamma, stream);   // [0, F): sum du; [F, 2F): sum du zhat
+    if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail, whole, parts);
+    else hipLaunchKernelGGL((vlad_df_kernel<1, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail, whole, parts);
+    epc_partial_sum_wide_launch(partials, wgs, 2 * F, dbeta_dgamma, stream);   // [0, F): sum du; [F, 2F): sum du zhat
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -66,27 +66,38 @@ __global__ __launch_bounds__(256) void h32_pack_conv5_kernel(const float* __rest
 // ----------------------------------------------------------------------------------------------------------------
 #define C32_STAGE_U4 (8 * 2 * 2 * 64)   // 32 KB: [k-step 8][nt 2][hi, lo][lane]
 
-__global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __restrict__ A, int rows, const u32x4* __restrict__ Bp,
+// Work split (round 5): EIGHT waves = a 256-row tile per workgroup, one workgroup per CU (256 registers a lane: two waves per SIMD).  What
+// bounds this kernel is the weights' stream: every workgroup draws the whole 1-MB pack through its CU's miss path (~10 B/clk), 604 MB per
+// launch with 128-row tiles -- twice the bytes of z5 -- and 302 with 256-row ones.  A workgroup takes a tile and a RANGE of its sixteen
+// 64-column chunks: 18 x 4096 rows are 288 tiles, and a tile per workgroup on 256 CUs is two rounds with the second one eighth full;
+// instead the first `whole` tiles (a multiple of the slot count) go to one workgroup each and every remaining tile to `parts` workgroups
+// of 16 / parts chunks -- 256 + 32 x 8 workgroups, 18 chunk-times per CU instead of 32.  Statistics partials stay [tile][3][1024]: every
+// (tile, chunk) is produced by exactly one workgroup.
+#define C32_WAVES 8
+__global__ __launch_bounds__(64 * C32_WAVES, 1) void h32_conv5_fwd_kernel(const float* __restrict__ A, int rows, const u32x4* __restrict__ Bp,
                                                                const float* __restrict__ inv_col, const float* __restrict__ bias,
-                                                               float* __restrict__ Z, float* __restrict__ stats) {
+                                                               float* __restrict__ Z, float* __restrict__ stats, int whole, int parts) {
     __shared__ u32x4 Bs[2][C32_STAGE_U4];
-    __shared__ float wst[2][4][3][64];
-    __shared__ float rowc[4][32];
-    __shared__ bool wlive[4];
+    __shared__ float wst[2][C32_WAVES][3][64];
+    __shared__ float rowc[C32_WAVES][32];
+    __shared__ bool wlive[C32_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int r0 = blockIdx.x * 128 + wave * 32;
+    const int b = blockIdx.x;
+    const int tile = b < whole ? b : whole + (b - whole) / parts;
+    const int st_begin = b < whole ? 0 : ((b - whole) % parts) * (16 / parts), st_end = b < whole ? 16 : st_begin + 16 / parts;
+    const int r0 = tile * (32 * C32_WAVES) + wave * 32;
     const bool live = r0 < rows;
     if (lane == 0) wlive[wave] = live;
-    constexpr int PER = C32_STAGE_U4 / 256;
+    constexpr int PER = C32_STAGE_U4 / (64 * C32_WAVES);
     u32x4 pre[PER];
     auto request = [&](int step) {   // step = 2 chunk + half: [chunk][k-step][nt][piece][lane], so halves are contiguous
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pre[u] = Bp[(size_t)step * C32_STAGE_U4 + tid + u * 256];
+        for (int u = 0; u < PER; ++u) pre[u] = Bp[(size_t)step * C32_STAGE_U4 + tid + u * (64 * C32_WAVES)];
     };
     auto deposit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * (64 * C32_WAVES)] = pre[u];
     };
     f16x8 ah[16], al[16];      // (the first stage's fragments are requested AFTER the split: the raw row and they do not fit together)
     {
@@ -109,21 +120,19 @@ __global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __re
             split8_f16s(v, sc, ah[s], al[s]);
         }
     }
-    request(0);
+    request(2 * st_begin);
     deposit(0);
     __syncthreads();
     auto flush_stats = [&](int st, int buf) {
         if (tid < 64) {
             float S1, S2, P;
-            h16_merge_stats(wst[buf], wlive, tid, S1, S2, P);
-            float* o = stats + (size_t)blockIdx.x * 3 * 1024 + 64 * st + tid;
+            h16_merge_stats<C32_WAVES>(wst[buf], wlive, tid, S1, S2, P);
+            float* o = stats + (size_t)tile * 3 * 1024 + 64 * st + tid;
             o[0] = S1, o[1024] = S2, o[2048] = P;
         }
     };
-    float irow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) irow[r] = rowc[wave][mfma_row(r, h)];
-    for (int st = 0; st < 16; ++st) {
+    float* const zrow = Z + (size_t)r0 * 1024;   // (wave-uniform base: the stores take 32-bit lane offsets)
+    for (int st = st_begin; st < st_end; ++st) {
         const int sb = st & 1;
         f32x16 acc[2];
 #pragma unroll
@@ -143,12 +152,12 @@ __global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __re
                 }
         };
         request(2 * st + 1);
-        if (st > 0) flush_stats(st - 1, sb ^ 1);
+        if (st > st_begin) flush_stats(st - 1, sb ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if (live) half(0, 0);
         deposit(1);
         __syncthreads();
-        if (st + 1 < 16) request(2 * st + 2);
+        if (st + 1 < st_end) request(2 * st + 2);
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
             half(1, 8);
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __re
                 const int col = 64 * st + 32 * nt + i;
                 const float ic = inv_col[col], bv = bias[col];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] *= irow[r] * ic;       // (powers of two: exact)
+                for (int r = 0; r < 16; ++r) acc[nt][r] *= rowc[wave][mfma_row(r, h)] * ic;       // (powers of two: exact)
                 const float p = __shfl(acc[nt][0], i);                         // the wave's row 0
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -168,19 +177,19 @@ __global__ __launch_bounds__(256, 2) void h32_conv5_fwd_kernel(const float* __re
                 s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
                 if (h == 0) wst[sb][wave][0][32 * nt + i] = s1, wst[sb][wave][1][32 * nt + i] = s2, wst[sb][wave][2][32 * nt + i] = p;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Z[(size_t)(r0 + mfma_row(r, h)) * 1024 + col] = acc[nt][r] + bv;
+                for (int r = 0; r < 16; ++r) zrow[mfma_row(r, h) * 1024 + col] = acc[nt][r] + bv;
             }
         }
-        if (st + 1 < 16) deposit(0);
+        if (st + 1 < st_end) deposit(0);
         __syncthreads();
     }
-    flush_stats(15, 1);
+    flush_stats(st_end - 1, (st_end - 1) & 1);
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
 extern "C" size_t epc_h32_conv5_fwd_scratch_bytes(int rows) {
     if (rows <= 0) return 0;
-    return (size_t)256 * 1024 * 4 + 1024 * sizeof(float) + (size_t)((rows + 127) / 128) * 3 * 1024 * sizeof(float);
+    return (size_t)256 * 1024 * 4 + 1024 * sizeof(float) + (size_t)((rows + 127) / 128) * 3 * 1024 * sizeof(float);   // (>= the 256-row tiles' partials)
 }
 
 extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float* b5, int rows, float* z5, float* mean, float* var,
@@ -194,9 +203,12 @@ extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float*
     float* inv_col = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)256 * 1024 * 4);
     float* stats = inv_col + 1024;
     hipLaunchKernelGGL(h32_pack_conv5_kernel, dim3(16, 2, 4), dim3(256), 0, st, W5, pack, inv_col);
-    const int wgs = (rows + 127) / 128;
-    hipLaunchKernelGGL(h32_conv5_fwd_kernel, dim3(wgs), dim3(256), 0, st, cat, rows, (const u32x4*)pack, inv_col, b5, z5, stats);
-    epc_moments_finalize_launch(stats, wgs, 1024, rows, 128, b5, mean, var, stream);
+    const int tile_rows = 32 * C32_WAVES, tiles = (rows + tile_rows - 1) / tile_rows;
+    int whole, parts;
+    epc_tail_split(tiles, epc_device_cu_count(), 16, whole, parts);   // (one workgroup per CU)
+    hipLaunchKernelGGL(h32_conv5_fwd_kernel, dim3(whole + (tiles - whole) * parts), dim3(64 * C32_WAVES), 0, st, cat, rows, (const u32x4*)pack,
+                       inv_col, b5, z5, stats, whole, parts);
+    epc_moments_finalize_launch(stats, tiles, 1024, rows, tile_rows, b5, mean, var, stream);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
@@ -271,8 +283,15 @@ extern "C" int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, flo
     hipStream_t st = (hipStream_t)stream;
     h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, dz5, rows,
-                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
+    // the rows that fill whole rounds of CUs as 256-row workgroups of eight waves (one per CU), the rest as 128-row ones
+    const int main_rows = rows / 256 / epc_device_cu_count() * epc_device_cu_count() * 256, tail_rows = rows - main_rows;
+    if (main_rows > 0)
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, 8>), dim3(main_rows / 256, 1), dim3(512), 0, st, dz5, main_rows,
+                           (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
+    if (tail_rows > 0)
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((tail_rows + 127) / 128, 1), dim3(256), 0, st,
+                           dz5 + (size_t)main_rows * 1024, tail_rows, (const u32x4*)scratch, 0L, none, dcat + (size_t)main_rows * 256,
+                           (float*)nullptr, (float*)nullptr);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
