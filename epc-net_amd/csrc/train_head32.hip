@@ -283,15 +283,8 @@ extern "C" int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, flo
     hipStream_t st = (hipStream_t)stream;
     h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    // the rows that fill whole rounds of CUs as 256-row workgroups of eight waves (one per CU), the rest as 128-row ones
-    const int main_rows = rows / 256 / epc_device_cu_count() * epc_device_cu_count() * 256, tail_rows = rows - main_rows;
-    if (main_rows > 0)
-        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, 8>), dim3(main_rows / 256, 1), dim3(512), 0, st, dz5, main_rows,
-                           (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
-    if (tail_rows > 0)
-        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((tail_rows + 127) / 128, 1), dim3(256), 0, st,
-                           dz5 + (size_t)main_rows * 1024, tail_rows, (const u32x4*)scratch, 0L, none, dcat + (size_t)main_rows * 256,
-                           (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, dz5, rows,
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

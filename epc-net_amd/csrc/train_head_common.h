@@ -130,17 +130,16 @@ __device__ __forceinline__ void h16_merge_stats(const float (*w)[3][64], const b
 // ----------------------------------------------------------------------------------------------------------------
 // Row-streamed product: out (rows, 32 NT) f32 = T(A) B with A (rows, 1024) -- bf16 (TA = u16) or f32 (TA = float) -- streamed ONCE
 // (the next k chunk requested under this chunk's products), B (1024, 32 NT) packed in layout 1 with P pieces -- one matrix, or one per
-// cloud -- and streamed through a double-buffered LDS chunk of 16 KSC k shared by the workgroup's NW 32-row waves (NW = 4; dcat's
-// launches: 8 for the rows that fill whole rounds of CUs -- half the operand's stage traffic and barriers per row -- and 4 for the rest).
+// cloud -- and streamed through a double-buffered LDS chunk of 16 KSC k shared by the workgroup's four 32-row waves.
 //   XFORM: T = relu(batch_norm(.)) per channel (conv5's BatchNorm from its batch moments; coefficients in LDS) and the row factor
 //          rn = rsqrt(max(sum_c u^2, 1e-12)) from the f32 values of u, applied to the accumulators: out = rn (u B).
-//          rn_out != null: rn is written.  stats != null: column statistics of out ([workgroups][3][32 NT], tile_rows = 32 NW).
+//          rn_out != null: rn is written.  stats != null: column statistics of out ([workgroups][3][32 NT], tile_rows = 128).
 //   P: bf16 pieces per operand (hx_prod): 1 = the bf16 arithmetic; 2 / 3 = three / six products on f32 operands.
 //   NT = 2: the assignment's product and its gradient (B = Wc / dvlad[cloud]);  NT = 8, no XFORM: dcat = dz5 W5^T.
-// Workgroups never straddle clouds: grid = (ceil(n_points / (32 NW)), clouds); n_points a multiple of 32.
+// Workgroups never straddle clouds: grid = (ceil(n_points / 128), clouds); n_points a multiple of 32.
 // ----------------------------------------------------------------------------------------------------------------
-template <int NT, bool XFORM, typename TA, int P, int KSC, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
+template <int NT, bool XFORM, typename TA, int P, int KSC>
+__global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
                                                             float* __restrict__ rn_out, float* __restrict__ stats) {
     constexpr bool A32 = sizeof(TA) == 4;
@@ -149,26 +148,26 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __rest
     constexpr int AV = A32 ? 2 : 1;              // 16-byte loads per 8-value fragment
     __shared__ u32x4 Bs[2][CHUNK_U4];
     __shared__ __attribute__((aligned(16))) float coef[XFORM ? 2 : 1][XFORM ? 1024 : 4];
-    __shared__ float rowc[NW][32];
-    __shared__ float wst[NW][3][32 * NT];
-    __shared__ bool wlive[NW];
+    __shared__ float rowc[4][32];
+    __shared__ float wst[4][3][32 * NT];
+    __shared__ bool wlive[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int cloud = blockIdx.y;
-    const int r0 = blockIdx.x * (32 * NW) + wave * 32;         // within the cloud
+    const int r0 = blockIdx.x * 128 + wave * 32;               // within the cloud
     const bool live = r0 < n_points;
     if (lane == 0) wlive[wave] = live;
     const u32x4* src = Bp + (size_t)cloud * b_cloud_stride_u4;
-    constexpr int PER = CHUNK_U4 / (64 * NW);
-    static_assert(CHUNK_U4 % (64 * NW) == 0, "a chunk is a whole number of 16-byte pieces per thread");
+    constexpr int PER = CHUNK_U4 / 256;
+    static_assert(CHUNK_U4 % 256 == 0, "a chunk is a whole number of 16-byte pieces per thread");
     u32x4 pre[PER];
     auto request = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * (64 * NW)];
+        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * 256];
     };
     auto deposit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * (64 * NW)] = pre[u];
+        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
     };
     request(0);
     const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __rest
     };
     aload(0);
     if constexpr (XFORM) {
-        for (int c = tid; c < 1024; c += 64 * NW) {
+        for (int c = tid; c < 1024; c += 256) {
             const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
             coef[0][c] = a.s, coef[1][c] = a.t;
         }
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __rest
         if (tid < N) {
             float Pv = wst[0][2][tid], S1 = wst[0][0][tid], S2 = wst[0][1][tid];
 #pragma unroll
-            for (int q = 1; q < NW; ++q)
+            for (int q = 1; q < 4; ++q)
                 if (wlive[q]) {
                     const float d = wst[q][2][tid] - Pv, s1 = wst[q][0][tid];
                     S1 += s1 + 32.f * d;
