@@ -143,7 +143,7 @@ __host__ __device__ __forceinline__ float bf16_bits_to_float(unsigned short b) {
 // quarter of the CUs carry a third more).  `parts` = the power of two that minimises the slot-time  rounds x (1 / parts + overhead), with
 // a workgroup's fixed cost (its prologue: the resident operand, the first stage) priced at 6 % of a tile.
 // Workgroup b < whole: tile b, every chunk; else tile whole + (b - whole) / parts, part (b - whole) % parts.
-static inline void epc_tail_split(int tiles, int slots, int chunks, int& whole, int& parts) {
+static inline void tail_split(int tiles, int slots, int chunks, int& whole, int& parts) {
     whole = slots > 0 ? tiles / slots * slots : tiles;
     const int rem = tiles - whole;
     parts = 1;

@@ -359,7 +359,7 @@ extern "C" int epc_sq_err_bwd(const float* a, const float* b, long n, int mean, 
 // registers under the previous chunk's products -> LDS), one barrier per chunk; the wave writes whole 128-byte row segments.
 // Measured at 18 x 4096 rows (scripts/time_df.py): 114 us against 160-175 us for torch.cat + the generic product, the same bits.
 // Four-wave workgroups (three per CU at 146 registers; the tail form: two per CU, its tiles beyond a whole round cut into column parts --
-// epc_tail_split, 168 -> 136 us): eight-wave ones at 128 registers spilled and took 136-165 us.  Arithmetic: two bf16 pieces per operand, three products
+// tail_split, 168 -> 136 us): eight-wave ones at 128 registers spilled and took 136-165 us.  Arithmetic: two bf16 pieces per operand, three products
 // (epc_gemm_f32_fast's); PIECES = 1: one bf16 value per operand.
 // ----------------------------------------------------------------------------------------------------------------
 #define VDF_WAVES 4
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64 * VDF_WAVES, TAIL ? 2 : 3) void vlad_df_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     // Work split (round 5): workgroup = (a 128-row tile of a cloud, a RANGE of the column stages).  The first `whole` tiles (a multiple of
-    // the co-resident workgroup count) take every stage; each of the rest is cut into `parts` workgroups (epc_tail_split): the last,
+    // the co-resident workgroup count) take every stage; each of the rest is cut into `parts` workgroups (tail_split): the last,
     // partly filled round costs a fraction of a tile's time.  The sums' partials stay one per tile.
     const int tpc = ((n_points + 31) / 32 + VDF_WAVES - 1) / VDF_WAVES;   // 128-row tiles per cloud
     const int wg = (int)blockIdx.x < whole ? (int)blockIdx.x : whole + ((int)blockIdx.x - whole) / parts;
@@ -624,7 +624,7 @@ extern "C" int epc_vlad_df_tail(const float* a, const float* dz, const float* dv
     const int tiles = (n_points + 31) / 32;
     const int wgs = (tiles + VDF_WAVES - 1) / VDF_WAVES * num_clouds;
     int whole, parts;
-    epc_tail_split(wgs, 2 * epc_device_cu_count(), F / (32 * VDF_NT), whole, parts);   // (two workgroups per CU: launch bounds of the tail form)
+    tail_split(wgs, 2 * epc_device_cu_count(), F / (32 * VDF_NT), whole, parts);   // (two workgroups per CU: launch bounds of the tail form)
     const dim3 grid(whole + (wgs - whole) * parts);
     const VdfTail tail{z5, rn, trow, mean, var, gamma, beta, eps, partials};
     if (pieces == 2) hipLaunchKernelGGL((vlad_df_kernel<2, true>), grid, dim3(64 * VDF_WAVES), 0, st, a, dz, (const u32x4*)packed, n_points, F, du, tail, whole, parts);

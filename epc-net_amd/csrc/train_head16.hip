@@ -512,7 +512,7 @@ extern "C" int epc_h16_assign(const void* z5, const float* mean5, const float* v
     const dim3 grid((n_points + 127) / 128, num_clouds);
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, u16, 1, 4>), grid, dim3(256), 0, st, (const u16*)z5, n_points, (const u32x4*)scratch,
-                       per_cloud_operand ? (long)(1024 * 64 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr);
+                       per_cloud_operand ? (long)(1024 * 64 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<u16>{});
     if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -530,7 +530,27 @@ extern "C" int epc_h16_conv5_dx(const void* dz5, const float* W5, int rows, floa
     h16_pack<1>(W5, 1, 1024, 0, 1, 1024, 256, 1, 4, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
     hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, u16, 1, 4>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, (const u16*)dz5, rows,
-                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr, HxBnb<u16>{});
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// epc_h16_bn_bwd_apply and epc_h16_conv5_dx in ONE pass: dz5 = gamma rstd (du - dbeta / rows - zhat dgamma / rows) is formed from du and z5 as
+// they stream, written once (dz5 may be du) for dW5's product, and multiplied with W5^T from registers: dcat (rows, 256) f32.
+extern "C" int epc_h16_conv5_dx_bn(const void* du, const void* z5, const float* mean5, const float* var5, const float* gamma5, float eps,
+                                   const float* dbeta, const float* dgamma, const float* W5, int rows, void* dz5, float* dcat, void* scratch,
+                                   size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(du && z5 && mean5 && var5 && gamma5 && dbeta && dgamma && W5 && dz5 && dcat && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0, "rows must be a positive multiple of 32");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h16_dx_scratch_bytes(), "scratch too small (epc_h16_dx_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(du) && h16_aligned16(z5) && h16_aligned16(dz5) && h16_aligned16(scratch) && h16_aligned16(dcat),
+                  "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h16_pack<1>(W5, 1, 1024, 0, 1, 1024, 256, 1, 4, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
+    const H16Bn bn{mean5, var5, gamma5, nullptr, eps};
+    const HxBnb<u16> bnb{(const u16*)z5, dbeta, dgamma, 1.0f / rows, (u16*)dz5};
+    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, u16, 1, 4, true>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, (const u16*)du, rows,
+                       (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

@@ -205,7 +205,7 @@ extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float*
     hipLaunchKernelGGL(h32_pack_conv5_kernel, dim3(16, 2, 4), dim3(256), 0, st, W5, pack, inv_col);
     const int tile_rows = 32 * C32_WAVES, tiles = (rows + tile_rows - 1) / tile_rows;
     int whole, parts;
-    epc_tail_split(tiles, epc_device_cu_count(), 16, whole, parts);   // (one workgroup per CU)
+    tail_split(tiles, epc_device_cu_count(), 16, whole, parts);   // (one workgroup per CU)
     hipLaunchKernelGGL(h32_conv5_fwd_kernel, dim3(whole + (tiles - whole) * parts), dim3(64 * C32_WAVES), 0, st, cat, rows, (const u32x4*)pack,
                        inv_col, b5, z5, stats, whole, parts);
     epc_moments_finalize_launch(stats, tiles, 1024, rows, tile_rows, b5, mean, var, stream);
@@ -238,7 +238,7 @@ extern "C" int epc_h32_assign(const float* z5, const float* mean5, const float* 
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     h16_pack<2>(B, 64, 1, (long)1024 * 64, nb, 1024, 64, 1, 4, scratch, st);
     hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, float, 2, 4>), grid, dim3(256), 0, st, z5, n_points, (const u32x4*)scratch,
-                       per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr);
+                       per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<float>{});
     if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -284,7 +284,26 @@ extern "C" int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, flo
     h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn none{nullptr, nullptr, nullptr, nullptr, 0.f};
     hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, dz5, rows,
-                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr);
+                       (const u32x4*)scratch, 0L, none, dcat, (float*)nullptr, (float*)nullptr, HxBnb<float>{});
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+// epc_bn_apply_bwd_given and epc_h32_conv5_dx in ONE pass (epc_h16_conv5_dx_bn on f32 tensors, two bf16 pieces per operand)
+extern "C" int epc_h32_conv5_dx_bn(const float* du, const float* z5, const float* mean5, const float* var5, const float* gamma5, float eps,
+                                   const float* dbeta, const float* dgamma, const float* W5, int rows, float* dz5, float* dcat, void* scratch,
+                                   size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(du && z5 && mean5 && var5 && gamma5 && dbeta && dgamma && W5 && dz5 && dcat && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && rows % 32 == 0, "rows must be a positive multiple of 32");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_dx_scratch_bytes(), "scratch too small (epc_h32_dx_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(du) && h16_aligned16(z5) && h16_aligned16(dz5) && h16_aligned16(scratch) && h16_aligned16(dcat),
+                  "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
+    const H16Bn bn{mean5, var5, gamma5, nullptr, eps};
+    const HxBnb<float> bnb{z5, dbeta, dgamma, 1.0f / rows, dz5};
+    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, true>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, du, rows,
+                       (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

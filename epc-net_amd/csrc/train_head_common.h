@@ -136,20 +136,36 @@ __device__ __forceinline__ void h16_merge_stats(const float (*w)[3][64], const b
 //          rn_out != null: rn is written.  stats != null: column statistics of out ([workgroups][3][32 NT], tile_rows = 128).
 //   P: bf16 pieces per operand (hx_prod): 1 = the bf16 arithmetic; 2 / 3 = three / six products on f32 operands.
 //   NT = 2: the assignment's product and its gradient (B = Wc / dvlad[cloud]);  NT = 8, no XFORM: dcat = dz5 W5^T.
+//   BNB (with NT = 8, no XFORM): A is not read but FORMED -- the last step of conv5's BatchNorm backward,
+//          dz5 = gamma rstd (du - dbeta / R - zhat dgamma / R)   (bn_apply_bwd_given_wide_kernel's / h16_bn_bwd_apply_kernel's expression),
+//          from du (the A pointer) and z5 as the two are streamed, written back once (bnb.dz_out, may be du: every lane rewrites the
+//          16 or 32 bytes it read) for dW5's product and used as this product's operand in registers: the separate apply pass -- a
+//          read of du, a read of z5 and a write of dz5 -- and this kernel's own read of dz5 become two reads and one write.
 // Workgroups never straddle clouds: grid = (ceil(n_points / 128), clouds); n_points a multiple of 32.
 // ----------------------------------------------------------------------------------------------------------------
-template <int NT, bool XFORM, typename TA, int P, int KSC>
+template <typename TA>
+struct HxBnb {           // the BatchNorm backward fused into dcat's product (BNB)
+    const TA* z;         // (rows, 1024) conv5's pre-activation
+    const float* dbeta;  // (1024) sum du
+    const float* dgamma; // (1024) sum du zhat
+    float inv_rows;
+    TA* dz_out;          // (rows, 1024)
+};
+
+template <int NT, bool XFORM, typename TA, int P, int KSC, bool BNB = false>
 __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
-                                                            float* __restrict__ rn_out, float* __restrict__ stats) {
+                                                            float* __restrict__ rn_out, float* __restrict__ stats, HxBnb<TA> bnb) {
+    static_assert(!(BNB && XFORM), "one transformation of the streamed operand at a time");
     constexpr bool A32 = sizeof(TA) == 4;
     constexpr int CHUNK_U4 = KSC * NT * P * 64;
     constexpr int CHUNKS = 64 / KSC;             // K = 1024 = 64 k-steps
     constexpr int AV = A32 ? 2 : 1;              // 16-byte loads per 8-value fragment
     __shared__ u32x4 Bs[2][CHUNK_U4];
-    __shared__ __attribute__((aligned(16))) float coef[XFORM ? 2 : 1][XFORM ? 1024 : 4];
+    // BNB: k1 = gamma rstd, b2 = dbeta / R - mean gg, gg = rstd dgamma / R:  dz5 = k1 (du - b2 - z5 gg)  (three tables: two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float coef[XFORM ? 2 : (BNB ? 3 : 1)][XFORM || BNB ? 1024 : 4];
     __shared__ float rowc[4][32];
-    __shared__ float wst[4][3][32 * NT];
+    __shared__ float wst[4][3][XFORM ? 32 * NT : 1];   // (column statistics: the assignment's launches only)
     __shared__ bool wlive[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -172,14 +188,25 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
     request(0);
     const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
     const TA* arow = A + grow * 1024 + 8 * h;
-    u32x4 an[KSC][AV];
+    const TA* zrow = BNB ? bnb.z + grow * 1024 + 8 * h : nullptr;
+    // (the streamed operand runs ONE chunk ahead of the products; two chunks ahead measured the same: 64.7 / 151.9 us against 65.7 / 153)
+    u32x4 an[KSC][AV], zn[BNB ? KSC : 1][AV];
     auto aload = [&](int kc) {
 #pragma unroll
         for (int s = 0; s < KSC; ++s)
 #pragma unroll
-            for (int w = 0; w < AV; ++w) an[s][w] = *reinterpret_cast<const u32x4*>(arow + 16 * (KSC * kc + s) + (A32 ? 4 * w : 0));
+            for (int w = 0; w < AV; ++w) {
+                an[s][w] = *reinterpret_cast<const u32x4*>(arow + 16 * (KSC * kc + s) + (A32 ? 4 * w : 0));
+                if constexpr (BNB) zn[s][w] = *reinterpret_cast<const u32x4*>(zrow + 16 * (KSC * kc + s) + (A32 ? 4 * w : 0));
+            }
     };
     aload(0);
+    if constexpr (BNB) {
+        for (int c = tid; c < 1024; c += 256) {
+            const float r = 1.0f / sqrtf(bn.var[c] + bn.eps), gg = r * (bnb.dgamma[c] * bnb.inv_rows);
+            coef[0][c] = bn.gamma[c] * r, coef[1][c] = bnb.dbeta[c] * bnb.inv_rows - bn.mean[c] * gg, coef[2][c] = gg;
+        }
+    }
     if constexpr (XFORM) {
         for (int c = tid; c < 1024; c += 256) {
             const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
@@ -196,11 +223,57 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
     float ss = 0.f;
     for (int kc = 0; kc < CHUNKS; ++kc) {
         const int buf = kc & 1;
-        u32x4 av[KSC][AV];
+        u32x4 av[BNB ? 1 : KSC][AV];
+        bf16x8 afr[BNB ? KSC : 1][P];   // BNB: the chunk's fragments, formed (and dz5 written back) before the next chunk is requested
+        if constexpr (BNB) {
+            if (live) {
 #pragma unroll
-        for (int s = 0; s < KSC; ++s)
+                for (int s = 0; s < KSC; ++s) {
+                    const int c0 = 16 * (KSC * kc + s) + 8 * h;
+                    float g[8], z[8], k1[8], bb[8], gg[8], dzv[8];
+                    if constexpr (A32) {
 #pragma unroll
-            for (int w = 0; w < AV; ++w) av[s][w] = an[s][w];
+                        for (int w = 0; w < 4; ++w) {
+                            g[w] = __uint_as_float(an[s][0][w]), g[4 + w] = __uint_as_float(an[s][AV - 1][w]);
+                            z[w] = __uint_as_float(zn[s][0][w]), z[4 + w] = __uint_as_float(zn[s][AV - 1][w]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            g[2 * w] = bf_lo(an[s][0][w]), g[2 * w + 1] = bf_hi(an[s][0][w]);
+                            z[2 * w] = bf_lo(zn[s][0][w]), z[2 * w + 1] = bf_hi(zn[s][0][w]);
+                        }
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < 2; ++q4) {
+                        const float4 k4 = *reinterpret_cast<const float4*>(&coef[0][c0 + 4 * q4]), b4 = *reinterpret_cast<const float4*>(&coef[1][c0 + 4 * q4]);
+                        const float4 g4 = *reinterpret_cast<const float4*>(&coef[2][c0 + 4 * q4]);
+                        k1[4 * q4] = k4.x, k1[4 * q4 + 1] = k4.y, k1[4 * q4 + 2] = k4.z, k1[4 * q4 + 3] = k4.w;
+                        bb[4 * q4] = b4.x, bb[4 * q4 + 1] = b4.y, bb[4 * q4 + 2] = b4.z, bb[4 * q4 + 3] = b4.w;
+                        gg[4 * q4] = g4.x, gg[4 * q4 + 1] = g4.y, gg[4 * q4 + 2] = g4.z, gg[4 * q4 + 3] = g4.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dzv[j] = k1[j] * (g[j] - bb[j] - z[j] * gg[j]);   // (the apply kernels' expression, mean folded into bb)
+                    TA* orow = bnb.dz_out + grow * 1024 + 8 * h + 16 * (KSC * kc + s);
+                    if constexpr (A32) {
+                        *reinterpret_cast<float4*>(orow) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                        *reinterpret_cast<float4*>(orow + 4) = make_float4(dzv[4], dzv[5], dzv[6], dzv[7]);
+                        hx_split<P>(dzv, afr[s]);
+                    } else {
+                        u32x4 pk;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) pk[w] = pack2bf(dzv[2 * w], dzv[2 * w + 1]);
+                        *reinterpret_cast<u32x4*>(orow) = pk;
+                        afr[s][0] = __builtin_bit_cast(bf16x8, pk);   // (the stored, rounded values ARE the operand)
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+#pragma unroll
+                for (int w = 0; w < AV; ++w) av[s][w] = an[s][w];
+        }
         if (kc + 1 < CHUNKS) {
             request(kc + 1);
             aload(kc + 1);
@@ -210,7 +283,10 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
 #pragma unroll
             for (int s = 0; s < KSC; ++s) {
                 bf16x8 a[P];
-                if constexpr (!XFORM && !A32) {
+                if constexpr (BNB) {
+#pragma unroll
+                    for (int q = 0; q < P; ++q) a[q] = afr[s][q];
+                } else if constexpr (!XFORM && !A32) {
                     a[0] = __builtin_bit_cast(bf16x8, av[s][0]);
                 } else {
                     float u[8];
@@ -274,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
             for (int nt = 0; nt < NT; ++nt) ob[32 * nt] = acc[nt][r];
         }
     }
-    if (stats) {   // (workgroup-uniform)
+    if constexpr (XFORM) if (stats) {   // (workgroup-uniform; the assignment's launches only)
         if (live) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {

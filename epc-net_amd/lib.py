@@ -54,9 +54,9 @@ EXPORTS = [
     "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_vlad_df_tail_partial_floats", "epc_vlad_df_tail", "epc_bn_apply_bwd_given", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
     "epc_h16_conv5_fwd_scratch_bytes", "epc_h16_conv5_fwd", "epc_h16_assign_scratch_bytes", "epc_h16_assign",
     "epc_h16_colgemm_scratch_bytes", "epc_h16_colgemm", "epc_h16_df_tail_scratch_bytes", "epc_h16_df_tail", "epc_h16_bn_bwd_apply",
-    "epc_h16_dx_scratch_bytes", "epc_h16_conv5_dx", "epc_h16_conv5_dw_scratch_bytes", "epc_h16_conv5_dw", "epc_h16_expand", "epc_gemm_splitk_det_b16",
+    "epc_h16_dx_scratch_bytes", "epc_h16_conv5_dx", "epc_h16_conv5_dx_bn", "epc_h16_conv5_dw_scratch_bytes", "epc_h16_conv5_dw", "epc_h16_expand", "epc_gemm_splitk_det_b16",
     "epc_h32_conv5_fwd_scratch_bytes", "epc_h32_conv5_fwd", "epc_h32_assign_scratch_bytes", "epc_h32_assign",
-    "epc_h32_colgemm_scratch_bytes", "epc_h32_colgemm", "epc_h32_dx_scratch_bytes", "epc_h32_conv5_dx",
+    "epc_h32_colgemm_scratch_bytes", "epc_h32_colgemm", "epc_h32_dx_scratch_bytes", "epc_h32_conv5_dx", "epc_h32_conv5_dx_bn",
     "epc_maxpool_points_fwd", "epc_maxpool_points_bwd", "epc_vlad_w2_grad", "epc_group_sum_fwd", "epc_group_sum_bwd",
 ]
 EPC_NUM_STAGES = 10
@@ -218,6 +218,7 @@ _lib.epc_h16_bn_bwd_apply.argtypes = [_P, _P, _P, _P, _P, _P, c_float, _P, _P, c
 _lib.epc_h16_dx_scratch_bytes.restype = c_size_t
 _lib.epc_h16_dx_scratch_bytes.argtypes = []
 _lib.epc_h16_conv5_dx.argtypes = [_P, _P, c_int, _P, _P, c_size_t, _P]
+_lib.epc_h16_conv5_dx_bn.argtypes = [_P, _P, _P, _P, _P, c_float, _P, _P, _P, c_int, _P, _P, _P, c_size_t, _P]
 _lib.epc_h16_conv5_dw_scratch_bytes.restype = c_size_t
 _lib.epc_h16_conv5_dw_scratch_bytes.argtypes = [c_int]
 _lib.epc_h16_conv5_dw.argtypes = [_P, c_int, _P, c_int, _P, _P, c_size_t, _P]
@@ -235,6 +236,7 @@ _lib.epc_h32_colgemm.argtypes = _lib.epc_h16_colgemm.argtypes
 _lib.epc_h32_dx_scratch_bytes.restype = c_size_t
 _lib.epc_h32_dx_scratch_bytes.argtypes = []
 _lib.epc_h32_conv5_dx.argtypes = _lib.epc_h16_conv5_dx.argtypes
+_lib.epc_h32_conv5_dx_bn.argtypes = _lib.epc_h16_conv5_dx_bn.argtypes
 _lib.epc_maxpool_points_fwd.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_maxpool_points_bwd.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]
 _lib.epc_vlad_w2_grad.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]

@@ -1150,14 +1150,16 @@ class Conv5VladHead(torch.autograd.Function):
         L.check((lib.epc_h16_colgemm if h16 else lib.epc_h32_colgemm)(z5.data_ptr(), *bn5, dz.data_ptr(), rn.data_ptr(), B, N, 0,
                                                                      dWc.data_ptr(), sc.data_ptr(), n, _st()))
         # du = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f trow), the BatchNorm's column sums, then dz5 in place
+        need_dx = bool(ctx.needs_input_grad[0])
         du = torch.empty_like(z5)
         sums = f32(2, 1024)
         if h16:
             sc, n = _scratch_bytes(lib.epc_h16_df_tail_scratch_bytes(B, N), dev)
             L.check(lib.epc_h16_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, z5.data_ptr(), rn.data_ptr(),
                                         trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(), sc.data_ptr(), n, _st()))
-            L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), *bn5, sums[0].data_ptr(), sums[1].data_ptr(), rows,
-                                             du.data_ptr(), _st()))
+            if not need_dx:
+                L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), *bn5, sums[0].data_ptr(), sums[1].data_ptr(), rows,
+                                                 du.data_ptr(), _st()))
         else:
             nbytes = lib.epc_vlad_df_packed_bytes(B, 1024)
             pfl = lib.epc_vlad_df_tail_partial_floats(B, N)
@@ -1165,14 +1167,19 @@ class Conv5VladHead(torch.autograd.Function):
             L.check(lib.epc_vlad_df_tail(a.data_ptr(), dz.data_ptr(), dvlad.data_ptr(), Wc.data_ptr(), B, N, 2, scratch.data_ptr(), nbytes,
                                          z5.data_ptr(), rn.data_ptr(), trow.data_ptr(), *bn5, du.data_ptr(), sums.data_ptr(),
                                          scratch.data_ptr() + 4 * ((nbytes + 3) // 4), pfl, _st()))
-            L.check(lib.epc_bn_apply_bwd_given(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(),
-                                               sums[0].data_ptr(), sums[1].data_ptr(), ctx.eps5, rows, 1024, du.data_ptr(), _st()))
+            if not need_dx:
+                L.check(lib.epc_bn_apply_bwd_given(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(),
+                                                   bt5.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), ctx.eps5, rows, 1024, du.data_ptr(),
+                                                   _st()))
         dcat = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
+            # dz5 = gamma rstd (du - dbeta / R - zhat dgamma / R) is formed INSIDE dcat's product as du and z5 stream, and written over du for
+            # dW5's: one pass over the (rows, 1024) tensors instead of the apply pass + the product's own read
             dcat = f32(rows, 256)
             sc, n = _scratch_bytes((lib.epc_h16_dx_scratch_bytes if h16 else lib.epc_h32_dx_scratch_bytes)(), dev)
-            L.check((lib.epc_h16_conv5_dx if h16 else lib.epc_h32_conv5_dx)(du.data_ptr(), W5.data_ptr(), rows, dcat.data_ptr(),
-                                                                           sc.data_ptr(), n, _st()))
+            L.check((lib.epc_h16_conv5_dx_bn if h16 else lib.epc_h32_conv5_dx_bn)(
+                du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), ctx.eps5, sums[0].data_ptr(), sums[1].data_ptr(),
+                W5.data_ptr(), rows, du.data_ptr(), dcat.data_ptr(), sc.data_ptr(), n, _st()))
         # dW5 = cat^T dz5, row slices added in a fixed order
         if h16:
             dW5 = f32(256, 1024)

@@ -611,6 +611,9 @@ int epc_bn_apply_bwd_given(const float* dy, const float* z, const float* mean, c
  *   dbeta_dgamma (2, 1024) = (sum du, sum du zhat) from the f32 values.
  * epc_h16_bn_bwd_apply: dz5 = gamma rstd (du - dbeta / rows - zhat dgamma / rows), bf16 in, bf16 out; dz5 may be du.
  * epc_h16_conv5_dx: dcat (rows, 256) f32 = dz5 W5^T.
+ * epc_h16_conv5_dx_bn: epc_h16_bn_bwd_apply and epc_h16_conv5_dx in one pass -- dz5 is formed from du and z5 as they stream, written once
+ *   (dz5 may be du) for epc_h16_conv5_dw, and multiplied with W5^T from registers; the same values, one read of a (rows, 1024) tensor
+ *   and one launch fewer (utils/tf_util.py:94-106 seen from the gradient side, models/epc-net.py:136).
  * epc_h16_conv5_dw: dW5 (256, 1024) f32 = cat^T dz5 (cat f32 or bf16), row slices added in a fixed order.
  * epc_h16_expand: y (rows, 1024) f32 = the bf16 values (mean5 NULL) or relu(bn(z5)) rn (rn NULL: no row factor): the feature map
  *   for callers that need it materialised (the distillation variants' second output, models/kd_epc-net.py:158) and for tests. */
@@ -633,6 +636,9 @@ int epc_h16_bn_bwd_apply(const void* du, const void* z5, const float* mean5, con
                          float eps, const float* dbeta, const float* dgamma, int rows, void* dz5, void* stream);
 size_t epc_h16_dx_scratch_bytes(void);
 int epc_h16_conv5_dx(const void* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream);
+int epc_h16_conv5_dx_bn(const void* du, const void* z5, const float* mean5, const float* var5, const float* gamma5, float eps,
+                        const float* dbeta, const float* dgamma, const float* W5, int rows, void* dz5, float* dcat, void* scratch,
+                        size_t scratch_bytes, void* stream);
 size_t epc_h16_conv5_dw_scratch_bytes(int rows);
 int epc_h16_conv5_dw(const void* cat, int cat_is_bf16, const void* dz5, int rows, float* dW5, void* scratch, size_t scratch_bytes,
                      void* stream);
@@ -657,6 +663,10 @@ int epc_h32_colgemm(const float* z5, const float* mean5, const float* var5, cons
                     size_t scratch_bytes, void* stream);
 size_t epc_h32_dx_scratch_bytes(void);
 int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, float* dcat, void* scratch, size_t scratch_bytes, void* stream);
+/* epc_bn_apply_bwd_given and epc_h32_conv5_dx in one pass (epc_h16_conv5_dx_bn on f32 tensors) */
+int epc_h32_conv5_dx_bn(const float* du, const float* z5, const float* mean5, const float* var5, const float* gamma5, float eps,
+                        const float* dbeta, const float* dgamma, const float* W5, int rows, float* dz5, float* dcat, void* scratch,
+                        size_t scratch_bytes, void* stream);
 /* epc_gemm_splitk_det with the RIGHT operand stored as bf16 (strides and batch stride in elements; every side of the product at least
  * 64, K at least 32).  pieces: 1 = A rounded to one bf16 value, 2 = A in two bf16 pieces (the bf16 operand is exact either way). */
 int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,

@@ -226,3 +226,55 @@ def test_streamed_head_equals_the_per_layer_operators_in_a_training_step(dev):
     print("streamed head vs per-layer operators, 18 x 256: worst gradient relative L2 difference %.2e (%s)" % worst)
     assert worst[0] <= 1e-3, worst
 
+
+
+@pytest.mark.parametrize("h16", [True, False])
+@pytest.mark.parametrize("rows", [96, 18 * 256, 4 * 4096])
+def test_dcat_product_with_the_batchnorm_backward_formed_inside(dev, h16, rows):
+    """epc_h16_conv5_dx_bn / epc_h32_conv5_dx_bn -- dz5 = gamma rstd (du - dbeta / R - zhat dgamma / R) formed from du and z5 as they stream
+    through dcat's product, written once, multiplied from registers -- against the two launches they replace (epc_h16_bn_bwd_apply /
+    epc_bn_apply_bwd_given, then epc_h16_conv5_dx / epc_h32_conv5_dx) and against float64: utils/tf_util.py:94-106 seen from the gradient
+    side, models/epc-net.py:136.  The expression inside the product folds the mean into one coefficient: dz5 within float32 rounding of
+    the apply kernel's (bf16: a value on a rounding boundary may land on the neighbouring bf16), in place over du as the step calls it."""
+    L = H.pkg("lib")
+    lib = L.lib()
+    g = torch.Generator().manual_seed(rows)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    st = L.current_stream()
+    W5 = (rnd(256, 1024) * 0.08).to(dev)
+    mean5, var5, g5, bt5 = (0.2 * rnd(1024)).to(dev), (torch.rand(1024, generator=g) + 0.5).to(dev), (1 + 0.2 * rnd(1024)).to(dev), rnd(1024).to(dev)
+    dbeta, dgamma = (rnd(1024) * rows ** 0.5).to(dev), (rnd(1024) * rows ** 0.5).to(dev)
+    dt = torch.bfloat16 if h16 else torch.float32
+    du, z5 = rnd(rows, 1024).to(dev).to(dt), rnd(rows, 1024).to(dev).to(dt)
+    sc = torch.empty(1 << 21, dtype=torch.uint8, device=dev)
+    # the two launches
+    dz_ref = torch.empty_like(du)
+    if h16:
+        L.check(lib.epc_h16_bn_bwd_apply(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), EPS,
+                                         dbeta.data_ptr(), dgamma.data_ptr(), rows, dz_ref.data_ptr(), st))
+    else:
+        L.check(lib.epc_bn_apply_bwd_given(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(),
+                                           dbeta.data_ptr(), dgamma.data_ptr(), EPS, rows, 1024, dz_ref.data_ptr(), st))
+    dcat_ref = torch.empty((rows, 256), dtype=torch.float32, device=dev)
+    L.check((lib.epc_h16_conv5_dx if h16 else lib.epc_h32_conv5_dx)(dz_ref.data_ptr(), W5.data_ptr(), rows, dcat_ref.data_ptr(), sc.data_ptr(),
+                                                                   sc.numel(), st))
+    # the one launch, in place over du
+    buf = du.clone()
+    dcat = torch.empty_like(dcat_ref)
+    L.check((lib.epc_h16_conv5_dx_bn if h16 else lib.epc_h32_conv5_dx_bn)(buf.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(),
+                                                                         g5.data_ptr(), EPS, dbeta.data_ptr(), dgamma.data_ptr(), W5.data_ptr(),
+                                                                         rows, buf.data_ptr(), dcat.data_ptr(), sc.data_ptr(), sc.numel(), st))
+    torch.cuda.synchronize()
+    # float64 from the same stored operands
+    r = torch.rsqrt(var5.double() + EPS)
+    dz64 = (g5.double() * r) * (du.double() - dbeta.double() / rows - (z5.double() - mean5.double()) * r * (dgamma.double() / rows))
+    scale = float(dz64.abs().max())
+    tol = (2.0 ** -8 if h16 else 2e-6) * scale       # bf16: half an ulp of the largest value, and the neighbouring value on a boundary
+    assert float((buf.double() - dz64).abs().max()) <= tol
+    assert float((buf.double() - dz_ref.double()).abs().max()) <= tol
+    if h16:
+        assert float((buf != dz_ref).float().mean()) <= 2e-3          # (the folded coefficient moves a rounding boundary now and then)
+    dx64 = (buf.double() if h16 else dz64) @ (W5.double().to(dt).double() if h16 else W5.double()).T
+    rel = float((dcat.double() - dx64).abs().max() / dx64.abs().max())
+    assert rel <= (1e-5 if h16 else 2e-5), rel      # bf16: the stored operand times bf16(W5), f32 accumulation; f32: 2^-16 per product, K = 1024
+    assert float((dcat - dcat_ref).abs().max()) <= (2e-2 if h16 else 1e-4) * float(dcat_ref.abs().max())
