@@ -158,6 +158,19 @@ static inline void tail_split(int tiles, int slots, int chunks, int& whole, int&
     }
 }
 
+// Waves per workgroup (3 or 4: 96- or 128-row tiles) of a row-tiled launch whose workgroups have no independent parts to split: the one
+// that minimises  rounds x rows per workgroup  on `slots` co-resident workgroups (18 x 4096 rows on 512 slots: 768 tiles of 96 rows are two
+// rounds of 96, 576 of 128 two rounds of 128; on 768 slots the former is exactly one round).
+static inline int rows_tile_waves(int rows, int slots) {
+    int best = 4;
+    long best_cost = 0;
+    for (int nw = 4; nw >= 3; --nw) {
+        const long wgs = (rows + 32 * nw - 1) / (32 * nw), rounds = (wgs + slots - 1) / slots, cost = rounds * 32 * nw;
+        if (nw == 4 || cost < best_cost) best = nw, best_cost = cost;
+    }
+    return best;
+}
+
 void epc_set_error(const char* fmt, ...);
 // Compute units of the CURRENT device, cached per device id (a read-mostly table of ints: a racing first call writes the same
 // value twice).  256 when the query fails.

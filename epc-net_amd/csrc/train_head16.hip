@@ -549,7 +549,12 @@ extern "C" int epc_h16_conv5_dx_bn(const void* du, const void* z5, const float* 
     h16_pack<1>(W5, 1, 1024, 0, 1, 1024, 256, 1, 4, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn bn{mean5, var5, gamma5, nullptr, eps};
     const HxBnb<u16> bnb{(const u16*)z5, dbeta, dgamma, 1.0f / rows, (u16*)dz5};
-    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, u16, 1, 4, true>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, (const u16*)du, rows,
+    // 96- or 128-row workgroups, whichever leaves fewer rows on the busiest slot (two workgroups per CU: 235-248 registers a lane)
+    if (rows_tile_waves(rows, 2 * epc_device_cu_count()) == 3)
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, u16, 1, 4, true, 3>), dim3((rows + 95) / 96, 1), dim3(192), 0, st, (const u16*)du, rows,
+                       (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
+    else
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, u16, 1, 4, true, 4>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, (const u16*)du, rows,
                        (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
     EPC_CHECK_LAUNCH();
     return EPC_OK;

@@ -302,7 +302,12 @@ extern "C" int epc_h32_conv5_dx_bn(const float* du, const float* z5, const float
     h16_pack<2>(W5, 1, 1024, 0, 1, 1024, 256, 1, 2, scratch, st);      // B[k = output channel][n = input channel] = W5[n][k]
     const H16Bn bn{mean5, var5, gamma5, nullptr, eps};
     const HxBnb<float> bnb{z5, dbeta, dgamma, 1.0f / rows, dz5};
-    hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, true>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, du, rows,
+    // 96- or 128-row workgroups, whichever leaves fewer rows on the busiest slot (two workgroups per CU: 235-248 registers a lane)
+    if (rows_tile_waves(rows, 2 * epc_device_cu_count()) == 3)
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, true, 3>), dim3((rows + 95) / 96, 1), dim3(192), 0, st, du, rows,
+                       (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
+    else
+        hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, true, 4>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, du, rows,
                        (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
     EPC_CHECK_LAUNCH();
     return EPC_OK;

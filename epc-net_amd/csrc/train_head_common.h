@@ -152,8 +152,8 @@ struct HxBnb {           // the BatchNorm backward fused into dcat's product (BN
     TA* dz_out;          // (rows, 1024)
 };
 
-template <int NT, bool XFORM, typename TA, int P, int KSC, bool BNB = false>
-__global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
+template <int NT, bool XFORM, typename TA, int P, int KSC, bool BNB = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
                                                             float* __restrict__ rn_out, float* __restrict__ stats, HxBnb<TA> bnb) {
     static_assert(!(BNB && XFORM), "one transformation of the streamed operand at a time");
@@ -164,26 +164,27 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
     __shared__ u32x4 Bs[2][CHUNK_U4];
     // BNB: k1 = gamma rstd, b2 = dbeta / R - mean gg, gg = rstd dgamma / R:  dz5 = k1 (du - b2 - z5 gg)  (three tables: two workgroups per CU)
     __shared__ __attribute__((aligned(16))) float coef[XFORM ? 2 : (BNB ? 3 : 1)][XFORM || BNB ? 1024 : 4];
-    __shared__ float rowc[4][32];
-    __shared__ float wst[4][3][XFORM ? 32 * NT : 1];   // (column statistics: the assignment's launches only)
-    __shared__ bool wlive[4];
+    __shared__ float rowc[NW][32];
+    __shared__ float wst[NW][3][XFORM ? 32 * NT : 1];   // (column statistics: the assignment's launches only)
+    __shared__ bool wlive[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int cloud = blockIdx.y;
-    const int r0 = blockIdx.x * 128 + wave * 32;               // within the cloud
+    const int r0 = blockIdx.x * (32 * NW) + wave * 32;         // within the cloud
     const bool live = r0 < n_points;
     if (lane == 0) wlive[wave] = live;
     const u32x4* src = Bp + (size_t)cloud * b_cloud_stride_u4;
-    constexpr int PER = CHUNK_U4 / 256;
-    static_assert(CHUNK_U4 % 256 == 0, "a chunk is a whole number of 16-byte pieces per thread");
+    constexpr int WGT = 64 * NW, PER = (CHUNK_U4 + WGT - 1) / WGT;   // (three-wave workgroups: the last piece is predicated)
     u32x4 pre[PER];
     auto request = [&](int kc) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * 256];
+        for (int u = 0; u < PER; ++u)
+            if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * WGT];
     };
     auto deposit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
+        for (int u = 0; u < PER; ++u)
+            if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) Bs[buf][tid + u * WGT] = pre[u];
     };
     request(0);
     const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
@@ -202,13 +203,13 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
     };
     aload(0);
     if constexpr (BNB) {
-        for (int c = tid; c < 1024; c += 256) {
+        for (int c = tid; c < 1024; c += 64 * NW) {
             const float r = 1.0f / sqrtf(bn.var[c] + bn.eps), gg = r * (bnb.dgamma[c] * bnb.inv_rows);
             coef[0][c] = bn.gamma[c] * r, coef[1][c] = bnb.dbeta[c] * bnb.inv_rows - bn.mean[c] * gg, coef[2][c] = gg;
         }
     }
     if constexpr (XFORM) {
-        for (int c = tid; c < 1024; c += 256) {
+        for (int c = tid; c < 1024; c += 64 * NW) {
             const H16Affine a = h16_affine(bn.mean[c], bn.var[c], bn.gamma[c], bn.beta[c], bn.eps);
             coef[0][c] = a.s, coef[1][c] = a.t;
         }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void hx_rowgemm_kernel(const TA* __restrict
         if (tid < N) {
             float Pv = wst[0][2][tid], S1 = wst[0][0][tid], S2 = wst[0][1][tid];
 #pragma unroll
-            for (int q = 1; q < 4; ++q)
+            for (int q = 1; q < NW; ++q)
                 if (wlive[q]) {
                     const float d = wst[q][2][tid] - Pv, s1 = wst[q][0][tid];
                     S1 += s1 + 32.f * d;
