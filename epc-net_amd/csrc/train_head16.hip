@@ -492,7 +492,8 @@ extern "C" int epc_h16_conv5_fwd(const void* cat, int cat_is_bf16, const float* 
 extern "C" size_t epc_h16_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand) {
     if (num_clouds <= 0 || n_points <= 0) return 0;
     const size_t pack = (size_t)(per_cloud_operand ? num_clouds : 1) * 1024 * 64 * 2;
-    return pack + (size_t)num_clouds * ((n_points + 127) / 128) * 3 * 64 * sizeof(float);
+    const size_t tiles = (size_t)num_clouds * ((n_points + 127) / 128), tiles96 = ((size_t)num_clouds * n_points + 95) / 96;
+    return pack + (tiles > tiles96 ? tiles : tiles96) * 3 * 64 * sizeof(float);   // (the shared-operand launch may tile the rows by 96)
 }
 
 // za = rn (relu(bn(z5)) B): B = Wc (1024, 64) shared (per_cloud_operand = 0: the forward; rn and the batch moments of za are written when
@@ -511,6 +512,17 @@ extern "C" int epc_h16_assign(const void* z5, const float* mean5, const float* v
     float* stats = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + (size_t)nb * 1024 * 64 * 2);
     const dim3 grid((n_points + 127) / 128, num_clouds);
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
+    const long rows = (long)num_clouds * n_points;
+    if (!per_cloud_operand && rows < (1L << 31) && rows_tile_waves((int)rows, 4 * epc_device_cu_count()) == 3) {
+        // one operand for every row: the tiles need not respect the clouds -- 96-row workgroups where they spread evenly over the CUs
+        // (18 x 4096 rows: 768 of them, three per CU; 576 of 128 rows leave a quarter of the CUs a third more)
+        const int wgs = (int)((rows + 95) / 96);
+        hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, u16, 1, 4, false, 3>), dim3(wgs, 1), dim3(192), 0, st, (const u16*)z5, (int)rows,
+                           (const u32x4*)scratch, 0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<u16>{});
+        if (mean_out) epc_moments_finalize_launch(stats, wgs, 64, (int)rows, 96, nullptr, mean_out, var_out, stream);
+        EPC_CHECK_LAUNCH();
+        return EPC_OK;
+    }
     hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, u16, 1, 4>), grid, dim3(256), 0, st, (const u16*)z5, n_points, (const u32x4*)scratch,
                        per_cloud_operand ? (long)(1024 * 64 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<u16>{});
     if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);

@@ -216,7 +216,8 @@ extern "C" int epc_h32_conv5_fwd(const float* cat, const float* W5, const float*
 extern "C" size_t epc_h32_assign_scratch_bytes(int num_clouds, int n_points, int per_cloud_operand) {
     if (num_clouds <= 0 || n_points <= 0) return 0;
     const size_t pack = (size_t)(per_cloud_operand ? num_clouds : 1) * 1024 * 64 * 2 * 3;
-    return pack + (size_t)num_clouds * ((n_points + 127) / 128) * 3 * 64 * sizeof(float);
+    const size_t tiles = (size_t)num_clouds * ((n_points + 127) / 128), tiles96 = ((size_t)num_clouds * n_points + 95) / 96;
+    return pack + (tiles > tiles96 ? tiles : tiles96) * 3 * 64 * sizeof(float);   // (the shared-operand launch may tile the rows by 96)
 }
 
 // epc_h16_assign on f32 rows: out (rows, 64) = rn (relu(bn(z5)) B), three products.  per_cloud_operand = 0: B = cluster_weights (the
@@ -237,6 +238,17 @@ extern "C" int epc_h32_assign(const float* z5, const float* mean5, const float* 
     const dim3 grid((n_points + 127) / 128, num_clouds);
     const H16Bn bn{mean5, var5, gamma5, beta5, eps};
     h16_pack<2>(B, 64, 1, (long)1024 * 64, nb, 1024, 64, 1, 4, scratch, st);
+    const long rows = (long)num_clouds * n_points;
+    if (!per_cloud_operand && rows < (1L << 31) && rows_tile_waves((int)rows, 3 * epc_device_cu_count()) == 3) {
+        // one operand for every row: the tiles need not respect the clouds -- 96-row workgroups where they fill the CU's three slots evenly
+        // (18 x 4096 rows: 768 of them, three per CU; 576 of 128 rows leave a quarter of the CUs a third more)
+        const int wgs = (int)((rows + 95) / 96);
+        hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, float, 2, 4, false, 3>), dim3(wgs, 1), dim3(192), 0, st, z5, (int)rows, (const u32x4*)scratch,
+                           0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<float>{});
+        if (mean_out) epc_moments_finalize_launch(stats, wgs, 64, (int)rows, 96, nullptr, mean_out, var_out, stream);
+        EPC_CHECK_LAUNCH();
+        return EPC_OK;
+    }
     hipLaunchKernelGGL((hx_rowgemm_kernel<2, true, float, 2, 4>), grid, dim3(256), 0, st, z5, n_points, (const u32x4*)scratch,
                        per_cloud_operand ? (long)(1024 * 64 * 2 * 2 / 16) : 0L, bn, out, rn_out, mean_out ? stats : nullptr, HxBnb<float>{});
     if (mean_out) epc_moments_finalize_launch(stats, (int)(grid.x * grid.y), 64, num_clouds * n_points, 128, nullptr, mean_out, var_out, stream, n_points);
