@@ -51,6 +51,7 @@ EXPORTS = [
     "epc_assign_softmax_fwd", "epc_assign_softmax_bwd", "epc_gate_fwd",
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
+    "epc_chain_persist_ok", "epc_chain_persist_workspace_bytes", "epc_chain_persist_init", "epc_chain_fwd_persist", "epc_chain_persist_status", "epc_chain_persist_reset",
     "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_vlad_df_tail_partial_floats", "epc_vlad_df_tail", "epc_bn_apply_bwd_given", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
     "epc_h16_conv5_fwd_scratch_bytes", "epc_h16_conv5_fwd", "epc_h16_assign_scratch_bytes", "epc_h16_assign",
     "epc_h16_colgemm_scratch_bytes", "epc_h16_colgemm", "epc_h16_df_tail_scratch_bytes", "epc_h16_df_tail", "epc_h16_bn_bwd_apply",
@@ -189,6 +190,30 @@ _lib.epc_chain_bwd_gather.argtypes = [_P, _P, c_int] + [_P] * 7 + [c_int, c_int,
 _lib.epc_chain_sums.argtypes = [_P, c_int] + [_P] * 5 + [c_float, c_int, _P, _P]
 _lib.epc_chain_bn_bwd.argtypes = [_P] * 6 + [c_float, _P, _P, _P, c_int, _P, _P]
 _lib.epc_chain_dw_sum.argtypes = [c_int, _P, _P, c_int, _P]
+EPC_CHAIN_MAX_BLOCKS = 4
+
+
+class ChainFwdBlock(ctypes.Structure):
+    """``struct epc_chain_fwd_block`` of include/epcnet.h."""
+    _fields_ = [(n, _P) for n in ("gamma0", "beta0", "in_bias", "Wa", "ba", "gamma_a", "beta_a", "Wb", "bb", "gamma_b", "beta_b",
+                                  "W0_next", "b0_next", "z0", "mean0", "var0", "mean_a", "var_a", "mean_b", "var_b",
+                                  "d", "za", "zb", "z0_next")]
+
+
+class ChainFwdArgs(ctypes.Structure):
+    """``struct epc_chain_fwd_args`` of include/epcnet.h."""
+    _fields_ = [("blk", ChainFwdBlock * EPC_CHAIN_MAX_BLOCKS), ("nblocks", c_int), ("xyz", _P), ("idx", _P), ("cnt", _P), ("kth", _P),
+                ("cap", c_int), ("num_clouds", c_int), ("n", c_int), ("knn", c_int), ("cat", _P), ("cat_bf16", _P), ("eps", c_float),
+                ("workspace", _P), ("spin_ticks", ctypes.c_longlong)]
+
+
+_lib.epc_chain_persist_ok.argtypes = [c_int]
+_lib.epc_chain_persist_workspace_bytes.restype = c_size_t
+_lib.epc_chain_persist_workspace_bytes.argtypes = []
+_lib.epc_chain_persist_init.argtypes = [_P, _P]
+_lib.epc_chain_fwd_persist.argtypes = [POINTER(ChainFwdArgs), c_int, _P]
+_lib.epc_chain_persist_status.argtypes = [_P, _P]
+_lib.epc_chain_persist_reset.argtypes = [_P, _P]
 _lib.epc_knn_overflow_lists.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_vlad_df_packed_bytes.restype = c_size_t
 _lib.epc_vlad_df_packed_bytes.argtypes = [c_int, c_int]

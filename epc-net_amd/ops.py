@@ -3,6 +3,8 @@ calls into libepcnet_hip.so (``csrc/train_ops.hip``).  autograd is used as the t
 in these functions and no CPU fallback.  Reference semantics are cited per operator."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -607,6 +609,42 @@ class ProxyConvTail(torch.autograd.Function):
         return dx, None, None, dWa, None, dga, dbta, dWb, None, dgb, dbtb, None
 
 
+# The backbone chain as ONE persistent launch each way (csrc/train_chain_persist.hip: grid-wide barriers instead of kernel boundaries).
+# "auto": whenever the library covers the row count (epc_chain_persist_ok) and nothing that waits for the chain shares the device
+# with it; training.TrainStep switches the BACKWARD to the launches while a collective runs beside it (DP_OVERLAP).
+CHAIN_PERSIST_FWD = True
+CHAIN_PERSIST_BWD = True
+CHAIN_SPIN_TICKS = 0          # spin budget of a grid barrier in 10-ns ticks; 0: the library's default (a quarter second)
+_CHAIN_WS = {}
+
+
+def chain_workspace(device):
+    """The persistent chain's workspace of `device` (sequence number, error word, the barriers' tagged partials): zeroed once, then
+    left to the library.  One launch at a time: the chain's launches of a device are stream-ordered."""
+    key = (device.type, device.index)
+    t = _CHAIN_WS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the persistent chain's workspace must exist before a graph capture (its one-time zeroing would be "
+                               "replayed): run one eager step first, as TrainStep's warm-up does")
+        t = torch.empty(L.lib().epc_chain_persist_workspace_bytes(), dtype=torch.uint8, device=device)
+        L.check(L.lib().epc_chain_persist_init(t.data_ptr(), _st()))
+        _CHAIN_WS[key] = t
+    return t
+
+
+def chain_persist_check(device=None):
+    """Synchronises and raises EpcNetError when a persistent chain launch was abandoned (a barrier ran out of its spin budget);
+    the workspace is then reset so that the next step can run."""
+    for key, t in list(_CHAIN_WS.items()):
+        if device is not None and key != (device.type, device.index):
+            continue
+        rc = L.lib().epc_chain_persist_status(t.data_ptr(), _st())
+        if rc != L.EPC_OK:
+            L.lib().epc_chain_persist_reset(t.data_ptr(), _st())
+            L.check(rc)
+
+
 def chain_ok(rows):
     """The fused backbone chain (ProxyConvChain) covers both GEMM arithmetics of the step and any row count."""
     return rows >= 1
@@ -662,6 +700,14 @@ class ProxyConvChain(torch.autograd.Function):
             _CAT16.clear()
             _CAT16[cat.data_ptr()] = cat16
         g = graph
+        if CHAIN_PERSIST_FWD and nblocks <= L.EPC_CHAIN_MAX_BLOCKS and lib.epc_chain_persist_ok(rows):
+            saved, outs = ProxyConvChain._forward_persistent(lib, z01, g, k, eps, nblocks, pieces_fwd, blocks, cat, cat16)
+            ctx.save_for_backward(cat, *saved, *[p for p in params])
+            ctx.graph, ctx.k, ctx.eps, ctx.nblocks = graph, int(k), float(eps), int(nblocks)
+            ctx.pieces_bwd, ctx.n_params = int(pieces_bwd), len(params)
+            ctx.mark_non_differentiable(*outs)
+            ctx.set_materialize_grads(False)
+            return (cat,) + tuple(outs)
         st0 = stats()
         L.check(lib.epc_chain_stats(z01.data_ptr(), rows, st0.data_ptr(), _st()))
         z0, in_stats, in_bias = z01, st0, None
@@ -700,6 +746,41 @@ class ProxyConvChain(torch.autograd.Function):
         ctx.mark_non_differentiable(*outs)
         ctx.set_materialize_grads(False)
         return (cat,) + tuple(outs)
+
+    @staticmethod
+    def _forward_persistent(lib, z01, g, k, eps, nblocks, pieces_fwd, blocks, cat, cat16):
+        """The whole forward as one launch (epc_chain_fwd_persist); returns (saved, outs) in forward()'s order."""
+        rows, dev = int(z01.shape[0]), z01.device
+        new = lambda: torch.empty((rows, 64), dtype=torch.float32, device=dev)
+        vec = lambda: torch.empty(64, dtype=torch.float32, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        a = L.ChainFwdArgs()
+        a.nblocks = nblocks
+        a.xyz, a.idx, a.cnt, a.kth = g.xyz.data_ptr(), g.idx.data_ptr(), g.cnt.data_ptr(), g.kth.data_ptr()
+        a.cap, a.num_clouds, a.n, a.knn = L.EPC_KNN_CAP, g.num_clouds, g.n, int(k)
+        a.cat, a.cat_bf16 = cat.data_ptr(), ptr(cat16)
+        a.eps = float(eps)
+        a.workspace, a.spin_ticks = chain_workspace(dev).data_ptr(), int(CHAIN_SPIN_TICKS)
+        saved, outs = [], []
+        z0 = z01
+        for b, (W0, b0, g0, bt0, Wa, ba, ga, bta, Wb, bb, gb, btb) in enumerate(blocks):
+            m0, v0, ma, va, mb, vb = vec(), vec(), vec(), vec(), vec(), vec()
+            d, za, zb = new(), new(), new()
+            nxt = blocks[b + 1] if b + 1 < nblocks else None
+            z0n = new() if nxt is not None else None
+            B = a.blk[b]
+            B.gamma0, B.beta0, B.in_bias = g0.data_ptr(), bt0.data_ptr(), (ptr(b0) if b > 0 else None)
+            B.Wa, B.ba, B.gamma_a, B.beta_a = Wa.data_ptr(), ptr(ba), ga.data_ptr(), bta.data_ptr()
+            B.Wb, B.bb, B.gamma_b, B.beta_b = Wb.data_ptr(), ptr(bb), gb.data_ptr(), btb.data_ptr()
+            B.W0_next, B.b0_next = (nxt[0].data_ptr(), ptr(nxt[1])) if nxt is not None else (None, None)
+            B.z0, B.z0_next = z0.data_ptr(), ptr(z0n)
+            B.mean0, B.var0, B.mean_a, B.var_a, B.mean_b, B.var_b = (t.data_ptr() for t in (m0, v0, ma, va, mb, vb))
+            B.d, B.za, B.zb = d.data_ptr(), za.data_ptr(), zb.data_ptr()
+            saved += [z0, d, za, zb, m0, v0, ma, va, mb, vb]
+            outs += ([z0] if b > 0 else []) + [m0, v0, za, ma, va, zb, mb, vb]
+            z0 = z0n
+        L.check(lib.epc_chain_fwd_persist(ctypes.byref(a), int(pieces_fwd), _st()))
+        return saved, outs
 
     @staticmethod
     def backward(ctx, dcat, *_unused):

@@ -562,6 +562,48 @@ int epc_chain_sums(const float* dy, int dy_stride, const float* z, const float* 
 int epc_chain_bn_bwd(const float* dy, const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                      float eps, const float* sums, float* dgamma, float* dbeta, int rows, float* dz, void* stream);
 int epc_chain_dw_sum(int layers, const float* const* partials, float* const* dW, int rows, void* stream);
+/* ---- The same backbone as ONE persistent launch each way (csrc/train_chain_persist.hip) -----------------------------------------
+ * One workgroup per CU keeps its rows for the whole pass (a wave owns one 32-row tile; the tile handed to the next layer stays in
+ * LDS) and every training-mode BatchNorm costs a grid-wide BARRIER instead of a kernel boundary; the batch moments are reduced in
+ * two levels on the way through it.  Same arithmetic, operands and outputs as the launches above (the statistics' summation order
+ * differs: group partials by row range).  Usable when epc_chain_persist_ok(rows) != 0: at most 12 tiles per workgroup (rows <=
+ * 384 x CUs) and every workgroup co-resident by the occupancy query.  Nothing else may need the CUs these workgroups wait on: do not
+ * run it beside a kernel that waits for IT.  Every spin is bounded (spin_ticks of the 100-MHz s_memrealtime, 0 = a quarter second): on
+ * a time-out the sticky error word of the workspace is set, every workgroup leaves, results are undefined and every later launch on
+ * the same workspace returns at once -- epc_chain_persist_status() (synchronises the stream) then returns EPC_EHIP until
+ * epc_chain_persist_reset().  workspace: epc_chain_persist_workspace_bytes() bytes, zeroed ONCE with epc_chain_persist_init() and then
+ * left to the library (launch sequence number, the barriers' tagged partials); one launch at a time per workspace. */
+#define EPC_CHAIN_MAX_BLOCKS 4
+typedef struct epc_chain_fwd_block {
+    const float *gamma0, *beta0;   /* the block's leading BatchNorm (models/epc-net.py:66-69, 83, 99, 115) */
+    const float* in_bias;          /* the bias z0's moment partials lack: NULL for the first block (z0 = conv1's output as it stands) */
+    const float *Wa, *ba, *gamma_a, *beta_a, *Wb, *bb, *gamma_b, *beta_b;
+    const float *W0_next, *b0_next; /* the NEXT block's leading conv; NULL in the last block */
+    const float* z0;               /* the leading pre-activation: the input for the first block, the previous block's z0_next after */
+    float *mean0, *var0, *mean_a, *var_a, *mean_b, *var_b;   /* out: batch moments */
+    float *d, *za, *zb;            /* out (rows, 64): xm - x and the two pre-activations (the neighbour mean xm itself stays in registers) */
+    float* z0_next;                /* out (rows, 64); NULL in the last block */
+} epc_chain_fwd_block;
+typedef struct epc_chain_fwd_args {
+    epc_chain_fwd_block blk[EPC_CHAIN_MAX_BLOCKS];
+    int nblocks;
+    const float* xyz;              /* the kNN graph of epc_knn_topk: int32 lists, cap slots */
+    const int32_t* idx;
+    const int32_t* cnt;
+    const float* kth;
+    int cap, num_clouds, n, knn;
+    float* cat;                    /* out (rows, 64 nblocks): the concat (models/epc-net.py:134) */
+    void* cat_bf16;                /* optional: the same rounded to bf16 */
+    float eps;
+    void* workspace;
+    long long spin_ticks;
+} epc_chain_fwd_args;
+int epc_chain_persist_ok(int rows);
+size_t epc_chain_persist_workspace_bytes(void);
+int epc_chain_persist_init(void* workspace, void* stream);
+int epc_chain_fwd_persist(const epc_chain_fwd_args* a, int pieces, void* stream);
+int epc_chain_persist_status(const void* workspace, void* stream);
+int epc_chain_persist_reset(void* workspace, void* stream);
 /* per cloud the points whose neighbour list overflowed (cnt > cap), ascending: ovf_cnt (num_clouds), ovf_list (num_clouds, n) */
 int epc_knn_overflow_lists(const int32_t* cnt, int cap, int num_clouds, int n, int32_t* ovf_cnt, int32_t* ovf_list, void* stream);
 
