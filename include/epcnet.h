@@ -598,6 +598,38 @@ typedef struct epc_chain_fwd_args {
     void* workspace;
     long long spin_ticks;
 } epc_chain_fwd_args;
+/* The backward of the same chain as one launch (csrc/train_chain_persist.hip): per block, last to first,
+ *   conv_b's layer + BatchNorm backward -> conv_a's (its dx + the block's output gradient = s, written for the other workgroups) ->
+ *   the gather's transpose over epc_knn_transpose's lists (+ the overflow lists) -> the leading conv's layer (its dx + the concat's
+ *   gradient of the previous slice = the previous block's output gradient)
+ * with the gradient handed from layer to layer in REGISTERS and a barrier (carrying the next BatchNorm's two column sums) where
+ * epc_chain_bwd_linear / _gather have a kernel boundary.  Leaves every layer's dgamma / dbeta, the workgroups' dW partials
+ * ([epc_chain_parts(rows)][64][64] per layer: epc_chain_dw_sum adds them) and dz01, the gradient of the first block's leading
+ * pre-activation.  s: one (rows, 64) scratch tensor PER BLOCK (written once per launch); dx, g: one each for the whole chain. */
+typedef struct epc_chain_bwd_block {
+    const float *W0, *gamma0, *beta0, *mean0, *var0;   /* W0 NULL in the first block (conv1 keeps its own kernels) */
+    const float *Wa, *gamma_a, *beta_a, *mean_a, *var_a;
+    const float *Wb, *gamma_b, *beta_b, *mean_b, *var_b;
+    const float *z0, *d, *za, *zb;                     /* saved by the forward */
+    float *dgamma0, *dbeta0, *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
+    float *dw0_partials, *dwa_partials, *dwb_partials; /* dw0 NULL in the first block */
+    float* s;                                          /* scratch (rows, 64) */
+} epc_chain_bwd_block;
+typedef struct epc_chain_bwd_args {
+    epc_chain_bwd_block blk[EPC_CHAIN_MAX_BLOCKS];
+    int nblocks;
+    const float* cat;              /* (rows, 64 nblocks): the forward's output; */
+    const float* dcat;             /* its gradient */
+    const int32_t *rdeg, *roff, *rlist, *ovf_cnt, *ovf_list;
+    const float *xyz, *kth;
+    int num_clouds, n, knn;
+    float *dx, *g;                 /* scratch (rows, 64) each */
+    float* dz01;                   /* out (rows, 64) */
+    float eps;
+    void* workspace;
+    long long spin_ticks;
+} epc_chain_bwd_args;
+int epc_chain_bwd_persist(const epc_chain_bwd_args* a, int pieces, void* stream);
 int epc_chain_persist_ok(int rows);
 size_t epc_chain_persist_workspace_bytes(void);
 int epc_chain_persist_init(void* workspace, void* stream);

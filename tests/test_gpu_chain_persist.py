@@ -98,11 +98,18 @@ def test_persistent_chain_equals_the_launch_chain(dev, arch, ncl, n, kind, preci
             assert ga is None or np.abs(ga).max() <= 1e-4
             continue
         rel = np.linalg.norm(ga - gb) / max(np.linalg.norm(gb), 1e-30)
+        if precision == "bf16":      # as the outputs: as far from the f32-accurate gradient as the launch chain's, closer to it than to that
+            gc = c[1][k]
+            rac, rbc = np.linalg.norm(ga - gc) / np.linalg.norm(gc), np.linalg.norm(gb - gc) / np.linalg.norm(gc)
+            worst = max(worst, (rel / rbc, k))
+            assert rac <= 1.3 * rbc + 1e-3 and rel <= 1.2 * rbc + 1e-3, (k, rel, rac, rbc)
+            continue
         worst = max(worst, (rel, k))
         assert rel <= bar_grad, (k, rel)
     for k, vb in b[2].items():
-        assert np.abs(a[2][k] - vb).max() <= 2e-6 + (2e-6 if kind == "uniform" else 5e-5) * np.abs(vb).max(), k
-    print("persistent vs launch chain, %s %dx%d (%s, %s): cat max diff %.2e, worst gradient rel L2 %.2e (%s)"
+        bar = (2e-6 if kind == "uniform" else 5e-5) if precision != "bf16" else 5e-3      # (bf16: the statistics of bf16-rounded products)
+        assert np.abs(a[2][k] - vb).max() <= 2e-6 + bar * np.abs(vb).max(), k
+    print("persistent vs launch chain, %s %dx%d (%s, %s): cat max diff %.2e, worst gradient rel L2 (bf16: / the launch chain's distance from f32) %.2e (%s)"
           % (arch, ncl, n, kind, precision, np.abs(a[0] - b[0]).max(), worst[0], worst[1]))
 
 
