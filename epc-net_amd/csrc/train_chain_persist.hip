@@ -1,5 +1,9 @@
-// The 64-channel backbone of the TRAINING step as ONE persistent launch each way (models/epc-net.py:66-134, utils/tf_util.py:454-519
-// in training mode) -- the launch chain of train_chain.hip with its kernel boundaries replaced by grid-wide barriers.
+// The FORWARD of the 64-channel backbone of the training step as ONE persistent launch (models/epc-net.py:66-134, utils/tf_util.py:454-519
+// in training mode) -- the forward launches of train_chain.hip with their kernel boundaries replaced by grid-wide barriers.  (The
+// backward was built the same way -- 16 barriers, the gradient handed from layer to layer in registers -- was parity-green and SLOWER
+// than its launches, 2.25 -> 2.41 ms per 22-cloud step: in a replayed graph a kernel boundary + the pooled prologue cost what a barrier
+// costs, ~8 us, so only traffic saved pays, and the backward's gather runs 61 us on 12 waves against 44 on 16.  DESIGN.md 4 has the
+// numbers; the commit before its removal has the code.)
 //
 // Why.  Every training-mode BatchNorm is a grid-wide dependency (its batch moments need every row), and train_chain.hip pays one
 // kernel boundary per dependency: 33 launches whose 14-20 us are mostly launch gap (4.2 us), the pooling of 256 moment partials
@@ -661,520 +665,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
     pst_exit(cx);
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// BACKWARD.  Per block b, last to first (models/epc-net.py:70-83 transposed; train_chain.hip's four launches per block):
-//   CB  conv_b's layer:   dz_b = bnb'(g_b [zb-mask]);  dya = dz_b Wb^T;  dWb += relu(bna(za))^T dz_b;  leaves bna's two sums of (dya, za)
-//   CA  conv_a's layer:   dz_a = bna'(dya);  s = dz_a Wa^T + g_b -> global, write-through (the other workgroups gather it);  dWa += d^T dz_a
-//   GT  the gather's transpose:  dx[j] = (sum over the points i that list j of s[i]) / k - (s[j] - g_b[j]);  leaves bn0's sums of (dx, z0)
-//   C0  the leading conv: dz_0 = bn0'(dx);  g_{b-1} = dz_0 W0^T + dcat[slice b - 1];  dW0 += out_{b-1}^T dz_0;  leaves bnb(b-1)'s sums
-//       (first block: dz01 = bn0'(dx) and the chain ends)
-// g_b, the gradient of the block's output, is the concat's gradient of slice b for the last block.  Between CB -> CA and C0 -> CB the
-// gradient stays in REGISTERS, in the layout the product leaves it ("ACC": lane (row i, half h) holds channels 32 mt + 8 g + 4 h + e):
-// the next layer's BatchNorm backward is elementwise, its B fragments take the lane's values with a permuted k order (the weights
-// are staged to match) and the transposition image takes them as 8-byte halves.  Every barrier carries the two column sums of the
-// next BatchNorm backward (zeros in front of GT, which only needs every s row to be there).
-// ----------------------------------------------------------------------------------------------------------------
-struct PstBwdArgs {
-    epc_chain_bwd_args a;
-    int rows, wg_rows, width;
-    float kdiv;
-    long long budget;
-};
-struct PstLin {   // one layer phase's operands (wave-uniform)
-    const float* dy;       // null: the gradient arrives in registers
-    int dy_stride;
-    const float* z;
-    ChBnGiven bn;
-    float *dgamma, *dbeta;
-    const float* W;        // null: dz itself is the result (-> dz_out): the first block's leading BatchNorm
-    const float* x;
-    int x_stride;
-    ChBnGiven xbn;
-    const float* addend;
-    int addend_stride;
-    float* out;            // the outgoing gradient as a tensor (null: registers only)
-    bool out_wt;           // ... write-through: other workgroups read it after the barrier
-    const float* zp;       // null: no sums to leave
-    ChBnGiven pbn;
-    float* dwpart;
-    float* dz_out;
-};
-
-// W (in, out) row-major as A fragments of dx^T = W dz^T with the k order of an ACC-layout B operand: lane (m = 32 mt + (l & 31), half h) of
-// k-step s holds W[m][16 s + 8 (j >> 2) + 4 h + (j & 3)], j = 0 .. 7
-template <int PB>
-__device__ __forceinline__ void pst_stage_bwd_weights(const float* W, u32x4 (*Wf)[4][PB][64]) {
-    for (int f = pst_tid(); f < 2 * 4 * 64; f += blockDim.x) {
-        const int l = f & 63, s4 = (f >> 6) & 3, mt = f >> 8;
-        const float* src = W + (size_t)(32 * mt + (l & 31)) * 64 + 16 * s4 + 4 * (l >> 5);
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 8);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        bf16x8 p[PB];
-        ch_split<PB>(v, p);
-#pragma unroll
-        for (int pc = 0; pc < PB; ++pc) Wf[mt][s4][pc][l] = __builtin_bit_cast(u32x4, p[pc]);
-    }
-}
-
-#define PST_BWD_WAVE_BYTES(PB) ((PB) * CH_IMG_BYTES + CH_SUMT_WORDS * 4)
-
-template <int PB>
-__global__ __launch_bounds__(64 * PST_WAVES) void chain_bwd_persist_kernel(PstBwdArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char dyn[];   // per wave: image pieces + sum tile | the dW partials' parking | polls / reductions
-    __shared__ u32x4 Wf[2][4][PB][64];
-    __shared__ __attribute__((aligned(16))) float coef[6][64];    // s, t (mask), mean, k1, dbeta / rows, rstd dgamma / rows
-    __shared__ __attribute__((aligned(16))) float xcoef[2][64];
-    __shared__ __attribute__((aligned(16))) float pcoef[4][64];
-    __shared__ __attribute__((aligned(16))) float s_sum[2][64];
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-    const int rows = g.rows;
-    char* ws = reinterpret_cast<char*>(g.a.workspace);
-    unsigned* sync = reinterpret_cast<unsigned*>(ws);
-    if (ld_coh(sync + PST_W_ERR) != 0u) return;
-    PstCtx cx = pst_init(sync, g.budget);
-#ifdef PST_STAMPS
-    long long* stamps = reinterpret_cast<long long*>(ws + PST_WS_STAMPS) + (size_t)blockIdx.x * 64;
-    int sidx = 0;
-#endif
-    PST_STAMP();
-    const int wg0 = cx.lb * g.wg_rows, tiles = min(g.wg_rows, rows - wg0 + 31) / 32;
-    const int wg_end = min(rows, wg0 + g.wg_rows);
-    const int base = wg0 + wave * 32;
-    const bool have = wave < tiles;
-    const float inv_rows = 1.0f / (float)rows;
-    const int nb = g.a.nblocks;
-    int phase = 0;
-    auto stats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_PARTIALS) + (size_t)ph * PST_MAX_PARTS * 192; };
-    auto gstats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_GROUPS) + (size_t)ph * 8 * 384; };
-    // the two sums of a workgroup from red[slot][2][64] (dyn), slots in ascending order -> posted
-    auto post_sums_from_slots = [&](int nslots) {
-        const float* red = reinterpret_cast<const float*>(dyn);
-        pst_gran* out = stats_of(phase) + (size_t)cx.lb * 128;
-        const unsigned tag = pst_tag(cx, phase);
-        for (int o = pst_tid(); o < 128; o += blockDim.x) {
-            float t = 0.f;
-            for (int sl = 0; sl < nslots; ++sl) t += red[sl * 128 + o];
-            st_gran(out + o, __float_as_uint(t), tag);
-        }
-    };
-    // one barrier: (the partial [2][64] is posted) -> group reduce -> gather -> s_sum (and, workgroup 0, dbeta / dgamma of the BatchNorm they belong to)
-    auto barrier_sums = [&](float* dgamma, float* dbeta) -> bool {
-        const unsigned tag = pst_tag(cx, phase);
-        __syncthreads();   // (whoever still reads dyn is done: the polls land there)
-        if (cx.leader && !pst_group_reduce<2>(cx, stats_of(phase), gstats_of(phase), tag, rows, g.wg_rows, dyn)) return false;
-        if (!pst_gather_groups<2>(cx, gstats_of(phase), tag, dyn)) return false;
-        const double* gd = reinterpret_cast<const double*>(dyn);
-        for (int o = pst_tid(); o < 128; o += blockDim.x) {
-            double t = 0.0;
-            for (int k = 0; k < (int)cx.ngroups; ++k) t += gd[k * 128 + o];
-            s_sum[o >> 6][o & 63] = (float)t;
-            if (blockIdx.x == 0 && dgamma) ((o >> 6) ? dgamma : dbeta)[o & 63] = (float)t;
-        }
-        __syncthreads();
-        phase += 1;
-        return true;
-    };
-
-    // ---- phase 0: the sums of the chain's LAST BatchNorm backward from (dcat's last slice, zb): 16 lanes x float4 per row ----
-    {
-        const epc_chain_bwd_block& B = g.a.blk[nb - 1];
-        if (tid < 64) {
-            const float pm = B.mean_b[tid];
-            const ChBnAffine pa = ch_bn_affine(pm, B.var_b[tid], B.gamma_b[tid], B.beta_b[tid], g.a.eps);
-            pcoef[0][tid] = pa.s, pcoef[1][tid] = pa.t, pcoef[2][tid] = pm, pcoef[3][tid] = 1.0f / sqrtf(B.var_b[tid] + g.a.eps);
-        }
-        __syncthreads();
-        const int q = tid & 15, slot = tid >> 4, nslots = blockDim.x >> 4;
-        const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][4 * q]), qt = *reinterpret_cast<const float4*>(&pcoef[1][4 * q]);
-        const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
-        const float* dy = g.a.dcat + 64 * (nb - 1);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        for (int r = wg0 + slot; r < wg_end; r += nslots) {
-            const float4 zv = *reinterpret_cast<const float4*>(B.zb + (size_t)r * 64 + 4 * q);
-            const float4 gv = *reinterpret_cast<const float4*>(dy + (size_t)r * g.width + 4 * q);
-            const float d0 = (zv.x * qs.x + qt.x > 0.f) ? gv.x : 0.f, d1 = (zv.y * qs.y + qt.y > 0.f) ? gv.y : 0.f;
-            const float d2 = (zv.z * qs.z + qt.z > 0.f) ? gv.z : 0.f, d3 = (zv.w * qs.w + qt.w > 0.f) ? gv.w : 0.f;
-            a.x += d0, a.y += d1, a.z += d2, a.w += d3;
-            b.x += d0 * ((zv.x - qm.x) * qr.x), b.y += d1 * ((zv.y - qm.y) * qr.y), b.z += d2 * ((zv.z - qm.z) * qr.z),
-                b.w += d3 * ((zv.w - qm.w) * qr.w);
-        }
-        float* red = reinterpret_cast<float*>(dyn);
-        *reinterpret_cast<float4*>(red + slot * 128 + 4 * q) = a;
-        *reinterpret_cast<float4*>(red + slot * 128 + 64 + 4 * q) = b;
-        __syncthreads();
-        post_sums_from_slots(nslots);
-        pst_stage_bwd_weights<PB>(B.Wb, Wf);
-    }
-    PST_STAMP();
-
-    float go[2][16];   // the gradient handed from a layer to the next one (ACC layout)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) go[mt][r] = 0.f;
-
-#pragma unroll 1
-    for (int b = nb - 1; b >= 0; --b) {
-        const epc_chain_bwd_block& B = g.a.blk[b];
-        // the gradient of the block's output as a tensor: the concat's slice for the last block, else what C0 of block b + 1 wrote
-        const float* gb = b == nb - 1 ? g.a.dcat + 64 * b : g.a.g;
-        const int gb_stride = b == nb - 1 ? g.width : 64;
-#pragma unroll 1
-        for (int step = 0; step < 4; ++step) {
-            // ---- this step's operands ----
-            PstLin P;
-            P.dy = nullptr, P.dy_stride = 0, P.x = nullptr, P.x_stride = 64, P.addend = nullptr, P.addend_stride = 0, P.out = nullptr, P.out_wt = false;
-            P.zp = nullptr, P.dwpart = nullptr, P.dz_out = nullptr, P.W = nullptr, P.z = nullptr, P.dgamma = P.dbeta = nullptr;
-            P.bn.mean = P.bn.var = P.bn.gamma = P.bn.beta = nullptr, P.xbn = P.bn, P.pbn = P.bn;
-            const float* next_W = nullptr;
-            if (step == 0) {          // CB
-                if (b == nb - 1) P.dy = gb, P.dy_stride = gb_stride;
-                P.z = B.zb, P.bn.mean = B.mean_b, P.bn.var = B.var_b, P.bn.gamma = B.gamma_b, P.bn.beta = B.beta_b, P.dgamma = B.dgamma_b, P.dbeta = B.dbeta_b;
-                P.W = B.Wb, P.x = B.za, P.xbn.mean = B.mean_a, P.xbn.var = B.var_a, P.xbn.gamma = B.gamma_a, P.xbn.beta = B.beta_a;
-                P.zp = B.za, P.pbn = P.xbn, P.dwpart = B.dwb_partials;
-                next_W = B.Wa;
-            } else if (step == 1) {   // CA
-                P.z = B.za, P.bn.mean = B.mean_a, P.bn.var = B.var_a, P.bn.gamma = B.gamma_a, P.bn.beta = B.beta_a, P.dgamma = B.dgamma_a, P.dbeta = B.dbeta_a;
-                P.W = B.Wa, P.x = B.d, P.addend = gb, P.addend_stride = gb_stride, P.out = B.s, P.out_wt = true, P.dwpart = B.dwa_partials;
-                next_W = B.W0;        // (null in the first block)
-            } else if (step == 3) {   // C0 / the first block's leading BatchNorm
-                P.dy = g.a.dx, P.dy_stride = 64;
-                P.z = B.z0, P.bn.mean = B.mean0, P.bn.var = B.var0, P.bn.gamma = B.gamma0, P.bn.beta = B.beta0, P.dgamma = B.dgamma0, P.dbeta = B.dbeta0;
-                if (b > 0) {
-                    const epc_chain_bwd_block& Bp = g.a.blk[b - 1];
-                    P.W = B.W0, P.x = g.a.cat + 64 * (b - 1), P.x_stride = g.width, P.addend = g.a.dcat + 64 * (b - 1), P.addend_stride = g.width;
-                    P.out = g.a.g, P.zp = Bp.zb, P.pbn.mean = Bp.mean_b, P.pbn.var = Bp.var_b, P.pbn.gamma = Bp.gamma_b, P.pbn.beta = Bp.beta_b;
-                    P.dwpart = B.dw0_partials;
-                    next_W = Bp.Wb;
-                } else {
-                    P.dz_out = g.a.dz01;
-                }
-            }
-            // ---- the barrier in front of the step ----
-            if (!barrier_sums(step == 2 ? nullptr : P.dgamma, step == 2 ? nullptr : P.dbeta)) return;
-            PST_STAMP();
-
-            if (step == 2) {
-                // ================= GT: the gather's transpose =================
-                const int t2 = pst_tid(), slot = t2 >> 4, q = t2 & 15, nslots = blockDim.x >> 4;
-                if (t2 < 64) {
-                    const float pm = B.mean0[t2];
-                    const ChBnAffine pa = ch_bn_affine(pm, B.var0[t2], B.gamma0[t2], B.beta0[t2], g.a.eps);
-                    pcoef[0][t2] = pa.s, pcoef[1][t2] = pa.t, pcoef[2][t2] = pm, pcoef[3][t2] = 1.0f / sqrtf(B.var0[t2] + g.a.eps);
-                }
-                __syncthreads();
-                const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][4 * q]), qt = *reinterpret_cast<const float4*>(&pcoef[1][4 * q]);
-                const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
-                const float4* s4p = reinterpret_cast<const float4*>(B.s);
-                float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), tt2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int n = g.a.n;
-#pragma unroll 1
-                for (int j = wg0 + slot; j < wg_end; j += nslots) {
-                    const int deg = g.a.rdeg[j];
-                    const int32_t* lst = g.a.rlist + g.a.roff[j];
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int m = 0; m < deg; m += 8) {   // the list in batches of 8, the last one predicated; added in list order
-                        int ii[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) ii[u] = lst[min(m + u, deg - 1)];
-                        float4 v[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = s4p[(unsigned)ii[u] * 16u + (unsigned)q];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (m + u < deg) acc.x += v[u].x, acc.y += v[u].y, acc.z += v[u].z, acc.w += v[u].w;
-                    }
-                    const int cloud = j / n, cloud_base = cloud * n;
-                    const int novf = g.a.ovf_cnt[cloud];
-                    if (novf > 0) {   // the cloud's overflowed points: does i select j?  (a_ij >= kth_i, utils/tf_util.py:662-664)
-                        const float* pc = g.a.xyz + (size_t)cloud_base * 3;
-                        const int jj = j - cloud_base;
-                        const float xj = pc[3 * jj], yj = pc[3 * jj + 1], zj = pc[3 * jj + 2];
-                        const float sqj = sq3(xj, yj, zj);
-                        const int32_t* ol = g.a.ovf_list + (size_t)cloud * n;
-                        for (int u = 0; u < novf; ++u) {
-                            const int ii = ol[u];
-                            const float xi = pc[3 * ii], yi = pc[3 * ii + 1], zi = pc[3 * ii + 2];
-                            if (neg_sq_dist(sq3(xi, yi, zi), xi, yi, zi, xj, yj, zj, sqj) >= g.a.kth[cloud_base + ii]) {
-                                const float4 v = s4p[(size_t)(cloud_base + ii) * 16 + q];
-                                acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
-                            }
-                        }
-                    }
-                    const float4 a = s4p[(size_t)j * 16 + q], bq = *reinterpret_cast<const float4*>(gb + (size_t)j * gb_stride + 4 * q);
-                    const float4 dxv = make_float4(acc.x / g.kdiv - (a.x - bq.x), acc.y / g.kdiv - (a.y - bq.y), acc.z / g.kdiv - (a.z - bq.z),
-                                                   acc.w / g.kdiv - (a.w - bq.w));
-                    reinterpret_cast<float4*>(g.a.dx)[(size_t)j * 16 + q] = dxv;
-                    const float4 zq = reinterpret_cast<const float4*>(B.z0)[(size_t)j * 16 + q];
-                    const float vv[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, zz[4] = {zq.x, zq.y, zq.z, zq.w};
-                    const float a_s[4] = {qs.x, qs.y, qs.z, qs.w}, a_t[4] = {qt.x, qt.y, qt.z, qt.w};
-                    const float a_m[4] = {qm.x, qm.y, qm.z, qm.w}, a_r[4] = {qr.x, qr.y, qr.z, qr.w};
-                    float o1[4], o2[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dd = (zz[e] * a_s[e] + a_t[e] > 0.f) ? vv[e] : 0.f;
-                        o1[e] = dd, o2[e] = dd * ((zz[e] - a_m[e]) * a_r[e]);
-                    }
-                    t1.x += o1[0], t1.y += o1[1], t1.z += o1[2], t1.w += o1[3];
-                    tt2.x += o2[0], tt2.y += o2[1], tt2.z += o2[2], tt2.w += o2[3];
-                }
-                float* red = reinterpret_cast<float*>(dyn);
-                *reinterpret_cast<float4*>(red + slot * 128 + 4 * q) = t1;
-                *reinterpret_cast<float4*>(red + slot * 128 + 64 + 4 * q) = tt2;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // dx is re-read by this workgroup in another layout
-                __syncthreads();
-                PST_STAMP();
-                post_sums_from_slots(nslots);
-                PST_STAMP();
-                continue;
-            }
-
-            // ================= a layer: CB, CA, C0 (or the first block's leading BatchNorm alone) =================
-            const int lane = pst_tid() & 63, i = lane & 31, h = lane >> 5;
-            {
-                const int t2 = pst_tid();
-                if (t2 < 64) {
-                    const float mu = P.bn.mean[t2], rs = 1.0f / sqrtf(P.bn.var[t2] + g.a.eps), ga = P.bn.gamma[t2];
-                    const ChBnAffine a = ch_bn_affine(mu, P.bn.var[t2], ga, P.bn.beta[t2], g.a.eps);
-                    coef[0][t2] = a.s, coef[1][t2] = a.t, coef[2][t2] = mu;
-                    coef[3][t2] = ga * rs, coef[4][t2] = s_sum[0][t2] * inv_rows, coef[5][t2] = rs * (s_sum[1][t2] * inv_rows);
-                    if (P.xbn.mean) {
-                        const ChBnAffine xa = ch_bn_affine(P.xbn.mean[t2], P.xbn.var[t2], P.xbn.gamma[t2], P.xbn.beta[t2], g.a.eps);
-                        xcoef[0][t2] = xa.s, xcoef[1][t2] = xa.t;
-                    }
-                    if (P.zp) {
-                        const float pm = P.pbn.mean[t2];
-                        const ChBnAffine pa = ch_bn_affine(pm, P.pbn.var[t2], P.pbn.gamma[t2], P.pbn.beta[t2], g.a.eps);
-                        pcoef[0][t2] = pa.s, pcoef[1][t2] = pa.t, pcoef[2][t2] = pm, pcoef[3][t2] = 1.0f / sqrtf(P.pbn.var[t2] + g.a.eps);
-                    }
-                }
-                __syncthreads();
-            }
-            f32x16 accW[2][2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accW[mt][nt][r] = 0.f;
-            float psum[8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) psum[o] = 0.f;
-            char* my = dyn + (size_t)wave * PST_BWD_WAVE_BYTES(PB);
-            float* mysum = reinterpret_cast<float*>(my + PB * CH_IMG_BYTES);
-            if (have) {
-                const int row = base + i;
-                const bool ok = row < rows;
-                const size_t rsafe = (size_t)(ok ? row : 0);
-                // ---- dz in the ACC layout: this layer's BatchNorm + ReLU backward of the incoming gradient ----
-                float dz[2][16];
-                {
-                    float4 gq[8], zq[8];
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        const int c0 = 32 * (o >> 2) + 8 * (o & 3) + 4 * h;
-                        zq[o] = *reinterpret_cast<const float4*>(P.z + rsafe * 64 + c0);
-                        if (P.dy) gq[o] = *reinterpret_cast<const float4*>(P.dy + rsafe * P.dy_stride + c0);
-                        else gq[o] = make_float4(go[o >> 2][4 * (o & 3)], go[o >> 2][4 * (o & 3) + 1], go[o >> 2][4 * (o & 3) + 2], go[o >> 2][4 * (o & 3) + 3]);
-                    }
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) {
-                        const int c0 = 32 * (o >> 2) + 8 * (o & 3) + 4 * h;
-                        const float4 cs = *reinterpret_cast<const float4*>(&coef[0][c0]), ct = *reinterpret_cast<const float4*>(&coef[1][c0]);
-                        const float4 mu = *reinterpret_cast<const float4*>(&coef[2][c0]), k1 = *reinterpret_cast<const float4*>(&coef[3][c0]);
-                        const float4 bb = *reinterpret_cast<const float4*>(&coef[4][c0]), gg = *reinterpret_cast<const float4*>(&coef[5][c0]);
-                        const float zz[4] = {zq[o].x, zq[o].y, zq[o].z, zq[o].w}, gv[4] = {gq[o].x, gq[o].y, gq[o].z, gq[o].w};
-                        const float a_s[4] = {cs.x, cs.y, cs.z, cs.w}, a_t[4] = {ct.x, ct.y, ct.z, ct.w}, a_m[4] = {mu.x, mu.y, mu.z, mu.w};
-                        const float a_k[4] = {k1.x, k1.y, k1.z, k1.w}, a_b[4] = {bb.x, bb.y, bb.z, bb.w}, a_g[4] = {gg.x, gg.y, gg.z, gg.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float dd = !(zz[e] * a_s[e] + a_t[e] > 0.f) ? 0.f : gv[e];   // the forward's own expression
-                            const float v = a_k[e] * (dd - a_b[e] - (zz[e] - a_m[e]) * a_g[e]);
-                            dz[o >> 2][4 * (o & 3) + e] = ok ? v : 0.f;
-                        }
-                    }
-                }
-                if (!P.W) {   // the first block's leading BatchNorm: dz is the result
-                    if (ok) {
-#pragma unroll
-                        for (int o = 0; o < 8; ++o)
-                            *reinterpret_cast<float4*>(P.dz_out + (size_t)row * 64 + 32 * (o >> 2) + 8 * (o & 3) + 4 * h) =
-                                make_float4(dz[o >> 2][4 * (o & 3)], dz[o >> 2][4 * (o & 3) + 1], dz[o >> 2][4 * (o & 3) + 2], dz[o >> 2][4 * (o & 3) + 3]);
-                    }
-                } else {
-                    // ---- B fragments of dx^T = W dz^T (k-step s4: the lane's channels 16 s4 + 8 (j >> 2) + 4 h + (j & 3)); pieces -> the image ----
-                    bf16x8 zf[4][PB];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        float v[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = dz[s4 >> 1][4 * (2 * (s4 & 1) + (j >> 2)) + (j & 3)];
-                        ch_split<PB>(v, zf[s4]);
-#pragma unroll
-                        for (int pc = 0; pc < PB; ++pc) {   // row i: channels 16 s4 + 4 h .. + 3 and 16 s4 + 8 + 4 h .. + 3: 8-byte halves of chunks 2 s4, 2 s4 + 1
-                            const uint4 bits = __builtin_bit_cast(uint4, zf[s4][pc]);
-                            *reinterpret_cast<uint2*>(my + pc * CH_IMG_BYTES + ch_img_off(i, 2 * s4) + 8 * h) = make_uint2(bits.x, bits.y);
-                            *reinterpret_cast<uint2*>(my + pc * CH_IMG_BYTES + ch_img_off(i, 2 * s4 + 1) + 8 * h) = make_uint2(bits.z, bits.w);
-                        }
-                    }
-                    // x's rows are requested now (row layout: lane (i, h) channels 16 s4 + 8 h ..): they land under the dx products
-                    float xv[4][8];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) ch_ld8(P.x + rsafe * P.x_stride + 16 * s4 + 8 * h, xv[s4]);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        f32x16 acc;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            bf16x8 w[PB];
-#pragma unroll
-                            for (int pc = 0; pc < PB; ++pc) w[pc] = __builtin_bit_cast(bf16x8, Wf[mt][s4][pc][lane]);
-                            acc = ch_prod<PB>(w, zf[s4], acc);
-                        }
-                        float4 av[4], zq4[4];
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const int c0 = 32 * mt + 8 * gq + 4 * h;
-                            av[gq] = P.addend ? *reinterpret_cast<const float4*>(P.addend + rsafe * P.addend_stride + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                            zq4[gq] = P.zp ? *reinterpret_cast<const float4*>(P.zp + rsafe * 64 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        }
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const int c0 = 32 * mt + 8 * gq + 4 * h;
-                            float4 v = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
-                            if (P.addend) v.x += av[gq].x, v.y += av[gq].y, v.z += av[gq].z, v.w += av[gq].w;
-                            go[mt][4 * gq] = v.x, go[mt][4 * gq + 1] = v.y, go[mt][4 * gq + 2] = v.z, go[mt][4 * gq + 3] = v.w;
-                            if (P.out && ok) {
-                                if (P.out_wt) st_wt4(P.out + (size_t)row * 64 + c0, v);
-                                else *reinterpret_cast<float4*>(P.out + (size_t)row * 64 + c0) = v;
-                            }
-                            if (P.zp) {   // the producer's BatchNorm sums of this gradient: d1 = g [mask], d2 = g [mask] zhat -> the sum tile
-                                const float4 zq = zq4[gq];
-                                const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][c0]), qt = *reinterpret_cast<const float4*>(&pcoef[1][c0]);
-                                const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][c0]), qr = *reinterpret_cast<const float4*>(&pcoef[3][c0]);
-                                const float vv[4] = {v.x, v.y, v.z, v.w}, zz[4] = {zq.x, zq.y, zq.z, zq.w};
-                                const float a_s[4] = {qs.x, qs.y, qs.z, qs.w}, a_t[4] = {qt.x, qt.y, qt.z, qt.w};
-                                const float a_m[4] = {qm.x, qm.y, qm.z, qm.w}, a_r[4] = {qr.x, qr.y, qr.z, qr.w};
-                                float d1[4], d2[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    d1[e] = (ok && (zz[e] * a_s[e] + a_t[e] > 0.f)) ? vv[e] : 0.f;
-                                    d2[e] = d1[e] * ((zz[e] - a_m[e]) * a_r[e]);
-                                }
-                                *reinterpret_cast<float4*>(mysum + ch_sumt_word(0, i, 4 * h)) = make_float4(d1[0], d1[1], d1[2], d1[3]);
-                                *reinterpret_cast<float4*>(mysum + ch_sumt_word(1, i, 4 * h)) = make_float4(d2[0], d2[1], d2[2], d2[3]);
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                const int qn = (lane >> 3) & 1, chn = lane & 7, rgp = lane >> 4;
-                                float part = 0.f;
-#pragma unroll
-                                for (int r = 0; r < 8; ++r) part += mysum[ch_sumt_word(qn, 8 * rgp + r, chn)];   // rows in ascending order
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                part += __shfl_xor(part, 16);
-                                part += __shfl_xor(part, 32);
-                                psum[4 * mt + gq] += part;
-                            }
-                        }
-                    }
-                    // ---- dz^T: the B fragments of dW (k = rows, n = out channel), read transposed from the image ----
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    bf16x8 dzt[2][2][PB];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                            for (int pc = 0; pc < PB; ++pc) dzt[nt][s2][pc] = ch_tr_frag(my + pc * CH_IMG_BYTES, nt, s2, lane);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // ---- x (row layout) -> pieces -> image -> A fragments of dW (k = rows, m = in channel) ----
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        asm volatile("" ::: "memory");
-                        if (P.xbn.mean) {
-                            float cs[8], ct[8];
-                            ch_ld8(&xcoef[0][16 * s4 + 8 * h], cs), ch_ld8(&xcoef[1][16 * s4 + 8 * h], ct);
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) xv[s4][u] = fmaxf(xv[s4][u] * cs[u] + ct[u], 0.f);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) xv[s4][u] = ok ? xv[s4][u] : 0.f;
-                        bf16x8 p[PB];
-                        ch_split<PB>(xv[s4], p);
-                        const int o = ch_img_off(i, 2 * s4 + h);
-#pragma unroll
-                        for (int pc = 0; pc < PB; ++pc) *reinterpret_cast<u32x4*>(my + pc * CH_IMG_BYTES + o) = __builtin_bit_cast(u32x4, p[pc]);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            bf16x8 xt[PB];
-#pragma unroll
-                            for (int pc = 0; pc < PB; ++pc) xt[pc] = ch_tr_frag(my + pc * CH_IMG_BYTES, mt, s2, lane);
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt) accW[mt][nt] = ch_prod<PB>(xt, dzt[nt][s2], accW[mt][nt]);
-                        }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-            PST_STAMP();
-            // ---- the phase's end: the stores that others read have completed; the sums go out first, the dW partials meet under the wait ----
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();   // every wave is done with its image and sum tile: what follows aliases them
-            if (P.W || step != 3) {
-                float* pred = reinterpret_cast<float*>(dyn);   // [wave][2][64]
-                if (lane < 16) {
-#pragma unroll
-                    for (int o = 0; o < 8; ++o) pred[wave * 128 + ((lane >> 3) & 1) * 64 + 32 * (o >> 2) + 8 * (o & 3) + (lane & 7)] = P.zp ? psum[o] : 0.f;
-                }
-                __syncthreads();
-                post_sums_from_slots(nw);
-                __syncthreads();
-            }
-            PST_STAMP();
-            if (P.W) {
-                // the waves' dW partials meet in a fixed binary tree (absent waves left out); wave 0 stores the workgroup's
-                float (*red)[4][16][64] = reinterpret_cast<float (*)[4][16][64]>(dyn);   // [slot][tile][register][lane]
-#pragma unroll
-                for (int stp = 1; stp < 16; stp <<= 1) {
-                    if ((wave & (2 * stp - 1)) == stp) {
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) red[wave / (2 * stp)][mt * 2 + nt][r][lane] = accW[mt][nt][r];
-                    }
-                    __syncthreads();
-                    if ((wave & (2 * stp - 1)) == 0 && wave + stp < nw) {
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) accW[mt][nt][r] += red[wave / (2 * stp)][mt * 2 + nt][r][lane];
-                    }
-                    __syncthreads();
-                }
-                if (wave == 0) {
-                    float* out = P.dwpart + (size_t)cx.lb * 4096;
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) out[(32 * mt + mfma_row(r, h)) * 64 + 32 * nt + i] = accW[mt][nt][r];
-                }
-            }
-            if (next_W) pst_stage_bwd_weights<PB>(next_W, Wf);
-            PST_STAMP();
-        }
-    }
-    pst_exit(cx);
-}
-
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 static bool pst_aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 #define PST_DEFAULT_BUDGET 25000000ll   // a quarter second of the 100-MHz s_memrealtime
@@ -1196,14 +686,6 @@ static int pst_occupancy(K kernel, int threads, size_t lds) {
     return occ;
 }
 
-// dynamic LDS of the backward kernel: per wave the image pieces + the sum tile; the dW partials' parking (16 KB per parked wave, half the
-// waves in the first round); the polls' landing zone / the slot reductions (24 KB)
-static size_t pst_bwd_lds(int nw, int pb) {
-    size_t a = (size_t)nw * (pb * CH_IMG_BYTES + CH_SUMT_WORDS * 4), b = (size_t)((nw + 1) / 2) * 16384, c = PST_SCRATCH_BYTES;
-    a = a > b ? a : b;
-    return a > c ? a : c;
-}
-
 extern "C" int epc_chain_persist_ok(int rows) {
     if (rows <= 0) return 0;
     const int wg_rows = pst_wg_rows(rows), nw = wg_rows / 32, parts = epc_chain_parts(rows);
@@ -1214,8 +696,7 @@ extern "C" int epc_chain_persist_ok(int rows) {
     static int cached[PST_WAVES + 1] = {0};   // 0: unknown, 1: fits, 2: does not (per wave count; a racing first call writes the same value)
     if (cached[nw] == 0) {
         const int o1 = pst_occupancy(chain_fwd_persist_kernel<1>, 64 * nw, lds), o3 = pst_occupancy(chain_fwd_persist_kernel<3>, 64 * nw, lds);
-        const int b1 = pst_occupancy(chain_bwd_persist_kernel<1>, 64 * nw, pst_bwd_lds(nw, 1)), b2 = pst_occupancy(chain_bwd_persist_kernel<2>, 64 * nw, pst_bwd_lds(nw, 2));
-        cached[nw] = (o1 >= 1 && o3 >= 1 && b1 >= 1 && b2 >= 1) ? 1 : 2;
+        cached[nw] = (o1 >= 1 && o3 >= 1) ? 1 : 2;
     }
     return cached[nw] == 1 && parts <= cus;
 }
@@ -1253,44 +734,6 @@ extern "C" int epc_chain_fwd_persist(const epc_chain_fwd_args* a, int pieces, vo
     const size_t lds = (size_t)nw * PST_TILE_BYTES;
     if (pieces == 3) hipLaunchKernelGGL(chain_fwd_persist_kernel<3>, grid, block, lds, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(chain_fwd_persist_kernel<1>, grid, block, lds, (hipStream_t)stream, g);
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
-}
-
-extern "C" int epc_chain_bwd_persist(const epc_chain_bwd_args* a, int pieces, void* stream) {
-    EPC_CHECK_ARG(a && a->nblocks >= 1 && a->nblocks <= EPC_CHAIN_MAX_BLOCKS, "null descriptor / 1 .. 4 blocks");
-    EPC_CHECK_ARG(pieces == 2 || pieces == 1, "pieces: 2 or 1");
-    EPC_CHECK_ARG(a->cat && a->dcat && a->rdeg && a->roff && a->rlist && a->ovf_cnt && a->ovf_list && a->xyz && a->kth && a->dx && a->dz01 && a->workspace,
-                  "null pointer");
-    EPC_CHECK_ARG(a->nblocks == 1 || a->g, "g: the scratch tensor of the gradient handed from block to block");
-    EPC_CHECK_ARG(a->num_clouds > 0 && a->n > 0 && a->knn > 0, "bad shape");
-    EPC_CHECK_ARG((long)a->num_clouds * a->n < (1L << 31) / 64, "too many rows");
-    const int rows = a->num_clouds * a->n;
-    EPC_CHECK_ARG(epc_chain_persist_ok(rows), "rows not covered by the persistent chain (epc_chain_persist_ok)");
-    EPC_CHECK_ARG(epc_chain_parts(rows) <= PST_MAX_PARTS && 4 * a->nblocks <= PST_MAX_PHASES, "grid / phase count beyond the workspace layout");
-    EPC_CHECK_ARG(pst_aligned16(a->cat) && pst_aligned16(a->dcat) && pst_aligned16(a->dx) && pst_aligned16(a->g) && pst_aligned16(a->dz01) && pst_aligned16(a->workspace),
-                  "tensors must be 16-byte aligned");
-    for (int b = 0; b < a->nblocks; ++b) {
-        const epc_chain_bwd_block& B = a->blk[b];
-        EPC_CHECK_ARG(B.gamma0 && B.beta0 && B.mean0 && B.var0 && B.Wa && B.gamma_a && B.beta_a && B.mean_a && B.var_a && B.Wb && B.gamma_b && B.beta_b &&
-                          B.mean_b && B.var_b && B.z0 && B.d && B.za && B.zb && B.dgamma0 && B.dbeta0 && B.dgamma_a && B.dbeta_a && B.dgamma_b && B.dbeta_b &&
-                          B.dwa_partials && B.dwb_partials && B.s,
-                      "null pointer in a block");
-        EPC_CHECK_ARG(b == 0 ? (!B.W0 && !B.dw0_partials) : (B.W0 && B.dw0_partials), "W0 / dw0_partials: both in every block but the first");
-        EPC_CHECK_ARG(pst_aligned16(B.z0) && pst_aligned16(B.d) && pst_aligned16(B.za) && pst_aligned16(B.zb) && pst_aligned16(B.s) && pst_aligned16(B.W0) &&
-                          pst_aligned16(B.Wa) && pst_aligned16(B.Wb),
-                      "tensors must be 16-byte aligned");
-        for (int c = 0; c < b; ++c) EPC_CHECK_ARG(a->blk[c].s != B.s, "s: one tensor per block (written once per launch)");
-    }
-    PstBwdArgs g;
-    g.a = *a;
-    g.rows = rows, g.wg_rows = pst_wg_rows(rows), g.width = 64 * a->nblocks, g.kdiv = (float)a->knn;
-    g.budget = a->spin_ticks > 0 ? a->spin_ticks : PST_DEFAULT_BUDGET;
-    const int nw = g.wg_rows / 32;
-    const dim3 grid(epc_chain_parts(rows)), block(64 * nw);
-    const size_t lds = pst_bwd_lds(nw, pieces);
-    if (pieces == 2) hipLaunchKernelGGL(chain_bwd_persist_kernel<2>, grid, block, lds, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(chain_bwd_persist_kernel<1>, grid, block, lds, (hipStream_t)stream, g);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

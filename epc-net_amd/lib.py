@@ -51,7 +51,7 @@ EXPORTS = [
     "epc_assign_softmax_fwd", "epc_assign_softmax_bwd", "epc_gate_fwd",
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
-    "epc_chain_persist_ok", "epc_chain_persist_workspace_bytes", "epc_chain_persist_init", "epc_chain_fwd_persist", "epc_chain_bwd_persist", "epc_chain_persist_status", "epc_chain_persist_reset",
+    "epc_chain_persist_ok", "epc_chain_persist_workspace_bytes", "epc_chain_persist_init", "epc_chain_fwd_persist", "epc_chain_persist_status", "epc_chain_persist_reset",
     "epc_vlad_df_packed_bytes", "epc_vlad_df", "epc_vlad_df_tail_partial_floats", "epc_vlad_df_tail", "epc_bn_apply_bwd_given", "epc_gate_bwd", "epc_sq_err_partial_floats", "epc_sq_err_fwd", "epc_sq_err_bwd", "epc_adam_step", "epc_adam_step_dev", "epc_ema_update", "epc_adam_multi", "epc_ema_multi", "epc_crc32c",
     "epc_h16_conv5_fwd_scratch_bytes", "epc_h16_conv5_fwd", "epc_h16_assign_scratch_bytes", "epc_h16_assign",
     "epc_h16_colgemm_scratch_bytes", "epc_h16_colgemm", "epc_h16_df_tail_scratch_bytes", "epc_h16_df_tail", "epc_h16_bn_bwd_apply",
@@ -207,23 +207,6 @@ class ChainFwdArgs(ctypes.Structure):
                 ("workspace", _P), ("spin_ticks", ctypes.c_longlong)]
 
 
-class ChainBwdBlock(ctypes.Structure):
-    """``struct epc_chain_bwd_block`` of include/epcnet.h."""
-    _fields_ = [(n, _P) for n in ("W0", "gamma0", "beta0", "mean0", "var0", "Wa", "gamma_a", "beta_a", "mean_a", "var_a",
-                                  "Wb", "gamma_b", "beta_b", "mean_b", "var_b", "z0", "d", "za", "zb",
-                                  "dgamma0", "dbeta0", "dgamma_a", "dbeta_a", "dgamma_b", "dbeta_b",
-                                  "dw0_partials", "dwa_partials", "dwb_partials", "s")]
-
-
-class ChainBwdArgs(ctypes.Structure):
-    """``struct epc_chain_bwd_args`` of include/epcnet.h."""
-    _fields_ = [("blk", ChainBwdBlock * EPC_CHAIN_MAX_BLOCKS), ("nblocks", c_int), ("cat", _P), ("dcat", _P), ("rdeg", _P), ("roff", _P),
-                ("rlist", _P), ("ovf_cnt", _P), ("ovf_list", _P), ("xyz", _P), ("kth", _P), ("num_clouds", c_int), ("n", c_int),
-                ("knn", c_int), ("dx", _P), ("g", _P), ("dz01", _P), ("eps", c_float), ("workspace", _P),
-                ("spin_ticks", ctypes.c_longlong)]
-
-
-_lib.epc_chain_bwd_persist.argtypes = [POINTER(ChainBwdArgs), c_int, _P]
 _lib.epc_chain_persist_ok.argtypes = [c_int]
 _lib.epc_chain_persist_workspace_bytes.restype = c_size_t
 _lib.epc_chain_persist_workspace_bytes.argtypes = []

@@ -609,11 +609,11 @@ class ProxyConvTail(torch.autograd.Function):
         return dx, None, None, dWa, None, dga, dbta, dWb, None, dgb, dbtb, None
 
 
-# The backbone chain as ONE persistent launch each way (csrc/train_chain_persist.hip: grid-wide barriers instead of kernel boundaries).
-# "auto": whenever the library covers the row count (epc_chain_persist_ok) and nothing that waits for the chain shares the device
-# with it; training.TrainStep switches the BACKWARD to the launches while a collective runs beside it (DP_OVERLAP).
+# The backbone chain's FORWARD as one persistent launch (csrc/train_chain_persist.hip: grid-wide barriers instead of kernel boundaries)
+# whenever the library covers the row count (epc_chain_persist_ok); the backward stays the launch chain (its persistent form was
+# built, was parity-green and measured slower: DESIGN.md 4).  Nothing runs beside the forward in the step (the data-parallel step's
+# collectives overlap the BACKWARD), so no kernel that waits for it shares the device with it.
 CHAIN_PERSIST_FWD = True
-CHAIN_PERSIST_BWD = True
 CHAIN_SPIN_TICKS = 0          # spin budget of a grid barrier in 10-ns ticks; 0: the library's default (a quarter second)
 _CHAIN_WS = {}
 
@@ -809,52 +809,6 @@ class ProxyConvChain(torch.autograd.Function):
         ovc, ovl = g.overflow()
         grads = [None] * ctx.n_params
         at_of = lambda b: 0 if b == 0 else 10 + 12 * (b - 1)          # index of block b's first parameter in `params`
-        if CHAIN_PERSIST_BWD and nb <= L.EPC_CHAIN_MAX_BLOCKS and lib.epc_chain_persist_ok(rows):
-            # the whole backward as one launch (epc_chain_bwd_persist) + the sum of the dW partials
-            a = L.ChainBwdArgs()
-            a.nblocks = nb
-            a.cat, a.dcat = cat.data_ptr(), dcat.data_ptr()
-            a.rdeg, a.roff, a.rlist, a.ovf_cnt, a.ovf_list = (t.data_ptr() for t in (rdeg, roff, rlist, ovc, ovl))
-            a.xyz, a.kth, a.num_clouds, a.n, a.knn = g.xyz.data_ptr(), g.kth.data_ptr(), g.num_clouds, g.n, k
-            dxs, gs, dz01 = new(), (new() if nb > 1 else None), new()
-            a.dx, a.g, a.dz01, a.eps = dxs.data_ptr(), (gs.data_ptr() if gs is not None else None), dz01.data_ptr(), eps
-            a.workspace, a.spin_ticks = chain_workspace(dev).data_ptr(), int(CHAIN_SPIN_TICKS)
-            keep = []
-            for b in range(nb - 1, -1, -1):                           # (the dW partials in the launch chain's layer order)
-                z0, d, za, zb, m0, v0, ma, va, mb, vb = per[b]
-                W0, b0, g0, bt0, Wa, ba, ga, bta, Wb, bb, gb, btb = blocks[b]
-                B = a.blk[b]
-                B.W0 = W0.data_ptr() if b > 0 else None
-                B.gamma0, B.beta0, B.mean0, B.var0 = g0.data_ptr(), bt0.data_ptr(), m0.data_ptr(), v0.data_ptr()
-                B.Wa, B.gamma_a, B.beta_a, B.mean_a, B.var_a = Wa.data_ptr(), ga.data_ptr(), bta.data_ptr(), ma.data_ptr(), va.data_ptr()
-                B.Wb, B.gamma_b, B.beta_b, B.mean_b, B.var_b = Wb.data_ptr(), gb.data_ptr(), btb.data_ptr(), mb.data_ptr(), vb.data_ptr()
-                B.z0, B.d, B.za, B.zb = z0.data_ptr(), d.data_ptr(), za.data_ptr(), zb.data_ptr()
-                dg0, dbt0, dga, dbta, dgb, dbtb, s_ = vec(), vec(), vec(), vec(), vec(), vec(), new()
-                B.dgamma0, B.dbeta0, B.dgamma_a, B.dbeta_a, B.dgamma_b, B.dbeta_b = (t.data_ptr() for t in (dg0, dbt0, dga, dbta, dgb, dbtb))
-                B.s = s_.data_ptr()
-                keep.append(s_)
-                base = at_of(b) + (2 if b == 0 else 4)
-                dWb, dWa = torch.empty_like(Wb), torch.empty_like(Wa)
-                B.dwb_partials, B.dwa_partials = parts[layer_at].data_ptr(), parts[layer_at + 1].data_ptr()
-                layer_dw += [dWb, dWa]
-                layer_at += 2
-                grads[base + 4], grads[base + 6], grads[base + 7] = dWb, dgb, dbtb
-                grads[base + 0], grads[base + 2], grads[base + 3] = dWa, dga, dbta
-                if b > 0:
-                    dW0 = torch.empty_like(W0)
-                    B.dw0_partials = parts[layer_at].data_ptr()
-                    layer_dw.append(dW0)
-                    layer_at += 1
-                    a0 = at_of(b)
-                    grads[a0 + 0], grads[a0 + 2], grads[a0 + 3] = dW0, dg0, dbt0
-                else:
-                    B.dw0_partials = None
-                    grads[0], grads[1] = dg0, dbt0
-            L.check(lib.epc_chain_bwd_persist(ctypes.byref(a), pc, _st()))
-            pa = (ctypes.c_void_p * n_layers)(*[parts[l].data_ptr() for l in range(n_layers)])
-            pw = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in layer_dw])
-            L.check(lib.epc_chain_dw_sum(n_layers, pa, pw, rows, _st()))
-            return (dz01 if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(grads)
         z_b, m_b, v_b = per[nb - 1][3], per[nb - 1][8], per[nb - 1][9]
         sums_b = sums()
         last = dcat.data_ptr() + 4 * 64 * (nb - 1)

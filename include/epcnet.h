@@ -562,7 +562,7 @@ int epc_chain_sums(const float* dy, int dy_stride, const float* z, const float* 
 int epc_chain_bn_bwd(const float* dy, const float* z, const float* mean, const float* var, const float* gamma, const float* beta,
                      float eps, const float* sums, float* dgamma, float* dbeta, int rows, float* dz, void* stream);
 int epc_chain_dw_sum(int layers, const float* const* partials, float* const* dW, int rows, void* stream);
-/* ---- The same backbone as ONE persistent launch each way (csrc/train_chain_persist.hip) -----------------------------------------
+/* ---- The same backbone's FORWARD as ONE persistent launch (csrc/train_chain_persist.hip) -----------------------------------------
  * One workgroup per CU keeps its rows for the whole pass (a wave owns one 32-row tile; the tile handed to the next layer stays in
  * LDS) and every training-mode BatchNorm costs a grid-wide BARRIER instead of a kernel boundary; the batch moments are reduced in
  * two levels on the way through it.  Same arithmetic, operands and outputs as the launches above (the statistics' summation order
@@ -598,38 +598,6 @@ typedef struct epc_chain_fwd_args {
     void* workspace;
     long long spin_ticks;
 } epc_chain_fwd_args;
-/* The backward of the same chain as one launch (csrc/train_chain_persist.hip): per block, last to first,
- *   conv_b's layer + BatchNorm backward -> conv_a's (its dx + the block's output gradient = s, written for the other workgroups) ->
- *   the gather's transpose over epc_knn_transpose's lists (+ the overflow lists) -> the leading conv's layer (its dx + the concat's
- *   gradient of the previous slice = the previous block's output gradient)
- * with the gradient handed from layer to layer in REGISTERS and a barrier (carrying the next BatchNorm's two column sums) where
- * epc_chain_bwd_linear / _gather have a kernel boundary.  Leaves every layer's dgamma / dbeta, the workgroups' dW partials
- * ([epc_chain_parts(rows)][64][64] per layer: epc_chain_dw_sum adds them) and dz01, the gradient of the first block's leading
- * pre-activation.  s: one (rows, 64) scratch tensor PER BLOCK (written once per launch); dx, g: one each for the whole chain. */
-typedef struct epc_chain_bwd_block {
-    const float *W0, *gamma0, *beta0, *mean0, *var0;   /* W0 NULL in the first block (conv1 keeps its own kernels) */
-    const float *Wa, *gamma_a, *beta_a, *mean_a, *var_a;
-    const float *Wb, *gamma_b, *beta_b, *mean_b, *var_b;
-    const float *z0, *d, *za, *zb;                     /* saved by the forward */
-    float *dgamma0, *dbeta0, *dgamma_a, *dbeta_a, *dgamma_b, *dbeta_b;
-    float *dw0_partials, *dwa_partials, *dwb_partials; /* dw0 NULL in the first block */
-    float* s;                                          /* scratch (rows, 64) */
-} epc_chain_bwd_block;
-typedef struct epc_chain_bwd_args {
-    epc_chain_bwd_block blk[EPC_CHAIN_MAX_BLOCKS];
-    int nblocks;
-    const float* cat;              /* (rows, 64 nblocks): the forward's output; */
-    const float* dcat;             /* its gradient */
-    const int32_t *rdeg, *roff, *rlist, *ovf_cnt, *ovf_list;
-    const float *xyz, *kth;
-    int num_clouds, n, knn;
-    float *dx, *g;                 /* scratch (rows, 64) each */
-    float* dz01;                   /* out (rows, 64) */
-    float eps;
-    void* workspace;
-    long long spin_ticks;
-} epc_chain_bwd_args;
-int epc_chain_bwd_persist(const epc_chain_bwd_args* a, int pieces, void* stream);
 int epc_chain_persist_ok(int rows);
 size_t epc_chain_persist_workspace_bytes(void);
 int epc_chain_persist_init(void* workspace, void* stream);

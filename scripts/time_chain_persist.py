@@ -46,10 +46,8 @@ def timeit(label):
     print("%-28s %s %dx%d %s: %.1f us per %s (eager, includes host launch gaps)" % (label, arch, ncl, n, prec, best * 1e3, "fwd+bwd" if bwd else "fwd"))
 
 outs = {}
-for label, f, b in (("launch chain", False, False), ("persistent fwd", True, False), ("persistent fwd+bwd", True, True)):
-    if b and not (bwd and hasattr(L.lib(), "epc_chain_bwd_persist")):
-        continue
-    ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD = f, b
+for label, f in (("launch chain", False), ("persistent fwd", True)):
+    ops.CHAIN_PERSIST_FWD = f
     outs[label] = run().detach().float().cpu().numpy()
     ops.chain_persist_check()
     timeit(label)
@@ -57,10 +55,8 @@ ref = outs["launch chain"]
 for k, v in outs.items():
     print("%-28s max |cat - launch chain| = %.3e (scale %.3e), rel L2 %.3e" % (k, np.abs(v - ref).max(), np.abs(ref).max(), np.linalg.norm(v - ref) / np.linalg.norm(ref)))
 
-if os.environ.get("STAMPS", "0") in ("1", "bwd"):      # needs a -DPST_STAMPS build of the library (scripts/build_variant.sh, EPCNET_LIB=...)
-    which = os.environ["STAMPS"]
-    ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD = True, which == "bwd"
-    bwd = which == "bwd"
+if os.environ.get("STAMPS", "0") == "1":      # needs a -DPST_STAMPS build of the library (scripts/build_variant.sh, EPCNET_LIB=...)
+    ops.CHAIN_PERSIST_FWD = True
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -72,17 +68,10 @@ if os.environ.get("STAMPS", "0") in ("1", "bwd"):      # needs a -DPST_STAMPS bu
     nst = int((st_[0] != 0).sum())
     t0 = st_[:, 0].min()
     names = ["start", "S done"]
-    if not bwd:
-        for b in range(nb):
-            names += ["b%d reduced0" % b, "b%d gathered0" % b, "b%d pooled0" % b, "b%d G done" % b, "b%d posted_a" % b,
-                      "b%d reduced_a" % b, "b%d gathered_a" % b, "b%d pooled_a" % b, "b%d M done" % b, "b%d posted_b" % b,
-                      "b%d reduced_b" % b, "b%d gathered_b" % b, "b%d pooled_b" % b, "b%d H done" % b, "b%d posted0'" % b]
-    else:
-        for b in range(nb - 1, -1, -1):
-            for ph in ("CB", "CA"):
-                names += ["b%d %s barrier" % (b, ph), "b%d %s compute" % (b, ph), "b%d %s posted" % (b, ph), "b%d %s dW+stage" % (b, ph)]
-            names += ["b%d GT barrier" % b, "b%d GT compute" % b, "b%d GT posted" % b]
-            names += ["b%d C0 barrier" % b, "b%d C0 compute" % b, "b%d C0 posted" % b, "b%d C0 dW+stage" % b]
+    for b in range(nb):
+        names += ["b%d reduced0" % b, "b%d gathered0" % b, "b%d pooled0" % b, "b%d G done" % b, "b%d posted_a" % b,
+                  "b%d reduced_a" % b, "b%d gathered_a" % b, "b%d pooled_a" % b, "b%d M done" % b, "b%d posted_b" % b,
+                  "b%d reduced_b" % b, "b%d gathered_b" % b, "b%d pooled_b" % b, "b%d H done" % b, "b%d posted0'" % b]
     print("stamp (10-ns ticks -> us): min / median / max over %d workgroups, relative to the earliest start; delta of medians; [leaders' median]" % P)
     prev = 0.0
     for k in range(nst):

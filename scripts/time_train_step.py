@@ -11,9 +11,8 @@ TR = bench.pkg("training")
 params = dict(bench.PARAMS, ARCH=arch, TRAIN_PRECISION=os.environ.get("PRECISION", "bf16x6"), BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5, MARGIN_2=0.2)
 if os.environ.get("ASSIGN_F16X3", "1") == "0":      # A/B: the assignment product in the six-product bf16 form instead of f16x3
     bench.pkg("ops").F16X3_ASSIGN = None
-if "PERSIST" in os.environ:                          # A/B: the backbone chain as persistent launches (1) or as the launch chain (0); "10": forward only
-    v = os.environ["PERSIST"]
-    bench.pkg("ops").CHAIN_PERSIST_FWD, bench.pkg("ops").CHAIN_PERSIST_BWD = v[0] == "1", v[-1] == "1"
+if "PERSIST" in os.environ:                          # A/B: the backbone chain as persistent launches (1) or as the launch chain (0); 
+    bench.pkg("ops").CHAIN_PERSIST_FWD = os.environ["PERSIST"][0] == "1"
 ts = TR.TrainStep(params, store, outer=bench.OUTER)
 g = torch.Generator().manual_seed(0)
 mk = lambda p: (torch.rand((1, p, 4096, 3), generator=g) * 2 - 1).to(dev)

@@ -1,4 +1,4 @@
-"""GPU tests of the PERSISTENT backbone chain (csrc/train_chain_persist.hip: one launch each way, grid-wide barriers instead of
+"""GPU tests of the PERSISTENT forward of the backbone chain (csrc/train_chain_persist.hip: one launch, grid-wide barriers instead of
 kernel boundaries; models/epc-net.py:66-134 in training mode) against the launch chain it replaces (csrc/train_chain.hip) -- the same
 products in the same arithmetic on the same operands; only the summation order of the batch statistics differs (group partials by row
 range instead of sixteen strided slices)."""
@@ -26,14 +26,14 @@ def dev():
 
 def _with_persist(on, fn):
     ops = H.pkg("ops")
-    prev = ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD
-    ops.CHAIN_PERSIST_FWD = ops.CHAIN_PERSIST_BWD = on
+    prev = ops.CHAIN_PERSIST_FWD
+    ops.CHAIN_PERSIST_FWD = on
     try:
         out = fn()
         ops.chain_persist_check()
         return out
     finally:
-        ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD = prev
+        ops.CHAIN_PERSIST_FWD = prev
 
 
 def test_first_launch_in_a_child_process():
@@ -49,10 +49,10 @@ ops = H.pkg("ops")
 dev = torch.device("cuda:0")
 assert H.pkg("lib").lib().epc_chain_persist_ok(4 * 256) == 1
 w = O.seeded_weights("epc-net", 4); pc = O.synthetic_clouds(4, 256, 5)
-ops.CHAIN_PERSIST_FWD = ops.CHAIN_PERSIST_BWD = True
+ops.CHAIN_PERSIST_FWD = True
 a = _backbone("epc-net", w, pc, dev, True)
 ops.chain_persist_check()
-ops.CHAIN_PERSIST_FWD = ops.CHAIN_PERSIST_BWD = False
+ops.CHAIN_PERSIST_FWD = False
 b = _backbone("epc-net", w, pc, dev, True)
 print("max diff", float(np.abs(a[0] - b[0]).max()))
 assert np.isfinite(a[0]).all() and np.abs(a[0] - b[0]).max() <= 1e-5 * max(np.abs(b[0]).max(), 1.0)
@@ -135,9 +135,9 @@ def test_abandoned_barrier_is_reported_not_hung(dev):
     pc = O.synthetic_clouds(18, 4096, 5)
     ws = ops.chain_workspace(dev)
     words = ws.view(torch.int32)
-    prev_ticks, prev_flags = ops.CHAIN_SPIN_TICKS, (ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD)
+    prev_ticks, prev_flags = ops.CHAIN_SPIN_TICKS, ops.CHAIN_PERSIST_FWD
     try:
-        ops.CHAIN_PERSIST_FWD = ops.CHAIN_PERSIST_BWD = True
+        ops.CHAIN_PERSIST_FWD = True
         ops.CHAIN_SPIN_TICKS = 1
         _backbone("epc-net", w, pc, dev, True)
         torch.cuda.synchronize()
@@ -153,9 +153,9 @@ def test_abandoned_barrier_is_reported_not_hung(dev):
         assert int(words[2112]) == 0 and int(words[2048]) == 0 and int(words[0]) == seq + 1
         a = _backbone("epc-net", w, pc, dev, True)
         ops.chain_persist_check()
-        ops.CHAIN_PERSIST_FWD = ops.CHAIN_PERSIST_BWD = False
+        ops.CHAIN_PERSIST_FWD = False
         b = _backbone("epc-net", w, pc, dev, True)
         assert np.isfinite(a[0]).all() and np.abs(a[0] - b[0]).max() <= 5e-5 * np.abs(b[0]).max()
     finally:
         ops.CHAIN_SPIN_TICKS = prev_ticks
-        ops.CHAIN_PERSIST_FWD, ops.CHAIN_PERSIST_BWD = prev_flags
+        ops.CHAIN_PERSIST_FWD = prev_flags
