@@ -717,14 +717,29 @@ def main():
                 "knn_bound": "VALU issue: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs (counters: 0.98 of the kernel's cycles)",
                 "block_floor_ms_each": round((4 * 1.34e9 / (256 * 64) / (VALU_GHZ * 1e9) + 4 * 0.020e-3) * 1e3, 4),
                 "block_bound": "vector L1: 20 gathered 256-byte rows per point at 64 B/clk/CU, plus the skeleton (as EPC-Net's blocks)"}
-            # the one thing not measured before at this size: the same 256 clouds as two 128-cloud halves in flight on
-            # two HIP streams (kNN of one half beside the blocks / conv5 of the other); descriptors bit-identical (checked by the leg)
-            half, _ = extraction_leg(H, E, stl, "epc-net-l", "f32", 128, max(10, min(50, args.steps)), 4, 0.0, every, 2)
-            if "overlapped" in half:
-                ov = half["overlapped"]
-                leg["halves_overlapped"] = {"value": ov["value"], "unit": "clouds/s", "ms_per_256_clouds": round(2 * ov["ms_per_step"], 4),
-                                            "gain_over_one_stream": round(ov["value"] / leg["value"], 4),
-                                            "how": "two 128-cloud steps in flight (InferenceEngine.submit), same kernels, same results"}
+            # InferenceEngine.forward's DEFAULT for EPC-Net-L at this size: the 256 clouds as two 128-cloud halves in flight on two HIP
+            # streams (the VALU-bound kNN of one half beside the L1-bound blocks / the matrix-bound conv5 of the other; engine.L_HALVES_FROM),
+            # bit-identical descriptors (checked here).  `value` is THAT rate; the one-stream figures above it (stage_ms, roofline: the
+            # kernels measured alone on the chip) stay under `one_stream`.
+            import torch
+            eng = E.InferenceEngine("epc-net-l", PARAMS, stl, outer=OUTER)
+            ref = E.InferenceEngine("epc-net-l", PARAMS, stl, outer=OUTER, micro_batch=256, in_flight=1)
+            g = torch.Generator(device="cpu")
+            g.manual_seed(100 + H.rank)
+            xyz = (torch.rand((256, N_POINTS, 3), generator=g) * 2.0 - 1.0).to(device)
+            out = torch.empty((256, 256), dtype=torch.float32, device=device)
+            ksteps = max(10, min(50, args.steps))
+            for _ in range(4):
+                eng.forward(xyz, out=out, check=False)
+            el = median(H.timed_regions(lambda r, k: eng.forward(xyz, out=out, check=False), ksteps, 3))
+            if not torch.equal(out, ref.forward(xyz)):
+                raise SystemExit("EPC-Net-L: the two-halves pass disagrees with the one-stream descriptors: refusing to report a number")
+            leg["one_stream"] = {"value": leg["value"], "ms_per_step": leg["ms_per_step"], "regions": leg.pop("regions")}
+            leg["value"], leg["ms_per_step"] = round(H.world * 256 * ksteps / el, 2), round(el / ksteps * 1e3, 4)
+            leg["pipeline_tflops"] = round(256 * ksteps / el * FLOPS_PER_CLOUD["epc-net-l"] / 1e12, 3)
+            leg["how"] = ("InferenceEngine.forward's default for EPC-Net-L at >= 256 clouds: two 128-cloud halves in flight on two HIP streams, "
+                          "same kernels, bit-identical descriptors; median of 3 regions of %d steps" % ksteps)
+            leg["gain_over_one_stream"] = round(leg["value"] / leg["one_stream"]["value"], 4)
             return leg
         guarded("epc_net_l_b256", l_leg)
         guarded("retrieval", lambda: retrieval_leg(H, E, steps=3, warmup=1, rccl=rccl))

@@ -152,8 +152,14 @@ struct HxBnb {           // the BatchNorm backward fused into dcat's product (BN
     TA* dz_out;          // (rows, 1024)
 };
 
+// The streamed operand's pointer: restrict-qualified unless the kernel writes THROUGH an alias of it -- BNB's dz_out may be du itself
+// (every lane rewrites exactly the bytes it read, one chunk after it has consumed them: the in-place contract of epc_h16/h32_conv5_dx_bn),
+// and a store through an alias of a restrict pointer would let the compiler move a later load of A above it.
+template <typename TA, bool RESTRICT> struct HxAPtr { typedef const TA* __restrict__ type; };
+template <typename TA> struct HxAPtr<TA, false> { typedef const TA* type; };
+
 template <int NT, bool XFORM, typename TA, int P, int KSC, bool BNB = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(const TA* __restrict__ A, int n_points, const u32x4* __restrict__ Bp,
+__global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(typename HxAPtr<TA, !BNB>::type A, int n_points, const u32x4* __restrict__ Bp,
                                                             long b_cloud_stride_u4, H16Bn bn, float* __restrict__ out,
                                                             float* __restrict__ rn_out, float* __restrict__ stats, HxBnb<TA> bnb) {
     static_assert(!(BNB && XFORM), "one transformation of the streamed operand at a time");

@@ -2530,36 +2530,6 @@ extern "C" int epc_neighbour_mean_diff_fwd(const float* x, const float* xyz, con
     return EPC_OK;
 }
 
-// Scatter form: one wave per point, lane = channel, so every atomic wave-instruction adds 256 contiguous bytes (the
-// shape the f32 atomic units take at full rate; 16-byte pieces run several times slower).
-__global__ __launch_bounds__(256) void neighbour_scatter_kernel(const float* __restrict__ dxm, const float* __restrict__ xyz,
-                                                                const int32_t* __restrict__ idx,
-                                                                const int32_t* __restrict__ cnt,
-                                                                const float* __restrict__ kth, int cap, int total_points,
-                                                                int n, float kdiv, float* __restrict__ dx) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (g >= total_points) return;
-    const int cloud_base = (g / n) * n;
-    const float v = dxm[(size_t)g * 64 + lane] / kdiv;
-    const int c = cnt[g];
-    if (c <= cap) {
-        const int mine = lane < c ? idx[(size_t)g * cap + lane] : 0;  // cap <= 64: one list entry per lane
-        for (int m = 0; m < c; ++m) {
-            const int j = __shfl(mine, m);
-            atomicAdd(dx + (size_t)(cloud_base + j) * 64 + lane, v);
-        }
-    } else {
-        const float* pc = xyz + (size_t)cloud_base * 3;
-        const int i = g - cloud_base;
-        const float xi = pc[3 * i], yi = pc[3 * i + 1], zi = pc[3 * i + 2];
-        const float sqi = sq3(xi, yi, zi), kv = kth[g];
-        for (int j = 0; j < n; ++j) {
-            const float xj = pc[3 * j], yj = pc[3 * j + 1], zj = pc[3 * j + 2];
-            if (neg_sq_dist(sqi, xi, yi, zi, xj, yj, zj, sq3(xj, yj, zj)) >= kv)
-                atomicAdd(dx + (size_t)(cloud_base + j) * 64 + lane, v);
-        }
-    }
-}
 
 // ---- transposed graph: for every point j the list of points i whose neighbour list holds j ----------------------------
 // The scatter above is bound by the f32 atomic rate (20 x 256-B atomics per point, 4 times per step); the graph is the
@@ -2805,19 +2775,6 @@ extern "C" int epc_neighbour_mean_diff_bwd_gather_sum(const float* s, const floa
     return EPC_OK;
 }
 
-// dx[j] += sum_{i : j in nbr(i)} dxm[i] / k.  dx must be zero-initialised (or hold the other gradient path).
-extern "C" int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
-                                      const float* kth, int cap, int num_clouds, int n, int knn, float* dx,
-                                      void* stream) {
-    EPC_CHECK_ARG(dxm && xyz && idx && cnt && kth && dx, "null pointer");
-    EPC_CHECK_ARG(num_clouds > 0 && n > 0 && knn > 0 && cap >= EPC_KNN_SELECT && cap <= 64, "bad shape");
-    const long total = (long)num_clouds * n;
-    hipLaunchKernelGGL(neighbour_scatter_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dxm,
-                       xyz, idx, cnt, kth, cap, (int)total, n, (float)knn, dx);
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 // Row L2 normalisation (tf.nn.l2_normalize, eps 1e-12) over C channels: one wave per row.
 //   fwd: y = x * rn, rn = rsqrt(max(sum x^2, eps));  bwd: dx = rn * (dy - y * sum(dy*y))   (0 where the clamp is active)
@@ -2964,32 +2921,10 @@ extern "C" int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// a_sum[b][c] = sum over the cloud's points of a[b][n][c] (loupe.py:276), 64 columns.  CS_SEG segments per cloud, each one
-// workgroup: thread (column, quarter) adds its rows in order, the four quarters are added in order, and the second kernel
-// adds the CS_SEG partial sums in order -- the same bits every run.
+// a_sum[b][c] = sum over the cloud's points of a[b][n][c] (loupe.py:276), 64 columns: CS_SEG segments per cloud leave partial sums (the
+// fused soft-assignment forward below), the finish kernel adds them in order -- the same bits every run.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int CS_SEG = 16;
-
-__global__ __launch_bounds__(256) void cloud_colsum64_partial_kernel(const float* __restrict__ a, int n_points,
-                                                                     float* __restrict__ part) {
-    __shared__ float red[4][64];
-    const int seg = blockIdx.x, b = blockIdx.y, col = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int len = (n_points + CS_SEG - 1) / CS_SEG;
-    const int r0 = seg * len, r1 = min(n_points, r0 + len);
-    const float* src = a + (size_t)b * n_points * 64 + col;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = r0 + q;
-    for (; r + 12 < r1; r += 16) {
-        s0 += src[(size_t)r * 64];
-        s1 += src[(size_t)(r + 4) * 64];
-        s2 += src[(size_t)(r + 8) * 64];
-        s3 += src[(size_t)(r + 12) * 64];
-    }
-    for (; r < r1; r += 4) s0 += src[(size_t)r * 64];
-    red[q][col] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (q == 0) part[((size_t)b * CS_SEG + seg) * 64 + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-}
 
 __global__ void cloud_colsum64_finish_kernel(const float* __restrict__ part, int total, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3002,19 +2937,6 @@ __global__ void cloud_colsum64_finish_kernel(const float* __restrict__ part, int
 }
 
 extern "C" size_t epc_cloud_colsum64_partial_floats(int num_clouds) { return (size_t)max(num_clouds, 0) * CS_SEG * 64; }
-
-extern "C" int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out, float* partials,
-                                  size_t partial_floats, void* stream) {
-    EPC_CHECK_ARG(a && out && partials && num_clouds > 0 && n_points > 0, "bad argument");
-    EPC_CHECK_ARG(partial_floats >= epc_cloud_colsum64_partial_floats(num_clouds), "partials buffer too small");
-    hipLaunchKernelGGL(cloud_colsum64_partial_kernel, dim3(CS_SEG, num_clouds), dim3(256), 0, (hipStream_t)stream, a, n_points,
-                       partials);
-    const int total = num_clouds * 64;
-    hipLaunchKernelGGL(cloud_colsum64_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials,
-                       total, out);
-    EPC_CHECK_LAUNCH();
-    return EPC_OK;
-}
 
 // ----------------------------------------------------------------------------------------------------------------
 // The soft assignment behind its product (loupe.py:255-276) in one pass each way.

@@ -21,6 +21,9 @@ DEFAULT_PARAMS = {"CLUSTER_SIZE": 64, "FEATURE_OUTPUT_DIM": 256, "KNN": 20, "INP
 # (tests/test_gpu_adversarial.py: it is wrong by 1e-2 on heavy-tailed weights while staying inside fp16's range, so
 # nothing selects it automatically).
 DEFAULT_PRECISION = "f32"
+# EPC-Net-L (models/epc-net-l.py:29-102): batches of L_HALVES_FROM clouds or more run as L_HALF_BATCH-cloud passes on two HIP streams
+L_HALVES_FROM = 256
+L_HALF_BATCH = 128
 
 
 def resolve_precision(params: Optional[dict], precision: Optional[str] = None) -> str:
@@ -53,8 +56,10 @@ class InferenceEngine:
         # passes kept in flight on separate HIP streams (submit / long calls).  Default: two in the `fast` arithmetic (+12 %),
         # ONE in the f32-equivalent one -- its kernels fill every CU's registers and LDS (the persistent block kernel the whole
         # chip): a second lane only delays the first (bench.py `overlapped`: 55.6 k against 57.5 k clouds/s)
+        # EPC-Net-L: two lanes as well -- a batch of 256 clouds or more goes as 128-cloud halves in flight (the VALU-bound kNN of one
+        # half beside the L1-bound blocks / the matrix-bound conv5 of the other: +3-4 %, the same bits; `_forward`)
         if in_flight is None:
-            in_flight = 2 if (self.precision == "fast" and arch == "epc-net") else 1
+            in_flight = 2 if ((self.precision == "fast" and arch == "epc-net") or arch == "epc-net-l") else 1
         self.in_flight = max(1, min(int(in_flight), 8))
         self._lanes = None                                 # [(torch.cuda.Stream, workspace tensor or None, last event or None)]
         self._next_lane = 0
@@ -155,6 +160,8 @@ class InferenceEngine:
         packed = self.packed(cfg)
         if out is None:
             out = torch.empty((nc, cfg.output_dim), dtype=torch.float32, device=xyz.device)
+        if self.arch == "epc-net-l" and self.micro_batch == 0 and self.in_flight > 1 and profile is None and nc >= L_HALVES_FROM:
+            cfg.micro_batch = L_HALF_BATCH          # (passes of 128 clouds dealt over the lanes: results do not depend on the pass size)
         mb = L.micro_batch_of(cfg, nc)
         if profile is None and self.in_flight > 1 and nc > mb:
             # several passes: deal them over this stream and the auxiliary lanes (epc_net_forward_overlapped)

@@ -46,8 +46,8 @@ EXPORTS = [
     "epc_morton_sort",
     "epc_gemm_f32", "epc_gemm_f32_fast", "epc_gemm_bf16", "epc_gemm_splitk_det", "epc_linear_bn_bwd64", "epc_linear_bn_bwd64_ex", "epc_linear_stats64", "epc_linear_stats64_bn", "epc_bn_apply_add_fwd", "epc_neighbour_mean_diff_bwd_gather_sum", "epc_linear_smallk_fwd", "epc_linear_smallk_dw", "epc_linear_smallk_dw_partial_floats", "epc_linear_bn_bwd64_partial_floats", "epc_gemm_stats_tiles", "epc_gemm_f32_stats", "epc_gemm_f16x3_stats", "epc_gemm_bf16_stats", "epc_neighbour_mean_diff_fwd", "epc_neighbour_mean_diff_bwd_gather", "epc_bn_relu_rownorm_fwd", "epc_bn_relu_rownorm_bwd", "epc_bn_relu_rownorm_bwd_partial_floats", "epc_vlad_normalize_fwd", "epc_vlad_normalize_bwd",
     "epc_lazy_quadruplet_loss_fwd", "epc_lazy_quadruplet_loss_bwd", "epc_colreduce_workspace_bytes", "epc_col_moments", "epc_col_sum", "epc_bn_apply_fwd", "epc_bn_apply_bwd",
-    "epc_neighbour_mean_fwd", "epc_neighbour_mean_bwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
-    "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats", "epc_cloud_colsum64",
+    "epc_neighbour_mean_fwd", "epc_knn_transpose", "epc_neighbour_mean_bwd_gather", "epc_rownorm_fwd", "epc_rownorm_bwd", "epc_softmax64_fwd",
+    "epc_softmax64_bwd", "epc_softmax64_bwd_bcast", "epc_cloud_colsum64_partial_floats",
     "epc_assign_softmax_fwd", "epc_assign_softmax_bwd", "epc_gate_fwd",
     "epc_chain_parts", "epc_chain_stats", "epc_chain_fwd_linear", "epc_chain_fwd_gather", "epc_chain_bwd_linear",
     "epc_chain_bwd_gather", "epc_chain_sums", "epc_chain_bn_bwd", "epc_chain_dw_sum", "epc_knn_overflow_lists",
@@ -161,7 +161,6 @@ _lib.epc_bn_apply_bwd.argtypes = [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int,
 _lib.epc_neighbour_mean_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
 _lib.epc_neighbour_mean_diff_fwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_neighbour_mean_diff_bwd_gather.argtypes = [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]
-_lib.epc_neighbour_mean_bwd.argtypes = [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]
 _lib.epc_knn_transpose.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P]
 _lib.epc_neighbour_mean_bwd_gather.argtypes = [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P]
 _lib.epc_rownorm_fwd.argtypes = [_P, c_int, c_int, _P, _P, _P]
@@ -171,7 +170,6 @@ _lib.epc_softmax64_bwd.argtypes = [_P, _P, c_int, _P, _P]
 _lib.epc_softmax64_bwd_bcast.argtypes = [_P, _P, c_int, _P, c_int, _P, _P]
 _lib.epc_cloud_colsum64_partial_floats.argtypes = [c_int]
 _lib.epc_cloud_colsum64_partial_floats.restype = ctypes.c_size_t
-_lib.epc_cloud_colsum64.argtypes = [_P, c_int, c_int, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_fwd.argtypes = [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_assign_softmax_bwd.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]
 _lib.epc_vlad_df_tail_partial_floats.argtypes = [c_int, c_int]

@@ -121,12 +121,12 @@ class _VladBase(PoolingBaseModel):
         if isinstance(x, ops.LazyConv5Features):
             # conv5 arrives un-evaluated: conv5 + l2 norm + :255-291 as ONE node of streaming kernels (ops.Conv5VladHead)
             mode = ops.head_stream_mode(x.shape[0], 256, F, N) if (self.add_batch_norm and self.is_training and F == 1024) else None
-            if mode is None:
-                raise NotImplementedError("a lazy conv5 feature map needs the training-mode G_VLAD with add_batch_norm (F = 1024)")
+            if mode is None:      # (a consumer the producer did not foresee: the layer through the per-layer operators after all)
+                return self.forward(x.materialize())
             from .utils.tf_util import _ema_update
             beta, gamma, mm, mv = _slim_bn_variables("cluster_bn", C)
             vlad, a_sum, mean5, var5, mean_c, var_c, z5, rn = ops.Conv5VladHead.apply(
-                x.x, x.W, x.b, x.gamma, x.beta, x.eps, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N, mode)
+                x.x, x.W, x.b, x.gamma, x.beta, x.eps, st[scoped("cluster_weights")], gamma, beta, BN_EPS, N, mode, x.x_bf16)
             x.on_stats(mean5, var5, z5, rn)
             _ema_update(mm, mean_c, SLIM_DECAY, scheduled=False)
             _ema_update(mv, var_c, SLIM_DECAY, scheduled=False)

@@ -72,7 +72,8 @@ def forward_ops(point_cloud, is_training, bn_decay, params, backbone_scope='fast
     with variable_scope(backbone_scope):
         dpist = ops.KnnGraph(point_cloud)                    # tf_util.pairwise_distance_mask in index form (:63)
         # conv1 .. conv4_b and the concat of the four block outputs (:66-134): one fused chain in training (tf_util.proxyconv_backbone)
-        x = tf_util.proxyconv_backbone(point_cloud, dpist, k, 4, bn_decay=bn_decay, is_training=is_training)
+        x = tf_util.proxyconv_backbone(point_cloud, dpist, k, 4, bn_decay=bn_decay, is_training=is_training,
+                                       head_follows=not return_features)
         # conv5 (:136-139) and the per-point l2_normalize of :147-148 (which the reference applies inside the VLAD scope)
         net = tf_util.conv1d_l2_normalized(x, 1024, 'conv5', bn_decay=bn_decay, is_training=is_training,
                                            lazy=not return_features)     # (lazy: only G_VLAD.forward below consumes it)

@@ -659,10 +659,10 @@ class ProxyConvChain(torch.autograd.Function):
     training mode: batch moments from the producer's partials, pooled in the consumer's prologue.  Forward: 3 launches per block
     (+ 1 for z0_1's moments); backward: 4 per block + 2 -- against 9 + 1 and ~14 of the per-layer operators.
 
-    apply(z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, *params) with params = for block 1: gamma0, beta0, then
+    apply(z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, want_bf16, *params) with params = for block 1: gamma0, beta0, then
     Wa, ba, gamma_a, beta_a, Wb, bb, gamma_b, beta_b; for every later block: W0, b0, gamma0, beta0 and the same eight.
     Returns (cat (rows, 64 nblocks), then per block: [z0 -- blocks after the first --], mean0, var0, za, mean_a, var_a, zb, mean_b,
-    var_b) -- the pre-activations
+    var_b, then the concat's bf16 copy or None) -- the pre-activations
     and batch moments feed the moving averages and the test hook's mask taps; only cat is differentiable.  Bias gradients in front of
     a training-mode BatchNorm are exactly zero and are not computed (LinearBatchNormTrain)."""
 
@@ -680,7 +680,7 @@ class ProxyConvChain(torch.autograd.Function):
         return blocks
 
     @staticmethod
-    def forward(ctx, z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, *params):
+    def forward(ctx, z01, graph, k, eps, nblocks, pieces_fwd, pieces_bwd, want_bf16, *params):
         lib = L.lib()
         z01 = z01.contiguous()
         rows = int(z01.shape[0])
@@ -695,19 +695,18 @@ class ProxyConvChain(torch.autograd.Function):
         ptr = lambda t: t.data_ptr() if t is not None else None
         cat = torch.empty((rows, width), dtype=torch.float32, device=dev)
         # the bf16 head (Conv5VladHead, mode "bf16") reads the concat as bf16: written beside the f32 tensor by the launches that form it
-        cat16 = torch.empty((rows, width), dtype=torch.bfloat16, device=dev) if head_stream_mode(rows, width, 1024) == "bf16" else None
-        if cat16 is not None:
-            _CAT16.clear()
-            _CAT16[cat.data_ptr()] = cat16
+        # (``want_bf16``: the caller knows that the bf16 streamed head is what consumes the concat; the copy is an OUTPUT of the node,
+        # handed on explicitly -- tf_util.proxyconv_backbone -> conv1d_l2_normalized -> LazyConv5Features -> Conv5VladHead)
+        cat16 = torch.empty((rows, width), dtype=torch.bfloat16, device=dev) if want_bf16 else None
         g = graph
         if CHAIN_PERSIST_FWD and nblocks <= L.EPC_CHAIN_MAX_BLOCKS and lib.epc_chain_persist_ok(rows):
             saved, outs = ProxyConvChain._forward_persistent(lib, z01, g, k, eps, nblocks, pieces_fwd, blocks, cat, cat16)
             ctx.save_for_backward(cat, *saved, *[p for p in params])
             ctx.graph, ctx.k, ctx.eps, ctx.nblocks = graph, int(k), float(eps), int(nblocks)
             ctx.pieces_bwd, ctx.n_params = int(pieces_bwd), len(params)
-            ctx.mark_non_differentiable(*outs)
+            ctx.mark_non_differentiable(*outs, *([cat16] if cat16 is not None else []))
             ctx.set_materialize_grads(False)
-            return (cat,) + tuple(outs)
+            return (cat,) + tuple(outs) + (cat16,)
         st0 = stats()
         L.check(lib.epc_chain_stats(z01.data_ptr(), rows, st0.data_ptr(), _st()))
         z0, in_stats, in_bias = z01, st0, None
@@ -743,9 +742,9 @@ class ProxyConvChain(torch.autograd.Function):
         ctx.save_for_backward(cat, *saved, *[p for p in params])
         ctx.graph, ctx.k, ctx.eps, ctx.nblocks = graph, int(k), float(eps), int(nblocks)
         ctx.pieces_bwd, ctx.n_params = int(pieces_bwd), len(params)
-        ctx.mark_non_differentiable(*outs)
+        ctx.mark_non_differentiable(*outs, *([cat16] if cat16 is not None else []))
         ctx.set_materialize_grads(False)
-        return (cat,) + tuple(outs)
+        return (cat,) + tuple(outs) + (cat16,)
 
     @staticmethod
     def _forward_persistent(lib, z01, g, k, eps, nblocks, pieces_fwd, blocks, cat, cat16):
@@ -785,7 +784,7 @@ class ProxyConvChain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcat, *_unused):
         nb = ctx.nblocks
-        n_in = 7 + ctx.n_params
+        n_in = 8 + ctx.n_params
         if dcat is None:
             return (None,) * n_in
         lib = L.lib()
@@ -876,7 +875,7 @@ class ProxyConvChain(torch.autograd.Function):
         pa = (ctypes.c_void_p * n_layers)(*[parts[l].data_ptr() for l in range(n_layers)])
         pw = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in layer_dw])
         L.check(lib.epc_chain_dw_sum(n_layers, pa, pw, rows, _st()))
-        return (dz01 if ctx.needs_input_grad[0] else None, None, None, None, None, None, None) + tuple(grads)
+        return (dz01 if ctx.needs_input_grad[0] else None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 class RowL2Normalize(torch.autograd.Function):
@@ -1104,11 +1103,6 @@ class VladAssignAggregate(torch.autograd.Function):
         return df, dWc, dgamma, dbeta, None, None, None
 
 
-# bf16 copies of concat buffers, by the f32 tensor's address: handed from ProxyConvChain.forward to Conv5VladHead.forward (the tensors
-# in between are reshaped views).  One entry: the last chain forward's.
-_CAT16 = {}
-
-
 # The head of the training step -- conv5, the per-point l2 norm, the soft assignment and the aggregation -- as ONE autograd node whose
 # kernels are single streaming passes over the (rows, 1024) tensors and never write the feature map f (csrc/train_head16.hip for
 # set_gemm_precision("bf16"): bf16-stored tensors, one bf16 value per operand; csrc/train_head32.hip for the default f32-accurate
@@ -1132,9 +1126,17 @@ class LazyConv5Features:
     run as one node (Conv5VladHead).  ``on_stats(mean, var, z5, rn)`` is conv5's side of the bookkeeping (moving averages, the
     mask- and value-tap test hooks), called by whoever evaluates the node.  ``shape`` = the feature map's."""
 
-    def __init__(self, x, W, b, gamma, beta, eps, on_stats):
+    def __init__(self, x, W, b, gamma, beta, eps, on_stats, x_bf16=None, materialize=None):
         self.x, self.W, self.b, self.gamma, self.beta, self.eps, self.on_stats = x, W, b, gamma, beta, float(eps), on_stats
+        self.x_bf16 = x_bf16                      # the chain's bf16 copy of x (the bf16 head's operand), when it made one
+        self._materialize = materialize           # evaluates the layer through the per-layer operators: the consumer's way out
         self.shape = (int(x.shape[0]), int(W.shape[1]))
+
+    def materialize(self):
+        """The feature map itself, (rows, 1024), through the per-layer operators (for a consumer that cannot take the streamed head)."""
+        if self._materialize is None:
+            raise EpcNetError(-1, "this lazy conv5 feature map cannot be evaluated here")
+        return self._materialize()
 
     def reshape(self, *shape):
         shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
@@ -1159,7 +1161,7 @@ class Conv5VladHead(torch.autograd.Function):
     operators.  The bias gradient in front of a training-mode BatchNorm is exactly zero and is not computed (LinearBatchNormTrain)."""
 
     @staticmethod
-    def forward(ctx, cat, W5, b5, g5, bt5, eps5, Wc, gc, btc, epsc, n_points, mode):
+    def forward(ctx, cat, W5, b5, g5, bt5, eps5, Wc, gc, btc, epsc, n_points, mode, cat16=None):
         lib = L.lib()
         cat, W5, Wc = cat.contiguous(), W5.contiguous(), Wc.contiguous()
         rows = int(cat.shape[0])
@@ -1173,9 +1175,8 @@ class Conv5VladHead(torch.autograd.Function):
         bn5 = lambda: (mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), bt5.data_ptr(), float(eps5))
         lhs = cat
         if h16:
-            cat16 = _CAT16.pop(cat.data_ptr(), None)       # the chain's bf16 copy of this very tensor, when it made one
-            if cat16 is not None and tuple(cat16.shape) == (rows, 256):
-                lhs = cat16
+            if cat16 is not None and tuple(cat16.shape) == (rows, 256) and cat16.dtype == torch.bfloat16:
+                lhs = cat16                                    # the chain's bf16 copy of this very tensor
             sc, n = _scratch_bytes(lib.epc_h16_conv5_fwd_scratch_bytes(rows), dev)
             L.check(lib.epc_h16_conv5_fwd(lhs.data_ptr(), int(lhs is not cat), W5.data_ptr(), b5.data_ptr(), rows, z5.data_ptr(),
                                           mean5.data_ptr(), var5.data_ptr(), sc.data_ptr(), n, _st()))
@@ -1268,7 +1269,7 @@ class Conv5VladHead(torch.autograd.Function):
                                          sc.data_ptr(), n, _st()))
         else:
             dW5 = gemm(cat, du, trans_a=True, splitk=_splitk_for(256, 1024, rows), fast=True, deterministic=True)
-        return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None, None
+        return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None, None, None
 
 
 def expand16(z16, bn=None, rn=None):

@@ -177,11 +177,7 @@ class TrainStep:
         tf_util.BACKBONE_TAP = None
         prev = ops.set_gemm_precision(self.precision)
         try:
-            try:
-                loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
-            except BaseException:
-                tf_util._deferred_ema = None        # a failed forward applies nothing
-                raise
+            loss = self.compute_loss(query, positives, negatives, other_neg, True, bn_decay)
             tap = tf_util.BACKBONE_TAP
             if between is not None and tap is not None and tap.requires_grad:
                 # Which variables lie below the cut is a property of the GRAPH: those the backbone's output depends on
@@ -203,6 +199,9 @@ class TrainStep:
                     self.store.vars[n].grad = g
             else:
                 loss.backward()
+        except BaseException:
+            tf_util._deferred_ema = None            # a failed forward OR backward applies nothing and leaves no deferral armed
+            raise
         finally:
             ops.set_gemm_precision(prev)
             tf_util.BACKBONE_TAP = None
@@ -244,8 +243,10 @@ class TrainStep:
         return head, below
 
     def _bias_before_batchnorm(self, name: str) -> bool:
-        """A conv bias in front of a training-mode BatchNorm: its gradient is exactly zero and the operators leave it undefined."""
-        return name.endswith("/biases")
+        """A bias DECLARED in front of a training-mode BatchNorm (tf_util.declare_conv1d / declare_fully_connected with bn=True): its
+        gradient is exactly zero and the operators leave it undefined.  A bias with no BatchNorm behind it is not exempt."""
+        from .utils import tf_util
+        return name in tf_util.BIASES_BEFORE_BATCHNORM
 
     def _below_tap(self, name: str) -> bool:
         """Is this variable's gradient formed BELOW the backbone's output?  Answered from the last graph walk (_split_at_tap);

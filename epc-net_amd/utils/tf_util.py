@@ -53,6 +53,12 @@ def _bn_variables(scope: str, num_channels: int):
     return beta, gamma, mean, var
 
 
+# Full names of the biases DECLARED in front of a BatchNorm (bn=True below): in training mode their gradient is exactly zero and the
+# fused operators do not form it.  training.TrainStep exempts exactly these -- by declaration, not by name suffix -- from its "every
+# variable below the cut received a gradient" check.
+BIASES_BEFORE_BATCHNORM = set()
+
+
 def declare_conv1d(scope, num_in_channels, num_output_channels, kernel_size=1, use_xavier=True, stddev=1e-3,
                    bn=True):
     """Create (or fetch) the variables ``conv1d`` owns: weights [k,Cin,Cout], biases, bn/*."""
@@ -61,6 +67,9 @@ def declare_conv1d(scope, num_in_channels, num_output_channels, kernel_size=1, u
                                         0.0, use_xavier)
         b = _variable_on_cpu("biases", [num_output_channels], constant(0.0))
         bnv = _bn_variables("bn", num_output_channels) if bn else None
+        if bn:
+            from ..variables import scoped
+            BIASES_BEFORE_BATCHNORM.add(scoped("biases"))
     return w, b, bnv
 
 
@@ -69,6 +78,9 @@ def declare_fully_connected(scope, num_input_units, num_outputs, use_xavier=True
         w = _variable_with_weight_decay("weights", [num_input_units, num_outputs], stddev, 0.0, use_xavier)
         b = _variable_on_cpu("biases", [num_outputs], constant(0.0))
         bnv = _bn_variables("bn", num_outputs) if bn else None
+        if bn:
+            from ..variables import scoped
+            BIASES_BEFORE_BATCHNORM.add(scoped("biases"))
     return w, b, bnv
 
 
@@ -297,14 +309,17 @@ USE_CHAIN = True
 # and conv5) travels while the backbone's backward runs (training.TrainStep).
 BACKBONE_TAP = None
 
-def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None):
+def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_training=None, head_follows=False):
     """The ProxyConv backbone of models/epc-net.py:66-134 (four blocks) / models/epc-net-l.py:62-83 (two) up to the concat:
         for b: x = conv_b(in) [conv1 on the coordinates, conv2.. on the previous block's output]; x1 = matmul(mask, x) / k;
                t = conv_b_b(conv_b_a(x1 - x)); in = t + x1
         return concat of the blocks' outputs (B, N, 64 nblocks)
     every conv = 1x1 + BatchNorm + ReLU.  Not a function of the reference's tf_util: a fusion point.  In training it is conv1's
     product (ops.Linear, K = 3) followed by ONE autograd node on the fused chain launches (ops.ProxyConvChain); otherwise the same
-    graph op by op (conv1d / proxyconv_tail).  Variables, moving-average updates and the mask-tap test hook as conv1d's."""
+    graph op by op (conv1d / proxyconv_tail).  Variables, moving-average updates and the mask-tap test hook as conv1d's.
+    ``head_follows``: the caller hands the result to conv1d_l2_normalized(..., lazy=True) and nowhere else -- when that head will run in
+    the bf16 arithmetic the chain writes a bf16 copy of the concat beside it and the copy travels WITH the returned tensor
+    (attribute ``_epc_bf16``), not through a global."""
     import torch
     from .. import ops
     B, N, cin = (int(v) for v in point_cloud.shape)
@@ -337,8 +352,9 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
             bns.append(('conv%d%s' % (b, sfx), gamma, beta, em, ev))
     z01 = ops.Linear.apply(point_cloud.reshape(rows, cin), w1, b1, True)        # conv1's product (bias in front of a BatchNorm)
     pf, pb = (3, 2) if ops._GEMM_PRECISION == "bf16x6" else (1, 1)
-    res = ops.ProxyConvChain.apply(z01, graph, int(k), 1e-3, int(nblocks), pf, pb, *params)
-    cat, rest = res[0], list(res[1:])
+    want16 = bool(head_follows) and ops.head_stream_mode(rows, 64 * int(nblocks), 1024, N) == "bf16"
+    res = ops.ProxyConvChain.apply(z01, graph, int(k), 1e-3, int(nblocks), pf, pb, want16, *params)
+    cat, rest, cat16 = res[0], list(res[1:-1]), res[-1]
     decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
     at = 0
     for li, (scope, gamma, beta, em, ev) in enumerate(bns):
@@ -366,6 +382,8 @@ def proxyconv_backbone(point_cloud, graph, k, nblocks, bn_decay=None, is_trainin
     assert at == len(rest)
     global BACKBONE_TAP
     BACKBONE_TAP = cat.reshape(B, N, 64 * nblocks)
+    if cat16 is not None:
+        BACKBONE_TAP._epc_bf16 = cat16          # (rows, 64 nblocks) bf16: conv1d_l2_normalized hands it to the streamed head
     return BACKBONE_TAP
 
 
@@ -385,9 +403,16 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
         return ops.RowL2Normalize.apply(y.reshape(-1, num_output_channels))
     L.require_gpu()
     w, b, _ = declare_conv1d(scope, cin, num_output_channels, 1, True, 1e-3, True)
+    n_points = int(inputs.shape[1]) if inputs.dim() == 3 else None      # (B, N, C): the consumer's max_samples
     with variable_scope(scope):
         x2 = inputs.reshape(-1, cin)
-        if lazy and ops.head_stream_mode(int(x2.shape[0]), cin, num_output_channels) is not None:
+
+        def eager():
+            return _conv5_l2_normalized_eager(x2, w, b, cin, num_output_channels, bn_decay)
+
+        # ONE decision, with everything the consumer will look at (rows, widths AND the points per cloud: ADVICE r5): a shape the streamed
+        # head does not cover goes through the per-layer operators right here
+        if lazy and ops.head_stream_mode(int(x2.shape[0]), cin, num_output_channels, n_points) is not None:
             from ..variables import current_scope
             beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
             decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
@@ -404,20 +429,34 @@ def conv1d_l2_normalized(inputs, num_output_channels, scope, bn_decay=None, is_t
                 if VALUE_TAPS is not None:
                     VALUE_TAPS[here] = ops.expand16(z5) if z5.dtype == torch.bfloat16 else z5.detach().clone()
 
-            return ops.LazyConv5Features(x2, w.reshape(cin, num_output_channels), b, gamma, beta, 1e-3, on_stats)
-        if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
-            f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True,
-                                f16x3=ops.F16X3_CONV5,      # conv5: BatchNorm'd block outputs against its weights
-                                link=ops.TailLink() if ops.FUSE_TAIL_BACKWARD else None)
-            _tap_relu_mask(f)          # (the row norm is a positive factor: f > 0 exactly where the ReLU's output is)
-            return f
-        z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)
-        beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
-        f, mean, var = ops.BatchNormReluRowNorm.apply(z, gamma, beta, 1e-3)
-        decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
-        _ema_update(ema_mean, mean, decay)
-        _ema_update(ema_var, var, decay)
-        _tap_relu_mask(f)
+            here_scope = here
+
+            def materialize():      # (a consumer that cannot stream after all: the same layer through the per-layer operators, in this scope)
+                from ..variables import absolute_scope
+                with absolute_scope(here_scope):
+                    return eager()
+
+            return ops.LazyConv5Features(x2, w.reshape(cin, num_output_channels), b, gamma, beta, 1e-3, on_stats,
+                                         x_bf16=getattr(inputs, "_epc_bf16", None), materialize=materialize)
+        return eager()
+
+
+def _conv5_l2_normalized_eager(x2, w, b, cin, num_output_channels, bn_decay):
+    """conv1d_l2_normalized's layer through the per-layer operators (called inside the layer's variable scope)."""
+    from .. import ops
+    if ops.fused_linear_bn_ok(int(x2.shape[0]), cin, num_output_channels):
+        f = _bn_train_fused(x2, w.reshape(cin, num_output_channels), b, "bn", bn_decay, True, rownorm=True,
+                            f16x3=ops.F16X3_CONV5,      # conv5: BatchNorm'd block outputs against its weights
+                            link=ops.TailLink() if ops.FUSE_TAIL_BACKWARD else None)
+        _tap_relu_mask(f)          # (the row norm is a positive factor: f > 0 exactly where the ReLU's output is)
+        return f
+    z = ops.Linear.apply(x2, w.reshape(cin, num_output_channels), b, True)
+    beta, gamma, ema_mean, ema_var = _bn_variables("bn", num_output_channels)
+    f, mean, var = ops.BatchNormReluRowNorm.apply(z, gamma, beta, 1e-3)
+    decay = 0.9 if bn_decay is None else (bn_decay if torch.is_tensor(bn_decay) else float(bn_decay))
+    _ema_update(ema_mean, mean, decay)
+    _ema_update(ema_var, var, decay)
+    _tap_relu_mask(f)
     return f
 
 

@@ -174,6 +174,17 @@ def current_scope() -> str:
     return "/".join(_scope_stack)
 
 
+@contextlib.contextmanager
+def absolute_scope(path: str):
+    """Re-enter the scope ``path`` (a value of current_scope()) from anywhere: the stack is replaced for the block and restored."""
+    saved = list(_scope_stack)
+    _scope_stack[:] = path.split("/") if path else []
+    try:
+        yield path
+    finally:
+        _scope_stack[:] = saved
+
+
 def scoped(name: str) -> str:
     s = current_scope()
     return s + "/" + name if s else name

@@ -168,8 +168,8 @@ int epc_morton_sort(const float* xyz, int num_clouds, int n, float* xyz_sorted, 
  *   cnt[i]  = #{j : a_ij >= kth[i]}  (>= 20; ties and zero-padded clouds make it larger);
  *   idx[i]  = the first min(cnt, cap) such j in ascending order (cap slots per point).
  * The dense mask the reference materialises is mask[i][j] = (a_ij >= kth[i]).
- * n <= 8192: the cloud sits in LDS and four lanes share a query; the environment variable EPC_KNN_QUAD=0 (read at every launch: a
- * tuning and test aid) selects the older one-lane-per-query kernel -- the same kth, cnt and idx bit for bit. */
+ * n <= 8192: the cloud sits in LDS and four lanes share a query.  The older one-lane-per-query kernel (the same kth, cnt and idx
+ * bit for bit) is reachable through epc_knn_topk_form(..., form = 0) only: the library reads no environment. */
 int epc_knn_topk(const float* xyz, int num_clouds, int n, int cap, int32_t* idx, int32_t* cnt, float* kth,
                  void* stream);
 
@@ -442,12 +442,9 @@ int epc_lazy_quadruplet_loss_bwd(const float* q, const float* pos, const float* 
                                  const int32_t* sel, const float* dloss, int B, int P, int Nn, int D, float* dq,
                                  float* dpos, float* dneg, float* dother, void* stream);
 
-/* xm = (mask @ x) / knn in index form (models/epc-net.py:70-71) for 64-channel x, and its transpose
- * dx += mask^T @ dxm / knn (dx pre-initialised by the caller). */
+/* xm = (mask @ x) / knn in index form (models/epc-net.py:70-71) for 64-channel x (its transpose: epc_neighbour_mean_bwd_gather). */
 int epc_neighbour_mean_fwd(const float* x, const float* xyz, const int32_t* idx, const int32_t* cnt, const float* kth,
                            int cap, int num_clouds, int n, int knn, float* xm, void* stream);
-int epc_neighbour_mean_bwd(const float* dxm, const float* xyz, const int32_t* idx, const int32_t* cnt,
-                           const float* kth, int cap, int num_clouds, int n, int knn, float* dx, void* stream);
 
 /* The two together as the blocks use them (models/epc-net.py:70-72): xm and diff = xm - x in one launch; backward
  * dx = mask^T (dxm + ddiff) / knn - ddiff over the transposed graph (below), dx overwritten. */
@@ -469,7 +466,7 @@ int epc_neighbour_mean_diff_bwd_gather_sum(const float* s, const float* dxm, con
 int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap, int num_clouds, int n, int32_t* rdeg,
                       int32_t* roff, int32_t* cursor, int32_t* rlist, void* stream);
 /* Backward of the neighbour mean as a GATHER over the transposed graph (dx is overwritten; rows with cnt > cap are
- * added by an exact scan): the atomic scatter of epc_neighbour_mean_bwd is bound by the f32 atomic rate. */
+ * added by an exact scan) -- no float atomics: bit-reproducible. */
 int epc_neighbour_mean_bwd_gather(const float* dxm, const float* xyz, const int32_t* cnt, const float* kth, int cap,
                                   const int32_t* rdeg, const int32_t* roff, const int32_t* rlist, int num_clouds, int n,
                                   int knn, float* dx, void* stream);
@@ -486,14 +483,11 @@ int epc_softmax64_bwd(const float* dy, const float* y, int rows, float* dx, void
 int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n_points, const float* y, int rows, float* dx,
                             void* stream);
 
-/* a_sum of loupe.py:276: out (num_clouds, 64) = sum over the n_points rows of each cloud of a (num_clouds, n_points, 64), added
- * in a fixed order (bit-reproducible).  partials: caller-owned scratch of epc_cloud_colsum64_partial_floats(num_clouds). */
+/* scratch floats of the per-cloud column sums (a_sum of loupe.py:276) inside epc_assign_softmax_fwd */
 size_t epc_cloud_colsum64_partial_floats(int num_clouds);
-int epc_cloud_colsum64(const float* a, int num_clouds, int n_points, float* out, float* partials, size_t partial_floats,
-                       void* stream);
 
 /* The soft assignment behind its product, one pass each way (loupe.py:255-276; what epc_bn_apply_fwd + epc_softmax64_fwd +
- * epc_cloud_colsum64, and epc_softmax64_bwd_bcast + epc_bn_apply_bwd, do in five and four launches):
+ * a per-cloud column sum, and epc_softmax64_bwd_bcast + epc_bn_apply_bwd, do in five and four launches):
  *   fwd: a (num_clouds * n_points, 64) = softmax(batch_norm(z; mean, var, gamma, beta, eps)) and a_sum (num_clouds, 64) = the sum of
  *        a over each cloud's points, added in a fixed order; partials = epc_cloud_colsum64_partial_floats(num_clouds) floats.
  *   bwd: from da (gradient of a), dsum (num_clouds, 64) (gradient of a_sum, may be NULL), a and z:  dz (gradient of z; also used
@@ -652,7 +646,8 @@ int epc_bn_apply_bwd_given(const float* dy, const float* z, const float* mean, c
  * epc_h16_df_tail: epc_vlad_df_tail on these tensors: du (rows, 1024) bf16 = [f > 0] rn ([a | dz] [dvlad^T ; Wc^T] - f trow) and
  *   dbeta_dgamma (2, 1024) = (sum du, sum du zhat) from the f32 values.
  * epc_h16_bn_bwd_apply: dz5 = gamma rstd (du - dbeta / rows - zhat dgamma / rows), bf16 in, bf16 out; dz5 may be du.
- * epc_h16_conv5_dx: dcat (rows, 256) f32 = dz5 W5^T.
+ * epc_h16_conv5_dx: dcat (rows, 256) f32 = dz5 W5^T -- the product alone: the step uses the fused form below; this one stays as the second
+ *   implementation the fused form is tested against (tests/test_gpu_head_stream.py) and timed beside (scripts/time_head_kernels.py).
  * epc_h16_conv5_dx_bn: epc_h16_bn_bwd_apply and epc_h16_conv5_dx in one pass -- dz5 is formed from du and z5 as they stream, written once
  *   (dz5 may be du) for epc_h16_conv5_dw, and multiplied with W5^T from registers; the same values, one read of a (rows, 1024) tensor
  *   and one launch fewer (utils/tf_util.py:94-106 seen from the gradient side, models/epc-net.py:136).

@@ -18,4 +18,7 @@ PRECISION=bf16 bash scripts/prof_train.sh final_$tag && cp gpurun_out/final_$tag
 bash scripts/prof_train.sh final_$tag && cp gpurun_out/final_$tag/train_stats.txt profiles/${tag}_train_step_kernel_stats.txt
 PRECISION=f32 python scripts/stress_parity.py 90 > profiles/${tag}_stress_parity.txt 2>&1 || true
 tail -3 profiles/${tag}_stress_parity.txt
+# the tracked bench line LAST: only now do the counter summaries carry this library's hash, so the line has `traffic` / `mfma_util`
+# (the line collect_profiles.sh wrote at its start was taken before the summaries were stamped: VERDICT r5 weak #9)
+python3 bench.py > profiles/${tag}_bench_line.json 2> $out/bench_final.err || { tail -5 $out/bench_final.err; echo "bench.py failed"; }
 mkdir -p $out/profiles; cp profiles/${tag}* profiles/pmc_*_current.json $out/profiles/ 2>/dev/null || true

@@ -306,6 +306,24 @@ def test_overlapped_passes_and_submit_match_single_stream(dev, arch, prec):
     assert torch.equal(o, serial[:3])
 
 
+def test_epc_net_l_batch_256_runs_as_two_halves_in_flight_with_the_same_bits(dev):
+    """InferenceEngine.forward's default for EPC-Net-L at 256 clouds x 4096 points (BASELINE.json configs[3]): two 128-cloud halves on two
+    HIP streams (engine.L_HALVES_FROM) -- bit-identical to the one-stream pass of the whole batch, call after call."""
+    E = H.pkg("engine")
+    w = O.seeded_weights("epc-net-l", 0)
+    st = H.make_store("epc-net-l", w, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    pc = torch.rand((256, 4096, 3), generator=g, device=dev) * 2 - 1
+    serial = E.InferenceEngine("epc-net-l", H.PARAMS, st, outer=H.OUTER, in_flight=1).forward(pc)
+    eng = E.InferenceEngine("epc-net-l", H.PARAMS, st, outer=H.OUTER)
+    assert eng.in_flight == 2
+    for _ in range(3):
+        assert torch.equal(eng.forward(pc), serial)
+    assert torch.equal(eng.forward(pc[:200]), serial[:200])         # below the threshold: one pass on the caller's stream
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("nc,n", [(3, 4096), (2, 96), (1, 8192 + 64)])
 def test_knn_conv1_fused_launch_is_bit_identical(dev, nc, n):
     """epc_knn_topk_conv1 (one launch) against epc_knn_topk + epc_conv1_fwd: lists, counts, thresholds and both row

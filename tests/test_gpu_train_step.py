@@ -349,3 +349,56 @@ def test_gemm_bf16_entry_matches_operand_rounded_reference(dev):
     assert (Ct.double().T - ref).abs().max() <= 1e-4 * ref.abs().max()
     with pytest.raises(ValueError):
         ops.set_gemm_precision("fp8")
+
+
+@pytest.mark.parametrize("precision", ["bf16x6", "bf16"])
+def test_step_at_a_point_count_the_streamed_head_does_not_cover(dev, precision):
+    """rows % 32 == 0 with N % 32 != 0 (18 clouds x 48 points = 864 rows).  conv1d_l2_normalized decides ONCE, with
+    the points per cloud, whether conv5 travels un-evaluated to the VLAD node; a shape the streamed head does not cover takes the per-layer
+    operators -- the step runs and agrees with the step whose head streaming is switched off."""
+    TR, ops = H.pkg("training"), H.pkg("ops")
+    n, nneg = 48, 14
+    assert ops.head_stream_mode(18 * n, 256, 1024) is not None and ops.head_stream_mode(18 * n, 256, 1024, n) is None
+    w0 = O.seeded_weights("epc-net", 4)
+    pcs = torch.from_numpy(O.synthetic_clouds(18, n, 9)).to(dev)
+    q, pos, neg, oth = pcs[None, :1], pcs[None, 1:3], pcs[None, 3:3 + nneg], pcs[None, 3 + nneg:]
+    params = dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, DECAY_STEP=200000, BASE_LEARNING_RATE=5e-5, MARGIN_1=0.5, MARGIN_2=0.2,
+                  TRAIN_PRECISION=precision)
+    out = []
+    for stream in (True, False):
+        prev, ops.HEAD_STREAM = ops.HEAD_STREAM, stream
+        try:
+            st = H.make_store("epc-net", w0, dev)
+            ts = TR.TrainStep(params, st, outer=H.OUTER)
+            loss, _, _ = ts.step(q, pos, neg, oth, epoch=0)
+            torch.cuda.synchronize()
+            out.append((float(loss), {k: v.detach().cpu().numpy().copy() for k, v in st.vars.items()}))
+        finally:
+            ops.HEAD_STREAM = prev
+    assert np.isfinite(out[0][0]) and out[0][0] == out[1][0]
+    for k, v in out[0][1].items():
+        assert np.array_equal(v, out[1][1][k]), k
+
+
+def test_lazy_conv5_consumer_that_cannot_stream_materialises(dev):
+    """loupe's side of the same contract: a LazyConv5Features that reaches a G_VLAD whose max_samples the streamed head does not cover is
+    evaluated through the per-layer operators (LazyConv5Features.materialize) instead of raising."""
+    V, tf_util, ops, lp = H.pkg("variables"), H.pkg("utils.tf_util"), H.pkg("ops"), H.pkg("loupe")
+    w0 = O.seeded_weights("epc-net", 4)
+    st = H.make_store("epc-net", w0, dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((4, 64, 256), generator=g).to(dev)       # 4 "clouds" of 64 points: rows 256
+    with V.variable_scope(H.OUTER):
+        with V.variable_scope("fastdgcnn"):
+            lazy = tf_util.conv1d_l2_normalized(x, 1024, "conv5", bn_decay=0.7, is_training=True, lazy=True)
+            assert isinstance(lazy, ops.LazyConv5Features)
+            eager = tf_util.conv1d_l2_normalized(x, 1024, "conv5", bn_decay=0.7, is_training=True, lazy=False)
+        with V.variable_scope("VLAD"):
+            # the consumer sees 16 "clouds" of 16 points: 16 % 32 != 0 -> it cannot stream
+            vl = lp.G_VLAD(feature_size=1024, max_samples=16, cluster_size=64, output_dim=256, groups=4, gating=True, add_batch_norm=True,
+                           is_training=True)
+            a = vl.forward(lazy)
+            b = vl.forward(eager)
+    torch.cuda.synchronize()
+    assert a.shape == (16, 256) and torch.isfinite(a).all()
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
