@@ -72,6 +72,7 @@ class InferenceEngine:
         self._packed_key = None
         self._ws: Optional[torch.Tensor] = None
         self._last_cfg: Optional[L.EpcCfg] = None
+        self._last_overlap = None                          # (cfg, lanes, bytes per lane slice, clouds) of a one-pass-per-lane overlapped call
         self._fallback: "Optional[InferenceEngine]" = None   # f32-equivalent engine for clouds the fast path flags
 
     # ------------------------------------------------------------------------------------------------------
@@ -171,13 +172,16 @@ class InferenceEngine:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
             aux = [ln[0] for ln in self._get_lanes(xyz.device)[:lanes - 1]]
             arr = (ctypes.c_void_p * max(len(aux), 1))(*[a.cuda_stream for a in aux])
-            self._last_cfg = None            # several lanes, several workspace slices: last_status() has no single answer
+            # several lanes, several workspace slices: last_status() can answer only while no slice has been reused (one pass per lane)
+            self._last_cfg = None
+            self._last_overlap = (cfg, lanes, L.lib().epc_net_workspace_bytes(ctypes.byref(cfg), nc), nc) if (nc + mb - 1) // mb <= lanes else None
             L.check(L.lib().epc_net_forward_overlapped(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                        self._ws.data_ptr(), self._ws.numel(), L.current_stream(), arr,
                                                        len(aux)))
             return out
         ws = self.workspace(cfg, max(nc, 1), xyz.device)
         self._last_cfg = cfg
+        self._last_overlap = None
         L.check(L.lib().epc_net_forward_profiled(ctypes.byref(cfg), packed.data_ptr(), L.ptr(xyz), nc, L.ptr(out),
                                                  ws.data_ptr(), ws.numel(), L.current_stream(),
                                                  profile.handle if profile is not None else None))
@@ -192,6 +196,19 @@ class InferenceEngine:
         nc = int(xyz_or_count.shape[0]) if torch.is_tensor(xyz_or_count) else int(xyz_or_count)
         if nc <= 0:
             return []
+        ov = getattr(self, "_last_overlap", None)
+        if self._ws is not None and self._last_cfg is None and ov is not None and ov[3] == nc:
+            # the last call went as one pass per lane (EPC-Net-L's two halves): every pass's words are still in its lane's slice
+            cfg, lanes, slice_bytes, _ = ov
+            mb = L.micro_batch_of(cfg, nc)
+            words = []
+            for p in range((nc + mb - 1) // mb):
+                n_p = min(mb, nc - p * mb)
+                arr = (ctypes.c_int32 * n_p)()
+                L.check(L.lib().epc_net_last_status(ctypes.byref(cfg), self._ws.data_ptr() + (p % lanes) * slice_bytes, n_p, arr,
+                                                    L.current_stream()))
+                words += [int(v) for v in arr]
+            return words
         if self._ws is None or self._last_cfg is None:
             # nothing ran yet, or the last call was dealt over the engine's lanes (num_clouds > micro_batch with in_flight > 1:
             # epc_net_forward_overlapped keeps one workspace slice per lane, so "the last pass's status words" do not exist in
