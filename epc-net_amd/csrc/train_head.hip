@@ -764,3 +764,247 @@ extern "C" int epc_group_sum_bwd(const float* dy, int rows_out, int G, int O, fl
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// The VLAD tail behind the hidden projection (loupe.py:323-331 + :61-101) as ONE launch each way -- nine and ten launches of 2-8 us
+// on (B G, O) and (B, O) tensors before (column moments + finish + apply, the group sum, the gating product, its BatchNorm's three,
+// the gate):
+//   y = bn1(h) over the B G rows (training mode: batch mean / population variance);   v[b] = sum_g y[b G + g]        (:323, :326-328)
+//   gl = v Wg;   gt = bn2(gl) over the B rows;   out = v * sigmoid(gt)                                                  (:75-100)
+// ONE workgroup of 1024 threads.  The column-wise parts: thread (column c = tid % O, slice q = tid / O), every reduction over rows on
+// the slices in parallel, meeting in LDS in slice order (bit-reproducible).  The (B, O) x (O, O) products on the matrix pipe: the B <= 32
+// rows are ONE 32-row tile in LDS (rows beyond B zero), a wave takes 32-column tiles, operands split into bf16 pieces exactly as the
+// per-op GEMMs split them (forward three pieces / six products, backward two / three) -- f32-accurate in BOTH arithmetics of the step:
+// products with at most 32 rows stay float32 under "bf16" too (oracle/epcnet_oracle_torch.py: bf16_product_rule; the per-op path ran
+// them on plain FMAs).  A first version on scalar FMAs with v broadcast from LDS took 106 / 146 us: one CU's LDS pipe.
+// O in {64, 128, 256}; B <= 32.
+// ----------------------------------------------------------------------------------------------------------------
+#include "train_chain_common.h"
+#define HT_THREADS 1024
+#define HT_ROWS 32
+
+// sum over the slices of red[slice][c] (slices in order) -> every thread of column c
+__device__ __forceinline__ float ht_meet(float part, float* red, int c, int q, int slices, int O) {
+    __syncthreads();
+    red[q * O + c] = part;
+    __syncthreads();
+    float t = 0.f;
+    for (int s = 0; s < slices; ++s) t += red[s * O + c];
+    return t;
+}
+
+// out[b][n] (+)= sum_k A[b][k] Bm(k, n) for the 32-row tile A (LDS, row stride O) and an (O, O) global matrix W: TRANS = false: Bm(k, n) =
+// W[k][n]; true: Bm(k, n) = W[n][k].  Wave w takes the 32-column tiles w, w + waves, ...; the result lands in `dst` (LDS, row stride O),
+// added to what is there when ACCUM.  P bf16 pieces per operand.
+template <int P, bool TRANS, bool ACCUM>
+__device__ __forceinline__ void ht_product(const float* A, const float* __restrict__ W, int O, float* dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, i = lane & 31, hh = lane >> 5;
+    for (int nt = wave; nt < O / 32; nt += nwaves) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < O / 16; ++s) {
+            float a8[8], b8[8];
+            ch_ld8(A + i * O + 16 * s + 8 * hh, a8);
+            if (TRANS) {
+                ch_ld8(W + (size_t)(32 * nt + i) * O + 16 * s + 8 * hh, b8);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b8[j] = W[(size_t)(16 * s + 8 * hh + j) * O + 32 * nt + i];
+            }
+            bf16x8 ap[P], bp[P];
+            ch_split<P>(a8, ap), ch_split<P>(b8, bp);
+            acc = ch_prod<P>(ap, bp, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* d = dst + mfma_row(r, hh) * O + 32 * nt + i;
+            *d = ACCUM ? *d + acc[r] : acc[r];
+        }
+    }
+}
+
+template <int P>
+__global__ __launch_bounds__(HT_THREADS) void hidden_tail_fwd_kernel(const float* __restrict__ h, int B, int G, int O, const float* __restrict__ gamma1,
+                                                                    const float* __restrict__ beta1, const float* __restrict__ Wg,
+                                                                    const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps,
+                                                                    float bessel1, float bessel2, float* __restrict__ mean1,
+                                                                    float* __restrict__ var1, float* __restrict__ var1u, float* __restrict__ v_out,
+                                                                    float* __restrict__ gl_out, float* __restrict__ mean2, float* __restrict__ var2,
+                                                                    float* __restrict__ var2u, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // v[32][O] | gl[32][O] | red[slices][O]
+    const int tid = threadIdx.x, c = tid % O, q = tid / O, slices = HT_THREADS / O, R = B * G;
+    float* vs = lds;
+    float* acc = lds + (size_t)HT_ROWS * O;
+    float* red = acc + (size_t)HT_ROWS * O;
+    // ---- bn1: batch moments of column c over the R rows (two passes: mean, then the centred second moment) ----
+    // (holding a slice's rows of h in registers across the three passes was built and measured: 24.8 us against 22.5 -- not kept)
+    float p = 0.f;
+#pragma unroll 8
+    for (int r = q; r < R; r += slices) p += h[(size_t)r * O + c];   // (unrolled: a row per iteration would be one dependent L2 round trip each)
+    const float m1 = ht_meet(p, red, c, q, slices, O) / (float)R;
+    p = 0.f;
+#pragma unroll 8
+    for (int r = q; r < R; r += slices) {
+        const float d = h[(size_t)r * O + c] - m1;
+        p += d * d;
+    }
+    const float v1 = ht_meet(p, red, c, q, slices, O) / (float)R;
+    const float s1 = (1.0f / sqrtf(v1 + eps)) * gamma1[c], t1 = beta1[c] - m1 * s1;   // y = z s + t (bn_affine's expression)
+    if (q == 0) mean1[c] = m1, var1[c] = v1, var1u[c] = v1 * bessel1;   // (the fused slim op feeds the Bessel-corrected variance to the moving average)
+    // ---- the group sums (rows beyond B: zeros -- the products' tile is 32 rows) ----
+#pragma unroll 2
+    for (int b = q; b < HT_ROWS; b += slices) {
+        float t = 0.f;
+        if (b < B) {
+#pragma unroll 4
+            for (int g = 0; g < G; ++g) t += h[(size_t)(b * G + g) * O + c] * s1 + t1;
+            v_out[(size_t)b * O + c] = t;
+        }
+        vs[b * O + c] = t;
+    }
+    __syncthreads();
+    ht_product<P, false, false>(vs, Wg, O, acc);   // gl = v Wg
+    __syncthreads();
+    // ---- bn2 over the B rows, the gate ----
+    p = 0.f;
+    for (int b = q; b < B; b += slices) p += acc[b * O + c];
+    const float m2 = ht_meet(p, red, c, q, slices, O) / (float)B;
+    p = 0.f;
+    for (int b = q; b < B; b += slices) {
+        const float d = acc[b * O + c] - m2;
+        p += d * d;
+    }
+    const float v2 = ht_meet(p, red, c, q, slices, O) / (float)B;
+    const float s2 = (1.0f / sqrtf(v2 + eps)) * gamma2[c], t2 = beta2[c] - m2 * s2;
+    if (q == 0) mean2[c] = m2, var2[c] = v2, var2u[c] = v2 * bessel2;
+    for (int b = q; b < B; b += slices) {
+        const float gl = acc[b * O + c], gt = gl * s2 + t2;
+        gl_out[(size_t)b * O + c] = gl;
+        out[(size_t)b * O + c] = vs[b * O + c] * (1.f / (1.f + expf(-gt)));
+    }
+}
+
+// Backward: from dout (B, O) and the forward's h, mean1, var1, v, gl, mean2, var2:
+//   s = sigmoid(bn2(gl));  dv = dout s;  dgt = dout v s (1 - s);  bn2': dgl = gamma2 rstd2 (dgt - dbeta2 / B - gt^ dgamma2 / B);
+//   dWg = v^T dgl;  dv += dgl Wg^T;  dy[b G + g] = dv[b];  bn1': dh = gamma1 rstd1 (dy - dbeta1 / R - z^ dgamma1 / R)
+template <int P>
+__global__ __launch_bounds__(HT_THREADS) void hidden_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ h, int B, int G, int O,
+                                                                    const float* __restrict__ gamma1, const float* __restrict__ mean1,
+                                                                    const float* __restrict__ var1, const float* __restrict__ v,
+                                                                    const float* __restrict__ gl, const float* __restrict__ Wg,
+                                                                    const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                                    const float* __restrict__ mean2, const float* __restrict__ var2, float eps,
+                                                                    float* __restrict__ dh, float* __restrict__ dgamma1,
+                                                                    float* __restrict__ dbeta1, float* __restrict__ dWg, float* __restrict__ dgamma2,
+                                                                    float* __restrict__ dbeta2) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // vs[32][O] | dgl[32][O] | dv[32][O] | red[slices][O]
+    const int tid = threadIdx.x, c = tid % O, q = tid / O, slices = HT_THREADS / O, R = B * G;
+    float* vs = lds;
+    float* dgls = lds + (size_t)HT_ROWS * O;
+    float* dvs = dgls + (size_t)HT_ROWS * O;
+    float* red = dvs + (size_t)HT_ROWS * O;
+    const float rs2 = 1.0f / sqrtf(var2[c] + eps), m2 = mean2[c], s2 = rs2 * gamma2[c], t2 = beta2[c] - m2 * s2;
+    // ---- the gate's backward; bn2's two sums (rows beyond B: zeros) ----
+    float pb = 0.f, pg = 0.f;
+#pragma unroll 4
+    for (int b = q; b < HT_ROWS; b += slices) {
+        float vv = 0.f, dvv = 0.f, dgt = 0.f;
+        if (b < B) {
+            const float glv = gl[(size_t)b * O + c], gt = glv * s2 + t2, s = 1.f / (1.f + expf(-gt)), d = dout[(size_t)b * O + c];
+            vv = v[(size_t)b * O + c];
+            dvv = d * s;
+            dgt = d * vv * (s * (1.f - s));
+            pb += dgt, pg += dgt * ((glv - m2) * rs2);
+        }
+        vs[b * O + c] = vv, dvs[b * O + c] = dvv, dgls[b * O + c] = dgt;   // (dgt for now)
+    }
+    const float db2 = ht_meet(pb, red, c, q, slices, O), dg2 = ht_meet(pg, red, c, q, slices, O);
+    if (q == 0) dbeta2[c] = db2, dgamma2[c] = dg2;
+#pragma unroll 4
+    for (int b = q; b < B; b += slices) {
+        const float zh = (gl[(size_t)b * O + c] - m2) * rs2;
+        dgls[b * O + c] = s2 * (dgls[b * O + c] - db2 / (float)B - zh * (dg2 / (float)B));
+    }
+    __syncthreads();
+    // ---- dWg = v^T dgl: 32 x 32 output tiles over the waves, the 32 rows are two k-steps ----
+    {
+        const int lane = tid & 63, wave = tid >> 6, nwaves = HT_THREADS / 64, i = lane & 31, hh = lane >> 5, T = O / 32;
+        for (int t = wave; t < T * T; t += nwaves) {
+            const int mt = t / T, nt = t % T;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float a8[8], b8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = vs[(16 * s + 8 * hh + j) * O + 32 * mt + i], b8[j] = dgls[(16 * s + 8 * hh + j) * O + 32 * nt + i];
+                bf16x8 ap[P], bp[P];
+                ch_split<P>(a8, ap), ch_split<P>(b8, bp);
+                acc = ch_prod<P>(ap, bp, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dWg[(size_t)(32 * mt + mfma_row(r, hh)) * O + 32 * nt + i] = acc[r];
+        }
+    }
+    ht_product<P, true, true>(dgls, Wg, O, dvs);   // dv += dgl Wg^T
+    __syncthreads();
+    // ---- the group sum's transpose and bn1's backward over the R rows ----
+    const float rs1 = 1.0f / sqrtf(var1[c] + eps), m1 = mean1[c], k1g = rs1 * gamma1[c];
+    pb = 0.f, pg = 0.f;
+#pragma unroll 8
+    for (int r = q; r < R; r += slices) {
+        const float dy = dvs[(r / G) * O + c];
+        pb += dy, pg += dy * ((h[(size_t)r * O + c] - m1) * rs1);
+    }
+    const float db1 = ht_meet(pb, red, c, q, slices, O), dg1 = ht_meet(pg, red, c, q, slices, O);
+    if (q == 0) dbeta1[c] = db1, dgamma1[c] = dg1;
+#pragma unroll 8
+    for (int r = q; r < R; r += slices) {
+        const float dy = dvs[(r / G) * O + c], zh = (h[(size_t)r * O + c] - m1) * rs1;
+        dh[(size_t)r * O + c] = k1g * (dy - db1 / (float)R - zh * (dg1 / (float)R));
+    }
+}
+
+static bool ht_shape_ok(int B, int G, int O) { return B > 0 && B <= HT_ROWS && G > 0 && (O == 64 || O == 128 || O == 256); }
+
+extern "C" int epc_hidden_tail_ok(int B, int G, int O) { return ht_shape_ok(B, G, O) ? 1 : 0; }
+
+extern "C" int epc_hidden_tail_fwd(const float* h, int B, int G, int O, const float* gamma1, const float* beta1, const float* Wg,
+                                   const float* gamma2, const float* beta2, float eps, float bessel1, float bessel2, float* mean1,
+                                   float* var1, float* var1u, float* v, float* gl, float* mean2, float* var2, float* var2u, float* out,
+                                   void* stream) {
+    EPC_CHECK_ARG(h && gamma1 && beta1 && Wg && gamma2 && beta2 && mean1 && var1 && var1u && v && gl && mean2 && var2 && var2u && out, "null pointer");
+    EPC_CHECK_ARG(ht_shape_ok(B, G, O), "shape not covered (epc_hidden_tail_ok)");
+    const size_t lds = ((size_t)2 * HT_ROWS * O + (size_t)(HT_THREADS / O) * O) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hidden_tail_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        epc_set_error("%s: hipFuncSetAttribute failed", __func__);
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(hidden_tail_fwd_kernel<3>, dim3(1), dim3(HT_THREADS), lds, (hipStream_t)stream, h, B, G, O, gamma1, beta1, Wg, gamma2, beta2, eps,
+                       bessel1, bessel2, mean1, var1, var1u, v, gl, mean2, var2, var2u, out);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+extern "C" int epc_hidden_tail_bwd(const float* dout, const float* h, int B, int G, int O, const float* gamma1, const float* mean1, const float* var1,
+                                   const float* v, const float* gl, const float* Wg, const float* gamma2, const float* beta2, const float* mean2,
+                                   const float* var2, float eps, float* dh, float* dgamma1, float* dbeta1, float* dWg,
+                                   float* dgamma2, float* dbeta2, void* stream) {
+    EPC_CHECK_ARG(dout && h && gamma1 && mean1 && var1 && v && gl && Wg && gamma2 && beta2 && mean2 && var2 && dh && dgamma1 && dbeta1 && dWg &&
+                      dgamma2 && dbeta2,
+                  "null pointer");
+    EPC_CHECK_ARG(ht_shape_ok(B, G, O), "shape not covered (epc_hidden_tail_ok)");
+    EPC_CHECK_ARG((reinterpret_cast<size_t>(Wg) & 15) == 0, "Wg must be 16-byte aligned");
+    const size_t lds = ((size_t)3 * HT_ROWS * O + (size_t)(HT_THREADS / O) * O) * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hidden_tail_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        epc_set_error("%s: hipFuncSetAttribute failed", __func__);
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(hidden_tail_bwd_kernel<2>, dim3(1), dim3(HT_THREADS), lds, (hipStream_t)stream, dout, h, B, G, O, gamma1, mean1, var1, v, gl, Wg,
+                       gamma2, beta2, mean2, var2, eps, dh, dgamma1, dbeta1, dWg, dgamma2, dbeta2);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}

@@ -59,6 +59,7 @@ EXPORTS = [
     "epc_h32_conv5_fwd_scratch_bytes", "epc_h32_conv5_fwd", "epc_h32_assign_scratch_bytes", "epc_h32_assign",
     "epc_h32_colgemm_scratch_bytes", "epc_h32_colgemm", "epc_h32_dx_scratch_bytes", "epc_h32_conv5_dx", "epc_h32_conv5_dx_bn",
     "epc_maxpool_points_fwd", "epc_maxpool_points_bwd", "epc_vlad_w2_grad", "epc_group_sum_fwd", "epc_group_sum_bwd",
+    "epc_hidden_tail_ok", "epc_hidden_tail_fwd", "epc_hidden_tail_bwd",
 ]
 EPC_NUM_STAGES = 10
 STAGE_NAMES = ["sort", "knn", "conv1", "block1", "block2", "block3", "block4", "conv5", "aggregate", "head"]
@@ -178,6 +179,9 @@ _lib.epc_vlad_df_tail.argtypes = [_P, _P, _P, _P, c_int, c_int, c_int, _P, ctype
 _lib.epc_bn_apply_bwd_given.argtypes = [_P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P]
 _lib.epc_gate_fwd.argtypes = [_P, _P, ctypes.c_long, _P, _P]
 _lib.epc_gate_bwd.argtypes = [_P, _P, _P, ctypes.c_long, _P, _P, _P]
+_lib.epc_hidden_tail_ok.argtypes = [c_int, c_int, c_int]
+_lib.epc_hidden_tail_fwd.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float] + [_P] * 9 + [_P]
+_lib.epc_hidden_tail_bwd.argtypes = [_P, _P, c_int, c_int, c_int] + [_P] * 10 + [c_float] + [_P] * 7
 _lib.epc_chain_parts.argtypes = [c_int]
 _lib.epc_chain_stats.argtypes = [_P, c_int, _P, _P]
 _lib.epc_chain_fwd_linear.argtypes = [_P] * 7 + [c_float, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]

@@ -154,6 +154,18 @@ class _VladBase(PoolingBaseModel):
         vlad = vlad.reshape(-1, C * F)
         vlad = vlad.reshape(-1, C * F // G)                                                      # :302 (groups)
         vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                       # :322
+        if self.is_training and self.gating and self.add_batch_norm and ops.hidden_tail_ok(int(vlad.shape[0]), G, O):
+            # :323-331 (+ :61-101) as ONE node: BatchNorm, the group sum, context gating
+            from .utils.tf_util import _ema_update
+            beta1, gamma1, mm1, mv1 = _slim_bn_variables("bn", O)
+            self._declare_gating(O)
+            beta2, gamma2, mm2, mv2 = _slim_bn_variables("gating_bn", O)
+            out, mean1, var1u, mean2, var2u = ops.HiddenTail.apply(vlad, gamma1, beta1, G, st[scoped("gating_weights")], gamma2, beta2,
+                                                                   BN_EPS)
+            for mm, mv, mean, varu in ((mm1, mv1, mean1, var1u), (mm2, mv2, mean2, var2u)):
+                _ema_update(mm, mean, SLIM_DECAY, scheduled=False)
+                _ema_update(mv, varu, SLIM_DECAY, scheduled=False)      # (the fused slim op: the Bessel-corrected batch variance)
+            return out
         vlad = _slim_batch_norm(vlad, "bn", self.is_training, fused=True)                        # :323
         if G > 1:
             vlad = ops.GroupSum.apply(vlad, G)                                                   # :326-328

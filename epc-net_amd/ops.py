@@ -1306,6 +1306,64 @@ class GroupSum(torch.autograd.Function):
         return dx, None
 
 
+# The VLAD tail behind the hidden projection -- its BatchNorm, the group sum, context gating (product, BatchNorm, sigmoid gate) -- as ONE
+# launch each way (csrc/train_head.hip: epc_hidden_tail_fwd / _bwd) instead of nine and ten of 2-8 us; False: the per-op path (the
+# second implementation tests/test_gpu_hidden_tail.py holds it to).
+HIDDEN_TAIL = True
+
+
+def hidden_tail_ok(rows, G, O):
+    return bool(HIDDEN_TAIL and rows % int(G) == 0 and L.lib().epc_hidden_tail_ok(int(rows) // int(G), int(G), int(O)))
+
+
+class HiddenTail(torch.autograd.Function):
+    """loupe.py:323-331 + :61-101 on h (B G, O), the hidden projection's output, in training mode:
+        y = slim.batch_norm(h);  v = reduce_sum over the G group rows;  out = v * sigmoid(slim.batch_norm(v @ gating_weights))
+    Returns (out (B, O), mean1, var1u, mean2, var2u): the batch means and the Bessel-corrected batch variances -- what the fused slim
+    op feeds its moving averages (the population variances normalise).  The gating product is f32-accurate in both arithmetics of the
+    step (at most 32 rows: oracle/epcnet_oracle_torch.py, bf16_product_rule)."""
+
+    @staticmethod
+    def forward(ctx, h, gamma1, beta1, G, Wg, gamma2, beta2, eps):
+        lib = L.lib()
+        h, Wg = h.contiguous(), Wg.contiguous()
+        R, O = (int(v) for v in h.shape)
+        G = int(G)
+        B = R // G
+        dev = h.device
+        vec = lambda: torch.empty(O, dtype=torch.float32, device=dev)
+        mat = lambda: torch.empty((B, O), dtype=torch.float32, device=dev)
+        mean1, var1, var1u, mean2, var2, var2u, v, gl, out = vec(), vec(), vec(), vec(), vec(), vec(), mat(), mat(), mat()
+        L.check(lib.epc_hidden_tail_fwd(h.data_ptr(), B, G, O, gamma1.data_ptr(), beta1.data_ptr(), Wg.data_ptr(), gamma2.data_ptr(),
+                                        beta2.data_ptr(), float(eps), R / max(R - 1, 1), B / max(B - 1, 1), mean1.data_ptr(), var1.data_ptr(),
+                                        var1u.data_ptr(), v.data_ptr(), gl.data_ptr(), mean2.data_ptr(), var2.data_ptr(), var2u.data_ptr(),
+                                        out.data_ptr(), _st()))
+        ctx.save_for_backward(h, gamma1, mean1, var1, v, gl, Wg, gamma2, beta2, mean2, var2)
+        ctx.G, ctx.eps = G, float(eps)
+        ctx.mark_non_differentiable(mean1, var1u, mean2, var2u)
+        ctx.set_materialize_grads(False)
+        return out, mean1, var1u, mean2, var2u
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        if dout is None:
+            return (None,) * 8
+        lib = L.lib()
+        h, gamma1, mean1, var1, v, gl, Wg, gamma2, beta2, mean2, var2 = ctx.saved_tensors
+        R, O = (int(x) for x in h.shape)
+        B = R // ctx.G
+        dev = h.device
+        dout = dout.contiguous()
+        vec = lambda: torch.empty(O, dtype=torch.float32, device=dev)
+        dh, dWg = torch.empty_like(h), torch.empty_like(Wg)
+        dg1, db1, dg2, db2 = vec(), vec(), vec(), vec()
+        L.check(lib.epc_hidden_tail_bwd(dout.data_ptr(), h.data_ptr(), B, ctx.G, O, gamma1.data_ptr(), mean1.data_ptr(), var1.data_ptr(),
+                                        v.data_ptr(), gl.data_ptr(), Wg.data_ptr(), gamma2.data_ptr(), beta2.data_ptr(), mean2.data_ptr(),
+                                        var2.data_ptr(), ctx.eps, dh.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dWg.data_ptr(),
+                                        dg2.data_ptr(), db2.data_ptr(), _st()))
+        return dh, dg1, db1, None, dWg, dg2, db2, None
+
+
 class MaxPoolPoints(torch.autograd.Function):
     """EPC-Net-L's global max over a cloud's points (models/epc-net-l.py:88-92: tf_util.max_pool2d with the kernel covering all N
     points): (B, N, C) -> (B, C); the gradient goes to the row that held the maximum (the first on ties, tf.nn.max_pool's)."""

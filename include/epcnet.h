@@ -506,6 +506,23 @@ int epc_assign_softmax_bwd(const float* da, const float* dsum, const float* a, c
 int epc_gate_fwd(const float* y, const float* g, long n, float* out, void* stream);
 int epc_gate_bwd(const float* dout, const float* y, const float* g, long n, float* dy, float* dg, void* stream);
 
+/* The VLAD tail behind the hidden projection as ONE launch each way (loupe.py:323-331 and :61-101): from h (B G, O), the projection's
+ * output,   y = batch_norm(h) over the B G rows (training mode; mean1 / var1 = batch mean / population variance);   v[b] = the sum of
+ * the G group rows of y (:326-328);   gl = v Wg (gating_weights, (O, O));   out = v * sigmoid(batch_norm(gl)) over the B rows
+ * (mean2 / var2); var1u / var2u = var x bessel1 / bessel2, what the fused slim op feeds its moving variance (rows / (rows - 1)).
+ * One workgroup; reductions meet in a fixed order (bit-reproducible); the (B, O) x (O, O) products on the matrix pipe with the per-op
+ * GEMMs' f32-accurate arithmetic (forward three bf16 pieces per operand: six products; backward two: three) in both arithmetics of the
+ * step: products with at most 32 rows stay float32 under "bf16" as well.  Shapes: epc_hidden_tail_ok(B, G, O): B <= 32, O in {64, 128, 256}.
+ * The backward takes the forward's h, mean1, var1, v, gl, mean2, var2 and returns dh, dgamma1, dbeta1, dWg, dgamma2, dbeta2. */
+int epc_hidden_tail_ok(int B, int G, int O);
+int epc_hidden_tail_fwd(const float* h, int B, int G, int O, const float* gamma1, const float* beta1, const float* Wg,
+                        const float* gamma2, const float* beta2, float eps, float bessel1, float bessel2, float* mean1,
+                        float* var1, float* var1u, float* v, float* gl, float* mean2, float* var2, float* var2u, float* out, void* stream);
+int epc_hidden_tail_bwd(const float* dout, const float* h, int B, int G, int O, const float* gamma1, const float* mean1, const float* var1,
+                        const float* v, const float* gl, const float* Wg, const float* gamma2, const float* beta2, const float* mean2,
+                        const float* var2, float eps, float* dh, float* dgamma1, float* dbeta1, float* dWg,
+                        float* dgamma2, float* dbeta2, void* stream);
+
 /* ---- The 64-channel backbone of the training step as a chain of fused launches (csrc/train_chain.hip) -----------------------
  * models/epc-net.py:66-134 in training mode (utils/tf_util.py:52-107, 454-519): every 64 -> 64 layer is followed by a training-mode
  * BatchNorm + ReLU whose batch statistics need all rows.  A producer leaves per-workgroup PARTIALS -- epc_chain_parts(rows) of
