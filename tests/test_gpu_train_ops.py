@@ -682,3 +682,70 @@ def test_vlad_w2_grad_and_group_sum_ops(dev):
     w = torch.randn(6, 256, generator=g).to(dev)
     (gx,) = torch.autograd.grad((y * w).sum(), x)
     assert torch.equal(gx, w[:, None, :].expand(6, 4, 256).reshape(24, 256))
+
+
+@pytest.mark.parametrize("ncl,n,kind", [(3, 4096, "uniform"), (2, 1000, "uniform"), (5, 96, "uniform"), (2, 2048, "ties"), (1, 8192 + 64, "uniform")])
+def test_transposed_graph_lists_are_the_sorted_inverse_of_the_knn_lists(dev, ncl, n, kind):
+    """epc_knn_transpose: for every point j, rdeg[j] entries at rlist[roff[j]..] = the ABSOLUTE rows i whose neighbour list holds j,
+    ascending -- against a numpy inversion of the lists; rows whose own list overflowed (cnt > cap: "ties": 200 copies of one point) are
+    not in the graph; twice the same bits."""
+    ops, L = H.pkg("ops"), H.pkg("lib")
+    pc = O.synthetic_clouds(ncl, n, 17)
+    if kind == "ties":
+        pc[0, 300:500] = pc[0, 11]
+    x = ops.morton_sort(torch.from_numpy(pc).to(dev))
+    g = ops.KnnGraph(x)
+    rdeg, roff, rlist = (t.cpu().numpy() for t in g.transposed())
+    idx, cnt = g.idx.cpu().numpy().reshape(ncl * n, -1), g.cnt.cpu().numpy().reshape(-1)
+    cap = idx.shape[1]
+    want = [[] for _ in range(ncl * n)]
+    for i in range(ncl * n):
+        if cnt[i] <= cap:
+            base = (i // n) * n
+            for j in idx[i, :cnt[i]]:
+                want[base + int(j)].append(i)
+    assert kind != "ties" or (cnt > cap).any()
+    for j in range(ncl * n):
+        assert rdeg[j] == len(want[j]), j
+        assert list(rlist[roff[j]:roff[j] + rdeg[j]]) == want[j], j          # (ascending: i runs upward)
+    for c in range(ncl):                                                      # a cloud's lists are packed back to back from its base
+        assert roff[c * n] == c * n * cap
+        assert np.array_equal(roff[c * n + 1:(c + 1) * n], roff[c * n] + np.cumsum(rdeg[c * n:(c + 1) * n - 1]))
+    g2 = ops.KnnGraph(x)
+    rdeg2, roff2, rlist2 = (t.cpu().numpy() for t in g2.transposed())
+    assert np.array_equal(rdeg2, rdeg) and np.array_equal(roff2, roff)
+    for c in range(ncl):
+        used = int(rdeg[c * n:(c + 1) * n].sum())
+        assert np.array_equal(rlist2[c * n * cap:c * n * cap + used], rlist[c * n * cap:c * n * cap + used])
+
+
+def test_transposed_graph_with_a_hub_longer_than_a_wave(dev):
+    """epc_knn_transpose on hand-made lists: target 5 of cloud 0 is in every third source's list (683 entries: the one-lane insertion sort
+    of lists longer than 64)."""
+    L = H.pkg("lib")
+    lib = L.lib()
+    ncl, n, cap = 2, 2048, 32
+    rng = np.random.default_rng(3)
+    idx = np.zeros((ncl * n, cap), dtype=np.int32)
+    cnt = np.zeros(ncl * n, dtype=np.int32)
+    for i in range(ncl * n):
+        t = set(rng.choice(n, size=int(rng.integers(18, 25)), replace=False).tolist())
+        if i % 3 == 0 and i < n:
+            t.add(5)
+        t = sorted(t)[:cap]
+        idx[i, :len(t)], cnt[i] = t, len(t)
+    d_idx, d_cnt = torch.from_numpy(idx).to(dev), torch.from_numpy(cnt).to(dev)
+    M = ncl * n
+    rdeg, roff, cursor = (torch.empty(M, dtype=torch.int32, device=dev) for _ in range(3))
+    rlist = torch.empty(M * cap, dtype=torch.int32, device=dev)
+    L.check(lib.epc_knn_transpose(d_idx.data_ptr(), d_cnt.data_ptr(), cap, ncl, n, rdeg.data_ptr(), roff.data_ptr(), cursor.data_ptr(),
+                                  rlist.data_ptr(), L.current_stream()))
+    torch.cuda.synchronize()
+    rdeg, roff, rlist = rdeg.cpu().numpy(), roff.cpu().numpy(), rlist.cpu().numpy()
+    want = [[] for _ in range(M)]
+    for i in range(M):
+        for j in idx[i, :cnt[i]]:
+            want[(i // n) * n + int(j)].append(i)
+    for j in range(M):
+        assert rdeg[j] == len(want[j]) and list(rlist[roff[j]:roff[j] + rdeg[j]]) == want[j], j
+    assert rdeg[5] > 600
