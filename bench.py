@@ -625,6 +625,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.same_device:
         local_rank = 0
+        if world > 1:
+            # Two ranks on ONE GPU: the persistent forward chain needs all its workgroups co-resident (one per CU) and two processes'
+            # launches would hold each other's CUs -- each would sit in its first barrier until its spin budget ran out.  The dry run
+            # keeps the launch chain; on real ranks (one GPU each) nothing shares the device with the forward.
+            pkg("ops").CHAIN_PERSIST_FWD = False
     if args.backend == "nccl" and args.same_device and world > 1:
         raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
     torch.cuda.set_device(local_rank)

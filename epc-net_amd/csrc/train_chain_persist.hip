@@ -30,7 +30,8 @@
 //
 // Safety.  The grid is at most the CU count and the host checks with the occupancy query that every workgroup is co-resident; every
 // spin is bounded by a wall-clock budget (s_memrealtime), a time-out sets the sticky error word and every workgroup leaves at its next
-// poll; a launch that finds the error word set leaves at once.  epc_chain_persist_status() reads the word, _reset() clears it.
+// poll; a launch that finds the error word set leaves at once.  Either way the launch leaves NaN in the concat (a row per workgroup), so
+// the loss is NaN; epc_chain_persist_status() reads the word, _reset() clears it.
 #include "train_chain_common.h"
 
 #define PST_WAVES 12                 // one 32-row tile per wave: at most 384 rows per workgroup (98 304 rows on 256 CUs)
@@ -354,7 +355,11 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
     const int rows = g.rows;
     char* ws = reinterpret_cast<char*>(g.a.workspace);
     unsigned* sync = reinterpret_cast<unsigned*>(ws);
-    if (ld_coh(sync + PST_W_ERR) != 0u) return;   // an earlier launch was abandoned and not reset
+    if (ld_coh(sync + PST_W_ERR) != 0u) {         // an earlier launch was abandoned and not reset: NaN out (as an abandoned launch does)
+        const int lb_ = xcd_contiguous_block(blockIdx.x, gridDim.x);
+        for (int o = threadIdx.x; o < g.width; o += blockDim.x) g.a.cat[(size_t)lb_ * g.wg_rows * g.width + o] = __int_as_float(0x7fc00000);
+        return;
+    }
     PstCtx cx = pst_init(sync, g.budget);
 #ifdef PST_STAMPS
     long long* stamps = reinterpret_cast<long long*>(ws + PST_WS_STAMPS) + (size_t)blockIdx.x * 64;
@@ -367,6 +372,11 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
     const int base = wg0 + wave * 32;   // the wave's tile (wave < tiles)
     const bool have = wave < tiles;
     int phase = 0;
+    // an abandoned launch leaves NaN in the first row of the workgroup's slice of the concat: whatever consumes the result sees it
+    // (the loss is NaN) even when nobody asks epc_chain_persist_status
+    auto poison = [&]() {
+        for (int o = threadIdx.x; o < g.width; o += blockDim.x) g.a.cat[(size_t)wg0 * g.width + o] = __int_as_float(0x7fc00000);
+    };
     auto stats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_PARTIALS) + (size_t)ph * PST_MAX_PARTS * 192; };
     auto gstats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_GROUPS) + (size_t)ph * 8 * 384; };
     // one barrier: (the caller has posted its partial) -> the group's first workgroup reduces its group -> everyone merges the groups
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         const int i = lane & 31, h = lane >> 5;
         const int p4 = lane >> 4, q = lane & 15;
         // ================= barrier: z0's moments =================
-        if (!barrier_moments(B.in_bias, B.gamma0, B.beta0, B.mean0, B.var0)) return;
+        if (!barrier_moments(B.in_bias, B.gamma0, B.beta0, B.mean0, B.var0)) { poison(); return; }
         PST_STAMP();
         // ================= phase G =================
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, piv[2] = {0.f, 0.f};
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         PST_STAMP();
         pst_stage_fwd_weights<PF>(B.Wb, Wf);   // (every wave is past its products: pst_post_stats' barrier) -- under the wait
         // ================= barrier: za's moments =================
-        if (!barrier_moments(B.ba, B.gamma_a, B.beta_a, B.mean_a, B.var_a)) return;
+        if (!barrier_moments(B.ba, B.gamma_a, B.beta_a, B.mean_a, B.var_a)) { poison(); return; }
         PST_STAMP();
         // ================= phase M =================
         s1[0] = s1[1] = s2[0] = s2[1] = piv[0] = piv[1] = 0.f;
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         PST_STAMP();
         if (B.W0_next) pst_stage_fwd_weights<PF>(B.W0_next, Wf);
         // ================= barrier: zb's moments =================
-        if (!barrier_moments(B.bb, B.gamma_b, B.beta_b, B.mean_b, B.var_b)) return;
+        if (!barrier_moments(B.bb, B.gamma_b, B.beta_b, B.mean_b, B.var_b)) { poison(); return; }
         PST_STAMP();
         // ================= phase H =================
         s1[0] = s1[1] = s2[0] = s2[1] = piv[0] = piv[1] = 0.f;

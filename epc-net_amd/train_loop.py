@@ -131,6 +131,10 @@ class Trainer:
                 continue
             loss, lr, _ = self.step.step(*batch, epoch=epoch, graph=self.graph) if self.graph else self.step.step(*batch, epoch=epoch)
             losses.append(float(loss))
+            if not np.isfinite(losses[-1]):
+                # a persistent chain launch that was abandoned (a grid barrier ran out of its spin budget) leaves NaN: say so, and reset
+                from . import ops
+                ops.chain_persist_check()
             self.history.append({"epoch": epoch, "iter": i, "loss": losses[-1], "lr": lr})
             self.log.info("Epoch: [%d/%d][%d/%d] Loss %.4f lr %.8f", epoch, self.max_epoch, i + 1, iter_num, losses[-1], lr)
             if i % 200 == 7 and self.TEST_QUERIES is not None:                                  # train.py:523-594

@@ -580,7 +580,7 @@ int epc_chain_dw_sum(int layers, const float* const* partials, float* const* dW,
  * differs: group partials by row range).  Usable when epc_chain_persist_ok(rows) != 0: at most 12 tiles per workgroup (rows <=
  * 384 x CUs) and every workgroup co-resident by the occupancy query.  Nothing else may need the CUs these workgroups wait on: do not
  * run it beside a kernel that waits for IT.  Every spin is bounded (spin_ticks of the 100-MHz s_memrealtime, 0 = a quarter second): on
- * a time-out the sticky error word of the workspace is set, every workgroup leaves, results are undefined and every later launch on
+ * a time-out the sticky error word of the workspace is set, every workgroup leaves, the concat holds NaN rows (so the loss is NaN) and every later launch on
  * the same workspace returns at once -- epc_chain_persist_status() (synchronises the stream) then returns EPC_EHIP until
  * epc_chain_persist_reset().  workspace: epc_chain_persist_workspace_bytes() bytes, zeroed ONCE with epc_chain_persist_init() and then
  * left to the library (launch sequence number, the barriers' tagged partials); one launch at a time per workspace. */

@@ -34,6 +34,9 @@ def _worker(rank, world, port, graph, overlap, out_dir):
     dev = torch.device("cuda:0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     TR, V = H.pkg("training"), H.pkg("variables")
+    # (two processes on ONE GPU: the persistent forward chain wants its workgroups co-resident, and two such launches from two processes
+    # could hold each other's CUs until a spin budget ran out -- real ranks have a GPU each; here the launch chain)
+    H.pkg("ops").CHAIN_PERSIST_FWD = False
     params = dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, DP_OVERLAP=overlap)
     st = V.reset_default_store(device=dev, seed=321)
     ts = TR.TrainStep(params, st, outer=H.OUTER)
