@@ -37,6 +37,9 @@
 // barrier per stage; a column chunk's result leaves as one dword (two adjacent columns) per lane and row: whole 128-byte runs.  Per stage and wave the
 // pivot-shifted column sums go to LDS; 64 threads merge the four waves of the PREVIOUS stage behind the barrier that exists anyway.
 // rows a multiple of 32.  stats: [workgroups][3][1024] (tile_rows = 128 for epc_moments_finalize_launch).
+// (Round 6, VERDICT r5 #4: SIXTY-FOUR rows per wave -- two A fragments per B-fragment read, 256-row workgroups, 238 registers, two
+// workgroups per CU -- was built, was parity-green and measured 103.9 us against 86.5 at 18 clouds (104.7 / 93.9 at 22), pack and
+// finalize launches included: half the LDS reads do not pay for a third less occupancy.  Not kept; the other kernels were not rebuilt.)
 // ----------------------------------------------------------------------------------------------------------------
 #define C5_KS 16
 #define C5_STAGE_U4 (8 * 2 * 64)   // 16 KB: half the k-steps of a 64-column chunk ([k-step 8][nt 2][lane])
