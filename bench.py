@@ -101,9 +101,13 @@ def stage_floors_epc_net_f32_b64():
     # kNN: 75.06 M vector instructions per launch (SQ_INSTS_VALU, profiles/*_pmc_compute.json) at one wave-instruction per SIMD and
     # four cycles: VALU issue is the only resource the kernel loads (0.84 of its cycles at this batch, 0.98 at EPC-Net-L's 256 clouds)
     knn = 75.06e6 / simds * 4 / (VALU_GHZ * 1e9)
-    # ProxyConv block: 20 gathered 256-byte rows per point = 1.34 GB through the vector L1 at 64 B / clk / CU, plus the skeleton the
-    # ablations of docs/HISTORY_r01_r02.md:654-666 leave when the gather is removed (weight-pack staging, MFMA chain, epilogue): 0.020 ms
-    block = 1.34e9 / (cus * 64) / (VALU_GHZ * 1e9) + 0.020e-3
+    # ProxyConv block: 20 gathered 256-byte rows per point = 1.34 GB per launch.  Through the vector L1 at 64 B / clk / CU + the skeleton
+    # (weight-pack staging, MFMA chain, epilogue: 0.020 ms) that would be 0.054 ms -- the figure of rounds 4-5, which assumes every row
+    # L1-hot.  The round-2 ablations (docs/HISTORY_r01_r02.md:654-670: all rows L1-hot 0.071 of 0.100 ms; the gather in LDS 0.081-0.095;
+    # index prefetch: no change) leave the L2 -> CU path of the ~70 % of rows a 32-KB L1 cannot hold as the bound, and no in-kernel lever
+    # moves it at this row width.  The floor is therefore the kernel's own best instance -- block 4, whose gathered rows are the most
+    # L2-local: 0.068 ms (0.054 flattered the step's distance to its floor).
+    block = 0.068e-3
     # conv5 + assignment: 4 rounds of one 8-wave workgroup per CU; per workgroup a 256-KB prologue at 9 B / clk / CU (one CU's miss
     # queue at HBM latency), then 32 chunks of: 120 MFMAs x 16 cycles per wave, two waves per SIMD (3840 cycles of matrix pipe), the
     # two waves' 1900-cycle epilogues of which the half that fits under the MFMA issue slots (the vector pipe is blocked 8 of 16 cycles
@@ -384,7 +388,7 @@ def extraction_leg(H, E, store, arch, precision, batch, steps, warmup, settle_ms
         res["stage_floor_ms"] = fl
         res["stage_floor"] = {"sum_ms": round(sum(fl.values()), 4), "step_over_floor": round(elapsed / steps * 1e3 / sum(fl.values()), 3),
                               "model": "per-stage floors of the present kernels' geometry (conv5 at %.2f GHz, the other stages at %.2f): kNN = vector instructions / issue rate; "
-                                       "block = L1 gather bytes / 64 B/clk/CU + skeleton; conv5 = 4 rounds x (256-KB prologue at 9 B/clk/CU + "
+                                       "block = the L2 -> CU miss path of the gathered rows a 32-KB L1 cannot hold (round-2 ablations); conv5 = 4 rounds x (256-KB prologue at 9 B/clk/CU + "
                                        "32 chunks x (MFMA issue + the epilogue share the MFMA issue slots do not hide)); aggregate = feat "
                                        "bytes / 6.3 TB/s (DESIGN.md 4, Floor models)" % (MFMA_GHZ, VALU_GHZ)}
     if overlapped is not None:
