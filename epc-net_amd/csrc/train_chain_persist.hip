@@ -377,6 +377,17 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
     auto poison = [&]() {
         for (int o = threadIdx.x; o < g.width; o += blockDim.x) g.a.cat[(size_t)wg0 * g.width + o] = __int_as_float(0x7fc00000);
     };
+    // The wave's tile as it stands -> its rows of a dense (rows, 64) tensor, 16 lanes x float4 per row.  The tensors only LATER launches
+    // read (za, zb for the backward; the concat) leave this way AFTER the phase's partial is posted: their stores drain under the
+    // barrier's round trips instead of in front of the post (a wave's stores and the loads of its polls retire in order).
+    auto store_tile_rows = [&](float* dst) {
+        const int ln = pst_tid() & 63, p4_ = ln >> 4, q_ = ln & 15;
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int rl = 4 * r8 + p4_, pt = base + rl;
+            if (pt < rows) *reinterpret_cast<float4*>(dst + (size_t)pt * 64 + 4 * q_) = *reinterpret_cast<const float4*>(tile + rl * CH_STG_STRIDE + 4 * q_);
+        }
+    };
     auto stats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_PARTIALS) + (size_t)ph * PST_MAX_PARTS * 192; };
     auto gstats_of = [&](int ph) { return reinterpret_cast<pst_gran*>(ws + PST_WS_GROUPS) + (size_t)ph * 8 * 384; };
     // one barrier: (the caller has posted its partial) -> the group's first workgroup reduces its group -> everyone merges the groups
@@ -510,7 +521,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in registers: the tile takes za next
             const float b0 = B.ba ? B.ba[i] : 0.f, b1 = B.ba ? B.ba[32 + i] : 0.f;
-            float* zlane = B.za + (size_t)(base + 4 * h) * 64 + i;   // the lane's rows are base + 4 h + (r & 3) + 8 (r >> 2): constant offsets
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x16 acc;
@@ -533,7 +543,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
                         const float dlt = v - piv[nt];
                         s1[nt] += dlt;
                         s2[nt] += dlt * dlt;
-                        zlane[rl4 * 64 + 32 * nt] = v + bv;
                     }
                     tile[rl * CH_STG_STRIDE + 32 * nt + i] = v + bv;
                 }
@@ -543,6 +552,7 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         PST_STAMP();
         pst_post_stats(s1, s2, piv, my_rows, sred, snrows, stats_of(phase) + (size_t)cx.lb * 192, pst_tag(cx, phase));
         PST_STAMP();
+        if (have) store_tile_rows(B.za);       // (after the post: under the barrier)
         pst_stage_fwd_weights<PF>(B.Wb, Wf);   // (every wave is past its products: pst_post_stats' barrier) -- under the wait
         // ================= barrier: za's moments =================
         if (!barrier_moments(B.ba, B.gamma_a, B.beta_a, B.mean_a, B.var_a)) { poison(); return; }
@@ -564,7 +574,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // in registers: the tile takes zb next
             const float b0 = B.bb ? B.bb[i] : 0.f, b1 = B.bb ? B.bb[32 + i] : 0.f;
-            float* zlane = B.zb + (size_t)(base + 4 * h) * 64 + i;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x16 acc;
@@ -587,7 +596,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
                         const float dlt = v - piv[nt];
                         s1[nt] += dlt;
                         s2[nt] += dlt * dlt;
-                        zlane[rl4 * 64 + 32 * nt] = v + bv;
                     }
                     tile[rl * CH_STG_STRIDE + 32 * nt + i] = v + bv;
                 }
@@ -596,6 +604,7 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         PST_STAMP();
         pst_post_stats(s1, s2, piv, my_rows, sred, snrows, stats_of(phase) + (size_t)cx.lb * 192, pst_tag(cx, phase));
         PST_STAMP();
+        if (have) store_tile_rows(B.zb);
         if (B.W0_next) pst_stage_fwd_weights<PF>(B.W0_next, Wf);
         // ================= barrier: zb's moments =================
         if (!barrier_moments(B.bb, B.gamma_b, B.beta_b, B.mean_b, B.var_b)) { poison(); return; }
@@ -604,8 +613,6 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         s1[0] = s1[1] = s2[0] = s2[1] = piv[0] = piv[1] = 0.f;
         if (have) {
             const float4 cs = *reinterpret_cast<const float4*>(&coef[0][4 * q]), ct = *reinterpret_cast<const float4*>(&coef[1][4 * q]);
-            float* cat_b = g.a.cat + 64 * b;
-            unsigned short* cat16_b = g.a.cat_bf16 ? (unsigned short*)g.a.cat_bf16 + 64 * b : nullptr;
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8) {
                 const int rl = 4 * r8 + p4, pt = base + rl;
@@ -614,16 +621,8 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
                 v.x = fmaxf(z.x * cs.x + ct.x, 0.f), v.y = fmaxf(z.y * cs.y + ct.y, 0.f), v.z = fmaxf(z.z * cs.z + ct.z, 0.f),
                 v.w = fmaxf(z.w * cs.w + ct.w, 0.f);
                 v.x += xmr[r8].x, v.y += xmr[r8].y, v.z += xmr[r8].z, v.w += xmr[r8].w;
-                if (pt < rows) {
-                    *reinterpret_cast<float4*>(cat_b + (size_t)pt * g.width + 4 * q) = v;
-                    if (cat16_b) {
-                        const pst_bf16x4 pk = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                        *reinterpret_cast<uint2*>(cat16_b + (size_t)pt * g.width + 4 * q) = __builtin_bit_cast(uint2, pk);
-                    }
-                } else {
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                *reinterpret_cast<float4*>(tile + rl * CH_STG_STRIDE + 4 * q) = v;
+                if (pt >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(tile + rl * CH_STG_STRIDE + 4 * q) = v;   // (the concat's slice leaves from here after the post)
             }
             if (B.W0_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -669,8 +668,26 @@ __global__ __launch_bounds__(64 * PST_WAVES) void chain_fwd_persist_kernel(PstFw
         if (B.W0_next) {
             pst_post_stats(s1, s2, piv, my_rows, sred, snrows, stats_of(phase) + (size_t)cx.lb * 192, pst_tag(cx, phase));
             PST_STAMP();
-            pst_stage_fwd_weights<PF>(g.a.blk[b + 1].Wa, Wf);
         }
+        if (have) {   // the block's slice of the concat (and its bf16 copy) from the tile: after the post, under the barrier
+            const int ln = pst_tid() & 63, p4_ = ln >> 4, q_ = ln & 15;
+            float* cat_b = g.a.cat + 64 * b;
+            unsigned short* cat16_b = g.a.cat_bf16 ? (unsigned short*)g.a.cat_bf16 + 64 * b : nullptr;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int rl = 4 * r8 + p4_, pt = base + rl;
+                if (pt < rows) {
+                    const float4 v = *reinterpret_cast<const float4*>(tile + rl * CH_STG_STRIDE + 4 * q_);
+                    *reinterpret_cast<float4*>(cat_b + (size_t)pt * g.width + 4 * q_) = v;
+                    if (cat16_b) {
+                        const pst_bf16x4 pk = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                        *reinterpret_cast<uint2*>(cat16_b + (size_t)pt * g.width + 4 * q_) = __builtin_bit_cast(uint2, pk);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is read: the next block's gather stages d in it
+        }
+        if (B.W0_next) pst_stage_fwd_weights<PF>(g.a.blk[b + 1].Wa, Wf);
     }
     pst_exit(cx);
 }
