@@ -439,6 +439,9 @@ def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0, n_neg=14
     del losses[:]
     elapsed = H.timed(run(True), steps)
     loss_vals = [float(x) for x in losses]
+    ops = pkg("ops")
+    ops.chain_persist_check(H.device)                          # an abandoned grid barrier of the persistent forward chain fails the leg loudly
+    persistent = bool(ops.CHAIN_PERSIST_FWD and pkg("lib").lib().epc_chain_persist_ok(ncl * N_POINTS))
     flops = 3.0 * FLOPS_PER_CLOUD["epc-net"] * ncl
     tflops = flops * steps / elapsed / 1e12
     ms = elapsed / steps * 1e3
@@ -467,6 +470,8 @@ def train_step_leg(H, steps, warmup, precision="bf16x6", eager_steps=0, n_neg=14
            "dtype": ("bf16x6 / f16x3 forward, bf16x3 backward GEMMs (f32-accurate), f32 tensors" if precision == "bf16x6" else
                      "bf16: the (rows, 1024) activations and gradients of conv5 .. VLAD stored as bf16, one bf16 value per GEMM "
                      "operand, f32 accumulate / statistics / master weights (the 64-channel backbone's tensors are f32)"),
+           "backbone_forward": ("one persistent launch: a workgroup per CU keeps its rows, a grid-wide barrier per BatchNorm (csrc/train_chain_persist.hip)"
+                                if persistent else "13 fused launches (csrc/train_chain.hip)"),
            "tflops": round(tflops, 2), "algorithmic_flops_per_step": flops,
            # the whole step against the dense 16-bit matrix peak (96 % of its FLOPs are dense contractions)
            "roofline": roof,

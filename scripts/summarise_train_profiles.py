@@ -51,7 +51,10 @@ def model_bytes(prec, ncl, n=4096):
     r64, r256, r1024 = R * 64, R * 256, R * 1024
     # backbone chain (11 layers of 64 channels, f32 tensors in both arithmetics): per forward linear launch read z + write z (+ xm, cat
     # slice on the block heads); per gather launch read the lists + z0, write xm, d, za; backward the mirror image with dy / dx
-    chain_fwd = 8 * (2 * r64 * f4) + 4 * (3 * r64 * f4 + R * 32 * 4 + r64 * f4) + 4 * (2 * r64 * f4)
+    # (round 6: the forward is ONE persistent launch -- the input's moments read z0 once; per block the gather reads the lists and z0 and
+    # writes d and za, conv_b writes zb, the block's head writes its slice of the concat and the next z0: za, zb and the neighbour mean
+    # are handed on in LDS / registers and never re-read; the launch chain it replaced moved 40 (rows, 64) tensors, this one 24)
+    chain_fwd = r64 * f4 + 4 * (3 * r64 * f4 + R * 32 * 4) + 4 * (r64 * f4) + 4 * (r64 * f4) + 3 * (r64 * f4)
     chain_bwd = 11 * (4 * r64 * f4) + 4 * (3 * r64 * f4 + R * 32 * 4)
     cat16 = r256 * 2 if prec == "bf16" else 0
     if prec == "bf16":
