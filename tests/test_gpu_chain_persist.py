@@ -63,6 +63,7 @@ print("CHILD OK")
 
 
 @pytest.mark.parametrize("arch,ncl,n,kind,precision", [("epc-net", 3, 256, "uniform", "bf16x6"), ("epc-net-l", 5, 96, "uniform", "bf16x6"),
+                                                      ("epc-net", 2, 32, "uniform", "bf16x6"),          # two workgroups of one wave: two groups of one
                                                       ("epc-net", 2, 256, "ties", "bf16x6"), ("epc-net", 18, 4096, "uniform", "bf16x6"),
                                                       ("epc-net", 22, 4096, "uniform", "bf16"), ("epc-net", 7, 1000, "uniform", "bf16")])
 def test_persistent_chain_equals_the_launch_chain(dev, arch, ncl, n, kind, precision):
@@ -159,3 +160,15 @@ def test_abandoned_barrier_is_reported_not_hung(dev):
     finally:
         ops.CHAIN_SPIN_TICKS = prev_ticks
         ops.CHAIN_PERSIST_FWD = prev_flags
+
+
+def test_rows_beyond_the_persistent_form_take_the_launch_chain(dev):
+    """More than twelve 32-row tiles per workgroup (25 x 4096 rows on 256 CUs: thirteen) is not covered: epc_chain_persist_ok says so and
+    ProxyConvChain takes the launches -- same interface, no error."""
+    lib = H.pkg("lib").lib()
+    assert lib.epc_chain_persist_ok(24 * 4096) == 1 and lib.epc_chain_persist_ok(25 * 4096) == 0
+    w = O.seeded_weights("epc-net-l", 4)
+    pc = O.synthetic_clouds(25, 4096, 5)
+    a = _with_persist(True, lambda: _backbone("epc-net-l", w, pc, dev, True))
+    b = _with_persist(False, lambda: _backbone("epc-net-l", w, pc, dev, True))
+    assert np.array_equal(a[0], b[0])
