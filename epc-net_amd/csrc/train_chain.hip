@@ -875,15 +875,17 @@ __global__ __launch_bounds__(256) void chain_dw_sum_kernel(ChDwSumArgs g) {
     }
 }
 
-// the points of each cloud whose neighbour list overflowed (cnt > cap), ascending: one workgroup per cloud
-__global__ __launch_bounds__(256) void knn_overflow_list_kernel(const int32_t* __restrict__ cnt, int cap, int n,
-                                                                int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf_list) {
-    __shared__ int wtot[4];
+// the points of each cloud whose neighbour list overflowed (cnt > cap), ascending: one workgroup per cloud (1024 threads: four rounds of
+// three barriers for 4096 points instead of sixteen)
+#define OVF_THREADS 1024
+__global__ __launch_bounds__(OVF_THREADS) void knn_overflow_list_kernel(const int32_t* __restrict__ cnt, int cap, int n,
+                                                                        int32_t* __restrict__ ovf_cnt, int32_t* __restrict__ ovf_list) {
+    __shared__ int wtot[OVF_THREADS / 64];
     __shared__ int carry;
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += 256) {
+    for (int j0 = 0; j0 < n; j0 += OVF_THREADS) {
         const int j = j0 + tid;
         const bool on = j < n && cnt[(size_t)cloud * n + j] > cap;
         const unsigned long long bal = __ballot(on);
@@ -894,7 +896,11 @@ __global__ __launch_bounds__(256) void knn_overflow_list_kernel(const int32_t* _
         for (int w = 0; w < wave; ++w) off += wtot[w];
         if (on) ovf_list[(size_t)cloud * n + off + before] = j;
         __syncthreads();
-        if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < OVF_THREADS / 64; ++w) t += wtot[w];
+            carry += t;
+        }
         __syncthreads();
     }
     if (tid == 0) ovf_cnt[cloud] = carry;
@@ -1085,7 +1091,7 @@ extern "C" int epc_chain_dw_sum(int layers, const float* const* partials, float*
 extern "C" int epc_knn_overflow_lists(const int32_t* cnt, int cap, int num_clouds, int n, int32_t* ovf_cnt, int32_t* ovf_list,
                                       void* stream) {
     EPC_CHECK_ARG(cnt && ovf_cnt && ovf_list && num_clouds > 0 && n > 0 && cap >= EPC_KNN_SELECT, "null pointer / bad shape");
-    hipLaunchKernelGGL(knn_overflow_list_kernel, dim3(num_clouds), dim3(256), 0, (hipStream_t)stream, cnt, cap, n, ovf_cnt, ovf_list);
+    hipLaunchKernelGGL(knn_overflow_list_kernel, dim3(num_clouds), dim3(OVF_THREADS), 0, (hipStream_t)stream, cnt, cap, n, ovf_cnt, ovf_list);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

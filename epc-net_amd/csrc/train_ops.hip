@@ -2537,12 +2537,12 @@ extern "C" int epc_neighbour_mean_diff_fwd(const float* x, const float* xyz, con
 // becomes a gather like the forward.  Rows with more than `cap` entries (exact ties: duplicated / zero-padded clouds)
 // are not listed; the scatter kernel adds their contributions afterwards.
 // Layout: cloud c owns rlist[c*n*cap .. +n*cap); roff[j] = start of j's list (absolute), rdeg[j] = its length.
-// (LANES lanes per point: 32 when the lists have at most 32 slots -- two points per wave, half the waves: round 6)
-template <int LANES>
+// (two points per wave -- 32 lanes each when the lists have at most 32 slots, half the waves -- was measured in round 6: count 20.8 -> 22.5 us,
+// fill 26.7 -> 35.5 us at 18 x 4096; an LDS-segment rewrite, count + fill + sort per (cloud, 1024 targets) workgroup: 118 us against 89)
 __global__ __launch_bounds__(256) void transpose_count_kernel(const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ cnt, int cap, int total_points,
                                                               int n, int32_t* __restrict__ rdeg) {
-    const int g = blockIdx.x * (256 / LANES) + threadIdx.x / LANES, lane = threadIdx.x % LANES;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= total_points) return;
     const int c = cnt[g];
     if (c > cap) return;
@@ -2580,12 +2580,11 @@ __global__ __launch_bounds__(1024) void transpose_scan_kernel(const int32_t* __r
     }
 }
 
-template <int LANES>
 __global__ __launch_bounds__(256) void transpose_fill_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
                                                              int cap, int total_points, int n,
                                                              const int32_t* __restrict__ roff, int32_t* __restrict__ cursor,
                                                              int32_t* __restrict__ rlist) {
-    const int g = blockIdx.x * (256 / LANES) + threadIdx.x / LANES, lane = threadIdx.x % LANES;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= total_points) return;
     const int c = cnt[g];
     if (c > cap) return;
@@ -2636,12 +2635,9 @@ extern "C" int epc_knn_transpose(const int32_t* idx, const int32_t* cnt, int cap
         return EPC_EHIP;
     }
     const unsigned blocks = (unsigned)((total + 3) / 4);
-    const unsigned blocks8 = (unsigned)((total + 7) / 8);
-    if (cap <= 32) hipLaunchKernelGGL(transpose_count_kernel<32>, dim3(blocks8), dim3(256), 0, st, idx, cnt, cap, (int)total, n, rdeg);
-    else hipLaunchKernelGGL(transpose_count_kernel<64>, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, rdeg);
+    hipLaunchKernelGGL(transpose_count_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, rdeg);
     hipLaunchKernelGGL(transpose_scan_kernel, dim3(num_clouds), dim3(1024), 0, st, rdeg, n, cap, roff, cursor);
-    if (cap <= 32) hipLaunchKernelGGL(transpose_fill_kernel<32>, dim3(blocks8), dim3(256), 0, st, idx, cnt, cap, (int)total, n, roff, cursor, rlist);
-    else hipLaunchKernelGGL(transpose_fill_kernel<64>, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, roff, cursor, rlist);
+    hipLaunchKernelGGL(transpose_fill_kernel, dim3(blocks), dim3(256), 0, st, idx, cnt, cap, (int)total, n, roff, cursor, rlist);
     hipLaunchKernelGGL(transpose_sort_kernel, dim3(blocks), dim3(256), 0, st, rdeg, roff, (int)total, rlist);
     EPC_CHECK_LAUNCH();
     return EPC_OK;

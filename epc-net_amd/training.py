@@ -21,6 +21,9 @@ from .variables import VariableStore, default_store, variable_scope
 BN_INIT_DECAY, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP = 0.5, 0.5, 0.99   # train.py:127-130 (hard-coded there)
 
 
+REPLAYS_PER_SYNC = 32         # replayed steps between two stream synchronisations (TrainStep._graphed_step: a runtime limit)
+
+
 def get_bn_decay(batch: int, batch_num_queries: int, decay_step: float) -> float:
     """train.py:138-146: min(0.99, 1 - 0.5 * 0.5 ** floor(batch*BATCH_NUM_QUERIES / DECAY_STEP))."""
     bn_momentum = BN_INIT_DECAY * BN_DECAY_DECAY_RATE ** math.floor(batch * batch_num_queries / float(decay_step))
@@ -68,6 +71,7 @@ class TrainStep:
         self.m: Dict[str, torch.Tensor] = {}
         self.v: Dict[str, torch.Tensor] = {}
         self._graph = None                        # captured HIP graph(s) of one step (step(..., graph=True))
+        self._replays_since_sync = 0              # replayed steps since the last stream synchronisation (REPLAYS_PER_SYNC)
         self._exchange = None                     # flat gradient / statistics buffer of data-parallel steps
         # GEMM arithmetic of the step (ops.set_gemm_precision): "bf16x6" = f32-accurate like the reference's fp32 graph
         # (default); "bf16" = one bf16 value per operand, the arithmetic BASELINE.json configs[2] names
@@ -490,6 +494,15 @@ class TrainStep:
             if pending is not None:
                 pending.wait()
             g["graph2"].replay()
+        # A caller that never waits for the stream would queue replays without limit, and this runtime (ROCm 7.0 / PyTorch 2.10) faults
+        # once the packets of replayed graphs have filled the stream's hardware queue a first time without a hipStreamSynchronize in
+        # between ("Memory access fault ... Write access to a read-only page" at the ~101st un-synchronised step of ~80 launches: 8192
+        # packets; measured in round 6, also on round 5's tree; event waits and `.item()` reads do not prevent it, eager launches do not
+        # show it).  A stream synchronisation every REPLAYS_PER_SYNC replayed steps costs one pipeline drain (~0.1 ms) per 32 steps.
+        self._replays_since_sync += 1
+        if self._replays_since_sync >= REPLAYS_PER_SYNC:
+            torch.cuda.current_stream(g["joined"].device).synchronize()
+            self._replays_since_sync = 0
         return g["loss"]
 
     def compute_loss(self, query, positives, negatives, other_neg, is_training: bool, bn_decay=None):

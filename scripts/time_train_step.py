@@ -13,6 +13,10 @@ if os.environ.get("ASSIGN_F16X3", "1") == "0":      # A/B: the assignment produc
     bench.pkg("ops").F16X3_ASSIGN = None
 if "PERSIST" in os.environ:                          # A/B: the backbone chain as persistent launches (1) or as the launch chain (0); 
     bench.pkg("ops").CHAIN_PERSIST_FWD = os.environ["PERSIST"][0] == "1"
+if "HIDDEN_TAIL" in os.environ:                      # A/B: the VLAD tail behind the hidden projection as one launch each way (1) or op by op (0)
+    bench.pkg("ops").HIDDEN_TAIL = os.environ["HIDDEN_TAIL"] == "1"
+if "REPLAYS_PER_SYNC" in os.environ:                 # (the step synchronises its stream every 32 replays: a runtime limit, training.py)
+    TR.REPLAYS_PER_SYNC = int(os.environ["REPLAYS_PER_SYNC"])
 ts = TR.TrainStep(params, store, outer=bench.OUTER)
 g = torch.Generator().manual_seed(0)
 mk = lambda p: (torch.rand((1, p, 4096, 3), generator=g) * 2 - 1).to(dev)
@@ -23,8 +27,18 @@ for _ in range(int(os.environ.get("WARM", "30"))):   # warm-up: graph capture, l
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 K = int(os.environ.get("STEPS", "60"))
-for _ in range(K):
+for k_ in range(K):
     loss, lr, bd = ts.step(q, pos, ng, oth, epoch=0, graph=use_graph)
+    if os.environ.get("SYNC_EVERY") and (k_ + 1) % int(os.environ["SYNC_EVERY"]) == 0:
+        how = os.environ.get("SYNC_HOW", "device")        # debugging the long-run fault: which kind of wait keeps a long replay loop alive
+        if how == "device":
+            torch.cuda.synchronize()
+        elif how == "stream":
+            torch.cuda.current_stream().synchronize()
+        elif how == "item":
+            float(loss)
+        elif how == "print":
+            print("host at step", k_ + 1, flush=True)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 ncl = 1 + 2 + neg + 1

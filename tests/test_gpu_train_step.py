@@ -416,3 +416,31 @@ def test_lazy_conv5_consumer_that_cannot_stream_materialises(dev):
     torch.cuda.synchronize()
     assert a.shape == (16, 256) and torch.isfinite(a).all()
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_long_unsynchronised_replay_loop_in_a_child_process():
+    """A caller that never waits for its stream: 300 replayed steps back to back at the training tuple's full size (22 x 4096: the host
+    runs a hundred steps ahead of the device).  Without the stream synchronisation TrainStep inserts every REPLAYS_PER_SYNC replays this
+    runtime faults at the ~101st step ("Memory access fault ... Write access to a read-only page"; round 6, also on round 5's tree; at
+    18 x 256, where the host cannot run ahead, it does not) -- in a CHILD, so that a regression aborts the child, not the test run."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers as H
+from helpers import O
+TR = H.pkg("training")
+dev = torch.device("cuda:0")
+st = H.make_store("epc-net", O.seeded_weights("epc-net", 4), dev)
+ts = TR.TrainStep(dict(H.PARAMS, ARCH="epc-net", BATCH_NUM_QUERIES=1, TRAIN_PRECISION="bf16"), st, outer=H.OUTER)
+pcs = torch.from_numpy(O.synthetic_clouds(22, 4096, 9)).to(dev)
+tup = (pcs[None, :1], pcs[None, 1:3], pcs[None, 3:21], pcs[None, 21:])
+for k in range(300):
+    loss, _, _ = ts.step(*tup, epoch=0, graph=True)
+torch.cuda.synchronize()
+assert torch.isfinite(loss).all()
+print("CHILD OK", float(loss))
+""" % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHILD OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
