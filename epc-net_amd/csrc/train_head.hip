@@ -16,6 +16,9 @@
 #define VN_THREADS 1024
 #define VN_GROUPS (VN_THREADS / 64)
 #define L2_EPS 1e-12f
+#ifndef VN_UNROLL
+#define VN_UNROLL 8     // rows of a column in flight per thread and round trip (one workgroup per cloud: the passes are chains of dependent L2 round trips)
+#endif
 
 __device__ __forceinline__ float group_sum(float v, float (*red)[64], int c, int g) {  // sum over the 16 feature groups
     __syncthreads();
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
     const float* pr = raw + (size_t)b * F * 64;
     const float as = a_sum[b * 64 + c];
     float ss = 0.f;
-#pragma unroll 8
+#pragma unroll VN_UNROLL
     for (int f = g; f < F; f += VN_GROUPS) {
         const float v = pr[f * 64 + c] - as * w2[f * 64 + c];
         ss += v * v;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
     for (int q = 0; q < 64; ++q) tot += s_tot[q];
     const float rb = 1.0f / sqrtf(fmaxf(tot, L2_EPS));
     float* po = out + (size_t)b * F * 64;
-#pragma unroll 8
+#pragma unroll VN_UNROLL
     for (int f = g; f < F; f += VN_GROUPS) {
         const float v = pr[f * 64 + c] - as * w2[f * 64 + c];
         po[f * 64 + c] = (v * rc) * rb;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const float* pd = dout + (size_t)b * F * 64;
     const float* po = out + (size_t)b * F * 64;
     float T = 0.f, Q = 0.f;
-#pragma unroll 8
+#pragma unroll VN_UNROLL
     for (int f = g; f < F; f += VN_GROUPS) {
         const float o = po[f * 64 + c], d = pd[f * 64 + c];
         T += d * o;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const float inv_rb = 1.0f / rb;
     float* pw = draw + (size_t)b * F * 64;
     float da = 0.f;
-#pragma unroll 8
+#pragma unroll VN_UNROLL
     for (int f = g; f < F; f += VN_GROUPS) {
         const float o = po[f * 64 + c], d = pd[f * 64 + c];
         const float dv = rc * (rb * (d - o * S) - (o * inv_rb) * Sc);
