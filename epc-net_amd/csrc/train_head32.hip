@@ -186,6 +186,121 @@ __global__ __launch_bounds__(64 * C32_WAVES, 1) void h32_conv5_fwd_kernel(const 
     flush_stats(st_end - 1, (st_end - 1) & 1);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// conv5's weight gradient dW5 (256, 1024) = cat^T dz5 on f32 rows (models/epc-net.py:136's kernel, backward), two bf16 pieces per operand and
+// three products -- the arithmetic of every backward product of this file -- in h16_dw5_kernel's shape (train_head16.hip): a workgroup of
+// eight waves owns all 256 input channels x 256 output columns over a slice of the rows and moves every byte ONCE, 16 bytes per lane.
+// What differs: a step is 32 rows (2 k-steps; hi + lo fragments of both operands: 2 x 64 KB of LDS); a loader wave takes 8 rows of its
+// operand, a whole 1-KB row per load instruction, lane l the values 4 l .. 4 l + 3 -- the MFMA wants 8 consecutive rows of ONE value per lane,
+// and with f32 in registers that is the split itself (no byte permutes): value q of the lane's 8 rows -> one hi and one lo entry.  Entry
+// (tile T, lane L) sits at position L ^ (T & 3) of its tile: a write instruction (fixed q) then spreads its 64 lanes over all sixteen
+// 16-byte bank groups, four lanes each (in lane order: four groups, sixteen lanes each).  Per k-step and wave 12 fragment reads feed 24
+// MFMAs (lo hi + hi lo + hi hi into the same eight accumulators).  Slices are added in ascending order by h16_partial_reduce_kernel.
+// Replaces the split-K tile product of train_ops.hip on this path (gemm_split_kernel<2,2,2,false,2>: operand tiles re-read and re-split per
+// output tile, 159 us at 18 x 4096 rows).
+// ----------------------------------------------------------------------------------------------------------------
+#define DW32_STEP_U4 (2 * 8 * 2 * 64)   // one operand of one 32-row step: [k-step 2][tile 8][hi, lo][lane 64] x 16 bytes = 32 KB
+
+__global__ __launch_bounds__(512, 1) void h32_dw5_kernel(const float* __restrict__ cat, const float* __restrict__ dz5, int rows,
+                                                         int rows_per_wg, float* __restrict__ P) {
+    extern __shared__ u32x4 dw32_lds[];                // [buffer 2][operand 2][DW32_STEP_U4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int n0 = blockIdx.x * 256;
+    const int rbeg = blockIdx.y * rows_per_wg, rend = min(rbeg + rows_per_wg, rows);
+    // loader role: operand (0 = cat, 1 = dz5), rows 16 ks + 8 hh + j of the step, values 4 lane .. 4 lane + 3
+    const int oper = wave >> 2, ks_ld = (wave >> 1) & 1, hh = wave & 1;
+    const int last = max(rend - 1, rbeg);
+    const float* src = oper == 0 ? cat + 4 * lane : dz5 + n0 + 4 * lane;
+    const size_t pitch = oper == 0 ? 256 : 1024;
+    float4 in[8];
+    auto load = [&](int rb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + 16 * ks_ld + 8 * hh + j;
+            in[j] = ld4(src + (size_t)min(row, last) * pitch);
+            if (oper == 1 && row >= rend) in[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a row past the slice contributes zeros)
+        }
+    };
+    // value 4 lane + q: tile T = lane >> 3, fragment lane L = 32 hh + 4 (lane & 7) + q
+    const int wr_tile = lane >> 3;
+    const int wr_base = oper * DW32_STEP_U4 + (ks_ld * 8 + wr_tile) * 128;
+    const int wr_lane = 32 * hh + 4 * (lane & 7);
+    auto deposit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[8] = {(&in[0].x)[q], (&in[1].x)[q], (&in[2].x)[q], (&in[3].x)[q],
+                                (&in[4].x)[q], (&in[5].x)[q], (&in[6].x)[q], (&in[7].x)[q]};
+            bf16x8 hi, lo;
+            split8(v, hi, lo);
+            u32x4* dst = dw32_lds + buf * 2 * DW32_STEP_U4 + wr_base + ((wr_lane + q) ^ (wr_tile & 3));
+            dst[0] = __builtin_bit_cast(u32x4, hi);
+            dst[64] = __builtin_bit_cast(u32x4, lo);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
+    if (rbeg < rend) {
+        load(rbeg);
+        deposit(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int rb = rbeg; rb < rend; rb += 32, buf ^= 1) {
+        const bool more = rb + 32 < rend;
+        if (more) load(rb + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4* As = dw32_lds + buf * 2 * DW32_STEP_U4;
+        const u32x4* Bs = As + DW32_STEP_U4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int T = 4 * wm + q;
+                const u32x4* f = As + (ks * 8 + T) * 128 + (lane ^ (T & 3));
+                ah[q] = __builtin_bit_cast(bf16x8, f[0]), al[q] = __builtin_bit_cast(bf16x8, f[64]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int T = 2 * wn + t;
+                const u32x4* f = Bs + (ks * 8 + T) * 128 + (lane ^ (T & 3));
+                bh[t] = __builtin_bit_cast(bf16x8, f[0]), bl[t] = __builtin_bit_cast(bf16x8, f[64]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(al[q], bh[t], acc[q][t]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(ah[q], bl[t], acc[q][t]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(ah[q], bh[t], acc[q][t]);
+        }
+        if (more) deposit(buf ^ 1);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
+        __syncthreads();
+    }
+    // D: lane (i, h), register r of (q, t) = dW5[channel 128 wm + 32 q + mfma_row(r, h)][column n0 + 64 wn + 32 t + i]
+    const int i = lane & 31, h = lane >> 5;
+    float* o = P + (size_t)blockIdx.y * 256 * 1024 + n0 + 64 * wn + i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = 128 * wm + 32 * q + mfma_row(r, h);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) o[(size_t)ch * 1024 + 32 * t] = acc[q][t][r];
+        }
+}
+
 // ---- C ABI ---------------------------------------------------------------------------------------------------------------------
 extern "C" size_t epc_h32_conv5_fwd_scratch_bytes(int rows) {
     if (rows <= 0) return 0;
@@ -321,6 +436,39 @@ extern "C" int epc_h32_conv5_dx_bn(const float* du, const float* z5, const float
     else
         hipLaunchKernelGGL((hx_rowgemm_kernel<8, false, float, 2, 2, true, 4>), dim3((rows + 127) / 128, 1), dim3(256), 0, st, du, rows,
                        (const u32x4*)scratch, 0L, bn, dcat, (float*)nullptr, (float*)nullptr, bnb);
+    EPC_CHECK_LAUNCH();
+    return EPC_OK;
+}
+
+static int h32_dw5_splits(int rows) {
+    const int cus = epc_device_cu_count();
+    int s = max(1, cus / 4);                              // 4 column tiles per slice: one workgroup (eight waves) per CU
+    while (s > 1 && (rows + s - 1) / s < 32) s >>= 1;     // (short inputs: at least 32 rows per slice)
+    return s;
+}
+
+extern "C" size_t epc_h32_conv5_dw_scratch_bytes(int rows) {
+    return rows > 0 ? (size_t)h32_dw5_splits(rows) * 256 * 1024 * sizeof(float) : 0;
+}
+
+// dW5 (256, 1024) f32 = cat^T dz5: cat (rows, 256) f32, dz5 (rows, 1024) f32, two bf16 pieces per operand (three products)
+extern "C" int epc_h32_conv5_dw(const float* cat, const float* dz5, int rows, float* dW5, void* scratch, size_t scratch_bytes, void* stream) {
+    EPC_CHECK_ARG(cat && dz5 && dW5 && scratch, "null pointer");
+    EPC_CHECK_ARG(rows > 0 && (long)rows * 1024 < (1L << 32), "bad shape");
+    EPC_CHECK_ARG(scratch_bytes >= epc_h32_conv5_dw_scratch_bytes(rows), "scratch too small (epc_h32_conv5_dw_scratch_bytes)");
+    EPC_CHECK_ARG(h16_aligned16(cat) && h16_aligned16(dz5) && h16_aligned16(dW5) && h16_aligned16(scratch), "tensors must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int S = h32_dw5_splits(rows);
+    const int rows_per_wg = ((rows + S - 1) / S + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * 2 * DW32_STEP_U4 * sizeof(u32x4);     // 128 KB
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(h32_dw5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        epc_set_error("epc_h32_conv5_dw: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return EPC_EHIP;
+    }
+    hipLaunchKernelGGL(h32_dw5_kernel, dim3(4, S), dim3(512), lds, st, cat, dz5, rows, rows_per_wg, (float*)scratch);
+    const long per = 256 * 1024;
+    hipLaunchKernelGGL(h16_partial_reduce_kernel, dim3((unsigned)(per / 4 / 256), 1), dim3(256), 0, st, (const float*)scratch, S, per, dW5);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
 }

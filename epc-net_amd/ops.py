@@ -1268,7 +1268,9 @@ class Conv5VladHead(torch.autograd.Function):
             L.check(lib.epc_h16_conv5_dw(cat.data_ptr(), int(cat.dtype == torch.bfloat16), du.data_ptr(), rows, dW5.data_ptr(),
                                          sc.data_ptr(), n, _st()))
         else:
-            dW5 = gemm(cat, du, trans_a=True, splitk=_splitk_for(256, 1024, rows), fast=True, deterministic=True)
+            dW5 = f32(256, 1024)
+            sc, n = _scratch_bytes(lib.epc_h32_conv5_dw_scratch_bytes(rows), dev)
+            L.check(lib.epc_h32_conv5_dw(cat.data_ptr(), du.data_ptr(), rows, dW5.data_ptr(), sc.data_ptr(), n, _st()))
         return dcat, dW5, None, sums[1], sums[0], None, dWc, dgc, dbtc, None, None, None, None
 
 

@@ -703,7 +703,8 @@ int epc_h16_expand(const void* z, const float* mean5, const float* var5, const f
  * Arithmetic: epc_h32_conv5_fwd scaled split-fp16 (every row of cat and every column of W5 brought into [2^14, 2^15) by a power of two,
  * hi + lo fp16, three products: 2^-21 per product, no range restriction); epc_h32_assign, epc_h32_colgemm and epc_h32_conv5_dx two bf16
  * pieces per operand, three products (epc_gemm_f32_fast's: 2^-16 per product).  Arguments as the bf16 head's entry points of the same name.  The rest of the head's backward on f32 tensors:
- * epc_vlad_df_tail, epc_bn_apply_bwd_given, and the split-K tile product for dW5. */
+ * epc_vlad_df_tail, epc_bn_apply_bwd_given; dW5 = cat^T dz5 by epc_h32_conv5_dw (round 6: epc_h16_conv5_dw's shape on f32 rows, two bf16
+ * pieces per operand; the split-K tile product epc_gemm_splitk_det stays the second implementation it is tested against). */
 size_t epc_h32_conv5_fwd_scratch_bytes(int rows);
 int epc_h32_conv5_fwd(const float* cat, const float* W5, const float* b5, int rows, float* z5, float* mean, float* var, void* scratch,
                       size_t scratch_bytes, void* stream);
@@ -721,6 +722,10 @@ int epc_h32_conv5_dx(const float* dz5, const float* W5, int rows, float* dcat, v
 int epc_h32_conv5_dx_bn(const float* du, const float* z5, const float* mean5, const float* var5, const float* gamma5, float eps,
                         const float* dbeta, const float* dgamma, const float* W5, int rows, float* dz5, float* dcat, void* scratch,
                         size_t scratch_bytes, void* stream);
+/* dW5 (256, 1024) f32 = cat^T dz5: cat (rows, 256), dz5 (rows, 1024) f32; rows any positive count (rows * 1024 < 2^32); row slices added
+ * in a fixed order (the same bits every run).  Replaces on this path: models/epc-net.py:136's weight gradient. */
+size_t epc_h32_conv5_dw_scratch_bytes(int rows);
+int epc_h32_conv5_dw(const float* cat, const float* dz5, int rows, float* dW5, void* scratch, size_t scratch_bytes, void* stream);
 /* epc_gemm_splitk_det with the RIGHT operand stored as bf16 (strides and batch stride in elements; every side of the product at least
  * 64, K at least 32).  pieces: 1 = A rounded to one bf16 value, 2 = A in two bf16 pieces (the bf16 operand is exact either way). */
 int epc_gemm_splitk_det_b16(const float* A, const void* B16, float* C, const float* bias, int M, int N, int K, long sAm, long sAk,

@@ -61,3 +61,5 @@ for mode in os.environ.get("MODES", "bf16,f32").split(","):
     t("dx (dz5 -> dcat)", R * (1024 * w + 256 * 4), lambda: dx(du.data_ptr(), W5.data_ptr(), R, dcat.data_ptr(), sc.data_ptr(), sc.numel(), st))
     dxbn = lib.epc_h16_conv5_dx_bn if h16 else lib.epc_h32_conv5_dx_bn
     t("dx + bn bwd (du, z5 -> dz5, dcat)", R * (3 * 1024 * w + 256 * 4), lambda: dxbn(du.data_ptr(), z5.data_ptr(), mean5.data_ptr(), var5.data_ptr(), g5.data_ptr(), EPS, sums.data_ptr(), sums.data_ptr() + 4096, W5.data_ptr(), R, du.data_ptr(), dcat.data_ptr(), sc.data_ptr(), sc.numel(), st))
+    if not h16:
+        t("dW5 (cat, dz5 -> dW5)", R * (256 * 4 + 1024 * w), lambda: lib.epc_h32_conv5_dw(cat.data_ptr(), du.data_ptr(), R, dW5.data_ptr(), sc.data_ptr(), sc.numel(), st))

@@ -167,6 +167,41 @@ def test_gemm_b16_entry(dev):
                                                 0, 0, 0, 1, 0, 1, None, 0, L.current_stream()))
 
 
+@pytest.mark.parametrize("R", [32, 40, 4608, 8200])
+def test_conv5_weight_gradient_on_f32_rows(dev, R):
+    """epc_h32_conv5_dw -- dW5 = cat^T dz5 on f32 rows, two bf16 pieces per operand, three products (models/epc-net.py:136's weight
+    gradient in the default arithmetic): against the float64 product at the three-product form's accuracy, against the split-K tile
+    product it replaces on this path (the same arithmetic, another order of sums), bit-identical across calls; row counts that are
+    not a multiple of the 32-row step or of the slice count, operands with a wide range of magnitudes."""
+    L, ops = H.pkg("lib"), H.pkg("ops")
+    g = torch.Generator().manual_seed(R)
+    A = (torch.randn(R, 256, generator=g) * torch.exp(2 * torch.randn(R, 1, generator=g))).to(dev)
+    Bf = (torch.randn(R, 1024, generator=g) * torch.exp(torch.randn(1, 1024, generator=g))).to(dev)
+    nb = L.lib().epc_h32_conv5_dw_scratch_bytes(R)
+    outs = []
+    for _ in range(2):
+        C = torch.full((256, 1024), float("nan"), dtype=torch.float32, device=dev)
+        sc = torch.full((nb,), 0xFF, dtype=torch.uint8, device=dev)         # (NaN patterns: every slice partial must be written)
+        L.check(L.lib().epc_h32_conv5_dw(A.data_ptr(), Bf.data_ptr(), R, C.data_ptr(), sc.data_ptr(), nb, L.current_stream()))
+        outs.append(C)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double().cpu().t() @ Bf.double().cpu()
+    scale = (A.double().cpu().abs().t() @ Bf.double().cpu().abs())           # the sum of |terms|: what a product's rounding is relative to
+    err = float(((outs[0].double().cpu() - ref).abs() / scale).max())
+    assert err <= 3e-5, err                                                   # 2^-16 per product before averaging over the rows
+    prev = ops.set_gemm_precision("bf16x6")
+    try:
+        tile = ops.gemm(A, Bf, trans_a=True, splitk=max(1, min(16, R // 512)), fast=True, deterministic=True)
+    finally:
+        ops.set_gemm_precision(prev)
+    assert float((outs[0] - tile).abs().max() / ref.abs().max()) <= 2e-5
+    with pytest.raises(L.EpcNetError):
+        L.check(L.lib().epc_h32_conv5_dw(A.data_ptr(), Bf.data_ptr(), R, C.data_ptr(), sc.data_ptr(), nb - 1, L.current_stream()))
+    with pytest.raises(L.EpcNetError):
+        L.check(L.lib().epc_h32_conv5_dw(A.data_ptr(), Bf.data_ptr(), 0, C.data_ptr(), sc.data_ptr(), nb, L.current_stream()))
+
+
 def test_expand16_and_argument_checks(dev):
     L, ops = H.pkg("lib"), H.pkg("ops")
     z = torch.randn(64, 1024, device=dev).to(torch.bfloat16)
