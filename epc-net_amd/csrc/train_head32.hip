@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64 * C32_WAVES, 1) void h32_conv5_fwd_kernel(const 
 // 16-byte bank groups, four lanes each (in lane order: four groups, sixteen lanes each).  Per k-step and wave 12 fragment reads feed 24
 // MFMAs (lo hi + hi lo + hi hi into the same eight accumulators).  Slices are added in ascending order by h16_partial_reduce_kernel.
 // Replaces the split-K tile product of train_ops.hip on this path (gemm_split_kernel<2,2,2,false,2>: operand tiles re-read and re-split per
-// output tile, 159 us at 18 x 4096 rows).
+// output tile, 159 + 10 us at 18 x 4096 rows; this one 129 + 21 for the slices' sum).  What bounds it: 602 MB per launch -- dz5 once and
+// cat once per column tile (a 256 x 256 tile per workgroup is the square that minimises that sum; its accumulators are half a CU's
+// registers) -- at 4.7 TB/s, with one 64-KB step per CU in flight.  Rows travelling TWO steps ahead (a second register set) spill at 256
+// registers a lane (128 accumulators + 64 + the fragments): built, not kept.
 // ----------------------------------------------------------------------------------------------------------------
 #define DW32_STEP_U4 (2 * 8 * 2 * 64)   // one operand of one 32-row step: [k-step 2][tile 8][hi, lo][lane 64] x 16 bytes = 32 KB
 
