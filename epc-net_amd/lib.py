@@ -58,6 +58,7 @@ EXPORTS = [
     "epc_h16_dx_scratch_bytes", "epc_h16_conv5_dx", "epc_h16_conv5_dx_bn", "epc_h16_conv5_dw_scratch_bytes", "epc_h16_conv5_dw", "epc_h16_expand", "epc_gemm_splitk_det_b16",
     "epc_h32_conv5_fwd_scratch_bytes", "epc_h32_conv5_fwd", "epc_h32_assign_scratch_bytes", "epc_h32_assign",
     "epc_h32_colgemm_scratch_bytes", "epc_h32_colgemm", "epc_h32_dx_scratch_bytes", "epc_h32_conv5_dx", "epc_h32_conv5_dx_bn", "epc_h32_conv5_dw_scratch_bytes", "epc_h32_conv5_dw",
+    "epc_hidden_proj_ok", "epc_hidden_proj_scratch_bytes", "epc_hidden_proj_fwd", "epc_hidden_proj_bwd",
     "epc_maxpool_points_fwd", "epc_maxpool_points_bwd", "epc_vlad_w2_grad", "epc_group_sum_fwd", "epc_group_sum_bwd",
     "epc_hidden_tail_ok", "epc_hidden_tail_fwd", "epc_hidden_tail_bwd",
 ]
@@ -267,6 +268,11 @@ _lib.epc_h32_conv5_dx_bn.argtypes = _lib.epc_h16_conv5_dx_bn.argtypes
 _lib.epc_h32_conv5_dw_scratch_bytes.restype = c_size_t
 _lib.epc_h32_conv5_dw_scratch_bytes.argtypes = [c_int]
 _lib.epc_h32_conv5_dw.argtypes = [_P, _P, c_int, _P, _P, c_size_t, _P]
+_lib.epc_hidden_proj_ok.argtypes = [c_int, c_int, c_int]
+_lib.epc_hidden_proj_scratch_bytes.restype = c_size_t
+_lib.epc_hidden_proj_scratch_bytes.argtypes = [c_int, c_int]
+_lib.epc_hidden_proj_fwd.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]
+_lib.epc_hidden_proj_bwd.argtypes = [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_maxpool_points_fwd.argtypes = [_P, c_int, c_int, c_int, _P, _P, _P]
 _lib.epc_maxpool_points_bwd.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]
 _lib.epc_vlad_w2_grad.argtypes = [_P, _P, c_int, c_int, c_int, _P, _P]

@@ -153,7 +153,10 @@ class _VladBase(PoolingBaseModel):
         vlad = ops.VladNormalize.apply(vlad, a_sum, st[scoped("cluster_weights2")])
         vlad = vlad.reshape(-1, C * F)
         vlad = vlad.reshape(-1, C * F // G)                                                      # :302 (groups)
-        vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                       # :322
+        if self.is_training and ops.hidden_proj_ok(int(vlad.shape[0]), C * F // G, O):
+            vlad = ops.HiddenProjection.apply(vlad, st[scoped("hidden1_weights")])               # :322 (one pass over the weights)
+        else:
+            vlad = ops.Linear.apply(vlad, st[scoped("hidden1_weights")], None)                   # :322
         if self.is_training and self.gating and self.add_batch_norm and ops.hidden_tail_ok(int(vlad.shape[0]), G, O):
             # :323-331 (+ :61-101) as ONE node: BatchNorm, the group sum, context gating
             from .utils.tf_util import _ema_update

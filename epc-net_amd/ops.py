@@ -1308,6 +1308,46 @@ class GroupSum(torch.autograd.Function):
         return dx, None
 
 
+# The grouped hidden projection (loupe.py:302-322) and its two gradients on the skinny kernels of csrc/train_hidden.hip -- one pass over
+# the 16-MB weight matrix per product -- where the shape is covered (64 .. 128 rows: 16 .. 32 clouds x 4 groups); False, or any other
+# shape: ops.Linear's tile GEMMs (the second implementation tests/test_gpu_hidden_tail.py holds it to).
+HIDDEN_PROJ = True
+
+
+def hidden_proj_ok(rows, cin, cout):
+    return bool(HIDDEN_PROJ and L.lib().epc_hidden_proj_ok(int(rows), int(cin), int(cout)))
+
+
+class HiddenProjection(torch.autograd.Function):
+    """y = x @ W for the (B G, C F / G) x (C F / G, O) product of loupe.py:322 (no bias: a BatchNorm follows).  Arithmetic as
+    ops.Linear's: under "bf16x6" three bf16 pieces per operand forward (six products, f32-accurate), two backward; under "bf16" one
+    (every side of the three products is at least 64: oracle/epcnet_oracle_torch.py, bf16_product_rule)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        x, W = x.contiguous(), W.contiguous()
+        M, K = int(x.shape[0]), int(x.shape[1])
+        lib = L.lib()
+        bf16 = _GEMM_PRECISION == "bf16"
+        y = torch.empty((M, int(W.shape[1])), dtype=torch.float32, device=x.device)
+        sc, n = _scratch_bytes(lib.epc_hidden_proj_scratch_bytes(M, K), x.device)
+        L.check(lib.epc_hidden_proj_fwd(x.data_ptr(), W.data_ptr(), M, K, 1 if bf16 else 3, y.data_ptr(), sc.data_ptr(), n, _st()))
+        ctx.save_for_backward(x, W)
+        ctx.pieces = 1 if bf16 else 2
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = int(x.shape[0]), int(x.shape[1])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        L.check(L.lib().epc_hidden_proj_bwd(x.data_ptr(), W.data_ptr(), dy.data_ptr(), M, K, ctx.pieces,
+                                            dx.data_ptr() if dx is not None else None, dW.data_ptr() if dW is not None else None, _st()))
+        return dx, dW
+
+
 # The VLAD tail behind the hidden projection -- its BatchNorm, the group sum, context gating (product, BatchNorm, sigmoid gate) -- as ONE
 # launch each way (csrc/train_head.hip: epc_hidden_tail_fwd / _bwd) instead of nine and ten of 2-8 us; False: the per-op path (the
 # second implementation tests/test_gpu_hidden_tail.py holds it to).

@@ -523,6 +523,18 @@ int epc_hidden_tail_bwd(const float* dout, const float* h, int B, int G, int O, 
                         const float* var2, float eps, float* dh, float* dgamma1, float* dbeta1, float* dWg,
                         float* dgamma2, float* dbeta2, void* stream);
 
+/* The grouped hidden projection itself in the training step (loupe.py:302-322; csrc/train_hidden.hip): Y (M, 256) = X (M, K) W (K, 256)
+ * with M = B G rows and K = C F / G, and its gradients dX (M, K) = dY W^T, dW (K, 256) = X^T dY -- three skinny products around a 16-MB
+ * weight matrix, each ONE pass over it by 256 workgroups (the tile GEMM's split-K forms took 34 + 10, 17 and 16 us at 18 clouds where the
+ * bytes are 3 us each).  pieces: bf16 pieces per operand -- 1 (the "bf16" step), 2 (three products: the default step's backward products),
+ * 3 (six products: its forward products); f32 accumulation, sums met in a fixed order (bit-reproducible).  Shapes:
+ * epc_hidden_proj_ok(M, K, N): 64 <= M <= 128, M % 4 == 0, N == 256, K a positive multiple of 256; other shapes stay on epc_gemm_*.
+ * dX or dW may be NULL (not computed).  scratch: the forward's K / 256 slice partials. */
+int epc_hidden_proj_ok(int M, int K, int N);
+size_t epc_hidden_proj_scratch_bytes(int M, int K);
+int epc_hidden_proj_fwd(const float* X, const float* W, int M, int K, int pieces, float* Y, void* scratch, size_t scratch_bytes, void* stream);
+int epc_hidden_proj_bwd(const float* X, const float* W, const float* dY, int M, int K, int pieces, float* dX, float* dW, void* stream);
+
 /* ---- The 64-channel backbone of the training step as a chain of fused launches (csrc/train_chain.hip) -----------------------
  * models/epc-net.py:66-134 in training mode (utils/tf_util.py:52-107, 454-519): every 64 -> 64 layer is followed by a training-mode
  * BatchNorm + ReLU whose batch statistics need all rows.  A producer leaves per-workgroup PARTIALS -- epc_chain_parts(rows) of

@@ -9,7 +9,7 @@ mkdir -p build_variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on -fno-slp-vectorize $flags -Iepc-net_amd/csrc \
     -c epc-net_amd/csrc/$src -o build_variants/${name}_${src%.hip}.o
 objs=""
-for f in api sort knn block conv5_vlad conv5_f32 head pack retrieval pipeline train_ops train_head train_head16 train_head32 train_chain train_chain_persist; do
+for f in api sort knn block conv5_vlad conv5_f32 head pack retrieval pipeline train_ops train_head train_head16 train_head32 train_chain train_chain_persist train_hidden; do
   if [ "$f.hip" == "$src" ]; then objs="$objs build_variants/${name}_$f.o"; else objs="$objs epc-net_amd/csrc/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_variants/lib_$name.so $objs

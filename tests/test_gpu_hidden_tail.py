@@ -126,3 +126,56 @@ def test_g_vlad_with_the_fused_tail_equals_the_per_op_path(dev, precision):
         assert rel(a[1][k], b[1][k]) <= bar_grad, (k, rel(a[1][k], b[1][k]))
     for k in b[2]:
         assert np.abs(a[2][k] - b[2][k]).max() <= 1e-6 + bar * np.abs(b[2][k]).max(), k
+
+
+@pytest.mark.parametrize("M,K,precision", [(72, 16384, "bf16x6"), (88, 16384, "bf16x6"), (72, 16384, "bf16"), (88, 16384, "bf16"),
+                                           (64, 512, "bf16x6"), (128, 1024, "bf16"), (100, 768, "bf16x6")])
+def test_hidden_projection_node_matches_float64(dev, M, K, precision):
+    """ops.HiddenProjection (csrc/train_hidden.hip: epc_hidden_proj_fwd / _bwd; loupe.py:322 and its two gradients) against the float64
+    products -- in the "bf16" arithmetic with every product's operands rounded to bf16 first, so that what is left is accumulation
+    order -- and against ops.Linear's tile GEMMs on the same inputs; bit-identical across calls; rows that do not fill a 32- or 16-row
+    tile (72, 88, 100), the smallest and the largest covered shape."""
+    ops, L = H.pkg("ops"), H.pkg("lib")
+    assert ops.hidden_proj_ok(M, K, 256)
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(dev).requires_grad_(True)
+    W = (torch.randn(K, 256, generator=g) / np.sqrt(K) * torch.exp(0.5 * torch.randn(1, 256, generator=g))).to(dev).requires_grad_(True)
+    dy = torch.randn(M, 256, generator=g).to(dev)
+    bf = precision == "bf16"
+    rnd = (lambda t: t.to(torch.float32).to(torch.bfloat16).to(torch.float64)) if bf else (lambda t: t)
+    x64, W64, d64 = x.detach().double().cpu(), W.detach().double().cpu(), dy.double().cpu()
+    ref = (rnd(x64) @ rnd(W64), rnd(d64) @ rnd(W64).t(), rnd(x64).t() @ rnd(d64))
+    mag = (x64.abs() @ W64.abs(), d64.abs() @ W64.abs().t(), x64.abs().t() @ d64.abs())      # the sums of |terms|
+    prev = ops.set_gemm_precision(precision)
+    try:
+        got = []
+        for _ in range(2):
+            x.grad = W.grad = None
+            y = ops.HiddenProjection.apply(x, W)
+            y.backward(dy)
+            got.append((y.detach().clone(), x.grad.clone(), W.grad.clone()))
+        x.grad = W.grad = None
+        y2 = ops.Linear.apply(x, W, None)
+        y2.backward(dy)
+        lin = (y2.detach(), x.grad, W.grad)
+    finally:
+        ops.set_gemm_precision(prev)
+    torch.cuda.synchronize()
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b)
+    # forward: six products (2^-24 per product) or exact products of rounded operands; backward: three products (2^-16)
+    bars = (2e-6, 2e-6, 2e-6) if bf else (3e-7, 3e-5, 3e-5)
+    for name, a, r, m, bar, l in zip(("y", "dx", "dW"), got[0], ref, mag, bars, lin):
+        err = float(((a.double().cpu() - r).abs() / m).max())
+        assert err <= bar, (name, err)
+        assert float((a - l).abs().max() / r.abs().max()) <= (1e-5 if bf else 2e-5), name
+    # one side only; shapes that are not covered are refused
+    lib = L.lib()
+    dX = torch.full_like(x, float("nan"))
+    L.check(lib.epc_hidden_proj_bwd(x.data_ptr(), W.data_ptr(), dy.data_ptr(), M, K, 1 if bf else 2, dX.data_ptr(), None, L.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dX, got[0][1])
+    assert not ops.hidden_proj_ok(60, K, 256) and not ops.hidden_proj_ok(132, K, 256) and not ops.hidden_proj_ok(M, K + 64, 256)
+    assert not ops.hidden_proj_ok(M, K, 128) and not ops.hidden_proj_ok(66, K, 256)
+    with pytest.raises(L.EpcNetError):
+        L.check(lib.epc_hidden_proj_bwd(x.data_ptr(), W.data_ptr(), dy.data_ptr(), 60, K, 2, dX.data_ptr(), None, L.current_stream()))
