@@ -371,24 +371,28 @@ __global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict_
     const int oper = wave >> 2, piece = wave & 3, c = lane & 31, hh = lane >> 5;
     const int last = max(rend - 1, rbeg);
     u32x4 in[8];
+    // Every load of a step is UNCONDITIONAL and the rows past the slice are zeroed at deposit time: a load guarded per lane (the first form of
+    // this lambda: `if (row >= rend) in[j] = 0` right behind it) is compiled into load, s_waitcnt vmcnt(0), select -- eight dependent round
+    // trips per step instead of eight loads in flight (found in the ISA in round 6).
     auto load = [&](int rb) {
+        const int r0 = rb + 16 * piece + 8 * hh;
+        if (oper == 0) {
+            if constexpr (AF32) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = rb + 16 * piece + 8 * hh + j;
-            const size_t rr = (size_t)min(row, last);
-            if (oper == 0) {
-                if constexpr (AF32) {
-                    const float* p = reinterpret_cast<const float*>(cat_) + rr * 256 + 8 * c;
+                for (int j = 0; j < 8; ++j) {
+                    const float* p = reinterpret_cast<const float*>(cat_) + (size_t)min(r0 + j, last) * 256 + 8 * c;
                     const float4 x = ld4(p), y = ld4(p + 4);
                     const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
                     in[j] = __builtin_bit_cast(u32x4, cvt8(v));
-                } else {
-                    in[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(cat_) + rr * 256 + 8 * c);
                 }
             } else {
-                in[j] = *reinterpret_cast<const u32x4*>(dz5 + rr * 1024 + n0 + 8 * c);
-                if (row >= rend) in[j] = u32x4{0u, 0u, 0u, 0u};   // (a row past the slice contributes zeros)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    in[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(cat_) + (size_t)min(r0 + j, last) * 256 + 8 * c);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) in[j] = *reinterpret_cast<const u32x4*>(dz5 + (size_t)min(r0 + j, last) * 1024 + n0 + 8 * c);
         }
     };
     // fragment entry of value q of this lane: k-step = piece, tile = c >> 2, lane (i = 8 (c & 3) + q, h = hh).  Entry L of tile T sits at
@@ -397,7 +401,12 @@ __global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict_
     const int wr_tile = c >> 2;
     const int wr_base = oper * DW_STEP_U4 + (piece * 8 + wr_tile) * 64;
     const int wr_lane = 32 * hh + 8 * (c & 3);
-    auto deposit = [&](int buf) {
+    auto deposit = [&](int buf, int rb) {         // rb: the step whose rows `in` holds
+        if (oper == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (rb + 16 * piece + 8 * hh + j >= rend) in[j] = u32x4{0u, 0u, 0u, 0u};   // (a row past the slice contributes zeros)
+        }
         u32x4 out[8];
         h16_transpose8x8(in, out);
 #pragma unroll
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict_
             for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
     if (rbeg < rend) {
         load(rbeg);
-        deposit(0);
+        deposit(0, rbeg);
     }
     __syncthreads();
     int buf = 0;
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void h16_dw5_kernel(const void* __restrict_
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(a[q], b[t], acc[q][t]);
         }
-        if (more) deposit(buf ^ 1);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
+        if (more) deposit(buf ^ 1, rb + 64);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
         __syncthreads();
     }
     // D: lane (i, h), register r of (q, t) = dW5[channel 128 wm + 32 q + mfma_row(r, h)][column n0 + 64 wn + 32 t + i]

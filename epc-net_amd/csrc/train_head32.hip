@@ -217,19 +217,20 @@ __global__ __launch_bounds__(512, 1) void h32_dw5_kernel(const float* __restrict
     const float* src = oper == 0 ? cat + 4 * lane : dz5 + n0 + 4 * lane;
     const size_t pitch = oper == 0 ? 256 : 1024;
     float4 in[8];
-    auto load = [&](int rb) {
+    auto load = [&](int rb) {       // (unconditional loads, rows past the slice zeroed at deposit time: h16_dw5_kernel's comment)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = rb + 16 * ks_ld + 8 * hh + j;
-            in[j] = ld4(src + (size_t)min(row, last) * pitch);
-            if (oper == 1 && row >= rend) in[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a row past the slice contributes zeros)
-        }
+        for (int j = 0; j < 8; ++j) in[j] = ld4(src + (size_t)min(rb + 16 * ks_ld + 8 * hh + j, last) * pitch);
     };
     // value 4 lane + q: tile T = lane >> 3, fragment lane L = 32 hh + 4 (lane & 7) + q
     const int wr_tile = lane >> 3;
     const int wr_base = oper * DW32_STEP_U4 + (ks_ld * 8 + wr_tile) * 128;
     const int wr_lane = 32 * hh + 4 * (lane & 7);
-    auto deposit = [&](int buf) {
+    auto deposit = [&](int buf, int rb) {         // rb: the step whose rows `in` holds
+        if (oper == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (rb + 16 * ks_ld + 8 * hh + j >= rend) in[j] = make_float4(0.f, 0.f, 0.f, 0.f);   // (a row past the slice contributes zeros)
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float v[8] = {(&in[0].x)[q], (&in[1].x)[q], (&in[2].x)[q], (&in[3].x)[q],
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void h32_dw5_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[q][t][r] = 0.f;
     if (rbeg < rend) {
         load(rbeg);
-        deposit(0);
+        deposit(0, rbeg);
     }
     __syncthreads();
     int buf = 0;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void h32_dw5_kernel(const float* __restrict
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[q][t] = mfma_bf16(ah[q], bh[t], acc[q][t]);
         }
-        if (more) deposit(buf ^ 1);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
+        if (more) deposit(buf ^ 1, rb + 32);    // (the other buffer: its last readers passed the barrier at the end of the previous step)
         __syncthreads();
     }
     // D: lane (i, h), register r of (q, t) = dW5[channel 128 wm + 32 q + mfma_row(r, h)][column n0 + 64 wn + 32 t + i]
