@@ -33,7 +33,9 @@
 // ----------------------------------------------------------------------------------------------------------------
 // conv5's forward: z5 = bf16(A W5 + b5) with A = cat (rows, 256), f32 or bf16, and the batch statistics of the product.
 // A wave's 32 rows are RESIDENT as bf16 fragments (64 registers, read once); W5 streams through double-buffered 16-KB LDS stages (64
-// output columns x 128 k) shared by the workgroup's four waves (global -> registers under the previous stage's products -> LDS), one
+// output columns x 128 k) shared by the workgroup's four waves -- global -> LDS by LDS-DMA under the previous stage's products (round 6;
+// until then through 16 staging registers and ds_writes: 86.5 -> 82 us at 18 clouds, and with the B fragments read two k-steps ahead of
+// their products 80; 93.5 -> 84.6 at 22) -- one
 // barrier per stage; a column chunk's result leaves as one dword (two adjacent columns) per lane and row: whole 128-byte runs.  Per stage and wave the
 // pivot-shifted column sums go to LDS; 64 threads merge the four waves of the PREVIOUS stage behind the barrier that exists anyway.
 // rows a multiple of 32.  stats: [workgroups][3][1024] (tile_rows = 128 for epc_moments_finalize_launch).
@@ -44,32 +46,61 @@
 #define C5_KS 16
 #define C5_STAGE_U4 (8 * 2 * 64)   // 16 KB: half the k-steps of a 64-column chunk ([k-step 8][nt 2][lane])
 
+// Sixteen products of a half-stage: B fragments [k-step 8][nt 2][lane] from LDS, read `AHEAD` k-steps ahead of the products that use them
+// (the compiler's own schedule reads a k-step's two fragments, waits, multiplies: an LDS round trip per two MFMAs inside a wave)
+template <int AHEAD, int S>
+__device__ __forceinline__ void c5_step(const u32x4* __restrict__ B, int lane, const bf16x8* a, u32x4 (&f)[AHEAD + 1][2], f32x16& acc0,
+                                        f32x16& acc1) {
+    if constexpr (S < 8) {
+        if constexpr (S + AHEAD < 8) {
+            f[(S + AHEAD) % (AHEAD + 1)][0] = B[((S + AHEAD) * 2 + 0) * 64 + lane];
+            f[(S + AHEAD) % (AHEAD + 1)][1] = B[((S + AHEAD) * 2 + 1) * 64 + lane];
+        }
+        acc0 = mfma_bf16(a[S], __builtin_bit_cast(bf16x8, f[S % (AHEAD + 1)][0]), acc0);
+        acc1 = mfma_bf16(a[S], __builtin_bit_cast(bf16x8, f[S % (AHEAD + 1)][1]), acc1);
+        if constexpr (S + AHEAD < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // this step's two LDS reads (for k-step S + AHEAD)
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                  // then its two MFMAs
+        c5_step<AHEAD, S + 1>(B, lane, a, f, acc0, acc1);
+    }
+}
+template <int AHEAD>
+__device__ __forceinline__ void c5_half(const u32x4* __restrict__ B, int lane, const bf16x8* a, f32x16& acc0, f32x16& acc1) {
+    u32x4 f[AHEAD + 1][2];
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) f[s][0] = B[(s * 2 + 0) * 64 + lane], f[s][1] = B[(s * 2 + 1) * 64 + lane];
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * AHEAD, 0);
+    c5_step<AHEAD, 0>(B, lane, a, f, acc0, acc1);
+}
+
 template <bool AF32>
 __global__ __launch_bounds__(256, AF32 ? 2 : 3) void h16_conv5_fwd_kernel(const void* __restrict__ A_, int rows, const u32x4* __restrict__ Bp,
                                                                           const float* __restrict__ bias, unsigned* __restrict__ Z,
                                                                           float* __restrict__ stats) {
     // A stage = one HALF (128 k) of a 64-column chunk: 2 x 16 KB of LDS instead of 2 x 32, so that three workgroups share a CU (with the
-    // bf16 operand: 166 registers) and the 576 workgroups of the training tuple are resident at once -- with two per CU the last 64
-    // ran alone in a second round.
+    // bf16 operand: 144 registers; 42 KB of LDS) and the 576 workgroups of the training tuple are resident at once -- with two per CU the
+    // last 64 ran alone in a second round.
     __shared__ u32x4 Bs[2][C5_STAGE_U4];
     __shared__ float wst[2][4][3][64];
     __shared__ bool wlive[4];
+    __shared__ float bias_s[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int r0 = blockIdx.x * 128 + wave * 32;
     const bool live = r0 < rows;
     if (lane == 0) wlive[wave] = live;
     constexpr int PER = C5_STAGE_U4 / 256;
-    u32x4 pre[PER];
-    auto request = [&](int step) {   // step = 2 chunk + half: the pack is [chunk][k-step][nt][lane], so halves are contiguous
+    // W5's stages travel global -> LDS by LDS-DMA (no staging registers, no ds_write): a wave moves four 1-KB pieces of a stage.  The
+    // target buffer is free when the request is issued (its last readers passed the previous barrier); a wave waits for ITS pieces with a
+    // counted s_waitcnt before the barrier that publishes the buffer (vmcnt retires in order: `younger` = the wave's memory operations
+    // issued after the request that may still be in flight -- the chunk's sixteen z5 stores).
+    const unsigned bs_base = (unsigned)(size_t)(const __attribute__((address_space(3))) u32x4*)&Bs[0][0];
+    auto request = [&](int step, int buf) {   // step = 2 chunk + half: the pack is [chunk][k-step][nt][lane], so halves are contiguous
+        const float* src = reinterpret_cast<const float*>(Bp + (size_t)step * C5_STAGE_U4);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pre[u] = Bp[(size_t)step * C5_STAGE_U4 + tid + u * 256];
+        for (int u = 0; u < PER; ++u)
+            glds16(src, 16u * (u * 256 + wave * 64 + lane), bs_base + 16u * (buf * C5_STAGE_U4 + u * 256 + wave * 64));
     };
-    auto deposit = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
-    };
-    request(0);
+    request(0, 0);
     bf16x8 ah[C5_KS];
     {
         const size_t row = (size_t)min(r0 + i, rows - 1);
@@ -87,7 +118,13 @@ __global__ __launch_bounds__(256, AF32 ? 2 : 3) void h16_conv5_fwd_kernel(const 
             for (int s = 0; s < C5_KS; ++s) ah[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p + 16 * s));
         }
     }
-    deposit(0);
+    // the loop below holds no load the compiler can see (the bias comes from LDS), and its counted waits are ours: the resident fragments
+    // are pinned as COMPLETE here -- the compiler's counters do not see the asm waits, and without this it guards every first use of a
+    // fragment in every iteration with a counted vmcnt that drains the stage in flight
+    for (int e = tid; e < 1024; e += 256) bias_s[e] = bias[e];
+#pragma unroll
+    for (int s = 0; s < C5_KS; ++s) asm volatile("" : "+v"(ah[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const size_t zbase = (size_t)r0 * 512;            // dwords: a row is 512 of them
     const unsigned voff = 4u * h * 512u + i;
@@ -105,27 +142,19 @@ __global__ __launch_bounds__(256, AF32 ? 2 : 3) void h16_conv5_fwd_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
         // first half: k-steps 0..7 from buffer 0 (the second half's fragments travel meanwhile)
-        request(2 * st + 1);
         if (st > 0) flush_stats(st - 1, sb ^ 1);
+        request(2 * st + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                acc0 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[0][(s * 2 + 0) * 64 + lane]), acc0);
-                acc1 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[0][(s * 2 + 1) * 64 + lane]), acc1);
-            }
+            c5_half<2>(Bs[0], lane, ah, acc0, acc1);
         }
-        deposit(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing younger than the request in this half)
         __syncthreads();
         // second half: k-steps 8..15 from buffer 1, then the chunk's epilogue
-        if (st + 1 < 16) request(2 * st + 2);
+        if (st + 1 < 16) request(2 * st + 2, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                acc0 = mfma_bf16(ah[8 + s], __builtin_bit_cast(bf16x8, Bs[1][(s * 2 + 0) * 64 + lane]), acc0);
-                acc1 = mfma_bf16(ah[8 + s], __builtin_bit_cast(bf16x8, Bs[1][(s * 2 + 1) * 64 + lane]), acc1);
-            }
+            c5_half<2>(Bs[1], lane, ah + 8, acc0, acc1);
             // D: lane (i, h), register r = row mfma_row(r, h), columns 64 st + 2 i (acc0) and + 1 (acc1).  Pivot = the wave's row 0
             const float p0 = __shfl(acc0[0], i), p1 = __shfl(acc1[0], i);
             float a1 = 0.f, a2 = 0.f, b1s = 0.f, b2s = 0.f;
@@ -139,14 +168,15 @@ __global__ __launch_bounds__(256, AF32 ? 2 : 3) void h16_conv5_fwd_kernel(const 
                 wst[sb][wave][0][2 * i] = a1, wst[sb][wave][1][2 * i] = a2, wst[sb][wave][2][2 * i] = p0;
                 wst[sb][wave][0][2 * i + 1] = b1s, wst[sb][wave][1][2 * i + 1] = b2s, wst[sb][wave][2][2 * i + 1] = p1;
             }
-            const float2 bv = *reinterpret_cast<const float2*>(bias + 64 * st + 2 * i);
+            const float2 bv = *reinterpret_cast<const float2*>(bias_s + 64 * st + 2 * i);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 unsigned* ob = Z + zbase + (size_t)((r & 3) + 8 * (r >> 2)) * 512 + 32 * st;
                 ob[voff] = pack2bf(acc0[r] + bv.x, acc1[r] + bv.y);
             }
         }
-        if (st + 1 < 16) deposit(0);                   // (buffer 0's last readers passed the barrier in the middle of this chunk)
+        if (live) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // (the sixteen z5 stores of this chunk may still travel)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     flush_stats(15, 1);
