@@ -180,19 +180,31 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(typename HxAPtr<
     const bool live = r0 < n_points;
     if (lane == 0) wlive[wave] = live;
     const u32x4* src = Bp + (size_t)cloud * b_cloud_stride_u4;
-    constexpr int WGT = 64 * NW, PER = (CHUNK_U4 + WGT - 1) / WGT;   // (three-wave workgroups: the last piece is predicated)
+    // B's chunks, global -> LDS.  Without BNB: by LDS-DMA (round 6: no staging registers, no ds_writes; 1-KB pieces, piece wave + u NW of the
+    // chunk's KSC NT P) -- a request is issued BEFORE the streamed operand's loads of the same chunk and the counter retires in order, so once
+    // those loads have landed (`deposit` pins them in front of the barrier that publishes the buffer: the compiler's own wait) the pieces
+    // have too; 1 - 8 % per launch (f32: assignment 94.5 / 96.5 -> 92 / 93 us, dcat's product 154 -> 143; bf16: 42.9 / 40.2 -> 41.8 / 38.1, 64 -> 59).
+    // With BNB: through staging registers as before -- the DMA form measured the same or 3 % slower there (the fused form's chunk is short and
+    // it streams two tensors; its loads sit behind dz5's stores).
+    constexpr bool DMA = !BNB;
+    constexpr int WGT = 64 * NW, PER = DMA ? 1 : (CHUNK_U4 + WGT - 1) / WGT;   // (three-wave workgroups: the last piece is predicated)
+    constexpr int PIECES = CHUNK_U4 / 64, DPER = (PIECES + NW - 1) / NW;
+    const unsigned bs_base = (unsigned)(size_t)(const __attribute__((address_space(3))) u32x4*)&Bs[0][0];
     u32x4 pre[PER];
-    auto request = [&](int kc) {
+    auto request = [&](int kc, int buf) {
+        if constexpr (DMA) {
+            const float* from = reinterpret_cast<const float*>(src + (size_t)kc * CHUNK_U4);
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-            if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * WGT];
-    };
-    auto deposit = [&](int buf) {
+            for (int u = 0; u < DPER; ++u)
+                if (PIECES % NW == 0 || wave + u * NW < PIECES)
+                    glds16(from, 16u * ((wave + u * NW) * 64 + lane), bs_base + 16u * (buf * CHUNK_U4 + (wave + u * NW) * 64));
+        } else {
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-            if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) Bs[buf][tid + u * WGT] = pre[u];
+            for (int u = 0; u < PER; ++u)
+                if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) pre[u] = src[(size_t)kc * CHUNK_U4 + tid + u * WGT];
+        }
     };
-    request(0);
+    request(0, 0);
     const size_t grow = (size_t)cloud * n_points + min(r0 + i, n_points - 1);
     const TA* arow = A + grow * 1024 + 8 * h;
     const TA* zrow = BNB ? bnb.z + grow * 1024 + 8 * h : nullptr;
@@ -220,6 +232,18 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(typename HxAPtr<
             coef[0][c] = a.s, coef[1][c] = a.t;
         }
     }
+    auto deposit = [&](int buf) {
+        if constexpr (DMA) {
+#pragma unroll
+            for (int s = 0; s < KSC; ++s)
+#pragma unroll
+                for (int w = 0; w < AV; ++w) asm volatile("" : "+v"(an[s][w]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (CHUNK_U4 % WGT == 0 || tid + u * WGT < CHUNK_U4) Bs[buf][tid + u * WGT] = pre[u];
+        }
+    };
     deposit(0);
     __syncthreads();
     f32x16 acc[NT];
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, 2) void hx_rowgemm_kernel(typename HxAPtr<
                 for (int w = 0; w < AV; ++w) av[s][w] = an[s][w];
         }
         if (kc + 1 < CHUNKS) {
-            request(kc + 1);
+            request(kc + 1, buf ^ 1);      // (DMA: the buffer's last readers passed the barrier at the end of the previous chunk)
             aload(kc + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
