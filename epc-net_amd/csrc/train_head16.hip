@@ -225,17 +225,17 @@ __global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __rest
     const bool live = r0 < n_points;
     const size_t row = (size_t)b * n_points + min(r0 + i, n_points - 1);
     const u32x4* src = Bp + (size_t)b * 16 * DF_STAGE_U4;
+    // the operand's stages travel global -> LDS by LDS-DMA, a wave four 1-KB pieces of a stage (h16_conv5_fwd_kernel's scheme: the counted
+    // wait in front of the barrier leaves the wave's younger operations -- the next z5 values, this stage's du stores -- in flight)
     constexpr int PER = DF_STAGE_U4 / 256;
-    u32x4 pre[PER];
-    auto request = [&](int st) {
+    const unsigned bs_base = (unsigned)(size_t)(const __attribute__((address_space(3))) u32x4*)&Bs[0][0];
+    auto request = [&](int st, int buf) {
+        const float* from = reinterpret_cast<const float*>(src + (size_t)st * DF_STAGE_U4);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) pre[u] = src[(size_t)st * DF_STAGE_U4 + tid + u * 256];
+        for (int u = 0; u < PER; ++u)
+            glds16(from, 16u * (u * 256 + wave * 64 + lane), bs_base + 16u * (buf * DF_STAGE_U4 + u * 256 + wave * 64));
     };
-    auto deposit = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PER; ++u) Bs[buf][tid + u * 256] = pre[u];
-    };
-    request(0);
+    request(0, 0);
     bf16x8 ah[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __rest
         rowc[wave][0][i] = rnv;
         rowc[wave][1][i] = rnv >= 0.99e6f ? 0.f : rnv * tv;
     }
-    deposit(0);
+    // (the resident fragments pinned as complete: the compiler's counters do not see the asm waits of the loop -- h16_conv5_fwd_kernel)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(ah[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const size_t tile_base = ((size_t)b * n_points + r0) * 512;   // dwords
@@ -274,10 +277,10 @@ __global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __rest
     };
     for (int st = 0; st < 16; ++st) {
         const int buf = st & 1;
-        if (st + 1 < 16) request(st + 1);
         unsigned zv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) zv[r] = zn[r];
+        if (st + 1 < 16) request(st + 1, buf ^ 1);      // (the buffer's last readers passed the barrier at the end of the previous stage)
         if (live && st + 1 < 16) zload(st + 1);
         if (st > 0) flush(st - 1, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -285,11 +288,7 @@ __global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __rest
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                acc0 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[buf][(s * 2 + 0) * 64 + lane]), acc0);
-                acc1 = mfma_bf16(ah[s], __builtin_bit_cast(bf16x8, Bs[buf][(s * 2 + 1) * 64 + lane]), acc1);
-            }
+            c5_half<2>(Bs[buf], lane, ah, acc0, acc1);
             const int c0 = 64 * st + 2 * i;
             const float2 cs = *reinterpret_cast<const float2*>(&coef[0][c0]), ct = *reinterpret_cast<const float2*>(&coef[1][c0]);
             const float2 mu = *reinterpret_cast<const float2*>(&coef[2][c0]), rs = *reinterpret_cast<const float2*>(&coef[3][c0]);
@@ -315,7 +314,11 @@ __global__ __launch_bounds__(256, 3) void h16_df_tail_kernel(const float* __rest
             psum[buf][wave][0][2 * i] = 0.f, psum[buf][wave][1][2 * i] = 0.f;
             psum[buf][wave][0][2 * i + 1] = 0.f, psum[buf][wave][1][2 * i + 1] = 0.f;
         }
-        if (st + 1 < 16) deposit(buf ^ 1);
+        // younger than the request: the sixteen z5 loads of the next stage (when there is one) and this stage's sixteen du stores (+ one
+        // partial's store on two of the waves)
+        if (live && st + 1 < 16) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else if (live) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     flush(15, 1);
