@@ -385,20 +385,32 @@ __global__ __launch_bounds__(64 * CH_BWD_MAX_WAVES) void chain_bwd_linear_kernel
             ch_ld8(g.dy + (size_t)r * g.dy_stride + 16 * s4 + 8 * h, gv[s4]), ch_ld8(g.z + (size_t)r * 64 + 16 * s4 + 8 * h, zv[s4]);
     };
     request_tile(wave, gv0, zv0);
+    // the three BatchNorms' vectors are requested BEFORE the pooling, unconditionally (an absent one reads this layer's instead): one round
+    // trip under the pooling -- guarded by their pointers and placed behind it they were three dependent round trips of every launch's
+    // prologue (found in the ISA, round 6)
+    float bv[3][4] = {};
+    if (tid < 64) {
+        const bool hx = g.xbn.mean != nullptr, hp = g.zp != nullptr;
+        bv[0][0] = g.bn.mean[tid], bv[0][1] = g.bn.var[tid], bv[0][2] = g.bn.gamma[tid], bv[0][3] = g.bn.beta[tid];
+        bv[1][0] = (hx ? g.xbn.mean : g.bn.mean)[tid], bv[1][1] = (hx ? g.xbn.var : g.bn.var)[tid];
+        bv[1][2] = (hx ? g.xbn.gamma : g.bn.gamma)[tid], bv[1][3] = (hx ? g.xbn.beta : g.bn.beta)[tid];
+        bv[2][0] = (hp ? g.pbn.mean : g.bn.mean)[tid], bv[2][1] = (hp ? g.pbn.var : g.bn.var)[tid];
+        bv[2][2] = (hp ? g.pbn.gamma : g.bn.gamma)[tid], bv[2][3] = (hp ? g.pbn.beta : g.bn.beta)[tid];
+    }
     ch_pool_sums(g.sums, g.parts, reinterpret_cast<double*>(img_all), s_sum, g.dbeta, g.dgamma);
     if (tid < 64) {
-        const float mu = g.bn.mean[tid], rs = 1.0f / sqrtf(g.bn.var[tid] + g.eps), ga = g.bn.gamma[tid];
-        const ChBnAffine a = ch_bn_affine(mu, g.bn.var[tid], ga, g.bn.beta[tid], g.eps);
+        const float mu = bv[0][0], rs = 1.0f / sqrtf(bv[0][1] + g.eps), ga = bv[0][2];
+        const ChBnAffine a = ch_bn_affine(mu, bv[0][1], ga, bv[0][3], g.eps);
         coef[0][tid] = a.s, coef[1][tid] = a.t, coef[2][tid] = mu;
         coef[3][tid] = ga * rs, coef[4][tid] = s_sum[0][tid] * inv_rows, coef[5][tid] = rs * (s_sum[1][tid] * inv_rows);
         if (g.xbn.mean) {
-            const ChBnAffine xa = ch_bn_affine(g.xbn.mean[tid], g.xbn.var[tid], g.xbn.gamma[tid], g.xbn.beta[tid], g.eps);
+            const ChBnAffine xa = ch_bn_affine(bv[1][0], bv[1][1], bv[1][2], bv[1][3], g.eps);
             xcoef[0][tid] = xa.s, xcoef[1][tid] = xa.t;
         }
         if (g.zp) {
-            const float pm = g.pbn.mean[tid];
-            const ChBnAffine pa = ch_bn_affine(pm, g.pbn.var[tid], g.pbn.gamma[tid], g.pbn.beta[tid], g.eps);
-            pcoef[0][tid] = pa.s, pcoef[1][tid] = pa.t, pcoef[2][tid] = pm, pcoef[3][tid] = 1.0f / sqrtf(g.pbn.var[tid] + g.eps);
+            const float pm = bv[2][0];
+            const ChBnAffine pa = ch_bn_affine(pm, bv[2][1], bv[2][2], bv[2][3], g.eps);
+            pcoef[0][tid] = pa.s, pcoef[1][tid] = pa.t, pcoef[2][tid] = pm, pcoef[3][tid] = 1.0f / sqrtf(bv[2][1] + g.eps);
         }
     }
     __syncthreads();
