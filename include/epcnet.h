@@ -528,7 +528,7 @@ int epc_hidden_tail_bwd(const float* dout, const float* h, int B, int G, int O, 
  * weight matrix, each ONE pass over it by 256 workgroups (the tile GEMM's split-K forms took 34 + 10, 17 and 16 us at 18 clouds where the
  * bytes are 3 us each).  pieces: bf16 pieces per operand -- 1 (the "bf16" step), 2 (three products: the default step's backward products),
  * 3 (six products: its forward products); f32 accumulation, sums met in a fixed order (bit-reproducible).  Shapes:
- * epc_hidden_proj_ok(M, K, N): 64 <= M <= 128, M % 4 == 0, N == 256, K a positive multiple of 256; other shapes stay on epc_gemm_*.
+ * epc_hidden_proj_ok(M, K, N): 64 <= M <= 128, M % 4 == 0, N == 256, K a positive multiple of 256; other shapes stay on the tile GEMMs (epc_gemm_f32 and its siblings).
  * dX or dW may be NULL (not computed).  scratch: the forward's K / 256 slice partials. */
 int epc_hidden_proj_ok(int M, int K, int N);
 size_t epc_hidden_proj_scratch_bytes(int M, int K);
