@@ -655,6 +655,12 @@ struct ChBwdGatherArgs {
 // (256 threads walking 16 points each took 107 us per launch at 18 x 4096: the chain degree -> offset -> list -> rows is four
 // dependent round trips per point, and only waves in flight hide them.)
 #define CH_GB_THREADS 1024
+// entry u of a point's list, clamped to its last one; an EMPTY list (a point nobody lists) reads the word at its offset -- possibly past the
+// written part of rlist -- and takes the point itself instead (a valid row; zero weight either way)
+__device__ __forceinline__ int ch_gb_entry(const int32_t* __restrict__ lst, int u, int deg, int self) {
+    const int e = lst[min(u, max(deg - 1, 0))];
+    return deg > 0 ? e : self;
+}
 #define CH_GB_SLOTS (CH_GB_THREADS / 16)
 __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGatherArgs g) {
     __shared__ __attribute__((aligned(16))) float pcoef[4][64];
@@ -667,19 +673,64 @@ __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGa
         pcoef[0][tid] = pa.s, pcoef[1][tid] = pa.t, pcoef[2][tid] = pm, pcoef[3][tid] = 1.0f / sqrtf(g.bn.var[tid] + g.eps);
     }
     __syncthreads();
-    const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][4 * q]), qt = *reinterpret_cast<const float4*>(&pcoef[1][4 * q]);
-    const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
     const float4* s4 = reinterpret_cast<const float4*>(g.s);
     float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int wg_end = min(g.total, (lb + 1) * g.wg_rows);
+    // A slot's points are a chain of dependent round trips -- degree / offset -> list entries -> rows, batch after batch -- and what hides
+    // them is only the other slots in flight: the first form of this loop (everything of a point requested when the point came up, the
+    // list in dependent batches of 8) took ~9 round trips per point, 37 us per launch at 18 x 4096.  Now the NEXT point's degree, offset
+    // and first 8 entries are requested under this point's rows, the entries 8 .. 23 together with the rows of the first 8, and rows
+    // travel in two buffers of 8: two round trips for a point of up to 24 listers (the mean is 20).  Every load is UNCONDITIONAL (entries
+    // clamped to the list's last one, their rows given zero weight by a select; the row sums keep the list order: the same bits).
+    int j = lb * g.wg_rows + slot;
+    int deg = 0;
+    const int32_t* lst = g.rlist;
+    int e0[8];
+    {
+        const int jc = min(j, wg_end - 1);
+        deg = g.rdeg[jc];
+        lst = g.rlist + g.roff[jc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e0[u] = ch_gb_entry(lst, u, deg, jc);
+    }
 #pragma unroll 1
-    for (int j = lb * g.wg_rows + slot; j < wg_end; j += CH_GB_SLOTS) {
-        const int deg = g.rdeg[j];
-        const int32_t* lst = g.rlist + g.roff[j];
+    for (; j < wg_end; j += CH_GB_SLOTS) {
+        const int jn = min(j + CH_GB_SLOTS, wg_end - 1);
+        const int degn = g.rdeg[jn], offn = g.roff[jn];
+        int e1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) e1[u] = ch_gb_entry(lst, 8 + u, deg, j);
+        float4 v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v0[u] = s4[(size_t)e0[u] * 16 + q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v1[u] = s4[(size_t)e1[u] * 16 + q];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // the list in batches of 8, the last one predicated (clamped entries, zero weight): a tail of single entries would be one
-        // dependent (entry, row) round trip each.  Added in list order.
-        for (int m = 0; m < deg; m += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = u < deg ? 1.f : 0.f;
+            acc.x += w * v0[u].x, acc.y += w * v0[u].y, acc.z += w * v0[u].z, acc.w += w * v0[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v0[u] = s4[(size_t)e1[8 + u] * 16 + q];
+        // the next point's first entries, and this point's own rows (its epilogue)
+        const int32_t* lstn = g.rlist + offn;
+        int e0n[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e0n[u] = ch_gb_entry(lstn, u, degn, jn);
+        const float4 a = s4[(size_t)j * 16 + q], b = *reinterpret_cast<const float4*>(g.dout + (size_t)j * g.dout_stride + 4 * q);
+        const float4 zq = reinterpret_cast<const float4*>(g.z0)[(size_t)j * 16 + q];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = 8 + u < deg ? 1.f : 0.f;
+            acc.x += w * v1[u].x, acc.y += w * v1[u].y, acc.z += w * v1[u].z, acc.w += w * v1[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w = 16 + u < deg ? 1.f : 0.f;
+            acc.x += w * v0[u].x, acc.y += w * v0[u].y, acc.z += w * v0[u].z, acc.w += w * v0[u].w;
+        }
+        for (int m = 24; m < deg; m += 8) {   // (a hub: dependent batches of 8, the last one clamped)
             int ii[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) ii[u] = lst[min(m + u, deg - 1)];
@@ -707,11 +758,12 @@ __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGa
                 }
             }
         }
-        const float4 a = s4[(size_t)j * 16 + q], b = *reinterpret_cast<const float4*>(g.dout + (size_t)j * g.dout_stride + 4 * q);
         const float4 dxv = make_float4(acc.x / g.kdiv - (a.x - b.x), acc.y / g.kdiv - (a.y - b.y), acc.z / g.kdiv - (a.z - b.z),
                                        acc.w / g.kdiv - (a.w - b.w));
         reinterpret_cast<float4*>(g.dx)[(size_t)j * 16 + q] = dxv;
-        const float4 zq = reinterpret_cast<const float4*>(g.z0)[(size_t)j * 16 + q];
+        // (the producer's coefficients from LDS here, not from sixteen registers held across the loop: the rows' buffers need them)
+        const float4 qs = *reinterpret_cast<const float4*>(&pcoef[0][4 * q]), qt = *reinterpret_cast<const float4*>(&pcoef[1][4 * q]);
+        const float4 qm = *reinterpret_cast<const float4*>(&pcoef[2][4 * q]), qr = *reinterpret_cast<const float4*>(&pcoef[3][4 * q]);
         const float vv[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, zz[4] = {zq.x, zq.y, zq.z, zq.w};
         const float a_s[4] = {qs.x, qs.y, qs.z, qs.w}, a_t[4] = {qt.x, qt.y, qt.z, qt.w};
         const float a_m[4] = {qm.x, qm.y, qm.z, qm.w}, a_r[4] = {qr.x, qr.y, qr.z, qr.w};
@@ -723,6 +775,9 @@ __global__ __launch_bounds__(CH_GB_THREADS) void chain_bwd_gather_kernel(ChBwdGa
         }
         t1.x += o1[0], t1.y += o1[1], t1.z += o1[2], t1.w += o1[3];
         t2.x += o2[0], t2.y += o2[1], t2.z += o2[2], t2.w += o2[3];
+        deg = degn, lst = lstn;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e0[u] = e0n[u];
     }
     *reinterpret_cast<float4*>(&red[slot][0][4 * q]) = t1;
     *reinterpret_cast<float4*>(&red[slot][1][4 * q]) = t2;
