@@ -2926,7 +2926,7 @@ extern "C" int epc_softmax64_bwd_bcast(const float* dy, const float* dsum, int n
 // a_sum[b][c] = sum over the cloud's points of a[b][n][c] (loupe.py:276), 64 columns: CS_SEG segments per cloud leave partial sums (the
 // fused soft-assignment forward below), the finish kernel adds them in order -- the same bits every run.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int CS_SEG = 16;
+constexpr int CS_SEG = 64;   // (round 6: 64 segments per cloud -- 18 x 64 workgroups of four waves -- instead of 16: the forward 17 -> 11 us at 18 clouds)
 
 __global__ void cloud_colsum64_finish_kernel(const float* __restrict__ part, int total, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
