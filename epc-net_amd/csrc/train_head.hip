@@ -15,6 +15,10 @@
 // ----------------------------------------------------------------------------------------------------------------
 #define VN_THREADS 1024
 #define VN_GROUPS (VN_THREADS / 64)
+// Round 6: VN_SLICES workgroups per cloud.  Each runs the WHOLE first pass (the column sums: the cloud's 256 - 768 KB, from L2 for all but
+// the first) -- the same sums in the same order, so nothing has to cross workgroups -- and writes one slice of the second pass: one
+// workgroup per cloud left 18 CUs moving a megabyte each (19 + 20 us); 8 x 18 workgroups: 8 + 9 us.
+#define VN_SLICES 8
 #define L2_EPS 1e-12f
 #ifndef VN_UNROLL
 #define VN_UNROLL 8     // rows of a column in flight per thread and round trip (16 and 32 measured in round 6: the step 2.02 -> 2.05 / 2.07 ms)
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
                                                                         float* __restrict__ r2) {
     __shared__ float red[VN_GROUPS][64];
     __shared__ float s_tot[64];
-    const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int b = blockIdx.x, sl = blockIdx.y, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const float* pr = raw + (size_t)b * F * 64;
     const float as = a_sum[b * 64 + c];
     float ss = 0.f;
@@ -56,13 +60,16 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_fwd_kernel(const fl
     for (int q = 0; q < 64; ++q) tot += s_tot[q];
     const float rb = 1.0f / sqrtf(fmaxf(tot, L2_EPS));
     float* po = out + (size_t)b * F * 64;
+    const int f0 = sl * (F / VN_SLICES), f1 = sl + 1 == VN_SLICES ? F : f0 + F / VN_SLICES;   // this workgroup's slice of the second pass
 #pragma unroll VN_UNROLL
-    for (int f = g; f < F; f += VN_GROUPS) {
+    for (int f = f0 + g; f < f1; f += VN_GROUPS) {
         const float v = pr[f * 64 + c] - as * w2[f * 64 + c];
         po[f * 64 + c] = (v * rc) * rb;
     }
-    if (g == 0) r1[b * 64 + c] = rc;
-    if (threadIdx.x == 0) r2[b] = rb;
+    if (sl == 0) {
+        if (g == 0) r1[b * 64 + c] = rc;
+        if (threadIdx.x == 0) r2[b] = rb;
+    }
 }
 
 __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const float* __restrict__ dout,
@@ -77,15 +84,19 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const int b = blockIdx.x, c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const float* pd = dout + (size_t)b * F * 64;
     const float* po = out + (size_t)b * F * 64;
-    float T = 0.f, Q = 0.f;
+    float T = 0.f, Q = 0.f, DW = 0.f, OW = 0.f;   // + sum_f d w2, sum_f o w2: d a_sum follows from the four sums (dv is linear in d and o)
 #pragma unroll VN_UNROLL
     for (int f = g; f < F; f += VN_GROUPS) {
-        const float o = po[f * 64 + c], d = pd[f * 64 + c];
+        const float o = po[f * 64 + c], d = pd[f * 64 + c], w = w2[f * 64 + c];
         T += d * o;
         Q += o * o;
+        DW += d * w;
+        OW += o * w;
     }
     T = group_sum(T, red, c, g);
     Q = group_sum(Q, red, c, g);
+    DW = group_sum(DW, red, c, g);
+    OW = group_sum(OW, red, c, g);
     if (g == 0) s_t[c] = T;
     __syncthreads();
     float S = 0.f;
@@ -96,23 +107,22 @@ __global__ __launch_bounds__(VN_THREADS) void vlad_normalize_bwd_kernel(const fl
     const float Sc = (rc >= 0.99e6f) ? 0.f : (T - S * Q);         // inner clamp active: no projection term
     const float inv_rb = 1.0f / rb;
     float* pw = draw + (size_t)b * F * 64;
-    float da = 0.f;
+    const int sl = blockIdx.y;
+    const int f0 = sl * (F / VN_SLICES), f1 = sl + 1 == VN_SLICES ? F : f0 + F / VN_SLICES;
 #pragma unroll VN_UNROLL
-    for (int f = g; f < F; f += VN_GROUPS) {
+    for (int f = f0 + g; f < f1; f += VN_GROUPS) {
         const float o = po[f * 64 + c], d = pd[f * 64 + c];
-        const float dv = rc * (rb * (d - o * S) - (o * inv_rb) * Sc);
-        pw[f * 64 + c] = dv;
-        da -= dv * w2[f * 64 + c];
+        pw[f * 64 + c] = rc * (rb * (d - o * S) - (o * inv_rb) * Sc);
     }
-    da = group_sum(da, red, c, g);
-    if (g == 0) da_sum[b * 64 + c] = da;
+    // d a_sum[c] = -sum_f dv w2 = -rc (rb (DW - S OW) - (Sc / rb) OW)
+    if (sl == 0 && g == 0) da_sum[b * 64 + c] = -(rc * (rb * (DW - S * OW) - (inv_rb * Sc) * OW));
 }
 
 extern "C" int epc_vlad_normalize_fwd(const float* raw, const float* a_sum, const float* w2, int num_clouds, int F, int C,
                                       float* out, float* r1, float* r2, void* stream) {
     EPC_CHECK_ARG(raw && a_sum && w2 && out && r1 && r2, "null pointer");
     EPC_CHECK_ARG(num_clouds > 0 && F > 0 && C == 64, "cluster_size must be 64");
-    hipLaunchKernelGGL(vlad_normalize_fwd_kernel, dim3(num_clouds), dim3(VN_THREADS), 0, (hipStream_t)stream, raw, a_sum, w2,
+    hipLaunchKernelGGL(vlad_normalize_fwd_kernel, dim3(num_clouds, VN_SLICES), dim3(VN_THREADS), 0, (hipStream_t)stream, raw, a_sum, w2,
                        F, out, r1, r2);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
@@ -123,7 +133,7 @@ extern "C" int epc_vlad_normalize_bwd(const float* dout, const float* out, const
                                       void* stream) {
     EPC_CHECK_ARG(dout && out && r1 && r2 && w2 && draw && da_sum, "null pointer");
     EPC_CHECK_ARG(num_clouds > 0 && F > 0 && C == 64, "cluster_size must be 64");
-    hipLaunchKernelGGL(vlad_normalize_bwd_kernel, dim3(num_clouds), dim3(VN_THREADS), 0, (hipStream_t)stream, dout, out, r1,
+    hipLaunchKernelGGL(vlad_normalize_bwd_kernel, dim3(num_clouds, VN_SLICES), dim3(VN_THREADS), 0, (hipStream_t)stream, dout, out, r1,
                        r2, w2, F, draw, da_sum);
     EPC_CHECK_LAUNCH();
     return EPC_OK;
