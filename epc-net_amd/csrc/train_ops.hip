@@ -2368,7 +2368,7 @@ __global__ __launch_bounds__(256) void linear_smallk_fwd_kernel(const float* __r
     *reinterpret_cast<float4*>(z + row * cout + c) = acc;
 }
 
-#define SK_ROWS_PER_WG 1024
+#define SK_ROWS_PER_WG 256     // (round 6: 288 workgroups at 18 x 4096 rows instead of 72 -- 1024 rows per workgroup left two thirds of the CUs idle: 15.5 -> 6 us)
 __global__ __launch_bounds__(256) void linear_smallk_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                int rows, int cin, float* __restrict__ part) {
     // cout == 64: thread = (row group rg of 16, channel quad l16 of 16)
