@@ -37,15 +37,8 @@ __device__ __forceinline__ void hp_split(const float (&v)[8], HpFrag<P>& f) {
         }
     }
 }
-// the products of piece x of a and piece s - x of b for s = P - 1 .. 0 (smallest terms first): 1, 3 or 6 MFMAs
-template <int P>
-__device__ __forceinline__ f32x16 hp_mac(const HpFrag<P>& a, const HpFrag<P>& b, f32x16 c) {
-#pragma unroll
-    for (int s = P - 1; s >= 0; --s)
-#pragma unroll
-        for (int x = 0; x <= s; ++x) c = mfma_bf16(a.p[x], b.p[s - x], c);
-    return c;
-}
+// (the products: piece x of a with piece s - x of b for s = P - 1 .. 0, smallest terms first -- 1, 3 or 6 MFMAs, interleaved over two
+// accumulators in the kernels)
 
 // rows 0 .. mpad - 1 of a row-major matrix (1 KB of each: 256 floats from column c0), rows past M - 1 clamped, into LDS at HP_PITCH
 __device__ __forceinline__ void hp_stage_rows(const float* __restrict__ src, long row_stride, int M, int mpad, unsigned lds_base, int wave,
