@@ -397,7 +397,12 @@ __global__ __launch_bounds__(64 * CH_BWD_MAX_WAVES) void chain_bwd_linear_kernel
         bv[2][0] = (hp ? g.pbn.mean : g.bn.mean)[tid], bv[2][1] = (hp ? g.pbn.var : g.bn.var)[tid];
         bv[2][2] = (hp ? g.pbn.gamma : g.bn.gamma)[tid], bv[2][3] = (hp ? g.pbn.beta : g.bn.beta)[tid];
     }
+#ifdef CH_ABL_NOPOOL   // timing only
+    if (tid < 128) s_sum[tid >> 6][tid & 63] = 0.f;
+    __syncthreads();
+#else
     ch_pool_sums(g.sums, g.parts, reinterpret_cast<double*>(img_all), s_sum, g.dbeta, g.dgamma);
+#endif
     if (tid < 64) {
         const float mu = bv[0][0], rs = 1.0f / sqrtf(bv[0][1] + g.eps), ga = bv[0][2];
         const ChBnAffine a = ch_bn_affine(mu, bv[0][1], ga, bv[0][3], g.eps);
@@ -466,7 +471,11 @@ __global__ __launch_bounds__(64 * CH_BWD_MAX_WAVES) void chain_bwd_linear_kernel
         float xv[4][8];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) ch_ld8(g.x + rsafe * g.x_stride + 16 * s4 + 8 * h, xv[s4]);
+#ifdef CH_ABL_NODX   // timing only
+        if (false) {
+#else
         if (g.dx) {
+#endif
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 f32x16 acc;
@@ -523,6 +532,9 @@ __global__ __launch_bounds__(64 * CH_BWD_MAX_WAVES) void chain_bwd_linear_kernel
                 }
             }
         }
+#ifdef CH_ABL_NODW   // timing only
+        return;
+#endif
         // ---- dz^T: the B fragments of dW (k = rows, n = out channel), read transposed from the image ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own image writes have landed before its reads)
         bf16x8 dzt[2][2][PB];   // [out tile][k-step][piece]
